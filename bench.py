@@ -1,0 +1,262 @@
+#!/usr/bin/env python3
+"""bench.py -- loop-closure candidate pairs/s on MI355X (BASELINE.json metric).
+
+One "step" = one pass of the hot path over one batch of synthetic input on every rank:
+  host: (cos, sin) of each pair's odometry heading difference (16 B/pair) + async H2D
+  K1  : likelihood grids of the batch's target scans          (nhip_grid_build_dev)
+  K2/3: exhaustive (theta, x, y) correlation + argmax per pair (nhip_csm_match_dev)
+  N>1 : ONE RCCL all-gather of the 16-byte best-pose records   (torch.distributed, backend nccl)
+Workload at every N (weak scaling): BASELINE configs[1] per GPU -- 1,000 dense 1081-beam scans,
+10,000 candidate pairs (10 per target), 61 x 81 x 81 lattice (1 deg / 5 cm over +-30 deg / +-2 m),
+1200 x 1200 grid at 0.05 m.  Scans, pair list and odometry are resident in HBM before the timed
+region; the PCIe-inclusive figure is discussed in DESIGN.md.
+"""
+import argparse
+import ctypes as C
+import json
+import math
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--scans", type=int, default=1000)
+    ap.add_argument("--per-target", type=int, default=10)
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-resid", action="store_true", help="skip the secondary residual-kernel measurement")
+    return ap.parse_args()
+
+
+def cpu_baseline(bag, xy, off, ids, src, slot, th0, budget_s):
+    """The oracle (CPU restatement, OpenMP over pairs like the reference's -fopenmp build) timed on
+    this host's cores on a bounded sample of the same workload: whole targets (grid build + their
+    pairs), sized from a one-pair calibration to ~budget_s seconds."""
+    from oracle import oracle as O
+    ospec = O.grid_spec()
+    oss = O.search_spec(61, 81, 81, math.radians(1.0))
+    cores = O.num_threads()
+    t0 = time.perf_counter()
+    g0 = O.grid_build_batch(xy, off, ids[:1], ospec, 1)
+    O.csm_match_batch(xy, off, g0, ospec, src[:1], np.zeros(1, np.int32), th0[:1], oss, None, 1)
+    t_one = time.perf_counter() - t0  # one grid + one pair on one core
+    per_target = int(np.sum(slot == 0))
+    t_target = t_one * (1 + per_target) / 2.0  # grid ~ pair cost, amortised below by measuring
+    n_targets = int(max(1, min(len(ids), (budget_s * cores) / max(t_target, 1e-3))))
+    n_targets = max(cores // max(per_target, 1), n_targets)
+    n_targets = min(n_targets, len(ids), 400)  # oracle grids are 1.44 MB each, keep host memory small
+    sel = np.nonzero(slot < n_targets)[0]
+    t0 = time.perf_counter()
+    grids = O.grid_build_batch(xy, off, ids[:n_targets], ospec, cores)
+    t_grid = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    res = O.csm_match_batch(xy, off, grids, ospec, src[sel], slot[sel], th0[sel], oss, None, cores)
+    t_match = time.perf_counter() - t0
+    return {"value": len(sel) / (t_grid + t_match), "unit": "pairs/s", "cores": cores, "kind": "port",
+            "sample": "%d pairs / %d targets of the same workload (grid build %.2f s + match %.2f s), "
+                      "oracle C restatement, OpenMP over pairs" % (len(sel), n_targets, t_grid, t_match),
+            }, sel, res
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    import torch.distributed as dist
+    from nautilus_amd import _lib, csm, synth
+    lib = _lib.load()
+    assert torch.cuda.is_available(), "bench.py needs an MI355X: there is no CPU path"
+    torch.cuda.set_device(local)
+    _lib.check(lib.nhip_set_device(local))
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    # ---- synthetic workload (per rank; seeds differ per rank so shards are not copies)
+    bag = synth.SynthBag(a.scans, dense=True, seed=synth.SEED + 1000 * rank)
+    assert all(len(s) == synth.N_BEAMS for s in bag.scans), "dense world must return all 1081 beams"
+    xy, off = csm.pack_scans(bag.scans)
+    ids = np.arange(a.scans, dtype=np.int32)
+    src, tgt, th0 = bag.sample_pairs(per_target=a.per_target, targets=ids, max_dist=1.5, min_sep=20,
+                                     seed=synth.SEED + 1000 * rank)
+    slot = tgt.astype(np.int32)  # target i -> grid slot i; pairs are already sorted by target
+    n_pairs = len(src)
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40)
+    search = csm.search_spec(61, 81, 81, math.radians(1.0))
+    L = csm.grid_layout(spec)
+
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_xy, d_off, d_ids, d_src, d_slot = t(xy), t(off), t(ids), t(src), t(slot)
+    d_delta = t(csm.delta_table(search))
+    h_th0 = np.ascontiguousarray(th0, dtype=np.float64)
+    h_rot0 = torch.empty((n_pairs, 2), dtype=torch.float64).pin_memory()
+    d_rot0 = torch.empty((n_pairs, 2), dtype=torch.float64, device=dev)
+    d_grids = torch.empty(lib.nhip_grids_bytes(C.byref(spec), len(ids)), dtype=torch.uint8, device=dev)
+    chunk = 128
+    ws_bytes = lib.nhip_grid_workspace_bytes(C.byref(spec), chunk)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    d_keys = torch.empty(n_pairs, dtype=torch.int64, device=dev)
+    d_out = torch.empty((n_pairs, 4), dtype=torch.int32, device=dev)
+    d_sums = torch.empty(n_pairs, dtype=torch.int32, device=dev)
+    d_all = torch.empty((world * n_pairs, 4), dtype=torch.int32, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    rot0_np = h_rot0.numpy()
+
+    def step():
+        _lib.check(lib.nhip_csm_rot0(_lib.ptr(h_th0), None, n_pairs, _lib.ptr(rot0_np)))
+        d_rot0.copy_(h_rot0, non_blocking=True)
+        _lib.check(lib.nhip_grid_build_dev(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), len(ids),
+                                           C.byref(spec), d_grids.data_ptr(), d_ws.data_ptr(), ws_bytes, sp))
+        _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), d_grids.data_ptr(), C.byref(spec),
+                                          d_src.data_ptr(), d_slot.data_ptr(), d_rot0.data_ptr(),
+                                          d_delta.data_ptr(), None, n_pairs, C.byref(search),
+                                          d_keys.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), sp))
+        if world > 1:
+            dist.all_gather_into_tensor(d_all, d_out)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    fence()
+    lib.nhip_timing_reset()
+    lib.nhip_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    lib.nhip_timing_enable(0)
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    k_ms, k_n = C.c_double(0), C.c_int32(0)
+    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_CSM, C.byref(k_ms), C.byref(k_n)))
+    g_ms, g_n = C.c_double(0), C.c_int32(0)
+    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_GRID, C.byref(g_ms), C.byref(g_n)))
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    # ---- parity spot check of the timed result against the oracle happens inside cpu_baseline
+    got = d_out.cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
+    got_sums = d_sums.cpu().numpy()
+    lookups_per_pair = search.n_theta * search.nx * search.ny * synth.N_BEAMS  # 432,638,901
+    bytes_per_launch = float(n_pairs) * lookups_per_pair * 1  # 1-byte cells
+    avg_ms = k_ms.value / max(k_n.value, 1)
+    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+    traffic = None
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tf):
+        try:
+            traffic = json.load(open(tf)).get("csm_correlate_bytes_per_launch_%dpairs" % n_pairs)
+        except Exception:
+            traffic = None
+    out = {
+        "metric": "loop-closure candidate pairs/sec (1081-beam)",
+        "value": world * n_pairs * a.steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": a.steps,
+        "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "u8",
+        "data": "synthetic",
+        "config": {"workload": "BASELINE configs[1] per GPU: %d dense 1081-beam scans, %d candidate pairs "
+                               "(%d per target), 61x81x81 lattice (1 deg / 5 cm over +-30 deg / +-2 m), "
+                               "1200x1200 u8 log-likelihood grid at 0.05 m; grid build + match + all-gather"
+                               % (a.scans, n_pairs, a.per_target),
+                   "pairs_per_gpu": n_pairs, "scans_per_gpu": a.scans, "lattice": [61, 81, 81],
+                   "grid": [L.side, L.side], "cell_bytes": 1, "collective": "all_gather 16 B/pair" if world > 1 else "none"},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "csm_correlate_kernel", "avg_launch_ms": avg_ms, "launches": k_n.value,
+                     "algorithmic_bytes_per_launch": bytes_per_launch,
+                     "note": "algorithmic gather bytes (1 B per grid lookup) / kernel time; the grid is "
+                             "cache/LDS-resident, so this exceeds what HBM itself moves (see traffic)"},
+        "kernels_ms_per_step": {"csm_correlate": k_ms.value / a.steps, "grid_blur": g_ms.value / a.steps},
+    }
+    if world == 1 and a.cpu_seconds > 0:
+        cb, sel, ref = cpu_baseline(bag, xy, off, ids, src, slot, h_th0, a.cpu_seconds)
+        ok = all(np.array_equal(got[f][sel], ref[f]) for f in ("itheta", "ix", "iy")) and \
+            np.array_equal(got_sums[sel], ref["sum"])
+        cb["gpu_matches_oracle_on_sample"] = bool(ok)
+        out["cpu_baseline"] = cb
+        if not ok:
+            print("PARITY FAILURE: GPU result differs from the oracle on the cpu_baseline sample", file=sys.stderr)
+    if world == 1 and not a.no_resid:
+        try:
+            out["secondary"] = {"resid_lidar": bench_residuals(torch, lib, dev, sp)}
+        except Exception as e:  # secondary measurement must not lose the headline line
+            out["secondary"] = {"resid_lidar_error": repr(e)}
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def bench_residuals(torch, lib, dev, sp, n_blocks=9945, n_per=1081, iters=20):
+    """BASELINE configs[2] shape: 9,945 (i, j) blocks x 1081 correspondences, residual + both
+    Jacobians (144 B per correspondence), synthetic correspondences already in HBM."""
+    from nautilus_amd import _lib
+    n_corr = n_blocks * n_per
+    g = torch.Generator(device=dev)
+    g.manual_seed(1)
+    corr = torch.randn((n_corr, 8), device=dev, dtype=torch.float32, generator=g)
+    cb = torch.arange(n_blocks, device=dev, dtype=torch.int32).repeat_interleave(n_per)
+    bs = (torch.arange(n_blocks, device=dev, dtype=torch.int32) % 999) + 1
+    bt = bs - 1
+    poses = torch.randn((1000, 3), device=dev, dtype=torch.float64, generator=g)
+    consts = torch.empty(8 * n_blocks, device=dev, dtype=torch.float64)
+    res = torch.empty(2 * n_corr, device=dev, dtype=torch.float64)
+    js = torch.empty(6 * n_corr, device=dev, dtype=torch.float64)
+    jt = torch.empty(6 * n_corr, device=dev, dtype=torch.float64)
+
+    def run():
+        _lib.check(lib.nhip_resid_lidar_dev(0, corr.data_ptr(), cb.data_ptr(), n_corr, bs.data_ptr(), bt.data_ptr(),
+                                            n_blocks, poses.data_ptr(), 1000, consts.data_ptr(), res.data_ptr(),
+                                            js.data_ptr(), jt.data_ptr(), sp))
+    run()
+    torch.cuda.synchronize()
+    lib.nhip_timing_reset()
+    lib.nhip_timing_enable(1)
+    for _ in range(iters):
+        run()
+    torch.cuda.synchronize()
+    lib.nhip_timing_enable(0)
+    ms, n = C.c_double(0), C.c_int32(0)
+    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_RESID, C.byref(ms), C.byref(n)))
+    avg = ms.value / max(n.value, 1)
+    bytes_alg = 144.0 * n_corr
+    gbs = bytes_alg / (avg * 1e-3) / 1e9
+    return {"workload": "configs[2]: %d blocks x %d correspondences, LIDARNormal residual + 2 Jacobians" % (n_blocks, n_per),
+            "correspondences_per_s": n_corr / (avg * 1e-3), "avg_launch_ms": avg,
+            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": bytes_alg}}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,229 @@
+/*
+ * nautilus_hip.h -- C ABI of the MI355X (gfx950) implementation of nautilus's loop-closure
+ * correlative scan matcher and batched Ceres-residual evaluation.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ / torch types.  Each entry
+ * point cites the reference interface it replaces (paths relative to the nautilus tree):
+ *
+ *   CorrelativeScanMatcher(30, 2, 0.3, 0.01)              src/optimization/solver.cc:56,633
+ *   CorrelativeScanMatcher::GetTransformation(...)        src/optimization/solver.cc:634-638
+ *   lookup-table geometry (side, cell index, rasterise)   src/visualization/cimg_debug.h:20-64
+ *   LIDARNormalResidual / LIDARPointResidual functors     src/optimization/slam_residuals.h:64-177
+ *   PointToLineResidual functor                           src/optimization/slam_residuals.h:179-216
+ *   OdometryResidual functor                              src/optimization/slam_residuals.h:17-61
+ *   ceres::CostFunction::Evaluate(parameters, residuals, jacobians) contract (Ceres 1.14):
+ *       row-major num_residuals x 3 Jacobian per parameter block, NULL = not requested
+ *   double pose[3] = (x, y, theta) parameter block        src/util/slam_types.h:159-178
+ *
+ * Conventions: every function returns 0 on success and a negative NHIP_ERR_* code on
+ * failure (never aborts, never throws across the ABI); nhip_last_error() returns a
+ * thread-local message.  "_dev" entry points take DEVICE pointers owned by the caller and
+ * only enqueue work on `stream` (a hipStream_t passed as void*; NULL = default stream):
+ * they allocate nothing and do not synchronise, so they can be captured in a hipGraph.
+ * Handle entry points take HOST pointers, own their device memory and synchronise.
+ * There is no CPU fallback anywhere: without a gfx950 device compute calls fail with
+ * NHIP_ERR_NODEV.
+ */
+#ifndef NAUTILUS_HIP_H_
+#define NAUTILUS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NHIP_OK 0
+#define NHIP_ERR_ARG (-1)    /* bad argument / shape mismatch (glog CHECK_* in the reference) */
+#define NHIP_ERR_NODEV (-2)  /* no HIP device visible */
+#define NHIP_ERR_HIP (-3)    /* a HIP runtime call failed */
+#define NHIP_ERR_ALLOC (-4)  /* device or host allocation failed */
+#define NHIP_ERR_STATE (-5)  /* handle used in the wrong state */
+
+/* ------------------------------------------------------------------ general */
+int nhip_init(int *n_devices);
+int nhip_set_device(int device);
+const char *nhip_last_error(void);
+const char *nhip_version(void);
+
+/* ------------------------------------------------------------------ likelihood grids
+ * Replaces the lookup table CorrelativeScanMatcher builds from the target point cloud.
+ * Geometry follows cimg_debug.h:20-37; the likelihood model (integer separable Gaussian
+ * blur of the hit raster, floor, natural log, 8-bit quantisation) is the build-defined
+ * spec of DESIGN.md section 3. */
+typedef struct nhip_grid_spec {
+  double range;       /* scanner range [m]: ctor arg 1 (solver.cc:633); side = floor(2*range/res) */
+  double res;         /* cell size [m] */
+  double sigma;       /* blur sigma in cells */
+  double floor_p;     /* likelihood floor before the log (1e-10) */
+  int32_t max_shift;  /* largest |cell shift| a search on these grids may use */
+  int32_t reserved;
+} nhip_grid_spec_t;
+
+typedef struct nhip_grid_layout {
+  int32_t side;        /* S: cells per side (cimg_debug.h:21-22) */
+  int32_t pad;         /* zero border on every side: 2*max_shift + 4, multiple of 4 */
+  int32_t pitch;       /* bytes per stored row = S + 2*pad rounded up to a multiple of 4 */
+  int32_t rows;        /* stored rows = S + 2*pad; cell (row, col) is byte (row+pad)*pitch + col+pad */
+  int32_t blur_radius; /* R = ceil(3*sigma) */
+  int32_t reserved;
+  int64_t tap_sum;     /* K = sum of the integer blur taps */
+  int64_t grid_bytes;  /* pitch*rows: bytes of one stored grid */
+  double score_floor;  /* Lf = ln(floor_p): value of cell 0 */
+  double score_step;   /* log-likelihood per quantisation step = -Lf/255 */
+} nhip_grid_layout_t;
+
+/* Pure host helpers (work without a GPU). */
+int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out);
+/* bytes the caller must allocate for n grids (n*grid_bytes + 256 B read slack) */
+int64_t nhip_grids_bytes(const nhip_grid_spec_t *spec, int64_t n_grids);
+/* workspace for nhip_grid_build_dev processing `chunk` targets at a time */
+int64_t nhip_grid_workspace_bytes(const nhip_grid_spec_t *spec, int32_t chunk);
+/* integer blur taps (2R+1 values) and the 256-entry quantiser threshold table */
+int nhip_grid_tables(const nhip_grid_spec_t *spec, int32_t *taps, uint32_t *thresholds);
+
+/* ------------------------------------------------------------------ search lattice
+ * BASELINE config #2: n_theta = 61, theta_step = 1 deg, nx = ny = 81 (one cell = 5 cm).
+ * Translations are integer cell shifts ix-(nx-1)/2, iy-(ny-1)/2; rotation k is
+ * theta0 + (k-(n_theta-1)/2)*theta_step with theta0 = AngleMod(rot_a - rot_b)
+ * (math_util.h:81-89), i.e. the odometry estimate of "A to B in B's frame"
+ * (solver.cc:631-638). */
+typedef struct nhip_search {
+  int32_t n_theta;
+  int32_t nx;
+  int32_t ny;
+  int32_t reserved;
+  double theta_step; /* radians */
+} nhip_search_t;
+
+/* One result per candidate pair: 16 bytes, the record that is all-gathered across GPUs. */
+typedef struct nhip_match {
+  int32_t itheta;
+  int32_t ix;
+  int32_t iy;
+  float score; /* mean log-likelihood (<= 0), cf. csm_score_threshold = -5 (default_config.lua:85) */
+} nhip_match_t;
+
+/* Host helpers: (cos, sin) of theta0 per pair and of the lattice offsets, in double. */
+int nhip_csm_rot0(const double *rot_a, const double *rot_b, int32_t n, double *cs_out /* 2n */);
+int nhip_csm_delta_table(const nhip_search_t *search, double *cs_out /* 2*n_theta */);
+/* Host helper: (tx, ty, theta) of a match, as consumed at solver.cc:640-644. */
+int nhip_match_to_transform(const nhip_match_t *m, const nhip_grid_spec_t *spec,
+                            const nhip_search_t *search, double theta0, int32_t origin_x,
+                            int32_t origin_y, float *tx, float *ty, float *theta);
+double nhip_score_from_sum(const nhip_grid_spec_t *spec, int64_t sum, int32_t n_points);
+
+/* ------------------------------------------------------------------ device-pointer API */
+/* K1: build likelihood grids for n_targets scans (scan ids in d_target_ids) into
+ * d_grids[slot] (slot = position in d_target_ids).  d_xy: float2 points of all scans,
+ * d_offsets: n_scans+1 prefix offsets (in points). */
+int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+                        int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
+                        void *d_workspace, int64_t workspace_bytes, void *stream);
+
+/* K2+K3: exhaustive (theta, x, y) correlation + argmax for n_pairs candidate pairs.
+ * Pair i matches scan d_pair_src[i] against grid slot d_pair_slot[i].
+ * d_rot0_cs: 2 doubles (cos, sin theta0) per pair; d_delta_cs: 2 doubles per lattice rotation.
+ * d_pair_origin: NULL, or 2 int32 per pair = (x, y) cell offset of the search centre (used by
+ * the fine level of a coarse-to-fine search); |origin| + half-width must be <= max_shift.
+ * d_keys: n_pairs uint64 scratch; d_out: n_pairs records; d_sums: n_pairs int32 or NULL. */
+int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                       const nhip_grid_spec_t *spec, const int32_t *d_pair_src,
+                       const int32_t *d_pair_slot, const double *d_rot0_cs,
+                       const double *d_delta_cs, const int32_t *d_pair_origin, int32_t n_pairs,
+                       const nhip_search_t *search, uint64_t *d_keys, nhip_match_t *d_out,
+                       int32_t *d_sums, void *stream);
+
+/* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy]. */
+int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                        const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
+                        const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
+                        int32_t origin_y, const nhip_search_t *search, int32_t *d_sums,
+                        void *stream);
+
+/* K4: batched LIDAR residual + Jacobian evaluation.
+ * kind: NHIP_LIDAR_NORMAL (slam_residuals.h:65-89) or NHIP_LIDAR_POINT (:124-145).
+ * d_corr: 8 floats per correspondence (source point, target point, source normal, target
+ * normal -- the four vectors of PointCorrespondences, data_structures.h:62-66).
+ * d_corr_block: block id of every correspondence; block b reads poses d_block_src[b]
+ * ("source_pose", parameter block 0) and d_block_tgt[b] ("target_pose", block 1) from
+ * d_poses[n_poses][3].  d_block_consts: n_blocks*8 doubles scratch.
+ * Outputs: d_residuals 2 doubles / correspondence; d_jac_src, d_jac_tgt 6 doubles /
+ * correspondence (rows 2i, 2i+1 of the row-major (2N x 3) Jacobian); either may be NULL. */
+#define NHIP_LIDAR_NORMAL 0
+#define NHIP_LIDAR_POINT 1
+int nhip_resid_lidar_dev(int kind, const float *d_corr, const int32_t *d_corr_block,
+                         int64_t n_corr, const int32_t *d_block_src, const int32_t *d_block_tgt,
+                         int32_t n_blocks, const double *d_poses, int32_t n_poses,
+                         double *d_block_consts, double *d_residuals, double *d_jac_src,
+                         double *d_jac_tgt, void *stream);
+
+/* PointToLineResidual (slam_residuals.h:180-200): block b has line segment d_segments[4b..]
+ * (x0 y0 x1 y1, LineSegment<float>), points d_points[2i..] with block id d_point_block[i],
+ * parameter blocks pose = d_poses[d_block_pose[b]] and line_pose = d_line_poses[d_block_line[b]].
+ * Outputs: 1 residual / point, 3 doubles / point per Jacobian (may be NULL). */
+int nhip_resid_point_to_line_dev(const float *d_segments, const float *d_points,
+                                 const int32_t *d_point_block, int64_t n_points,
+                                 const int32_t *d_block_pose, const int32_t *d_block_line,
+                                 int32_t n_blocks, const double *d_poses,
+                                 const double *d_line_poses, double *d_residuals,
+                                 double *d_jac_pose, double *d_jac_line, void *stream);
+
+/* OdometryResidual (slam_residuals.h:18-40): factor f has T_odom d_t_odom[2f..] (Vector2f),
+ * R_odom d_r_odom[f] (float), poses d_pose_i[f], d_pose_j[f].  3 residuals, 3x3 Jacobians. */
+int nhip_resid_odometry_dev(const float *d_t_odom, const float *d_r_odom, const int32_t *d_pose_i,
+                            const int32_t *d_pose_j, int32_t n_factors, double translation_weight,
+                            double rotation_weight, const double *d_poses, double *d_residuals,
+                            double *d_jac_i, double *d_jac_j, void *stream);
+
+/* ------------------------------------------------------------------ handle API (host pointers) */
+typedef struct nhip_scans nhip_scans_t;
+typedef struct nhip_grids nhip_grids_t;
+typedef struct nhip_resid_batch nhip_resid_batch_t;
+
+/* std::vector<Eigen::Vector2f> point clouds of n_scans scans, concatenated. */
+int nhip_scans_upload(const float *xy, const int32_t *offsets, int32_t n_scans, nhip_scans_t **out);
+int nhip_scans_free(nhip_scans_t *scans);
+
+int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32_t n_targets,
+                     const nhip_grid_spec_t *spec, nhip_grids_t **out);
+int nhip_grids_free(nhip_grids_t *grids);
+/* copy stored (padded) grid `slot` to host: layout.grid_bytes bytes */
+int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
+
+/* Batched GetTransformation: theta0[i] = AngleMod(rot_a - rot_b) of pair i;
+ * pair_origin: NULL or 2 int32 per pair (search centre in cells). */
+int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const int32_t *pair_src,
+                   const int32_t *pair_slot, const double *theta0, const int32_t *pair_origin,
+                   int32_t n_pairs, const nhip_search_t *search, nhip_match_t *out,
+                   int32_t *out_sums);
+int nhip_csm_scores(const nhip_scans_t *scans, const nhip_grids_t *grids, int32_t src, int32_t slot,
+                    double theta0, int32_t origin_x, int32_t origin_y, const nhip_search_t *search,
+                    int32_t *out_sums);
+
+/* Residual batch: all LIDAR residual blocks of one ceres::Problem build (immutable after
+ * creation, like the functors' copied vectors, slam_residuals.h:117-120). */
+int nhip_resid_batch_create(int kind, const float *corr, const int32_t *block_offsets,
+                            const int32_t *block_src, const int32_t *block_tgt, int32_t n_blocks,
+                            int32_t n_poses, nhip_resid_batch_t **out);
+/* poses: n_poses*3 doubles.  residuals: 2*n_corr; jac_src / jac_tgt: 6*n_corr or NULL. */
+int nhip_resid_batch_eval(nhip_resid_batch_t *batch, const double *poses, double *residuals,
+                          double *jac_src, double *jac_tgt);
+int nhip_resid_batch_free(nhip_resid_batch_t *batch);
+
+/* ------------------------------------------------------------------ in-stream kernel timing
+ * When enabled, the dominant kernels are bracketed by hipEvents on their own stream.
+ * ids: 0 = csm_correlate, 1 = grid_build (blur), 2 = resid_lidar. */
+#define NHIP_TIMER_CSM 0
+#define NHIP_TIMER_GRID 1
+#define NHIP_TIMER_RESID 2
+int nhip_timing_enable(int on);
+int nhip_timing_reset(void);
+/* synchronises the recorded events; total_ms / launches since the last reset */
+int nhip_timing_get(int id, double *total_ms, int32_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NAUTILUS_HIP_H_ */

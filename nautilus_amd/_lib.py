@@ -1,0 +1,122 @@
+"""ctypes binding of libnautilus_hip.so (include/nautilus_hip.h).
+
+The library is the product: there is no Python or CPU fallback.  If the shared object is
+missing this module raises at import of the symbol table; if no GPU is visible every
+compute entry point returns NHIP_ERR_NODEV and `check()` raises NhipError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libnautilus_hip.so")
+
+NHIP_OK, NHIP_ERR_ARG, NHIP_ERR_NODEV, NHIP_ERR_HIP, NHIP_ERR_ALLOC, NHIP_ERR_STATE = 0, -1, -2, -3, -4, -5
+NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1
+NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID = 0, 1, 2
+
+
+class NhipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("nautilus_hip error %d: %s" % (code, msg))
+        self.code = code
+
+
+class GridSpec(C.Structure):
+    _fields_ = [("range", C.c_double), ("res", C.c_double), ("sigma", C.c_double),
+                ("floor_p", C.c_double), ("max_shift", C.c_int32), ("reserved", C.c_int32)]
+
+
+class GridLayout(C.Structure):
+    _fields_ = [("side", C.c_int32), ("pad", C.c_int32), ("pitch", C.c_int32), ("rows", C.c_int32),
+                ("blur_radius", C.c_int32), ("reserved", C.c_int32), ("tap_sum", C.c_int64),
+                ("grid_bytes", C.c_int64), ("score_floor", C.c_double), ("score_step", C.c_double)]
+
+
+class Search(C.Structure):
+    _fields_ = [("n_theta", C.c_int32), ("nx", C.c_int32), ("ny", C.c_int32), ("reserved", C.c_int32),
+                ("theta_step", C.c_double)]
+
+
+class Match(C.Structure):
+    _fields_ = [("itheta", C.c_int32), ("ix", C.c_int32), ("iy", C.c_int32), ("score", C.c_float)]
+
+
+_vp, _i32, _i64, _f64 = C.c_void_p, C.c_int32, C.c_int64, C.c_double
+_P = C.POINTER
+
+# name -> (restype, argtypes); the list is also what tests check against the header.
+PROTOTYPES = {
+    "nhip_init": (C.c_int, [_P(C.c_int)]),
+    "nhip_set_device": (C.c_int, [C.c_int]),
+    "nhip_last_error": (C.c_char_p, []),
+    "nhip_version": (C.c_char_p, []),
+    "nhip_grid_layout": (C.c_int, [_P(GridSpec), _P(GridLayout)]),
+    "nhip_grids_bytes": (_i64, [_P(GridSpec), _i64]),
+    "nhip_grid_workspace_bytes": (_i64, [_P(GridSpec), _i32]),
+    "nhip_grid_tables": (C.c_int, [_P(GridSpec), _vp, _vp]),
+    "nhip_csm_rot0": (C.c_int, [_vp, _vp, _i32, _vp]),
+    "nhip_csm_delta_table": (C.c_int, [_P(Search), _vp]),
+    "nhip_match_to_transform": (C.c_int, [_P(Match), _P(GridSpec), _P(Search), _f64, _i32, _i32,
+                                          _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
+    "nhip_score_from_sum": (_f64, [_P(GridSpec), _i64, _i32]),
+    "nhip_grid_build_dev": (C.c_int, [_vp, _vp, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
+    "nhip_csm_match_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _vp, _vp, _vp, _vp, _vp, _i32,
+                                     _P(Search), _vp, _vp, _vp, _vp]),
+    "nhip_csm_scores_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _i32, _i32, _vp, _vp, _i32, _i32,
+                                      _P(Search), _vp, _vp]),
+    "nhip_resid_lidar_dev": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp,
+                                       _vp, _vp, _vp, _vp]),
+    "nhip_resid_point_to_line_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp,
+                                               _vp, _vp, _vp, _vp]),
+    "nhip_resid_odometry_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _vp, _vp,
+                                          _vp, _vp]),
+    "nhip_scans_upload": (C.c_int, [_vp, _vp, _i32, _P(_vp)]),
+    "nhip_scans_free": (C.c_int, [_vp]),
+    "nhip_grids_build": (C.c_int, [_vp, _vp, _i32, _P(GridSpec), _P(_vp)]),
+    "nhip_grids_free": (C.c_int, [_vp]),
+    "nhip_grids_download": (C.c_int, [_vp, _i32, _vp]),
+    "nhip_csm_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _P(Search), _vp, _vp]),
+    "nhip_csm_scores": (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, _i32, _P(Search), _vp]),
+    "nhip_resid_batch_create": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _P(_vp)]),
+    "nhip_resid_batch_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "nhip_resid_batch_free": (C.c_int, [_vp]),
+    "nhip_timing_enable": (C.c_int, [C.c_int]),
+    "nhip_timing_reset": (C.c_int, []),
+    "nhip_timing_get": (C.c_int, [C.c_int, _P(_f64), _P(_i32)]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once) and bind every prototype.  Fails loudly."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "nautilus_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C nautilus_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc):
+    if rc != NHIP_OK:
+        raise NhipError(rc, load().nhip_last_error().decode("utf-8", "replace"))
+
+
+def device_count():
+    n = C.c_int(0)
+    load().nhip_init(C.byref(n))
+    return n.value
+
+
+def ptr(a):
+    """void* of a numpy array (None -> NULL)."""
+    return None if a is None else a.ctypes.data_as(C.c_void_p)

@@ -1,0 +1,195 @@
+"""Host-side mirror of the loop-closure scan matcher interface, over the C ABI.
+
+Mirrors (same names / argument meaning):
+  CorrelativeScanMatcher(scanner_range, trans_range, low_res, high_res)
+      .GetTransformation(pc_a, pc_b, rot_a, rot_b, rot_restriction)
+          -> (score, ((tx, ty), theta))        /root/reference/src/optimization/solver.cc:633-644
+plus the batched form the hot path is built for (ScanTable / LikelihoodGrids / match_pairs).
+All compute happens in libnautilus_hip.so; nothing here falls back to the CPU.
+"""
+import ctypes as C
+import math
+
+import numpy as np
+
+from . import _lib
+from ._lib import GridSpec, GridLayout, Search, Match, check, ptr
+
+MATCH_DTYPE = np.dtype([("itheta", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("score", "<f4")])
+assert MATCH_DTYPE.itemsize == C.sizeof(Match) == 16
+
+
+def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40):
+    return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(max_shift), 0)
+
+
+def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0)):
+    return Search(int(n_theta), int(nx), int(ny), 0, float(theta_step))
+
+
+def grid_layout(spec):
+    out = GridLayout()
+    check(_lib.load().nhip_grid_layout(C.byref(spec), C.byref(out)))
+    return out
+
+
+def angle_mod(a):
+    """math_util.h:81-84"""
+    return a - 2.0 * math.pi * np.rint(a / (2.0 * math.pi))
+
+
+def rot0_table(rot_a, rot_b=None):
+    rot_a = np.ascontiguousarray(rot_a, dtype=np.float64)
+    rb = None if rot_b is None else np.ascontiguousarray(rot_b, dtype=np.float64)
+    out = np.empty((rot_a.size, 2), dtype=np.float64)
+    check(_lib.load().nhip_csm_rot0(ptr(rot_a), ptr(rb), rot_a.size, ptr(out)))
+    return out
+
+
+def delta_table(search):
+    out = np.empty((search.n_theta, 2), dtype=np.float64)
+    check(_lib.load().nhip_csm_delta_table(C.byref(search), ptr(out)))
+    return out
+
+
+def pack_scans(scans):
+    """list of (N_i, 2) float32 clouds -> (xy (sum N, 2) float32, offsets (n+1) int32)."""
+    offsets = np.zeros(len(scans) + 1, dtype=np.int32)
+    for i, s in enumerate(scans):
+        offsets[i + 1] = offsets[i] + len(s)
+    xy = np.zeros((int(offsets[-1]), 2), dtype=np.float32)
+    for i, s in enumerate(scans):
+        if len(s):
+            xy[offsets[i]:offsets[i + 1]] = np.asarray(s, dtype=np.float32).reshape(-1, 2)
+    return xy, offsets
+
+
+class ScanTable:
+    """Device copy of the point clouds (std::vector<Vector2f> per node, slam_types.h:41-76)."""
+
+    def __init__(self, xy, offsets):
+        self.xy = np.ascontiguousarray(xy, dtype=np.float32).reshape(-1, 2)
+        self.offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+        self.n_scans = self.offsets.size - 1
+        self._h = C.c_void_p()
+        check(_lib.load().nhip_scans_upload(ptr(self.xy), ptr(self.offsets), self.n_scans, C.byref(self._h)))
+
+    @classmethod
+    def from_list(cls, scans):
+        return cls(*pack_scans(scans))
+
+    def close(self):
+        if self._h:
+            _lib.load().nhip_scans_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+class LikelihoodGrids:
+    """Log-likelihood lookup tables of the target scans, resident in HBM."""
+
+    def __init__(self, scans, target_ids, spec):
+        self.spec = spec
+        self.layout = grid_layout(spec)
+        self.target_ids = np.ascontiguousarray(target_ids, dtype=np.int32)
+        self._h = C.c_void_p()
+        check(_lib.load().nhip_grids_build(scans._h, ptr(self.target_ids), self.target_ids.size,
+                                           C.byref(spec), C.byref(self._h)))
+
+    def download(self, slot):
+        """Stored (padded) grid as (rows, pitch) uint8."""
+        L = self.layout
+        out = np.empty((L.rows, L.pitch), dtype=np.uint8)
+        check(_lib.load().nhip_grids_download(self._h, int(slot), ptr(out)))
+        return out
+
+    def interior(self, slot):
+        L = self.layout
+        return self.download(slot)[L.pad:L.pad + L.side, L.pad:L.pad + L.side]
+
+    def close(self):
+        if self._h:
+            _lib.load().nhip_grids_free(self._h)
+            self._h = C.c_void_p()
+
+    __del__ = close
+
+
+def match_pairs(scans, grids, pair_src, pair_slot, theta0, search, pair_origin=None):
+    """Batched GetTransformation.  Returns (matches MATCH_DTYPE[n], sums int32[n])."""
+    pair_src = np.ascontiguousarray(pair_src, dtype=np.int32)
+    pair_slot = np.ascontiguousarray(pair_slot, dtype=np.int32)
+    theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+    n = pair_src.size
+    if pair_slot.size != n or theta0.size != n:
+        raise ValueError("pair arrays differ in length")
+    org = None
+    if pair_origin is not None:
+        org = np.ascontiguousarray(pair_origin, dtype=np.int32).reshape(n, 2)
+    out = np.zeros(n, dtype=MATCH_DTYPE)
+    sums = np.zeros(n, dtype=np.int32)
+    check(_lib.load().nhip_csm_match(scans._h, grids._h, ptr(pair_src), ptr(pair_slot), ptr(theta0),
+                                     ptr(org), n, C.byref(search), ptr(out), ptr(sums)))
+    return out, sums
+
+
+def score_volume(scans, grids, src, slot, theta0, search, origin=(0, 0)):
+    out = np.zeros((search.n_theta, search.nx, search.ny), dtype=np.int32)
+    check(_lib.load().nhip_csm_scores(scans._h, grids._h, int(src), int(slot), float(theta0),
+                                      int(origin[0]), int(origin[1]), C.byref(search), ptr(out)))
+    return out
+
+
+def match_to_transform(m, spec, search, theta0, origin=(0, 0)):
+    """(tx, ty, theta) as consumed at solver.cc:640-644: T_AB = Translation(tx, ty) * Rotation(theta)."""
+    tx = (origin[0] + int(m["ix"]) - (search.nx - 1) // 2) * spec.res
+    ty = (origin[1] + int(m["iy"]) - (search.ny - 1) // 2) * spec.res
+    th = theta0 + (int(m["itheta"]) - (search.n_theta - 1) // 2) * search.theta_step
+    return np.float32(tx), np.float32(ty), np.float32(th)
+
+
+class CorrelativeScanMatcher:
+    """Drop-in shape of third_party/csm's class as nautilus uses it (solver.h:18,126; solver.cc:56,633).
+
+    Coarse-to-fine like the ctor's (low_res, high_res) pair implies: an exhaustive search on the
+    low_res grid over +-trans_range / +-rot_restriction, then an exhaustive refinement on the
+    high_res grid around the coarse optimum (build-defined).
+    """
+
+    COARSE_THETA_STEP = math.radians(1.0)
+    FINE_THETA_STEPS = 10  # fine rotation step = coarse / 10
+
+    def __init__(self, scanner_range, trans_range, low_res, high_res, sigma=2.0):
+        self.range = float(scanner_range)
+        self.trans_range = float(trans_range)
+        self.low_res = float(low_res)
+        self.high_res = float(high_res)
+        self.sigma = float(sigma)
+
+    def GetTransformation(self, pointcloud_a, pointcloud_b, rotation_a, rotation_b, rotation_restriction):
+        scans = ScanTable.from_list([pointcloud_a, pointcloud_b])
+        theta0 = float(angle_mod(np.float64(rotation_a) - np.float64(rotation_b)))
+        # level 1: low_res grid, whole translation range
+        h1 = int(math.floor(self.trans_range / self.low_res))
+        n_th = 2 * int(math.floor(rotation_restriction / self.COARSE_THETA_STEP)) + 1
+        spec1 = grid_spec(self.range, self.low_res, self.sigma, 1e-10, h1)
+        s1 = search_spec(n_th, 2 * h1 + 1, 2 * h1 + 1, self.COARSE_THETA_STEP)
+        g1 = LikelihoodGrids(scans, [1], spec1)
+        m1, _ = match_pairs(scans, g1, [0], [0], [theta0], s1)
+        tx1, ty1, th1 = match_to_transform(m1[0], spec1, s1, theta0)
+        g1.close()
+        # level 2: high_res grid, +-low_res around the coarse optimum, +-1 coarse step in theta
+        ratio = int(round(self.low_res / self.high_res))
+        cx = int(round(float(tx1) / self.high_res))
+        cy = int(round(float(ty1) / self.high_res))
+        h2 = ratio
+        spec2 = grid_spec(self.range, self.high_res, self.sigma, 1e-10, max(abs(cx), abs(cy)) + h2)
+        s2 = search_spec(2 * self.FINE_THETA_STEPS + 1, 2 * h2 + 1, 2 * h2 + 1,
+                         self.COARSE_THETA_STEP / self.FINE_THETA_STEPS)
+        g2 = LikelihoodGrids(scans, [1], spec2)
+        m2, _ = match_pairs(scans, g2, [0], [0], [float(th1)], s2, pair_origin=[[cx, cy]])
+        tx, ty, th = match_to_transform(m2[0], spec2, s2, float(th1), (cx, cy))
+        g2.close()
+        scans.close()
+        return float(m2[0]["score"]), ((tx, ty), th)

@@ -1,0 +1,675 @@
+// nhip_api.hip -- extern "C" shim of libnautilus_hip (include/nautilus_hip.h): argument
+// checking, host-side spec tables, handle objects, in-stream kernel timing.
+#include <cstdarg>
+#include <mutex>
+
+#include "nhip_common.h"
+
+namespace nhip {
+
+static thread_local std::string g_err;
+
+void set_error(const char *fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line) {
+  set_error("HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, what);
+  return NHIP_ERR_HIP;
+}
+
+int require_device() {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    (void)hipGetLastError();
+    set_error("no HIP device visible (hipGetDeviceCount -> %d, n = %d): this library has no CPU path",
+              (int)e, n);
+    return NHIP_ERR_NODEV;
+  }
+  return NHIP_OK;
+}
+
+// ---------------------------------------------------------------- spec tables (host)
+int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
+  NHIP_REQUIRE(spec != nullptr && L != nullptr, "grid spec: null pointer");
+  NHIP_REQUIRE(spec->range > 0 && spec->res > 0, "grid spec: range and res must be > 0");
+  NHIP_REQUIRE(spec->sigma > 0 && spec->sigma <= 16.0 / 3.0, "grid spec: sigma must be in (0, 5.33] cells");
+  NHIP_REQUIRE(spec->floor_p > 0 && spec->floor_p < 1, "grid spec: floor_p must be in (0, 1)");
+  NHIP_REQUIRE(spec->max_shift >= 0 && spec->max_shift <= 4096, "grid spec: max_shift out of range");
+  const double side = floor((spec->range * 2.0) / spec->res);  // cimg_debug.h:21-22
+  NHIP_REQUIRE(side >= 1 && side <= 16384, "grid spec: side %g out of range [1, 16384]", side);
+  L->S = (int32_t)side;
+  L->pad = ((2 * spec->max_shift + 4) + 3) & ~3;
+  L->pitch = ((L->S + 2 * L->pad) + 3) & ~3;
+  L->R = (int32_t)ceil(3.0 * spec->sigma);
+  L->grid_bytes = (int64_t)L->pitch * (int64_t)(L->S + 2 * L->pad);
+  L->Lf = log(spec->floor_p);
+  L->step = -L->Lf / 255.0;
+  // integer taps: round(16384 * g_i / sum g)
+  double g[129], tot = 0.0;
+  for (int i = -L->R; i <= L->R; i++) {
+    g[i + L->R] = exp(-((double)i * (double)i) / (2.0 * spec->sigma * spec->sigma));
+    tot += g[i + L->R];
+  }
+  L->K = 0;
+  for (int i = 0; i <= 2 * L->R; i++) L->K += (int64_t)floor(16384.0 * g[i] / tot + 0.5);
+  return NHIP_OK;
+}
+
+// The quantiser of the spec, evaluated directly (used only to build the threshold table).
+static uint32_t quantise_direct(uint64_t V, int64_t K, double floor_p) {
+  double v = (double)V / ((double)K * (double)K);
+  if (v < floor_p) v = floor_p;
+  const double Lf = log(floor_p);
+  const double step = -Lf / 255.0;
+  double q = floor((log(v) - Lf) / step + 0.5);
+  if (q < 0.0) q = 0.0;
+  if (q > 255.0) q = 255.0;
+  return (uint32_t)q;
+}
+
+int make_tables(const nhip_grid_spec_t *spec, const GridLayout &L, GridTables *T) {
+  memset(T, 0, sizeof(*T));
+  double g[129], tot = 0.0;
+  for (int i = -L.R; i <= L.R; i++) {
+    g[i + L.R] = exp(-((double)i * (double)i) / (2.0 * spec->sigma * spec->sigma));
+    tot += g[i + L.R];
+  }
+  for (int i = 0; i <= 2 * L.R; i++) T->taps[i] = (int32_t)floor(16384.0 * g[i] / tot + 0.5);
+  // thr[k] = smallest integer V whose quantised value is >= k (V ranges over [0, K*K]).
+  const uint64_t vmax = (uint64_t)L.K * (uint64_t)L.K;
+  T->thr[0] = 0;
+  for (int k = 1; k <= 255; k++) {
+    if (quantise_direct(vmax, L.K, spec->floor_p) < (uint32_t)k) {
+      T->thr[k] = 0xffffffffu;  // unreachable level
+      continue;
+    }
+    uint64_t lo = 0, hi = vmax;  // q(lo) < k <= q(hi) unless q(0) >= k
+    if (quantise_direct(0, L.K, spec->floor_p) >= (uint32_t)k) {
+      T->thr[k] = 0;
+      continue;
+    }
+    while (hi - lo > 1) {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      if (quantise_direct(mid, L.K, spec->floor_p) >= (uint32_t)k) hi = mid; else lo = mid;
+    }
+    T->thr[k] = (uint32_t)hi;
+  }
+  return NHIP_OK;
+}
+
+// ---------------------------------------------------------------- in-stream timing
+namespace {
+struct TimerSlot {
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> ev;
+  hipEvent_t open = nullptr;
+};
+std::mutex g_tmu;
+bool g_timing = false;
+TimerSlot g_slots[3];
+}  // namespace
+
+void timer_begin(int id, hipStream_t s) {
+  if (!g_timing) return;
+  std::lock_guard<std::mutex> lk(g_tmu);
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_slots[id].open = e;
+}
+
+void timer_end(int id, hipStream_t s) {
+  if (!g_timing) return;
+  std::lock_guard<std::mutex> lk(g_tmu);
+  if (!g_slots[id].open) return;
+  hipEvent_t e;
+  if (hipEventCreate(&e) != hipSuccess) return;
+  (void)hipEventRecord(e, s);
+  g_slots[id].ev.emplace_back(g_slots[id].open, e);
+  g_slots[id].open = nullptr;
+}
+
+// ---------------------------------------------------------------- handles
+struct DevBuf {
+  void *p = nullptr;
+  size_t bytes = 0;
+  int alloc(size_t n) {
+    free();
+    if (n == 0) n = 16;
+    hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {
+      p = nullptr;
+      set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
+      return NHIP_ERR_ALLOC;
+    }
+    bytes = n;
+    return NHIP_OK;
+  }
+  void free() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    bytes = 0;
+  }
+  ~DevBuf() { free(); }
+};
+
+}  // namespace nhip
+
+struct nhip_scans {
+  nhip::DevBuf xy, offsets;
+  int32_t n_scans = 0;
+  int64_t n_points = 0;
+  std::vector<int32_t> h_offsets;
+};
+
+struct nhip_grids {
+  nhip::DevBuf grids;
+  nhip_grid_spec_t spec;
+  nhip::GridLayout L;
+  int32_t n = 0;
+};
+
+struct nhip_resid_batch {
+  nhip::DevBuf corr, corr_block, block_src, block_tgt, consts, poses, res, jsrc, jtgt;
+  int kind = 0;
+  int32_t n_blocks = 0, n_poses = 0;
+  int64_t n_corr = 0;
+};
+
+using namespace nhip;
+
+extern "C" {
+
+const char *nhip_last_error(void) { return g_err.c_str(); }
+const char *nhip_version(void) { return "nautilus_hip 0.1 (gfx950)"; }
+
+int nhip_init(int *n_devices) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    n = 0;
+  }
+  if (n_devices) *n_devices = n;
+  if (n <= 0) {
+    set_error("no HIP device visible");
+    return NHIP_ERR_NODEV;
+  }
+  return NHIP_OK;
+}
+
+int nhip_set_device(int device) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipSetDevice(device));
+  return NHIP_OK;
+}
+
+int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out) {
+  GridLayout L;
+  int rc = make_layout(spec, &L);
+  if (rc) return rc;
+  NHIP_REQUIRE(out != nullptr, "grid_layout: null out");
+  out->side = L.S;
+  out->pad = L.pad;
+  out->pitch = L.pitch;
+  out->rows = L.S + 2 * L.pad;
+  out->blur_radius = L.R;
+  out->reserved = 0;
+  out->tap_sum = L.K;
+  out->grid_bytes = L.grid_bytes;
+  out->score_floor = L.Lf;
+  out->score_step = L.step;
+  return NHIP_OK;
+}
+
+int64_t nhip_grids_bytes(const nhip_grid_spec_t *spec, int64_t n_grids) {
+  GridLayout L;
+  if (make_layout(spec, &L)) return -1;
+  return n_grids * L.grid_bytes + 256;
+}
+
+int64_t nhip_grid_workspace_bytes(const nhip_grid_spec_t *spec, int32_t chunk) {
+  GridLayout L;
+  if (make_layout(spec, &L)) return -1;
+  if (chunk < 1) chunk = 1;
+  return (int64_t)chunk * L.S * L.S;
+}
+
+int nhip_grid_tables(const nhip_grid_spec_t *spec, int32_t *taps, uint32_t *thresholds) {
+  GridLayout L;
+  int rc = make_layout(spec, &L);
+  if (rc) return rc;
+  GridTables T;
+  rc = make_tables(spec, L, &T);
+  if (rc) return rc;
+  if (taps) memcpy(taps, T.taps, sizeof(int32_t) * (2 * L.R + 1));
+  if (thresholds) memcpy(thresholds, T.thr, sizeof(T.thr));
+  return NHIP_OK;
+}
+
+int nhip_csm_rot0(const double *rot_a, const double *rot_b, int32_t n, double *cs_out) {
+  NHIP_REQUIRE(rot_a && cs_out && n >= 0, "csm_rot0: bad arguments");
+  for (int32_t i = 0; i < n; i++) {
+    // math_util.h:81-89: AngleDiff(a0, a1) = AngleMod(a0 - a1), AngleMod: a -= 2pi*rint(a / 2pi)
+    double a = rot_a[i] - (rot_b ? rot_b[i] : 0.0);
+    a -= (2.0 * M_PI) * rint(a / (2.0 * M_PI));
+    cs_out[2 * i] = cos(a);
+    cs_out[2 * i + 1] = sin(a);
+  }
+  return NHIP_OK;
+}
+
+int nhip_csm_delta_table(const nhip_search_t *search, double *cs_out) {
+  NHIP_REQUIRE(search && cs_out && search->n_theta >= 1, "csm_delta_table: bad arguments");
+  for (int32_t k = 0; k < search->n_theta; k++) {
+    const double d = (double)(k - (search->n_theta - 1) / 2) * search->theta_step;
+    cs_out[2 * k] = cos(d);
+    cs_out[2 * k + 1] = sin(d);
+  }
+  return NHIP_OK;
+}
+
+int nhip_match_to_transform(const nhip_match_t *m, const nhip_grid_spec_t *spec,
+                            const nhip_search_t *search, double theta0, int32_t origin_x,
+                            int32_t origin_y, float *tx, float *ty, float *theta) {
+  NHIP_REQUIRE(m && spec && search, "match_to_transform: null argument");
+  if (tx) *tx = (float)((double)(origin_x + m->ix - (search->nx - 1) / 2) * spec->res);
+  if (ty) *ty = (float)((double)(origin_y + m->iy - (search->ny - 1) / 2) * spec->res);
+  if (theta) *theta = (float)(theta0 + (double)(m->itheta - (search->n_theta - 1) / 2) * search->theta_step);
+  return NHIP_OK;
+}
+
+double nhip_score_from_sum(const nhip_grid_spec_t *spec, int64_t sum, int32_t n_points) {
+  const double Lf = log(spec->floor_p), step = -Lf / 255.0;
+  if (n_points <= 0) return Lf;
+  const double t = step * (double)sum;
+  const double u = t / (double)n_points;
+  return Lf + u;
+}
+
+// ---------------------------------------------------------------- device-pointer API
+int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+                        int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
+                        void *d_workspace, int64_t workspace_bytes, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_xy && d_offsets && d_target_ids && d_grids && d_workspace, "grid_build_dev: null pointer");
+  NHIP_REQUIRE(n_targets >= 0, "grid_build_dev: n_targets < 0");
+  GridLayout L;
+  rc = make_layout(spec, &L);
+  if (rc) return rc;
+  if (n_targets == 0) return NHIP_OK;
+  return launch_grid_build(d_xy, d_offsets, d_target_ids, n_targets, spec, L, d_grids, d_workspace,
+                           workspace_bytes, static_cast<hipStream_t>(stream));
+}
+
+int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                       const nhip_grid_spec_t *spec, const int32_t *d_pair_src,
+                       const int32_t *d_pair_slot, const double *d_rot0_cs,
+                       const double *d_delta_cs, const int32_t *d_pair_origin, int32_t n_pairs,
+                       const nhip_search_t *search, uint64_t *d_keys, nhip_match_t *d_out,
+                       int32_t *d_sums, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_xy && d_offsets && d_grids && d_pair_src && d_pair_slot && d_rot0_cs && d_delta_cs &&
+                   d_keys && d_out && search,
+               "csm_match_dev: null pointer");
+  NHIP_REQUIRE(n_pairs >= 0, "csm_match_dev: n_pairs < 0");
+  GridLayout L;
+  rc = make_layout(spec, &L);
+  if (rc) return rc;
+  return launch_csm_match(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs,
+                          d_delta_cs, d_pair_origin, n_pairs, search, d_keys, d_out, d_sums,
+                          static_cast<hipStream_t>(stream));
+}
+
+int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                        const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
+                        const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
+                        int32_t origin_y, const nhip_search_t *search, int32_t *d_sums,
+                        void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_xy && d_offsets && d_grids && d_rot0_cs && d_delta_cs && d_sums && search,
+               "csm_scores_dev: null pointer");
+  GridLayout L;
+  rc = make_layout(spec, &L);
+  if (rc) return rc;
+  return launch_csm_scores(d_xy, d_offsets, d_grids, spec, L, src, slot, d_rot0_cs, d_delta_cs,
+                           origin_x, origin_y, search, d_sums, static_cast<hipStream_t>(stream));
+}
+
+int nhip_resid_lidar_dev(int kind, const float *d_corr, const int32_t *d_corr_block,
+                         int64_t n_corr, const int32_t *d_block_src, const int32_t *d_block_tgt,
+                         int32_t n_blocks, const double *d_poses, int32_t n_poses,
+                         double *d_block_consts, double *d_residuals, double *d_jac_src,
+                         double *d_jac_tgt, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_corr && d_corr_block && d_block_src && d_block_tgt && d_poses && d_block_consts &&
+                   d_residuals,
+               "resid_lidar_dev: null pointer");
+  return launch_resid_lidar(kind, d_corr, d_corr_block, n_corr, d_block_src, d_block_tgt, n_blocks,
+                            d_poses, n_poses, d_block_consts, d_residuals, d_jac_src, d_jac_tgt,
+                            static_cast<hipStream_t>(stream));
+}
+
+int nhip_resid_point_to_line_dev(const float *d_segments, const float *d_points,
+                                 const int32_t *d_point_block, int64_t n_points,
+                                 const int32_t *d_block_pose, const int32_t *d_block_line,
+                                 int32_t n_blocks, const double *d_poses,
+                                 const double *d_line_poses, double *d_residuals,
+                                 double *d_jac_pose, double *d_jac_line, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_segments && d_points && d_point_block && d_block_pose && d_block_line && d_poses &&
+                   d_line_poses && d_residuals,
+               "resid_point_to_line_dev: null pointer");
+  return launch_resid_point_to_line(d_segments, d_points, d_point_block, n_points, d_block_pose,
+                                    d_block_line, n_blocks, d_poses, d_line_poses, d_residuals,
+                                    d_jac_pose, d_jac_line, static_cast<hipStream_t>(stream));
+}
+
+int nhip_resid_odometry_dev(const float *d_t_odom, const float *d_r_odom, const int32_t *d_pose_i,
+                            const int32_t *d_pose_j, int32_t n_factors, double translation_weight,
+                            double rotation_weight, const double *d_poses, double *d_residuals,
+                            double *d_jac_i, double *d_jac_j, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_t_odom && d_r_odom && d_pose_i && d_pose_j && d_poses && d_residuals,
+               "resid_odometry_dev: null pointer");
+  return launch_resid_odometry(d_t_odom, d_r_odom, d_pose_i, d_pose_j, n_factors,
+                               translation_weight, rotation_weight, d_poses, d_residuals, d_jac_i,
+                               d_jac_j, static_cast<hipStream_t>(stream));
+}
+
+// ---------------------------------------------------------------- handle API
+int nhip_scans_upload(const float *xy, const int32_t *offsets, int32_t n_scans, nhip_scans_t **out) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(offsets && out && n_scans >= 0, "scans_upload: bad arguments");
+  NHIP_REQUIRE(offsets[0] == 0, "scans_upload: offsets[0] must be 0");
+  for (int32_t i = 0; i < n_scans; i++)
+    NHIP_REQUIRE(offsets[i + 1] >= offsets[i], "scans_upload: offsets not monotone at scan %d", i);
+  const int64_t n_points = offsets[n_scans];
+  NHIP_REQUIRE(n_points == 0 || xy, "scans_upload: null xy");
+  nhip_scans *s = new nhip_scans();
+  s->n_scans = n_scans;
+  s->n_points = n_points;
+  s->h_offsets.assign(offsets, offsets + n_scans + 1);
+  if ((rc = s->xy.alloc(sizeof(float) * 2 * (size_t)n_points)) ||
+      (rc = s->offsets.alloc(sizeof(int32_t) * (size_t)(n_scans + 1)))) {
+    delete s;
+    return rc;
+  }
+  hipError_t e = hipSuccess;
+  if (n_points) e = hipMemcpy(s->xy.p, xy, sizeof(float) * 2 * (size_t)n_points, hipMemcpyHostToDevice);
+  if (e == hipSuccess)
+    e = hipMemcpy(s->offsets.p, offsets, sizeof(int32_t) * (size_t)(n_scans + 1), hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete s;
+    return hip_fail(e, "scans_upload memcpy", __FILE__, __LINE__);
+  }
+  *out = s;
+  return NHIP_OK;
+}
+
+int nhip_scans_free(nhip_scans_t *scans) {
+  delete scans;
+  return NHIP_OK;
+}
+
+int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32_t n_targets,
+                     const nhip_grid_spec_t *spec, nhip_grids_t **out) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(scans && out && n_targets >= 0 && (target_ids || n_targets == 0), "grids_build: bad arguments");
+  for (int32_t i = 0; i < n_targets; i++)
+    NHIP_REQUIRE(target_ids[i] >= 0 && target_ids[i] < scans->n_scans,
+                 "grids_build: target id %d out of range", target_ids[i]);
+  GridLayout L;
+  rc = make_layout(spec, &L);
+  if (rc) return rc;
+  nhip_grids *g = new nhip_grids();
+  g->spec = *spec;
+  g->L = L;
+  g->n = n_targets;
+  DevBuf ids, ws;
+  const int32_t chunk = n_targets < 64 ? (n_targets > 0 ? n_targets : 1) : 64;
+  const int64_t ws_bytes = (int64_t)chunk * L.S * L.S;
+  if ((rc = g->grids.alloc((size_t)n_targets * L.grid_bytes + 256)) ||
+      (rc = ids.alloc(sizeof(int32_t) * (size_t)(n_targets > 0 ? n_targets : 1))) ||
+      (rc = ws.alloc((size_t)ws_bytes))) {
+    delete g;
+    return rc;
+  }
+  hipError_t e = hipMemset(g->grids.p, 0, g->grids.bytes);
+  if (e == hipSuccess && n_targets)
+    e = hipMemcpy(ids.p, target_ids, sizeof(int32_t) * (size_t)n_targets, hipMemcpyHostToDevice);
+  if (e != hipSuccess) {
+    delete g;
+    return hip_fail(e, "grids_build setup", __FILE__, __LINE__);
+  }
+  if (n_targets) {
+    rc = launch_grid_build(static_cast<const float *>(scans->xy.p),
+                           static_cast<const int32_t *>(scans->offsets.p),
+                           static_cast<const int32_t *>(ids.p), n_targets, spec, L,
+                           static_cast<uint8_t *>(g->grids.p), ws.p, ws_bytes, nullptr);
+    if (rc == NHIP_OK) {
+      e = hipDeviceSynchronize();
+      if (e != hipSuccess) rc = hip_fail(e, "grids_build sync", __FILE__, __LINE__);
+    }
+    if (rc) {
+      delete g;
+      return rc;
+    }
+  }
+  *out = g;
+  return NHIP_OK;
+}
+
+int nhip_grids_free(nhip_grids_t *grids) {
+  delete grids;
+  return NHIP_OK;
+}
+
+int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
+  NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download: bad arguments");
+  NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * grids->L.grid_bytes,
+                         (size_t)grids->L.grid_bytes, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const int32_t *pair_src,
+                   const int32_t *pair_slot, const double *theta0, const int32_t *pair_origin,
+                   int32_t n_pairs, const nhip_search_t *search, nhip_match_t *out,
+                   int32_t *out_sums) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(scans && grids && search && n_pairs >= 0, "csm_match: bad arguments");
+  NHIP_REQUIRE(n_pairs == 0 || (pair_src && pair_slot && theta0 && out), "csm_match: null array");
+  for (int32_t i = 0; i < n_pairs; i++) {
+    NHIP_REQUIRE(pair_src[i] >= 0 && pair_src[i] < scans->n_scans, "csm_match: pair %d source %d out of range", i, pair_src[i]);
+    NHIP_REQUIRE(pair_slot[i] >= 0 && pair_slot[i] < grids->n, "csm_match: pair %d grid slot %d out of range", i, pair_slot[i]);
+    if (pair_origin)
+      NHIP_REQUIRE(abs(pair_origin[2 * i]) + (search->nx - 1) / 2 <= grids->spec.max_shift &&
+                       abs(pair_origin[2 * i + 1]) + (search->ny - 1) / 2 <= grids->spec.max_shift,
+                   "csm_match: pair %d search centre (%d, %d) exceeds the grids' max_shift %d", i,
+                   pair_origin[2 * i], pair_origin[2 * i + 1], grids->spec.max_shift);
+  }
+  if (n_pairs == 0) return NHIP_OK;
+  std::vector<double> rot0(2 * (size_t)n_pairs), delta(2 * (size_t)search->n_theta);
+  if ((rc = nhip_csm_rot0(theta0, nullptr, n_pairs, rot0.data()))) return rc;
+  if ((rc = nhip_csm_delta_table(search, delta.data()))) return rc;
+  DevBuf d_src, d_slot, d_rot0, d_delta, d_keys, d_out, d_sums, d_org;
+  if (pair_origin) {
+    if ((rc = d_org.alloc(sizeof(int32_t) * 2 * (size_t)n_pairs))) return rc;
+    NHIP_TRY_HIP(hipMemcpy(d_org.p, pair_origin, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice));
+  }
+  if ((rc = d_src.alloc(sizeof(int32_t) * (size_t)n_pairs)) || (rc = d_slot.alloc(sizeof(int32_t) * (size_t)n_pairs)) ||
+      (rc = d_rot0.alloc(sizeof(double) * rot0.size())) || (rc = d_delta.alloc(sizeof(double) * delta.size())) ||
+      (rc = d_keys.alloc(sizeof(uint64_t) * (size_t)n_pairs)) || (rc = d_out.alloc(sizeof(nhip_match_t) * (size_t)n_pairs)) ||
+      (rc = d_sums.alloc(sizeof(int32_t) * (size_t)n_pairs)))
+    return rc;
+  NHIP_TRY_HIP(hipMemcpy(d_src.p, pair_src, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyHostToDevice));
+  NHIP_TRY_HIP(hipMemcpy(d_slot.p, pair_slot, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyHostToDevice));
+  NHIP_TRY_HIP(hipMemcpy(d_rot0.p, rot0.data(), sizeof(double) * rot0.size(), hipMemcpyHostToDevice));
+  NHIP_TRY_HIP(hipMemcpy(d_delta.p, delta.data(), sizeof(double) * delta.size(), hipMemcpyHostToDevice));
+  rc = launch_csm_match(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p),
+                        static_cast<const uint8_t *>(grids->grids.p), &grids->spec, grids->L,
+                        static_cast<const int32_t *>(d_src.p), static_cast<const int32_t *>(d_slot.p),
+                        static_cast<const double *>(d_rot0.p), static_cast<const double *>(d_delta.p),
+                        pair_origin ? static_cast<const int32_t *>(d_org.p) : nullptr, n_pairs, search, static_cast<uint64_t *>(d_keys.p), static_cast<nhip_match_t *>(d_out.p),
+                        static_cast<int32_t *>(d_sums.p), nullptr);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(out, d_out.p, sizeof(nhip_match_t) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+  if (out_sums) NHIP_TRY_HIP(hipMemcpy(out_sums, d_sums.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_csm_scores(const nhip_scans_t *scans, const nhip_grids_t *grids, int32_t src, int32_t slot,
+                    double theta0, int32_t origin_x, int32_t origin_y, const nhip_search_t *search,
+                    int32_t *out_sums) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(scans && grids && search && out_sums, "csm_scores: bad arguments");
+  NHIP_REQUIRE(src >= 0 && src < scans->n_scans && slot >= 0 && slot < grids->n, "csm_scores: index out of range");
+  double rot0[2];
+  std::vector<double> delta(2 * (size_t)search->n_theta);
+  if ((rc = nhip_csm_rot0(&theta0, nullptr, 1, rot0))) return rc;
+  if ((rc = nhip_csm_delta_table(search, delta.data()))) return rc;
+  const size_t vol = (size_t)search->n_theta * search->nx * search->ny;
+  DevBuf d_rot0, d_delta, d_vol;
+  if ((rc = d_rot0.alloc(sizeof(rot0))) || (rc = d_delta.alloc(sizeof(double) * delta.size())) ||
+      (rc = d_vol.alloc(sizeof(int32_t) * vol)))
+    return rc;
+  NHIP_TRY_HIP(hipMemcpy(d_rot0.p, rot0, sizeof(rot0), hipMemcpyHostToDevice));
+  NHIP_TRY_HIP(hipMemcpy(d_delta.p, delta.data(), sizeof(double) * delta.size(), hipMemcpyHostToDevice));
+  rc = launch_csm_scores(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p),
+                         static_cast<const uint8_t *>(grids->grids.p), &grids->spec, grids->L, src, slot,
+                         static_cast<const double *>(d_rot0.p), static_cast<const double *>(d_delta.p),
+                         origin_x, origin_y, search, static_cast<int32_t *>(d_vol.p), nullptr);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(out_sums, d_vol.p, sizeof(int32_t) * vol, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_resid_batch_create(int kind, const float *corr, const int32_t *block_offsets,
+                            const int32_t *block_src, const int32_t *block_tgt, int32_t n_blocks,
+                            int32_t n_poses, nhip_resid_batch_t **out) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(kind == NHIP_LIDAR_NORMAL || kind == NHIP_LIDAR_POINT, "resid_batch_create: bad kind %d", kind);
+  NHIP_REQUIRE(block_offsets && block_src && block_tgt && out && n_blocks >= 0 && n_poses >= 0,
+               "resid_batch_create: bad arguments");
+  NHIP_REQUIRE(block_offsets[0] == 0, "resid_batch_create: block_offsets[0] must be 0");
+  for (int32_t b = 0; b < n_blocks; b++) {
+    // slam_residuals.h:109 CHECK_GT(source_points.size(), 0)
+    NHIP_REQUIRE(block_offsets[b + 1] > block_offsets[b], "resid_batch_create: block %d is empty", b);
+    NHIP_REQUIRE(block_src[b] >= 0 && block_src[b] < n_poses && block_tgt[b] >= 0 && block_tgt[b] < n_poses,
+                 "resid_batch_create: block %d pose index out of range", b);
+  }
+  const int64_t n_corr = block_offsets[n_blocks];
+  NHIP_REQUIRE(n_corr == 0 || corr, "resid_batch_create: null corr");
+  std::vector<int32_t> cb((size_t)n_corr);
+  for (int32_t b = 0; b < n_blocks; b++)
+    for (int32_t i = block_offsets[b]; i < block_offsets[b + 1]; i++) cb[i] = b;
+  nhip_resid_batch *B = new nhip_resid_batch();
+  B->kind = kind;
+  B->n_blocks = n_blocks;
+  B->n_poses = n_poses;
+  B->n_corr = n_corr;
+  if ((rc = B->corr.alloc(sizeof(float) * 8 * (size_t)n_corr)) || (rc = B->corr_block.alloc(sizeof(int32_t) * (size_t)n_corr)) ||
+      (rc = B->block_src.alloc(sizeof(int32_t) * (size_t)n_blocks)) || (rc = B->block_tgt.alloc(sizeof(int32_t) * (size_t)n_blocks)) ||
+      (rc = B->consts.alloc(sizeof(double) * 8 * (size_t)n_blocks)) || (rc = B->poses.alloc(sizeof(double) * 3 * (size_t)n_poses)) ||
+      (rc = B->res.alloc(sizeof(double) * 2 * (size_t)n_corr)) || (rc = B->jsrc.alloc(sizeof(double) * 6 * (size_t)n_corr)) ||
+      (rc = B->jtgt.alloc(sizeof(double) * 6 * (size_t)n_corr))) {
+    delete B;
+    return rc;
+  }
+  hipError_t e = hipSuccess;
+  if (n_corr) {
+    e = hipMemcpy(B->corr.p, corr, sizeof(float) * 8 * (size_t)n_corr, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(B->corr_block.p, cb.data(), sizeof(int32_t) * (size_t)n_corr, hipMemcpyHostToDevice);
+  }
+  if (e == hipSuccess && n_blocks) {
+    e = hipMemcpy(B->block_src.p, block_src, sizeof(int32_t) * (size_t)n_blocks, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(B->block_tgt.p, block_tgt, sizeof(int32_t) * (size_t)n_blocks, hipMemcpyHostToDevice);
+  }
+  if (e != hipSuccess) {
+    delete B;
+    return hip_fail(e, "resid_batch_create memcpy", __FILE__, __LINE__);
+  }
+  *out = B;
+  return NHIP_OK;
+}
+
+int nhip_resid_batch_eval(nhip_resid_batch_t *B, const double *poses, double *residuals,
+                          double *jac_src, double *jac_tgt) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(B && poses && residuals, "resid_batch_eval: bad arguments");
+  if (B->n_corr == 0) return NHIP_OK;
+  NHIP_TRY_HIP(hipMemcpy(B->poses.p, poses, sizeof(double) * 3 * (size_t)B->n_poses, hipMemcpyHostToDevice));
+  rc = launch_resid_lidar(B->kind, static_cast<const float *>(B->corr.p), static_cast<const int32_t *>(B->corr_block.p),
+                          B->n_corr, static_cast<const int32_t *>(B->block_src.p),
+                          static_cast<const int32_t *>(B->block_tgt.p), B->n_blocks,
+                          static_cast<const double *>(B->poses.p), B->n_poses, static_cast<double *>(B->consts.p),
+                          static_cast<double *>(B->res.p), jac_src ? static_cast<double *>(B->jsrc.p) : nullptr,
+                          jac_tgt ? static_cast<double *>(B->jtgt.p) : nullptr, nullptr);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(residuals, B->res.p, sizeof(double) * 2 * (size_t)B->n_corr, hipMemcpyDeviceToHost));
+  if (jac_src) NHIP_TRY_HIP(hipMemcpy(jac_src, B->jsrc.p, sizeof(double) * 6 * (size_t)B->n_corr, hipMemcpyDeviceToHost));
+  if (jac_tgt) NHIP_TRY_HIP(hipMemcpy(jac_tgt, B->jtgt.p, sizeof(double) * 6 * (size_t)B->n_corr, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_resid_batch_free(nhip_resid_batch_t *batch) {
+  delete batch;
+  return NHIP_OK;
+}
+
+// ---------------------------------------------------------------- timing
+int nhip_timing_enable(int on) {
+  std::lock_guard<std::mutex> lk(g_tmu);
+  g_timing = on != 0;
+  return NHIP_OK;
+}
+
+int nhip_timing_reset(void) {
+  std::lock_guard<std::mutex> lk(g_tmu);
+  for (auto &s : g_slots) {
+    for (auto &p : s.ev) {
+      (void)hipEventDestroy(p.first);
+      (void)hipEventDestroy(p.second);
+    }
+    s.ev.clear();
+    if (s.open) (void)hipEventDestroy(s.open);
+    s.open = nullptr;
+  }
+  return NHIP_OK;
+}
+
+int nhip_timing_get(int id, double *total_ms, int32_t *launches) {
+  NHIP_REQUIRE(id >= 0 && id < 3, "timing_get: bad id %d", id);
+  std::lock_guard<std::mutex> lk(g_tmu);
+  double tot = 0.0;
+  for (auto &p : g_slots[id].ev) {
+    NHIP_TRY_HIP(hipEventSynchronize(p.second));
+    float ms = 0.f;
+    NHIP_TRY_HIP(hipEventElapsedTime(&ms, p.first, p.second));
+    tot += ms;
+  }
+  if (total_ms) *total_ms = tot;
+  if (launches) *launches = (int32_t)g_slots[id].ev.size();
+  return NHIP_OK;
+}
+
+}  // extern "C"

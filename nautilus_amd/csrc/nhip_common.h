@@ -1,0 +1,89 @@
+// nhip_common.h -- shared internals of libnautilus_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nautilus_hip.h"
+
+namespace nhip {
+
+// ---- error plumbing (thread-local message, int codes across the ABI) ----
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define NHIP_TRY_HIP(expr)                                            \
+  do {                                                                \
+    hipError_t _e = (expr);                                           \
+    if (_e != hipSuccess) return ::nhip::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+#define NHIP_REQUIRE(cond, ...)          \
+  do {                                   \
+    if (!(cond)) {                       \
+      ::nhip::set_error(__VA_ARGS__);    \
+      return NHIP_ERR_ARG;               \
+    }                                    \
+  } while (0)
+
+int require_device();
+
+// ---- grid layout (host) ----
+struct GridLayout {
+  int32_t S, pad, pitch, R;
+  int64_t K;  // tap sum
+  int64_t grid_bytes;
+  double Lf, step;
+};
+int make_layout(const nhip_grid_spec_t *spec, GridLayout *L);
+
+// Device-side constant tables of one grid spec (taps + quantiser thresholds), cached.
+struct GridTables {
+  int32_t taps[129];
+  uint32_t thr[256];
+};
+int make_tables(const nhip_grid_spec_t *spec, const GridLayout &L, GridTables *T);
+
+// ---- in-stream timing ----
+void timer_begin(int id, hipStream_t s);
+void timer_end(int id, hipStream_t s);
+
+// ---- kernel launchers (defined in the .hip files) ----
+int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+                      int32_t n_targets, const nhip_grid_spec_t *spec, const GridLayout &L,
+                      uint8_t *d_grids, void *d_ws, int64_t ws_bytes, hipStream_t s);
+
+int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                     const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
+                     const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
+                     const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
+                     uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s);
+
+int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                      const nhip_grid_spec_t *spec, const GridLayout &L, int32_t src, int32_t slot,
+                      const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
+                      int32_t origin_y, const nhip_search_t *search, int32_t *d_sums,
+                      hipStream_t s);
+
+int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_block, int64_t n_corr,
+                       const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
+                       const double *d_poses, int32_t n_poses, double *d_block_consts,
+                       double *d_res, double *d_jsrc, double *d_jtgt, hipStream_t s);
+
+int launch_resid_point_to_line(const float *d_segments, const float *d_points,
+                               const int32_t *d_point_block, int64_t n_points,
+                               const int32_t *d_block_pose, const int32_t *d_block_line,
+                               int32_t n_blocks, const double *d_poses, const double *d_line_poses,
+                               double *d_res, double *d_jpose, double *d_jline, hipStream_t s);
+
+int launch_resid_odometry(const float *d_t_odom, const float *d_r_odom, const int32_t *d_pose_i,
+                          const int32_t *d_pose_j, int32_t n_factors, double tw, double rw,
+                          const double *d_poses, double *d_res, double *d_ji, double *d_jj,
+                          hipStream_t s);
+
+}  // namespace nhip

@@ -1,0 +1,147 @@
+// nhip_grid.hip -- K1: likelihood-grid construction on gfx950.
+//
+// Replaces the lookup table that CorrelativeScanMatcher rasterises from the target cloud
+// (call site src/optimization/solver.cc:633-638; geometry src/visualization/cimg_debug.h:20-64).
+// Spec: hit raster -> exact integer separable Gaussian blur ->
+// floor, natural log, 8-bit quantisation (by an integer threshold table, so the grid is
+// bit-identical to the CPU formulation).  Stored with a zero border of `pad` cells so the
+// correlation kernel never bounds-checks.
+//
+// HBM-bound byte work: per target, S*S hit bytes written+read and pitch*pitch grid bytes
+// written; almost all 64x64 tiles are empty and exit after the LDS any-hit vote.
+#include "nhip_common.h"
+
+namespace nhip {
+
+namespace {
+
+constexpr int TILE = 64;
+constexpr int MAX_R = 16;
+constexpr int TH_MAX = TILE + 2 * MAX_R;  // 96
+
+struct GridKernelTables {
+  int32_t taps[2 * MAX_R + 1];
+  uint32_t thr[256];
+};
+
+// One block per target scan: mark the cells that contain at least one point.
+__global__ __launch_bounds__(256) void grid_raster_kernel(
+    const float2 *__restrict__ xy, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ target_ids, int32_t t0, uint8_t *__restrict__ H, int32_t S,
+    double res) {
+  const int32_t t = blockIdx.x;
+  const int32_t scan = target_ids[t0 + t];
+  const int32_t beg = offsets[scan], end = offsets[scan + 1];
+  uint8_t *h = H + (size_t)t * S * S;
+  const long half = S / 2;
+  for (int32_t p = beg + threadIdx.x; p < end; p += blockDim.x) {
+    const float2 q = xy[p];
+    if (!(fabsf(q.x) < 1e9f) || !(fabsf(q.y) < 1e9f)) continue;
+    // cimg_debug.h:31-37: side/2 + floor(x / resolution), float promoted to double
+    const long c = half + (long)floor((double)q.x / res);
+    const long r = half + (long)floor((double)q.y / res);
+    if (c < 0 || c >= S || r < 0 || r >= S) continue;  // cimg_debug.h:48-50
+    h[(size_t)r * S + c] = 1;
+  }
+}
+
+// 64x64 output tile per block: H tile (+halo) -> LDS, horizontal pass -> LDS, vertical
+// pass + quantise -> padded grid.  Grid memory is pre-zeroed; empty tiles return early.
+__global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restrict__ H,
+                                                        uint8_t *__restrict__ grids, int32_t S,
+                                                        int32_t pad, int32_t pitch, int32_t R,
+                                                        GridKernelTables tab) {
+  __shared__ uint8_t sH[TH_MAX][TH_MAX + 4];
+  __shared__ uint32_t sV[TH_MAX][TILE + 1];
+  __shared__ uint32_t sThr[256];
+  const int32_t t = blockIdx.z;
+  const int32_t r0 = blockIdx.y * TILE, c0 = blockIdx.x * TILE;
+  const uint8_t *h = H + (size_t)t * S * S;
+  uint8_t *g = grids + (size_t)t * pitch * pitch;
+  const int TH = TILE + 2 * R;
+  int any = 0;
+  for (int i = threadIdx.x; i < TH * TH; i += 256) {
+    const int rr = i / TH, cc = i % TH;
+    const int r = r0 + rr - R, c = c0 + cc - R;
+    uint8_t v = 0;
+    if (r >= 0 && r < S && c >= 0 && c < S) v = h[(size_t)r * S + c];
+    sH[rr][cc] = v;
+    any |= v;
+  }
+  sThr[threadIdx.x] = tab.thr[threadIdx.x];
+  if (!__syncthreads_or(any)) return;
+  // horizontal pass: V1[rr][c] = sum_j taps[j] * H[rr][c + j]
+  for (int i = threadIdx.x; i < TH * TILE; i += 256) {
+    const int rr = i / TILE, c = i % TILE;
+    uint32_t a = 0;
+    for (int j = 0; j <= 2 * R; j++) a += (uint32_t)tab.taps[j] * sH[rr][c + j];
+    sV[rr][c] = a;
+  }
+  __syncthreads();
+  // vertical pass + quantise; each thread produces 4 consecutive columns of one row
+  for (int i = threadIdx.x; i < TILE * (TILE / 4); i += 256) {
+    const int r = i / (TILE / 4), c4 = (i % (TILE / 4)) * 4;
+    if (r0 + r >= S) continue;
+    uint32_t packed = 0;
+    for (int b = 0; b < 4; b++) {
+      uint32_t a = 0;
+      for (int k = 0; k <= 2 * R; k++) a += (uint32_t)tab.taps[k] * sV[r + k][c4 + b];
+      uint32_t q = 0;
+      if (a) {
+        // q = #{k in 1..255 : thr[k] <= a}; thr is non-decreasing
+        for (int step = 128; step >= 1; step >>= 1) {
+          const uint32_t n = q + step;
+          if (n <= 255 && sThr[n] <= a) q = n;
+        }
+      }
+      packed |= q << (8 * b);
+    }
+    uint8_t *dst = g + (size_t)(r0 + r + pad) * pitch + (c0 + c4 + pad);
+    if (c0 + c4 + 3 < S) {
+      *reinterpret_cast<uint32_t *>(dst) = packed;  // pad, c0, c4 are multiples of 4
+    } else {
+      for (int b = 0; b < 4; b++)
+        if (c0 + c4 + b < S) dst[b] = (uint8_t)(packed >> (8 * b));
+    }
+  }
+}
+
+}  // namespace
+
+int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+                      int32_t n_targets, const nhip_grid_spec_t *spec, const GridLayout &L,
+                      uint8_t *d_grids, void *d_ws, int64_t ws_bytes, hipStream_t s) {
+  NHIP_REQUIRE(L.R <= MAX_R, "grid_build: blur radius %d > %d (sigma too large)", L.R, MAX_R);
+  NHIP_REQUIRE(L.K * L.K < (1ll << 32), "grid_build: tap sum overflows 32-bit accumulation");
+  NHIP_REQUIRE(L.pitch % 4 == 0, "grid_build: pitch must be a multiple of 4");
+  const int64_t per = (int64_t)L.S * L.S;
+  const int64_t chunk = ws_bytes / per;
+  NHIP_REQUIRE(chunk >= 1, "grid_build: workspace %lld B < one hit raster (%lld B)",
+               (long long)ws_bytes, (long long)per);
+  GridTables T;
+  int rc = make_tables(spec, L, &T);
+  if (rc) return rc;
+  GridKernelTables kt;
+  memset(&kt, 0, sizeof(kt));
+  for (int i = 0; i <= 2 * L.R; i++) kt.taps[i] = T.taps[i];
+  for (int i = 0; i < 256; i++) kt.thr[i] = T.thr[i];
+  const int tiles = (L.S + TILE - 1) / TILE;
+  for (int64_t t0 = 0; t0 < n_targets; t0 += chunk) {
+    const int32_t n = (int32_t)((n_targets - t0 < chunk) ? (n_targets - t0) : chunk);
+    uint8_t *H = static_cast<uint8_t *>(d_ws);
+    uint8_t *g = d_grids + (size_t)t0 * L.grid_bytes;
+    NHIP_TRY_HIP(hipMemsetAsync(H, 0, (size_t)n * per, s));
+    NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.grid_bytes, s));
+    hipLaunchKernelGGL(grid_raster_kernel, dim3(n), dim3(256), 0, s,
+                       reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
+                       (int32_t)t0, H, L.S, spec->res);
+    timer_begin(NHIP_TIMER_GRID, s);
+    hipLaunchKernelGGL(grid_blur_kernel, dim3(tiles, tiles, n), dim3(256), 0, s, H, g, L.S, L.pad,
+                       L.pitch, L.R, kt);
+    timer_end(NHIP_TIMER_GRID, s);
+  }
+  NHIP_TRY_HIP(hipGetLastError());
+  return NHIP_OK;
+}
+
+}  // namespace nhip

@@ -1,0 +1,332 @@
+/*
+ * oracle/csm_oracle.c -- CPU restatement of the loop-closure correlative scan matcher.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this.  The product path (nautilus_amd/, include/)
+ * never links, imports or calls anything in oracle/.
+ *
+ * PARITY UNPINNED: the matcher's arithmetic lives in the un-vendored submodule
+ * third_party/csm (ut-amrl/correlative-scan-matching, pinned commit unknown,
+ * /root/reference/.gitmodules:4-6); the directory is empty and no reference test
+ * touches it.  What IS in the reference tree and what this file follows:
+ *   - call contract      src/optimization/solver.cc:630-649 (ctor (30,2,0.3,0.01),
+ *                        GetTransformation(pc_a, pc_b, rot_a, rot_b, restrict) ->
+ *                        (score, ((tx,ty), theta)); T_AB = Trans(t) * Rot(theta))
+ *   - grid indexing      src/visualization/cimg_debug.h:20-37 (side = floor(2*range/res),
+ *                        col = side/2 + floor(x/res) evaluated in double on a float x)
+ *   - rasterisation      src/visualization/cimg_debug.h:45-64 (hit cells = 1, out-of-grid
+ *                        points dropped)
+ *   - score convention   config/default_config.lua:84-85 (csm_score_threshold = -5.0:
+ *                        scores are mean log-likelihoods <= 0)
+ * Everything else is the build-defined spec of SURVEY.md section 8(a) ("Build-defined
+ * CSM spec"), restated in DESIGN.md section 3: published algorithm = Olson 2009,
+ * "Real-Time Correlative Scan Matching" (8-bit log-likelihood lookup table, exhaustive
+ * (x, y, theta) search, first maximum wins).
+ *
+ * This file is deliberately written with explicit bounds checks on an UNPADDED grid and
+ * a direct libm log() quantiser, i.e. a different formulation from the HIP kernels
+ * (padded grid, integer threshold table), so that agreement is evidence.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* built with -ffp-contract=off (oracle/Makefile): products are individually rounded */
+
+typedef struct {
+  double range;     /* scanner range in metres (ctor arg 1, solver.cc:633)            */
+  double res;       /* cell size in metres                                            */
+  double sigma;     /* Gaussian blur sigma, in cells (build-defined, default 2.0)     */
+  double floor_p;   /* likelihood floor before the log (build-defined, 1e-10)         */
+} orc_grid_spec;
+
+typedef struct {
+  int32_t n_theta;     /* number of rotations, odd; k = 0 .. n_theta-1                 */
+  int32_t nx, ny;      /* number of x / y cell shifts, odd; shift = i - (n-1)/2        */
+  double theta_step;   /* radians between consecutive rotations                       */
+} orc_search_spec;
+
+typedef struct {
+  int32_t itheta, ix, iy;   /* argmax indices                                          */
+  int32_t sum;              /* integer sum of 8-bit cells at the argmax                */
+  double score;             /* mean log-likelihood = Lf + step * sum / N              */
+} orc_match;
+
+/* cimg_debug.h:21-22: width = floor((range * 2.0) / resolution) */
+int32_t orc_grid_side(double range, double res) {
+  return (int32_t)floor((range * 2.0) / res);
+}
+
+/* cimg_debug.h:31-37: width / 2 + floor(x / resolution), x float promoted to double.
+ * Returned as a signed cell index (the reference wraps negatives to huge uint64 and
+ * drops them by the `x >= width` test, cimg_debug.h:48-50; signed + range test is the
+ * same predicate). */
+static inline int64_t orc_cell(float v, double res, int32_t S) {
+  return (int64_t)(S / 2) + (int64_t)floor((double)v / res);
+}
+
+int32_t orc_blur_radius(double sigma) { return (int32_t)ceil(3.0 * sigma); }
+
+/* Integer Gaussian taps k[i], i = -R..R: round(16384 * g_i / sum g).  Returns sum k. */
+int64_t orc_blur_taps(double sigma, int32_t R, int32_t *taps /* 2R+1 */) {
+  double g[2 * 64 + 1];
+  double tot = 0.0;
+  for (int i = -R; i <= R; i++) {
+    g[i + R] = exp(-((double)i * (double)i) / (2.0 * sigma * sigma));
+    tot += g[i + R];
+  }
+  int64_t K = 0;
+  for (int i = 0; i <= 2 * R; i++) {
+    taps[i] = (int32_t)floor(16384.0 * g[i] / tot + 0.5);
+    K += taps[i];
+  }
+  return K;
+}
+
+/* 8-bit quantiser of the log-likelihood: q = round((ln(max(v, floor_p)) - Lf) / step),
+ * Lf = ln(floor_p), step = -Lf / 255, so q = 0 is the floor and q = 255 is v = 1. */
+static inline uint8_t orc_quantise(uint64_t V, int64_t K, double floor_p) {
+  double v = (double)V / ((double)K * (double)K);
+  if (v < floor_p) v = floor_p;
+  double Lf = log(floor_p);
+  double step = -Lf / 255.0;
+  double q = floor((log(v) - Lf) / step + 0.5);
+  if (q < 0.0) q = 0.0;
+  if (q > 255.0) q = 255.0;
+  return (uint8_t)q;
+}
+
+double orc_score_floor(const orc_grid_spec *gs) { return log(gs->floor_p); }
+double orc_score_step(const orc_grid_spec *gs) { return -log(gs->floor_p) / 255.0; }
+
+/*
+ * Likelihood grid of one target scan (K1).  out is S*S bytes, row-major [row(y)][col(x)].
+ * 1. hit raster H (cimg_debug.h:57-64), 2. separable integer Gaussian blur (exact),
+ * 3. clamp, natural log, 8-bit quantisation.
+ */
+int orc_grid_build(const float *xy, int32_t n_points, const orc_grid_spec *gs, uint8_t *out) {
+  const int32_t S = orc_grid_side(gs->range, gs->res);
+  const int32_t R = orc_blur_radius(gs->sigma);
+  if (S <= 0 || R < 0 || R > 64) return -1;
+  int32_t taps[2 * 64 + 1];
+  const int64_t K = orc_blur_taps(gs->sigma, R, taps);
+  uint8_t *H = (uint8_t *)calloc((size_t)S * S, 1);
+  uint32_t *V1 = (uint32_t *)calloc((size_t)S * S, sizeof(uint32_t));
+  if (!H || !V1) { free(H); free(V1); return -2; }
+  for (int32_t p = 0; p < n_points; p++) {
+    int64_t c = orc_cell(xy[2 * p + 0], gs->res, S);
+    int64_t r = orc_cell(xy[2 * p + 1], gs->res, S);
+    if (c < 0 || c >= S || r < 0 || r >= S) continue; /* cimg_debug.h:48-50 */
+    H[(size_t)r * S + c] = 1;
+  }
+  /* horizontal pass */
+  for (int32_t r = 0; r < S; r++) {
+    for (int32_t c = 0; c < S; c++) {
+      uint32_t a = 0;
+      for (int j = -R; j <= R; j++) {
+        int32_t cc = c + j;
+        if (cc < 0 || cc >= S) continue;
+        a += (uint32_t)taps[j + R] * H[(size_t)r * S + cc];
+      }
+      V1[(size_t)r * S + c] = a;
+    }
+  }
+  /* vertical pass + quantise */
+  for (int32_t r = 0; r < S; r++) {
+    for (int32_t c = 0; c < S; c++) {
+      uint64_t a = 0;
+      for (int i = -R; i <= R; i++) {
+        int32_t rr = r + i;
+        if (rr < 0 || rr >= S) continue;
+        a += (uint64_t)taps[i + R] * V1[(size_t)rr * S + c];
+      }
+      out[(size_t)r * S + c] = orc_quantise(a, K, gs->floor_p);
+    }
+  }
+  free(H);
+  free(V1);
+  return 0;
+}
+
+/* Rotation k of the search lattice.  theta_k = theta0 + (k - (n-1)/2) * step is applied
+ * as R(theta0) * R(d_k): the composition is done in double with individually rounded
+ * products (no FMA), then rounded to float; the point is rotated in float, again with
+ * individually rounded products (Eigen Affine2f * Vector2f on baseline x86-64). */
+static inline void orc_rotation(double theta0, const orc_search_spec *ss, int32_t k, float *cf,
+                                float *sf) {
+  const double c0 = cos(theta0), s0 = sin(theta0);
+  const double d = (double)(k - (ss->n_theta - 1) / 2) * ss->theta_step;
+  const double cd = cos(d), sd = sin(d);
+  const double a = c0 * cd, b = s0 * sd, e = s0 * cd, f = c0 * sd;
+  *cf = (float)(a - b);
+  *sf = (float)(e + f);
+}
+
+/*
+ * Exhaustive (theta, x, y) correlation of one source scan against one target grid (K2+K3).
+ * grid is the S*S table of orc_grid_build.  Out-of-grid lookups contribute the floor (0).
+ * Argmax: maximise the integer sum; ties -> smallest linear index (k*nx + ix)*ny + iy.
+ */
+int orc_csm_match(const float *src_xy, int32_t n_points, const uint8_t *grid,
+                  const orc_grid_spec *gs, double theta0, int32_t origin_x, int32_t origin_y,
+                  const orc_search_spec *ss, orc_match *out) {
+  const int32_t S = orc_grid_side(gs->range, gs->res);
+  const int32_t nx = ss->nx, ny = ss->ny, hx = (nx - 1) / 2, hy = (ny - 1) / 2;
+  if (ss->n_theta < 1 || nx < 1 || ny < 1 || !(nx & 1) || !(ny & 1) || !(ss->n_theta & 1))
+    return -1;
+  int32_t *acc = (int32_t *)malloc(sizeof(int32_t) * (size_t)nx * ny);
+  int64_t *cols = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_points > 0 ? n_points : 1));
+  int64_t *rows = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n_points > 0 ? n_points : 1));
+  if (!acc || !cols || !rows) { free(acc); free(cols); free(rows); return -2; }
+  int64_t best_sum = -1;
+  int32_t bk = 0, bx = 0, by = 0;
+  for (int32_t k = 0; k < ss->n_theta; k++) {
+    float cf, sf;
+    orc_rotation(theta0, ss, k, &cf, &sf);
+    for (int32_t p = 0; p < n_points; p++) {
+      const float x = src_xy[2 * p], y = src_xy[2 * p + 1];
+      const float ax = cf * x, bx_ = sf * y, ay = sf * x, by_ = cf * y;
+      const float xr = ax - bx_;
+      const float yr = ay + by_;
+      cols[p] = orc_cell(xr, gs->res, S) + origin_x;
+      rows[p] = orc_cell(yr, gs->res, S) + origin_y;
+    }
+    memset(acc, 0, sizeof(int32_t) * (size_t)nx * ny);
+    for (int32_t p = 0; p < n_points; p++) {
+      const int64_t c0 = cols[p] - hx, r0 = rows[p] - hy;
+      if (c0 + nx <= 0 || c0 >= S || r0 + ny <= 0 || r0 >= S) continue;
+      const int32_t ix_lo = c0 < 0 ? (int32_t)(-c0) : 0;
+      const int32_t ix_hi = c0 + nx > S ? (int32_t)(S - c0) : nx;
+      for (int32_t iy = 0; iy < ny; iy++) {
+        const int64_t r = r0 + iy;
+        if (r < 0 || r >= S) continue;
+        const uint8_t *g = grid + (size_t)r * S + c0;
+        int32_t *a = acc + (size_t)iy * nx;
+        for (int32_t ix = ix_lo; ix < ix_hi; ix++) a[ix] += g[ix];
+      }
+    }
+    for (int32_t ix = 0; ix < nx; ix++)
+      for (int32_t iy = 0; iy < ny; iy++) {
+        const int64_t s = acc[(size_t)iy * nx + ix];
+        if (s > best_sum) { best_sum = s; bk = k; bx = ix; by = iy; }
+      }
+  }
+  out->itheta = bk;
+  out->ix = bx;
+  out->iy = by;
+  out->sum = (int32_t)best_sum;
+  {
+    const double Lf = log(gs->floor_p);
+    const double step = -Lf / 255.0;
+    if (n_points > 0) {
+      const double t = step * (double)best_sum;
+      const double u = t / (double)n_points;
+      out->score = Lf + u;
+    } else {
+      out->score = Lf;
+    }
+  }
+  free(acc); free(cols); free(rows);
+  return 0;
+}
+
+/* Full score volume of one pair (for tests that check more than the argmax):
+ * sums[(k*nx + ix)*ny + iy]. */
+int orc_csm_scores(const float *src_xy, int32_t n_points, const uint8_t *grid,
+                   const orc_grid_spec *gs, double theta0, int32_t origin_x, int32_t origin_y,
+                   const orc_search_spec *ss, int32_t *sums) {
+  const int32_t S = orc_grid_side(gs->range, gs->res);
+  const int32_t nx = ss->nx, ny = ss->ny, hx = (nx - 1) / 2, hy = (ny - 1) / 2;
+  for (int32_t k = 0; k < ss->n_theta; k++) {
+    float cf, sf;
+    orc_rotation(theta0, ss, k, &cf, &sf);
+    for (int32_t ix = 0; ix < nx; ix++)
+      for (int32_t iy = 0; iy < ny; iy++) {
+        int64_t s = 0;
+        for (int32_t p = 0; p < n_points; p++) {
+          const float x = src_xy[2 * p], y = src_xy[2 * p + 1];
+          const float ax = cf * x, bx_ = sf * y, ay = sf * x, by_ = cf * y;
+          const float xr = ax - bx_;
+          const float yr = ay + by_;
+          const int64_t c = orc_cell(xr, gs->res, S) + origin_x + (ix - hx);
+          const int64_t r = orc_cell(yr, gs->res, S) + origin_y + (iy - hy);
+          if (c < 0 || c >= S || r < 0 || r >= S) continue;
+          s += grid[(size_t)r * S + c];
+        }
+        sums[((size_t)k * nx + ix) * ny + iy] = (int32_t)s;
+      }
+  }
+  return 0;
+}
+
+/*
+ * Batched driver: the same (scan table, target grids, pair list) shape as the product's
+ * C-ABI, used by tests and by bench.py's cpu_baseline leg.  OpenMP over pairs when built
+ * with -fopenmp (the reference builds with -fopenmp -O3, CMakeLists.txt:16).
+ *   xy[offsets[i]..offsets[i+1]) = points of scan i; grids[slot] = S*S bytes.
+ */
+int orc_csm_match_batch(const float *xy, const int32_t *offsets, const uint8_t *grids,
+                        const orc_grid_spec *gs, const int32_t *pair_src,
+                        const int32_t *pair_slot, const double *theta0,
+                        const int32_t *pair_origin, int32_t n_pairs, const orc_search_spec *ss,
+                        orc_match *out, int32_t n_threads) {
+  const int32_t S = orc_grid_side(gs->range, gs->res);
+  int rc = 0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int32_t i = 0; i < n_pairs; i++) {
+    const int32_t s = pair_src[i];
+    const int32_t n = offsets[s + 1] - offsets[s];
+    int r = orc_csm_match(xy + 2 * (size_t)offsets[s], n,
+                          grids + (size_t)pair_slot[i] * S * S, gs, theta0[i],
+                          pair_origin ? pair_origin[2 * i] : 0,
+                          pair_origin ? pair_origin[2 * i + 1] : 0, ss, &out[i]);
+    if (r != 0) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+      rc = r;
+    }
+  }
+  (void)n_threads;
+  return rc;
+}
+
+int orc_grid_build_batch(const float *xy, const int32_t *offsets, const int32_t *target_ids,
+                         int32_t n_targets, const orc_grid_spec *gs, uint8_t *grids,
+                         int32_t n_threads) {
+  const int32_t S = orc_grid_side(gs->range, gs->res);
+  int rc = 0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int32_t t = 0; t < n_targets; t++) {
+    const int32_t s = target_ids[t];
+    int r = orc_grid_build(xy + 2 * (size_t)offsets[s], offsets[s + 1] - offsets[s], gs,
+                           grids + (size_t)t * S * S);
+    if (r != 0) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+      rc = r;
+    }
+  }
+  (void)n_threads;
+  return rc;
+}
+
+int orc_num_threads(void) {
+#ifdef _OPENMP
+  return omp_get_max_threads();
+#else
+  return 1;
+#endif
+}

@@ -1,0 +1,212 @@
+"""ctypes binding of oracle/liboracle.so -- TEST INFRASTRUCTURE ONLY.
+
+Importable from tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg; the product
+package (nautilus_amd/) never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liboracle.so")
+
+
+class GridSpec(C.Structure):
+    _fields_ = [("range", C.c_double), ("res", C.c_double), ("sigma", C.c_double), ("floor_p", C.c_double)]
+
+
+class SearchSpec(C.Structure):
+    _fields_ = [("n_theta", C.c_int32), ("nx", C.c_int32), ("ny", C.c_int32), ("theta_step", C.c_double)]
+
+
+class OMatch(C.Structure):
+    _fields_ = [("itheta", C.c_int32), ("ix", C.c_int32), ("iy", C.c_int32), ("sum", C.c_int32),
+                ("score", C.c_double)]
+
+
+OMATCH_DTYPE = np.dtype([("itheta", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("sum", "<i4"), ("score", "<f8")])
+assert OMATCH_DTYPE.itemsize == C.sizeof(OMatch)
+
+_lib = None
+_vp, _i32, _f64 = C.c_void_p, C.c_int32, C.c_double
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE, "all"])
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        build()
+    lib = C.CDLL(LIB_PATH)
+    lib.orc_grid_side.restype = _i32
+    lib.orc_grid_side.argtypes = [_f64, _f64]
+    lib.orc_score_floor.restype = _f64
+    lib.orc_score_floor.argtypes = [C.POINTER(GridSpec)]
+    lib.orc_score_step.restype = _f64
+    lib.orc_score_step.argtypes = [C.POINTER(GridSpec)]
+    lib.orc_grid_build.argtypes = [_vp, _i32, C.POINTER(GridSpec), _vp]
+    lib.orc_csm_match.argtypes = [_vp, _i32, _vp, C.POINTER(GridSpec), _f64, _i32, _i32,
+                                  C.POINTER(SearchSpec), C.POINTER(OMatch)]
+    lib.orc_csm_scores.argtypes = [_vp, _i32, _vp, C.POINTER(GridSpec), _f64, _i32, _i32,
+                                   C.POINTER(SearchSpec), _vp]
+    lib.orc_csm_match_batch.argtypes = [_vp, _vp, _vp, C.POINTER(GridSpec), _vp, _vp, _vp, _vp, _i32,
+                                        C.POINTER(SearchSpec), _vp, _i32]
+    lib.orc_grid_build_batch.argtypes = [_vp, _vp, _vp, _i32, C.POINTER(GridSpec), _vp, _i32]
+    lib.orc_num_threads.restype = C.c_int
+    lib.orc_dist_to_segment_f.restype = C.c_float
+    lib.orc_dist_to_segment_f.argtypes = [C.c_float] * 6
+    lib.orc_dist_to_segment_d.restype = _f64
+    lib.orc_dist_to_segment_d.argtypes = [_f64] * 6
+    lib.orc_lidar_block.argtypes = [C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    lib.orc_point_to_line_block.argtypes = [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
+    lib.orc_odometry_block.argtypes = [_vp, C.c_float, _f64, _f64, _vp, _vp, _vp, _vp, _vp]
+    lib.orc_lidar_batch.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32]
+    _lib = lib
+    return lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_vp)
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise RuntimeError("oracle %s failed: %d" % (what, rc))
+
+
+def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10):
+    return GridSpec(float(range_m), float(res), float(sigma), float(floor_p))
+
+
+def search_spec(n_theta, nx, ny, theta_step):
+    return SearchSpec(int(n_theta), int(nx), int(ny), float(theta_step))
+
+
+def grid_side(gs):
+    return load().orc_grid_side(gs.range, gs.res)
+
+
+def grid_build(points, gs):
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
+    S = grid_side(gs)
+    out = np.zeros((S, S), dtype=np.uint8)
+    _chk(load().orc_grid_build(_p(pts), len(pts), C.byref(gs), _p(out)), "grid_build")
+    return out
+
+
+def csm_match(src_points, grid, gs, theta0, ss, origin=(0, 0)):
+    pts = np.ascontiguousarray(src_points, dtype=np.float32).reshape(-1, 2)
+    g = np.ascontiguousarray(grid, dtype=np.uint8)
+    m = OMatch()
+    _chk(load().orc_csm_match(_p(pts), len(pts), _p(g), C.byref(gs), float(theta0), int(origin[0]),
+                              int(origin[1]), C.byref(ss), C.byref(m)), "csm_match")
+    return m
+
+
+def csm_scores(src_points, grid, gs, theta0, ss, origin=(0, 0)):
+    pts = np.ascontiguousarray(src_points, dtype=np.float32).reshape(-1, 2)
+    g = np.ascontiguousarray(grid, dtype=np.uint8)
+    out = np.zeros((ss.n_theta, ss.nx, ss.ny), dtype=np.int32)
+    _chk(load().orc_csm_scores(_p(pts), len(pts), _p(g), C.byref(gs), float(theta0), int(origin[0]),
+                               int(origin[1]), C.byref(ss), _p(out)), "csm_scores")
+    return out
+
+
+def grid_build_batch(xy, offsets, target_ids, gs, n_threads=0):
+    xy = np.ascontiguousarray(xy, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    target_ids = np.ascontiguousarray(target_ids, dtype=np.int32)
+    S = grid_side(gs)
+    out = np.zeros((len(target_ids), S, S), dtype=np.uint8)
+    _chk(load().orc_grid_build_batch(_p(xy), _p(offsets), _p(target_ids), len(target_ids), C.byref(gs),
+                                     _p(out), n_threads), "grid_build_batch")
+    return out
+
+
+def csm_match_batch(xy, offsets, grids, gs, pair_src, pair_slot, theta0, ss, pair_origin=None, n_threads=0):
+    xy = np.ascontiguousarray(xy, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    grids = np.ascontiguousarray(grids, dtype=np.uint8)
+    pair_src = np.ascontiguousarray(pair_src, dtype=np.int32)
+    pair_slot = np.ascontiguousarray(pair_slot, dtype=np.int32)
+    theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
+    org = None if pair_origin is None else np.ascontiguousarray(pair_origin, dtype=np.int32)
+    out = np.zeros(len(pair_src), dtype=OMATCH_DTYPE)
+    _chk(load().orc_csm_match_batch(_p(xy), _p(offsets), _p(grids), C.byref(gs), _p(pair_src), _p(pair_slot),
+                                    _p(theta0), _p(org), len(pair_src), C.byref(ss), _p(out), n_threads),
+         "csm_match_batch")
+    return out
+
+
+def num_threads():
+    return load().orc_num_threads()
+
+
+def dist_to_segment_f(p, a, b):
+    return float(load().orc_dist_to_segment_f(p[0], p[1], a[0], a[1], b[0], b[1]))
+
+
+def dist_to_segment_d(p, a, b):
+    return float(load().orc_dist_to_segment_d(p[0], p[1], a[0], a[1], b[0], b[1]))
+
+
+def _f32(a):
+    return np.ascontiguousarray(a, dtype=np.float32)
+
+
+def lidar_block(kind, sp, tp, sn, tn, source_pose, target_pose, jac=(True, True)):
+    sp, tp, sn, tn = _f32(sp), _f32(tp), _f32(sn), _f32(tn)
+    n = len(sp)
+    a = np.ascontiguousarray(source_pose, dtype=np.float64)
+    b = np.ascontiguousarray(target_pose, dtype=np.float64)
+    r = np.zeros(2 * n)
+    j0 = np.zeros((2 * n, 3)) if jac[0] else None
+    j1 = np.zeros((2 * n, 3)) if jac[1] else None
+    _chk(load().orc_lidar_block(kind, _p(sp), _p(tp), _p(sn), _p(tn), n, _p(a), _p(b), _p(r), _p(j0), _p(j1)),
+         "lidar_block")
+    return r, j0, j1
+
+
+def point_to_line_block(seg, pts, pose, line_pose, jac=(True, True)):
+    seg, pts = _f32(seg).reshape(4), _f32(pts).reshape(-1, 2)
+    n = len(pts)
+    a = np.ascontiguousarray(pose, dtype=np.float64)
+    b = np.ascontiguousarray(line_pose, dtype=np.float64)
+    r = np.zeros(n)
+    j0 = np.zeros((n, 3)) if jac[0] else None
+    j1 = np.zeros((n, 3)) if jac[1] else None
+    _chk(load().orc_point_to_line_block(_p(seg), _p(pts), n, _p(a), _p(b), _p(r), _p(j0), _p(j1)), "p2l")
+    return r, j0, j1
+
+
+def odometry_block(t_odom, r_odom, tw, rw, pose_i, pose_j, jac=(True, True)):
+    t = _f32(t_odom).reshape(2)
+    a = np.ascontiguousarray(pose_i, dtype=np.float64)
+    b = np.ascontiguousarray(pose_j, dtype=np.float64)
+    r = np.zeros(3)
+    j0 = np.zeros((3, 3)) if jac[0] else None
+    j1 = np.zeros((3, 3)) if jac[1] else None
+    _chk(load().orc_odometry_block(_p(t), float(r_odom), float(tw), float(rw), _p(a), _p(b), _p(r), _p(j0),
+                                   _p(j1)), "odometry")
+    return r, j0, j1
+
+
+def lidar_batch(kind, corr, block_offsets, block_src, block_tgt, poses, want_jac=True, n_threads=0):
+    corr = _f32(corr).reshape(-1, 8)
+    bo = np.ascontiguousarray(block_offsets, dtype=np.int32)
+    bs = np.ascontiguousarray(block_src, dtype=np.int32)
+    bt = np.ascontiguousarray(block_tgt, dtype=np.int32)
+    poses = np.ascontiguousarray(poses, dtype=np.float64)
+    n = len(corr)
+    r = np.zeros(2 * n)
+    j0 = np.zeros((2 * n, 3)) if want_jac else None
+    j1 = np.zeros((2 * n, 3)) if want_jac else None
+    _chk(load().orc_lidar_batch(kind, _p(corr), _p(bo), _p(bs), _p(bt), len(bs), _p(poses), _p(r), _p(j0),
+                                _p(j1), n_threads), "lidar_batch")
+    return r, j0, j1

@@ -1,0 +1,128 @@
+"""CPU-side checks of the C-ABI boundary: the library loads, exports every symbol the header
+declares, its pure-host helpers agree with the oracle's formulas, and compute entry points
+fail loudly (NHIP_ERR_NODEV) instead of falling back when no GPU is present."""
+import ctypes as C
+import math
+import os
+import re
+
+import numpy as np
+import pytest
+
+from nautilus_amd import _lib, csm
+from oracle import oracle as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_symbols():
+    txt = open(os.path.join(ROOT, "include", "nautilus_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(nhip_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = _lib.load()
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), "symbol %s declared in include/nautilus_hip.h is not exported" % s
+    assert sorted(_lib.PROTOTYPES) == syms, "python prototypes and header disagree"
+
+
+def test_struct_sizes_match_header():
+    assert C.sizeof(_lib.Match) == 16
+    assert C.sizeof(_lib.GridSpec) == 40
+    assert C.sizeof(_lib.Search) == 24
+    assert C.sizeof(_lib.GridLayout) == 56
+
+
+def test_grid_layout_follows_cimg_debug():
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40)
+    L = csm.grid_layout(spec)
+    assert L.side == 1200 == O.grid_side(O.grid_spec(30.0, 0.05))  # floor(2*30/0.05), cimg_debug.h:21
+    assert L.pad == 84 and L.pitch == 1368 and L.rows == 1368
+    assert L.blur_radius == 6
+    assert L.grid_bytes == 1368 * 1368
+    assert abs(L.score_floor - math.log(1e-10)) < 1e-15
+    for (r, res, side) in [(30, 0.3, 200), (30, 0.01, 6000), (10, 0.03, 666)]:
+        assert csm.grid_layout(csm.grid_spec(r, res, 2.0, 1e-10, 4)).side == side
+
+
+def test_bad_specs_are_rejected_with_message():
+    lib = _lib.load()
+    out = _lib.GridLayout()
+    for bad in [csm.grid_spec(-1, 0.05), csm.grid_spec(30, 0), csm.grid_spec(30, 0.05, sigma=9.0),
+                csm.grid_spec(30, 0.05, floor_p=2.0)]:
+        assert lib.nhip_grid_layout(C.byref(bad), C.byref(out)) == _lib.NHIP_ERR_ARG
+        assert len(lib.nhip_last_error()) > 0
+
+
+def test_threshold_table_reproduces_direct_quantiser():
+    """thr[k] <= V  <=>  q(V) >= k, against the oracle's direct libm quantiser on a 1-point grid."""
+    spec = csm.grid_spec(1.0, 0.05, 2.0, 1e-10, 2)
+    L = csm.grid_layout(spec)
+    taps = np.zeros(2 * L.blur_radius + 1, dtype=np.int32)
+    thr = np.zeros(256, dtype=np.uint32)
+    _lib.check(_lib.load().nhip_grid_tables(C.byref(spec), _lib.ptr(taps), _lib.ptr(thr)))
+    assert taps.sum() == L.tap_sum and np.all(taps == taps[::-1]) and taps.argmax() == L.blur_radius
+    assert np.all(np.diff(thr.astype(np.int64)) >= 0)
+    # one hit in the middle of a 40x40 grid: V[r][c] = taps[i]*taps[j] exactly
+    g = O.grid_build(np.array([[0.01, 0.01]], dtype=np.float32), O.grid_spec(1.0, 0.05, 2.0, 1e-10))
+    R = L.blur_radius
+    for i in range(-R, R + 1):
+        for j in range(-R, R + 1):
+            V = int(taps[i + R]) * int(taps[j + R])
+            q = int(np.searchsorted(thr[1:], V, side="right"))
+            assert q == g[20 + i, 20 + j], (i, j, V, q, g[20 + i, 20 + j])
+
+
+def test_rot0_and_delta_tables():
+    a = np.array([0.3, 3.0, -3.0, 7.0])
+    b = np.array([0.1, -3.0, 3.0, 0.0])
+    cs = csm.rot0_table(a, b)
+    d = a - b
+    d = d - 2 * math.pi * np.rint(d / (2 * math.pi))  # math_util.h:81-89
+    assert np.array_equal(cs[:, 0], np.cos(d)) and np.array_equal(cs[:, 1], np.sin(d))
+    s = csm.search_spec(61, 81, 81, math.radians(1))
+    t = csm.delta_table(s)
+    assert t.shape == (61, 2) and t[30, 0] == 1.0 and t[30, 1] == 0.0
+    assert t[0, 1] == math.sin(-30 * math.radians(1))
+
+
+def test_score_from_sum_matches_oracle_formula():
+    spec = csm.grid_spec()
+    lib = _lib.load()
+    Lf = math.log(1e-10)
+    step = -Lf / 255.0
+    assert lib.nhip_score_from_sum(C.byref(spec), 231113, 975) == Lf + (step * 231113) / 975
+    assert lib.nhip_score_from_sum(C.byref(spec), 0, 0) == Lf
+
+
+@pytest.mark.skipif(_lib.load() is not None and _lib.device_count() > 0, reason="GPU present")
+def test_compute_fails_loudly_without_gpu():
+    """No CPU fallback: with no device the product refuses to compute."""
+    xy = np.zeros((4, 2), dtype=np.float32)
+    off = np.array([0, 4], dtype=np.int32)
+    h = C.c_void_p()
+    rc = _lib.load().nhip_scans_upload(_lib.ptr(xy), _lib.ptr(off), 1, C.byref(h))
+    assert rc == _lib.NHIP_ERR_NODEV
+    assert b"no HIP device" in _lib.load().nhip_last_error()
+    with pytest.raises(_lib.NhipError):
+        csm.ScanTable(xy, off)
+    spec = csm.grid_spec()
+    rc = _lib.load().nhip_grid_build_dev(None, None, None, 0, C.byref(spec), None, None, 0, None)
+    assert rc == _lib.NHIP_ERR_NODEV
+
+
+def test_product_never_imports_oracle():
+    """The product package must not reference oracle/ (only tests, smoke and bench may)."""
+    bad = re.compile(r"(import\s+oracle|from\s+oracle|from\s+\.+\s*oracle|liboracle|orc_[a-z_]+\s*\(|"
+                     r"#include\s*[\"<][^\">]*oracle)")
+    for sub in ("nautilus_amd", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, sub)):
+            for f in fs:
+                if f.endswith((".py", ".h", ".hip", ".cc", ".cpp", "Makefile")):
+                    txt = open(os.path.join(dp, f)).read()
+                    m = bad.search(txt)
+                    assert m is None, "%s references the oracle: %r" % (os.path.join(dp, f), m.group(0))

@@ -1,0 +1,272 @@
+"""GPU parity of the correlative scan matcher (K1 grid build, K2 correlation, K3 argmax) against
+the CPU oracle, through the C ABI.  Bar: grids, integer sums and best-pose indices bit-exact;
+scores equal as floats (same double expression rounded once)."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from nautilus_amd import _lib, csm, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DEG = math.radians(1.0)
+
+
+def _specs(range_m=30.0, res=0.05, sigma=2.0, max_shift=40):
+    return csm.grid_spec(range_m, res, sigma, 1e-10, max_shift), O.grid_spec(range_m, res, sigma, 1e-10)
+
+
+def _check_pairs(scans_list, target_ids, pair_src, pair_slot, theta0, spec, ospec, search, origin=None):
+    xy, off = csm.pack_scans(scans_list)
+    st = csm.ScanTable(xy, off)
+    grids = csm.LikelihoodGrids(st, target_ids, spec)
+    got, sums = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, search, origin)
+    ogr = O.grid_build_batch(xy, off, target_ids, ospec)
+    oss = O.search_spec(search.n_theta, search.nx, search.ny, search.theta_step)
+    want = O.csm_match_batch(xy, off, ogr, ospec, pair_src, pair_slot, theta0, oss, origin)
+    for f in ("itheta", "ix", "iy"):
+        assert np.array_equal(got[f], want[f]), (f, got[f], want[f])
+    assert np.array_equal(sums, want["sum"])
+    assert np.array_equal(got["score"], want["score"].astype(np.float32))
+    grids.close()
+    st.close()
+    return got, want
+
+
+def test_grid_bit_exact_and_border_zero(gpu, small_bag):
+    spec, ospec = _specs()
+    st = csm.ScanTable.from_list(small_bag.scans)
+    ids = [0, 7, 23, 47]
+    grids = csm.LikelihoodGrids(st, ids, spec)
+    L = grids.layout
+    for slot, sid in enumerate(ids):
+        stored = grids.download(slot)
+        want = O.grid_build(small_bag.scans[sid], ospec)
+        inner = stored[L.pad:L.pad + L.side, L.pad:L.pad + L.side]
+        assert np.array_equal(inner, want)
+        assert want.max() > 200 and (want > 0).sum() > 1000
+        border = stored.copy()
+        border[L.pad:L.pad + L.side, L.pad:L.pad + L.side] = 0
+        assert not border.any(), "zero border violated"
+    grids.close()
+    st.close()
+
+
+@pytest.mark.parametrize("range_m,res,sigma,max_shift", [(30.0, 0.3, 2.0, 6), (10.0, 0.03, 1.0, 10),
+                                                         (30.0, 0.05, 0.7, 8), (4.0, 0.05, 5.0, 3)])
+def test_grid_other_geometries(gpu, small_bag, range_m, res, sigma, max_shift):
+    """side not a multiple of 4/64 (666), points outside the grid dropped (cimg_debug.h:48-50)."""
+    spec, ospec = _specs(range_m, res, sigma, max_shift)
+    st = csm.ScanTable.from_list(small_bag.scans[:6])
+    grids = csm.LikelihoodGrids(st, [1, 4], spec)
+    for slot, sid in enumerate([1, 4]):
+        assert np.array_equal(grids.interior(slot), O.grid_build(small_bag.scans[sid], ospec))
+    grids.close()
+    st.close()
+
+
+def test_match_small_lattice(gpu, small_bag):
+    spec, ospec = _specs(max_shift=10)
+    src, tgt, th0 = small_bag.sample_pairs(per_target=3, targets=[5, 20, 40], min_sep=2)
+    ids = np.unique(tgt)
+    slot = np.searchsorted(ids, tgt)
+    _check_pairs(small_bag.scans, ids, src, slot, th0, spec, ospec, csm.search_spec(7, 21, 21, 2 * DEG))
+
+
+def test_match_full_lattice_recovers_ground_truth(gpu):
+    """BASELINE config #2 lattice (61 x 81 x 81, 1 deg / 5 cm) on a handful of pairs."""
+    bag = synth.SynthBag(120)
+    spec, ospec = _specs()
+    src, tgt, th0 = bag.sample_pairs(per_target=2, targets=[10, 60, 110], max_dist=1.5, min_sep=3)
+    ids = np.unique(tgt)
+    slot = np.searchsorted(ids, tgt)
+    search = csm.search_spec(61, 81, 81, DEG)
+    got, _ = _check_pairs(bag.scans, ids, src, slot, th0, spec, ospec, search)
+    for m, s, t, t0 in zip(got, src, tgt, th0):
+        tx, ty, th = csm.match_to_transform(m, spec, search, t0)
+        gx, gy, gth = bag.true_relative(s, t)
+        assert abs(tx - gx) <= 0.11 and abs(ty - gy) <= 0.11, (tx, ty, gx, gy)
+        assert abs(th - gth) <= math.radians(1.6)
+        assert m["score"] > -5.0  # csm_score_threshold (default_config.lua:85)
+
+
+def test_score_volume_bit_exact(gpu, small_bag):
+    """Every one of the n_theta*nx*ny sums, not just the argmax; non-square plane."""
+    spec, ospec = _specs(max_shift=12)
+    st = csm.ScanTable.from_list(small_bag.scans)
+    grids = csm.LikelihoodGrids(st, [12], spec)
+    search = csm.search_spec(5, 25, 9, 3 * DEG)
+    got = csm.score_volume(st, grids, 14, 0, 0.03, search)
+    want = O.csm_scores(small_bag.scans[14], O.grid_build(small_bag.scans[12], ospec), ospec, 0.03,
+                        O.search_spec(5, 25, 9, 3 * DEG))
+    assert np.array_equal(got, want)
+    assert got.max() > 0
+    grids.close()
+    st.close()
+
+
+def test_wide_plane_uses_several_plane_blocks(gpu, small_bag):
+    """nx > 84 and ny > 85: more than one plane block per rotation."""
+    spec, ospec = _specs(30.0, 0.05, 2.0, 60)
+    src, tgt, th0 = small_bag.sample_pairs(per_target=2, targets=[9], min_sep=2)
+    _check_pairs(small_bag.scans, [9], src, [0, 0], th0, spec, ospec, csm.search_spec(3, 101, 121, 2 * DEG))
+
+
+def test_ragged_empty_and_out_of_grid(gpu, small_bag):
+    """Empty source scan, empty target, 1-point scans, points far outside the grid."""
+    far = np.array([[500.0, -700.0], [29.99, 29.99], [-30.0, -30.0], [30.0, 30.0]], dtype=np.float32)
+    scans = [np.zeros((0, 2), np.float32), small_bag.scans[3], np.array([[1.0, 2.0]], np.float32), far,
+             small_bag.scans[4][:65], small_bag.scans[5][:64], small_bag.scans[6][:63]]
+    spec, ospec = _specs(max_shift=8)
+    pair_src = [0, 1, 2, 3, 4, 5, 6, 1, 3]
+    pair_slot = [1, 0, 1, 1, 1, 1, 1, 2, 3]  # targets: [0 (empty), 1, 2 (one point), 3 (far)]
+    th0 = np.linspace(-0.2, 0.2, len(pair_src))
+    got, want = _check_pairs(scans, [0, 1, 2, 3], pair_src, pair_slot, th0, spec, ospec,
+                             csm.search_spec(5, 17, 17, 2 * DEG))
+    assert got[0]["itheta"] == 0 and got[0]["ix"] == 0 and got[0]["iy"] == 0  # empty scan: first index
+    assert got[0]["score"] == np.float32(math.log(1e-10))
+
+
+def test_rotation_wraparound(gpu, small_bag):
+    """theta0 near +-pi, where AngleMod (math_util.h:81-84) wraps."""
+    spec, ospec = _specs(max_shift=6)
+    rot = []
+    for a in (math.pi - 1e-3, -math.pi + 1e-3, 3.0, -3.1):
+        c, s = math.cos(a), math.sin(a)
+        p = small_bag.scans[8]
+        rot.append(np.stack([c * p[:, 0] - s * p[:, 1], s * p[:, 0] + c * p[:, 1]], 1).astype(np.float32))
+    scans = [small_bag.scans[8]] + rot
+    th0 = [-(math.pi - 1e-3), -(-math.pi + 1e-3), -3.0, 3.1]
+    got, _ = _check_pairs(scans, [0], [1, 2, 3, 4], [0, 0, 0, 0], th0, spec, ospec,
+                          csm.search_spec(5, 13, 13, DEG))
+    assert np.all(np.abs(got["itheta"] - 2) <= 1)  # the rotated copies realign at the lattice centre
+
+
+def test_search_origin(gpu, small_bag):
+    spec, ospec = _specs(max_shift=30)
+    src, tgt, th0 = small_bag.sample_pairs(per_target=3, targets=[30], min_sep=2)
+    origin = np.array([[5, -7], [-20, 20], [0, 11]], dtype=np.int32)
+    _check_pairs(small_bag.scans, [30], src, [0, 0, 0], th0, spec, ospec, csm.search_spec(3, 21, 19, DEG), origin)
+    st = csm.ScanTable.from_list(small_bag.scans)
+    grids = csm.LikelihoodGrids(st, [30], spec)
+    with pytest.raises(_lib.NhipError):  # centre + half-width beyond the stored border
+        csm.match_pairs(st, grids, [1], [0], [0.0], csm.search_spec(3, 21, 19, DEG), [[25, 0]])
+
+
+def test_argument_errors(gpu, small_bag):
+    spec, _ = _specs(max_shift=4)
+    st = csm.ScanTable.from_list(small_bag.scans[:4])
+    grids = csm.LikelihoodGrids(st, [0, 1], spec)
+    ok = csm.search_spec(3, 9, 9, DEG)
+    for bad in [csm.search_spec(4, 9, 9, DEG), csm.search_spec(3, 8, 9, DEG), csm.search_spec(3, 11, 9, DEG)]:
+        with pytest.raises(_lib.NhipError):
+            csm.match_pairs(st, grids, [0], [0], [0.0], bad)
+    with pytest.raises(_lib.NhipError):
+        csm.match_pairs(st, grids, [9], [0], [0.0], ok)  # source out of range
+    with pytest.raises(_lib.NhipError):
+        csm.match_pairs(st, grids, [0], [2], [0.0], ok)  # grid slot out of range
+    with pytest.raises(_lib.NhipError):
+        csm.LikelihoodGrids(st, [7], spec)
+
+
+def test_deterministic_bytes(gpu, small_bag):
+    spec, _ = _specs(max_shift=10)
+    st = csm.ScanTable.from_list(small_bag.scans)
+    grids = csm.LikelihoodGrids(st, [3, 9], spec)
+    src, slot, th0 = [1, 2, 5, 7] * 8, [0, 1, 1, 0] * 8, np.linspace(-0.3, 0.3, 32)
+    s = csm.search_spec(9, 21, 21, DEG)
+    a, sa = csm.match_pairs(st, grids, src, slot, th0, s)
+    b, sb = csm.match_pairs(st, grids, src, slot, th0, s)
+    assert a.tobytes() == b.tobytes() and sa.tobytes() == sb.tobytes()
+
+
+def test_full_size_properties(gpu):
+    """BASELINE config #2 sizes (1081-beam scans, 1200^2 grid, 61x81x81 lattice) checked through
+    size-independent properties, on more pairs than the oracle is asked to redo:
+      (a) self-match: a scan against its own grid peaks at the lattice centre with the scan's own
+          grid sum; (b) integer cell shift equivariance: searching with centre (cx, cy) equals the
+          zero-centre volume shifted; (c) a batch equals the concatenation of its halves."""
+    bag = synth.SynthBag(64, dense=True)
+    assert all(len(s) == synth.N_BEAMS for s in bag.scans)
+    spec, ospec = _specs()
+    st = csm.ScanTable.from_list(bag.scans)
+    ids = np.arange(0, 64, 4)
+    grids = csm.LikelihoodGrids(st, ids, spec)
+    search = csm.search_spec(61, 81, 81, DEG)
+    # (a)
+    got, sums = csm.match_pairs(st, grids, ids, np.arange(len(ids)), np.zeros(len(ids)), search)
+    assert np.all(got["itheta"] == 30) and np.all(got["ix"] == 40) and np.all(got["iy"] == 40)
+    for slot, sid in enumerate(ids[:3]):
+        g = grids.interior(slot)
+        p = bag.scans[sid].astype(np.float64)
+        c = 600 + np.floor(p[:, 0] / 0.05).astype(int)
+        r = 600 + np.floor(p[:, 1] / 0.05).astype(int)
+        assert sums[slot] == int(g[r, c].astype(np.int64).sum())
+    # (b)
+    s_small = csm.search_spec(3, 21, 21, DEG)
+    v0 = csm.score_volume(st, grids, 5, 1, 0.02, csm.search_spec(3, 41, 41, DEG))
+    v1 = csm.score_volume(st, grids, 5, 1, 0.02, s_small, origin=(7, -9))
+    assert np.array_equal(v1, v0[:, 10 + 7:31 + 7, 10 - 9:31 - 9])
+    # (c)
+    src, tgt, th0 = bag.sample_pairs(per_target=4, targets=ids, max_dist=2.0, min_sep=1)
+    slot = np.searchsorted(ids, tgt)
+    whole, ws = csm.match_pairs(st, grids, src, slot, th0, search)
+    h = len(src) // 2
+    a, sa = csm.match_pairs(st, grids, src[:h], slot[:h], th0[:h], search)
+    b, sb = csm.match_pairs(st, grids, src[h:], slot[h:], th0[h:], search)
+    assert whole.tobytes() == np.concatenate([a, b]).tobytes()
+    # and a sample of the batch against the oracle
+    pick = np.arange(0, len(src), 13)
+    ogr = O.grid_build_batch(st.xy, st.offsets, ids, ospec)
+    want = O.csm_match_batch(st.xy, st.offsets, ogr, ospec, src[pick], slot[pick], th0[pick],
+                             O.search_spec(61, 81, 81, DEG))
+    for f in ("itheta", "ix", "iy"):
+        assert np.array_equal(whole[f][pick], want[f])
+    assert np.array_equal(ws[pick], want["sum"])
+    grids.close()
+    st.close()
+
+
+def test_device_pointer_api_on_torch_stream(gpu, small_bag):
+    """The *_dev entry points: caller-owned HBM (torch tensors), launched on torch's stream."""
+    import torch
+    dev = torch.device("cuda:0")
+    spec, ospec = _specs(max_shift=10)
+    L = csm.grid_layout(spec)
+    xy, off = csm.pack_scans(small_bag.scans)
+    ids = np.array([2, 11], dtype=np.int32)
+    src = np.array([3, 4, 12, 13], dtype=np.int32)
+    slot = np.array([0, 0, 1, 1], dtype=np.int32)
+    th0 = np.array([0.01, -0.02, 0.03, 0.0])
+    search = csm.search_spec(9, 21, 21, DEG)
+    lib = _lib.load()
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_xy, d_off, d_ids, d_src, d_slot = t(xy), t(off), t(ids), t(src), t(slot)
+    d_rot0, d_delta = t(csm.rot0_table(th0)), t(csm.delta_table(search))
+    d_grids = torch.empty(lib.nhip_grids_bytes(C.byref(spec), 2), dtype=torch.uint8, device=dev)
+    ws_bytes = lib.nhip_grid_workspace_bytes(C.byref(spec), 2)
+    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    d_keys = torch.empty(4, dtype=torch.int64, device=dev)
+    d_out = torch.empty(4 * 4, dtype=torch.int32, device=dev)
+    d_sums = torch.empty(4, dtype=torch.int32, device=dev)
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        sp = C.c_void_p(stream.cuda_stream)
+        _lib.check(lib.nhip_grid_build_dev(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), 2, C.byref(spec),
+                                           d_grids.data_ptr(), d_ws.data_ptr(), ws_bytes, sp))
+        _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), d_grids.data_ptr(), C.byref(spec),
+                                          d_src.data_ptr(), d_slot.data_ptr(), d_rot0.data_ptr(),
+                                          d_delta.data_ptr(), None, 4, C.byref(search), d_keys.data_ptr(),
+                                          d_out.data_ptr(), d_sums.data_ptr(), sp))
+    stream.synchronize()
+    got = d_out.cpu().numpy().view(csm.MATCH_DTYPE)
+    ogr = O.grid_build_batch(xy, off, ids, ospec)
+    want = O.csm_match_batch(xy, off, ogr, ospec, src, slot, th0, O.search_spec(9, 21, 21, DEG))
+    for f in ("itheta", "ix", "iy"):
+        assert np.array_equal(got[f], want[f])
+    assert np.array_equal(d_sums.cpu().numpy(), want["sum"])
+    g = d_grids[:2 * L.grid_bytes].cpu().numpy().reshape(2, L.rows, L.pitch)
+    assert np.array_equal(g[1, L.pad:L.pad + L.side, L.pad:L.pad + L.side], ogr[1])

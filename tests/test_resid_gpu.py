@@ -1,0 +1,181 @@
+"""GPU parity of the batched Ceres-functor evaluation (K4) against the CPU oracle (which
+differentiates the restated functors with Jet<6> duals exactly as ceres::AutoDiffCostFunction
+does).  Tolerance: 1e-9 relative to the block scale -- far inside BASELINE's 1e-5 -- because the
+GPU uses closed-form Jacobians and a different sin/cos implementation."""
+import ctypes as C
+import math
+
+import numpy as np
+import pytest
+
+from nautilus_amd import _lib, residuals as R, synth
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-9
+
+
+def close(a, b, scale=1.0):
+    a, b = np.asarray(a), np.asarray(b)
+    assert a.shape == b.shape
+    err = np.max(np.abs(a - b)) if a.size else 0.0
+    assert err <= RTOL * max(scale, float(np.max(np.abs(b))) if b.size else 1.0), err
+
+
+def oracle_eval(kind, blocks, src, tgt, poses):
+    r, j0, j1 = [], [], []
+    for c, s, t in zip(blocks, src, tgt):
+        a, b, d = O.lidar_block(kind, c[:, 0:2], c[:, 2:4], c[:, 4:6], c[:, 6:8], poses[s], poses[t])
+        r.append(a), j0.append(b), j1.append(d)
+    return np.concatenate(r), np.concatenate(j0), np.concatenate(j1)
+
+
+@pytest.mark.parametrize("kind", [_lib.NHIP_LIDAR_NORMAL, _lib.NHIP_LIDAR_POINT])
+def test_lidar_blocks_match_autodiff_oracle(gpu, small_bag, kind):
+    rng = np.random.default_rng(7)
+    poses = small_bag.odom + rng.normal(0, [0.01, 0.01, math.radians(0.2)], small_bag.odom.shape)
+    blocks, src, tgt = [], [], []
+    for i in range(4, 40, 3):
+        for j in (i - 1, i - 4):
+            c = small_bag.correspondences(i, j, poses)
+            if len(c):
+                blocks.append(c), src.append(i), tgt.append(j)
+    blocks.append(blocks[0][:1]), src.append(src[0]), tgt.append(tgt[0])      # N = 1
+    blocks.append(blocks[1][:257]), src.append(src[1]), tgt.append(tgt[1])    # crosses a 256-lane tile
+    assert sum(len(b) for b in blocks) > 5000
+    batch = R.LidarResidualBatch(kind, blocks, src, tgt, len(poses))
+    res, js, jt = batch.evaluate(poses)
+    wr, wj0, wj1 = oracle_eval(kind, blocks, src, tgt, poses)
+    close(res, wr)
+    close(js, wj0, 30.0)
+    close(jt, wj1, 30.0)
+    # residual-only and single-Jacobian requests (NULL jacobian pointers, solver.cc:384-386)
+    r2, a2, b2 = batch.evaluate(poses, False, False)
+    assert a2 is None and b2 is None and np.array_equal(r2, res)
+    r3, a3, b3 = batch.evaluate(poses, False, True)
+    assert a3 is None and np.array_equal(b3, jt) and np.array_equal(r3, res)
+    r4, a4, b4 = batch.evaluate(poses, True, False)
+    assert b4 is None and np.array_equal(a4, js)
+    # batched oracle driver agrees with the per-block one (used by bench's cpu_baseline)
+    br, bj0, bj1 = O.lidar_batch(kind, batch.corr, batch.block_offsets, batch.block_src, batch.block_tgt, poses)
+    assert np.array_equal(br, wr) and np.array_equal(bj0, wj0) and np.array_equal(bj1, wj1)
+    batch.close()
+
+
+def test_lidar_angles_near_pi_and_large_translation(gpu):
+    rng = np.random.default_rng(3)
+    n = 300
+    c = rng.normal(0, 5, (n, 8)).astype(np.float32)
+    poses = np.array([[100.0, -250.0, math.pi - 1e-9], [-80.0, 40.0, -math.pi + 1e-9], [0, 0, 0],
+                      [1e-3, -1e-3, 12.5]])
+    blocks = [c[:100], c[100:200], c[200:]]
+    src, tgt = [0, 1, 3], [1, 2, 0]
+    for kind in (_lib.NHIP_LIDAR_NORMAL, _lib.NHIP_LIDAR_POINT):
+        batch = R.LidarResidualBatch(kind, blocks, src, tgt, 4)
+        res, js, jt = batch.evaluate(poses)
+        wr, wj0, wj1 = oracle_eval(kind, blocks, src, tgt, poses)
+        close(res, wr), close(js, wj0), close(jt, wj1)
+        batch.close()
+
+
+def test_factory_checks_mirror_reference(gpu):
+    p = np.zeros((3, 2), np.float32)
+    with pytest.raises(ValueError):
+        R.LIDARNormalResidual.create(p, p[:2], p, p)      # CHECK_EQ sizes, slam_residuals.h:99-101
+    with pytest.raises(ValueError):
+        R.LIDARPointResidual.create(p[:0], p[:0], p[:0], p[:0])  # CHECK_GT(size, 0), :165
+    with pytest.raises(_lib.NhipError):
+        R.LidarResidualBatch(0, [np.zeros((2, 8), np.float32)], [5], [0], 3)  # pose index out of range
+    prob = R.ResidualProblem(4)
+    blk = R.LIDARNormalResidual.create(p + 1, p + 2, p + 3, p + 4)
+    assert blk.num_residuals == 6
+    prob.AddResidualBlock(blk, 1, 0)
+    prob.AddResidualBlock(R.LIDARPointResidual.create(p + 1, p + 2, p + 3, p + 4), 2, 1)
+    out = prob.Evaluate(np.arange(12, dtype=np.float64).reshape(4, 3) * 0.1)
+    assert set(out) == {0, 1} and out[0][0].shape == (6,) and out[1][1].shape == (6, 3)
+
+
+def _dev(a):
+    import torch
+    return torch.from_numpy(np.ascontiguousarray(a)).to("cuda:0")
+
+
+def test_point_to_line_matches_autodiff_oracle(gpu):
+    """HITL PointToLineResidual, every branch of DistanceToLineSegment (slam_util.h:92-110)."""
+    import torch
+    rng = np.random.default_rng(11)
+    segs = np.array([[0, 0, 2, 2], [-1, 3, 4, 3], [2, -2, 2, 5], [0.5, 0.5, -3, 1]], dtype=np.float32)
+    poses = np.array([[0.2, -0.1, 0.3], [1.0, 2.0, -2.9], [-3, 0.5, 1.57]])
+    lines = np.array([[0, 0, 0], [0.1, -0.2, 0.05], [-0.5, 0.3, -0.4]])  # chosen_line_pose, data_structures.h:46
+    pts, pblock, bpose, bline = [], [], [], []
+    for b in range(8):
+        n = int(rng.integers(10, 90))
+        pts.append(rng.uniform(-6, 6, (n, 2)).astype(np.float32))
+        pblock += [b] * n
+        bpose.append(b % 3), bline.append((b * 2) % 3)
+    bseg = segs[np.arange(8) % 4]
+    P = np.concatenate(pts)
+    n = len(P)
+    d_res = torch.empty(n, dtype=torch.float64, device="cuda:0")
+    d_j0 = torch.empty(3 * n, dtype=torch.float64, device="cuda:0")
+    d_j1 = torch.empty(3 * n, dtype=torch.float64, device="cuda:0")
+    args = [_dev(bseg), _dev(P), _dev(np.asarray(pblock, np.int32)), _dev(np.asarray(bpose, np.int32)),
+            _dev(np.asarray(bline, np.int32)), _dev(poses), _dev(lines)]
+    _lib.check(_lib.load().nhip_resid_point_to_line_dev(
+        args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(), n, args[3].data_ptr(), args[4].data_ptr(), 8,
+        args[5].data_ptr(), args[6].data_ptr(), d_res.data_ptr(), d_j0.data_ptr(), d_j1.data_ptr(), None))
+    torch.cuda.synchronize()
+    res, j0, j1 = d_res.cpu().numpy(), d_j0.cpu().numpy().reshape(n, 3), d_j1.cpu().numpy().reshape(n, 3)
+    o = 0
+    seen_inside = seen_end = 0
+    for b in range(8):
+        wr, w0, w1 = O.point_to_line_block(bseg[b], pts[b], poses[bpose[b]], lines[bline[b]])
+        k = len(pts[b])
+        close(res[o:o + k], wr), close(j0[o:o + k], w0, 10.0), close(j1[o:o + k], w1, 10.0)
+        o += k
+    assert np.all(res >= 0)
+
+
+def test_odometry_matches_autodiff_oracle(gpu):
+    import torch
+    rng = np.random.default_rng(5)
+    n = 200
+    poses = rng.normal(0, 3, (n + 1, 3))
+    poses[:, 2] = rng.uniform(-7, 7, n + 1)
+    t_odom = rng.normal(0, 0.3, (n, 2)).astype(np.float32)
+    r_odom = rng.uniform(-3.2, 3.2, n).astype(np.float32)
+    pi, pj = np.arange(n, dtype=np.int32), np.arange(1, n + 1, dtype=np.int32)
+    d = [_dev(t_odom), _dev(r_odom), _dev(pi), _dev(pj), _dev(poses)]
+    d_res = torch.empty(3 * n, dtype=torch.float64, device="cuda:0")
+    d_ji = torch.empty(9 * n, dtype=torch.float64, device="cuda:0")
+    d_jj = torch.empty(9 * n, dtype=torch.float64, device="cuda:0")
+    _lib.check(_lib.load().nhip_resid_odometry_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
+                                                   d[3].data_ptr(), n, 1.0, 2.5, d[4].data_ptr(),
+                                                   d_res.data_ptr(), d_ji.data_ptr(), d_jj.data_ptr(), None))
+    torch.cuda.synchronize()
+    res = d_res.cpu().numpy().reshape(n, 3)
+    ji, jj = d_ji.cpu().numpy().reshape(n, 3, 3), d_jj.cpu().numpy().reshape(n, 3, 3)
+    for f in range(n):
+        wr, w0, w1 = O.odometry_block(t_odom[f], r_odom[f], 1.0, 2.5, poses[f], poses[f + 1])
+        close(res[f], wr), close(ji[f], w0), close(jj[f], w1)
+
+
+def test_full_size_block_properties(gpu):
+    """Config #3 scale (1081-point blocks) through size-independent properties:
+    LIDARPoint residuals are linear in the target point; Jacobian columns match central differences."""
+    bag = synth.SynthBag(12, dense=True)
+    poses = bag.odom.copy()
+    blocks, src, tgt = bag.window_blocks(window=3, poses=poses)
+    assert max(len(b) for b in blocks) > 900
+    batch = R.LidarResidualBatch(_lib.NHIP_LIDAR_NORMAL, blocks, src, tgt, len(poses))
+    res, js, jt = batch.evaluate(poses)
+    eps = 1e-6
+    for col in range(3):
+        dp = np.zeros_like(poses)
+        dp[:, col] = eps
+        rp, _, _ = batch.evaluate(poses + dp, False, False)
+        rm, _, _ = batch.evaluate(poses - dp, False, False)
+        fd = (rp - rm) / (2 * eps)       # every pose moved: d r / d src[col] + d r / d tgt[col]
+        assert np.max(np.abs(fd - (js[:, col] + jt[:, col]))) < 1e-5
+    batch.close()
