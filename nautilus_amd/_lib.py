@@ -97,6 +97,14 @@ def load():
         raise ImportError(
             "nautilus_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
             "g.build()'` or `make -C nautilus_amd/csrc`; there is no CPU fallback" % LIB_PATH)
+    # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 (same SONAME as
+    # /opt/rocm's).  If ours were resolved first, torch would later bind to the system runtime
+    # and see no GPUs.  Importing torch first makes both share torch's copy; without torch
+    # (a C++ host) the library binds to /opt/rocm as linked.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -49,15 +49,15 @@ __global__ __launch_bounds__(256) void grid_raster_kernel(
 // pass + quantise -> padded grid.  Grid memory is pre-zeroed; empty tiles return early.
 __global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restrict__ H,
                                                         uint8_t *__restrict__ grids, int32_t S,
-                                                        int32_t pad, int32_t pitch, int32_t R,
-                                                        GridKernelTables tab) {
+                                                        int32_t pad, int32_t pitch, int64_t grid_bytes,
+                                                        int32_t R, GridKernelTables tab) {
   __shared__ uint8_t sH[TH_MAX][TH_MAX + 4];
   __shared__ uint32_t sV[TH_MAX][TILE + 1];
   __shared__ uint32_t sThr[256];
   const int32_t t = blockIdx.z;
   const int32_t r0 = blockIdx.y * TILE, c0 = blockIdx.x * TILE;
   const uint8_t *h = H + (size_t)t * S * S;
-  uint8_t *g = grids + (size_t)t * pitch * pitch;
+  uint8_t *g = grids + (size_t)t * grid_bytes;
   const int TH = TILE + 2 * R;
   int any = 0;
   for (int i = threadIdx.x; i < TH * TH; i += 256) {
@@ -137,7 +137,7 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
                        (int32_t)t0, H, L.S, spec->res);
     timer_begin(NHIP_TIMER_GRID, s);
     hipLaunchKernelGGL(grid_blur_kernel, dim3(tiles, tiles, n), dim3(256), 0, s, H, g, L.S, L.pad,
-                       L.pitch, L.R, kt);
+                       L.pitch, L.grid_bytes, L.R, kt);
     timer_end(NHIP_TIMER_GRID, s);
   }
   NHIP_TRY_HIP(hipGetLastError());
