@@ -63,8 +63,8 @@ typedef struct nhip_grid_spec {
 
 typedef struct nhip_grid_layout {
   int32_t side;        /* S: cells per side (cimg_debug.h:21-22) */
-  int32_t pad;         /* zero border on every side: 2*max_shift + 4, multiple of 4 */
-  int32_t pitch;       /* bytes per stored row = S + 2*pad rounded up to a multiple of 4 */
+  int32_t pad;         /* zero border on every side: 2*max_shift + 16, multiple of 4 */
+  int32_t pitch;       /* bytes per stored row = S + 2*pad rounded up to a multiple of 16 */
   int32_t rows;        /* stored rows = S + 2*pad; cell (row, col) is byte (row+pad)*pitch + col+pad */
   int32_t blur_radius; /* R = ceil(3*sigma) */
   int32_t reserved;

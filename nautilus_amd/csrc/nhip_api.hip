@@ -45,8 +45,8 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   const double side = floor((spec->range * 2.0) / spec->res);  // cimg_debug.h:21-22
   NHIP_REQUIRE(side >= 1 && side <= 16384, "grid spec: side %g out of range [1, 16384]", side);
   L->S = (int32_t)side;
-  L->pad = ((2 * spec->max_shift + 4) + 3) & ~3;
-  L->pitch = ((L->S + 2 * L->pad) + 3) & ~3;
+  L->pad = ((2 * spec->max_shift + 16) + 3) & ~3;
+  L->pitch = ((L->S + 2 * L->pad) + 15) & ~15;
   L->R = (int32_t)ceil(3.0 * spec->sigma);
   L->grid_bytes = (int64_t)L->pitch * (int64_t)(L->S + 2 * L->pad);
   L->Lf = log(spec->floor_p);

@@ -3,18 +3,19 @@
 // Replaces CorrelativeScanMatcher::GetTransformation (call site
 // src/optimization/solver.cc:633-638), batched over candidate pairs.
 //
-// Formulation (accumulator-stationary): one workgroup owns one rotation k of one pair and
-// keeps an (nx x ny) plane of integer score accumulators in registers -- lane t owns 28
-// consecutive x-shifts of y-shift t/3.  Points are visited one at a time by the whole
-// workgroup (the point's window origin is wave-uniform, read with v_readlane), every lane
-// reads its 28 window bytes as two 16-byte loads and adds them.  A point's contribution to
-// the plane is the (nx x ny) window of the target grid anchored at its rotated cell, so
-// consecutive lanes read consecutive bytes of grid rows (coalesced), and all arithmetic is
-// integer: sums are order-independent, hence bit-exact against the CPU oracle.
+// Formulation (accumulator-stationary, LDS-tiled): one workgroup owns one rotation k of one
+// pair and keeps an (nx x ny) plane of integer score accumulators in registers -- lane t owns
+// 28 consecutive x-shifts of y-shift t/3.  A point's contribution to the plane is the
+// (nx x ny) window of the target grid anchored at its rotated cell.  Points are visited in
+// beam order; consecutive beams hit neighbouring cells, so a run of points shares one grid
+// tile: the workgroup stages a 144-row x 212-byte tile of the grid in LDS (coalesced 4-byte
+// reads of HBM/L2, once per run), then every point of the run is a wave-uniform LDS offset
+// (v_readlane) from which each lane reads its 8 dwords and adds 28 bytes.  LDS pitch 53 dwords
+// makes the 32-lane read groups conflict-free (bank = 7 * lane mod 32).
+// All arithmetic is integer: sums are order-independent, hence bit-exact against the oracle.
 //
-// No bounds checks in the inner loop: grids are stored with a zero border of
-// pad = 2*max_shift+4 cells, and points whose whole window misses the grid are redirected
-// to the all-zero corner window (offset 0).
+// No bounds checks: grids carry a zero border of pad = 2*max_shift+16 cells and rotated cells
+// are clamped to one cell outside the window-overlap range (a clamped point only sees border).
 #include "nhip_common.h"
 
 namespace nhip {
@@ -22,14 +23,17 @@ namespace nhip {
 namespace {
 
 constexpr int CSM_THREADS = 256;
-constexpr int SEG_DW = 7;              // dwords of accumulated columns per lane
-constexpr int SEG_COLS = 4 * SEG_DW;   // 28 x-shifts per lane
-constexpr int SEGS = 3;                // lanes per plane row
-constexpr int PB_NX = SEGS * SEG_COLS; // 84 x-shifts per plane block
+constexpr int SEG_DW = 7;                  // dwords of accumulated columns per lane
+constexpr int SEG_COLS = 4 * SEG_DW;       // 28 x-shifts per lane
+constexpr int SEGS = 3;                    // lanes per plane row
+constexpr int PB_NX = SEGS * SEG_COLS;     // 84 x-shifts per plane block
 constexpr int PB_NY = CSM_THREADS / SEGS;  // 85 y-shifts per plane block
-constexpr int LDS_POINTS = 2048;       // window origins staged per pass
-
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4), aligned(4)));
+constexpr int LDS_POINTS = 1152;           // rotated cells staged per pass
+constexpr int LP_DW = 53;                  // LDS tile pitch in dwords (conflict-free: 53 = 21 mod 32)
+constexpr int LP = 4 * LP_DW;              // 212 bytes
+constexpr int TILE_ROWS = 144;
+constexpr int ROW_BYTES = PB_NX + 4;       // bytes of a tile row one point may touch (88)
+constexpr int COL_SPAN = LP - ROW_BYTES;   // max (pcol - tile_col0) of a covered point (124)
 
 struct CsmParams {
   const float2 *xy;
@@ -43,27 +47,33 @@ struct CsmParams {
   unsigned long long *keys;
   int32_t *volume;  // full score volume (scores kernel only)
   int32_t n_pairs, n_theta, nx, ny, hx, hy, npbx, npby;
-  int32_t S, pad, pitch, max_shift;
+  int32_t S, pad, pitch, rows, max_shift;
   int32_t single_src, single_slot;  // scores kernel: the one pair
   int32_t single_ox, single_oy;
   int64_t grid_bytes;
   double res;
 };
 
-// Window origin (byte offset into the stored grid) of point q under rotation (cf, sf).
-// Spec: rotate in float with individually rounded products (Eigen Affine2f * Vector2f on
-// baseline x86-64: no FMA), cell = S/2 + floor(double(v) / res) (cimg_debug.h:31-37).
-__device__ __forceinline__ int32_t window_origin(float2 q, float cf, float sf, const CsmParams &P,
-                                                 int32_t ox, int32_t oy, int32_t cx, int32_t cy) {
+// Stored-grid coordinates (row, col) of the top-left cell of point q's window under rotation
+// (cf, sf), packed (row << 16) | col.  Spec: rotate in float with individually rounded
+// products (Eigen Affine2f * Vector2f on baseline x86-64: no FMA), cell = S/2 +
+// floor(double(v) / res) (cimg_debug.h:31-37).  Cells are clamped to [-h-1, S+h]: beyond that
+// range every lookup of the window falls on the zero border, and so does the clamped window.
+__device__ __forceinline__ uint32_t window_cell(float2 q, float cf, float sf, const CsmParams &P,
+                                                int32_t ox, int32_t oy, int32_t cx, int32_t cy) {
   const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
   const float yr = __fadd_rn(__fmul_rn(sf, q.x), __fmul_rn(cf, q.y));
-  if (!(fabsf(xr) < 1e9f) || !(fabsf(yr) < 1e9f)) return 0;
-  const long half = P.S / 2;
-  const long col = half + (long)floor(__ddiv_rn((double)xr, P.res)) + cx;
-  const long row = half + (long)floor(__ddiv_rn((double)yr, P.res)) + cy;
-  // whole window outside the grid -> contributes only floor cells (0): use the zero corner
-  if (col + P.hx < 0 || col - P.hx >= P.S || row + P.hy < 0 || row - P.hy >= P.S) return 0;
-  return (int32_t)((row - P.hy + oy + P.pad) * P.pitch + (col - P.hx + ox + P.pad));
+  long col = -P.hx - 1, row = -P.hy - 1;  // non-finite points score nothing
+  if ((fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f)) {
+    const long half = P.S / 2;
+    col = half + (long)floor(__ddiv_rn((double)xr, P.res)) + cx;
+    row = half + (long)floor(__ddiv_rn((double)yr, P.res)) + cy;
+    col = col < -P.hx - 1 ? -P.hx - 1 : (col > P.S + P.hx ? P.S + P.hx : col);
+    row = row < -P.hy - 1 ? -P.hy - 1 : (row > P.S + P.hy ? P.S + P.hy : row);
+  }
+  const uint32_t pcol = (uint32_t)(col - P.hx + ox + P.pad);
+  const uint32_t prow = (uint32_t)(row - P.hy + oy + P.pad);
+  return (prow << 16) | pcol;
 }
 
 __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
@@ -73,9 +83,18 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// Where to put point j inside a fresh tile: ahead of the direction the beam sweep is moving.
+__device__ __forceinline__ int32_t place(int32_t here, int32_t ahead, int32_t span) {
+  const int32_t d = ahead - here;
+  const int32_t off = d > 2 ? span / 8 : (d < -2 ? span - span / 8 : span / 2);
+  const int32_t a = here - off;
+  return a < 0 ? 0 : a;
+}
+
 template <bool VOLUME>
 __global__ __launch_bounds__(CSM_THREADS) void csm_correlate_kernel(CsmParams P) {
-  __shared__ int32_t s_origin[LDS_POINTS];
+  __shared__ uint32_t s_tile[TILE_ROWS * LP_DW];
+  __shared__ uint32_t s_cell[LDS_POINTS];
   __shared__ unsigned long long s_best[CSM_THREADS / 64];
 
   // ---- block -> (pair, rotation, plane block); all rotations of a pair share an XCD
@@ -95,16 +114,17 @@ __global__ __launch_bounds__(CSM_THREADS) void csm_correlate_kernel(CsmParams P)
   const int32_t k = w / npb;
   const int32_t pb = w % npb;
   const int32_t ox = (pb % P.npbx) * PB_NX, oy = (pb / P.npbx) * PB_NY;
+  const int32_t nyb = min(P.ny - oy, PB_NY);  // plane rows of this block
+  const int32_t row_span = TILE_ROWS - nyb;   // max (prow - tile_row0) of a covered point
 
   const int32_t src = VOLUME ? P.single_src : P.pair_src[pair];
   const int32_t slot = VOLUME ? P.single_slot : P.pair_slot[pair];
   const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
   const uint8_t *grid = P.grids + (size_t)slot * P.grid_bytes;
-  // search centre in cells; a centre the stored border cannot cover scores nothing (never faults)
+  // search centre in cells; a centre the stored border cannot cover scores nothing
   int32_t cx = VOLUME ? P.single_ox : (P.pair_origin ? P.pair_origin[2 * pair] : 0);
   int32_t cy = VOLUME ? P.single_oy : (P.pair_origin ? P.pair_origin[2 * pair + 1] : 0);
   const bool centre_ok = (abs(cx) + P.hx <= P.max_shift) && (abs(cy) + P.hy <= P.max_shift);
-  if (!centre_ok) { cx = 0; cy = 0; }
 
   // rotation k: R(theta0) * R(delta_k), composed in double with individually rounded ops
   const double c0 = P.rot0_cs[2 * pair], s0 = P.rot0_cs[2 * pair + 1];
@@ -115,46 +135,82 @@ __global__ __launch_bounds__(CSM_THREADS) void csm_correlate_kernel(CsmParams P)
   const int tid = threadIdx.x, lane = tid & 63;
   const int dy = tid / SEGS, seg = tid % SEGS;
   // lanes past the plane block's rows re-read row 0 (their sums are never used)
-  const int dyc = (oy + dy < P.ny && dy < PB_NY) ? dy : 0;
-  const uint32_t lane_off = (uint32_t)(dyc * P.pitch + seg * SEG_COLS);
+  const int dyc = (dy < nyb) ? dy : 0;
+  const uint32_t lane_off = (uint32_t)(dyc * LP + seg * SEG_COLS);
+  const uint8_t *tile_bytes = reinterpret_cast<const uint8_t *>(s_tile);
 
   uint32_t acc[SEG_COLS];
 #pragma unroll
   for (int i = 0; i < SEG_COLS; i++) acc[i] = 0;
 
-  for (int32_t base = 0; base < n_pts; base += LDS_POINTS) {
+  // current tile: stored-grid rows [t_row0, t_row0 + TILE_ROWS), byte columns [t_col0, t_col0 + LP)
+  int32_t t_row0 = 0, t_col0 = 0;
+  bool have_tile = false;
+
+  for (int32_t base = 0; base < n_pts && centre_ok; base += LDS_POINTS) {
     const int32_t cnt = min(n_pts - base, LDS_POINTS);
-    const int32_t cnt64 = (cnt + 63) & ~63;
     __syncthreads();
-    for (int32_t i = tid; i < cnt64; i += CSM_THREADS)
-      s_origin[i] = (i < cnt && centre_ok)
-                        ? window_origin(P.xy[beg + base + i], cf, sf, P, ox, oy, cx, cy)
-                        : 0;
+    for (int32_t i = tid; i < cnt; i += CSM_THREADS)
+      s_cell[i] = window_cell(P.xy[beg + base + i], cf, sf, P, ox, oy, cx, cy);
     __syncthreads();
-    for (int32_t pb64 = 0; pb64 < cnt64; pb64 += 64) {
-      const int32_t vorg = s_origin[pb64 + lane];
-#pragma unroll 4
-      for (int j = 0; j < 64; j++) {
-        const uint32_t org = (uint32_t)__builtin_amdgcn_readlane(vorg, j);
-        const uint32_t sh = org & 3u;
-        const uint8_t *p = grid + (org & ~3u) + lane_off;
-        const u32x4 a = *reinterpret_cast<const u32x4 *>(p);
-        const u32x4 b = *reinterpret_cast<const u32x4 *>(p + 16);
-        const uint32_t d[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-#pragma unroll
-        for (int i = 0; i < SEG_DW; i++) {
-          const uint32_t wv = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
-          acc[4 * i + 0] += wv & 0xffu;
-          acc[4 * i + 1] += (wv >> 8) & 0xffu;
-          acc[4 * i + 2] += (wv >> 16) & 0xffu;
-          acc[4 * i + 3] += wv >> 24;
+    for (int32_t c64 = 0; c64 < cnt; c64 += 64) {
+      const int32_t n = min(cnt - c64, 64);
+      const uint32_t vcell = (lane < n) ? s_cell[c64 + lane] : 0u;
+      const int32_t vcol = (int32_t)(vcell & 0xffffu), vrow = (int32_t)(vcell >> 16);
+      const unsigned long long live = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+      int32_t j = 0;
+      while (j < n) {
+        // lanes whose window lies inside the staged tile
+        const bool cov = have_tile && (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
+                         (uint32_t)(vrow - t_row0) <= (uint32_t)row_span;
+        const unsigned long long miss = ~__ballot(cov) & live & ~((1ull << j) - 1ull);
+        const int32_t e = miss ? (int32_t)__builtin_ctzll(miss) : n;
+        if (e == j) {
+          // point j is outside: stage a new tile around it, biased along the sweep direction
+          const int32_t ja = min(j + 16, n - 1);
+          const int32_t cj = __builtin_amdgcn_readlane(vcol, j), rj = __builtin_amdgcn_readlane(vrow, j);
+          const int32_t ca = __builtin_amdgcn_readlane(vcol, ja), ra = __builtin_amdgcn_readlane(vrow, ja);
+          t_col0 = place(cj, ca, COL_SPAN - 15) & ~15;
+          t_row0 = place(rj, ra, row_span);
+          have_tile = true;
+          const int32_t fill_rows = min(TILE_ROWS, P.rows - t_row0);
+          const int32_t n_dw = fill_rows * LP_DW;
+          const uint8_t *gsrc = grid + (size_t)t_row0 * P.pitch + t_col0;
+          __syncthreads();  // every wave is done with the old tile
+          int32_t r = tid / LP_DW, x = tid % LP_DW;
+          for (int32_t d = tid; d < n_dw; d += CSM_THREADS) {
+            s_tile[d] = *reinterpret_cast<const uint32_t *>(gsrc + (size_t)r * P.pitch + 4 * x);
+            r += CSM_THREADS / LP_DW;  // 256 = 4 * 53 + 44
+            x += CSM_THREADS % LP_DW;
+            if (x >= LP_DW) { x -= LP_DW; r += 1; }
+          }
+          __syncthreads();
+          continue;
         }
+        for (int32_t jj = j; jj < e; jj++) {
+          const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int32_t)vcell, jj);
+          const uint32_t org = ((pc >> 16) - (uint32_t)t_row0) * LP + ((pc & 0xffffu) - (uint32_t)t_col0);
+          const uint32_t sh = org & 3u;
+          const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_bytes + (org & ~3u) + lane_off);
+          uint32_t d[8];
+#pragma unroll
+          for (int i = 0; i < 8; i++) d[i] = p[i];
+#pragma unroll
+          for (int i = 0; i < SEG_DW; i++) {
+            const uint32_t wv = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
+            acc[4 * i + 0] += wv & 0xffu;
+            acc[4 * i + 1] += (wv >> 8) & 0xffu;
+            acc[4 * i + 2] += (wv >> 16) & 0xffu;
+            acc[4 * i + 3] += wv >> 24;
+          }
+        }
+        j = e;
       }
     }
   }
 
   const int32_t iy = oy + dy;
-  const bool row_ok = (dy < PB_NY) && (iy < P.ny);
+  const bool row_ok = dy < nyb;
   if (VOLUME) {
     if (row_ok) {
 #pragma unroll
@@ -216,7 +272,7 @@ __global__ void csm_finalize_kernel(const unsigned long long *__restrict__ keys,
   if (sums) sums[i] = (int32_t)sum;
 }
 
-int check_search(const nhip_grid_spec_t *spec, const nhip_search_t *search) {
+int check_search(const nhip_grid_spec_t *spec, const GridLayout &L, const nhip_search_t *search) {
   NHIP_REQUIRE(search->n_theta >= 1 && (search->n_theta & 1), "search: n_theta must be odd >= 1");
   NHIP_REQUIRE(search->nx >= 1 && (search->nx & 1), "search: nx must be odd >= 1");
   NHIP_REQUIRE(search->ny >= 1 && (search->ny & 1), "search: ny must be odd >= 1");
@@ -225,6 +281,9 @@ int check_search(const nhip_grid_spec_t *spec, const nhip_search_t *search) {
                (search->ny - 1) / 2, spec->max_shift);
   NHIP_REQUIRE((int64_t)search->n_theta * search->nx * search->ny < 0x7fffffffll,
                "search: lattice too large for 32-bit linear index");
+  NHIP_REQUIRE(L.S + 2 * L.pad < 65536, "search: stored grid side %d does not fit 16-bit cell packing",
+               L.S + 2 * L.pad);
+  NHIP_REQUIRE(L.pitch % 16 == 0, "search: grid pitch must be a multiple of 16");
   return NHIP_OK;
 }
 
@@ -241,6 +300,7 @@ void fill_params(CsmParams &P, const nhip_grid_spec_t *spec, const GridLayout &L
   P.S = L.S;
   P.pad = L.pad;
   P.pitch = L.pitch;
+  P.rows = L.S + 2 * L.pad;
   P.max_shift = spec->max_shift;
   P.grid_bytes = L.grid_bytes;
   P.res = spec->res;
@@ -252,9 +312,8 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
-                     uint64_t *d_keys,
-                     nhip_match_t *d_out, int32_t *d_sums, hipStream_t s) {
-  int rc = check_search(spec, search);
+                     uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s) {
+  int rc = check_search(spec, L, search);
   if (rc) return rc;
   if (n_pairs == 0) return NHIP_OK;
   CsmParams P;
@@ -289,7 +348,7 @@ int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t
                       const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
                       int32_t origin_y, const nhip_search_t *search, int32_t *d_sums,
                       hipStream_t s) {
-  int rc = check_search(spec, search);
+  int rc = check_search(spec, L, search);
   if (rc) return rc;
   CsmParams P;
   fill_params(P, spec, L, search);

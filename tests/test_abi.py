@@ -41,9 +41,9 @@ def test_grid_layout_follows_cimg_debug():
     spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40)
     L = csm.grid_layout(spec)
     assert L.side == 1200 == O.grid_side(O.grid_spec(30.0, 0.05))  # floor(2*30/0.05), cimg_debug.h:21
-    assert L.pad == 84 and L.pitch == 1368 and L.rows == 1368
+    assert L.pad == 96 and L.pitch == 1392 and L.rows == 1392
     assert L.blur_radius == 6
-    assert L.grid_bytes == 1368 * 1368
+    assert L.grid_bytes == 1392 * 1392
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
     for (r, res, side) in [(30, 0.3, 200), (30, 0.01, 6000), (10, 0.03, 666)]:
         assert csm.grid_layout(csm.grid_spec(r, res, 2.0, 1e-10, 4)).side == side
