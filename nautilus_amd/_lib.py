@@ -8,7 +8,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libnautilus_hip.so")
+# NHIP_LIB lets kernel A/B experiments point at another build of the same library
+LIB_PATH = os.environ.get("NHIP_LIB") or os.path.join(_HERE, "lib", "libnautilus_hip.so")
 
 NHIP_OK, NHIP_ERR_ARG, NHIP_ERR_NODEV, NHIP_ERR_HIP, NHIP_ERR_ALLOC, NHIP_ERR_STATE = 0, -1, -2, -3, -4, -5
 NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1

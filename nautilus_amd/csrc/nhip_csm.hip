@@ -83,6 +83,101 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// ---- SWAR byte accumulation -------------------------------------------------------------
+// gfx950 issues plain VOP2 integer ops (v_add_u32, v_and_b32, v_lshrrev_b32) at 2 clk per
+// wave64 but every SDWA / VOP3 form (byte-select adds, v_alignbyte, v_bfe, v_perm, v_add3) at
+// ~4.2 clk (tools/ubench_valu.hip).  So a lane never extracts bytes per point.  It reads its 8
+// ALIGNED dwords w and does, per dword, 4 full-rate ops:
+//     even += w & 0x00FF00FF      (two 16-bit fields: sum b0 | sum b2)
+//     odd  += w >> 8              (= sum b1 + 256 sum b2 + 65536 sum b3, no overflow <= 255 pts)
+// The byte alignment sh = (window start) & 3 is wave-uniform, so points are accumulated into
+// one of four register sets by a scalar branch, and the sets are unpacked (b1/b3 recovered as
+// odd - 256 * sum b2) into the 28 window-relative 32-bit sums every <= 255 points.
+constexpr int FLUSH_POINTS = 255;  // a 16-bit field holds 255 byte values
+constexpr int FLUSH_GROUP = 192;   // points between unpacks: 3 lane-chunks of 64
+static_assert(FLUSH_GROUP <= FLUSH_POINTS && FLUSH_GROUP % 64 == 0, "SWAR fields would overflow");
+#ifndef NHIP_CSM_UNROLL
+#define NHIP_CSM_UNROLL 1  // points read together per iteration; 2-4 measured 0-12 % slower
+#endif
+
+struct Swar {
+  uint32_t e[4][8], o[4][8];
+};
+
+template <int SH>
+__device__ __forceinline__ void swar_add(Swar &A, const uint32_t (&d)[8]) {
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    A.e[SH][i] += d[i] & 0x00ff00ffu;
+    A.o[SH][i] += d[i] >> 8;
+  }
+}
+
+// Pop the lowest point of mask m and issue the loads of its 8 aligned dwords.
+template <int SH>
+__device__ __forceinline__ void swar_load(uint32_t (&d)[8], const uint8_t *tile_bytes,
+                                          uint32_t lane_off, uint32_t vorg, unsigned long long &m) {
+  const int jj = (int)__builtin_ctzll(m);
+  m &= m - 1ull;
+  const uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int32_t)vorg, jj);
+  const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_bytes + (org - SH) + lane_off);
+#pragma unroll
+  for (int i = 0; i < 8; i++) d[i] = p[i];
+}
+
+// All points of the current run segment (lanes in seg_mask) whose window start has byte
+// alignment SH: the point's LDS offset is read from its lane (wave-uniform), every lane loads
+// its 8 aligned dwords and accumulates them into register set SH.
+template <int SH>
+__device__ __forceinline__ void swar_pass(Swar &A, const uint8_t *tile_bytes, uint32_t lane_off,
+                                          uint32_t vorg, unsigned long long seg_mask) {
+  unsigned long long m = __ballot((vorg & 3u) == (uint32_t)SH) & seg_mask;
+  // NHIP_CSM_UNROLL points per iteration: their LDS reads are issued back to back, so the
+  // adds of one point overlap the read latency of the next
+#pragma nounroll
+  while (__builtin_popcountll(m) >= NHIP_CSM_UNROLL) {
+    uint32_t d[NHIP_CSM_UNROLL][8];
+#pragma unroll
+    for (int u = 0; u < NHIP_CSM_UNROLL; u++) swar_load<SH>(d[u], tile_bytes, lane_off, vorg, m);
+#pragma unroll
+    for (int u = 0; u < NHIP_CSM_UNROLL; u++) swar_add<SH>(A, d[u]);
+  }
+#pragma nounroll
+  while (m) {
+    uint32_t d[8];
+    swar_load<SH>(d, tile_bytes, lane_off, vorg, m);
+    swar_add<SH>(A, d);
+  }
+}
+
+__device__ __forceinline__ void swar_clear(Swar &A) {
+#pragma unroll
+  for (int s = 0; s < 4; s++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) A.e[s][i] = A.o[s][i] = 0;
+}
+
+// acc[j] += byte sums; byte b of aligned dword i of class s is window column 4*i + b - s.
+__device__ __forceinline__ void swar_flush(Swar &A, uint32_t (&acc)[SEG_COLS]) {
+#pragma unroll
+  for (int s = 0; s < 4; s++) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint32_t ev = A.e[s][i];
+      const uint32_t b0 = ev & 0xffffu, b2 = ev >> 16;
+      const uint32_t od = A.o[s][i] - (b2 << 8);
+      const uint32_t b1 = od & 0xffffu, b3 = od >> 16;
+      const uint32_t b[4] = {b0, b1, b2, b3};
+#pragma unroll
+      for (int k = 0; k < 4; k++) {
+        const int j = 4 * i + k - s;
+        if (j >= 0 && j < SEG_COLS) acc[j] += b[k];
+      }
+    }
+  }
+  swar_clear(A);
+}
+
 // Where to put point j inside a fresh tile: ahead of the direction the beam sweep is moving.
 __device__ __forceinline__ int32_t place(int32_t here, int32_t ahead, int32_t span) {
   const int32_t d = ahead - here;
@@ -92,7 +187,7 @@ __device__ __forceinline__ int32_t place(int32_t here, int32_t ahead, int32_t sp
 }
 
 template <bool VOLUME>
-__global__ __launch_bounds__(CSM_THREADS) void csm_correlate_kernel(CsmParams P) {
+__global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams P) {
   __shared__ uint32_t s_tile[TILE_ROWS * LP_DW];
   __shared__ uint32_t s_cell[LDS_POINTS];
   __shared__ unsigned long long s_best[CSM_THREADS / 64];
@@ -142,6 +237,8 @@ __global__ __launch_bounds__(CSM_THREADS) void csm_correlate_kernel(CsmParams P)
   uint32_t acc[SEG_COLS];
 #pragma unroll
   for (int i = 0; i < SEG_COLS; i++) acc[i] = 0;
+  Swar A;
+  swar_clear(A);
 
   // current tile: stored-grid rows [t_row0, t_row0 + TILE_ROWS), byte columns [t_col0, t_col0 + LP)
   int32_t t_row0 = 0, t_col0 = 0;
@@ -153,20 +250,25 @@ __global__ __launch_bounds__(CSM_THREADS) void csm_correlate_kernel(CsmParams P)
     for (int32_t i = tid; i < cnt; i += CSM_THREADS)
       s_cell[i] = window_cell(P.xy[beg + base + i], cf, sf, P, ox, oy, cx, cy);
     __syncthreads();
-    for (int32_t c64 = 0; c64 < cnt; c64 += 64) {
-      const int32_t n = min(cnt - c64, 64);
+    // groups of 192 points (<= FLUSH_POINTS), each followed by an unconditional unpack
+    for (int32_t g0 = 0; g0 < cnt; g0 += FLUSH_GROUP) {
+    const int32_t g1 = min(cnt, g0 + FLUSH_GROUP);
+    for (int32_t c64 = g0; c64 < g1; c64 += 64) {
+      const int32_t n = min(g1 - c64, 64);
       const uint32_t vcell = (lane < n) ? s_cell[c64 + lane] : 0u;
       const int32_t vcol = (int32_t)(vcell & 0xffffu), vrow = (int32_t)(vcell >> 16);
       const unsigned long long live = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
       int32_t j = 0;
       while (j < n) {
-        // lanes whose window lies inside the staged tile
-        const bool cov = have_tile && (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
-                         (uint32_t)(vrow - t_row0) <= (uint32_t)row_span;
-        const unsigned long long miss = ~__ballot(cov) & live & ~((1ull << j) - 1ull);
-        const int32_t e = miss ? (int32_t)__builtin_ctzll(miss) : n;
+        // lanes whose window lies inside the staged tile; e = first lane >= j that is not
+        const unsigned long long from_j = live & ~((1ull << j) - 1ull);
+        bool cov = have_tile && (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
+                   (uint32_t)(vrow - t_row0) <= (uint32_t)row_span;
+        unsigned long long miss = ~__ballot(cov) & from_j;
+        int32_t e = miss ? (int32_t)__builtin_ctzll(miss) : n;
         if (e == j) {
-          // point j is outside: stage a new tile around it, biased along the sweep direction
+          // point j is outside: stage a new tile around it, biased along the sweep direction.
+          // (This branch never touches the accumulators.)
           const int32_t ja = min(j + 16, n - 1);
           const int32_t cj = __builtin_amdgcn_readlane(vcol, j), rj = __builtin_amdgcn_readlane(vrow, j);
           const int32_t ca = __builtin_amdgcn_readlane(vcol, ja), ra = __builtin_amdgcn_readlane(vrow, ja);
@@ -185,27 +287,23 @@ __global__ __launch_bounds__(CSM_THREADS) void csm_correlate_kernel(CsmParams P)
             if (x >= LP_DW) { x -= LP_DW; r += 1; }
           }
           __syncthreads();
-          continue;
+          cov = (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
+                (uint32_t)(vrow - t_row0) <= (uint32_t)row_span;
+          miss = ~__ballot(cov) & from_j;
+          e = miss ? (int32_t)__builtin_ctzll(miss) : n;  // > j: the new tile covers point j
         }
-        for (int32_t jj = j; jj < e; jj++) {
-          const uint32_t pc = (uint32_t)__builtin_amdgcn_readlane((int32_t)vcell, jj);
-          const uint32_t org = ((pc >> 16) - (uint32_t)t_row0) * LP + ((pc & 0xffffu) - (uint32_t)t_col0);
-          const uint32_t sh = org & 3u;
-          const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_bytes + (org & ~3u) + lane_off);
-          uint32_t d[8];
-#pragma unroll
-          for (int i = 0; i < 8; i++) d[i] = p[i];
-#pragma unroll
-          for (int i = 0; i < SEG_DW; i++) {
-            const uint32_t wv = __builtin_amdgcn_alignbyte(d[i + 1], d[i], sh);
-            acc[4 * i + 0] += wv & 0xffu;
-            acc[4 * i + 1] += (wv >> 8) & 0xffu;
-            acc[4 * i + 2] += (wv >> 16) & 0xffu;
-            acc[4 * i + 3] += wv >> 24;
-          }
-        }
+        // points j..e-1 are covered: LDS byte offset of each lane's window start, then one
+        // sub-pass per alignment class (each touches only its own SWAR register set)
+        const uint32_t vorg = (uint32_t)(vrow - t_row0) * LP + (uint32_t)(vcol - t_col0);
+        const unsigned long long seg_mask = (e == 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << j) - 1ull);
+        swar_pass<0>(A, tile_bytes, lane_off, vorg, seg_mask);
+        swar_pass<1>(A, tile_bytes, lane_off, vorg, seg_mask);
+        swar_pass<2>(A, tile_bytes, lane_off, vorg, seg_mask);
+        swar_pass<3>(A, tile_bytes, lane_off, vorg, seg_mask);
         j = e;
       }
+    }
+    swar_flush(A, acc);
     }
   }
 
