@@ -1,0 +1,101 @@
+// adapter_test.cc -- exercises the C++ drop-ins the way nautilus's solver.cc would
+// (GetRelativeTransform, solver.cc:630-649; AddResidualBlock + ceres::Solve evaluation).
+// Needs an MI355X: run by tests/test_adapters_gpu.py.  Prints ADAPTER_OK on success.
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#include "CorrelativeScanMatcher.h"
+#include "slam_residuals_hip.h"
+
+using nautilus_hip::Vec2f;
+
+static std::vector<Vec2f> Room(double ox, double oy, double oth) {
+  // points on the walls of a 9 m x 6 m room with a pillar, seen from pose (ox, oy, oth)
+  std::vector<Vec2f> world;
+  for (double x = -4.5; x <= 4.5; x += 0.04) { world.emplace_back(x, -3.0); world.emplace_back(x, 3.0); }
+  for (double y = -3.0; y <= 3.0; y += 0.04) { world.emplace_back(-4.5, y); world.emplace_back(4.5, y); }
+  for (double t = 0; t < 1.0; t += 0.04) { world.emplace_back(1.0 + t, 0.5); world.emplace_back(1.0, 0.5 + 0.6 * t); }
+  std::vector<Vec2f> out;
+  const double c = std::cos(-oth), s = std::sin(-oth);
+  for (const Vec2f &w : world) {
+    const double dx = w(0) - ox, dy = w(1) - oy;
+    out.emplace_back((float)(c * dx - s * dy), (float)(s * dx + c * dy));
+  }
+  return out;
+}
+
+#define REQUIRE(cond)                                                        \
+  do {                                                                       \
+    if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
+  } while (0)
+
+int main() {
+  int ndev = 0;
+  if (nhip_init(&ndev) != NHIP_OK) { std::printf("no GPU: %s\n", nhip_last_error()); return 2; }
+  // ---- scan matcher, used exactly as solver.cc:633-644
+  const double ax = 0.62, ay = -0.37, ath = 0.21;  // pose of A in B's frame (B at the origin)
+  const std::vector<Vec2f> pc_b = Room(0, 0, 0), pc_a = Room(ax, ay, ath);
+  CorrelativeScanMatcher scan_matcher(30, 2, 0.3, 0.01);
+  auto trans_pair = scan_matcher.GetTransformation(pc_a, pc_b, ath + 0.05, 0.0, M_PI / 2);
+  const float tx = trans_pair.second.first(0), ty = trans_pair.second.first(1), th = trans_pair.second.second;
+  std::printf("csm: score %.4f  t = (%.3f, %.3f)  theta = %.4f   truth (%.3f, %.3f, %.4f)\n", trans_pair.first, tx, ty,
+              th, ax, ay, ath);
+  REQUIRE(std::fabs(tx - ax) < 0.03 && std::fabs(ty - ay) < 0.03 && std::fabs(th - ath) < 0.01);
+  REQUIRE(trans_pair.first > -8.0 && trans_pair.first <= 0.0);
+  // batched form, BASELINE lattice
+  nhip_search_t search = {61, 81, 81, 0, M_PI / 180.0};
+  CorrelativeScanMatcherBatch batch(30.0, 0.05, search);
+  auto res = batch.Match({pc_a, pc_b}, {{0, 1}, {1, 0}}, {ath - 0.03, 0.0});
+  std::printf("batch: (%.2f %.2f %.3f) (%.2f %.2f %.3f)\n", res[0].translation(0), res[0].translation(1), res[0].rotation,
+              res[1].translation(0), res[1].translation(1), res[1].rotation);
+  REQUIRE(std::fabs(res[0].translation(0) - ax) <= 0.051 && std::fabs(res[0].translation(1) - ay) <= 0.051);
+  REQUIRE(std::fabs(res[0].rotation - ath) <= 0.0176);
+
+  // ---- residual blocks, used as solver.cc:277-295 + Ceres' evaluation loop would
+  auto &B = nautilus_hip::ResidualBatcher::Instance();
+  B.Reset();
+  std::vector<Vec2f> sp, tp, sn, tn;
+  for (int i = 0; i < 300; i++) {
+    const float a = 0.01f * i;
+    sp.emplace_back(2.f * std::cos(a), 2.f * std::sin(a));
+    tp.emplace_back(2.05f * std::cos(a + 0.02f), 1.95f * std::sin(a + 0.02f));
+    sn.emplace_back(std::cos(a), std::sin(a));
+    tn.emplace_back(std::cos(a + 0.02f), std::sin(a + 0.02f));
+  }
+  double poses[3][3] = {{0.1, -0.2, 0.05}, {0.0, 0.0, 0.0}, {1.0, 0.5, -0.4}};
+  auto *c0 = nautilus::LIDARNormalResidual::create(sp, tp, sn, tn);
+  auto *c1 = nautilus::LIDARPointResidual::create(sp, tp, sn, tn);
+  auto *c2 = nautilus::LIDARNormalResidual::create(tp, sp, tn, sn);
+  REQUIRE(c0->num_residuals() == 600 && c0->parameter_block_sizes().size() == 2 && c0->parameter_block_sizes()[0] == 3);
+  std::vector<double> r(600), j0(1800), j1(1800);
+  double *jac[2] = {j0.data(), j1.data()};
+  double const *params[2] = {poses[0], poses[1]};
+  REQUIRE(!c0->Evaluate(params, r.data(), jac));  // not prepared: fails loudly, no CPU fallback
+  B.Bind(c0, poses[0], poses[1]);
+  B.Bind(c1, poses[0], poses[1]);
+  B.Bind(c2, poses[2], poses[0]);
+  B.PrepareForEvaluation(true, true);
+  REQUIRE(c0->Evaluate(params, r.data(), jac));
+  // central differences through the same path (residual-only evaluations)
+  double maxerr = 0;
+  for (int k = 0; k < 3; k++) {
+    std::vector<double> rp(600), rm(600);
+    const double eps = 1e-6, keep = poses[0][k];
+    poses[0][k] = keep + eps; B.PrepareForEvaluation(false, true); REQUIRE(c0->Evaluate(params, rp.data(), nullptr));
+    poses[0][k] = keep - eps; B.PrepareForEvaluation(false, true); REQUIRE(c0->Evaluate(params, rm.data(), nullptr));
+    poses[0][k] = keep;
+    for (int i = 0; i < 600; i++) maxerr = std::fmax(maxerr, std::fabs((rp[i] - rm[i]) / (2 * eps) - j0[3 * i + k]));
+  }
+  std::printf("resid: |J - finite difference|_max = %.3g\n", maxerr);
+  REQUIRE(maxerr < 1e-6);
+  B.PrepareForEvaluation(true, true);
+  double *only_tgt[2] = {nullptr, j1.data()};  // constant first block: NULL jacobian (solver.cc:384-386)
+  REQUIRE(c1->Evaluate(params, r.data(), only_tgt));
+  REQUIRE(std::fabs(r[0] - (tp[0](0) - (std::cos(0.05) * sp[0](0) - std::sin(0.05) * sp[0](1) + 0.1))) < 1e-12);
+  delete c0; delete c1; delete c2;
+  B.Reset();
+  std::printf("ADAPTER_OK\n");
+  return 0;
+}
