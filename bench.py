@@ -27,6 +27,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def _traffic(key):
+    """HBM bytes per launch from the committed PMC profile (profiles/traffic.json), or None."""
+    tf = os.path.join(ROOT, "profiles", "traffic.json")
+    try:
+        return json.load(open(tf)).get(key)
+    except Exception:
+        return None
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -82,8 +91,20 @@ def main():
     torch.cuda.set_device(local)
     _lib.check(lib.nhip_set_device(local))
     dev = torch.device("cuda", local)
-    if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+    use_dist = "RANK" in os.environ  # launched by torch.distributed.run: RCCL group even at N=1
+    if use_dist:
+        # RCCL prints a version banner on stdout when the communicator is created; keep stdout to
+        # the one JSON line by routing fd 1 to stderr until the first collective has run.
+        saved = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            dist.init_process_group("nccl", device_id=dev)
+            dist.barrier()
+            torch.cuda.synchronize()
+        finally:
+            sys.stdout.flush()
+            os.dup2(saved, 1)
+            os.close(saved)
 
     # ---- synthetic workload (per rank; seeds differ per rank so shards are not copies)
     bag = synth.SynthBag(a.scans, dense=True, seed=synth.SEED + 1000 * rank)
@@ -111,7 +132,7 @@ def main():
     d_keys = torch.empty(n_pairs, dtype=torch.int64, device=dev)
     d_out = torch.empty((n_pairs, 4), dtype=torch.int32, device=dev)
     d_sums = torch.empty(n_pairs, dtype=torch.int32, device=dev)
-    d_all = torch.empty((world * n_pairs, 4), dtype=torch.int32, device=dev) if world > 1 else None
+    d_all = torch.empty((world * n_pairs, 4), dtype=torch.int32, device=dev) if use_dist else None
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     rot0_np = h_rot0.numpy()
@@ -125,11 +146,11 @@ def main():
                                           d_src.data_ptr(), d_slot.data_ptr(), d_rot0.data_ptr(),
                                           d_delta.data_ptr(), None, n_pairs, C.byref(search),
                                           d_keys.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), sp))
-        if world > 1:
-            dist.all_gather_into_tensor(d_all, d_out)
+        if use_dist:
+            dist.all_gather_into_tensor(d_all, d_out)  # the ONE collective: 16 B per pair
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -144,7 +165,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     lib.nhip_timing_enable(0)
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -153,9 +174,12 @@ def main():
     g_ms, g_n = C.c_double(0), C.c_int32(0)
     _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_GRID, C.byref(g_ms), C.byref(g_n)))
 
+    if use_dist:
+        # every rank's block of the gathered table must equal what that rank computed
+        mine = d_all[rank * n_pairs:(rank + 1) * n_pairs]
+        assert torch.equal(mine, d_out), "all-gather returned a different block for this rank"
     if rank != 0:
-        if world > 1:
-            dist.destroy_process_group()
+        dist.destroy_process_group()
         return
 
     # ---- parity spot check of the timed result against the oracle happens inside cpu_baseline
@@ -165,13 +189,7 @@ def main():
     bytes_per_launch = float(n_pairs) * lookups_per_pair * 1  # 1-byte cells
     avg_ms = k_ms.value / max(k_n.value, 1)
     achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    traffic = None
-    tf = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tf):
-        try:
-            traffic = json.load(open(tf)).get("csm_correlate_bytes_per_launch_%dpairs" % n_pairs)
-        except Exception:
-            traffic = None
+    traffic = _traffic("csm_correlate_bytes_per_launch_%dpairs" % n_pairs)
     out = {
         "metric": "loop-closure candidate pairs/sec (1081-beam)",
         "value": world * n_pairs * a.steps / elapsed,
@@ -213,7 +231,7 @@ def main():
         except Exception as e:  # secondary measurement must not lose the headline line
             out["secondary"] = {"resid_lidar_error": repr(e)}
     print(json.dumps(out))
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
@@ -254,7 +272,7 @@ def bench_residuals(torch, lib, dev, sp, n_blocks=9945, n_per=1081, iters=20):
     return {"workload": "configs[2]: %d blocks x %d correspondences, LIDARNormal residual + 2 Jacobians" % (n_blocks, n_per),
             "correspondences_per_s": n_corr / (avg * 1e-3), "avg_launch_ms": avg,
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+                         "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic("resid_lidar_bytes_per_launch_%dcorr" % n_corr),
                          "algorithmic_bytes_per_launch": bytes_alg}}
 
 

@@ -276,15 +276,38 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
           t_row0 = place(rj, ra, row_span);
           have_tile = true;
           const int32_t fill_rows = min(TILE_ROWS, P.rows - t_row0);
-          const int32_t n_dw = fill_rows * LP_DW;
           const uint8_t *gsrc = grid + (size_t)t_row0 * P.pitch + t_col0;
           __syncthreads();  // every wave is done with the old tile
-          int32_t r = tid / LP_DW, x = tid % LP_DW;
-          for (int32_t d = tid; d < n_dw; d += CSM_THREADS) {
-            s_tile[d] = *reinterpret_cast<const uint32_t *>(gsrc + (size_t)r * P.pitch + 4 * x);
-            r += CSM_THREADS / LP_DW;  // 256 = 4 * 53 + 44
-            x += CSM_THREADS % LP_DW;
-            if (x >= LP_DW) { x -= LP_DW; r += 1; }
+          // Fill: 16-byte global loads (14 per 224-byte row span; t_col0 and the pitch are multiples
+          // of 16), 4 in flight per lane, then 4-byte LDS stores (the 212-byte LDS pitch that makes
+          // the reads conflict-free is not a multiple of 16).  Measured against LDS-DMA
+          // (global_load_lds_dword, 120 pieces of 256 B per tile, issue-bound): 3.6 % faster.
+          {
+            constexpr int ROW_CH = (LP + 15) / 16;  // 14
+            const int32_t n_ch = fill_rows * ROW_CH;
+            int32_t rr = tid / ROW_CH, kk = tid % ROW_CH;
+            for (int32_t c0 = tid; c0 < n_ch; c0 += 4 * CSM_THREADS) {
+              uint4 v[4];
+              int32_t rs[4], ks[4];
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                rs[u] = rr;
+                ks[u] = kk;
+                if (c0 + u * CSM_THREADS < n_ch)
+                  v[u] = *reinterpret_cast<const uint4 *>(gsrc + (size_t)rr * P.pitch + 16 * kk);
+                rr += CSM_THREADS / ROW_CH;  // 256 = 18 * 14 + 4
+                kk += CSM_THREADS % ROW_CH;
+                if (kk >= ROW_CH) { kk -= ROW_CH; rr += 1; }
+              }
+#pragma unroll
+              for (int u = 0; u < 4; u++) {
+                if (c0 + u * CSM_THREADS < n_ch) {
+                  uint32_t *dst = s_tile + rs[u] * LP_DW + 4 * ks[u];
+                  dst[0] = v[u].x;
+                  if (ks[u] < ROW_CH - 1) { dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w; }
+                }
+              }
+            }
           }
           __syncthreads();
           cov = (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
