@@ -8,10 +8,10 @@
 // 28 consecutive x-shifts of y-shift t/3.  A point's contribution to the plane is the
 // (nx x ny) window of the target grid anchored at its rotated cell.  Points are visited in
 // beam order; consecutive beams hit neighbouring cells, so a run of points shares one grid
-// tile: the workgroup stages a 144-row x 212-byte tile of the grid in LDS (coalesced 4-byte
-// reads of HBM/L2, once per run), then every point of the run is a wave-uniform LDS offset
-// (v_readlane) from which each lane reads its 8 dwords and adds 28 bytes.  LDS pitch 53 dwords
-// makes the 32-lane read groups conflict-free (bank = 7 * lane mod 32).
+// tile: the workgroup stages a 144-row x 212-byte tile of the grid in LDS (16-byte reads of
+// HBM/L2, once per run), then every point of the run is a wave-uniform LDS offset (v_readlane)
+// from which each lane reads its 8 aligned dwords and accumulates them SWAR-style (below).
+// LDS pitch 53 dwords makes the 32-lane read groups conflict-free (bank = 7 * lane mod 32).
 // All arithmetic is integer: sums are order-independent, hence bit-exact against the oracle.
 //
 // No bounds checks: grids carry a zero border of pad = 2*max_shift+16 cells and rotated cells
