@@ -230,6 +230,12 @@ def main():
             out["secondary"] = {"resid_lidar": bench_residuals(torch, lib, dev, sp)}
         except Exception as e:  # secondary measurement must not lose the headline line
             out["secondary"] = {"resid_lidar_error": repr(e)}
+        try:
+            del d_grids
+            torch.cuda.empty_cache()
+            out["secondary"]["icp_front_half"] = bench_icp(bag, xy, off, a.cpu_seconds > 0)
+        except Exception as e:
+            out["secondary"]["icp_front_half_error"] = repr(e)
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
@@ -274,6 +280,52 @@ def bench_residuals(torch, lib, dev, sp, n_blocks=9945, n_per=1081, iters=20):
             "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic("resid_lidar_bytes_per_launch_%dcorr" % n_corr),
                          "algorithmic_bytes_per_launch": bytes_alg}}
+
+
+def bench_icp(bag, xy, off, with_cpu, window=10, iters=5):
+    """SURVEY 8f rows 1-2 at BASELINE configs[2] scale: 1000 poses, window 10 -> 9,945 (i, j) blocks of
+    1081-point scans: correspondence search (K5) + per-block normal equations, all resident in HBM."""
+    import torch
+    from nautilus_amd import _lib
+    from nautilus_amd.correspondence import IcpBatch, window_pairs
+    lib = _lib.load()
+    nrm = np.concatenate(bag.normals).astype(np.float32)
+    bs, bt = window_pairs(bag.n_scans, window)
+    batch = IcpBatch(xy, nrm, off, bs, bt)
+    batch.set_poses(bag.odom)
+    n_corr = batch.search()
+    torch.cuda.synchronize()
+    lib.nhip_timing_reset()
+    lib.nhip_timing_enable(1)
+    for _ in range(iters):
+        batch.search(sync=False)
+        batch.normal_equations(_lib.NHIP_LIDAR_POINT)
+    torch.cuda.synchronize()
+    lib.nhip_timing_enable(0)
+    ms, n = C.c_double(0), C.c_int32(0)
+    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_CORR, C.byref(ms), C.byref(n)))
+    t_search = ms.value / max(n.value, 1)
+    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_NORMEQ, C.byref(ms), C.byref(n)))
+    t_neq = ms.value / max(n.value, 1)
+    cand = float(np.sum((off[bs + 1] - off[bs]).astype(np.float64) * (off[bt + 1] - off[bt])))
+    out = {"workload": "configs[2] shape: %d blocks (window %d) of 1081-point scans" % (len(bs), window),
+           "correspondences": n_corr, "corr_search_ms": t_search,
+           "corr_search_candidates_per_s": cand / (t_search * 1e-3),
+           "normal_eq_ms": t_neq, "normal_eq_correspondences_per_s": n_corr / (t_neq * 1e-3),
+           "normal_eq_roofline": {"bound": "hbm", "achieved": 32.0 * n_corr / (t_neq * 1e-3) / 1e9,
+                                  "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                  "frac": 32.0 * n_corr / (t_neq * 1e-3) / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                                  "note": "32 B read per correspondence, 224 B written per block"}}
+    if with_cpu:
+        from oracle import oracle as O
+        k = min(len(bs), 4 * O.num_threads())
+        t0 = time.perf_counter()
+        O.corr_search_batch(xy, nrm, off, bs[:k], bt[:k], O.pose_affines(bag.odom), 0.25, O.num_threads())
+        dt = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": k / dt, "unit": "blocks/s", "cores": O.num_threads(), "kind": "port",
+                               "sample": "%d blocks, oracle linear-scan restatement, OpenMP" % k,
+                               "gpu_blocks_per_s": len(bs) / (t_search * 1e-3)}
+    return out
 
 
 if __name__ == "__main__":

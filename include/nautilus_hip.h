@@ -159,6 +159,19 @@ int nhip_resid_lidar_dev(int kind, const float *d_corr, const int32_t *d_corr_bl
                          double *d_block_consts, double *d_residuals, double *d_jac_src,
                          double *d_jac_tgt, void *stream);
 
+/* On-device normal equations of the LIDAR blocks: instead of
+ * shipping 96 B of Jacobian per correspondence to the host, each block is reduced to what a
+ * Gauss-Newton / Levenberg-Marquardt step needs.  With J = [J_src | J_tgt] (2N x 6) and r (2N):
+ *   d_out[28*b +  0..20] = upper triangle of J^T J, row-major (i <= j)
+ *   d_out[28*b + 21..26] = J^T r
+ *   d_out[28*b + 27]     = r^T r
+ * Same functors, same closed-form Jacobians as nhip_resid_lidar_dev; d_block_offsets has
+ * n_blocks+1 entries (rows of d_corr per block). */
+int nhip_resid_lidar_normal_eq_dev(int kind, const float *d_corr, const int32_t *d_block_offsets,
+                                   const int32_t *d_block_src, const int32_t *d_block_tgt,
+                                   int32_t n_blocks, const double *d_poses, int32_t n_poses,
+                                   double *d_block_consts, double *d_out, void *stream);
+
 /* PointToLineResidual (slam_residuals.h:180-200): block b has line segment d_segments[4b..]
  * (x0 y0 x1 y1, LineSegment<float>), points d_points[2i..] with block id d_point_block[i],
  * parameter blocks pose = d_poses[d_block_pose[b]] and line_pose = d_line_poses[d_block_line[b]].
@@ -176,6 +189,27 @@ int nhip_resid_odometry_dev(const float *d_t_odom, const float *d_r_odom, const 
                             const int32_t *d_pose_j, int32_t n_factors, double translation_weight,
                             double rotation_weight, const double *d_poses, double *d_residuals,
                             double *d_jac_i, double *d_jac_j, void *stream);
+
+/* K5: correspondence search, the step that feeds K4 (Solver::GetPointToPointMatching,
+ * src/optimization/solver.cc:132-172; KDTree::FindNearestPoint, src/util/kdtree.cc:253-305).
+ * Block b pairs source scan d_block_src[b] with target scan d_block_tgt[b]: every source point is
+ * moved into the target frame by inverse(T_target) * T_source (float affines of the poses, see
+ * nhip_pose_affines), matched with its nearest target point and kept if the distance is below
+ * outlier_threshold (default_config.lua:66).  d_normals: one float2 per point of d_xy (the
+ * reference reads normals from its trees, solver.cc:67-78).  Rows (8 floats: source point, target
+ * point, source normal, target normal) are written in source order at
+ * d_corr_padded + 8*d_cap_offsets[b] (capacity = source points of block b); d_counts[b] rows are
+ * valid.  nhip_corr_compact_dev packs them into the contiguous layout nhip_resid_lidar_dev takes
+ * (d_block_offsets: n_blocks+1, d_corr: 8 floats/row, d_corr_block: block id per row). */
+int nhip_pose_affines(const double *poses, int32_t n, float *out /* 4n: cos sin x y */);
+int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+                         const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
+                         const float *d_pose_aff, float outlier_threshold,
+                         const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts,
+                         void *stream);
+int nhip_corr_compact_dev(const float *d_corr_padded, const int64_t *d_cap_offsets,
+                          const int32_t *d_counts, int32_t n_blocks, int32_t *d_block_offsets,
+                          float *d_corr, int32_t *d_corr_block, void *stream);
 
 /* ------------------------------------------------------------------ handle API (host pointers) */
 typedef struct nhip_scans nhip_scans_t;
@@ -214,10 +248,14 @@ int nhip_resid_batch_free(nhip_resid_batch_t *batch);
 
 /* ------------------------------------------------------------------ in-stream kernel timing
  * When enabled, the dominant kernels are bracketed by hipEvents on their own stream.
- * ids: 0 = csm_correlate, 1 = grid_build (blur), 2 = resid_lidar. */
+ * ids: 0 = csm_correlate, 1 = grid_build (blur), 2 = resid_lidar, 3 = corr_search,
+ *      4 = resid_normal_eq. */
 #define NHIP_TIMER_CSM 0
 #define NHIP_TIMER_GRID 1
 #define NHIP_TIMER_RESID 2
+#define NHIP_TIMER_CORR 3
+#define NHIP_TIMER_NORMEQ 4
+#define NHIP_TIMER_COUNT 5
 int nhip_timing_enable(int on);
 int nhip_timing_reset(void);
 /* synchronises the recorded events; total_ms / launches since the last reset */

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("NHIP_LIB") or os.path.join(_HERE, "lib", "libnautilus
 
 NHIP_OK, NHIP_ERR_ARG, NHIP_ERR_NODEV, NHIP_ERR_HIP, NHIP_ERR_ALLOC, NHIP_ERR_STATE = 0, -1, -2, -3, -4, -5
 NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1
-NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID = 0, 1, 2
+NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ = 0, 1, 2, 3, 4
 
 
 class NhipError(RuntimeError):
@@ -67,6 +67,10 @@ PROTOTYPES = {
                                       _P(Search), _vp, _vp]),
     "nhip_resid_lidar_dev": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp,
                                        _vp, _vp, _vp, _vp]),
+    "nhip_resid_lidar_normal_eq_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "nhip_pose_affines": (C.c_int, [_vp, _i32, _vp]),
+    "nhip_corr_search_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, _vp, _vp, _vp, _vp]),
+    "nhip_corr_compact_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "nhip_resid_point_to_line_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp,
                                                _vp, _vp, _vp, _vp]),
     "nhip_resid_odometry_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _vp, _vp,

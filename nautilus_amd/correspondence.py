@@ -1,0 +1,112 @@
+"""Device-resident ICP front half: correspondence search -> residual / normal-equation evaluation.
+
+Mirrors the reference's per-window problem build, batched:
+  Solver::BuildOptimizationOverWindow      /root/reference/src/optimization/solver.cc:321-333
+    -> AddLidarResiduals(i, j)             solver.cc:297-318
+       -> GetPointToPointMatching(i, j)    solver.cc:132-172   (K5, nhip_corr_search_dev)
+       -> LIDARPointResidual / LIDARNormalResidual blocks      (K4, nhip_resid_lidar_dev)
+Everything stays in HBM (torch tensors are only the allocator): correspondences never visit the
+host, and with `normal_equations()` neither do Jacobians.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check
+
+
+def window_pairs(n_scans, window):
+    """All (i, j), j in [max(i - window, 0), i): solver.cc:324-330."""
+    src, tgt = [], []
+    for i in range(n_scans):
+        for j in range(max(i - window, 0), i):
+            src.append(i)
+            tgt.append(j)
+    return np.asarray(src, dtype=np.int32), np.asarray(tgt, dtype=np.int32)
+
+
+class IcpBatch:
+    def __init__(self, xy, normals, offsets, block_src, block_tgt, device="cuda:0", outlier_threshold=0.25):
+        import torch
+        self.torch = torch
+        self.dev = torch.device(device)
+        self.lib = _lib.load()
+        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.dev)
+        self.offsets_h = np.ascontiguousarray(offsets, dtype=np.int32)
+        self.n_scans = len(self.offsets_h) - 1
+        self.d_xy, self.d_nrm, self.d_off = t(xy, np.float32), t(normals, np.float32), t(offsets, np.int32)
+        self.block_src = np.ascontiguousarray(block_src, dtype=np.int32)
+        self.block_tgt = np.ascontiguousarray(block_tgt, dtype=np.int32)
+        self.n_blocks = len(self.block_src)
+        self.d_bsrc, self.d_btgt = t(self.block_src, np.int32), t(self.block_tgt, np.int32)
+        cap = np.zeros(self.n_blocks + 1, dtype=np.int64)
+        cap[1:] = np.cumsum(self.offsets_h[self.block_src + 1] - self.offsets_h[self.block_src])
+        self.cap_h = cap
+        self.capacity = int(cap[-1])
+        self.d_cap = t(cap, np.int64)
+        self.thr = float(outlier_threshold)
+        e = lambda n, dt: torch.empty(max(int(n), 1), dtype=dt, device=self.dev)
+        self.d_aff = e(4 * self.n_scans, torch.float32)
+        self.d_poses = e(3 * self.n_scans, torch.float64)
+        self.d_padded = e(8 * self.capacity, torch.float32)
+        self.d_counts = e(self.n_blocks, torch.int32)
+        self.d_boff = e(self.n_blocks + 1, torch.int32)
+        self.d_corr = e(8 * self.capacity, torch.float32)
+        self.d_cblock = e(self.capacity, torch.int32)
+        self.d_consts = e(8 * self.n_blocks, torch.float64)
+        self.d_res = self.d_js = self.d_jt = self.d_neq = None
+        self.n_corr = 0
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def set_poses(self, poses):
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(self.n_scans, 3)
+        aff = np.empty((self.n_scans, 4), dtype=np.float32)
+        check(self.lib.nhip_pose_affines(_lib.ptr(poses), self.n_scans, _lib.ptr(aff)))
+        self.d_aff.copy_(self.torch.from_numpy(aff.reshape(-1)))
+        self.d_poses.copy_(self.torch.from_numpy(poses.reshape(-1)))
+
+    def search(self, sync=True):
+        """K5 + compaction.  Returns the number of correspondences (needs one sync to size outputs)."""
+        sp = self._stream()
+        check(self.lib.nhip_corr_search_dev(self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(),
+                                            self.d_bsrc.data_ptr(), self.d_btgt.data_ptr(), self.n_blocks,
+                                            self.d_aff.data_ptr(), self.thr, self.d_cap.data_ptr(),
+                                            self.d_padded.data_ptr(), self.d_counts.data_ptr(), sp))
+        check(self.lib.nhip_corr_compact_dev(self.d_padded.data_ptr(), self.d_cap.data_ptr(),
+                                             self.d_counts.data_ptr(), self.n_blocks, self.d_boff.data_ptr(),
+                                             self.d_corr.data_ptr(), self.d_cblock.data_ptr(), sp))
+        if sync:
+            self.n_corr = int(self.d_boff[self.n_blocks].item())
+        return self.n_corr
+
+    def correspondences(self):
+        """Host copy: (rows (n_corr, 8), block_offsets (n_blocks + 1))."""
+        n = self.n_corr
+        return (self.d_corr[:8 * n].cpu().numpy().reshape(n, 8), self.d_boff.cpu().numpy())
+
+    def residuals(self, kind, jacobians=True):
+        torch, n = self.torch, self.n_corr
+        if self.d_res is None or self.d_res.numel() < 2 * max(n, 1):
+            self.d_res = torch.empty(2 * max(n, 1), dtype=torch.float64, device=self.dev)
+            self.d_js = torch.empty(6 * max(n, 1), dtype=torch.float64, device=self.dev)
+            self.d_jt = torch.empty(6 * max(n, 1), dtype=torch.float64, device=self.dev)
+        check(self.lib.nhip_resid_lidar_dev(kind, self.d_corr.data_ptr(), self.d_cblock.data_ptr(), n,
+                                            self.d_bsrc.data_ptr(), self.d_btgt.data_ptr(), self.n_blocks,
+                                            self.d_poses.data_ptr(), self.n_scans, self.d_consts.data_ptr(),
+                                            self.d_res.data_ptr(), self.d_js.data_ptr() if jacobians else None,
+                                            self.d_jt.data_ptr() if jacobians else None, self._stream()))
+        return self.d_res[:2 * n], (self.d_js[:6 * n] if jacobians else None), (self.d_jt[:6 * n] if jacobians else None)
+
+    def normal_equations(self, kind):
+        """Per block: 21 upper-triangle entries of J^T J, 6 of J^T r, r^T r (28 doubles)."""
+        torch = self.torch
+        if self.d_neq is None:
+            self.d_neq = torch.empty(28 * max(self.n_blocks, 1), dtype=torch.float64, device=self.dev)
+        check(self.lib.nhip_resid_lidar_normal_eq_dev(kind, self.d_corr.data_ptr(), self.d_boff.data_ptr(),
+                                                      self.d_bsrc.data_ptr(), self.d_btgt.data_ptr(), self.n_blocks,
+                                                      self.d_poses.data_ptr(), self.n_scans,
+                                                      self.d_consts.data_ptr(), self.d_neq.data_ptr(), self._stream()))
+        return self.d_neq[:28 * self.n_blocks].view(self.n_blocks, 28)

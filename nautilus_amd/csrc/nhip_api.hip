@@ -112,7 +112,7 @@ struct TimerSlot {
 };
 std::mutex g_tmu;
 bool g_timing = false;
-TimerSlot g_slots[3];
+TimerSlot g_slots[NHIP_TIMER_COUNT];
 }  // namespace
 
 void timer_begin(int id, hipStream_t s) {
@@ -359,6 +359,59 @@ int nhip_resid_lidar_dev(int kind, const float *d_corr, const int32_t *d_corr_bl
   return launch_resid_lidar(kind, d_corr, d_corr_block, n_corr, d_block_src, d_block_tgt, n_blocks,
                             d_poses, n_poses, d_block_consts, d_residuals, d_jac_src, d_jac_tgt,
                             static_cast<hipStream_t>(stream));
+}
+
+int nhip_resid_lidar_normal_eq_dev(int kind, const float *d_corr, const int32_t *d_block_offsets,
+                                   const int32_t *d_block_src, const int32_t *d_block_tgt,
+                                   int32_t n_blocks, const double *d_poses, int32_t n_poses,
+                                   double *d_block_consts, double *d_out, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_corr && d_block_offsets && d_block_src && d_block_tgt && d_poses && d_block_consts && d_out,
+               "resid_lidar_normal_eq_dev: null pointer");
+  NHIP_REQUIRE(n_poses >= 0, "resid_lidar_normal_eq_dev: negative size");
+  return launch_resid_normal_eq(kind, d_corr, d_block_offsets, d_block_src, d_block_tgt, n_blocks, d_poses,
+                                d_block_consts, d_out, static_cast<hipStream_t>(stream));
+}
+
+int nhip_pose_affines(const double *poses, int32_t n, float *out) {
+  NHIP_REQUIRE(poses && out && n >= 0, "pose_affines: bad arguments");
+  for (int32_t i = 0; i < n; i++) {
+    // entries of PoseArrayToAffine<double>(pose).cast<float>() (slam_util.h:20-28, 37-40)
+    out[4 * i + 0] = (float)cos(poses[3 * i + 2]);
+    out[4 * i + 1] = (float)sin(poses[3 * i + 2]);
+    out[4 * i + 2] = (float)poses[3 * i + 0];
+    out[4 * i + 3] = (float)poses[3 * i + 1];
+  }
+  return NHIP_OK;
+}
+
+int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+                         const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
+                         const float *d_pose_aff, float outlier_threshold,
+                         const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts,
+                         void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_xy && d_normals && d_offsets && d_block_src && d_block_tgt && d_pose_aff && d_cap_offsets &&
+                   d_corr_padded && d_counts,
+               "corr_search_dev: null pointer");
+  NHIP_REQUIRE(n_blocks >= 0 && outlier_threshold > 0, "corr_search_dev: bad size or threshold");
+  return launch_corr_search(d_xy, d_normals, d_offsets, d_block_src, d_block_tgt, n_blocks, d_pose_aff,
+                            outlier_threshold, d_cap_offsets, d_corr_padded, d_counts,
+                            static_cast<hipStream_t>(stream));
+}
+
+int nhip_corr_compact_dev(const float *d_corr_padded, const int64_t *d_cap_offsets,
+                          const int32_t *d_counts, int32_t n_blocks, int32_t *d_block_offsets,
+                          float *d_corr, int32_t *d_corr_block, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_corr_padded && d_cap_offsets && d_counts && d_block_offsets && d_corr && d_corr_block,
+               "corr_compact_dev: null pointer");
+  NHIP_REQUIRE(n_blocks >= 0, "corr_compact_dev: n_blocks < 0");
+  return launch_corr_compact(d_corr_padded, d_cap_offsets, d_counts, n_blocks, d_block_offsets, d_corr,
+                             d_corr_block, static_cast<hipStream_t>(stream));
 }
 
 int nhip_resid_point_to_line_dev(const float *d_segments, const float *d_points,
@@ -658,7 +711,7 @@ int nhip_timing_reset(void) {
 }
 
 int nhip_timing_get(int id, double *total_ms, int32_t *launches) {
-  NHIP_REQUIRE(id >= 0 && id < 3, "timing_get: bad id %d", id);
+  NHIP_REQUIRE(id >= 0 && id < NHIP_TIMER_COUNT, "timing_get: bad id %d", id);
   std::lock_guard<std::mutex> lk(g_tmu);
   double tot = 0.0;
   for (auto &p : g_slots[id].ev) {

@@ -75,6 +75,20 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
                        const double *d_poses, int32_t n_poses, double *d_block_consts,
                        double *d_res, double *d_jsrc, double *d_jtgt, hipStream_t s);
 
+int launch_resid_normal_eq(int kind, const float *d_corr, const int32_t *d_block_offsets,
+                           const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
+                           const double *d_poses, double *d_block_consts, double *d_out,
+                           hipStream_t s);
+
+int launch_corr_search(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+                       const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
+                       const float *d_pose_aff, float thr, const int64_t *d_cap_offsets,
+                       float *d_corr_padded, int32_t *d_counts, hipStream_t s);
+
+int launch_corr_compact(const float *d_corr_padded, const int64_t *d_cap_offsets,
+                        const int32_t *d_counts, int32_t n_blocks, int32_t *d_block_offsets,
+                        float *d_corr, int32_t *d_corr_block, hipStream_t s);
+
 int launch_resid_point_to_line(const float *d_segments, const float *d_points,
                                const int32_t *d_point_block, int64_t n_points,
                                const int32_t *d_block_pose, const int32_t *d_block_line,

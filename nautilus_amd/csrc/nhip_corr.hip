@@ -1,0 +1,217 @@
+// nhip_corr.hip -- K5: correspondence search on gfx950.
+//
+// Replaces, batched over all (source, target) residual blocks of a problem build,
+//   Solver::GetPointToPointMatching          src/optimization/solver.cc:132-172
+//   FindClosestPoint                         src/optimization/solver.cc:80-90
+//   KDTree<float,2>::FindNearestPoint        src/util/kdtree.cc:253-305
+// which the reference runs from scratch for every (i, j) block and every window size
+// (solver.cc:321-356): three tree descents per matched point.
+//
+// Per block one workgroup: the target cloud is staged in LDS (8 B per point), every lane owns
+// a contiguous range of source points, transforms them into the target frame with the float
+// affine inverse(T_target) * T_source (Eigen Affine2f semantics, individually rounded products)
+// and scans all target points (LDS broadcast reads): exact nearest neighbour, ties to the
+// lowest index, kept if sqrt(d2) < outlier_threshold.  Kept rows are written in source order
+// (block-wide exclusive scan of the per-lane counts) as the 8-float rows K4 consumes.
+// ~8 VALU ops per (source, target) candidate: 1081 x 1081 candidates per block.
+#include "nhip_common.h"
+
+namespace nhip {
+
+namespace {
+
+constexpr int CT = 256;
+constexpr int TGT_CHUNK = 2048;  // target points staged per pass (16 KB)
+constexpr int MAX_PER_LANE = 8;  // source points a lane owns per pass (2048 per pass)
+
+struct Aff2f {
+  float m00, m01, m10, m11, tx, ty;
+};
+
+__device__ __forceinline__ Aff2f pose_affine(const float *a) {  // cos sin x y
+  return {a[0], -a[1], a[1], a[0], a[2], a[3]};
+}
+
+__device__ __forceinline__ Aff2f inverse_f(const Aff2f &A) {
+  const float det = __fsub_rn(__fmul_rn(A.m00, A.m11), __fmul_rn(A.m10, A.m01));
+  const float invdet = __fdiv_rn(1.0f, det);
+  Aff2f R;
+  R.m00 = __fmul_rn(A.m11, invdet);
+  R.m10 = __fmul_rn(-A.m10, invdet);
+  R.m01 = __fmul_rn(-A.m01, invdet);
+  R.m11 = __fmul_rn(A.m00, invdet);
+  R.tx = -__fadd_rn(__fmul_rn(R.m00, A.tx), __fmul_rn(R.m01, A.ty));
+  R.ty = -__fadd_rn(__fmul_rn(R.m10, A.tx), __fmul_rn(R.m11, A.ty));
+  return R;
+}
+
+__device__ __forceinline__ float dot2(float a, float b, float c, float d) {
+  return __fadd_rn(__fmul_rn(a, b), __fmul_rn(c, d));
+}
+
+__device__ __forceinline__ Aff2f mul_f(const Aff2f &A, const Aff2f &B) {
+  Aff2f C;
+  C.m00 = dot2(A.m00, B.m00, A.m01, B.m10);
+  C.m01 = dot2(A.m00, B.m01, A.m01, B.m11);
+  C.m10 = dot2(A.m10, B.m00, A.m11, B.m10);
+  C.m11 = dot2(A.m10, B.m01, A.m11, B.m11);
+  C.tx = __fadd_rn(dot2(A.m00, B.tx, A.m01, B.ty), A.tx);
+  C.ty = __fadd_rn(dot2(A.m10, B.tx, A.m11, B.ty), A.ty);
+  return C;
+}
+
+__global__ __launch_bounds__(CT) void corr_search_kernel(
+    const float2 *__restrict__ xy, const float2 *__restrict__ normals,
+    const int32_t *__restrict__ offsets, const int32_t *__restrict__ block_src,
+    const int32_t *__restrict__ block_tgt, const float *__restrict__ pose_aff, float thr,
+    const int64_t *__restrict__ cap_offsets, float4 *__restrict__ corr,
+    int32_t *__restrict__ counts) {
+  __shared__ float2 s_tgt[TGT_CHUNK];
+  __shared__ int32_t s_scan[CT];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int32_t s = block_src[b], t = block_tgt[b];
+  const int32_t sb = offsets[s], ns = offsets[s + 1] - sb;
+  const int32_t tb = offsets[t], nt = offsets[t + 1] - tb;
+  const Aff2f C = mul_f(inverse_f(pose_affine(pose_aff + 4 * (size_t)t)), pose_affine(pose_aff + 4 * (size_t)s));
+  float4 *out = corr + 2 * (size_t)cap_offsets[b];
+  int32_t written = 0;  // rows already emitted by earlier source passes (uniform)
+
+  for (int32_t s0 = 0; s0 < ns; s0 += CT * MAX_PER_LANE) {
+    const int32_t n_pass = min(ns - s0, CT * MAX_PER_LANE);
+    const int32_t per = (n_pass + CT - 1) / CT;  // <= MAX_PER_LANE
+    const int32_t lo = s0 + tid * per, hi = min(lo + per, s0 + n_pass);
+    float qx[MAX_PER_LANE], qy[MAX_PER_LANE], best[MAX_PER_LANE];
+    int32_t bi[MAX_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < MAX_PER_LANE; k++) {
+      bi[k] = -1;
+      best[k] = 3.0e38f;
+      qx[k] = qy[k] = 0.f;
+      if (lo + k < hi) {
+        const float2 p = xy[sb + lo + k];
+        qx[k] = __fadd_rn(dot2(C.m00, p.x, C.m01, p.y), C.tx);
+        qy[k] = __fadd_rn(dot2(C.m10, p.x, C.m11, p.y), C.ty);
+      }
+    }
+    for (int32_t t0 = 0; t0 < nt; t0 += TGT_CHUNK) {
+      const int32_t nc = min(nt - t0, TGT_CHUNK);
+      __syncthreads();
+      for (int32_t i = tid; i < nc; i += CT) s_tgt[i] = xy[tb + t0 + i];
+      __syncthreads();
+      for (int32_t i = 0; i < nc; i++) {
+        const float2 g = s_tgt[i];  // same address in every lane: LDS broadcast
+#pragma unroll
+        for (int k = 0; k < MAX_PER_LANE; k++) {
+          const float dx = __fsub_rn(g.x, qx[k]), dy = __fsub_rn(g.y, qy[k]);
+          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+          const bool better = d2 < best[k];  // strict: the lowest index wins ties
+          best[k] = better ? d2 : best[k];
+          bi[k] = better ? (t0 + i) : bi[k];
+        }
+      }
+    }
+    // keep = nearest within the threshold (kdtree.cc:253-305 + solver.cc:84-89)
+    int32_t mine = 0;
+    bool keep[MAX_PER_LANE];
+#pragma unroll
+    for (int k = 0; k < MAX_PER_LANE; k++) {
+      keep[k] = (lo + k < hi) && bi[k] >= 0 && (__fsqrt_rn(best[k]) < thr);
+      mine += keep[k] ? 1 : 0;
+    }
+    // block-wide exclusive scan of `mine` (source order = lane order x per-lane order)
+    __syncthreads();
+    s_scan[tid] = mine;
+    __syncthreads();
+    for (int off = 1; off < CT; off <<= 1) {
+      const int32_t v = (tid >= off) ? s_scan[tid - off] : 0;
+      __syncthreads();
+      s_scan[tid] += v;
+      __syncthreads();
+    }
+    int32_t pos = written + s_scan[tid] - mine;
+    const int32_t total = s_scan[CT - 1];
+#pragma unroll
+    for (int k = 0; k < MAX_PER_LANE; k++) {
+      if (keep[k]) {
+        const float2 p = xy[sb + lo + k], ps = normals[sb + lo + k];
+        const float2 g = xy[tb + bi[k]], gn = normals[tb + bi[k]];
+        out[2 * (size_t)pos] = make_float4(p.x, p.y, g.x, g.y);
+        out[2 * (size_t)pos + 1] = make_float4(ps.x, ps.y, gn.x, gn.y);
+        pos++;
+      }
+    }
+    written += total;
+  }
+  if (tid == 0) counts[b] = written;
+}
+
+// ---- compaction into the contiguous layout of the residual batch --------------------------
+// block_offsets = exclusive scan of counts (one workgroup; n_blocks is ~1e4)
+__global__ __launch_bounds__(1024) void corr_scan_kernel(const int32_t *__restrict__ counts,
+                                                         int32_t n_blocks,
+                                                         int32_t *__restrict__ block_offsets) {
+  __shared__ int32_t s[1024];
+  __shared__ int32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (int32_t base = 0; base < n_blocks; base += 1024) {
+    const int32_t i = base + threadIdx.x;
+    const int32_t v = i < n_blocks ? counts[i] : 0;
+    s[threadIdx.x] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+      const int32_t u = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+      __syncthreads();
+      s[threadIdx.x] += u;
+      __syncthreads();
+    }
+    if (i < n_blocks) block_offsets[i] = carry + s[threadIdx.x] - v;
+    __syncthreads();
+    if (threadIdx.x == 0) carry += s[1023];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) block_offsets[n_blocks] = carry;
+}
+
+__global__ __launch_bounds__(CT) void corr_compact_kernel(const float4 *__restrict__ padded,
+                                                          const int64_t *__restrict__ cap_offsets,
+                                                          const int32_t *__restrict__ block_offsets,
+                                                          float4 *__restrict__ corr,
+                                                          int32_t *__restrict__ corr_block) {
+  const int b = blockIdx.x;
+  const int32_t o = block_offsets[b], n = block_offsets[b + 1] - o;
+  const float4 *src = padded + 2 * (size_t)cap_offsets[b];
+  for (int32_t i = threadIdx.x; i < 2 * n; i += CT) corr[2 * (size_t)o + i] = src[i];
+  for (int32_t i = threadIdx.x; i < n; i += CT) corr_block[o + i] = b;
+}
+
+}  // namespace
+
+int launch_corr_search(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+                       const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
+                       const float *d_pose_aff, float thr, const int64_t *d_cap_offsets,
+                       float *d_corr_padded, int32_t *d_counts, hipStream_t s) {
+  if (n_blocks == 0) return NHIP_OK;
+  timer_begin(NHIP_TIMER_CORR, s);
+  hipLaunchKernelGGL(corr_search_kernel, dim3(n_blocks), dim3(CT), 0, s,
+                     reinterpret_cast<const float2 *>(d_xy), reinterpret_cast<const float2 *>(d_normals),
+                     d_offsets, d_block_src, d_block_tgt, d_pose_aff, thr, d_cap_offsets,
+                     reinterpret_cast<float4 *>(d_corr_padded), d_counts);
+  timer_end(NHIP_TIMER_CORR, s);
+  NHIP_TRY_HIP(hipGetLastError());
+  return NHIP_OK;
+}
+
+int launch_corr_compact(const float *d_corr_padded, const int64_t *d_cap_offsets,
+                        const int32_t *d_counts, int32_t n_blocks, int32_t *d_block_offsets,
+                        float *d_corr, int32_t *d_corr_block, hipStream_t s) {
+  hipLaunchKernelGGL(corr_scan_kernel, dim3(1), dim3(1024), 0, s, d_counts, n_blocks, d_block_offsets);
+  if (n_blocks > 0)
+    hipLaunchKernelGGL(corr_compact_kernel, dim3(n_blocks), dim3(CT), 0, s,
+                       reinterpret_cast<const float4 *>(d_corr_padded), d_cap_offsets, d_block_offsets,
+                       reinterpret_cast<float4 *>(d_corr), d_corr_block);
+  NHIP_TRY_HIP(hipGetLastError());
+  return NHIP_OK;
+}
+
+}  // namespace nhip

@@ -129,6 +129,81 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
   }
 }
 
+// Per-block normal equations: one workgroup per block, every lane runs the
+// same per-correspondence math as resid_lidar_kernel and keeps 28 fp64 partial sums (upper
+// triangle of J^T J, J^T r, r^T r); wave64 shuffles, then LDS across the 4 waves.  Output is
+// 224 B per block instead of 112 B per correspondence.
+template <int KIND>
+__global__ __launch_bounds__(RT) void resid_normal_eq_kernel(const float4 *__restrict__ corr,
+                                                             const int32_t *__restrict__ block_offsets,
+                                                             const double *__restrict__ consts,
+                                                             double *__restrict__ out) {
+  __shared__ double s_part[RT / 64][28];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int32_t o = block_offsets[b], n = block_offsets[b + 1] - o;
+  const double *c = consts + 8 * (size_t)b;
+  const double l00 = c[0], l01 = c[1], l10 = c[2], l11 = c[3], ctx = c[4], cty = c[5];
+  const double i00 = c[6], i01 = c[7], i10 = -i01, i11 = i00;
+  double acc[28];
+#pragma unroll
+  for (int k = 0; k < 28; k++) acc[k] = 0.0;
+  for (int32_t i = tid; i < n; i += RT) {
+    const float4 a = corr[2 * (size_t)(o + i)];
+    const float4 nn = corr[2 * (size_t)(o + i) + 1];
+    const double px = a.x, py = a.y, tx = a.z, ty = a.w;
+    const double ux = l00 * px + l01 * py, uy = l10 * px + l11 * py;
+    const double qx = ux + ctx, qy = uy + cty;
+    double r[2], J[2][6];
+    if (KIND == NHIP_LIDAR_NORMAL) {
+      const double nsx = nn.x, nsy = nn.y, ntx = nn.z, nty = nn.w;
+      const double ex = qx - tx, ey = qy - ty;
+      r[0] = ntx * ex + nty * ey;
+      r[1] = -(nsx * ex + nsy * ey);
+      J[0][0] = ntx * i00 + nty * i10;
+      J[0][1] = ntx * i01 + nty * i11;
+      J[0][2] = ntx * (-uy) + nty * ux;
+      J[1][0] = -(nsx * i00 + nsy * i10);
+      J[1][1] = -(nsx * i01 + nsy * i11);
+      J[1][2] = -(nsx * (-uy) + nsy * ux);
+      J[0][3] = -J[0][0];
+      J[0][4] = -J[0][1];
+      J[0][5] = ntx * qy - nty * qx;
+      J[1][3] = -J[1][0];
+      J[1][4] = -J[1][1];
+      J[1][5] = -(nsx * qy - nsy * qx);
+    } else {
+      r[0] = tx - qx;
+      r[1] = ty - qy;
+      J[0][0] = -i00; J[0][1] = -i01; J[0][2] = uy;
+      J[1][0] = -i10; J[1][1] = -i11; J[1][2] = -ux;
+      J[0][3] = i00;  J[0][4] = i01;  J[0][5] = -qy;
+      J[1][3] = i10;  J[1][4] = i11;  J[1][5] = qx;
+    }
+    int k = 0;
+#pragma unroll
+    for (int p = 0; p < 6; p++)
+#pragma unroll
+      for (int q = p; q < 6; q++) acc[k++] += J[0][p] * J[0][q] + J[1][p] * J[1][q];
+#pragma unroll
+    for (int p = 0; p < 6; p++) acc[21 + p] += J[0][p] * r[0] + J[1][p] * r[1];
+    acc[27] += r[0] * r[0] + r[1] * r[1];
+  }
+#pragma unroll
+  for (int k = 0; k < 28; k++) {
+    double v = acc[k];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    if ((tid & 63) == 0) s_part[tid >> 6][k] = v;
+  }
+  __syncthreads();
+  if (tid < 28) {
+    double v = 0.0;
+#pragma unroll
+    for (int w = 0; w < RT / 64; w++) v += s_part[w][tid];
+    out[28 * (size_t)b + tid] = v;
+  }
+}
+
 // ---------------------------------------------------------------- forward-mode duals
 // PointToLineResidual is branchy (DistanceToLineSegment, slam_util.h:92-110) and its
 // segment moves with line_pose, so it is differentiated the way Ceres does it: 6 partials
@@ -298,6 +373,28 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
                          d_corr_block, n_corr, d_block_consts, res, js, jt);
   }
   timer_end(NHIP_TIMER_RESID, s);
+  NHIP_TRY_HIP(hipGetLastError());
+  return NHIP_OK;
+}
+
+int launch_resid_normal_eq(int kind, const float *d_corr, const int32_t *d_block_offsets,
+                           const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
+                           const double *d_poses, double *d_block_consts, double *d_out,
+                           hipStream_t s) {
+  NHIP_REQUIRE(kind == NHIP_LIDAR_NORMAL || kind == NHIP_LIDAR_POINT, "resid_normal_eq: bad kind %d", kind);
+  NHIP_REQUIRE(n_blocks >= 0, "resid_normal_eq: negative size");
+  if (n_blocks == 0) return NHIP_OK;
+  hipLaunchKernelGGL(resid_block_consts_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, s,
+                     d_block_src, d_block_tgt, n_blocks, d_poses, d_block_consts);
+  const float4 *corr = reinterpret_cast<const float4 *>(d_corr);
+  timer_begin(NHIP_TIMER_NORMEQ, s);
+  if (kind == NHIP_LIDAR_NORMAL)
+    hipLaunchKernelGGL((resid_normal_eq_kernel<NHIP_LIDAR_NORMAL>), dim3(n_blocks), dim3(RT), 0, s, corr,
+                       d_block_offsets, d_block_consts, d_out);
+  else
+    hipLaunchKernelGGL((resid_normal_eq_kernel<NHIP_LIDAR_POINT>), dim3(n_blocks), dim3(RT), 0, s, corr,
+                       d_block_offsets, d_block_consts, d_out);
+  timer_end(NHIP_TIMER_NORMEQ, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }

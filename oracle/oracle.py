@@ -67,8 +67,45 @@ def load():
     lib.orc_point_to_line_block.argtypes = [_vp, _vp, C.c_int, _vp, _vp, _vp, _vp, _vp]
     lib.orc_odometry_block.argtypes = [_vp, C.c_float, _f64, _f64, _vp, _vp, _vp, _vp, _vp]
     lib.orc_lidar_batch.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32]
+    lib.orc_pose_affines.argtypes = [_vp, _i32, _vp]
+    lib.orc_pose_affines.restype = None
+    lib.orc_corr_search_block.restype = _i32
+    lib.orc_corr_search_block.argtypes = [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, C.c_float, _vp, _vp]
+    lib.orc_corr_search_batch.argtypes = [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, _vp, _vp, _vp, _i32]
     _lib = lib
     return lib
+
+
+def pose_affines(poses):
+    poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 3)
+    out = np.zeros((len(poses), 4), dtype=np.float32)
+    load().orc_pose_affines(_p(poses), len(poses), _p(out))
+    return out
+
+
+def corr_search_block(src_xy, src_nrm, tgt_xy, tgt_nrm, src_aff, tgt_aff, thr=0.25):
+    """One block of Solver::GetPointToPointMatching: (rows (n, 8) float32, matched target indices)."""
+    sx, sn, tx, tn = _f32(src_xy).reshape(-1, 2), _f32(src_nrm).reshape(-1, 2), _f32(tgt_xy).reshape(-1, 2), _f32(tgt_nrm).reshape(-1, 2)
+    out = np.zeros((max(len(sx), 1), 8), dtype=np.float32)
+    idx = np.zeros(max(len(sx), 1), dtype=np.int32)
+    n = load().orc_corr_search_block(_p(sx), _p(sn), len(sx), _p(tx), _p(tn), len(tx), _p(_f32(src_aff)),
+                                     _p(_f32(tgt_aff)), float(thr), _p(out), _p(idx))
+    return out[:n].copy(), idx[:n].copy()
+
+
+def corr_search_batch(xy, normals, offsets, block_src, block_tgt, pose_aff, thr=0.25, n_threads=0):
+    """Padded output like the product: (corr (cap, 8), counts, cap_offsets)."""
+    xy, normals = _f32(xy).reshape(-1, 2), _f32(normals).reshape(-1, 2)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    bs, bt = np.ascontiguousarray(block_src, dtype=np.int32), np.ascontiguousarray(block_tgt, dtype=np.int32)
+    cap = np.zeros(len(bs) + 1, dtype=np.int64)
+    cap[1:] = np.cumsum(offsets[bs + 1] - offsets[bs])
+    corr = np.zeros((int(cap[-1]), 8), dtype=np.float32)
+    counts = np.zeros(len(bs), dtype=np.int32)
+    _chk(load().orc_corr_search_batch(_p(xy), _p(normals), _p(offsets), _p(bs), _p(bt), len(bs),
+                                      _p(_f32(pose_aff)), float(thr), _p(cap), _p(corr), _p(counts), n_threads),
+         "corr_search_batch")
+    return corr, counts, cap
 
 
 def _p(a):

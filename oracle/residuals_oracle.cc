@@ -366,3 +366,110 @@ int orc_lidar_batch(int kind, const float *corr, const int32_t *block_offsets,
 }
 
 }  // extern "C"
+
+// =====================================================================================
+// Correspondence search -- CPU restatement of
+//   Solver::GetPointToPointMatching            src/optimization/solver.cc:132-172
+//   FindClosestPoint                           src/optimization/solver.cc:80-90
+//   KDTree<float,2>::FindNearestPoint          src/util/kdtree.cc:253-305
+//   GetPoseAsAffine<float>                     src/util/slam_util.h:37-40
+// For every source point: transform into the target frame with
+// target_to_world.inverse() * source_to_world (Affine2f, float arithmetic), take the nearest
+// target point (float Euclidean norm), keep it if dist < outlier_threshold, and append
+// (source point, source normal, match, target normal) in source order.
+// The kd-tree descent returns the exact nearest neighbour whenever one lies within the
+// threshold (it only prunes branches farther than min(best, threshold)), so a linear scan is
+// the same function.  Build-defined detail: exact distance ties go to the lowest target index
+// (the tree's own tie order depends on its build and is not specified by the reference).
+// Normals are inputs (the reference reads them from the trees, solver.cc:67-78; its Hough normal
+// estimation is non-deterministic, normal_computation.cc:82).
+namespace {
+struct Aff2f { float m00, m01, m10, m11, tx, ty; };
+inline Aff2f PoseAffineF(const float *a /* cos sin x y, already cast from double */) {
+  return {a[0], -a[1], a[1], a[0], a[2], a[3]};
+}
+inline Aff2f InverseF(const Aff2f &A) {
+  const float det = A.m00 * A.m11 - A.m10 * A.m01;
+  const float invdet = 1.0f / det;
+  Aff2f R;
+  R.m00 = A.m11 * invdet; R.m10 = -A.m10 * invdet; R.m01 = -A.m01 * invdet; R.m11 = A.m00 * invdet;
+  R.tx = -(R.m00 * A.tx + R.m01 * A.ty);
+  R.ty = -(R.m10 * A.tx + R.m11 * A.ty);
+  return R;
+}
+inline Aff2f MulF(const Aff2f &A, const Aff2f &B) {
+  Aff2f C;
+  C.m00 = A.m00 * B.m00 + A.m01 * B.m10; C.m01 = A.m00 * B.m01 + A.m01 * B.m11;
+  C.m10 = A.m10 * B.m00 + A.m11 * B.m10; C.m11 = A.m10 * B.m01 + A.m11 * B.m11;
+  C.tx = A.m00 * B.tx + A.m01 * B.ty + A.tx;
+  C.ty = A.m10 * B.tx + A.m11 * B.ty + A.ty;
+  return C;
+}
+}  // namespace
+
+extern "C" {
+
+/* (cos, sin, x, y) of a double[3] pose, each cast to float: the entries of
+ * PoseArrayToAffine<double>(pose).cast<float>() (slam_util.h:37-40). */
+void orc_pose_affines(const double *poses, int32_t n, float *out /* 4n */) {
+  for (int32_t i = 0; i < n; i++) {
+    out[4 * i + 0] = (float)std::cos(poses[3 * i + 2]);
+    out[4 * i + 1] = (float)std::sin(poses[3 * i + 2]);
+    out[4 * i + 2] = (float)poses[3 * i + 0];
+    out[4 * i + 3] = (float)poses[3 * i + 1];
+  }
+}
+
+/* One (source, target) block.  corr_out: up to n_src rows of 8 floats (source point, target
+ * point, source normal, target normal -- the layout the residual batch takes); match_idx_out
+ * (optional): target index per kept row.  Returns the number of correspondences. */
+int32_t orc_corr_search_block(const float *src_xy, const float *src_nrm, int32_t n_src,
+                              const float *tgt_xy, const float *tgt_nrm, int32_t n_tgt,
+                              const float *src_aff /*cos sin x y*/, const float *tgt_aff,
+                              float outlier_threshold, float *corr_out, int32_t *match_idx_out) {
+  const Aff2f C = MulF(InverseF(PoseAffineF(tgt_aff)), PoseAffineF(src_aff));
+  int32_t n = 0;
+  for (int32_t p = 0; p < n_src; p++) {
+    const float px = src_xy[2 * p], py = src_xy[2 * p + 1];
+    const float qx = C.m00 * px + C.m01 * py + C.tx;
+    const float qy = C.m10 * px + C.m11 * py + C.ty;
+    float best = 0.f;
+    int32_t bi = -1;
+    for (int32_t t = 0; t < n_tgt; t++) {
+      const float dx = tgt_xy[2 * t] - qx, dy = tgt_xy[2 * t + 1] - qy;
+      const float d2 = dx * dx + dy * dy;  // squaredNorm, individually rounded (no FMA)
+      if (bi < 0 || d2 < best) { best = d2; bi = t; }
+    }
+    if (bi < 0) continue;
+    if (!(std::sqrt(best) < outlier_threshold)) continue;  // dist < CONFIG_outlier_threshold
+    float *c = corr_out + 8 * (size_t)n;
+    c[0] = px; c[1] = py; c[2] = tgt_xy[2 * bi]; c[3] = tgt_xy[2 * bi + 1];
+    c[4] = src_nrm[2 * p]; c[5] = src_nrm[2 * p + 1]; c[6] = tgt_nrm[2 * bi]; c[7] = tgt_nrm[2 * bi + 1];
+    if (match_idx_out) match_idx_out[n] = bi;
+    n++;
+  }
+  return n;
+}
+
+/* Batched driver with the product's layout: scans table + per-block (source scan, target scan). */
+int orc_corr_search_batch(const float *xy, const float *normals, const int32_t *offsets,
+                          const int32_t *block_src, const int32_t *block_tgt, int32_t n_blocks,
+                          const float *pose_aff, float outlier_threshold, const int64_t *cap_offsets,
+                          float *corr, int32_t *counts, int32_t n_threads) {
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 8)
+#endif
+  for (int32_t b = 0; b < n_blocks; b++) {
+    const int32_t s = block_src[b], t = block_tgt[b];
+    counts[b] = orc_corr_search_block(xy + 2 * (size_t)offsets[s], normals + 2 * (size_t)offsets[s],
+                                      offsets[s + 1] - offsets[s], xy + 2 * (size_t)offsets[t],
+                                      normals + 2 * (size_t)offsets[t], offsets[t + 1] - offsets[t],
+                                      pose_aff + 4 * (size_t)s, pose_aff + 4 * (size_t)t, outlier_threshold,
+                                      corr + 8 * (size_t)cap_offsets[b], nullptr);
+  }
+  (void)n_threads;
+  return 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,150 @@
+"""correspondence search (K5) and on-device normal equations.
+K5 parity: matched rows and counts bit-exact against the oracle's restatement of
+Solver::GetPointToPointMatching (solver.cc:132-172) + KDTree::FindNearestPoint (kdtree.cc:253-305);
+the oracle's linear scan is itself checked against scipy's kd-tree (CPU test below)."""
+import math
+
+import numpy as np
+import pytest
+
+from nautilus_amd import _lib, csm, synth
+from oracle import oracle as O
+
+
+def _normals_table(bag):
+    return np.concatenate(bag.normals).astype(np.float32)
+
+
+def test_oracle_linear_scan_equals_kdtree(small_bag):
+    """The restated nearest-neighbour rule agrees with an independent kd-tree (scipy, fp64): same
+    neighbour distances to float rounding, same keep/drop decisions away from the threshold."""
+    from scipy.spatial import cKDTree
+    poses = small_bag.odom
+    aff = O.pose_affines(poses)
+    i, j = 14, 11
+    rows, idx = O.corr_search_block(small_bag.scans[i], small_bag.normals[i], small_bag.scans[j],
+                                    small_bag.normals[j], aff[i], aff[j], 0.25)
+    assert 50 < len(rows) <= len(small_bag.scans[i])
+    ci, si, cj, sj = math.cos(poses[i, 2]), math.sin(poses[i, 2]), math.cos(poses[j, 2]), math.sin(poses[j, 2])
+    p = small_bag.scans[i].astype(np.float64)
+    w = np.stack([ci * p[:, 0] - si * p[:, 1] + poses[i, 0] - poses[j, 0],
+                  si * p[:, 0] + ci * p[:, 1] + poses[i, 1] - poses[j, 1]], 1)
+    q = np.stack([cj * w[:, 0] + sj * w[:, 1], -sj * w[:, 0] + cj * w[:, 1]], 1)
+    dist, k = cKDTree(small_bag.scans[j].astype(np.float64)).query(q)
+    keep = dist < 0.25
+    safe = np.abs(dist - 0.25) > 1e-4
+    kept_src = {tuple(r[:2]) for r in rows}
+    for n in np.nonzero(safe)[0]:
+        assert (tuple(small_bag.scans[i][n]) in kept_src) == bool(keep[n])
+    # matched target of every kept row is a true nearest neighbour (distance equal to float rounding)
+    tgt = small_bag.scans[j].astype(np.float64)
+    src_index = {tuple(pt): n for n, pt in enumerate(small_bag.scans[i])}
+    for r, t in zip(rows, idx):
+        n = src_index[tuple(r[:2])]
+        assert abs(np.linalg.norm(tgt[t] - q[n]) - dist[n]) < 2e-5
+    # rows are in source order, carry the inputs' normals, and tie/empty edge cases behave
+    order = [src_index[tuple(r[:2])] for r in rows]
+    assert order == sorted(order)
+    assert np.array_equal(rows[:, 4:6], small_bag.normals[i][order])
+    assert np.array_equal(rows[:, 6:8], small_bag.normals[j][idx])
+    dup = np.array([[1.0, 1.0], [1.0, 1.0], [1.2, 1.0]], np.float32)  # duplicate target: lowest index wins
+    rr, ii = O.corr_search_block(np.array([[1.0, 1.0]], np.float32), dup[:1], dup, dup, [1, 0, 0, 0], [1, 0, 0, 0])
+    assert list(ii) == [0]
+    rr, ii = O.corr_search_block(np.zeros((0, 2), np.float32), np.zeros((0, 2), np.float32), dup, dup,
+                                 [1, 0, 0, 0], [1, 0, 0, 0])
+    assert len(rr) == 0
+
+
+@pytest.mark.gpu
+def test_corr_search_bit_exact(gpu, small_bag):
+    from nautilus_amd.correspondence import IcpBatch, window_pairs
+    rng = np.random.default_rng(2)
+    poses = small_bag.odom + rng.normal(0, [0.02, 0.02, math.radians(0.3)], small_bag.odom.shape)
+    xy, off = csm.pack_scans(small_bag.scans)
+    nrm = _normals_table(small_bag)
+    bs, bt = window_pairs(small_bag.n_scans, 5)
+    batch = IcpBatch(xy, nrm, off, bs, bt)
+    batch.set_poses(poses)
+    n = batch.search()
+    rows, boff = batch.correspondences()
+    want, counts, cap = O.corr_search_batch(xy, nrm, off, bs, bt, O.pose_affines(poses), 0.25)
+    assert np.array_equal(np.diff(boff), counts) and n == counts.sum() and n > 50000
+    for b in range(len(bs)):
+        assert np.array_equal(rows[boff[b]:boff[b + 1]], want[cap[b]:cap[b] + counts[b]]), b
+    assert np.array_equal(batch.d_cblock[:n].cpu().numpy(), np.repeat(np.arange(len(bs)), counts))
+    # determinism
+    batch.search()
+    rows2, boff2 = batch.correspondences()
+    assert rows2.tobytes() == rows.tobytes() and boff2.tobytes() == boff.tobytes()
+
+
+@pytest.mark.gpu
+def test_corr_search_edge_cases(gpu):
+    """Empty scans, blocks with no match, more than 2048 points (several LDS passes), far-apart poses."""
+    from nautilus_amd.correspondence import IcpBatch
+    rng = np.random.default_rng(5)
+    big = rng.uniform(-5, 5, (4500, 2)).astype(np.float32)
+    scans = [np.zeros((0, 2), np.float32), big, (big + rng.normal(0, 0.05, big.shape)).astype(np.float32)[:3000],
+             np.array([[0.0, 0.0]], np.float32), big[:7] + np.float32(100.0)]
+    normals = [rng.normal(0, 1, s.shape).astype(np.float32) for s in scans]
+    xy, off = csm.pack_scans(scans)
+    nrm = np.concatenate(normals)
+    bs = np.array([0, 1, 2, 1, 3, 4, 1, 2], np.int32)
+    bt = np.array([1, 0, 1, 2, 1, 1, 4, 2], np.int32)
+    poses = np.array([[0, 0, 0], [0.01, -0.02, 0.003], [0, 0, 0.001], [0.5, 0.5, 1.0], [0, 0, 0]], dtype=np.float64)
+    batch = IcpBatch(xy, nrm, off, bs, bt)
+    batch.set_poses(poses)
+    n = batch.search()
+    rows, boff = batch.correspondences()
+    want, counts, cap = O.corr_search_batch(xy, nrm, off, bs, bt, O.pose_affines(poses), 0.25)
+    assert np.array_equal(np.diff(boff), counts)
+    assert counts[0] == 0 and counts[1] == 0 and counts[5] == 0 and counts[2] > 2000 and counts[7] == 3000
+    for b in range(len(bs)):
+        assert np.array_equal(rows[boff[b]:boff[b + 1]], want[cap[b]:cap[b] + counts[b]]), b
+
+
+@pytest.mark.gpu
+def test_search_feeds_residuals_and_normal_equations(gpu, small_bag):
+    """K5 -> K4 without leaving HBM; normal equations == J^T J, J^T r, r^T r of the oracle's
+    autodiff Jacobians on the same correspondences."""
+    from nautilus_amd.correspondence import IcpBatch, window_pairs
+    poses = small_bag.odom.copy()
+    xy, off = csm.pack_scans(small_bag.scans)
+    nrm = _normals_table(small_bag)
+    bs, bt = window_pairs(small_bag.n_scans, 3)
+    batch = IcpBatch(xy, nrm, off, bs, bt)
+    batch.set_poses(poses)
+    n = batch.search()
+    rows, boff = batch.correspondences()
+    for kind in (_lib.NHIP_LIDAR_NORMAL, _lib.NHIP_LIDAR_POINT):
+        res, js, jt = batch.residuals(kind)
+        wr, w0, w1 = O.lidar_batch(kind, rows, boff, bs, bt, poses)
+        assert np.max(np.abs(res.cpu().numpy() - wr)) < 1e-9
+        assert np.max(np.abs(js.cpu().numpy().reshape(-1, 3) - w0)) < 1e-8
+        neq = batch.normal_equations(kind).cpu().numpy()
+        iu = np.triu_indices(6)
+        for b in range(len(bs)):
+            sl = slice(2 * boff[b], 2 * boff[b + 1])
+            J = np.hstack([w0[sl], w1[sl]])
+            H, g, rr = J.T @ J, J.T @ wr[sl], wr[sl] @ wr[sl]
+            scale = max(1.0, np.abs(H).max())
+            assert np.max(np.abs(neq[b, :21] - H[iu])) <= 1e-9 * scale, b
+            assert np.max(np.abs(neq[b, 21:27] - g)) <= 1e-9 * scale and abs(neq[b, 27] - rr) <= 1e-9 * scale
+    # a Gauss-Newton step assembled from the block systems reduces the cost (sanity of the reduction)
+    neq = batch.normal_equations(_lib.NHIP_LIDAR_POINT).cpu().numpy()
+    cost0 = neq[:, 27].sum()
+    N = small_bag.n_scans
+    H, g = np.zeros((3 * N, 3 * N)), np.zeros(3 * N)
+    iu = np.triu_indices(6)
+    for b in range(len(bs)):
+        Hb = np.zeros((6, 6))
+        Hb[iu] = neq[b, :21]
+        Hb = Hb + Hb.T - np.diag(np.diag(Hb))
+        ix = np.r_[3 * bs[b]:3 * bs[b] + 3, 3 * bt[b]:3 * bt[b] + 3]
+        H[np.ix_(ix, ix)] += Hb
+        g[ix] += neq[b, 21:27]
+    H[:3, :3] += np.eye(3) * 1e9  # pose 0 held constant (solver.cc:384-386)
+    step = np.linalg.solve(H + 1e-6 * np.eye(3 * N), -g)
+    batch.set_poses(poses + step.reshape(N, 3))
+    cost1 = batch.normal_equations(_lib.NHIP_LIDAR_POINT).cpu().numpy()[:, 27].sum()
+    assert cost1 < cost0
