@@ -232,6 +232,40 @@ def test_full_size_properties(gpu):
     st.close()
 
 
+def test_random_configuration_sweep(gpu, small_bag):
+    """Seeded sweep over grid geometry, blur, lattice shape, search centre and ragged clouds:
+    every case bit-exact against the oracle (indices, sums, scores)."""
+    rng = np.random.default_rng(20201114)
+    for case in range(24):
+        res = float(rng.choice([0.03, 0.05, 0.1, 0.3]))
+        range_m = float(rng.choice([3.0, 10.0, 30.0]))
+        sigma = float(rng.choice([0.6, 1.0, 2.0, 3.5]))
+        nx = int(rng.choice([1, 3, 21, 81, 85, 97]))
+        ny = int(rng.choice([1, 5, 33, 81, 87, 101]))
+        nth = int(rng.choice([1, 3, 7]))
+        max_shift = max(nx, ny) // 2 + int(rng.integers(0, 12))
+        spec, ospec = _specs(range_m, res, sigma, max_shift)
+        k = int(rng.integers(3, 7))
+        pick = rng.choice(len(small_bag.scans), k, replace=False)
+        scans = []
+        for i in pick:
+            s = small_bag.scans[i]
+            m = int(rng.choice([len(s), 1, 63, 64, 65, 200]))
+            scans.append(s[:m] * np.float32(rng.choice([1.0, 0.3])))  # some clouds shrink into small grids
+        n_pairs = int(rng.integers(1, 9))
+        src = rng.integers(0, k, n_pairs)
+        tgt_ids = np.unique(rng.integers(0, k, max(1, k // 2)))
+        slot = rng.integers(0, len(tgt_ids), n_pairs)
+        th0 = rng.uniform(-math.pi, math.pi, n_pairs)
+        origin = None
+        if rng.random() < 0.5:
+            room_x, room_y = max_shift - nx // 2, max_shift - ny // 2
+            origin = np.stack([rng.integers(-room_x, room_x + 1, n_pairs),
+                               rng.integers(-room_y, room_y + 1, n_pairs)], 1).astype(np.int32)
+        search = csm.search_spec(nth, nx, ny, float(rng.choice([0.5, 1.0, 3.0])) * DEG)
+        _check_pairs(scans, tgt_ids, src, slot, th0, spec, ospec, search, origin)
+
+
 def test_device_pointer_api_on_torch_stream(gpu, small_bag):
     """The *_dev entry points: caller-owned HBM (torch tensors), launched on torch's stream."""
     import torch
