@@ -96,9 +96,6 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 constexpr int FLUSH_POINTS = 255;  // a 16-bit field holds 255 byte values
 constexpr int FLUSH_GROUP = 192;   // points between unpacks: 3 lane-chunks of 64
 static_assert(FLUSH_GROUP <= FLUSH_POINTS && FLUSH_GROUP % 64 == 0, "SWAR fields would overflow");
-#ifndef NHIP_CSM_UNROLL
-#define NHIP_CSM_UNROLL 1  // points read together per iteration; 2-4 measured 0-12 % slower
-#endif
 
 struct Swar {
   uint32_t e[4][8], o[4][8];
@@ -132,16 +129,9 @@ template <int SH>
 __device__ __forceinline__ void swar_pass(Swar &A, const uint8_t *tile_bytes, uint32_t lane_off,
                                           uint32_t vorg, unsigned long long seg_mask) {
   unsigned long long m = __ballot((vorg & 3u) == (uint32_t)SH) & seg_mask;
-  // NHIP_CSM_UNROLL points per iteration: their LDS reads are issued back to back, so the
-  // adds of one point overlap the read latency of the next
-#pragma nounroll
-  while (__builtin_popcountll(m) >= NHIP_CSM_UNROLL) {
-    uint32_t d[NHIP_CSM_UNROLL][8];
-#pragma unroll
-    for (int u = 0; u < NHIP_CSM_UNROLL; u++) swar_load<SH>(d[u], tile_bytes, lane_off, vorg, m);
-#pragma unroll
-    for (int u = 0; u < NHIP_CSM_UNROLL; u++) swar_add<SH>(A, d[u]);
-  }
+  // One point per iteration.  Measured alternatives on gfx950: issuing
+  // the reads of 2-4 points together, or a two-buffer software pipeline, were 0-12 % SLOWER --
+  // they cost registers (occupancy 4 -> 3 waves/SIMD) and the 4 resident waves already overlap.
 #pragma nounroll
   while (m) {
     uint32_t d[8];
@@ -279,18 +269,21 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
           const uint8_t *gsrc = grid + (size_t)t_row0 * P.pitch + t_col0;
           __syncthreads();  // every wave is done with the old tile
           // Fill: 16-byte global loads (14 per 224-byte row span; t_col0 and the pitch are multiples
-          // of 16), 4 in flight per lane, then 4-byte LDS stores (the 212-byte LDS pitch that makes
-          // the reads conflict-free is not a multiple of 16).  Measured against LDS-DMA
+          // of 16), FILL_INFLIGHT per lane at a time, then 4-byte LDS stores (the 212-byte LDS pitch
+          // that makes the reads conflict-free is not a multiple of 16).  Measured against LDS-DMA
           // (global_load_lds_dword, 120 pieces of 256 B per tile, issue-bound): 3.6 % faster.
+          // 2 in flight runs as fast as 4 and keeps the kernel at 127 VGPRs with no scratch
+          // (4 spilled 28 B per lane = 1.5 GB of scratch writes per 10k-pair launch).
           {
             constexpr int ROW_CH = (LP + 15) / 16;  // 14
+            constexpr int FILL_INFLIGHT = 2;
             const int32_t n_ch = fill_rows * ROW_CH;
             int32_t rr = tid / ROW_CH, kk = tid % ROW_CH;
-            for (int32_t c0 = tid; c0 < n_ch; c0 += 4 * CSM_THREADS) {
-              uint4 v[4];
-              int32_t rs[4], ks[4];
+            for (int32_t c0 = tid; c0 < n_ch; c0 += FILL_INFLIGHT * CSM_THREADS) {
+              uint4 v[FILL_INFLIGHT];
+              int32_t rs[FILL_INFLIGHT], ks[FILL_INFLIGHT];
 #pragma unroll
-              for (int u = 0; u < 4; u++) {
+              for (int u = 0; u < FILL_INFLIGHT; u++) {
                 rs[u] = rr;
                 ks[u] = kk;
                 if (c0 + u * CSM_THREADS < n_ch)
@@ -300,7 +293,7 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
                 if (kk >= ROW_CH) { kk -= ROW_CH; rr += 1; }
               }
 #pragma unroll
-              for (int u = 0; u < 4; u++) {
+              for (int u = 0; u < FILL_INFLIGHT; u++) {
                 if (c0 + u * CSM_THREADS < n_ch) {
                   uint32_t *dst = s_tile + rs[u] * LP_DW + 4 * ks[u];
                   dst[0] = v[u].x;
