@@ -36,6 +36,20 @@ def _traffic(key):
         return None
 
 
+def _onchip(n_pairs, n_theta, avg_ms):
+    """LDS-read and VALU-issue utilisation of csm_correlate_kernel from its instruction mix:
+    per point a workgroup (4 waves) reads 8 dwords per lane (4 x 64 x 32 B = 8 KiB of LDS, ds_read2_b32)
+    and issues 40.4 VALU wave-instructions per wave (rocprofv3 SQ_INSTS_VALU, profiles/r01_pmc_sq_correlate.txt).
+    Peaks (MI355X_MICROARCH.md): ds_read_b32 128 B/clk/CU -> ~75 TB/s chip; VALU one wave64 instruction per
+    2 clk per SIMD -> 256 CU x 4 SIMD x 2.4 GHz / 2 = 1.23e12 wave-instructions/s."""
+    points = float(n_pairs) * n_theta * 1081.0
+    secs = avg_ms * 1e-3
+    lds = points * 8192.0 / secs / 1e12
+    valu = points * 4 * 40.4 / secs
+    return {"lds_read_TBps": lds, "lds_read_peak_TBps": 75.0, "lds_frac": lds / 75.0,
+            "valu_wave_instr_per_s": valu, "valu_peak_wave_instr_per_s": 1.2288e12, "valu_frac": valu / 1.2288e12}
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -216,6 +230,9 @@ def main():
                      "note": "algorithmic gather bytes (1 B per grid lookup) / kernel time; the grid is "
                              "cache/LDS-resident, so this exceeds what HBM itself moves (see traffic)"},
         "kernels_ms_per_step": {"csm_correlate": k_ms.value / a.steps, "grid_blur": g_ms.value / a.steps},
+        # what actually bounds the correlate kernel: the tile is LDS-resident, so
+        # the honest ceilings are the LDS read pipe and VALU issue, not HBM.
+        "onchip_roofline": _onchip(n_pairs, search.n_theta, avg_ms),
     }
     if world == 1 and a.cpu_seconds > 0:
         cb, sel, ref = cpu_baseline(bag, xy, off, ids, src, slot, h_th0, a.cpu_seconds)
