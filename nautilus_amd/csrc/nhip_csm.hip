@@ -4,13 +4,13 @@
 // src/optimization/solver.cc:633-638), batched over candidate pairs.
 //
 // Formulation (accumulator-stationary, LDS-tiled): one workgroup owns one rotation k of one
-// pair and keeps an (nx x ny) plane of integer score accumulators in registers -- lane t owns
-// 28 consecutive x-shifts of y-shift t/3.  A point's contribution to the plane is the
+// pair and keeps an (nx x ny) plane of integer score accumulators in registers -- three lanes
+// per y-shift, 28 consecutive x-shifts each, 21 y-shifts per wave.  A point's contribution to the plane is the
 // (nx x ny) window of the target grid anchored at its rotated cell.  Points are visited in
 // beam order; consecutive beams hit neighbouring cells, so a run of points shares one grid
 // tile: the workgroup stages a 144-row x 212-byte tile of the grid in LDS (16-byte reads of
 // HBM/L2, once per run), then every point of the run is a wave-uniform LDS offset (v_readlane)
-// from which each lane reads its 8 aligned dwords and accumulates them SWAR-style (below).
+// from which each lane reads its 7 aligned dwords and accumulates them SWAR-style (below).
 // LDS pitch 53 dwords makes the 32-lane read groups conflict-free (bank = 7 * lane mod 32).
 // All arithmetic is integer: sums are order-independent, hence bit-exact against the oracle.
 //
@@ -23,17 +23,18 @@ namespace nhip {
 namespace {
 
 constexpr int CSM_THREADS = 256;
-constexpr int SEG_DW = 7;                  // dwords of accumulated columns per lane
+constexpr int SEG_DW = 7;                  // aligned dwords a lane reads and accumulates per point
 constexpr int SEG_COLS = 4 * SEG_DW;       // 28 x-shifts per lane
-constexpr int SEGS = 3;                    // lanes per plane row
-constexpr int PB_NX = SEGS * SEG_COLS;     // 84 x-shifts per plane block
-constexpr int PB_NY = CSM_THREADS / SEGS;  // 85 y-shifts per plane block
+constexpr int SEGS = 3;                    // lanes per plane row: 84 aligned bytes >= 81 + 3
+constexpr int WAVE_ROWS = 63 / SEGS;       // 21 plane rows per wave (lane 63 idles: rows never straddle waves)
+constexpr int PB_NX = SEGS * SEG_COLS - 3; // 81 x-shifts per plane block (84 bytes minus alignment slack)
+constexpr int PB_NY = (CSM_THREADS / 64) * WAVE_ROWS;  // 84 y-shifts per plane block
 constexpr int LDS_POINTS = 1152;           // rotated cells staged per pass
 constexpr int LP_DW = 53;                  // LDS tile pitch in dwords (conflict-free: 53 = 21 mod 32)
 constexpr int LP = 4 * LP_DW;              // 212 bytes
 constexpr int TILE_ROWS = 144;
-constexpr int ROW_BYTES = PB_NX + 4;       // bytes of a tile row one point may touch (88)
-constexpr int COL_SPAN = LP - ROW_BYTES;   // max (pcol - tile_col0) of a covered point (124)
+constexpr int ROW_BYTES = SEGS * SEG_COLS; // bytes of a tile row one point touches from its aligned start (84)
+constexpr int COL_SPAN = LP - ROW_BYTES;   // max (pcol - tile_col0) of a covered point (128)
 
 struct CsmParams {
   const float2 *xy;
@@ -86,45 +87,48 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // ---- SWAR byte accumulation -------------------------------------------------------------
 // gfx950 issues plain VOP2 integer ops (v_add_u32, v_and_b32, v_lshrrev_b32) at 2 clk per
 // wave64 but every SDWA / VOP3 form (byte-select adds, v_alignbyte, v_bfe, v_perm, v_add3) at
-// ~4.2 clk (tools/ubench_valu.hip).  So a lane never extracts bytes per point.  It reads its 8
-// ALIGNED dwords w and does, per dword, 4 full-rate ops:
+// ~4.2 clk (tools/ubench_valu.hip).  So a lane never extracts bytes per point.  The three lanes
+// of a plane row read the 21 ALIGNED dwords that start at (window start & ~3) -- 84 bytes, enough
+// for the 81 window columns under any alignment -- 7 dwords each, and do per dword w:
 //     even += w & 0x00FF00FF      (two 16-bit fields: sum b0 | sum b2)
 //     odd  += w >> 8              (= sum b1 + 256 sum b2 + 65536 sum b3, no overflow <= 255 pts)
-// The byte alignment sh = (window start) & 3 is wave-uniform, so points are accumulated into
-// one of four register sets by a scalar branch, and the sets are unpacked (b1/b3 recovered as
-// odd - 256 * sum b2) into the 28 window-relative 32-bit sums every <= 255 points.
+// i.e. 4 full-rate ops per 4 lookups.  The byte alignment s = (window start) & 3 is
+// wave-uniform, so points are accumulated into one of four register sets (one class-filtered
+// sub-loop each) and the sets are unpacked every 192 points into the lane's 28 window-relative
+// 32-bit sums: byte p of a class-s lane is window column 28*seg + p - s, so bytes p < s belong
+// to the left neighbour lane and travel there with one wave shuffle each (6 per unpack).
 constexpr int FLUSH_POINTS = 255;  // a 16-bit field holds 255 byte values
 constexpr int FLUSH_GROUP = 192;   // points between unpacks: 3 lane-chunks of 64
 static_assert(FLUSH_GROUP <= FLUSH_POINTS && FLUSH_GROUP % 64 == 0, "SWAR fields would overflow");
 
 struct Swar {
-  uint32_t e[4][8], o[4][8];
+  uint32_t e[4][SEG_DW], o[4][SEG_DW];
 };
 
 template <int SH>
-__device__ __forceinline__ void swar_add(Swar &A, const uint32_t (&d)[8]) {
+__device__ __forceinline__ void swar_add(Swar &A, const uint32_t (&d)[SEG_DW]) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) {
+  for (int i = 0; i < SEG_DW; i++) {
     A.e[SH][i] += d[i] & 0x00ff00ffu;
     A.o[SH][i] += d[i] >> 8;
   }
 }
 
-// Pop the lowest point of mask m and issue the loads of its 8 aligned dwords.
+// Pop the lowest point of mask m and issue the loads of its 7 aligned dwords.
 template <int SH>
-__device__ __forceinline__ void swar_load(uint32_t (&d)[8], const uint8_t *tile_bytes,
+__device__ __forceinline__ void swar_load(uint32_t (&d)[SEG_DW], const uint8_t *tile_bytes,
                                           uint32_t lane_off, uint32_t vorg, unsigned long long &m) {
   const int jj = (int)__builtin_ctzll(m);
   m &= m - 1ull;
   const uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int32_t)vorg, jj);
   const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_bytes + (org - SH) + lane_off);
 #pragma unroll
-  for (int i = 0; i < 8; i++) d[i] = p[i];
+  for (int i = 0; i < SEG_DW; i++) d[i] = p[i];
 }
 
 // All points of the current run segment (lanes in seg_mask) whose window start has byte
 // alignment SH: the point's LDS offset is read from its lane (wave-uniform), every lane loads
-// its 8 aligned dwords and accumulates them into register set SH.
+// its 7 aligned dwords and accumulates them into register set SH.
 template <int SH>
 __device__ __forceinline__ void swar_pass(Swar &A, const uint8_t *tile_bytes, uint32_t lane_off,
                                           uint32_t vorg, unsigned long long seg_mask) {
@@ -134,7 +138,7 @@ __device__ __forceinline__ void swar_pass(Swar &A, const uint8_t *tile_bytes, ui
   // they cost registers (occupancy 4 -> 3 waves/SIMD) and the 4 resident waves already overlap.
 #pragma nounroll
   while (m) {
-    uint32_t d[8];
+    uint32_t d[SEG_DW];
     swar_load<SH>(d, tile_bytes, lane_off, vorg, m);
     swar_add<SH>(A, d);
   }
@@ -144,15 +148,18 @@ __device__ __forceinline__ void swar_clear(Swar &A) {
 #pragma unroll
   for (int s = 0; s < 4; s++)
 #pragma unroll
-    for (int i = 0; i < 8; i++) A.e[s][i] = A.o[s][i] = 0;
+    for (int i = 0; i < SEG_DW; i++) A.e[s][i] = A.o[s][i] = 0;
 }
 
-// acc[j] += byte sums; byte b of aligned dword i of class s is window column 4*i + b - s.
-__device__ __forceinline__ void swar_flush(Swar &A, uint32_t (&acc)[SEG_COLS]) {
+// acc[j] += byte sums.  Byte p = 4*i + k of a class-s lane is window column 28*seg + p - s:
+// p >= s lands in this lane's acc[p - s]; p < s (at most 3 bytes per class) is column
+// 28*seg - (s - p), i.e. acc[28 - (s - p)] of lane - 1, which reads it with a shuffle from
+// lane + 1 (same plane row: rows never straddle waves; segment-2 lanes have no right neighbour).
+__device__ __forceinline__ void swar_flush(Swar &A, uint32_t (&acc)[SEG_COLS], bool has_right) {
 #pragma unroll
   for (int s = 0; s < 4; s++) {
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < SEG_DW; i++) {
       const uint32_t ev = A.e[s][i];
       const uint32_t b0 = ev & 0xffffu, b2 = ev >> 16;
       const uint32_t od = A.o[s][i] - (b2 << 8);
@@ -160,8 +167,13 @@ __device__ __forceinline__ void swar_flush(Swar &A, uint32_t (&acc)[SEG_COLS]) {
       const uint32_t b[4] = {b0, b1, b2, b3};
 #pragma unroll
       for (int k = 0; k < 4; k++) {
-        const int j = 4 * i + k - s;
-        if (j >= 0 && j < SEG_COLS) acc[j] += b[k];
+        const int p = 4 * i + k;
+        if (p >= s) {
+          acc[p - s] += b[k];
+        } else {
+          const uint32_t from_right = (uint32_t)__shfl_down((int)b[k], 1, 64);
+          acc[SEG_COLS - (s - p)] += has_right ? from_right : 0u;
+        }
       }
     }
   }
@@ -218,7 +230,11 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   const float sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
 
   const int tid = threadIdx.x, lane = tid & 63;
-  const int dy = tid / SEGS, seg = tid % SEGS;
+  // wave w owns plane rows [21 w, 21 w + 21): lane = 3 * (row in wave) + segment, lane 63 idles
+  const int lane_c = lane < 63 ? lane : 62;
+  const int dy = (tid >> 6) * WAVE_ROWS + lane_c / SEGS, seg = lane_c % SEGS;
+  const bool lane_live = lane < 63;
+  const bool has_right = lane_live && seg < SEGS - 1;  // lane + 1 holds the next 28 bytes of the same row
   // lanes past the plane block's rows re-read row 0 (their sums are never used)
   const int dyc = (dy < nyb) ? dy : 0;
   const uint32_t lane_off = (uint32_t)(dyc * LP + seg * SEG_COLS);
@@ -319,18 +335,19 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
         j = e;
       }
     }
-    swar_flush(A, acc);
+    swar_flush(A, acc, has_right);
     }
   }
 
   const int32_t iy = oy + dy;
-  const bool row_ok = dy < nyb;
+  const bool row_ok = lane_live && dy < nyb;
   if (VOLUME) {
     if (row_ok) {
 #pragma unroll
       for (int i = 0; i < SEG_COLS; i++) {
         const int32_t ix = ox + seg * SEG_COLS + i;
-        if (ix < P.nx) P.volume[((size_t)k * P.nx + ix) * P.ny + iy] = (int32_t)acc[i];
+        if (seg * SEG_COLS + i < PB_NX && ix < P.nx)
+          P.volume[((size_t)k * P.nx + ix) * P.ny + iy] = (int32_t)acc[i];
       }
     }
     return;
@@ -342,7 +359,7 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
 #pragma unroll
     for (int i = 0; i < SEG_COLS; i++) {
       const int32_t ix = ox + seg * SEG_COLS + i;
-      if (ix < P.nx) {
+      if (seg * SEG_COLS + i < PB_NX && ix < P.nx) {
         const uint32_t lin = (uint32_t)((k * P.nx + ix) * P.ny + iy);
         const unsigned long long key = ((unsigned long long)acc[i] << 32) | (0xffffffffu - lin);
         best = key > best ? key : best;
