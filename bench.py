@@ -244,7 +244,7 @@ def main():
             print("PARITY FAILURE: GPU result differs from the oracle on the cpu_baseline sample", file=sys.stderr)
     if world == 1 and not a.no_resid:
         try:
-            out["secondary"] = {"resid_lidar": bench_residuals(torch, lib, dev, sp)}
+            out["secondary"] = {"resid_lidar": bench_residuals(torch, lib, dev, sp, a.cpu_seconds > 0)}
         except Exception as e:  # secondary measurement must not lose the headline line
             out["secondary"] = {"resid_lidar_error": repr(e)}
         try:
@@ -258,7 +258,7 @@ def main():
         dist.destroy_process_group()
 
 
-def bench_residuals(torch, lib, dev, sp, n_blocks=9945, n_per=1081, iters=20):
+def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=1081, iters=20):
     """BASELINE configs[2] shape: 9,945 (i, j) blocks x 1081 correspondences, residual + both
     Jacobians (144 B per correspondence), synthetic correspondences already in HBM."""
     from nautilus_amd import _lib
@@ -292,11 +292,28 @@ def bench_residuals(torch, lib, dev, sp, n_blocks=9945, n_per=1081, iters=20):
     avg = ms.value / max(n.value, 1)
     bytes_alg = 144.0 * n_corr
     gbs = bytes_alg / (avg * 1e-3) / 1e9
-    return {"workload": "configs[2]: %d blocks x %d correspondences, LIDARNormal residual + 2 Jacobians" % (n_blocks, n_per),
-            "correspondences_per_s": n_corr / (avg * 1e-3), "avg_launch_ms": avg,
-            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic("resid_lidar_bytes_per_launch_%dcorr" % n_corr),
-                         "algorithmic_bytes_per_launch": bytes_alg}}
+    out = {"workload": "configs[2]: %d blocks x %d correspondences, LIDARNormal residual + 2 Jacobians" % (n_blocks, n_per),
+           "correspondences_per_s": n_corr / (avg * 1e-3), "avg_launch_ms": avg,
+           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic("resid_lidar_bytes_per_launch_%dcorr" % n_corr),
+                        "algorithmic_bytes_per_launch": bytes_alg}}
+    if with_cpu:
+        # CPU side of the same blocks: the oracle's Jet<6> autodiff restatement (what
+        # ceres::AutoDiffCostFunction does per block), blocks across OpenMP threads like Ceres' num_threads.
+        from oracle import oracle as O
+        k = min(n_blocks, 8 * O.num_threads())
+        h_corr = corr[:k * n_per].cpu().numpy()
+        h_off = np.arange(k + 1, dtype=np.int32) * n_per
+        h_bs, h_bt, h_poses = bs[:k].cpu().numpy(), bt[:k].cpu().numpy(), poses.cpu().numpy()
+        t0 = time.perf_counter()
+        wr, w0, w1 = O.lidar_batch(0, h_corr, h_off, h_bs, h_bt, h_poses, True, O.num_threads())
+        dt = time.perf_counter() - t0
+        ok = bool(np.allclose(res[:2 * k * n_per].cpu().numpy(), wr, rtol=1e-9, atol=1e-9) and
+                  np.allclose(js[:6 * k * n_per].cpu().numpy().reshape(-1, 3), w0, rtol=1e-9, atol=1e-8))
+        out["cpu_baseline"] = {"value": k * n_per / dt, "unit": "correspondences/s", "cores": O.num_threads(), "kind": "port",
+                               "sample": "%d blocks x %d, Jet<6> autodiff restatement, OpenMP over blocks" % (k, n_per),
+                               "gpu_matches_oracle_on_sample": ok}
+    return out
 
 
 def bench_icp(bag, xy, off, with_cpu, window=10, iters=5):
