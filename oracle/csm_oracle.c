@@ -67,6 +67,10 @@ int32_t orc_grid_side(double range, double res) {
  * drops them by the `x >= width` test, cimg_debug.h:48-50; signed + range test is the
  * same predicate). */
 static inline int64_t orc_cell(float v, double res, int32_t S) {
+  /* NaN / inf / absurd coordinates: the reference's float->uint64 conversion is undefined there
+   * (and lands out of range in practice); they are off-grid: dropped from a target raster,
+   * contributing only floor cells as a source point. */
+  if (!(fabsf(v) < 1e9f)) return INT64_MIN / 4;
   return (int64_t)(S / 2) + (int64_t)floor((double)v / res);
 }
 

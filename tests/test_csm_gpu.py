@@ -132,6 +132,22 @@ def test_ragged_empty_and_out_of_grid(gpu, small_bag):
     assert got[0]["score"] == np.float32(math.log(1e-10))
 
 
+def test_non_finite_points_are_off_grid(gpu, small_bag):
+    """NaN / inf / absurd coordinates (a broken range reading) never fault and never score: dropped
+    from a target raster, floor-only as source points -- same answer as the oracle."""
+    bad = small_bag.scans[7].copy()
+    bad[5] = (np.nan, 1.0)
+    bad[6] = (2.0, np.inf)
+    bad[7] = (-np.inf, np.nan)
+    bad[8] = (1e12, -1e12)
+    bad[9] = (3e38, 0.0)
+    scans = [bad, small_bag.scans[9], np.full((3, 2), np.nan, np.float32)]
+    spec, ospec = _specs(max_shift=8)
+    got, want = _check_pairs(scans, [0, 1, 2], [0, 1, 2, 1, 0], [1, 0, 1, 2, 0], np.zeros(5), spec, ospec,
+                             csm.search_spec(5, 17, 17, 2 * DEG))
+    assert want["sum"][2] == 0 and want["sum"][3] == 0  # all-NaN source / all-NaN target score nothing
+
+
 def test_rotation_wraparound(gpu, small_bag):
     """theta0 near +-pi, where AngleMod (math_util.h:81-84) wraps."""
     spec, ospec = _specs(max_shift=6)
