@@ -1,0 +1,88 @@
+"""Host-side callers and file formats either side of the hot path.
+These stay on the host in the reference as well; they are restated here so the examples and the
+end-to-end test can be driven the way nautilus drives them.  Nothing here is on the measured path.
+
+  LCCandidateFilter::GetLCCandidates      /root/reference/src/loop_closure/lc_candidate_filter.cc:35-81
+  pose file  "timestamp x y theta"        written solver.cc:565-579, read back main.cc:131-157
+  map file   "x1,y1,x2,y2" per line       solver.cc:608-618
+  HitlSlamInputMsg (two line segments)    msg/HitlSlamInputMsg.msg:1-4, solver.cc:467-478
+"""
+import numpy as np
+
+
+def scatter_matrix_score(points):
+    """min/max eigenvalue of the scan's scatter matrix, float32 like the reference (:35-51)."""
+    p = np.asarray(points, dtype=np.float32).reshape(-1, 2)
+    if len(p) == 0:
+        return float("nan")
+    mean = (np.float32(1.0 / len(p)) * p.sum(axis=0, dtype=np.float32)).astype(np.float32)
+    d = p - mean
+    s = (d[:, :, None] * d[:, None, :]).sum(axis=0, dtype=np.float32)
+    ev = np.linalg.eigvals(s.astype(np.float32)).real
+    return float(min(ev) / max(ev))
+
+
+def lc_candidates(poses, scans, min_distance=5.0, min_score=0.70):
+    """GetLCCandidates (:64-81): walk the nodes in order, skip nodes closer than 5 m to the last
+    accepted scan, accept a node if its scatter score is >= 0.70."""
+    out = []
+    for i in range(len(scans)):
+        if out:
+            last = np.asarray(poses[out[-1]][:2], dtype=np.float32)
+            here = np.asarray(poses[i][:2], dtype=np.float32)
+            if float(np.linalg.norm(here - last)) < min_distance:
+                continue
+        if scatter_matrix_score(scans[i]) >= min_score:
+            out.append(i)
+    return out
+
+
+def write_poses(path, timestamps, poses):
+    """solver.cc:573-577: std::fixed (6 decimals) 'timestamp x y theta' per node."""
+    with open(path, "w") as f:
+        for t, p in zip(timestamps, poses):
+            f.write("%.6f %.6f %.6f %.6f\n" % (t, p[0], p[1], p[2]))
+
+
+def read_poses(path):
+    """main.cc:139-146: whitespace-separated double timestamp + three floats; returns {timestamp: pose}."""
+    out = {}
+    with open(path) as f:
+        for line in f:
+            parts = line.split()
+            if len(parts) < 4:
+                break
+            out[float(parts[0])] = np.array([np.float32(parts[1]), np.float32(parts[2]), np.float32(parts[3])], dtype=np.float32)
+    return out
+
+
+def load_solution(path, timestamps, poses):
+    """LoadSolutionFromFile (main.cc:131-157): overwrite poses whose (6-decimal) timestamp is in the file."""
+    table = read_poses(path)
+    poses = np.array(poses, dtype=np.float64)
+    missing = []
+    for i, t in enumerate(timestamps):
+        key = float("%.6f" % t)
+        if key in table:
+            poses[i] = table[key]
+        else:
+            missing.append(i)
+    return poses, missing
+
+
+def write_map_lines(path, lines):
+    """solver.cc:612-616: 'x1,y1,x2,y2' per vectorised map line (default ostream precision: 6 significant)."""
+    with open(path, "w") as f:
+        for l in lines:
+            f.write("%g,%g,%g,%g\n" % (l[0], l[1], l[2], l[3]))
+
+
+def read_map_lines(path):
+    return np.array([[float(v) for v in line.split(",")] for line in open(path) if line.strip()], dtype=np.float64).reshape(-1, 4)
+
+
+def hitl_segments(msg):
+    """LineSegmentsFromHitlMsg (solver.cc:467-478): msg = dict with line_a_start, line_a_end, line_b_start,
+    line_b_end, each (x, y[, z]) -> two LineSegment<float> as (x0, y0, x1, y1) float32 rows."""
+    row = lambda a, b: [msg[a][0], msg[a][1], msg[b][0], msg[b][1]]
+    return np.array([row("line_a_start", "line_a_end"), row("line_b_start", "line_b_end")], dtype=np.float32)

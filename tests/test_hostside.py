@@ -1,0 +1,35 @@
+"""Host-side callers / formats around the path: CPU only."""
+import numpy as np
+
+from nautilus_amd import hostside, synth
+
+
+def test_scatter_score_and_candidates():
+    line = np.stack([np.linspace(0, 5, 200), np.zeros(200)], 1)          # degenerate: a single wall
+    box = np.random.default_rng(0).uniform(-3, 3, (500, 2))               # spread in both axes
+    assert hostside.scatter_matrix_score(line) < 1e-6
+    assert hostside.scatter_matrix_score(box) > 0.7
+    poses = np.array([[0, 0, 0], [1, 0, 0], [6, 0, 0], [7, 0, 0], [12, 1, 0]], dtype=float)
+    scans = [box, box, line, box, box]
+    # node 1 is < 5 m from node 0; node 2 is far enough but a bad scan; node 3 is accepted; node 4: 5.1 m on
+    assert hostside.lc_candidates(poses, scans) == [0, 3, 4]
+    bag = synth.SynthBag(60)
+    c = hostside.lc_candidates(bag.truth, bag.scans)
+    assert all(np.linalg.norm(bag.truth[b, :2] - bag.truth[a, :2]) >= 5.0 for a, b in zip(c, c[1:]))
+
+
+def test_pose_and_map_files_roundtrip(tmp_path):
+    ts = [1583000000.123456, 1583000000.223456, 1583000001.0]
+    poses = np.array([[0.5, -1.25, 0.1], [1.5, 2.0, -3.0], [100.0, 0.0, 3.14159]])
+    p = tmp_path / "poses.txt"
+    hostside.write_poses(p, ts, poses)
+    first = open(p).readline().split()
+    assert first == ["1583000000.123456", "0.500000", "-1.250000", "0.100000"]   # std::fixed, solver.cc:573-577
+    got, missing = hostside.load_solution(p, ts + [5.0], np.zeros((4, 3)))
+    assert missing == [3] and np.allclose(got[:3], poses, atol=1e-6)
+    m = tmp_path / "map.txt"
+    hostside.write_map_lines(m, [[0, 0, 1.5, 2], [-3.25, 4, 5, 6]])
+    assert open(m).readline().strip() == "0,0,1.5,2"
+    assert np.allclose(hostside.read_map_lines(m), [[0, 0, 1.5, 2], [-3.25, 4, 5, 6]])
+    seg = hostside.hitl_segments({"line_a_start": (0, 0, 0), "line_a_end": (2, 2, 0), "line_b_start": (1, 0), "line_b_end": (1, 5)})
+    assert seg.dtype == np.float32 and seg.tolist() == [[0, 0, 2, 2], [1, 0, 1, 5]]
