@@ -132,6 +132,18 @@ def test_ragged_empty_and_out_of_grid(gpu, small_bag):
     assert got[0]["score"] == np.float32(math.log(1e-10))
 
 
+def test_long_clouds_cross_staging_batches(gpu, small_bag):
+    """Source clouds longer than one LDS batch of rotated cells (1152 points) and longer than the
+    16-bit SWAR unpack interval many times over; targets with several thousand points."""
+    long_a = np.concatenate([small_bag.scans[3], small_bag.scans[4] + np.float32(0.02), small_bag.scans[5]])
+    long_b = np.concatenate([small_bag.scans[i] for i in (6, 7, 8, 9, 10)])
+    assert len(long_a) > 2 * 1152 and len(long_b) > 4000
+    spec, ospec = _specs(max_shift=12)
+    got, want = _check_pairs([long_a, long_b, small_bag.scans[3]], [0, 1, 2], [0, 1, 0, 1, 2], [2, 2, 1, 0, 1],
+                             [0.0, 0.05, -0.04, 0.1, 0.0], spec, ospec, csm.search_spec(7, 25, 25, DEG))
+    assert want["sum"].max() > 255 * 1152  # sums beyond what a single unpack interval could hold
+
+
 def test_non_finite_points_are_off_grid(gpu, small_bag):
     """NaN / inf / absurd coordinates (a broken range reading) never fault and never score: dropped
     from a target raster, floor-only as source points -- same answer as the oracle."""
@@ -280,6 +292,34 @@ def test_random_configuration_sweep(gpu, small_bag):
                                rng.integers(-room_y, room_y + 1, n_pairs)], 1).astype(np.int32)
         search = csm.search_spec(nth, nx, ny, float(rng.choice([0.5, 1.0, 3.0])) * DEG)
         _check_pairs(scans, tgt_ids, src, slot, th0, spec, ospec, search, origin)
+
+
+def test_drop_in_class_matches_oracle_two_level_search(gpu, small_bag):
+    """CorrelativeScanMatcher(30, 2, 0.3, 0.01).GetTransformation(...) as solver.cc:633-638 calls it:
+    the coarse (0.3 m) then fine (0.01 m, 6000 x 6000 grid) exhaustive searches of the drop-in class,
+    against the same two searches run on the CPU oracle."""
+    a, b = small_bag.scans[17][::3], small_bag.scans[15][::3]   # thinned: the 0.01 m oracle grid is 36 MB
+    rot_a, rot_b = small_bag.odom[17, 2], small_bag.odom[15, 2]
+    m = csm.CorrelativeScanMatcher(30, 2, 0.3, 0.01)
+    score, ((tx, ty), th) = m.GetTransformation(a, b, rot_a, rot_b, math.radians(90))
+    # oracle, level 1
+    theta0 = float(csm.angle_mod(np.float64(rot_a) - np.float64(rot_b)))
+    g1s = O.grid_spec(30.0, 0.3, 2.0, 1e-10)
+    s1 = O.search_spec(181, 13, 13, math.radians(1.0))
+    m1 = O.csm_match(a, O.grid_build(b, g1s), g1s, theta0, s1)
+    tx1 = np.float32((m1.ix - 6) * 0.3)
+    ty1 = np.float32((m1.iy - 6) * 0.3)
+    th1 = np.float32(theta0 + (m1.itheta - 90) * math.radians(1.0))
+    # level 2 around the coarse optimum
+    cx, cy = int(round(float(tx1) / 0.01)), int(round(float(ty1) / 0.01))
+    g2s = O.grid_spec(30.0, 0.01, 2.0, 1e-10)
+    s2 = O.search_spec(21, 61, 61, math.radians(1.0) / 10)
+    m2 = O.csm_match(a, O.grid_build(b, g2s), g2s, float(th1), s2, (cx, cy))
+    assert tx == np.float32((cx + m2.ix - 30) * 0.01) and ty == np.float32((cy + m2.iy - 30) * 0.01)
+    assert th == np.float32(float(th1) + (m2.itheta - 10) * (math.radians(1.0) / 10))
+    assert np.float32(score) == np.float32(m2.score)
+    gx, gy, gth = small_bag.true_relative(17, 15)
+    assert abs(tx - gx) < 0.06 and abs(ty - gy) < 0.06 and abs(th - gth) < 0.02
 
 
 def test_device_pointer_api_on_torch_stream(gpu, small_bag):
