@@ -105,42 +105,64 @@ struct Swar {
   uint32_t e[4][SEG_DW], o[4][SEG_DW];
 };
 
+// Add one point's pre-split dwords into register set SH (14 full-rate adds).
 template <int SH>
-__device__ __forceinline__ void swar_add(Swar &A, const uint32_t (&d)[SEG_DW]) {
+__device__ __forceinline__ void swar_add(Swar &A, const uint32_t (&te)[SEG_DW], const uint32_t (&to)[SEG_DW]) {
 #pragma unroll
   for (int i = 0; i < SEG_DW; i++) {
-    A.e[SH][i] += d[i] & 0x00ff00ffu;
-    A.o[SH][i] += d[i] >> 8;
+    A.e[SH][i] += te[i];
+    A.o[SH][i] += to[i];
   }
 }
 
-// Pop the lowest point of mask m and issue the loads of its 7 aligned dwords.
+// n members of the group share class SH: the 14 plain (full-rate) adds, n times.  The empty
+// volatile asm keeps the loop a loop: without it hipcc rewrites it as acc += n * t with
+// v_mad_u32_u24, a half-rate VOP3 that costs twice as much in the common n == 1 case
+// (and an explicit n == 1 / n > 1 branch pair blows the register allocation: 44 B of scratch).
 template <int SH>
-__device__ __forceinline__ void swar_load(uint32_t (&d)[SEG_DW], const uint8_t *tile_bytes,
-                                          uint32_t lane_off, uint32_t vorg, unsigned long long &m) {
-  const int jj = (int)__builtin_ctzll(m);
-  m &= m - 1ull;
-  const uint32_t org = (uint32_t)__builtin_amdgcn_readlane((int32_t)vorg, jj);
-  const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_bytes + (org - SH) + lane_off);
-#pragma unroll
-  for (int i = 0; i < SEG_DW; i++) d[i] = p[i];
+__device__ __forceinline__ void swar_add_n(Swar &A, const uint32_t (&te)[SEG_DW], const uint32_t (&to)[SEG_DW], int n) {
+#pragma nounroll
+  for (int r = 0; r < n; r++) {
+    asm volatile("" ::: "memory");
+    swar_add<SH>(A, te, to);
+  }
 }
 
-// All points of the current run segment (lanes in seg_mask) whose window start has byte
-// alignment SH: the point's LDS offset is read from its lane (wave-uniform), every lane loads
-// its 7 aligned dwords and accumulates them into register set SH.
-template <int SH>
-__device__ __forceinline__ void swar_pass(Swar &A, const uint8_t *tile_bytes, uint32_t lane_off,
-                                          uint32_t vorg, unsigned long long seg_mask) {
-  unsigned long long m = __ballot((vorg & 3u) == (uint32_t)SH) & seg_mask;
-  // One point per iteration.  Measured alternatives on gfx950: issuing
-  // the reads of 2-4 points together, or a two-buffer software pipeline, were 0-12 % SLOWER --
-  // they cost registers (occupancy 4 -> 3 waves/SIMD) and the 4 resident waves already overlap.
+// All points of the current run segment (lanes in seg_mask), grouped by ALIGNED BASE.
+// Points whose window starts fall in the same aligned dword of the same tile row read the very
+// same 7 dwords and differ only in their alignment class -- and consecutive beams land in
+// neighbouring cells, so on the 1081-beam scans only ~47 % of the points have a base of their
+// own.  One ballot finds every lane of the segment that shares the lowest live lane's base; the
+// dwords are read and split (w & 0x00FF00FF, w >> 8) ONCE per group and then added into each
+// member's class set.  Measured alternatives: one point per iteration
+// (no grouping) 79k pairs/s; reading 2-4 points together or a two-buffer software pipeline were
+// 0-12 % slower than that (registers cost occupancy; the 4 resident waves already overlap).
+__device__ __forceinline__ void swar_segment(Swar &A, const uint8_t *tile_bytes, uint32_t lane_off,
+                                             uint32_t vorg, unsigned long long seg_mask) {
+  const uint32_t vbase = vorg & ~3u, vcls = vorg & 3u;
+  const unsigned long long cm0 = __ballot(vcls == 0u), cm1 = __ballot(vcls == 1u), cm2 = __ballot(vcls == 2u);
+  unsigned long long m = seg_mask;
 #pragma nounroll
   while (m) {
-    uint32_t d[SEG_DW];
-    swar_load<SH>(d, tile_bytes, lane_off, vorg, m);
-    swar_add<SH>(A, d);
+    const int jj = (int)__builtin_ctzll(m);
+    const uint32_t base = (uint32_t)__builtin_amdgcn_readlane((int32_t)vbase, jj);
+    const unsigned long long same = __ballot(vbase == base) & m;  // includes lane jj
+    m &= ~same;
+    const uint32_t *p = reinterpret_cast<const uint32_t *>(tile_bytes + base + lane_off);
+    uint32_t te[SEG_DW], to[SEG_DW];
+#pragma unroll
+    for (int i = 0; i < SEG_DW; i++) {
+      const uint32_t w = p[i];
+      te[i] = w & 0x00ff00ffu;
+      to[i] = w >> 8;
+    }
+    const int n0 = __builtin_popcountll(same & cm0), n1 = __builtin_popcountll(same & cm1);
+    const int n2 = __builtin_popcountll(same & cm2);
+    const int n3 = __builtin_popcountll(same) - n0 - n1 - n2;
+    swar_add_n<0>(A, te, to, n0);
+    swar_add_n<1>(A, te, to, n1);
+    swar_add_n<2>(A, te, to, n2);
+    swar_add_n<3>(A, te, to, n3);
   }
 }
 
@@ -324,14 +346,11 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
           miss = ~__ballot(cov) & from_j;
           e = miss ? (int32_t)__builtin_ctzll(miss) : n;  // > j: the new tile covers point j
         }
-        // points j..e-1 are covered: LDS byte offset of each lane's window start, then one
-        // sub-pass per alignment class (each touches only its own SWAR register set)
+        // points j..e-1 are covered: LDS byte offset of each lane's window start, then the
+        // grouped SWAR accumulation
         const uint32_t vorg = (uint32_t)(vrow - t_row0) * LP + (uint32_t)(vcol - t_col0);
         const unsigned long long seg_mask = (e == 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << j) - 1ull);
-        swar_pass<0>(A, tile_bytes, lane_off, vorg, seg_mask);
-        swar_pass<1>(A, tile_bytes, lane_off, vorg, seg_mask);
-        swar_pass<2>(A, tile_bytes, lane_off, vorg, seg_mask);
-        swar_pass<3>(A, tile_bytes, lane_off, vorg, seg_mask);
+        swar_segment(A, tile_bytes, lane_off, vorg, seg_mask);
         j = e;
       }
     }
