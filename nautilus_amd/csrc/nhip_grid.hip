@@ -27,12 +27,13 @@ struct GridKernelTables {
 // One block per target scan: mark the cells that contain at least one point.
 __global__ __launch_bounds__(256) void grid_raster_kernel(
     const float2 *__restrict__ xy, const int32_t *__restrict__ offsets,
-    const int32_t *__restrict__ target_ids, int32_t t0, uint8_t *__restrict__ H, int32_t S,
-    double res) {
+    const int32_t *__restrict__ target_ids, int32_t t0, uint8_t *__restrict__ H,
+    uint8_t *__restrict__ occ, int32_t S, int32_t tiles, int32_t R, double res) {
   const int32_t t = blockIdx.x;
   const int32_t scan = target_ids[t0 + t];
   const int32_t beg = offsets[scan], end = offsets[scan + 1];
   uint8_t *h = H + (size_t)t * S * S;
+  uint8_t *o = occ + (size_t)t * tiles * tiles;
   const long half = S / 2;
   for (int32_t p = beg + threadIdx.x; p < end; p += blockDim.x) {
     const float2 q = xy[p];
@@ -42,12 +43,18 @@ __global__ __launch_bounds__(256) void grid_raster_kernel(
     const long r = half + (long)floor((double)q.y / res);
     if (c < 0 || c >= S || r < 0 || r >= S) continue;  // cimg_debug.h:48-50
     h[(size_t)r * S + c] = 1;
+    // tiles whose (tile + blur halo) contains this cell: at most 2 x 2 (R <= 16 < TILE)
+    const int tx0 = (int)max(c - R, 0l) / TILE, tx1 = (int)min(c + R, (long)S - 1) / TILE;
+    const int ty0 = (int)max(r - R, 0l) / TILE, ty1 = (int)min(r + R, (long)S - 1) / TILE;
+    for (int ty = ty0; ty <= ty1; ty++)
+      for (int tx = tx0; tx <= tx1; tx++) o[ty * tiles + tx] = 1;
   }
 }
 
 // 64x64 output tile per block: H tile (+halo) -> LDS, horizontal pass -> LDS, vertical
 // pass + quantise -> padded grid.  Grid memory is pre-zeroed; empty tiles return early.
 __global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restrict__ H,
+                                                        const uint8_t *__restrict__ occ,
                                                         uint8_t *__restrict__ grids, int32_t S,
                                                         int32_t pad, int32_t pitch, int64_t grid_bytes,
                                                         int32_t R, GridKernelTables tab) {
@@ -55,6 +62,8 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restric
   __shared__ uint32_t sV[TH_MAX][TILE + 1];
   __shared__ uint32_t sThr[256];
   const int32_t t = blockIdx.z;
+  // ~95 % of the tiles of a scan's grid see no hit within their halo: leave before touching H
+  if (!occ[((size_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
   const int32_t r0 = blockIdx.y * TILE, c0 = blockIdx.x * TILE;
   const uint8_t *h = H + (size_t)t * S * S;
   uint8_t *g = grids + (size_t)t * grid_bytes;
@@ -114,7 +123,8 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
   NHIP_REQUIRE(L.R <= MAX_R, "grid_build: blur radius %d > %d (sigma too large)", L.R, MAX_R);
   NHIP_REQUIRE(L.K * L.K < (1ll << 32), "grid_build: tap sum overflows 32-bit accumulation");
   NHIP_REQUIRE(L.pitch % 4 == 0, "grid_build: pitch must be a multiple of 4");
-  const int64_t per = (int64_t)L.S * L.S;
+  const int tiles = (L.S + TILE - 1) / TILE;
+  const int64_t per = (int64_t)L.S * L.S + (int64_t)tiles * tiles;  // hit raster + tile occupancy
   const int64_t chunk = ws_bytes / per;
   NHIP_REQUIRE(chunk >= 1, "grid_build: workspace %lld B < one hit raster (%lld B)",
                (long long)ws_bytes, (long long)per);
@@ -125,18 +135,18 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
   memset(&kt, 0, sizeof(kt));
   for (int i = 0; i <= 2 * L.R; i++) kt.taps[i] = T.taps[i];
   for (int i = 0; i < 256; i++) kt.thr[i] = T.thr[i];
-  const int tiles = (L.S + TILE - 1) / TILE;
   for (int64_t t0 = 0; t0 < n_targets; t0 += chunk) {
     const int32_t n = (int32_t)((n_targets - t0 < chunk) ? (n_targets - t0) : chunk);
     uint8_t *H = static_cast<uint8_t *>(d_ws);
+    uint8_t *occ = H + (size_t)n * L.S * L.S;
     uint8_t *g = d_grids + (size_t)t0 * L.grid_bytes;
-    NHIP_TRY_HIP(hipMemsetAsync(H, 0, (size_t)n * per, s));
+    NHIP_TRY_HIP(hipMemsetAsync(H, 0, (size_t)n * per, s));  // raster and occupancy in one fill
     NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.grid_bytes, s));
     hipLaunchKernelGGL(grid_raster_kernel, dim3(n), dim3(256), 0, s,
                        reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
-                       (int32_t)t0, H, L.S, spec->res);
+                       (int32_t)t0, H, occ, L.S, tiles, L.R, spec->res);
     timer_begin(NHIP_TIMER_GRID, s);
-    hipLaunchKernelGGL(grid_blur_kernel, dim3(tiles, tiles, n), dim3(256), 0, s, H, g, L.S, L.pad,
+    hipLaunchKernelGGL(grid_blur_kernel, dim3(tiles, tiles, n), dim3(256), 0, s, H, occ, g, L.S, L.pad,
                        L.pitch, L.grid_bytes, L.R, kt);
     timer_end(NHIP_TIMER_GRID, s);
   }
