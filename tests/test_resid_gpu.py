@@ -137,6 +137,26 @@ def test_point_to_line_matches_autodiff_oracle(gpu):
     assert np.all(res >= 0)
 
 
+def test_reference_kats_through_the_hip_path(gpu):
+    """The reference's own six known-answer tests (test/solver_test.cc:12-64: DistanceToLineSegment on
+    the segment (0,0)-(2,2)) evaluated by the HIP PointToLineResidual kernel with identity poses."""
+    import torch
+    pts = np.array([[1, 1], [0, 2], [2, 0], [4, 4], [-2, -2], [2, 2]], dtype=np.float32)
+    want = np.array([0.0, 2.0 * math.sin(math.pi / 4), 2.0 * math.sin(math.pi / 4), math.sqrt(8), math.sqrt(8), 0.0])
+    seg = np.array([[0, 0, 2, 2]], dtype=np.float32)
+    zero = np.zeros((1, 3))
+    d = [_dev(seg), _dev(pts), _dev(np.zeros(6, np.int32)), _dev(np.zeros(1, np.int32)), _dev(np.zeros(1, np.int32)),
+         _dev(zero), _dev(zero)]
+    d_res = torch.empty(6, dtype=torch.float64, device="cuda:0")
+    _lib.check(_lib.load().nhip_resid_point_to_line_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 6,
+                                                        d[3].data_ptr(), d[4].data_ptr(), 1, d[5].data_ptr(),
+                                                        d[6].data_ptr(), d_res.data_ptr(), None, None, None))
+    torch.cuda.synchronize()
+    got = d_res.cpu().numpy()
+    assert got[0] == 0.0 and got[5] == 0.0                       # EXPECT_EQ(dist, 0) / EXPECT_FLOAT_EQ(dist, 0)
+    assert np.all(np.abs(got - want) <= 4 * np.spacing(np.float32(np.maximum(want, 1e-30))))  # EXPECT_FLOAT_EQ
+
+
 def test_odometry_matches_autodiff_oracle(gpu):
     import torch
     rng = np.random.default_rng(5)
