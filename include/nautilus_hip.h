@@ -246,6 +246,21 @@ int nhip_resid_batch_eval(nhip_resid_batch_t *batch, const double *poses, double
                           double *jac_src, double *jac_tgt);
 int nhip_resid_batch_free(nhip_resid_batch_t *batch);
 
+/* Host-pointer forms of the two small functor families (OdometryResidual, slam_residuals.h:18-40:
+ * one block per consecutive pose pair, solver.cc:370-387; PointToLineResidual, :180-200: HITL blocks,
+ * solver.cc:515-532).  Same argument meaning as the *_dev entry points; poses / line_poses are
+ * n x 3 doubles; outputs may be NULL where the *_dev form allows it.  They allocate, copy, launch
+ * and synchronise per call (the inputs are a few KB). */
+int nhip_resid_odometry(const float *t_odom, const float *r_odom, const int32_t *pose_i,
+                        const int32_t *pose_j, int32_t n_factors, double translation_weight,
+                        double rotation_weight, const double *poses, int32_t n_poses,
+                        double *residuals, double *jac_i, double *jac_j);
+int nhip_resid_point_to_line(const float *segments, const float *points, const int32_t *point_block,
+                             int64_t n_points, const int32_t *block_pose, const int32_t *block_line,
+                             int32_t n_blocks, const double *poses, int32_t n_poses,
+                             const double *line_poses, int32_t n_line_poses, double *residuals,
+                             double *jac_pose, double *jac_line);
+
 /* ------------------------------------------------------------------ in-stream kernel timing
  * When enabled, the dominant kernels are bracketed by hipEvents on their own stream.
  * ids: 0 = csm_correlate, 1 = grid_build (blur), 2 = resid_lidar, 3 = corr_search,

@@ -96,6 +96,44 @@ int main() {
   REQUIRE(std::fabs(r[0] - (tp[0](0) - (std::cos(0.05) * sp[0](0) - std::sin(0.05) * sp[0](1) + 0.1))) < 1e-12);
   delete c0; delete c1; delete c2;
   B.Reset();
+
+  // ---- odometry factors (solver.cc:378) and HITL line constraints (solver.cc:521,528) in the same problem
+  struct Factor { Vec2f translation; float rotation; };   // slam_types::OdometryFactor2D's members used by create()
+  struct Segment { Vec2f start, end; };                   // LineSegment<float>'s
+  const Factor f0{Vec2f(0.5f, -0.1f), 0.2f}, f1{Vec2f(-0.3f, 0.4f), -3.0f};
+  auto *o0 = nautilus::OdometryResidual::create(f0, 2.0, 5.0);
+  auto *o1 = nautilus::OdometryResidual::create(f1, 1.0, 0.5);
+  const Segment seg{Vec2f(-1.f, 0.f), Vec2f(1.f, 0.f)};
+  const std::vector<Vec2f> lp = {Vec2f(0.f, 0.5f), Vec2f(2.f, 1.f), Vec2f(-3.f, -0.25f)};
+  auto *l0 = nautilus::PointToLineResidual::create(seg, lp);
+  REQUIRE(o0->num_residuals() == 3 && l0->num_residuals() == 3);
+  double zero[3] = {0, 0, 0};
+  B.Bind(o0, poses[0], poses[1]);
+  B.Bind(o1, poses[1], poses[2]);
+  B.Bind(l0, zero, zero);
+  B.PrepareForEvaluation(true, true);
+  double ro[3], joi[9], joj[9];
+  double *ojac[2] = {joi, joj};
+  REQUIRE(o0->Evaluate(params, ro, ojac));
+  REQUIRE(std::fabs(ro[0] - 2.0 * (0.1 + (double)0.5f - 0.0)) < 1e-14);
+  REQUIRE(std::fabs(ro[1] - 2.0 * (-0.2 + (double)-0.1f - 0.0)) < 1e-14);
+  REQUIRE(std::fabs(ro[2] - 5.0 * (0.05 + (double)0.2f)) < 1e-14);
+  REQUIRE(joi[0] == 2.0 && joi[4] == 2.0 && std::fabs(joi[8] - 5.0) < 1e-14 && joj[0] == -2.0 && joi[1] == 0.0);
+  REQUIRE(o1->Evaluate(params, ro, ojac));
+  {  // angle wrap: 0 + (-3) - (-0.4) = -2.6 stays; weights differ per factor
+    REQUIRE(std::fabs(ro[2] - 0.5 * (double)(0.0 + (double)-3.0f + 0.4)) < 1e-14);
+    REQUIRE(std::fabs(ro[0] - (0.0 + (double)-0.3f - 1.0)) < 1e-14);
+  }
+  double rl[3], jl0[9], jl1[9];
+  double *ljac[2] = {jl0, jl1};
+  REQUIRE(l0->Evaluate(params, rl, ljac));
+  // identity poses: distance to the segment itself: 0.5 above the middle, sqrt(2) past the end, sqrt(4+1/16)
+  REQUIRE(std::fabs(rl[0] - 0.5) < 1e-12 && std::fabs(rl[1] - std::sqrt(2.0)) < 1e-12);
+  REQUIRE(std::fabs(rl[2] - std::sqrt(4.0 + 0.0625)) < 1e-12);
+  REQUIRE(std::fabs(jl0[1] - 1.0) < 1e-12 && std::fabs(jl1[1] + 1.0) < 1e-12);  // d r0 / d pose.y = +1, / d line.y = -1
+  std::printf("odometry + point-to-line blocks: ok (r_line = %.4f %.4f %.4f)\n", rl[0], rl[1], rl[2]);
+  delete o0; delete o1; delete l0;
+  B.Reset();
   std::printf("ADAPTER_OK\n");
   return 0;
 }

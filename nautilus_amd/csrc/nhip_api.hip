@@ -691,6 +691,82 @@ int nhip_resid_batch_free(nhip_resid_batch_t *batch) {
   return NHIP_OK;
 }
 
+namespace {
+// upload n bytes (n may be 0)
+int up(DevBuf &d, const void *h, size_t n) {
+  int rc = d.alloc(n);
+  if (rc) return rc;
+  if (n) NHIP_TRY_HIP(hipMemcpy(d.p, h, n, hipMemcpyHostToDevice));
+  return NHIP_OK;
+}
+}  // namespace
+
+int nhip_resid_odometry(const float *t_odom, const float *r_odom, const int32_t *pose_i,
+                        const int32_t *pose_j, int32_t n, double tw, double rw, const double *poses,
+                        int32_t n_poses, double *residuals, double *jac_i, double *jac_j) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(n >= 0 && n_poses >= 0, "resid_odometry: negative size");
+  if (n == 0) return NHIP_OK;
+  NHIP_REQUIRE(t_odom && r_odom && pose_i && pose_j && poses && residuals, "resid_odometry: null pointer");
+  for (int32_t f = 0; f < n; f++)
+    NHIP_REQUIRE(pose_i[f] >= 0 && pose_i[f] < n_poses && pose_j[f] >= 0 && pose_j[f] < n_poses,
+                 "resid_odometry: factor %d pose index out of range", f);
+  DevBuf dt, dr, di, dj, dp, res, ji, jj;
+  if ((rc = up(dt, t_odom, sizeof(float) * 2 * (size_t)n)) || (rc = up(dr, r_odom, sizeof(float) * (size_t)n)) ||
+      (rc = up(di, pose_i, sizeof(int32_t) * (size_t)n)) || (rc = up(dj, pose_j, sizeof(int32_t) * (size_t)n)) ||
+      (rc = up(dp, poses, sizeof(double) * 3 * (size_t)n_poses)) || (rc = res.alloc(sizeof(double) * 3 * (size_t)n)) ||
+      (rc = ji.alloc(sizeof(double) * 9 * (size_t)n)) || (rc = jj.alloc(sizeof(double) * 9 * (size_t)n)))
+    return rc;
+  rc = launch_resid_odometry(static_cast<const float *>(dt.p), static_cast<const float *>(dr.p),
+                             static_cast<const int32_t *>(di.p), static_cast<const int32_t *>(dj.p), n, tw, rw,
+                             static_cast<const double *>(dp.p), static_cast<double *>(res.p),
+                             jac_i ? static_cast<double *>(ji.p) : nullptr,
+                             jac_j ? static_cast<double *>(jj.p) : nullptr, nullptr);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(residuals, res.p, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost));
+  if (jac_i) NHIP_TRY_HIP(hipMemcpy(jac_i, ji.p, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost));
+  if (jac_j) NHIP_TRY_HIP(hipMemcpy(jac_j, jj.p, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_resid_point_to_line(const float *segments, const float *points, const int32_t *point_block,
+                             int64_t n_points, const int32_t *block_pose, const int32_t *block_line,
+                             int32_t n_blocks, const double *poses, int32_t n_poses,
+                             const double *line_poses, int32_t n_line_poses, double *residuals,
+                             double *jac_pose, double *jac_line) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(n_points >= 0 && n_blocks >= 0 && n_poses >= 0 && n_line_poses >= 0, "resid_point_to_line: negative size");
+  if (n_points == 0) return NHIP_OK;
+  NHIP_REQUIRE(segments && points && point_block && block_pose && block_line && poses && line_poses && residuals,
+               "resid_point_to_line: null pointer");
+  for (int32_t b = 0; b < n_blocks; b++)
+    NHIP_REQUIRE(block_pose[b] >= 0 && block_pose[b] < n_poses && block_line[b] >= 0 && block_line[b] < n_line_poses,
+                 "resid_point_to_line: block %d parameter index out of range", b);
+  for (int64_t i = 0; i < n_points; i++)
+    NHIP_REQUIRE(point_block[i] >= 0 && point_block[i] < n_blocks, "resid_point_to_line: point %lld block out of range",
+                 (long long)i);
+  DevBuf ds, dpt, dpb, dbp, dbl, dp, dl, res, j0, j1;
+  if ((rc = up(ds, segments, sizeof(float) * 4 * (size_t)n_blocks)) || (rc = up(dpt, points, sizeof(float) * 2 * (size_t)n_points)) ||
+      (rc = up(dpb, point_block, sizeof(int32_t) * (size_t)n_points)) || (rc = up(dbp, block_pose, sizeof(int32_t) * (size_t)n_blocks)) ||
+      (rc = up(dbl, block_line, sizeof(int32_t) * (size_t)n_blocks)) || (rc = up(dp, poses, sizeof(double) * 3 * (size_t)n_poses)) ||
+      (rc = up(dl, line_poses, sizeof(double) * 3 * (size_t)n_line_poses)) || (rc = res.alloc(sizeof(double) * (size_t)n_points)) ||
+      (rc = j0.alloc(sizeof(double) * 3 * (size_t)n_points)) || (rc = j1.alloc(sizeof(double) * 3 * (size_t)n_points)))
+    return rc;
+  rc = launch_resid_point_to_line(static_cast<const float *>(ds.p), static_cast<const float *>(dpt.p),
+                                  static_cast<const int32_t *>(dpb.p), n_points, static_cast<const int32_t *>(dbp.p),
+                                  static_cast<const int32_t *>(dbl.p), n_blocks, static_cast<const double *>(dp.p),
+                                  static_cast<const double *>(dl.p), static_cast<double *>(res.p),
+                                  jac_pose ? static_cast<double *>(j0.p) : nullptr,
+                                  jac_line ? static_cast<double *>(j1.p) : nullptr, nullptr);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(residuals, res.p, sizeof(double) * (size_t)n_points, hipMemcpyDeviceToHost));
+  if (jac_pose) NHIP_TRY_HIP(hipMemcpy(jac_pose, j0.p, sizeof(double) * 3 * (size_t)n_points, hipMemcpyDeviceToHost));
+  if (jac_line) NHIP_TRY_HIP(hipMemcpy(jac_line, j1.p, sizeof(double) * 3 * (size_t)n_points, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
 // ---------------------------------------------------------------- timing
 int nhip_timing_enable(int on) {
   std::lock_guard<std::mutex> lk(g_tmu);

@@ -15,7 +15,9 @@ def test_adapter_headers_mirror_reference_signatures():
     assert "class CorrelativeScanMatcher" in h and "GetTransformation(" in h
     assert "double scanner_range, double trans_range, double low_res, double high_res" in h
     r = open(os.path.join(ROOT, "nautilus_amd", "adapters", "slam_residuals_hip.h")).read()
-    for s in ("struct LIDARNormalResidual", "struct LIDARPointResidual", "namespace nautilus {", "static nautilus_hip::LidarCost *create("):
+    for s in ("struct OdometryResidual", "struct LIDARNormalResidual", "struct LIDARPointResidual",
+              "struct PointToLineResidual", "namespace nautilus {", "static nautilus_hip::BatchedCost *create(",
+              "double translation_weight, double rotation_weight", "line_segment, const std::vector<"):
         assert s in r
 
 

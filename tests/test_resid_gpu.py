@@ -181,6 +181,55 @@ def test_odometry_matches_autodiff_oracle(gpu):
         close(res[f], wr), close(ji[f], w0), close(jj[f], w1)
 
 
+def test_host_pointer_forms_of_odometry_and_point_to_line(gpu):
+    """nhip_resid_odometry / nhip_resid_point_to_line (what the C++ OdometryResidual::create /
+    PointToLineResidual::create drop-ins call): host buffers in, host buffers out, against the oracle;
+    out-of-range pose indices are an argument error, not a device fault."""
+    L = _lib.load()
+    rng = np.random.default_rng(23)
+    n = 64
+    poses = rng.normal(0, 2, (n + 1, 3))
+    t_odom = rng.normal(0, 0.3, (n, 2)).astype(np.float32)
+    r_odom = rng.uniform(-3.2, 3.2, n).astype(np.float32)
+    pi, pj = np.arange(n, dtype=np.int32), np.arange(1, n + 1, dtype=np.int32)
+    res, ji, jj = np.zeros((n, 3)), np.zeros((n, 3, 3)), np.zeros((n, 3, 3))
+    _lib.check(L.nhip_resid_odometry(_lib.ptr(t_odom), _lib.ptr(r_odom), _lib.ptr(pi), _lib.ptr(pj), n, 0.75, 3.0,
+                                     _lib.ptr(poses), n + 1, _lib.ptr(res), _lib.ptr(ji), _lib.ptr(jj)))
+    for f in range(n):
+        wr, w0, w1 = O.odometry_block(t_odom[f], r_odom[f], 0.75, 3.0, poses[f], poses[f + 1])
+        close(res[f], wr), close(ji[f], w0), close(jj[f], w1)
+    res_only = np.zeros((n, 3))
+    _lib.check(L.nhip_resid_odometry(_lib.ptr(t_odom), _lib.ptr(r_odom), _lib.ptr(pi), _lib.ptr(pj), n, 0.75, 3.0,
+                                     _lib.ptr(poses), n + 1, _lib.ptr(res_only), None, None))
+    assert np.array_equal(res_only, res)
+    bad = pj.copy()
+    bad[5] = n + 1
+    assert L.nhip_resid_odometry(_lib.ptr(t_odom), _lib.ptr(r_odom), _lib.ptr(pi), _lib.ptr(bad), n, 1.0, 1.0,
+                                 _lib.ptr(poses), n + 1, _lib.ptr(res), None, None) == _lib.NHIP_ERR_ARG
+
+    segs = np.array([[0, 0, 2, 2], [-1, 3, 4, 3], [2, -2, 2, 5]], dtype=np.float32)
+    lines = np.array([[0, 0, 0], [0.1, -0.2, 0.05]])
+    pts = [rng.uniform(-6, 6, (k, 2)).astype(np.float32) for k in (17, 1, 130)]
+    pblock = np.concatenate([np.full(len(p), b, np.int32) for b, p in enumerate(pts)])
+    bpose, bline = np.array([3, 0, 7], np.int32), np.array([1, 0, 1], np.int32)
+    P = np.concatenate(pts)
+    m = len(P)
+    r, j0, j1 = np.zeros(m), np.zeros((m, 3)), np.zeros((m, 3))
+    _lib.check(L.nhip_resid_point_to_line(_lib.ptr(segs), _lib.ptr(P), _lib.ptr(pblock), m, _lib.ptr(bpose),
+                                          _lib.ptr(bline), 3, _lib.ptr(poses), n + 1, _lib.ptr(lines), 2,
+                                          _lib.ptr(r), _lib.ptr(j0), _lib.ptr(j1)))
+    o = 0
+    for b in range(3):
+        wr, w0, w1 = O.point_to_line_block(segs[b], pts[b], poses[bpose[b]], lines[bline[b]])
+        k = len(pts[b])
+        close(r[o:o + k], wr), close(j0[o:o + k], w0, 10.0), close(j1[o:o + k], w1, 10.0)
+        o += k
+    bline[2] = 2
+    assert L.nhip_resid_point_to_line(_lib.ptr(segs), _lib.ptr(P), _lib.ptr(pblock), m, _lib.ptr(bpose),
+                                      _lib.ptr(bline), 3, _lib.ptr(poses), n + 1, _lib.ptr(lines), 2,
+                                      _lib.ptr(r), None, None) == _lib.NHIP_ERR_ARG
+
+
 def test_full_size_block_properties(gpu):
     """Config #3 scale (1081-point blocks) through size-independent properties:
     LIDARPoint residuals are linear in the target point; Jacobian columns match central differences."""
