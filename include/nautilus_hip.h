@@ -72,11 +72,16 @@ typedef struct nhip_grid_layout {
   int64_t grid_bytes;  /* pitch*rows: bytes of one stored grid */
   double score_floor;  /* Lf = ln(floor_p): value of cell 0 */
   double score_step;   /* log-likelihood per quantisation step = -Lf/255 */
+  int64_t skip_bytes;  /* bytes of the skip map stored right after each image: one byte per aligned
+                          dword column and stored row; bit w says "the 21 rows x 21 dwords starting
+                          21*w rows below hold a non-zero cell", so the correlation kernel can leave
+                          out the windows that only add zeros (same sums, bit for bit) */
+  int64_t slot_bytes;  /* grid_bytes + skip_bytes: grid t of a buffer starts at byte t*slot_bytes */
 } nhip_grid_layout_t;
 
 /* Pure host helpers (work without a GPU). */
 int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out);
-/* bytes the caller must allocate for n grids (n*grid_bytes + 256 B read slack) */
+/* bytes the caller must allocate for n grids (n*slot_bytes + 256 B read slack) */
 int64_t nhip_grids_bytes(const nhip_grid_spec_t *spec, int64_t n_grids);
 /* workspace for nhip_grid_build_dev processing `chunk` targets at a time */
 int64_t nhip_grid_workspace_bytes(const nhip_grid_spec_t *spec, int32_t chunk);

@@ -30,7 +30,8 @@ class GridSpec(C.Structure):
 class GridLayout(C.Structure):
     _fields_ = [("side", C.c_int32), ("pad", C.c_int32), ("pitch", C.c_int32), ("rows", C.c_int32),
                 ("blur_radius", C.c_int32), ("reserved", C.c_int32), ("tap_sum", C.c_int64),
-                ("grid_bytes", C.c_int64), ("score_floor", C.c_double), ("score_step", C.c_double)]
+                ("grid_bytes", C.c_int64), ("score_floor", C.c_double), ("score_step", C.c_double),
+                ("skip_bytes", C.c_int64), ("slot_bytes", C.c_int64)]
 
 
 class Search(C.Structure):

@@ -49,6 +49,8 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   L->pitch = ((L->S + 2 * L->pad) + 15) & ~15;
   L->R = (int32_t)ceil(3.0 * spec->sigma);
   L->grid_bytes = (int64_t)L->pitch * (int64_t)(L->S + 2 * L->pad);
+  L->skip_bytes = (((int64_t)(L->pitch / 4) * (int64_t)(L->S + 2 * L->pad)) + 15) & ~15ll;
+  L->slot_bytes = L->grid_bytes + L->skip_bytes;
   L->Lf = log(spec->floor_p);
   L->step = -L->Lf / 255.0;
   // integer taps: round(16384 * g_i / sum g)
@@ -226,13 +228,15 @@ int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out) {
   out->grid_bytes = L.grid_bytes;
   out->score_floor = L.Lf;
   out->score_step = L.step;
+  out->skip_bytes = L.skip_bytes;
+  out->slot_bytes = L.slot_bytes;
   return NHIP_OK;
 }
 
 int64_t nhip_grids_bytes(const nhip_grid_spec_t *spec, int64_t n_grids) {
   GridLayout L;
   if (make_layout(spec, &L)) return -1;
-  return n_grids * L.grid_bytes + 256;
+  return n_grids * L.slot_bytes + 256;
 }
 
 int64_t nhip_grid_workspace_bytes(const nhip_grid_spec_t *spec, int32_t chunk) {
@@ -499,7 +503,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
   const int32_t chunk = n_targets < 64 ? (n_targets > 0 ? n_targets : 1) : 64;
   const int64_t ws_tiles = (L.S + 63) / 64;
   const int64_t ws_bytes = (int64_t)chunk * ((int64_t)L.S * L.S + ws_tiles * ws_tiles);
-  if ((rc = g->grids.alloc((size_t)n_targets * L.grid_bytes + 256)) ||
+  if ((rc = g->grids.alloc((size_t)n_targets * L.slot_bytes + 256)) ||
       (rc = ids.alloc(sizeof(int32_t) * (size_t)(n_targets > 0 ? n_targets : 1))) ||
       (rc = ws.alloc((size_t)ws_bytes))) {
     delete g;
@@ -537,7 +541,7 @@ int nhip_grids_free(nhip_grids_t *grids) {
 
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download: bad arguments");
-  NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * grids->L.grid_bytes,
+  NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * grids->L.slot_bytes,
                          (size_t)grids->L.grid_bytes, hipMemcpyDeviceToHost));
   return NHIP_OK;
 }

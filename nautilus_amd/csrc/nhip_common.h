@@ -37,9 +37,16 @@ int require_device();
 struct GridLayout {
   int32_t S, pad, pitch, R;
   int64_t K;  // tap sum
-  int64_t grid_bytes;
+  int64_t grid_bytes;  // pitch * rows: the stored image
+  int64_t skip_bytes;  // (pitch / 4) * rows rounded up to 16: the skip map that follows the image
+  int64_t slot_bytes;  // grid_bytes + skip_bytes: stride between consecutive grids of a buffer
   double Lf, step;
 };
+// Geometry the skip map shares with the correlation kernel: a wave of csm_correlate_kernel owns
+// CSM_WAVE_ROWS plane rows and reads CSM_ROW_DW aligned dwords of each (nhip_csm.hip).
+constexpr int CSM_WAVE_ROWS = 21;
+constexpr int CSM_ROW_DW = 21;
+constexpr int CSM_WAVES = 4;
 int make_layout(const nhip_grid_spec_t *spec, GridLayout *L);
 
 // Device-side constant tables of one grid spec (taps + quantiser thresholds), cached.

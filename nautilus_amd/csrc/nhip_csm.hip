@@ -27,6 +27,8 @@ constexpr int SEG_DW = 7;                  // aligned dwords a lane reads and ac
 constexpr int SEG_COLS = 4 * SEG_DW;       // 28 x-shifts per lane
 constexpr int SEGS = 3;                    // lanes per plane row: 84 aligned bytes >= 81 + 3
 constexpr int WAVE_ROWS = 63 / SEGS;       // 21 plane rows per wave (lane 63 idles: rows never straddle waves)
+static_assert(WAVE_ROWS == CSM_WAVE_ROWS && SEGS * SEG_DW == CSM_ROW_DW && CSM_THREADS / 64 == CSM_WAVES,
+              "the skip map (nhip_grid.hip) is built for this wave footprint");
 constexpr int PB_NX = SEGS * SEG_COLS - 3; // 81 x-shifts per plane block (84 bytes minus alignment slack)
 constexpr int PB_NY = (CSM_THREADS / 64) * WAVE_ROWS;  // 84 y-shifts per plane block
 constexpr int LDS_POINTS = 1152;           // rotated cells staged per pass
@@ -51,7 +53,8 @@ struct CsmParams {
   int32_t S, pad, pitch, rows, max_shift;
   int32_t single_src, single_slot;  // scores kernel: the one pair
   int32_t single_ox, single_oy;
-  int64_t grid_bytes;
+  int32_t dense;  // 1: ignore the skip maps (every strip is added, zero or not)
+  int64_t grid_bytes, slot_bytes;
   double res;
 };
 
@@ -214,6 +217,7 @@ template <bool VOLUME>
 __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams P) {
   __shared__ uint32_t s_tile[TILE_ROWS * LP_DW];
   __shared__ uint32_t s_cell[LDS_POINTS];
+  __shared__ uint8_t s_skip[LDS_POINTS];  // skip-map byte of each point: bit w = wave w's strip is not all zero
   __shared__ unsigned long long s_best[CSM_THREADS / 64];
 
   // ---- block -> (pair, rotation, plane block); all rotations of a pair share an XCD
@@ -239,7 +243,9 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   const int32_t src = VOLUME ? P.single_src : P.pair_src[pair];
   const int32_t slot = VOLUME ? P.single_slot : P.pair_slot[pair];
   const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
-  const uint8_t *grid = P.grids + (size_t)slot * P.grid_bytes;
+  const uint8_t *grid = P.grids + (size_t)slot * P.slot_bytes;
+  const uint8_t *skip_map = grid + P.grid_bytes;
+  const int32_t mpitch = P.pitch >> 2;
   // search centre in cells; a centre the stored border cannot cover scores nothing
   int32_t cx = VOLUME ? P.single_ox : (P.pair_origin ? P.pair_origin[2 * pair] : 0);
   int32_t cy = VOLUME ? P.single_oy : (P.pair_origin ? P.pair_origin[2 * pair + 1] : 0);
@@ -254,7 +260,11 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   const int tid = threadIdx.x, lane = tid & 63;
   // wave w owns plane rows [21 w, 21 w + 21): lane = 3 * (row in wave) + segment, lane 63 idles
   const int lane_c = lane < 63 ? lane : 62;
-  const int dy = (tid >> 6) * WAVE_ROWS + lane_c / SEGS, seg = lane_c % SEGS;
+  // which of the plane's four 21-row strips this wave owns rotates with the rotation index: the
+  // strips that see a wall are nearly the same for neighbouring rotations of a pair (which run
+  // side by side on one CU), and a fixed wave -> strip map would pile them onto one SIMD
+  const int strip = ((tid >> 6) + k) & (CSM_THREADS / 64 - 1);
+  const int dy = strip * WAVE_ROWS + lane_c / SEGS, seg = lane_c % SEGS;
   const bool lane_live = lane < 63;
   const bool has_right = lane_live && seg < SEGS - 1;  // lane + 1 holds the next 28 bytes of the same row
   // lanes past the plane block's rows re-read row 0 (their sums are never used)
@@ -275,8 +285,11 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   for (int32_t base = 0; base < n_pts && centre_ok; base += LDS_POINTS) {
     const int32_t cnt = min(n_pts - base, LDS_POINTS);
     __syncthreads();
-    for (int32_t i = tid; i < cnt; i += CSM_THREADS)
-      s_cell[i] = window_cell(P.xy[beg + base + i], cf, sf, P, ox, oy, cx, cy);
+    for (int32_t i = tid; i < cnt; i += CSM_THREADS) {
+      const uint32_t cell = window_cell(P.xy[beg + base + i], cf, sf, P, ox, oy, cx, cy);
+      s_cell[i] = cell;
+      s_skip[i] = P.dense ? (uint8_t)0xf : skip_map[(size_t)(cell >> 16) * mpitch + ((cell & 0xffffu) >> 2)];
+    }
     __syncthreads();
     // groups of 192 points (<= FLUSH_POINTS), each followed by an unconditional unpack
     for (int32_t g0 = 0; g0 < cnt; g0 += FLUSH_GROUP) {
@@ -284,14 +297,18 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
     for (int32_t c64 = g0; c64 < g1; c64 += 64) {
       const int32_t n = min(g1 - c64, 64);
       const uint32_t vcell = (lane < n) ? s_cell[c64 + lane] : 0u;
+      const uint32_t vskip = (lane < n) ? s_skip[c64 + lane] : 0u;
       const int32_t vcol = (int32_t)(vcell & 0xffffu), vrow = (int32_t)(vcell >> 16);
       const unsigned long long live = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
+      // points whose strip for THIS wave holds a non-zero cell; a point with no such strip in any
+      // wave (vskip == 0) needs no tile at all
+      const unsigned long long work = __ballot((vskip >> strip) & 1u);
       int32_t j = 0;
       while (j < n) {
         // lanes whose window lies inside the staged tile; e = first lane >= j that is not
         const unsigned long long from_j = live & ~((1ull << j) - 1ull);
-        bool cov = have_tile && (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
-                   (uint32_t)(vrow - t_row0) <= (uint32_t)row_span;
+        bool cov = vskip == 0u || (have_tile && (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
+                                   (uint32_t)(vrow - t_row0) <= (uint32_t)row_span);
         unsigned long long miss = ~__ballot(cov) & from_j;
         int32_t e = miss ? (int32_t)__builtin_ctzll(miss) : n;
         if (e == j) {
@@ -341,15 +358,15 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
             }
           }
           __syncthreads();
-          cov = (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
-                (uint32_t)(vrow - t_row0) <= (uint32_t)row_span;
+          cov = vskip == 0u || ((uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
+                                (uint32_t)(vrow - t_row0) <= (uint32_t)row_span);
           miss = ~__ballot(cov) & from_j;
           e = miss ? (int32_t)__builtin_ctzll(miss) : n;  // > j: the new tile covers point j
         }
         // points j..e-1 are covered: LDS byte offset of each lane's window start, then the
         // grouped SWAR accumulation
         const uint32_t vorg = (uint32_t)(vrow - t_row0) * LP + (uint32_t)(vcol - t_col0);
-        const unsigned long long seg_mask = (e == 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << j) - 1ull);
+        const unsigned long long seg_mask = (e == 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << j) - 1ull) & work;
         swar_segment(A, tile_bytes, lane_off, vorg, seg_mask);
         j = e;
       }
@@ -453,6 +470,10 @@ void fill_params(CsmParams &P, const nhip_grid_spec_t *spec, const GridLayout &L
   P.rows = L.S + 2 * L.pad;
   P.max_shift = spec->max_shift;
   P.grid_bytes = L.grid_bytes;
+  P.slot_bytes = L.slot_bytes;
+  // NHIP_CSM_DENSE=1 switches the zero-strip skipping off (measurement: the same kernel, every add done)
+  const char *dense = getenv("NHIP_CSM_DENSE");
+  P.dense = (dense && dense[0] == '1') ? 1 : 0;
   P.res = spec->res;
 }
 

@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void grid_raster_kernel(
 __global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restrict__ H,
                                                         const uint8_t *__restrict__ occ,
                                                         uint8_t *__restrict__ grids, int32_t S,
-                                                        int32_t pad, int32_t pitch, int64_t grid_bytes,
+                                                        int32_t pad, int32_t pitch, int64_t slot_bytes,
                                                         int32_t R, GridKernelTables tab) {
   __shared__ uint8_t sH[TH_MAX][TH_MAX + 4];
   __shared__ uint32_t sV[TH_MAX][TILE + 1];
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restric
   if (!occ[((size_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
   const int32_t r0 = blockIdx.y * TILE, c0 = blockIdx.x * TILE;
   const uint8_t *h = H + (size_t)t * S * S;
-  uint8_t *g = grids + (size_t)t * grid_bytes;
+  uint8_t *g = grids + (size_t)t * slot_bytes;
   const int TH = TILE + 2 * R;
   int any = 0;
   for (int i = threadIdx.x; i < TH * TH; i += 256) {
@@ -115,6 +115,99 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restric
   }
 }
 
+// ---- skip map ---------------------------------------------------------------------------
+// A likelihood grid is zero except within the blur radius of a wall.  csm_correlate_kernel adds,
+// per point and per wave, the CSM_WAVE_ROWS x CSM_ROW_DW-dword strip of the grid that starts at
+// (window row + 21 * wave, window column & ~3); on the 1081-beam scans ~45 % of those strips hold
+// nothing but zeros.  The map stores, per stored row r and aligned dword column c, one byte whose
+// bit w says "rows [r + 21 w, r + 21 w + 21) x dwords [c, c + 21) contain a non-zero cell", so the
+// kernel can drop the all-zero strips (the sums are unchanged, bit for bit) with one byte load
+// per point.  One block per 64-row x 64-dword map tile; tiles whose footprint touches no
+// occupied blur tile stay on the memset's zeros.
+constexpr int MT = 64;
+constexpr int SK_ROWS = MT + CSM_WAVES * CSM_WAVE_ROWS - 1;  // grid rows feeding one map tile (147)
+static_assert(CSM_ROW_DW - 1 <= 20 && MT == 64, "row mask is built from one 64-lane and one 20-lane ballot");
+
+__global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__restrict__ occ,
+                                                           uint8_t *__restrict__ grids, int32_t S,
+                                                           int32_t tiles, int32_t pad, int32_t pitch,
+                                                           int32_t rows, int64_t grid_bytes,
+                                                           int64_t slot_bytes) {
+  __shared__ unsigned long long sH[SK_ROWS + 1];  // per grid row: bit c = a non-zero dword in [c0 + c, c0 + c + 21)
+  __shared__ unsigned long long sV[MT][CSM_WAVES];
+  const int32_t t = blockIdx.z, tid = threadIdx.x;
+  const int32_t r0 = blockIdx.y * MT, c0 = blockIdx.x * MT;  // first map row / dword column
+  // footprint in raster coordinates -> blur tiles that could have written into it
+  const int32_t fr0 = r0 - pad, fr1 = r0 + SK_ROWS - 1 - pad;
+  const int32_t fc0 = 4 * c0 - pad, fc1 = 4 * (c0 + MT + CSM_ROW_DW - 1) - 1 - pad;
+  int any = 0;
+  if (fr1 >= 0 && fr0 < S && fc1 >= 0 && fc0 < S) {
+    const int32_t ty0 = max(fr0, 0) / TILE, ty1 = min(fr1, S - 1) / TILE;
+    const int32_t tx0 = max(fc0, 0) / TILE, tx1 = min(fc1, S - 1) / TILE;
+    const int32_t ntx = tx1 - tx0 + 1, nt = (ty1 - ty0 + 1) * ntx;
+    for (int32_t i = tid; i < nt; i += 256)
+      any |= occ[((size_t)t * tiles + ty0 + i / ntx) * tiles + tx0 + i % ntx];
+  }
+  if (!__syncthreads_or(any)) return;
+  uint8_t *g = grids + (size_t)t * slot_bytes;
+  uint8_t *M = g + grid_bytes;
+  const int32_t mpitch = pitch / 4;
+  const int wave = tid >> 6, lane = tid & 63;
+  // horizontal: 84-bit non-zero mask of a row (two ballots), then OR over windows of 21 bits
+  constexpr int UNR = 4;
+  for (int32_t rb = wave * UNR; rb < SK_ROWS; rb += 4 * UNR) {
+    uint32_t v0[UNR], v1[UNR];
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const int32_t r = r0 + rb + u;
+      v0[u] = v1[u] = 0;
+      if (rb + u < SK_ROWS && r < rows) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(g + (size_t)r * pitch);
+        if (c0 + lane < mpitch) v0[u] = row[c0 + lane];
+        if (lane < CSM_ROW_DW - 1 && c0 + 64 + lane < mpitch) v1[u] = row[c0 + 64 + lane];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < UNR; u++) {
+      const unsigned long long b0 = __ballot(v0[u] != 0u), b1 = __ballot(v1[u] != 0u);
+      unsigned __int128 m = ((unsigned __int128)b1 << 64) | b0;
+      m |= m >> 1;
+      m |= m >> 2;
+      m |= m >> 4;                               // windows of 8
+      const unsigned __int128 m21 = m | (m >> 8) | (m >> 13);  // [c, c+16) U [c+13, c+21)
+      if (lane == 0 && rb + u < SK_ROWS) sH[rb + u] = (unsigned long long)m21;
+    }
+  }
+  __syncthreads();
+  // vertical: map row r, strip w = OR of the 21 row masks from r + 21 w
+  {
+    const int r = tid >> 2, w = tid & 3;
+    unsigned long long v = 0;
+    for (int j = 0; j < CSM_WAVE_ROWS; j++) v |= sH[r + CSM_WAVE_ROWS * w + j];
+    sV[r][w] = v;
+  }
+  __syncthreads();
+  // emit: each thread 16 map bytes (4 aligned dword stores)
+  {
+    const int r = tid >> 2, q = tid & 3;
+    if (r0 + r < rows) {
+      unsigned long long V[CSM_WAVES];
+      for (int w = 0; w < CSM_WAVES; w++) V[w] = sV[r][w];
+      for (int k = 0; k < 4; k++) {
+        const int c = 16 * q + 4 * k;
+        if (c0 + c >= mpitch) break;  // mpitch is a multiple of 4
+        uint32_t out = 0;
+        for (int b = 0; b < 4; b++) {
+          uint32_t bits = 0;
+          for (int w = 0; w < CSM_WAVES; w++) bits |= (uint32_t)((V[w] >> (c + b)) & 1ull) << w;
+          out |= bits << (8 * b);
+        }
+        *reinterpret_cast<uint32_t *>(M + (size_t)(r0 + r) * mpitch + c0 + c) = out;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
@@ -139,15 +232,18 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     const int32_t n = (int32_t)((n_targets - t0 < chunk) ? (n_targets - t0) : chunk);
     uint8_t *H = static_cast<uint8_t *>(d_ws);
     uint8_t *occ = H + (size_t)n * L.S * L.S;
-    uint8_t *g = d_grids + (size_t)t0 * L.grid_bytes;
+    uint8_t *g = d_grids + (size_t)t0 * L.slot_bytes;
     NHIP_TRY_HIP(hipMemsetAsync(H, 0, (size_t)n * per, s));  // raster and occupancy in one fill
-    NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.grid_bytes, s));
+    NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.slot_bytes, s));  // images and skip maps
     hipLaunchKernelGGL(grid_raster_kernel, dim3(n), dim3(256), 0, s,
                        reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
                        (int32_t)t0, H, occ, L.S, tiles, L.R, spec->res);
     timer_begin(NHIP_TIMER_GRID, s);
     hipLaunchKernelGGL(grid_blur_kernel, dim3(tiles, tiles, n), dim3(256), 0, s, H, occ, g, L.S, L.pad,
-                       L.pitch, L.grid_bytes, L.R, kt);
+                       L.pitch, L.slot_bytes, L.R, kt);
+    const int32_t rows = L.S + 2 * L.pad, mpitch = L.pitch / 4;
+    hipLaunchKernelGGL(grid_skipmap_kernel, dim3((mpitch + MT - 1) / MT, (rows + MT - 1) / MT, n), dim3(256), 0, s,
+                       occ, g, L.S, tiles, L.pad, L.pitch, rows, L.grid_bytes, L.slot_bytes);
     timer_end(NHIP_TIMER_GRID, s);
   }
   NHIP_TRY_HIP(hipGetLastError());

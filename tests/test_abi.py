@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Match) == 16
     assert C.sizeof(_lib.GridSpec) == 40
     assert C.sizeof(_lib.Search) == 24
-    assert C.sizeof(_lib.GridLayout) == 56
+    assert C.sizeof(_lib.GridLayout) == 72
 
 
 def test_grid_layout_follows_cimg_debug():
@@ -44,6 +44,7 @@ def test_grid_layout_follows_cimg_debug():
     assert L.pad == 96 and L.pitch == 1392 and L.rows == 1392
     assert L.blur_radius == 6
     assert L.grid_bytes == 1392 * 1392
+    assert L.skip_bytes == 1392 * 1392 // 4 and L.slot_bytes == L.grid_bytes + L.skip_bytes
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
     for (r, res, side) in [(30, 0.3, 200), (30, 0.01, 6000), (10, 0.03, 666)]:
         assert csm.grid_layout(csm.grid_spec(r, res, 2.0, 1e-10, 4)).side == side

@@ -360,5 +360,53 @@ def test_device_pointer_api_on_torch_stream(gpu, small_bag):
     for f in ("itheta", "ix", "iy"):
         assert np.array_equal(got[f], want[f])
     assert np.array_equal(d_sums.cpu().numpy(), want["sum"])
-    g = d_grids[:2 * L.grid_bytes].cpu().numpy().reshape(2, L.rows, L.pitch)
+    slots = d_grids[:2 * L.slot_bytes].cpu().numpy().reshape(2, L.slot_bytes)
+    g = slots[:, :L.grid_bytes].reshape(2, L.rows, L.pitch)
     assert np.array_equal(g[1, L.pad:L.pad + L.side, L.pad:L.pad + L.side], ogr[1])
+    # the skip map behind each image, against its definition on the stored image
+    for t_ in range(2):
+        got_map = slots[t_, L.grid_bytes:L.grid_bytes + L.rows * (L.pitch // 4)].reshape(L.rows, L.pitch // 4)
+        assert np.array_equal(got_map, skip_map_definition(g[t_]))
+
+
+def skip_map_definition(stored):
+    """include/nautilus_hip.h (nhip_grid_layout_t.skip_bytes): bit w of byte (r, c) = any non-zero cell in
+    stored rows [r + 21 w, r + 21 w + 21) x aligned dwords [c, c + 21), clipped to the image."""
+    rows, pitch = stored.shape
+    nz = stored.reshape(rows, pitch // 4, 4).any(axis=2)
+    big = np.zeros((rows + 84, pitch // 4 + 21), dtype=np.int64)
+    big[:rows, :pitch // 4] = nz
+    I = np.zeros((big.shape[0] + 1, big.shape[1] + 1), dtype=np.int64)
+    I[1:, 1:] = big.cumsum(0).cumsum(1)
+    out = np.zeros((rows, pitch // 4), dtype=np.uint8)
+    r = np.arange(rows)[:, None]
+    c = np.arange(pitch // 4)[None, :]
+    for w in range(4):
+        cnt = I[r + 21 * w + 21, c + 21] - I[r + 21 * w, c + 21] - I[r + 21 * w + 21, c] + I[r + 21 * w, c]
+        out |= ((cnt > 0).astype(np.uint8) << w)
+    return out
+
+
+def test_zero_strip_skipping_changes_nothing(gpu, small_bag, monkeypatch):
+    """NHIP_CSM_DENSE=1 adds every strip, zero or not; the default leaves the all-zero ones out.
+    Records and integer sums must be identical (and equal the oracle's)."""
+    xy, off = csm.pack_scans(small_bag.scans)
+    ids = np.array([3, 11], dtype=np.int32)
+    src = np.array([5, 9, 14, 2, 30, 31], dtype=np.int32)
+    slot = np.array([0, 1, 1, 0, 1, 0], dtype=np.int32)
+    th0 = np.array([0.1, -0.3, 0.0, 2.0, 0.7, -1.2])
+    spec, search = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40), csm.search_spec(7, 81, 81, DEG)
+    st = csm.ScanTable(xy, off)
+    grids = csm.LikelihoodGrids(st, ids, spec)
+    m1, s1 = csm.match_pairs(st, grids, src, slot, th0, search)
+    monkeypatch.setenv("NHIP_CSM_DENSE", "1")
+    m2, s2 = csm.match_pairs(st, grids, src, slot, th0, search)
+    monkeypatch.delenv("NHIP_CSM_DENSE")
+    assert np.array_equal(s1, s2) and m1.tobytes() == m2.tobytes()
+    ospec = O.grid_spec(30.0, 0.05, 2.0, 1e-10)
+    ogr = O.grid_build_batch(xy, off, ids, ospec)
+    want = O.csm_match_batch(xy, off, ogr, ospec, src, slot, th0, O.search_spec(7, 81, 81, DEG))
+    assert np.array_equal(s1, want["sum"])
+    for f in ("itheta", "ix", "iy"):
+        assert np.array_equal(m1[f], want[f])
+    grids.close(), st.close()
