@@ -22,19 +22,25 @@ namespace nhip {
 
 namespace {
 
-constexpr int CSM_THREADS = 256;
+constexpr int CSM_THREADS = 64;             // one wave per workgroup: waves never wait for each other
 constexpr int SEG_DW = 7;                  // aligned dwords a lane reads and accumulates per point
 constexpr int SEG_COLS = 4 * SEG_DW;       // 28 x-shifts per lane
 constexpr int SEGS = 3;                    // lanes per plane row: 84 aligned bytes >= 81 + 3
 constexpr int WAVE_ROWS = 63 / SEGS;       // 21 plane rows per wave (lane 63 idles: rows never straddle waves)
-static_assert(WAVE_ROWS == CSM_WAVE_ROWS && SEGS * SEG_DW == CSM_ROW_DW && CSM_THREADS / 64 == CSM_WAVES,
+static_assert(WAVE_ROWS == CSM_WAVE_ROWS && SEGS * SEG_DW == CSM_ROW_DW,
               "the skip map (nhip_grid.hip) is built for this wave footprint");
 constexpr int PB_NX = SEGS * SEG_COLS - 3; // 81 x-shifts per plane block (84 bytes minus alignment slack)
-constexpr int PB_NY = (CSM_THREADS / 64) * WAVE_ROWS;  // 84 y-shifts per plane block
-constexpr int LDS_POINTS = 1152;           // rotated cells staged per pass
+constexpr int PB_NY = WAVE_ROWS;           // 21 y-shifts per plane block
 constexpr int LP_DW = 53;                  // LDS tile pitch in dwords (conflict-free: 53 = 21 mod 32)
 constexpr int LP = 4 * LP_DW;              // 212 bytes
-constexpr int TILE_ROWS = 144;
+#ifndef NHIP_TILE_ROWS
+#define NHIP_TILE_ROWS 48
+#endif
+#ifndef NHIP_FILL_INFLIGHT
+#define NHIP_FILL_INFLIGHT 4
+#endif
+constexpr int TILE_ROWS = NHIP_TILE_ROWS;
+constexpr int FILL_INFLIGHT = NHIP_FILL_INFLIGHT;          // 16-byte tile-fill loads a lane keeps in flight
 constexpr int ROW_BYTES = SEGS * SEG_COLS; // bytes of a tile row one point touches from its aligned start (84)
 constexpr int COL_SPAN = LP - ROW_BYTES;   // max (pcol - tile_col0) of a covered point (128)
 
@@ -55,7 +61,7 @@ struct CsmParams {
   int32_t single_ox, single_oy;
   int32_t dense;  // 1: ignore the skip maps (every strip is added, zero or not)
   int64_t grid_bytes, slot_bytes;
-  double res;
+  double res, inv_res;
 };
 
 // Stored-grid coordinates (row, col) of the top-left cell of point q's window under rotation
@@ -63,6 +69,18 @@ struct CsmParams {
 // products (Eigen Affine2f * Vector2f on baseline x86-64: no FMA), cell = S/2 +
 // floor(double(v) / res) (cimg_debug.h:31-37).  Cells are clamped to [-h-1, S+h]: beyond that
 // range every lookup of the window falls on the zero border, and so does the clamped window.
+// floor(RN(v / res)) without the division on the common path.  m = RN(v * RN(1 / res)) differs
+// from the correctly rounded quotient by less than |m| * 2^-51, so the two floors can differ only
+// if m lies within that distance of an integer; those lanes (one point in ~10^12) take the division.
+__device__ __forceinline__ double floor_quotient(double v, double res, double inv_res) {
+  const double m = __dmul_rn(v, inv_res);
+  double f = floor(m);
+  const double frac = __dsub_rn(m, f);  // exact
+  const double tol = __dmul_rn(fabs(m), 0x1p-50);
+  if (frac <= tol || __dsub_rn(1.0, frac) <= tol) f = floor(__ddiv_rn(v, res));
+  return f;
+}
+
 __device__ __forceinline__ uint32_t window_cell(float2 q, float cf, float sf, const CsmParams &P,
                                                 int32_t ox, int32_t oy, int32_t cx, int32_t cy) {
   const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
@@ -70,8 +88,8 @@ __device__ __forceinline__ uint32_t window_cell(float2 q, float cf, float sf, co
   long col = -P.hx - 1, row = -P.hy - 1;  // non-finite points score nothing
   if ((fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f)) {
     const long half = P.S / 2;
-    col = half + (long)floor(__ddiv_rn((double)xr, P.res)) + cx;
-    row = half + (long)floor(__ddiv_rn((double)yr, P.res)) + cy;
+    col = half + (long)floor_quotient((double)xr, P.res, P.inv_res) + cx;
+    row = half + (long)floor_quotient((double)yr, P.res, P.inv_res) + cy;
     col = col < -P.hx - 1 ? -P.hx - 1 : (col > P.S + P.hx ? P.S + P.hx : col);
     row = row < -P.hy - 1 ? -P.hy - 1 : (row > P.S + P.hy ? P.S + P.hy : row);
   }
@@ -101,8 +119,9 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // 32-bit sums: byte p of a class-s lane is window column 28*seg + p - s, so bytes p < s belong
 // to the left neighbour lane and travel there with one wave shuffle each (6 per unpack).
 constexpr int FLUSH_POINTS = 255;  // a 16-bit field holds 255 byte values
-constexpr int FLUSH_GROUP = 192;   // points between unpacks: 3 lane-chunks of 64
-static_assert(FLUSH_GROUP <= FLUSH_POINTS && FLUSH_GROUP % 64 == 0, "SWAR fields would overflow");
+// a lane-chunk of 64 points is started only while at most this many points have been ADDED since
+// the last unpack (skipped points do not count), so a field never exceeds 191 + 64 values
+constexpr int FLUSH_START_MAX = FLUSH_POINTS - 64;
 
 struct Swar {
   uint32_t e[4][SEG_DW], o[4][SEG_DW];
@@ -216,11 +235,8 @@ __device__ __forceinline__ int32_t place(int32_t here, int32_t ahead, int32_t sp
 template <bool VOLUME>
 __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams P) {
   __shared__ uint32_t s_tile[TILE_ROWS * LP_DW];
-  __shared__ uint32_t s_cell[LDS_POINTS];
-  __shared__ uint8_t s_skip[LDS_POINTS];  // skip-map byte of each point: bit w = wave w's strip is not all zero
-  __shared__ unsigned long long s_best[CSM_THREADS / 64];
 
-  // ---- block -> (pair, rotation, plane block); all rotations of a pair share an XCD
+  // ---- block -> (pair, rotation, plane block); everything of a pair shares an XCD
   const int32_t npb = P.npbx * P.npby;
   const int32_t per_pair = P.n_theta * npb;
   int32_t pair, w;
@@ -237,7 +253,7 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   const int32_t k = w / npb;
   const int32_t pb = w % npb;
   const int32_t ox = (pb % P.npbx) * PB_NX, oy = (pb / P.npbx) * PB_NY;
-  const int32_t nyb = min(P.ny - oy, PB_NY);  // plane rows of this block
+  const int32_t nyb = min(P.ny - oy, PB_NY);  // plane rows of this block (1..21)
   const int32_t row_span = TILE_ROWS - nyb;   // max (prow - tile_row0) of a covered point
 
   const int32_t src = VOLUME ? P.single_src : P.pair_src[pair];
@@ -257,20 +273,20 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   const float cf = __double2float_rn(__dsub_rn(__dmul_rn(c0, cd), __dmul_rn(s0, sd)));
   const float sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
 
-  const int tid = threadIdx.x, lane = tid & 63;
-  // wave w owns plane rows [21 w, 21 w + 21): lane = 3 * (row in wave) + segment, lane 63 idles
+  // lane = 3 * (plane row) + segment; lane 63 idles
+  const int lane = threadIdx.x;
   const int lane_c = lane < 63 ? lane : 62;
-  // which of the plane's four 21-row strips this wave owns rotates with the rotation index: the
-  // strips that see a wall are nearly the same for neighbouring rotations of a pair (which run
-  // side by side on one CU), and a fixed wave -> strip map would pile them onto one SIMD
-  const int strip = ((tid >> 6) + k) & (CSM_THREADS / 64 - 1);
-  const int dy = strip * WAVE_ROWS + lane_c / SEGS, seg = lane_c % SEGS;
+  const int dy = lane_c / SEGS, seg = lane_c % SEGS;
   const bool lane_live = lane < 63;
   const bool has_right = lane_live && seg < SEGS - 1;  // lane + 1 holds the next 28 bytes of the same row
   // lanes past the plane block's rows re-read row 0 (their sums are never used)
   const int dyc = (dy < nyb) ? dy : 0;
   const uint32_t lane_off = (uint32_t)(dyc * LP + seg * SEG_COLS);
   const uint8_t *tile_bytes = reinterpret_cast<const uint8_t *>(s_tile);
+  // tile fill: lane -> (row within a 4-row step, 16-byte chunk of the row)
+  constexpr int ROW_CH = (LP + 15) / 16;     // 14
+  constexpr int FILL_ROWS = 64 / ROW_CH;     // 4 rows per step (lanes 56..63 idle)
+  static_assert(TILE_ROWS % (FILL_ROWS * FILL_INFLIGHT) == 0, "tile rows must be a whole number of fill batches");
 
   uint32_t acc[SEG_COLS];
 #pragma unroll
@@ -282,35 +298,30 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   int32_t t_row0 = 0, t_col0 = 0;
   bool have_tile = false;
 
-  for (int32_t base = 0; base < n_pts && centre_ok; base += LDS_POINTS) {
-    const int32_t cnt = min(n_pts - base, LDS_POINTS);
-    __syncthreads();
-    for (int32_t i = tid; i < cnt; i += CSM_THREADS) {
-      const uint32_t cell = window_cell(P.xy[beg + base + i], cf, sf, P, ox, oy, cx, cy);
-      s_cell[i] = cell;
-      s_skip[i] = P.dense ? (uint8_t)0xf : skip_map[(size_t)(cell >> 16) * mpitch + ((cell & 0xffffu) >> 2)];
-    }
-    __syncthreads();
-    // groups of 192 points (<= FLUSH_POINTS), each followed by an unconditional unpack
-    for (int32_t g0 = 0; g0 < cnt; g0 += FLUSH_GROUP) {
-    const int32_t g1 = min(cnt, g0 + FLUSH_GROUP);
-    for (int32_t c64 = g0; c64 < g1; c64 += 64) {
-      const int32_t n = min(g1 - c64, 64);
-      const uint32_t vcell = (lane < n) ? s_cell[c64 + lane] : 0u;
-      const uint32_t vskip = (lane < n) ? s_skip[c64 + lane] : 0u;
+  // lane-chunks of 64 points; an unconditional unpack after every run of chunks that added
+  // (at most) FLUSH_POINTS points
+  int32_t c64 = 0;
+  while (c64 < n_pts && centre_ok) {
+    int32_t added = 0;
+    for (; c64 < n_pts && added <= FLUSH_START_MAX; c64 += 64) {
+      const int32_t n = min(n_pts - c64, 64);
+      // one point per lane: rotated window cell, and whether this block's strip of its window
+      // holds anything but zeros (skip map, nhip_grid.hip)
+      uint32_t vcell = 0u, vwork = 0u;
+      if (lane < n) {
+        vcell = window_cell(P.xy[beg + c64 + lane], cf, sf, P, ox, oy, cx, cy);
+        vwork = P.dense ? 1u : ((uint32_t)skip_map[(size_t)(vcell >> 16) * mpitch + ((vcell & 0xffffu) >> 2)] & 1u);
+      }
       const int32_t vcol = (int32_t)(vcell & 0xffffu), vrow = (int32_t)(vcell >> 16);
-      const unsigned long long live = (n == 64) ? ~0ull : ((1ull << n) - 1ull);
-      // points whose strip for THIS wave holds a non-zero cell; a point with no such strip in any
-      // wave (vskip == 0) needs no tile at all
-      const unsigned long long work = __ballot((vskip >> strip) & 1u);
-      int32_t j = 0;
-      while (j < n) {
-        // lanes whose window lies inside the staged tile; e = first lane >= j that is not
-        const unsigned long long from_j = live & ~((1ull << j) - 1ull);
-        bool cov = vskip == 0u || (have_tile && (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
-                                   (uint32_t)(vrow - t_row0) <= (uint32_t)row_span);
-        unsigned long long miss = ~__ballot(cov) & from_j;
-        int32_t e = miss ? (int32_t)__builtin_ctzll(miss) : n;
+      unsigned long long todo = __ballot(vwork != 0u);
+      added += __builtin_popcountll(todo);
+      while (todo) {
+        const int32_t j = (int32_t)__builtin_ctzll(todo);
+        // remaining points inside the staged tile; e = first remaining point that is not
+        bool cov = have_tile && (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
+                   (uint32_t)(vrow - t_row0) <= (uint32_t)row_span;
+        unsigned long long miss = ~__ballot(cov) & todo;
+        int32_t e = miss ? (int32_t)__builtin_ctzll(miss) : 64;
         if (e == j) {
           // point j is outside: stage a new tile around it, biased along the sweep direction.
           // (This branch never touches the accumulators.)
@@ -322,57 +333,53 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
           have_tile = true;
           const int32_t fill_rows = min(TILE_ROWS, P.rows - t_row0);
           const uint8_t *gsrc = grid + (size_t)t_row0 * P.pitch + t_col0;
-          __syncthreads();  // every wave is done with the old tile
-          // Fill: 16-byte global loads (14 per 224-byte row span; t_col0 and the pitch are multiples
-          // of 16), FILL_INFLIGHT per lane at a time, then 4-byte LDS stores (the 212-byte LDS pitch
-          // that makes the reads conflict-free is not a multiple of 16).  Measured against LDS-DMA
-          // (global_load_lds_dword, 120 pieces of 256 B per tile, issue-bound): 3.6 % faster.
-          // 2 in flight runs as fast as 4 and keeps the kernel at 127 VGPRs with no scratch
-          // (4 spilled 28 B per lane = 1.5 GB of scratch writes per 10k-pair launch).
-          {
-            constexpr int ROW_CH = (LP + 15) / 16;  // 14
-            constexpr int FILL_INFLIGHT = 2;
-            const int32_t n_ch = fill_rows * ROW_CH;
-            int32_t rr = tid / ROW_CH, kk = tid % ROW_CH;
-            for (int32_t c0 = tid; c0 < n_ch; c0 += FILL_INFLIGHT * CSM_THREADS) {
+          __syncthreads();  // single wave: orders the LDS reads of the old tile before the stores
+          // Fill: lanes 0..55 move four tile rows per step -- one 16-byte global load per lane (14 per
+          // 224-byte row span; t_col0 and the pitch are multiples of 16), FILL_INFLIGHT steps at a
+          // time -- then 4-byte LDS stores (the 212-byte LDS pitch that makes the reads conflict-free
+          // is not a multiple of 16).  Tile rows past the stored grid re-read its last row; no
+          // covered window reaches them.
+          if (lane < FILL_ROWS * ROW_CH) {
+            const int fr = lane / ROW_CH, fk = lane % ROW_CH;  // (recomputed here: staging is rare, VGPRs are not)
+            const int fill_dw = fr * LP_DW + 4 * fk;
+            const uint8_t *lsrc = gsrc + 16 * fk;
+            const int32_t last_row = P.rows - 1 - t_row0;
+#pragma unroll
+            for (int b = 0; b < TILE_ROWS / FILL_ROWS; b += FILL_INFLIGHT) {
               uint4 v[FILL_INFLIGHT];
-              int32_t rs[FILL_INFLIGHT], ks[FILL_INFLIGHT];
 #pragma unroll
               for (int u = 0; u < FILL_INFLIGHT; u++) {
-                rs[u] = rr;
-                ks[u] = kk;
-                if (c0 + u * CSM_THREADS < n_ch)
-                  v[u] = *reinterpret_cast<const uint4 *>(gsrc + (size_t)rr * P.pitch + 16 * kk);
-                rr += CSM_THREADS / ROW_CH;  // 256 = 18 * 14 + 4
-                kk += CSM_THREADS % ROW_CH;
-                if (kk >= ROW_CH) { kk -= ROW_CH; rr += 1; }
+                const int32_t r = min(FILL_ROWS * (b + u) + fr, last_row);
+                v[u] = *reinterpret_cast<const uint4 *>(lsrc + (uint32_t)(r * P.pitch));
               }
 #pragma unroll
-              for (int u = 0; u < FILL_INFLIGHT; u++) {
-                if (c0 + u * CSM_THREADS < n_ch) {
-                  uint32_t *dst = s_tile + rs[u] * LP_DW + 4 * ks[u];
-                  dst[0] = v[u].x;
-                  if (ks[u] < ROW_CH - 1) { dst[1] = v[u].y; dst[2] = v[u].z; dst[3] = v[u].w; }
+              for (int u = 0; u < FILL_INFLIGHT; u++) s_tile[FILL_ROWS * (b + u) * LP_DW + fill_dw] = v[u].x;
+              if (fk < ROW_CH - 1) {
+#pragma unroll
+                for (int u = 0; u < FILL_INFLIGHT; u++) {
+                  uint32_t *dst = s_tile + FILL_ROWS * (b + u) * LP_DW + fill_dw;
+                  dst[1] = v[u].y;
+                  dst[2] = v[u].z;
+                  dst[3] = v[u].w;
                 }
               }
             }
           }
           __syncthreads();
-          cov = vskip == 0u || ((uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
-                                (uint32_t)(vrow - t_row0) <= (uint32_t)row_span);
-          miss = ~__ballot(cov) & from_j;
-          e = miss ? (int32_t)__builtin_ctzll(miss) : n;  // > j: the new tile covers point j
+          cov = (uint32_t)(vcol - t_col0) <= (uint32_t)COL_SPAN &&
+                (uint32_t)(vrow - t_row0) <= (uint32_t)row_span;
+          miss = ~__ballot(cov) & todo;
+          e = miss ? (int32_t)__builtin_ctzll(miss) : 64;  // > j: the new tile covers point j
         }
-        // points j..e-1 are covered: LDS byte offset of each lane's window start, then the
-        // grouped SWAR accumulation
+        // remaining points before e are covered: LDS byte offset of each lane's window start,
+        // then the grouped SWAR accumulation
         const uint32_t vorg = (uint32_t)(vrow - t_row0) * LP + (uint32_t)(vcol - t_col0);
-        const unsigned long long seg_mask = (e == 64 ? ~0ull : ((1ull << e) - 1ull)) & ~((1ull << j) - 1ull) & work;
+        const unsigned long long seg_mask = todo & (e == 64 ? ~0ull : ((1ull << e) - 1ull));
         swar_segment(A, tile_bytes, lane_off, vorg, seg_mask);
-        j = e;
+        todo &= ~seg_mask;
       }
     }
     swar_flush(A, acc, has_right);
-    }
   }
 
   const int32_t iy = oy + dy;
@@ -407,13 +414,7 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
     const unsigned long long o = shfl_xor_u64(best, m);
     best = o > best ? o : best;
   }
-  if (lane == 0) s_best[tid >> 6] = best;
-  __syncthreads();
-  if (tid == 0) {
-#pragma unroll
-    for (int i = 1; i < CSM_THREADS / 64; i++) best = s_best[i] > best ? s_best[i] : best;
-    atomicMax(&P.keys[pair], best);
-  }
+  if (lane == 0) atomicMax(&P.keys[pair], best);
 }
 
 __global__ void csm_finalize_kernel(const unsigned long long *__restrict__ keys,
@@ -475,6 +476,7 @@ void fill_params(CsmParams &P, const nhip_grid_spec_t *spec, const GridLayout &L
   const char *dense = getenv("NHIP_CSM_DENSE");
   P.dense = (dense && dense[0] == '1') ? 1 : 0;
   P.res = spec->res;
+  P.inv_res = 1.0 / spec->res;
 }
 
 }  // namespace
