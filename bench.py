@@ -37,21 +37,27 @@ def _traffic(key):
 
 
 def _onchip(n_pairs, n_theta, avg_ms):
-    """LDS-read, VALU- and SALU-issue utilisation of csm_correlate_kernel from its measured instruction
-    mix on this workload (rocprofv3 SQ counters, profiles/r01_pmc_sq_correlate.txt): per point-wave
-    27.2 VALU, 14.0 SALU and 2.4 LDS wave-instructions; a group of points that shares an aligned base
-    reads 7 dwords per lane once (0.53 groups per point -> 4 waves x 64 lanes x 28 B x 0.53 = 3.8 KiB of
-    LDS per point).  Peaks (MI355X_MICROARCH.md): ds_read_b32 128 B/clk/CU -> ~75 TB/s chip; VALU one
-    wave64 instruction per 2 clk per SIMD -> 256 CU x 4 SIMD x 2.4 GHz / 2 = 1.23e12 wave-instr/s; SALU
-    one instruction per clk per CU -> 6.1e11/s."""
-    points = float(n_pairs) * n_theta * 1081.0
+    """VALU-, SALU- and LDS-issue utilisation of csm_correlate_kernel: the instruction counts rocprofv3's SQ
+    counters measured for this workload (profiles/traffic.json <- profiles/r01_pmc_sq_correlate.txt, per
+    10k-pair launch, scaled by the pair count) divided by the kernel time measured live.  LDS read bytes:
+    every LDS instruction that is not a tile-fill store (3 per 16-byte fill load) moves 7/4 dwords per lane.
+    Peaks (MI355X_MICROARCH.md): ds_read_b32 128 B/clk/CU -> ~75 TB/s chip; VALU one wave64 instruction per
+    2 clk per SIMD -> 256 CU x 4 SIMD x 2.4 GHz / 2 = 1.23e12 wave-instr/s; SALU one instruction per clk per
+    CU -> 6.1e11/s."""
+    sq = _traffic("csm_correlate_sq_per_launch_10000pairs")
+    if not sq or n_theta != 61:
+        return None
+    k = n_pairs / 10000.0
     secs = avg_ms * 1e-3
-    lds = points * 7168.0 * 0.53 / secs / 1e12
-    valu = points * 4 * 27.2 / secs
-    salu = points * 4 * 14.0 / secs
+    valu, salu = k * sq["SQ_INSTS_VALU"] / secs, k * sq["SQ_INSTS_SALU"] / secs
+    waves = n_pairs * n_theta * 4.0
+    fill_loads = k * sq["SQ_INSTS_VMEM_RD"] - waves * 2 * 17  # minus the point and skip-byte loads of 17 lane-chunks
+    lds_reads = k * sq["SQ_INSTS_LDS"] - 3.0 * fill_loads
+    lds = lds_reads * (7.0 / 4.0) * 256.0 / secs / 1e12
     return {"lds_read_TBps": lds, "lds_read_peak_TBps": 75.0, "lds_frac": lds / 75.0,
             "valu_wave_instr_per_s": valu, "valu_peak_wave_instr_per_s": 1.2288e12, "valu_frac": valu / 1.2288e12,
-            "salu_instr_per_s": salu, "salu_peak_instr_per_s": 6.144e11, "salu_frac": salu / 6.144e11}
+            "salu_instr_per_s": salu, "salu_peak_instr_per_s": 6.144e11, "salu_frac": salu / 6.144e11,
+            "wave_wait_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]}
 
 
 def parse():

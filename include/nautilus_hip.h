@@ -72,10 +72,11 @@ typedef struct nhip_grid_layout {
   int64_t grid_bytes;  /* pitch*rows: bytes of one stored grid */
   double score_floor;  /* Lf = ln(floor_p): value of cell 0 */
   double score_step;   /* log-likelihood per quantisation step = -Lf/255 */
-  int64_t skip_bytes;  /* bytes of the skip map stored right after each image: one byte per aligned
-                          dword column and stored row; bit w says "the 21 rows x 21 dwords starting
-                          21*w rows below hold a non-zero cell", so the correlation kernel can leave
-                          out the windows that only add zeros (same sums, bit for bit) */
+  int64_t skip_bytes;  /* bytes of the skip map stored right after each image: one bit per stored row
+                          r and aligned dword column c (bit c&7 of byte c>>3, 8*ceil(pitch/256) bytes per
+                          row) = "stored rows [r, r+21) x dwords [c, c+21) hold a non-zero cell", so the
+                          correlation kernel can leave out window strips that only add zeros (same
+                          sums, bit for bit) */
   int64_t slot_bytes;  /* grid_bytes + skip_bytes: grid t of a buffer starts at byte t*slot_bytes */
 } nhip_grid_layout_t;
 

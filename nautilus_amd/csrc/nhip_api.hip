@@ -49,7 +49,7 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   L->pitch = ((L->S + 2 * L->pad) + 15) & ~15;
   L->R = (int32_t)ceil(3.0 * spec->sigma);
   L->grid_bytes = (int64_t)L->pitch * (int64_t)(L->S + 2 * L->pad);
-  L->skip_bytes = (((int64_t)(L->pitch / 4) * (int64_t)(L->S + 2 * L->pad)) + 15) & ~15ll;
+  L->skip_bytes = (((int64_t)skip_pitch(L->pitch) * (int64_t)(L->S + 2 * L->pad)) + 15) & ~15ll;
   L->slot_bytes = L->grid_bytes + L->skip_bytes;
   L->Lf = log(spec->floor_p);
   L->step = -L->Lf / 255.0;

@@ -38,7 +38,7 @@ struct GridLayout {
   int32_t S, pad, pitch, R;
   int64_t K;  // tap sum
   int64_t grid_bytes;  // pitch * rows: the stored image
-  int64_t skip_bytes;  // (pitch / 4) * rows rounded up to 16: the skip map that follows the image
+  int64_t skip_bytes;  // skip_pitch(pitch) * rows rounded up to 16: the skip map that follows the image
   int64_t slot_bytes;  // grid_bytes + skip_bytes: stride between consecutive grids of a buffer
   double Lf, step;
 };
@@ -46,7 +46,8 @@ struct GridLayout {
 // CSM_WAVE_ROWS plane rows and reads CSM_ROW_DW aligned dwords of each (nhip_csm.hip).
 constexpr int CSM_WAVE_ROWS = 21;
 constexpr int CSM_ROW_DW = 21;
-constexpr int CSM_WAVES = 4;
+// bytes per skip-map row: one bit per aligned dword column, whole 8-byte words
+__host__ __device__ constexpr int32_t skip_pitch(int32_t pitch) { return ((pitch / 4 + 63) / 64) * 8; }
 int make_layout(const nhip_grid_spec_t *spec, GridLayout *L);
 
 // Device-side constant tables of one grid spec (taps + quantiser thresholds), cached.

@@ -261,7 +261,7 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
   const uint8_t *grid = P.grids + (size_t)slot * P.slot_bytes;
   const uint8_t *skip_map = grid + P.grid_bytes;
-  const int32_t mpitch = P.pitch >> 2;
+  const int32_t mpitch = skip_pitch(P.pitch);
   // search centre in cells; a centre the stored border cannot cover scores nothing
   int32_t cx = VOLUME ? P.single_ox : (P.pair_origin ? P.pair_origin[2 * pair] : 0);
   int32_t cy = VOLUME ? P.single_oy : (P.pair_origin ? P.pair_origin[2 * pair + 1] : 0);
@@ -286,7 +286,7 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   // tile fill: lane -> (row within a 4-row step, 16-byte chunk of the row)
   constexpr int ROW_CH = (LP + 15) / 16;     // 14
   constexpr int FILL_ROWS = 64 / ROW_CH;     // 4 rows per step (lanes 56..63 idle)
-  static_assert(TILE_ROWS % (FILL_ROWS * FILL_INFLIGHT) == 0, "tile rows must be a whole number of fill batches");
+  static_assert(TILE_ROWS % FILL_ROWS == 0, "tile rows must be a whole number of fill steps");
 
   uint32_t acc[SEG_COLS];
 #pragma unroll
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
       uint32_t vcell = 0u, vwork = 0u;
       if (lane < n) {
         vcell = window_cell(P.xy[beg + c64 + lane], cf, sf, P, ox, oy, cx, cy);
-        vwork = P.dense ? 1u : ((uint32_t)skip_map[(size_t)(vcell >> 16) * mpitch + ((vcell & 0xffffu) >> 2)] & 1u);
+        vwork = P.dense ? 1u : (((uint32_t)skip_map[(size_t)(vcell >> 16) * mpitch + ((vcell & 0xffffu) >> 5)] >> ((vcell >> 2) & 7u)) & 1u);
       }
       const int32_t vcol = (int32_t)(vcell & 0xffffu), vrow = (int32_t)(vcell >> 16);
       unsigned long long todo = __ballot(vwork != 0u);
@@ -331,7 +331,6 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
           t_col0 = place(cj, ca, COL_SPAN - 15) & ~15;
           t_row0 = place(rj, ra, row_span);
           have_tile = true;
-          const int32_t fill_rows = min(TILE_ROWS, P.rows - t_row0);
           const uint8_t *gsrc = grid + (size_t)t_row0 * P.pitch + t_col0;
           __syncthreads();  // single wave: orders the LDS reads of the old tile before the stores
           // Fill: lanes 0..55 move four tile rows per step -- one 16-byte global load per lane (14 per
@@ -349,14 +348,17 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
               uint4 v[FILL_INFLIGHT];
 #pragma unroll
               for (int u = 0; u < FILL_INFLIGHT; u++) {
+                if (FILL_ROWS * (b + u) >= TILE_ROWS) continue;  // (compile time: the last batch may be short)
                 const int32_t r = min(FILL_ROWS * (b + u) + fr, last_row);
                 v[u] = *reinterpret_cast<const uint4 *>(lsrc + (uint32_t)(r * P.pitch));
               }
 #pragma unroll
-              for (int u = 0; u < FILL_INFLIGHT; u++) s_tile[FILL_ROWS * (b + u) * LP_DW + fill_dw] = v[u].x;
+              for (int u = 0; u < FILL_INFLIGHT; u++)
+                if (FILL_ROWS * (b + u) < TILE_ROWS) s_tile[FILL_ROWS * (b + u) * LP_DW + fill_dw] = v[u].x;
               if (fk < ROW_CH - 1) {
 #pragma unroll
                 for (int u = 0; u < FILL_INFLIGHT; u++) {
+                  if (FILL_ROWS * (b + u) >= TILE_ROWS) continue;
                   uint32_t *dst = s_tile + FILL_ROWS * (b + u) * LP_DW + fill_dw;
                   dst[1] = v[u].y;
                   dst[2] = v[u].z;

@@ -116,16 +116,16 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restric
 }
 
 // ---- skip map ---------------------------------------------------------------------------
-// A likelihood grid is zero except within the blur radius of a wall.  csm_correlate_kernel adds,
-// per point and per wave, the CSM_WAVE_ROWS x CSM_ROW_DW-dword strip of the grid that starts at
-// (window row + 21 * wave, window column & ~3); on the 1081-beam scans ~45 % of those strips hold
-// nothing but zeros.  The map stores, per stored row r and aligned dword column c, one byte whose
-// bit w says "rows [r + 21 w, r + 21 w + 21) x dwords [c, c + 21) contain a non-zero cell", so the
-// kernel can drop the all-zero strips (the sums are unchanged, bit for bit) with one byte load
-// per point.  One block per 64-row x 64-dword map tile; tiles whose footprint touches no
-// occupied blur tile stay on the memset's zeros.
+// A likelihood grid is zero except within the blur radius of a wall.  A wave of
+// csm_correlate_kernel adds, per point, the CSM_WAVE_ROWS x CSM_ROW_DW-dword strip of the grid that
+// starts at (window row, window column & ~3); on the 1081-beam scans ~45 % of those strips hold
+// nothing but zeros.  The map stores one BIT per stored row r and aligned dword column c: "rows
+// [r, r + 21) x dwords [c, c + 21) contain a non-zero cell" (bit c & 7 of byte c >> 3 of map row r,
+// SKIP_PITCH(pitch) bytes per row), so the kernel can leave those strips out -- the sums are
+// unchanged, bit for bit -- for one byte load per point.  One block per 64-row x 64-dword map
+// tile; tiles whose footprint touches no occupied blur tile stay on the memset's zeros.
 constexpr int MT = 64;
-constexpr int SK_ROWS = MT + CSM_WAVES * CSM_WAVE_ROWS - 1;  // grid rows feeding one map tile (147)
+constexpr int SK_ROWS = MT + CSM_WAVE_ROWS - 1;  // grid rows feeding one map tile (84)
 static_assert(CSM_ROW_DW - 1 <= 20 && MT == 64, "row mask is built from one 64-lane and one 20-lane ballot");
 
 __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__restrict__ occ,
@@ -133,8 +133,7 @@ __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__rest
                                                            int32_t tiles, int32_t pad, int32_t pitch,
                                                            int32_t rows, int64_t grid_bytes,
                                                            int64_t slot_bytes) {
-  __shared__ unsigned long long sH[SK_ROWS + 1];  // per grid row: bit c = a non-zero dword in [c0 + c, c0 + c + 21)
-  __shared__ unsigned long long sV[MT][CSM_WAVES];
+  __shared__ unsigned long long sH[SK_ROWS];  // per grid row: bit c = a non-zero dword in [c0 + c, c0 + c + 21)
   const int32_t t = blockIdx.z, tid = threadIdx.x;
   const int32_t r0 = blockIdx.y * MT, c0 = blockIdx.x * MT;  // first map row / dword column
   // footprint in raster coordinates -> blur tiles that could have written into it
@@ -173,38 +172,17 @@ __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__rest
       unsigned __int128 m = ((unsigned __int128)b1 << 64) | b0;
       m |= m >> 1;
       m |= m >> 2;
-      m |= m >> 4;                               // windows of 8
+      m |= m >> 4;                                             // windows of 8
       const unsigned __int128 m21 = m | (m >> 8) | (m >> 13);  // [c, c+16) U [c+13, c+21)
       if (lane == 0 && rb + u < SK_ROWS) sH[rb + u] = (unsigned long long)m21;
     }
   }
   __syncthreads();
-  // vertical: map row r, strip w = OR of the 21 row masks from r + 21 w
-  {
-    const int r = tid >> 2, w = tid & 3;
+  // vertical: map row r = OR of the 21 row masks from r on; 64 bits = 8 map bytes
+  if (tid < MT && r0 + tid < rows) {
     unsigned long long v = 0;
-    for (int j = 0; j < CSM_WAVE_ROWS; j++) v |= sH[r + CSM_WAVE_ROWS * w + j];
-    sV[r][w] = v;
-  }
-  __syncthreads();
-  // emit: each thread 16 map bytes (4 aligned dword stores)
-  {
-    const int r = tid >> 2, q = tid & 3;
-    if (r0 + r < rows) {
-      unsigned long long V[CSM_WAVES];
-      for (int w = 0; w < CSM_WAVES; w++) V[w] = sV[r][w];
-      for (int k = 0; k < 4; k++) {
-        const int c = 16 * q + 4 * k;
-        if (c0 + c >= mpitch) break;  // mpitch is a multiple of 4
-        uint32_t out = 0;
-        for (int b = 0; b < 4; b++) {
-          uint32_t bits = 0;
-          for (int w = 0; w < CSM_WAVES; w++) bits |= (uint32_t)((V[w] >> (c + b)) & 1ull) << w;
-          out |= bits << (8 * b);
-        }
-        *reinterpret_cast<uint32_t *>(M + (size_t)(r0 + r) * mpitch + c0 + c) = out;
-      }
-    }
+    for (int j = 0; j < CSM_WAVE_ROWS; j++) v |= sH[tid + j];
+    *reinterpret_cast<unsigned long long *>(M + (size_t)(r0 + tid) * skip_pitch(pitch) + c0 / 8) = v;
   }
 }
 

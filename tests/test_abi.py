@@ -44,7 +44,7 @@ def test_grid_layout_follows_cimg_debug():
     assert L.pad == 96 and L.pitch == 1392 and L.rows == 1392
     assert L.blur_radius == 6
     assert L.grid_bytes == 1392 * 1392
-    assert L.skip_bytes == 1392 * 1392 // 4 and L.slot_bytes == L.grid_bytes + L.skip_bytes
+    assert L.skip_bytes == 48 * 1392 and L.slot_bytes == L.grid_bytes + L.skip_bytes  # 1 bit per row and dword column
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
     for (r, res, side) in [(30, 0.3, 200), (30, 0.01, 6000), (10, 0.03, 666)]:
         assert csm.grid_layout(csm.grid_spec(r, res, 2.0, 1e-10, 4)).side == side

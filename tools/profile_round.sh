@@ -1,0 +1,27 @@
+#!/bin/bash
+# Collect the round's profiles on the GPU box (run through gpurun from the repo root):
+#   tools/profile_round.sh <tag>        e.g. r01b
+# Writes gpurun_out/prof_<tag>/{kernel_stats.txt,pmc_traffic.txt,pmc_sq.txt,bench_under_rocprof.json}.
+# Counters are collected in their own passes (never together with --kernel-trace / --stats).
+set -e
+TAG=${1:-rXX}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+OUT=$R/gpurun_out/prof_$TAG
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.log
+python3 $R/tools/rocprof_summary.py $OUT/kt > $OUT/kernel_stats.txt
+echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: $BENCH" > $OUT/pmc_traffic.txt
+for c in FETCH_SIZE WRITE_SIZE; do
+  rocprofv3 --pmc $c --output-format csv -d $OUT/pmc_$c -- $BENCH > /dev/null 2> $OUT/pmc_$c.log
+  python3 $R/tools/rocprof_summary.py $OUT/pmc_$c --pmc >> $OUT/pmc_traffic.txt
+done
+SQ="python3 $R/bench.py --steps 1 --warmup 0 --cpu-seconds 0 --no-resid"
+echo "# rocprofv3 --pmc (two passes) of: $SQ   (10000 pairs)" > $OUT/pmc_sq.txt
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/sq1 -- $SQ > /dev/null 2> $OUT/sq1.log
+rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq2 -- $SQ > /dev/null 2> $OUT/sq2.log
+python3 $R/tools/rocprof_summary.py $OUT/sq1 --pmc | grep -A9 "csm_correlate" >> $OUT/pmc_sq.txt
+python3 $R/tools/rocprof_summary.py $OUT/sq2 --pmc | grep -A9 "csm_correlate" >> $OUT/pmc_sq.txt
+rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/sq1 $OUT/sq2
+ls -la $OUT
