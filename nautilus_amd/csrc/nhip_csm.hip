@@ -3,16 +3,21 @@
 // Replaces CorrelativeScanMatcher::GetTransformation (call site
 // src/optimization/solver.cc:633-638), batched over candidate pairs.
 //
-// Formulation (accumulator-stationary, LDS-tiled): one workgroup owns one rotation k of one
-// pair and keeps an (nx x ny) plane of integer score accumulators in registers -- three lanes
-// per y-shift, 28 consecutive x-shifts each, 21 y-shifts per wave.  A point's contribution to the plane is the
-// (nx x ny) window of the target grid anchored at its rotated cell.  Points are visited in
-// beam order; consecutive beams hit neighbouring cells, so a run of points shares one grid
-// tile: the workgroup stages a 144-row x 212-byte tile of the grid in LDS (16-byte reads of
-// HBM/L2, once per run), then every point of the run is a wave-uniform LDS offset (v_readlane)
-// from which each lane reads its 7 aligned dwords and accumulates them SWAR-style (below).
+// Formulation (accumulator-stationary, LDS-tiled, one wave per workgroup): a 64-thread workgroup
+// owns one 21-row strip of the (nx x ny) score plane of one rotation k of one pair and keeps its
+// integer accumulators in registers -- three lanes per y-shift, 28 consecutive x-shifts each.
+// A point's contribution to the strip is the (81 x 21) window of the target grid anchored at its
+// rotated cell.  Per lane-chunk of 64 points the wave computes the rotated cells (one point per
+// lane) and looks up the target's skip map (nhip_grid.hip): points whose window strip holds only
+// zeros are dropped -- they would add nothing, so the sums are unchanged.  The others are visited
+// in beam order; consecutive beams hit neighbouring cells, so a run of points shares one grid
+// tile: the wave stages a 48-row x 212-byte tile of the grid in LDS (16-byte reads of HBM/L2,
+// once per run), then every point of the run is a wave-uniform LDS offset (v_readlane) from
+// which each lane reads its 7 aligned dwords and accumulates them SWAR-style (below).
 // LDS pitch 53 dwords makes the 32-lane read groups conflict-free (bank = 7 * lane mod 32).
 // All arithmetic is integer: sums are order-independent, hence bit-exact against the oracle.
+// One-wave workgroups never wait for each other (a shared tile made a 4-wave workgroup as slow
+// as its busiest strip), and the dispatcher balances the unequal strips across the SIMDs.
 //
 // No bounds checks: grids carry a zero border of pad = 2*max_shift+16 cells and rotated cells
 // are clamped to one cell outside the window-overlap range (a clamped point only sees border).
@@ -22,7 +27,7 @@ namespace nhip {
 
 namespace {
 
-constexpr int CSM_THREADS = 64;             // one wave per workgroup: waves never wait for each other
+constexpr int CSM_THREADS = 64;            // one wave per workgroup: waves never wait for each other
 constexpr int SEG_DW = 7;                  // aligned dwords a lane reads and accumulates per point
 constexpr int SEG_COLS = 4 * SEG_DW;       // 28 x-shifts per lane
 constexpr int SEGS = 3;                    // lanes per plane row: 84 aligned bytes >= 81 + 3
@@ -40,7 +45,7 @@ constexpr int LP = 4 * LP_DW;              // 212 bytes
 #define NHIP_FILL_INFLIGHT 4
 #endif
 constexpr int TILE_ROWS = NHIP_TILE_ROWS;
-constexpr int FILL_INFLIGHT = NHIP_FILL_INFLIGHT;          // 16-byte tile-fill loads a lane keeps in flight
+constexpr int FILL_INFLIGHT = NHIP_FILL_INFLIGHT;  // 16-byte tile-fill loads a lane keeps in flight
 constexpr int ROW_BYTES = SEGS * SEG_COLS; // bytes of a tile row one point touches from its aligned start (84)
 constexpr int COL_SPAN = LP - ROW_BYTES;   // max (pcol - tile_col0) of a covered point (128)
 
