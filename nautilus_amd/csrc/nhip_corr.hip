@@ -7,13 +7,18 @@
 // which the reference runs from scratch for every (i, j) block and every window size
 // (solver.cc:321-356): three tree descents per matched point.
 //
-// Per block one workgroup: the target cloud is staged in LDS (8 B per point), every lane owns
-// a contiguous range of source points, transforms them into the target frame with the float
-// affine inverse(T_target) * T_source (Eigen Affine2f semantics, individually rounded products)
-// and scans all target points (LDS broadcast reads): exact nearest neighbour, ties to the
-// lowest index, kept if sqrt(d2) < outlier_threshold.  Kept rows are written in source order
-// (block-wide exclusive scan of the per-lane counts) as the 8-float rows K4 consumes.
-// ~8 VALU ops per (source, target) candidate: 1081 x 1081 candidates per block.
+// Per block one workgroup: the target cloud is staged in LDS (8 B per point) and bucketed by a
+// uniform grid with cells a shade wider than the outlier threshold (counting sort on a 2048-entry
+// hash of the cell coordinates, all in LDS).  Every lane owns a contiguous range of source
+// points, transforms them into the target frame with the float affine inverse(T_target) * T_source
+// (Eigen Affine2f semantics, individually rounded products) and visits the 3 x 3 cells around
+// each: a target that passes sqrt(d2) < outlier_threshold lies in one of them, and so does the
+// global nearest neighbour whenever any target passes, so the kept rows equal an exhaustive
+// scan's (exact nearest neighbour, ties to the lowest index, kept if within the threshold).
+// Target clouds larger than the LDS stage, or coordinates so large that float cell indices are
+// no longer exact, take the exhaustive scan (LDS broadcast reads).  Kept rows are written in
+// source order (block-wide exclusive scan of the per-lane counts) as the 8-float rows K4 consumes.
+// ~25 candidates per source point instead of 1081.
 #include "nhip_common.h"
 
 namespace nhip {
@@ -60,6 +65,26 @@ __device__ __forceinline__ Aff2f mul_f(const Aff2f &A, const Aff2f &B) {
   return C;
 }
 
+constexpr int NB = 2048;  // hash buckets of the target grid
+
+__device__ __forceinline__ uint32_t cell_hash(int32_t cx, int32_t cy) {
+  return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u)) & (uint32_t)(NB - 1);
+}
+
+// block-wide inclusive scan of one int per thread (s_scan: CT ints)
+__device__ __forceinline__ int32_t block_scan_incl(int32_t v, int32_t *s_scan, int tid) {
+  __syncthreads();
+  s_scan[tid] = v;
+  __syncthreads();
+  for (int off = 1; off < CT; off <<= 1) {
+    const int32_t u = (tid >= off) ? s_scan[tid - off] : 0;
+    __syncthreads();
+    s_scan[tid] += u;
+    __syncthreads();
+  }
+  return s_scan[tid];
+}
+
 __global__ __launch_bounds__(CT) void corr_search_kernel(
     const float2 *__restrict__ xy, const float2 *__restrict__ normals,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ block_src,
@@ -67,6 +92,9 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
     const int64_t *__restrict__ cap_offsets, float4 *__restrict__ corr,
     int32_t *__restrict__ counts) {
   __shared__ float2 s_tgt[TGT_CHUNK];
+  __shared__ uint16_t s_sorted[TGT_CHUNK];  // target indices grouped by bucket
+  __shared__ uint32_t s_start[NB + 1];      // bucket h = s_sorted[s_start[h] .. s_start[h + 1])
+  __shared__ uint32_t s_cur[NB];
   __shared__ int32_t s_scan[CT];
   const int b = blockIdx.x, tid = threadIdx.x;
   const int32_t s = block_src[b], t = block_tgt[b];
@@ -76,12 +104,57 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
   float4 *out = corr + 2 * (size_t)cap_offsets[b];
   int32_t written = 0;  // rows already emitted by earlier source passes (uniform)
 
+  // cells 0.1 % wider than the threshold: |dx| < thr * (1 + 1e-6) for every target that passes
+  // sqrt(d2) < thr, and float cell coordinates below 2^20 are exact to 1e-1 cell
+  const float inv_cell = __fdiv_rn(1.0f, __fmul_rn(thr, 1.001f));
+  constexpr float CELL_LIMIT = 1048576.0f;
+  bool hashed = nt <= TGT_CHUNK && thr > 0.f && inv_cell < 3.0e38f;
+  if (hashed) {
+    // stage + bucket the whole target cloud once
+    int big = 0;
+    for (int32_t i = tid; i < NB; i += CT) s_start[i] = 0u;
+    __syncthreads();
+    for (int32_t i = tid; i < nt; i += CT) {
+      const float2 g = xy[tb + i];
+      s_tgt[i] = g;
+      const float fx = __fmul_rn(g.x, inv_cell), fy = __fmul_rn(g.y, inv_cell);
+      if (!(fabsf(fx) < CELL_LIMIT) || !(fabsf(fy) < CELL_LIMIT)) big = 1;
+      else atomicAdd(&s_start[cell_hash((int32_t)floorf(fx), (int32_t)floorf(fy))], 1u);
+    }
+    hashed = !__syncthreads_or(big);
+  }
+  if (hashed) {
+    // exclusive scan of the NB bucket counts (8 per thread), then scatter
+    uint32_t c[NB / CT], tot = 0;
+#pragma unroll
+    for (int k = 0; k < NB / CT; k++) {
+      c[k] = s_start[tid * (NB / CT) + k];
+      tot += c[k];
+    }
+    uint32_t run = (uint32_t)block_scan_incl((int32_t)tot, s_scan, tid) - tot;
+#pragma unroll
+    for (int k = 0; k < NB / CT; k++) {
+      s_start[tid * (NB / CT) + k] = run;
+      s_cur[tid * (NB / CT) + k] = run;
+      run += c[k];
+    }
+    if (tid == CT - 1) s_start[NB] = run;
+    __syncthreads();
+    for (int32_t i = tid; i < nt; i += CT) {
+      const float2 g = s_tgt[i];
+      const uint32_t h = cell_hash((int32_t)floorf(__fmul_rn(g.x, inv_cell)), (int32_t)floorf(__fmul_rn(g.y, inv_cell)));
+      s_sorted[atomicAdd(&s_cur[h], 1u)] = (uint16_t)i;
+    }
+    __syncthreads();
+  }
+
   for (int32_t s0 = 0; s0 < ns; s0 += CT * MAX_PER_LANE) {
     const int32_t n_pass = min(ns - s0, CT * MAX_PER_LANE);
     const int32_t per = (n_pass + CT - 1) / CT;  // <= MAX_PER_LANE
     const int32_t lo = s0 + tid * per, hi = min(lo + per, s0 + n_pass);
     float qx[MAX_PER_LANE], qy[MAX_PER_LANE], best[MAX_PER_LANE];
     int32_t bi[MAX_PER_LANE];
+    int big = 0;
 #pragma unroll
     for (int k = 0; k < MAX_PER_LANE; k++) {
       bi[k] = -1;
@@ -91,22 +164,52 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
         const float2 p = xy[sb + lo + k];
         qx[k] = __fadd_rn(dot2(C.m00, p.x, C.m01, p.y), C.tx);
         qy[k] = __fadd_rn(dot2(C.m10, p.x, C.m11, p.y), C.ty);
+        // (a non-finite query matches nothing on either path; only a huge finite one needs the scan)
+        if (fabsf(__fmul_rn(qx[k], inv_cell)) >= CELL_LIMIT || fabsf(__fmul_rn(qy[k], inv_cell)) >= CELL_LIMIT) big = 1;
       }
     }
-    for (int32_t t0 = 0; t0 < nt; t0 += TGT_CHUNK) {
-      const int32_t nc = min(nt - t0, TGT_CHUNK);
-      __syncthreads();
-      for (int32_t i = tid; i < nc; i += CT) s_tgt[i] = xy[tb + t0 + i];
-      __syncthreads();
-      for (int32_t i = 0; i < nc; i++) {
-        const float2 g = s_tgt[i];  // same address in every lane: LDS broadcast
+    const bool scan_all = !hashed || __syncthreads_or(hashed ? big : 0);
+    if (!scan_all) {
 #pragma unroll
-        for (int k = 0; k < MAX_PER_LANE; k++) {
-          const float dx = __fsub_rn(g.x, qx[k]), dy = __fsub_rn(g.y, qy[k]);
-          const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-          const bool better = d2 < best[k];  // strict: the lowest index wins ties
-          best[k] = better ? d2 : best[k];
-          bi[k] = better ? (t0 + i) : bi[k];
+      for (int k = 0; k < MAX_PER_LANE; k++) {
+        if (lo + k >= hi) continue;
+        const float fx = __fmul_rn(qx[k], inv_cell), fy = __fmul_rn(qy[k], inv_cell);
+        if (!(fabsf(fx) < CELL_LIMIT) || !(fabsf(fy) < CELL_LIMIT)) continue;  // NaN / inf: no match
+        const int32_t icx = (int32_t)floorf(fx), icy = (int32_t)floorf(fy);
+        for (int32_t oy = -1; oy <= 1; oy++)
+          for (int32_t ox = -1; ox <= 1; ox++) {
+            const uint32_t h = cell_hash(icx + ox, icy + oy);
+            const uint32_t e = s_start[h + 1];
+            for (uint32_t i = s_start[h]; i < e; i++) {
+              const int32_t idx = (int32_t)s_sorted[i];
+              const float2 g = s_tgt[idx];
+              const float dx = __fsub_rn(g.x, qx[k]), dy = __fsub_rn(g.y, qy[k]);
+              const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+              // the order of visits is arbitrary: (d2, index) lexicographic = "lowest index wins ties"
+              const bool better = d2 < best[k] || (d2 == best[k] && (uint32_t)idx < (uint32_t)bi[k]);
+              best[k] = better ? d2 : best[k];
+              bi[k] = better ? idx : bi[k];
+            }
+          }
+      }
+    } else {
+      for (int32_t t0 = 0; t0 < nt; t0 += TGT_CHUNK) {
+        const int32_t nc = min(nt - t0, TGT_CHUNK);
+        if (!hashed) {  // (a hashed block already holds the whole target cloud in s_tgt)
+          __syncthreads();
+          for (int32_t i = tid; i < nc; i += CT) s_tgt[i] = xy[tb + t0 + i];
+          __syncthreads();
+        }
+        for (int32_t i = 0; i < nc; i++) {
+          const float2 g = s_tgt[i];  // same address in every lane: LDS broadcast
+#pragma unroll
+          for (int k = 0; k < MAX_PER_LANE; k++) {
+            const float dx = __fsub_rn(g.x, qx[k]), dy = __fsub_rn(g.y, qy[k]);
+            const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+            const bool better = d2 < best[k];  // strict: the lowest index wins ties
+            best[k] = better ? d2 : best[k];
+            bi[k] = better ? (t0 + i) : bi[k];
+          }
         }
       }
     }
@@ -119,16 +222,8 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
       mine += keep[k] ? 1 : 0;
     }
     // block-wide exclusive scan of `mine` (source order = lane order x per-lane order)
-    __syncthreads();
-    s_scan[tid] = mine;
-    __syncthreads();
-    for (int off = 1; off < CT; off <<= 1) {
-      const int32_t v = (tid >= off) ? s_scan[tid - off] : 0;
-      __syncthreads();
-      s_scan[tid] += v;
-      __syncthreads();
-    }
-    int32_t pos = written + s_scan[tid] - mine;
+    const int32_t incl = block_scan_incl(mine, s_scan, tid);
+    int32_t pos = written + incl - mine;
     const int32_t total = s_scan[CT - 1];
 #pragma unroll
     for (int k = 0; k < MAX_PER_LANE; k++) {

@@ -104,6 +104,49 @@ def test_corr_search_edge_cases(gpu):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("thr", [0.25, 0.03, 1e-30, 7.5, 1e30])
+def test_corr_search_hash_grid_corner_cases(gpu, thr):
+    """The bucketed search must return what the exhaustive scan returns: exact ties between duplicate
+    targets (lowest index), points on cell boundaries and at negative coordinates, non-finite points,
+    coordinates too large for exact cell indices (-> exhaustive path), thresholds from 0 to 'everything'."""
+    from nautilus_amd.correspondence import IcpBatch
+    rng = np.random.default_rng(17)
+    cell = np.float32(0.25 * 1.001)
+    lattice = (np.stack(np.meshgrid(np.arange(-12, 12), np.arange(-12, 12)), -1).reshape(-1, 2) * cell).astype(np.float32)
+    dup = np.repeat(rng.uniform(-3, 3, (150, 2)).astype(np.float32), 4, axis=0)      # four copies of each target
+    wall = np.stack([np.linspace(-20, 20, 1081), np.full(1081, 2.0)], 1).astype(np.float32)
+    weird = rng.uniform(-4, 4, (400, 2)).astype(np.float32)
+    weird[5] = [np.nan, 1.0]
+    weird[6] = [np.inf, 0.0]
+    weird[7] = [-np.inf, np.nan]
+    weird[8] = [3e7, 1.0]                                                              # huge but finite
+    far = (rng.uniform(-1, 1, (300, 2)) + [2.0e7, -3.0e7]).astype(np.float32)
+    scans = [lattice, (lattice + rng.normal(0, 0.02, lattice.shape)).astype(np.float32), dup,
+             (dup[::4] + rng.normal(0, 0.01, (150, 2))).astype(np.float32), wall,
+             (wall + rng.normal(0, 0.05, wall.shape)).astype(np.float32), weird,
+             (weird + np.float32(0.01)).astype(np.float32), far, (far + np.float32(1.0)).astype(np.float32)]
+    normals = [rng.normal(0, 1, s_.shape).astype(np.float32) for s_ in scans]
+    xy, off = csm.pack_scans(scans)
+    nrm = np.concatenate(normals)
+    bs = np.array([1, 0, 3, 2, 5, 4, 7, 6, 6, 9, 8, 3], np.int32)
+    bt = np.array([0, 1, 2, 3, 4, 5, 6, 7, 6, 8, 9, 0], np.int32)
+    poses = rng.normal(0, [0.03, 0.03, 0.01], (len(scans), 3))
+    poses[8:] = 0.0
+    batch = IcpBatch(xy, nrm, off, bs, bt, outlier_threshold=thr)
+    batch.set_poses(poses)
+    n = batch.search()
+    rows, boff = batch.correspondences()
+    want, counts, cap = O.corr_search_batch(xy, nrm, off, bs, bt, O.pose_affines(poses), thr)
+    assert np.array_equal(np.diff(boff), counts) and n == counts.sum()
+    for b in range(len(bs)):
+        assert rows[boff[b]:boff[b + 1]].tobytes() == want[cap[b]:cap[b] + counts[b]].tobytes(), (b, thr)
+    if thr == 0.25:
+        assert counts[2] == 150 and counts[3] == 600 and counts[4] > 300 and counts[8] > 380  # (the test is not vacuous)
+    if thr == 1e-30:
+        assert counts[8] >= 390 and counts[:8].sum() == 0  # only exactly coincident points survive (2e7 + 1 == 2e7 in float)
+
+
+@pytest.mark.gpu
 def test_search_feeds_residuals_and_normal_equations(gpu, small_bag):
     """K5 -> K4 without leaving HBM; normal equations == J^T J, J^T r, r^T r of the oracle's
     autodiff Jacobians on the same correspondences."""
