@@ -371,9 +371,16 @@ def bench_icp(bag, xy, off, with_cpu, window=10, iters=5):
     _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_NORMEQ, C.byref(ms), C.byref(n)))
     t_neq = ms.value / max(n.value, 1)
     cand = float(np.sum((off[bs + 1] - off[bs]).astype(np.float64) * (off[bt + 1] - off[bt])))
+    pts_in = float(np.sum(off[bs + 1] - off[bs]) + np.sum(off[bt + 1] - off[bt]))
     out = {"workload": "configs[2] shape: %d blocks (window %d) of 1081-point scans" % (len(bs), window),
            "correspondences": n_corr, "corr_search_ms": t_search,
-           "corr_search_candidates_per_s": cand / (t_search * 1e-3),
+           "corr_search_blocks_per_s": len(bs) / (t_search * 1e-3),
+           "corr_search_exhaustive_equivalent_candidates_per_s": cand / (t_search * 1e-3),
+           "corr_search_roofline": {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": None,
+                                    "achieved": (8.0 * pts_in + 32.0 * n_corr) / (t_search * 1e-3) / 1e9,
+                                    "frac": (8.0 * pts_in + 32.0 * n_corr) / (t_search * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    "note": "8 B per source and target point read + 32 B per kept row written; the "
+                                            "kernel is bound by its LDS sort and divergent bucket walks, not by HBM"},
            "normal_eq_ms": t_neq, "normal_eq_correspondences_per_s": n_corr / (t_neq * 1e-3),
            "normal_eq_roofline": {"bound": "hbm", "achieved": 32.0 * n_corr / (t_neq * 1e-3) / 1e9,
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s",
