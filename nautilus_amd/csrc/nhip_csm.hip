@@ -27,7 +27,11 @@ namespace nhip {
 
 namespace {
 
-constexpr int CSM_THREADS = 64;            // one wave per workgroup: waves never wait for each other
+#ifndef NHIP_WG_WAVES
+#define NHIP_WG_WAVES 1
+#endif
+constexpr int WG_WAVES = NHIP_WG_WAVES;    // strips (waves) that share one tile; 1: waves never wait for each other
+constexpr int CSM_THREADS = 64 * WG_WAVES;
 constexpr int SEG_DW = 7;                  // aligned dwords a lane reads and accumulates per point
 constexpr int SEG_COLS = 4 * SEG_DW;       // 28 x-shifts per lane
 constexpr int SEGS = 3;                    // lanes per plane row: 84 aligned bytes >= 81 + 3
@@ -35,11 +39,11 @@ constexpr int WAVE_ROWS = 63 / SEGS;       // 21 plane rows per wave (lane 63 id
 static_assert(WAVE_ROWS == CSM_WAVE_ROWS && SEGS * SEG_DW == CSM_ROW_DW,
               "the skip map (nhip_grid.hip) is built for this wave footprint");
 constexpr int PB_NX = SEGS * SEG_COLS - 3; // 81 x-shifts per plane block (84 bytes minus alignment slack)
-constexpr int PB_NY = WAVE_ROWS;           // 21 y-shifts per plane block
+constexpr int PB_NY = WG_WAVES * WAVE_ROWS; // y-shifts per plane block (21 per wave)
 constexpr int LP_DW = 53;                  // LDS tile pitch in dwords (conflict-free: 53 = 21 mod 32)
 constexpr int LP = 4 * LP_DW;              // 212 bytes
 #ifndef NHIP_TILE_ROWS
-#define NHIP_TILE_ROWS 48
+#define NHIP_TILE_ROWS (48 * NHIP_WG_WAVES)
 #endif
 #ifndef NHIP_FILL_INFLIGHT
 #define NHIP_FILL_INFLIGHT 4
@@ -237,8 +241,11 @@ __device__ __forceinline__ int32_t place(int32_t here, int32_t ahead, int32_t sp
   return a < 0 ? 0 : a;
 }
 
+#ifndef NHIP_WAVES_PER_SIMD
+#define NHIP_WAVES_PER_SIMD 4
+#endif
 template <bool VOLUME>
-__global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams P) {
+__global__ __launch_bounds__(CSM_THREADS, NHIP_WAVES_PER_SIMD) void csm_correlate_kernel(CsmParams P) {
   __shared__ uint32_t s_tile[TILE_ROWS * LP_DW];
 
   // ---- block -> (pair, rotation, plane block); everything of a pair shares an XCD
@@ -279,9 +286,9 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   const float sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
 
   // lane = 3 * (plane row) + segment; lane 63 idles
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lane_c = lane < 63 ? lane : 62;
-  const int dy = lane_c / SEGS, seg = lane_c % SEGS;
+  const int dy = wave * WAVE_ROWS + lane_c / SEGS, seg = lane_c % SEGS;
   const bool lane_live = lane < 63;
   const bool has_right = lane_live && seg < SEGS - 1;  // lane + 1 holds the next 28 bytes of the same row
   // lanes past the plane block's rows re-read row 0 (their sums are never used)
@@ -291,7 +298,7 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
   // tile fill: lane -> (row within a 4-row step, 16-byte chunk of the row)
   constexpr int ROW_CH = (LP + 15) / 16;     // 14
   constexpr int FILL_ROWS = 64 / ROW_CH;     // 4 rows per step (lanes 56..63 idle)
-  static_assert(TILE_ROWS % FILL_ROWS == 0, "tile rows must be a whole number of fill steps");
+  static_assert(TILE_ROWS % (FILL_ROWS * WG_WAVES) == 0, "tile rows must be a whole number of fill steps");
 
   uint32_t acc[SEG_COLS];
 #pragma unroll
@@ -312,14 +319,20 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
       const int32_t n = min(n_pts - c64, 64);
       // one point per lane: rotated window cell, and whether this block's strip of its window
       // holds anything but zeros (skip map, nhip_grid.hip)
-      uint32_t vcell = 0u, vwork = 0u;
+      uint32_t vcell = 0u, vwork = 0u;  // vwork bit u: strip u of this plane block has work for the point
       if (lane < n) {
         vcell = window_cell(P.xy[beg + c64 + lane], cf, sf, P, ox, oy, cx, cy);
-        vwork = P.dense ? 1u : (((uint32_t)skip_map[(size_t)(vcell >> 16) * mpitch + ((vcell & 0xffffu) >> 5)] >> ((vcell >> 2) & 7u)) & 1u);
+#pragma unroll
+        for (int u = 0; u < WG_WAVES; u++) {
+          if (u * WAVE_ROWS >= nyb) break;
+          const uint32_t bit = P.dense ? 1u : (((uint32_t)skip_map[(size_t)((vcell >> 16) + u * WAVE_ROWS) * mpitch + ((vcell & 0xffffu) >> 5)] >> ((vcell >> 2) & 7u)) & 1u);
+          vwork |= bit << u;
+        }
       }
       const int32_t vcol = (int32_t)(vcell & 0xffffu), vrow = (int32_t)(vcell >> 16);
-      unsigned long long todo = __ballot(vwork != 0u);
-      added += __builtin_popcountll(todo);
+      unsigned long long todo = __ballot(vwork != 0u);           // points some wave of the workgroup needs
+      const unsigned long long mine = __ballot((vwork >> wave) & 1u);  // points this wave adds
+      added += __builtin_popcountll(mine);
       while (todo) {
         const int32_t j = (int32_t)__builtin_ctzll(todo);
         // remaining points inside the staged tile; e = first remaining point that is not
@@ -344,27 +357,29 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
           // is not a multiple of 16).  Tile rows past the stored grid re-read its last row; no
           // covered window reaches them.
           if (lane < FILL_ROWS * ROW_CH) {
-            const int fr = lane / ROW_CH, fk = lane % ROW_CH;  // (recomputed here: staging is rare, VGPRs are not)
+            // (recomputed here: staging is rare, VGPRs are not); wave w takes steps w, w + WG_WAVES, ...
+            const int fr = lane / ROW_CH + FILL_ROWS * wave, fk = lane % ROW_CH;
             const int fill_dw = fr * LP_DW + 4 * fk;
             const uint8_t *lsrc = gsrc + 16 * fk;
             const int32_t last_row = P.rows - 1 - t_row0;
+            constexpr int STEP_ROWS = FILL_ROWS * WG_WAVES;  // rows one step of the whole workgroup covers
 #pragma unroll
-            for (int b = 0; b < TILE_ROWS / FILL_ROWS; b += FILL_INFLIGHT) {
+            for (int b = 0; b < TILE_ROWS / STEP_ROWS; b += FILL_INFLIGHT) {
               uint4 v[FILL_INFLIGHT];
 #pragma unroll
               for (int u = 0; u < FILL_INFLIGHT; u++) {
-                if (FILL_ROWS * (b + u) >= TILE_ROWS) continue;  // (compile time: the last batch may be short)
-                const int32_t r = min(FILL_ROWS * (b + u) + fr, last_row);
+                if (STEP_ROWS * (b + u) >= TILE_ROWS) continue;  // (compile time: the last batch may be short)
+                const int32_t r = min(STEP_ROWS * (b + u) + fr, last_row);
                 v[u] = *reinterpret_cast<const uint4 *>(lsrc + (uint32_t)(r * P.pitch));
               }
 #pragma unroll
               for (int u = 0; u < FILL_INFLIGHT; u++)
-                if (FILL_ROWS * (b + u) < TILE_ROWS) s_tile[FILL_ROWS * (b + u) * LP_DW + fill_dw] = v[u].x;
+                if (STEP_ROWS * (b + u) < TILE_ROWS) s_tile[STEP_ROWS * (b + u) * LP_DW + fill_dw] = v[u].x;
               if (fk < ROW_CH - 1) {
 #pragma unroll
                 for (int u = 0; u < FILL_INFLIGHT; u++) {
-                  if (FILL_ROWS * (b + u) >= TILE_ROWS) continue;
-                  uint32_t *dst = s_tile + FILL_ROWS * (b + u) * LP_DW + fill_dw;
+                  if (STEP_ROWS * (b + u) >= TILE_ROWS) continue;
+                  uint32_t *dst = s_tile + STEP_ROWS * (b + u) * LP_DW + fill_dw;
                   dst[1] = v[u].y;
                   dst[2] = v[u].z;
                   dst[3] = v[u].w;
@@ -382,7 +397,7 @@ __global__ __launch_bounds__(CSM_THREADS, 4) void csm_correlate_kernel(CsmParams
         // then the grouped SWAR accumulation
         const uint32_t vorg = (uint32_t)(vrow - t_row0) * LP + (uint32_t)(vcol - t_col0);
         const unsigned long long seg_mask = todo & (e == 64 ? ~0ull : ((1ull << e) - 1ull));
-        swar_segment(A, tile_bytes, lane_off, vorg, seg_mask);
+        swar_segment(A, tile_bytes, lane_off, vorg, seg_mask & mine);
         todo &= ~seg_mask;
       }
     }
