@@ -17,18 +17,21 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
-def run(n_scans=320, window=5, seed=20201114, drift_t=0.02, drift_th_deg=0.3, per_target=2, verbose=False):
+def run(n_scans=320, window=5, seed=20201114, drift_t=0.02, drift_th_deg=0.3, per_target=2, verbose=False,
+        residual="normal"):
     from nautilus_amd import _lib, csm, posegraph, synth
     bag = synth.SynthBag(n_scans, dense=True, seed=seed)
     odom = synth.odometry_from_truth(bag.truth, sigma_t=drift_t, sigma_th_deg=drift_th_deg, seed=seed)
     odom = odom - odom[0] + bag.truth[0]  # both tracks start at the same anchor (pose 0 is held constant)
     xy, off = csm.pack_scans(bag.scans)
     nrm = np.concatenate(bag.normals).astype(np.float32)
-    out = {"n_scans": n_scans, "window": window, "err_odometry_m": posegraph.trajectory_error(odom, bag.truth)}
+    out = {"n_scans": n_scans, "window": window, "residual": residual, "err_odometry_m": posegraph.trajectory_error(odom, bag.truth)}
 
     t0 = time.perf_counter()
-    pg = posegraph.PoseGraph(xy, nrm, off, odom, window=window, kind=_lib.NHIP_LIDAR_POINT)
-    poses, hist = pg.solve(iterations=6, verbose=verbose)
+    # Solver::OptimizeOverGrowingWindow (solver.cc:339-355): window sizes 1..window, fresh correspondences each
+    pg, poses = posegraph.solve_growing_window(xy, nrm, off, odom, 1, window, iterations=6,
+                                               kind=_lib.NHIP_LIDAR_NORMAL if residual == "normal" else _lib.NHIP_LIDAR_POINT,
+                                               verbose=verbose)
     out["t_icp_solve_s"] = time.perf_counter() - t0
     out["err_icp_m"] = posegraph.trajectory_error(poses, bag.truth)
     out["icp_correspondences"] = pg.icp.n_corr
@@ -71,6 +74,9 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--scans", type=int, default=320)
     ap.add_argument("--window", type=int, default=5)
+    ap.add_argument("--residual", choices=["point", "normal"], default="normal",
+                    help="LIDARPointResidual on all points (the reference's non-FEATURE mode, solver.cc:308-314) or "
+                         "LIDARNormalResidual (its planar-feature mode, solver.cc:298-303)")
     ap.add_argument("-v", action="store_true")
     a = ap.parse_args()
-    print(json.dumps(run(a.scans, a.window, verbose=a.v)))
+    print(json.dumps(run(a.scans, a.window, verbose=a.v, residual=a.residual)))

@@ -80,14 +80,15 @@ def loop_closure_factors(poses, pairs_src, pairs_tgt, rel, **kw):
 
 class PoseGraph:
     def __init__(self, xy, normals, offsets, odom, window=10, kind=_lib.NHIP_LIDAR_POINT, outlier_threshold=0.25,
-                 odom_weights=(1.0, 1.0), device="cuda:0"):
+                 odom_weights=(1.0, 1.0), device="cuda:0", initial=None):
         self.n = len(odom)
         self.kind = kind
         bs, bt = window_pairs(self.n, window)
         self.icp = IcpBatch(xy, normals, offsets, bs, bt, device, outlier_threshold)
         self.odo = odometry_factors_from_poses(odom, tw=odom_weights[0], rw=odom_weights[1], device=device)
         self.lc = None
-        self.poses = np.array(odom, dtype=np.float64)
+        # odometry factors always come from `odom`; the estimate may start elsewhere (previous window pass)
+        self.poses = np.array(odom if initial is None else initial, dtype=np.float64)
 
     def add_loop_closures(self, pairs_src, pairs_tgt, rel, weights=(10.0, 10.0)):
         self.lc = loop_closure_factors(self.poses, pairs_src, pairs_tgt, rel, tw=weights[0], rw=weights[1],
@@ -154,6 +155,24 @@ class PoseGraph:
                 print("iter %d cost %.6g lambda %.2g" % (it, cost, lam))
         self.poses = poses
         return poses, history
+
+
+def solve_growing_window(xy, normals, offsets, odom, window_min=1, window_max=10, iterations=4,
+                         kind=_lib.NHIP_LIDAR_POINT, outlier_threshold=0.25, odom_weights=(1.0, 1.0),
+                         device="cuda:0", verbose=False):
+    """Solver::OptimizeOverGrowingWindow (solver.cc:339-355): for every window size from
+    lidar_constraint_amount_min to _max the problem is rebuilt -- odometry factors plus fresh
+    correspondences for all (i, j) blocks of the window, searched at the current estimate -- and solved.
+    Returns (PoseGraph of the last pass, poses, total correspondences of the last pass)."""
+    poses = np.array(odom, dtype=np.float64)
+    pg = None
+    for w in range(window_min, window_max + 1):
+        pg = PoseGraph(xy, normals, offsets, odom, window=w, kind=kind, outlier_threshold=outlier_threshold,
+                       odom_weights=odom_weights, device=device, initial=poses)
+        poses, hist = pg.solve(iterations=iterations, verbose=verbose)
+        if verbose:
+            print("window %d: cost %.6g -> %.6g" % (w, hist[0], hist[-1]))
+    return pg, poses
 
 
 def trajectory_error(poses, truth):
