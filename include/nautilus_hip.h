@@ -122,8 +122,9 @@ double nhip_score_from_sum(const nhip_grid_spec_t *spec, int64_t sum, int32_t n_
 
 /* ------------------------------------------------------------------ device-pointer API */
 /* K1: build likelihood grids for n_targets scans (scan ids in d_target_ids) into
- * d_grids[slot] (slot = position in d_target_ids).  d_xy: float2 points of all scans,
- * d_offsets: n_scans+1 prefix offsets (in points). */
+ * d_grids (nhip_grids_bytes(spec, n_targets) bytes): slot t = position in d_target_ids, at byte
+ * t * slot_bytes, holds the stored image (grid_bytes) followed by its skip map (skip_bytes).
+ * d_xy: float2 points of all scans, d_offsets: n_scans+1 prefix offsets (in points). */
 int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
                         int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
                         void *d_workspace, int64_t workspace_bytes, void *stream);
