@@ -246,6 +246,24 @@ def main():
         # the honest ceilings are the LDS read pipe and VALU issue, not HBM.
         "onchip_roofline": _onchip(n_pairs, search.n_theta, avg_ms),
     }
+    if world == 1:
+        # the same steps with the skip map ignored (every add of the exhaustive definition performed)
+        try:
+            os.environ["NHIP_CSM_DENSE"] = "1"
+            step()
+            fence()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                step()
+            fence()
+            dt = (time.perf_counter() - t0) / 2
+            same = bool(np.array_equal(d_sums.cpu().numpy(), got_sums) and
+                        d_out.cpu().numpy().tobytes() == got.tobytes())
+            out["zero_skip"] = {"dense_value": n_pairs / dt, "dense_ms_per_step": 1e3 * dt, "same_result": same,
+                                "note": "NHIP_CSM_DENSE=1: all-zero window strips are added like any other; `value` "
+                                        "leaves them out (skip map built with the grids), results are identical"}
+        finally:
+            os.environ.pop("NHIP_CSM_DENSE", None)
     if world == 1 and a.cpu_seconds > 0:
         cb, sel, ref = cpu_baseline(bag, xy, off, ids, src, slot, h_th0, a.cpu_seconds)
         ok = all(np.array_equal(got[f][sel], ref[f]) for f in ("itheta", "ix", "iy")) and \
