@@ -268,6 +268,18 @@ int nhip_resid_point_to_line(const float *segments, const float *points, const i
                              const double *line_poses, int32_t n_line_poses, double *residuals,
                              double *jac_pose, double *jac_line);
 
+/* ------------------------------------------------------------------ multi-GPU
+ * The one collective of the path: every GPU matched its own shard of the candidate pairs
+ * (pairs are independent; shard by target so a grid is built on exactly one GPU) and the
+ * 16-byte records are all-gathered.  `comm` is the RCCL communicator (ncclComm_t, one rank
+ * per GPU, created by the host with ncclCommInitRank) passed as void* so this header needs
+ * no RCCL include; every rank contributes n_local records (pad the shards to equal length)
+ * and receives world_size * n_local records ordered by rank.  librccl is bound on first use
+ * (dlopen: the copy already loaded in the process if there is one), so single-GPU hosts
+ * never need it.  A Python host does the same with torch.distributed (nautilus_amd/sharding.py). */
+int nhip_allgather_matches(void *comm, const nhip_match_t *d_local, int32_t n_local,
+                           nhip_match_t *d_all, void *stream);
+
 /* ------------------------------------------------------------------ in-stream kernel timing
  * When enabled, the dominant kernels are bracketed by hipEvents on their own stream.
  * ids: 0 = csm_correlate, 1 = grid_build (blur), 2 = resid_lidar, 3 = corr_search,

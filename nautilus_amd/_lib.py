@@ -89,6 +89,7 @@ PROTOTYPES = {
     "nhip_resid_odometry": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _i32, _vp, _vp, _vp]),
     "nhip_resid_point_to_line": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
                                            _vp, _vp, _vp]),
+    "nhip_allgather_matches": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "nhip_timing_enable": (C.c_int, [C.c_int]),
     "nhip_timing_reset": (C.c_int, []),
     "nhip_timing_get": (C.c_int, [C.c_int, _P(_f64), _P(_i32)]),

@@ -4,7 +4,11 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <vector>
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
 
 #include "CorrelativeScanMatcher.h"
 #include "slam_residuals_hip.h"
@@ -134,6 +138,30 @@ int main() {
   std::printf("odometry + point-to-line blocks: ok (r_line = %.4f %.4f %.4f)\n", rl[0], rl[1], rl[2]);
   delete o0; delete o1; delete l0;
   B.Reset();
+  // ---- the path's one collective through the C ABI: a C++ host owns the RCCL communicator
+  // (one rank per GPU; this box has one, so world size 1) and hands it over as void*
+  {
+    ncclUniqueId id;
+    ncclComm_t comm;
+    REQUIRE(ncclGetUniqueId(&id) == ncclSuccess);
+    REQUIRE(ncclCommInitRank(&comm, 1, id, 0) == ncclSuccess);
+    std::vector<nhip_match_t> local(1000), all(1000);
+    for (int i = 0; i < 1000; i++) local[i] = {i, 2 * i, 3 * i, -0.5f * i};
+    nhip_match_t *d_local, *d_all;
+    REQUIRE(hipMalloc(&d_local, sizeof(nhip_match_t) * 1000) == hipSuccess);
+    REQUIRE(hipMalloc(&d_all, sizeof(nhip_match_t) * 1000) == hipSuccess);
+    REQUIRE(hipMemcpy(d_local, local.data(), sizeof(nhip_match_t) * 1000, hipMemcpyHostToDevice) == hipSuccess);
+    hipStream_t st;
+    REQUIRE(hipStreamCreate(&st) == hipSuccess);
+    REQUIRE(nhip_allgather_matches(comm, d_local, 1000, d_all, st) == NHIP_OK);
+    REQUIRE(hipStreamSynchronize(st) == hipSuccess);
+    REQUIRE(hipMemcpy(all.data(), d_all, sizeof(nhip_match_t) * 1000, hipMemcpyDeviceToHost) == hipSuccess);
+    REQUIRE(std::memcmp(all.data(), local.data(), sizeof(nhip_match_t) * 1000) == 0);
+    REQUIRE(nhip_allgather_matches(nullptr, d_local, 1000, d_all, st) == NHIP_ERR_ARG);
+    (void)hipFree(d_local); (void)hipFree(d_all); (void)hipStreamDestroy(st);
+    ncclCommDestroy(comm);
+    std::printf("allgather of 1000 match records over RCCL (1 rank): ok\n");
+  }
   std::printf("ADAPTER_OK\n");
   return 0;
 }

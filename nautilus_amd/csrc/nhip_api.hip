@@ -1,5 +1,7 @@
 // nhip_api.hip -- extern "C" shim of libnautilus_hip (include/nautilus_hip.h): argument
 // checking, host-side spec tables, handle objects, in-stream kernel timing.
+#include <dlfcn.h>
+
 #include <cstdarg>
 #include <mutex>
 
@@ -768,6 +770,55 @@ int nhip_resid_point_to_line(const float *segments, const float *points, const i
   NHIP_TRY_HIP(hipMemcpy(residuals, res.p, sizeof(double) * (size_t)n_points, hipMemcpyDeviceToHost));
   if (jac_pose) NHIP_TRY_HIP(hipMemcpy(jac_pose, j0.p, sizeof(double) * 3 * (size_t)n_points, hipMemcpyDeviceToHost));
   if (jac_line) NHIP_TRY_HIP(hipMemcpy(jac_line, j1.p, sizeof(double) * 3 * (size_t)n_points, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+// ---------------------------------------------------------------- multi-GPU all-gather
+namespace {
+// ncclAllGather(sendbuff, recvbuff, sendcount, datatype, comm, stream); ncclInt8 = 0 (rccl.h)
+typedef int (*nccl_allgather_fn)(const void *, void *, size_t, int, void *, hipStream_t);
+typedef const char *(*nccl_errstr_fn)(int);
+nccl_allgather_fn g_allgather = nullptr;
+nccl_errstr_fn g_errstr = nullptr;
+std::once_flag g_rccl_once;
+
+void bind_rccl() {
+  // RTLD_NOLOAD first: a process that already holds an RCCL (PyTorch ships its own copy) must
+  // keep using that one, since the communicator came from it
+  void *h = nullptr;
+  for (const char *name : {"librccl.so.1", "librccl.so"}) {
+    h = dlopen(name, RTLD_NOW | RTLD_NOLOAD);
+    if (h) break;
+  }
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+    if (h) break;
+    h = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+  }
+  if (!h) return;
+  g_allgather = reinterpret_cast<nccl_allgather_fn>(dlsym(h, "ncclAllGather"));
+  g_errstr = reinterpret_cast<nccl_errstr_fn>(dlsym(h, "ncclGetErrorString"));
+}
+}  // namespace
+
+int nhip_allgather_matches(void *comm, const nhip_match_t *d_local, int32_t n_local, nhip_match_t *d_all,
+                           void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(n_local >= 0, "allgather_matches: negative count");
+  if (n_local == 0) return NHIP_OK;
+  NHIP_REQUIRE(comm && d_local && d_all, "allgather_matches: null pointer");
+  std::call_once(g_rccl_once, bind_rccl);
+  if (!g_allgather) {
+    const char *why = dlerror();
+    set_error("allgather_matches: librccl.so could not be loaded (%s)", why ? why : "no ncclAllGather symbol");
+    return NHIP_ERR_STATE;
+  }
+  const int st = g_allgather(d_local, d_all, sizeof(nhip_match_t) * (size_t)n_local, /*ncclInt8=*/0, comm,
+                             static_cast<hipStream_t>(stream));
+  if (st != 0) {
+    set_error("allgather_matches: ncclAllGather failed: %s", g_errstr ? g_errstr(st) : "unknown");
+    return NHIP_ERR_HIP;
+  }
   return NHIP_OK;
 }
 
