@@ -51,6 +51,17 @@ __global__ void resid_block_consts_kernel(const int32_t *__restrict__ block_src,
 
 // One lane per correspondence.  WANT_J selects residual-only vs residual + both Jacobians;
 // jac_src / jac_tgt may individually be null (Ceres passes NULL for constant blocks).
+// Outputs are written once and read by another kernel or the host: streaming (nontemporal) stores.
+typedef double dbl2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void store_stream(double2 *p, const double2 &v) {
+#ifdef NHIP_PLAIN_STORES
+  *p = v;
+#else
+  dbl2_t t = {v.x, v.y};
+  __builtin_nontemporal_store(t, reinterpret_cast<dbl2_t *>(p));
+#endif
+}
+
 template <int KIND, bool WANT_J>
 __global__ __launch_bounds__(RT) void resid_lidar_kernel(
     const float4 *__restrict__ corr, const int32_t *__restrict__ corr_block, int64_t n_corr,
@@ -103,7 +114,7 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
         jt[3] = i10;  jt[4] = i11;  jt[5] = qx;
       }
     }
-    residuals[i] = make_double2(r0, r1);
+    store_stream(&residuals[i], make_double2(r0, r1));
   }
   if (WANT_J) {
     // transpose through LDS: lane t holds 3 double2 per Jacobian; the block's 3*RT double2
@@ -122,8 +133,8 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
     for (int k = 0; k < 3; k++) {
       const int64_t e = (int64_t)k * RT + t;
       if (e < lim) {
-        if (jac_src) jac_src[3 * i0 + e] = ss[e];
-        if (jac_tgt) jac_tgt[3 * i0 + e] = st[e];
+        if (jac_src) store_stream(&jac_src[3 * i0 + e], ss[e]);
+        if (jac_tgt) store_stream(&jac_tgt[3 * i0 + e], st[e]);
       }
     }
   }
