@@ -158,9 +158,23 @@ __global__ __launch_bounds__(RT) void resid_normal_eq_kernel(const float4 *__res
   double acc[28];
 #pragma unroll
   for (int k = 0; k < 28; k++) acc[k] = 0.0;
-  for (int32_t i = tid; i < n; i += RT) {
-    const float4 a = corr[2 * (size_t)(o + i)];
-    const float4 nn = corr[2 * (size_t)(o + i) + 1];
+  // (the block's rows are loaded LOADS at a time ahead of the fp64 math: 1081 rows are only ~4 per lane)
+  constexpr int LOADS = 5;
+  for (int32_t i0 = tid; i0 < n; i0 += RT * LOADS) {
+    float4 av[LOADS], nv[LOADS];
+#pragma unroll
+    for (int u = 0; u < LOADS; u++) {
+      const int32_t i = i0 + u * RT;
+      if (i < n) {
+        av[u] = corr[2 * (size_t)(o + i)];
+        nv[u] = corr[2 * (size_t)(o + i) + 1];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < LOADS; u++) {
+    if (i0 + u * RT >= n) break;
+    const float4 a = av[u];
+    const float4 nn = nv[u];
     const double px = a.x, py = a.y, tx = a.z, ty = a.w;
     const double ux = l00 * px + l01 * py, uy = l10 * px + l11 * py;
     const double qx = ux + ctx, qy = uy + cty;
@@ -198,13 +212,33 @@ __global__ __launch_bounds__(RT) void resid_normal_eq_kernel(const float4 *__res
 #pragma unroll
     for (int p = 0; p < 6; p++) acc[21 + p] += J[0][p] * r[0] + J[1][p] * r[1];
     acc[27] += r[0] * r[0] + r[1] * r[1];
+    }
   }
+  // wave reduction as a reduce-scatter: at each butterfly step a lane hands half of its values to
+  // its partner and keeps the other half, so 32 -> 16 -> 8 -> 4 -> 2 -> 1 values per lane and 32
+  // fp64 shuffles in all (a plain all-reduce of 28 values takes 168); lane l ends with value l >> 1.
+  {
+    double v[32];
 #pragma unroll
-  for (int k = 0; k < 28; k++) {
-    double v = acc[k];
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
-    if ((tid & 63) == 0) s_part[tid >> 6][k] = v;
+    for (int k = 0; k < 32; k++) v[k] = k < 28 ? acc[k] : 0.0;
+    const int lane = tid & 63;
+#define NHIP_RS_STEP(M, N)                                          \
+  {                                                                 \
+    const bool lo = (lane & (M)) == 0;                              \
+    _Pragma("unroll") for (int j = 0; j < (N) / 2; j++) {           \
+      const double send = lo ? v[j + (N) / 2] : v[j];               \
+      const double recv = __shfl_xor(send, (M), 64);                \
+      v[j] = (lo ? v[j] : v[j + (N) / 2]) + recv;                   \
+    }                                                               \
+  }
+    NHIP_RS_STEP(32, 32)
+    NHIP_RS_STEP(16, 16)
+    NHIP_RS_STEP(8, 8)
+    NHIP_RS_STEP(4, 4)
+    NHIP_RS_STEP(2, 2)
+#undef NHIP_RS_STEP
+    const double total = v[0] + __shfl_xor(v[0], 1, 64);
+    if ((lane & 1) == 0 && (lane >> 1) < 28) s_part[tid >> 6][lane >> 1] = total;
   }
   __syncthreads();
   if (tid < 28) {
