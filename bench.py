@@ -241,7 +241,7 @@ def main():
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "algorithmic gather bytes (1 B per grid lookup) / kernel time; the grid is "
                              "cache/LDS-resident, so this exceeds what HBM itself moves (see traffic)"},
-        "kernels_ms_per_step": {"csm_correlate": k_ms.value / a.steps, "grid_blur": g_ms.value / a.steps},
+        "kernels_ms_per_step": {"csm_correlate": k_ms.value / a.steps, "grid_blur_and_skipmap": g_ms.value / a.steps},
         # what actually bounds the correlate kernel: the tile is LDS-resident, so
         # the honest ceilings are the LDS read pipe and VALU issue, not HBM.
         "onchip_roofline": _onchip(n_pairs, search.n_theta, avg_ms),
