@@ -8,7 +8,7 @@
 // (solver.cc:321-356): three tree descents per matched point.
 //
 // Per block one workgroup: the target cloud is staged in LDS (8 B per point) and bucketed by a
-// uniform grid with cells a shade wider than the outlier threshold (counting sort on a 2048-entry
+// uniform grid with cells a shade wider than the outlier threshold (counting sort on a 1024-entry
 // hash of the cell coordinates, all in LDS).  Every lane owns a contiguous range of source
 // points, transforms them into the target frame with the float affine inverse(T_target) * T_source
 // (Eigen Affine2f semantics, individually rounded products) and visits the 3 x 3 cells around
@@ -65,24 +65,30 @@ __device__ __forceinline__ Aff2f mul_f(const Aff2f &A, const Aff2f &B) {
   return C;
 }
 
-constexpr int NB = 2048;  // hash buckets of the target grid
+#ifndef NHIP_CORR_NB
+#define NHIP_CORR_NB 1024
+#endif
+constexpr int NB = NHIP_CORR_NB;  // hash buckets of the target grid
 
 __device__ __forceinline__ uint32_t cell_hash(int32_t cx, int32_t cy) {
   return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u)) & (uint32_t)(NB - 1);
 }
 
-// block-wide inclusive scan of one int per thread (s_scan: CT ints)
+// block-wide inclusive scan of one int per thread: wave scans by shuffles, wave totals through LDS
+// (s_scan: at least CT / 64 ints), two barriers
 __device__ __forceinline__ int32_t block_scan_incl(int32_t v, int32_t *s_scan, int tid) {
-  __syncthreads();
-  s_scan[tid] = v;
-  __syncthreads();
-  for (int off = 1; off < CT; off <<= 1) {
-    const int32_t u = (tid >= off) ? s_scan[tid - off] : 0;
-    __syncthreads();
-    s_scan[tid] += u;
-    __syncthreads();
+  const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int32_t u = __shfl_up(v, off, 64);
+    if (lane >= off) v += u;
   }
-  return s_scan[tid];
+  __syncthreads();  // s_scan may still be read by the previous user
+  if (lane == 63) s_scan[wv] = v;
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < CT / 64; w++) v += (w < wv) ? s_scan[w] : 0;
+  return v;
 }
 
 __global__ __launch_bounds__(CT) void corr_search_kernel(
@@ -150,8 +156,10 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
 
   for (int32_t s0 = 0; s0 < ns; s0 += CT * MAX_PER_LANE) {
     const int32_t n_pass = min(ns - s0, CT * MAX_PER_LANE);
-    const int32_t per = (n_pass + CT - 1) / CT;  // <= MAX_PER_LANE
-    const int32_t lo = s0 + tid * per, hi = min(lo + per, s0 + n_pass);
+    // lane t owns points s0 + t, s0 + t + CT, ...: consecutive lanes hold consecutive points, so loads
+    // and the kept rows of one round are contiguous across the wave
+    const int32_t hi = s0 + n_pass;
+#define SRC_INDEX(k) (s0 + (k) * CT + tid)
     float qx[MAX_PER_LANE], qy[MAX_PER_LANE], best[MAX_PER_LANE];
     int32_t bi[MAX_PER_LANE];
     int big = 0;
@@ -160,8 +168,8 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
       bi[k] = -1;
       best[k] = 3.0e38f;
       qx[k] = qy[k] = 0.f;
-      if (lo + k < hi) {
-        const float2 p = xy[sb + lo + k];
+      if (SRC_INDEX(k) < hi) {
+        const float2 p = xy[sb + SRC_INDEX(k)];
         qx[k] = __fadd_rn(dot2(C.m00, p.x, C.m01, p.y), C.tx);
         qy[k] = __fadd_rn(dot2(C.m10, p.x, C.m11, p.y), C.ty);
         // (a non-finite query matches nothing on either path; only a huge finite one needs the scan)
@@ -172,7 +180,7 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
     if (!scan_all) {
 #pragma unroll
       for (int k = 0; k < MAX_PER_LANE; k++) {
-        if (lo + k >= hi) continue;
+        if (SRC_INDEX(k) >= hi) continue;
         const float fx = __fmul_rn(qx[k], inv_cell), fy = __fmul_rn(qy[k], inv_cell);
         if (!(fabsf(fx) < CELL_LIMIT) || !(fabsf(fy) < CELL_LIMIT)) continue;  // NaN / inf: no match
         const int32_t icx = (int32_t)floorf(fx), icy = (int32_t)floorf(fy);
@@ -213,29 +221,42 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
         }
       }
     }
-    // keep = nearest within the threshold (kdtree.cc:253-305 + solver.cc:84-89)
-    int32_t mine = 0;
+    // keep = nearest within the threshold (kdtree.cc:253-305 + solver.cc:84-89).  Source order is
+    // round-major (round k holds points s0 + k*CT ..): per round a wave ballot gives the in-wave rank,
+    // one LDS table of (round, wave) counts and ONE barrier give the rest.
     bool keep[MAX_PER_LANE];
+    int32_t rank[MAX_PER_LANE];
+    const int lane = tid & 63, wv = tid >> 6;
+    __syncthreads();  // s_scan is free again (previous pass / bucket scan)
 #pragma unroll
     for (int k = 0; k < MAX_PER_LANE; k++) {
-      keep[k] = (lo + k < hi) && bi[k] >= 0 && (__fsqrt_rn(best[k]) < thr);
-      mine += keep[k] ? 1 : 0;
+      keep[k] = (SRC_INDEX(k) < hi) && bi[k] >= 0 && (__fsqrt_rn(best[k]) < thr);
+      const unsigned long long m = __ballot(keep[k]);
+      rank[k] = __builtin_popcountll(m & ((1ull << lane) - 1ull));
+      if (lane == 0) s_scan[k * (CT / 64) + wv] = __builtin_popcountll(m);
     }
-    // block-wide exclusive scan of `mine` (source order = lane order x per-lane order)
-    const int32_t incl = block_scan_incl(mine, s_scan, tid);
-    int32_t pos = written + incl - mine;
-    const int32_t total = s_scan[CT - 1];
+    __syncthreads();
+    int32_t pos = written;
 #pragma unroll
     for (int k = 0; k < MAX_PER_LANE; k++) {
-      if (keep[k]) {
-        const float2 p = xy[sb + lo + k], ps = normals[sb + lo + k];
-        const float2 g = xy[tb + bi[k]], gn = normals[tb + bi[k]];
-        out[2 * (size_t)pos] = make_float4(p.x, p.y, g.x, g.y);
-        out[2 * (size_t)pos + 1] = make_float4(ps.x, ps.y, gn.x, gn.y);
-        pos++;
+      int32_t before = 0, round_total = 0;
+#pragma unroll
+      for (int w = 0; w < CT / 64; w++) {
+        const int32_t c = s_scan[k * (CT / 64) + w];
+        before += (w < wv) ? c : 0;
+        round_total += c;
       }
+      if (keep[k]) {
+        const int32_t at = pos + before + rank[k];
+        const float2 p = xy[sb + SRC_INDEX(k)], ps = normals[sb + SRC_INDEX(k)];
+        const float2 g = xy[tb + bi[k]], gn = normals[tb + bi[k]];
+        out[2 * (size_t)at] = make_float4(p.x, p.y, g.x, g.y);
+        out[2 * (size_t)at + 1] = make_float4(ps.x, ps.y, gn.x, gn.y);
+      }
+      pos += round_total;
     }
-    written += total;
+    written = pos;
+#undef SRC_INDEX
   }
   if (tid == 0) counts[b] = written;
 }
