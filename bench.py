@@ -237,7 +237,7 @@ def main():
                    "grid": [L.side, L.side], "cell_bytes": 1, "collective": "all_gather 16 B/pair" if world > 1 else "none"},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "csm_correlate_kernel", "avg_launch_ms": avg_ms, "launches": k_n.value,
+                     "kernel": "csm_correlate_kernel<false, false>", "avg_launch_ms": avg_ms, "launches": k_n.value,
                      "algorithmic_bytes_per_launch": bytes_per_launch,
                      "note": "algorithmic gather bytes (1 B per grid lookup) / kernel time; the grid is "
                              "cache/LDS-resident, so this exceeds what HBM itself moves (see traffic)"},

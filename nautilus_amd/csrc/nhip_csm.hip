@@ -244,7 +244,8 @@ __device__ __forceinline__ int32_t place(int32_t here, int32_t ahead, int32_t sp
 #ifndef NHIP_WAVES_PER_SIMD
 #define NHIP_WAVES_PER_SIMD 4
 #endif
-template <bool VOLUME>
+// DENSE: ignore the skip maps (NHIP_CSM_DENSE=1) -- a separate instantiation, so profiles list it apart
+template <bool VOLUME, bool DENSE>
 __global__ __launch_bounds__(CSM_THREADS, NHIP_WAVES_PER_SIMD) void csm_correlate_kernel(CsmParams P) {
   __shared__ uint32_t s_tile[TILE_ROWS * LP_DW];
 
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(CSM_THREADS, NHIP_WAVES_PER_SIMD) void csm_correlat
 #pragma unroll
         for (int u = 0; u < WG_WAVES; u++) {
           if (u * WAVE_ROWS >= nyb) break;
-          const uint32_t bit = P.dense ? 1u : (((uint32_t)skip_map[(size_t)((vcell >> 16) + u * WAVE_ROWS) * mpitch + ((vcell & 0xffffu) >> 5)] >> ((vcell >> 2) & 7u)) & 1u);
+          const uint32_t bit = DENSE ? 1u : (((uint32_t)skip_map[(size_t)((vcell >> 16) + u * WAVE_ROWS) * mpitch + ((vcell & 0xffffu) >> 5)] >> ((vcell >> 2) & 7u)) & 1u);
           vwork |= bit << u;
         }
       }
@@ -529,8 +530,10 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                (long long)blocks);
   NHIP_TRY_HIP(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * (size_t)n_pairs, s));
   timer_begin(NHIP_TIMER_CSM, s);
-  hipLaunchKernelGGL(csm_correlate_kernel<false>, dim3((uint32_t)blocks), dim3(CSM_THREADS), 0, s,
-                     P);
+  if (P.dense)
+    hipLaunchKernelGGL((csm_correlate_kernel<false, true>), dim3((uint32_t)blocks), dim3(CSM_THREADS), 0, s, P);
+  else
+    hipLaunchKernelGGL((csm_correlate_kernel<false, false>), dim3((uint32_t)blocks), dim3(CSM_THREADS), 0, s, P);
   timer_end(NHIP_TIMER_CSM, s);
   hipLaunchKernelGGL(csm_finalize_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, P.keys,
                      d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L.Lf, L.step, d_out, d_sums);
@@ -559,8 +562,10 @@ int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t
   P.single_ox = origin_x;
   P.single_oy = origin_y;
   const int64_t blocks = (int64_t)P.n_theta * P.npbx * P.npby;
-  hipLaunchKernelGGL(csm_correlate_kernel<true>, dim3((uint32_t)blocks), dim3(CSM_THREADS), 0, s,
-                     P);
+  if (P.dense)
+    hipLaunchKernelGGL((csm_correlate_kernel<true, true>), dim3((uint32_t)blocks), dim3(CSM_THREADS), 0, s, P);
+  else
+    hipLaunchKernelGGL((csm_correlate_kernel<true, false>), dim3((uint32_t)blocks), dim3(CSM_THREADS), 0, s, P);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }
