@@ -344,6 +344,35 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic("resid_lidar_bytes_per_launch_%dcorr" % n_corr),
                         "algorithmic_bytes_per_launch": bytes_alg}}
+    try:
+        # PCIe-inclusive: the handle API a Ceres EvaluationCallback uses (adapters/slam_residuals_hip.h) -- poses in,
+        # residuals and both Jacobians out to host memory, every evaluation.  Never the figure above.
+        h_corr = corr.cpu().numpy()
+        h_off = (np.arange(n_blocks + 1, dtype=np.int64) * n_per).astype(np.int32)
+        h_bs, h_bt, h_poses = bs.cpu().numpy(), bt.cpu().numpy(), poses.cpu().numpy()
+        hnd = C.c_void_p()
+        _lib.check(lib.nhip_resid_batch_create(0, _lib.ptr(h_corr), _lib.ptr(h_off), _lib.ptr(h_bs), _lib.ptr(h_bt),
+                                               n_blocks, 1000, C.byref(hnd)))
+        h_r = np.empty(2 * n_corr)
+        h_js, h_jt = np.empty(6 * n_corr), np.empty(6 * n_corr)
+        _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(h_r), _lib.ptr(h_js), _lib.ptr(h_jt)))
+        t0 = time.perf_counter()
+        _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(h_r), _lib.ptr(h_js), _lib.ptr(h_jt)))
+        dt_j = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(h_r), None, None))
+        dt_r = time.perf_counter() - t0
+        lib.nhip_resid_batch_free(hnd)
+        out["host_buffer_api"] = {
+            "seconds_per_eval_with_jacobians": dt_j, "seconds_per_eval_residuals_only": dt_r,
+            "correspondences_per_s_with_jacobians": n_corr / dt_j,
+            "bytes_to_host_with_jacobians": 112.0 * n_corr,
+            "same_result_as_device_api": bool(np.array_equal(h_js, js.cpu().numpy())),
+            "note": "nhip_resid_batch_eval: 24 KB of poses up, 112 B per correspondence down over PCIe into pageable "
+                    "host memory; the per-block normal equations (icp_front_half) move 224 B per BLOCK instead"}
+        del h_r, h_js, h_jt
+    except Exception as e:
+        out["host_buffer_api_error"] = repr(e)
     if with_cpu:
         # CPU side of the same blocks: the oracle's Jet<6> autodiff restatement (what
         # ceres::AutoDiffCostFunction does per block), blocks across OpenMP threads like Ceres' num_threads.
