@@ -54,7 +54,10 @@ def _onchip(n_pairs, n_theta, avg_ms):
     fill_loads = k * sq["SQ_INSTS_VMEM_RD"] - waves * 2 * 17  # minus the point and skip-byte loads of 17 lane-chunks
     lds_reads = k * sq["SQ_INSTS_LDS"] - 3.0 * fill_loads
     lds = lds_reads * (7.0 / 4.0) * 256.0 / secs / 1e12
-    return {"lds_read_TBps": lds, "lds_read_peak_TBps": 75.0, "lds_frac": lds / 75.0,
+    # SQ_ACTIVE_INST_VALU counts 4-clock issue slots; 1024 SIMDs x kernel time x clock / 4 are available
+    active = sq.get("SQ_ACTIVE_INST_VALU")
+    valu_busy = (k * active) / (1024.0 * secs * 2.4e9 / 4.0) if active else None
+    return {"valu_issue_slots_busy": valu_busy, "lds_read_TBps": lds, "lds_read_peak_TBps": 75.0, "lds_frac": lds / 75.0,
             "valu_wave_instr_per_s": valu, "valu_peak_wave_instr_per_s": 1.2288e12, "valu_frac": valu / 1.2288e12,
             "salu_instr_per_s": salu, "salu_peak_instr_per_s": 6.144e11, "salu_frac": salu / 6.144e11,
             "wave_wait_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]}
