@@ -303,9 +303,55 @@ def main():
                         "hipMalloc/hipFree and PCIe copies (8.6 MB in, 0.2 MB out)"}
         except Exception as e:
             out["secondary"]["host_buffer_api_error"] = repr(e)
+    if world == 1 and not a.no_resid:
+        try:
+            out["secondary"]["drop_in_two_level"] = bench_drop_in(bag, a.cpu_seconds > 0)
+        except Exception as e:
+            out["secondary"]["drop_in_two_level_error"] = repr(e)
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+
+
+def bench_drop_in(bag, with_cpu, calls=8):
+    """The one-pair call of the reference, CorrelativeScanMatcher(30, 2, 0.3, 0.01).GetTransformation(...)
+    (solver.cc:633-638): coarse search on a 0.3 m grid, refinement on the 0.01 m (6000 x 6000) grid around the
+    coarse optimum -- latency per call through the host-buffer API, next to the same two searches on the CPU
+    oracle (the "csm-style restatement" of SURVEY 8d; the real third_party/csm is not in the tree)."""
+    from nautilus_amd import csm
+    m = csm.CorrelativeScanMatcher(30, 2, 0.3, 0.01)
+    pairs = [(40 + 7 * i, 37 + 7 * i) for i in range(calls)]
+    m.GetTransformation(bag.scans[pairs[0][0]], bag.scans[pairs[0][1]], bag.odom[pairs[0][0], 2],
+                        bag.odom[pairs[0][1], 2], math.radians(90))
+    t0 = time.perf_counter()
+    res = [m.GetTransformation(bag.scans[i], bag.scans[j], bag.odom[i, 2], bag.odom[j, 2], math.radians(90))
+           for i, j in pairs]
+    dt = (time.perf_counter() - t0) / calls
+    out = {"workload": "%d single-pair calls on dense 1081-beam scans: 181x13x13 lattice on a 200x200 grid, then "
+                       "21x61x61 on a 6000x6000 grid (36 MB built per call)" % calls,
+           "seconds_per_call": dt, "calls_per_s": 1.0 / dt}
+    if with_cpu:
+        from oracle import oracle as O
+        i, j = pairs[0]
+        a_, b_ = bag.scans[i], bag.scans[j]
+        t0 = time.perf_counter()
+        theta0 = float(csm.angle_mod(np.float64(bag.odom[i, 2]) - np.float64(bag.odom[j, 2])))
+        g1s = O.grid_spec(30.0, 0.3, 2.0, 1e-10)
+        m1 = O.csm_match(a_, O.grid_build(b_, g1s), g1s, theta0, O.search_spec(181, 13, 13, math.radians(1.0)))
+        tx1, ty1 = np.float32((m1.ix - 6) * 0.3), np.float32((m1.iy - 6) * 0.3)
+        th1 = np.float32(theta0 + (m1.itheta - 90) * math.radians(1.0))
+        cx, cy = int(round(float(tx1) / 0.01)), int(round(float(ty1) / 0.01))
+        g2s = O.grid_spec(30.0, 0.01, 2.0, 1e-10)
+        m2 = O.csm_match(a_, O.grid_build(b_, g2s), g2s, float(th1), O.search_spec(21, 61, 61, math.radians(0.1)),
+                         (cx, cy))
+        dc = time.perf_counter() - t0
+        same = bool(np.float32(res[0][0]) == np.float32(m2.score) and
+                    res[0][1][0][0] == np.float32((cx + m2.ix - 30) * 0.01) and
+                    res[0][1][0][1] == np.float32((cy + m2.iy - 30) * 0.01))
+        out["cpu_baseline"] = {"value": 1.0 / dc, "unit": "calls/s", "cores": 1, "kind": "port",
+                               "sample": "1 call, oracle C restatement of the same two-level search, single thread",
+                               "gpu_matches_oracle_on_sample": same}
+    return out
 
 
 def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=1081, iters=20):
