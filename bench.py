@@ -27,6 +27,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 
 
+def _cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
 def _traffic(key):
     """HBM bytes per launch from the committed PMC profile (profiles/traffic.json), or None."""
     tf = os.path.join(ROOT, "profiles", "traffic.json")
@@ -104,6 +114,7 @@ def cpu_baseline(bag, xy, off, ids, src, slot, th0, budget_s):
                       "oracle C restatement, OpenMP over pairs" % (len(sel), n_targets, t_grid, t_match),
             "single_thread_pairs_per_s": 1.0 / max(t_one, 1e-9),
             "build_flags": "-O3 -fopenmp -DNDEBUG (the reference's CMakeLists.txt:16), -ffp-contract=off",
+            "cpu_model": _cpu_model(),
             }, sel, res
 
 
