@@ -245,8 +245,7 @@ int64_t nhip_grid_workspace_bytes(const nhip_grid_spec_t *spec, int32_t chunk) {
   GridLayout L;
   if (make_layout(spec, &L)) return -1;
   if (chunk < 1) chunk = 1;
-  const int64_t tiles = (L.S + 63) / 64;
-  return (int64_t)chunk * ((int64_t)L.S * L.S + tiles * tiles);  // hit raster + tile occupancy bytes
+  return GRID_WS_HEADER + 4 + (int64_t)chunk * grid_ws_per_target(L.S);  // header | rasters | tile occupancy | tile list
 }
 
 int nhip_grid_tables(const nhip_grid_spec_t *spec, int32_t *taps, uint32_t *thresholds) {
@@ -503,8 +502,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
   g->n = n_targets;
   DevBuf ids, ws;
   const int32_t chunk = n_targets < 64 ? (n_targets > 0 ? n_targets : 1) : 64;
-  const int64_t ws_tiles = (L.S + 63) / 64;
-  const int64_t ws_bytes = (int64_t)chunk * ((int64_t)L.S * L.S + ws_tiles * ws_tiles);
+  const int64_t ws_bytes = nhip_grid_workspace_bytes(spec, chunk);
   if ((rc = g->grids.alloc((size_t)n_targets * L.slot_bytes + 256)) ||
       (rc = ids.alloc(sizeof(int32_t) * (size_t)(n_targets > 0 ? n_targets : 1))) ||
       (rc = ws.alloc((size_t)ws_bytes))) {

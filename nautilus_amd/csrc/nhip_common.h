@@ -46,6 +46,13 @@ struct GridLayout {
 // CSM_WAVE_ROWS plane rows and reads CSM_ROW_DW aligned dwords of each (nhip_csm.hip).
 constexpr int CSM_WAVE_ROWS = 21;
 constexpr int CSM_ROW_DW = 21;
+// grid-build workspace: 256-byte header, then per target the hit raster (S*S), one occupancy byte per
+// 64x64 tile and one 4-byte list slot per tile
+constexpr int64_t GRID_WS_HEADER = 256;
+inline int64_t grid_ws_per_target(int32_t S) {
+  const int64_t tiles = (S + 63) / 64;
+  return (int64_t)S * S + 5 * tiles * tiles;
+}
 // bytes per skip-map row: one bit per aligned dword column, whole 8-byte words
 __host__ __device__ constexpr int32_t skip_pitch(int32_t pitch) { return ((pitch / 4 + 63) / 64) * 8; }
 int make_layout(const nhip_grid_spec_t *spec, GridLayout *L);

@@ -51,66 +51,105 @@ __global__ __launch_bounds__(256) void grid_raster_kernel(
   }
 }
 
-// 64x64 output tile per block: H tile (+halo) -> LDS, horizontal pass -> LDS, vertical
-// pass + quantise -> padded grid.  Grid memory is pre-zeroed; empty tiles return early.
+// ~95 % of the 64x64 tiles of a scan's grid see no hit within their blur halo.  Launching a
+// workgroup per tile just to read its occupancy byte and leave cost more than the blur itself
+// (361k workgroups per 1000 targets), so the occupied (target, tile) pairs are compacted into a
+// list first and the blur runs as a persistent grid over that list.
+__global__ __launch_bounds__(256) void grid_tile_list_kernel(const uint8_t *__restrict__ occ, int32_t n_tiles_total,
+                                                             int32_t *__restrict__ count, int32_t *__restrict__ list) {
+  const int32_t i = blockIdx.x * 256 + threadIdx.x;
+  const bool on = i < n_tiles_total && occ[i];
+  // one atomic per wave: rank within the wave by ballot
+  const unsigned long long m = __ballot(on);
+  const int lane = threadIdx.x & 63;
+  int32_t base = 0;
+  if (lane == 0 && m) base = atomicAdd(count, (int32_t)__builtin_popcountll(m));
+  base = __shfl(base, 0, 64);
+  if (on) list[base + __builtin_popcountll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+// 64x64 output tile per list entry.  The hit raster is sparse (a few dozen hits per tile), so the
+// separable blur is evaluated as a scatter: every hit of the tile's (64 + 2R)^2 neighbourhood adds
+// taps[i] * taps[j] to the (2R+1)^2 outputs around it (LDS integer atomics -- the same integer sum as
+// the two-pass form, in any order), ~170 adds per hit instead of 29 multiply-adds per OUTPUT; then
+// the non-zero sums are quantised by binary search of the threshold table and stored as aligned
+// dwords.  Grid memory is pre-zeroed.
+constexpr int MAX_TILE_HITS = TH_MAX * TH_MAX;  // every cell of the neighbourhood a hit
+
 __global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restrict__ H,
-                                                        const uint8_t *__restrict__ occ,
+                                                        const int32_t *__restrict__ count,
+                                                        const int32_t *__restrict__ list, int32_t tiles,
                                                         uint8_t *__restrict__ grids, int32_t S,
                                                         int32_t pad, int32_t pitch, int64_t slot_bytes,
                                                         int32_t R, GridKernelTables tab) {
-  __shared__ uint8_t sH[TH_MAX][TH_MAX + 4];
-  __shared__ uint32_t sV[TH_MAX][TILE + 1];
+  __shared__ uint32_t sA[TILE][TILE + 1];
+  __shared__ uint16_t sHits[MAX_TILE_HITS];
   __shared__ uint32_t sThr[256];
-  const int32_t t = blockIdx.z;
-  // ~95 % of the tiles of a scan's grid see no hit within their halo: leave before touching H
-  if (!occ[((size_t)t * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x]) return;
-  const int32_t r0 = blockIdx.y * TILE, c0 = blockIdx.x * TILE;
-  const uint8_t *h = H + (size_t)t * S * S;
-  uint8_t *g = grids + (size_t)t * slot_bytes;
-  const int TH = TILE + 2 * R;
-  int any = 0;
-  for (int i = threadIdx.x; i < TH * TH; i += 256) {
-    const int rr = i / TH, cc = i % TH;
-    const int r = r0 + rr - R, c = c0 + cc - R;
-    uint8_t v = 0;
-    if (r >= 0 && r < S && c >= 0 && c < S) v = h[(size_t)r * S + c];
-    sH[rr][cc] = v;
-    any |= v;
-  }
+  __shared__ int32_t sTaps[2 * MAX_R + 1];
+  __shared__ int32_t sNH;
   sThr[threadIdx.x] = tab.thr[threadIdx.x];
-  if (!__syncthreads_or(any)) return;
-  // horizontal pass: V1[rr][c] = sum_j taps[j] * H[rr][c + j]
-  for (int i = threadIdx.x; i < TH * TILE; i += 256) {
-    const int rr = i / TILE, c = i % TILE;
-    uint32_t a = 0;
-    for (int j = 0; j <= 2 * R; j++) a += (uint32_t)tab.taps[j] * sH[rr][c + j];
-    sV[rr][c] = a;
-  }
-  __syncthreads();
-  // vertical pass + quantise; each thread produces 4 consecutive columns of one row
-  for (int i = threadIdx.x; i < TILE * (TILE / 4); i += 256) {
-    const int r = i / (TILE / 4), c4 = (i % (TILE / 4)) * 4;
-    if (r0 + r >= S) continue;
-    uint32_t packed = 0;
-    for (int b = 0; b < 4; b++) {
-      uint32_t a = 0;
-      for (int k = 0; k <= 2 * R; k++) a += (uint32_t)tab.taps[k] * sV[r + k][c4 + b];
-      uint32_t q = 0;
-      if (a) {
-        // q = #{k in 1..255 : thr[k] <= a}; thr is non-decreasing
-        for (int step = 128; step >= 1; step >>= 1) {
-          const uint32_t n = q + step;
-          if (n <= 255 && sThr[n] <= a) q = n;
-        }
+  if (threadIdx.x <= 2 * R) sTaps[threadIdx.x] = tab.taps[threadIdx.x];
+  const int32_t n_entries = *count;
+  const int TH = TILE + 2 * R, NT = 2 * R + 1;
+  for (int32_t e = blockIdx.x; e < n_entries; e += gridDim.x) {
+    const int32_t entry = list[e];
+    const int32_t t = entry / (tiles * tiles), tile = entry % (tiles * tiles);
+    const int32_t r0 = (tile / tiles) * TILE, c0 = (tile % tiles) * TILE;
+    const uint8_t *h = H + (size_t)t * S * S;
+    uint8_t *g = grids + (size_t)t * slot_bytes;
+    __syncthreads();  // the previous entry is done with the LDS arrays
+    for (int i = threadIdx.x; i < TILE * (TILE + 1); i += 256) (&sA[0][0])[i] = 0u;
+    if (threadIdx.x == 0) sNH = 0;
+    __syncthreads();
+    // hits of the neighbourhood -> list (row, column packed; TH <= 96)
+    for (int rr = threadIdx.x / 32; rr < TH; rr += 8) {
+      const int r = r0 + rr - R;
+      if (r < 0 || r >= S) continue;
+      for (int cc = threadIdx.x % 32; cc < TH; cc += 32) {
+        const int c = c0 + cc - R;
+        if (c >= 0 && c < S && h[(size_t)r * S + c]) sHits[atomicAdd(&sNH, 1)] = (uint16_t)((rr << 8) | cc);
       }
-      packed |= q << (8 * b);
     }
-    uint8_t *dst = g + (size_t)(r0 + r + pad) * pitch + (c0 + c4 + pad);
-    if (c0 + c4 + 3 < S) {
-      *reinterpret_cast<uint32_t *>(dst) = packed;  // pad, c0, c4 are multiples of 4
-    } else {
-      for (int b = 0; b < 4; b++)
-        if (c0 + c4 + b < S) dst[b] = (uint8_t)(packed >> (8 * b));
+    __syncthreads();
+    const int32_t nh = sNH;
+    if (nh == 0) continue;
+    // one work item per (hit, output row): up to 2R+1 atomic adds
+    for (int32_t wi = threadIdx.x; wi < nh * NT; wi += 256) {
+      const int32_t hit = sHits[wi / NT], di = wi % NT;
+      const int32_t ro = (hit >> 8) - di, cc = hit & 0xff;
+      if (ro < 0 || ro >= TILE) continue;
+      const uint32_t tr = (uint32_t)sTaps[di];
+      for (int dj = 0; dj < NT; dj++) {
+        const int32_t co = cc - dj;
+        if (co >= 0 && co < TILE) atomicAdd(&sA[ro][co], tr * (uint32_t)sTaps[dj]);
+      }
+    }
+    __syncthreads();
+    // quantise; each thread produces 4 consecutive columns of one row
+    for (int i = threadIdx.x; i < TILE * (TILE / 4); i += 256) {
+      const int r = i / (TILE / 4), c4 = (i % (TILE / 4)) * 4;
+      if (r0 + r >= S) continue;
+      uint32_t packed = 0;
+      for (int b = 0; b < 4; b++) {
+        const uint32_t a = sA[r][c4 + b];
+        uint32_t q = 0;
+        if (a) {
+          // q = #{k in 1..255 : thr[k] <= a}; thr is non-decreasing
+          for (int step = 128; step >= 1; step >>= 1) {
+            const uint32_t n = q + step;
+            if (n <= 255 && sThr[n] <= a) q = n;
+          }
+        }
+        packed |= q << (8 * b);
+      }
+      if (packed == 0u) continue;  // the grid is pre-zeroed
+      uint8_t *dst = g + (size_t)(r0 + r + pad) * pitch + (c0 + c4 + pad);
+      if (c0 + c4 + 3 < S) {
+        *reinterpret_cast<uint32_t *>(dst) = packed;  // pad, c0, c4 are multiples of 4
+      } else {
+        for (int b = 0; b < 4; b++)
+          if (c0 + c4 + b < S) dst[b] = (uint8_t)(packed >> (8 * b));
+      }
     }
   }
 }
@@ -195,10 +234,11 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
   NHIP_REQUIRE(L.K * L.K < (1ll << 32), "grid_build: tap sum overflows 32-bit accumulation");
   NHIP_REQUIRE(L.pitch % 4 == 0, "grid_build: pitch must be a multiple of 4");
   const int tiles = (L.S + TILE - 1) / TILE;
-  const int64_t per = (int64_t)L.S * L.S + (int64_t)tiles * tiles;  // hit raster + tile occupancy
-  const int64_t chunk = ws_bytes / per;
-  NHIP_REQUIRE(chunk >= 1, "grid_build: workspace %lld B < one hit raster (%lld B)",
-               (long long)ws_bytes, (long long)per);
+  // workspace: 256-byte header (list counter) | hit rasters | tile occupancy bytes | tile list
+  const int64_t per = grid_ws_per_target(L.S);
+  const int64_t chunk = (ws_bytes - GRID_WS_HEADER - 4) / per;
+  NHIP_REQUIRE(chunk >= 1, "grid_build: workspace %lld B < one target (%lld B)",
+               (long long)ws_bytes, (long long)(per + GRID_WS_HEADER + 4));
   GridTables T;
   int rc = make_tables(spec, L, &T);
   if (rc) return rc;
@@ -208,16 +248,25 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
   for (int i = 0; i < 256; i++) kt.thr[i] = T.thr[i];
   for (int64_t t0 = 0; t0 < n_targets; t0 += chunk) {
     const int32_t n = (int32_t)((n_targets - t0 < chunk) ? (n_targets - t0) : chunk);
-    uint8_t *H = static_cast<uint8_t *>(d_ws);
+    uint8_t *base = static_cast<uint8_t *>(d_ws);
+    int32_t *count = reinterpret_cast<int32_t *>(base);
+    uint8_t *H = base + GRID_WS_HEADER;
     uint8_t *occ = H + (size_t)n * L.S * L.S;
+    const size_t occ_bytes = (size_t)n * tiles * tiles;
+    int32_t *list = reinterpret_cast<int32_t *>(occ + ((occ_bytes + 3) & ~(size_t)3));
     uint8_t *g = d_grids + (size_t)t0 * L.slot_bytes;
-    NHIP_TRY_HIP(hipMemsetAsync(H, 0, (size_t)n * per, s));  // raster and occupancy in one fill
-    NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.slot_bytes, s));  // images and skip maps
+    // counter, rasters and occupancy in one fill; images and skip maps in another
+    NHIP_TRY_HIP(hipMemsetAsync(base, 0, GRID_WS_HEADER + (size_t)n * L.S * L.S + occ_bytes, s));
+    NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.slot_bytes, s));
     hipLaunchKernelGGL(grid_raster_kernel, dim3(n), dim3(256), 0, s,
                        reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
                        (int32_t)t0, H, occ, L.S, tiles, L.R, spec->res);
+    const int32_t n_tiles_total = n * tiles * tiles;
+    hipLaunchKernelGGL(grid_tile_list_kernel, dim3((n_tiles_total + 255) / 256), dim3(256), 0, s, occ,
+                       n_tiles_total, count, list);
     timer_begin(NHIP_TIMER_GRID, s);
-    hipLaunchKernelGGL(grid_blur_kernel, dim3(tiles, tiles, n), dim3(256), 0, s, H, occ, g, L.S, L.pad,
+    const int32_t blur_blocks = n_tiles_total < 8192 ? n_tiles_total : 8192;  // persistent over the list
+    hipLaunchKernelGGL(grid_blur_kernel, dim3(blur_blocks), dim3(256), 0, s, H, count, list, tiles, g, L.S, L.pad,
                        L.pitch, L.slot_bytes, L.R, kt);
     const int32_t rows = L.S + 2 * L.pad, mpitch = L.pitch / 4;
     hipLaunchKernelGGL(grid_skipmap_kernel, dim3((mpitch + MT - 1) / MT, (rows + MT - 1) / MT, n), dim3(256), 0, s,
