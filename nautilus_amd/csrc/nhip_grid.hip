@@ -7,8 +7,8 @@
 // bit-identical to the CPU formulation).  Stored with a zero border of `pad` cells so the
 // correlation kernel never bounds-checks.
 //
-// HBM-bound byte work: per target, S*S hit bytes written+read and pitch*pitch grid bytes
-// written; almost all 64x64 tiles are empty and exit after the LDS any-hit vote.
+// HBM-bound byte work: per target, S*S hit bytes written+read, the image and its skip map
+// zero-filled, and the ~20 % of 64x64 tiles within blur reach of a hit computed (kernels below).
 #include "nhip_common.h"
 
 namespace nhip {
