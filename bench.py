@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--per-target", type=int, default=10)
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-resid", action="store_true", help="skip the secondary residual-kernel measurement")
+    ap.add_argument("--no-drop-in", action="store_true",
+                    help="skip the single-pair latency leg (its small launches of the correlation kernel would "
+                         "blur that kernel's average in a rocprofv3 --stats summary)")
     return ap.parse_args()
 
 
@@ -314,7 +317,7 @@ def main():
                         "hipMalloc/hipFree and PCIe copies (8.6 MB in, 0.2 MB out)"}
         except Exception as e:
             out["secondary"]["host_buffer_api_error"] = repr(e)
-    if world == 1 and not a.no_resid:
+    if world == 1 and not a.no_resid and not a.no_drop_in:
         try:
             out["secondary"]["drop_in_two_level"] = bench_drop_in(bag, a.cpu_seconds > 0)
         except Exception as e:

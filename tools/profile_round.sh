@@ -9,7 +9,7 @@ R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0"
+BENCH="python3 $R/bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-drop-in"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/kt.log
 python3 $R/tools/rocprof_summary.py $OUT/kt > $OUT/kernel_stats.txt
 echo "# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) of: $BENCH" > $OUT/pmc_traffic.txt
