@@ -128,8 +128,10 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 // 32-bit sums: byte p of a class-s lane is window column 28*seg + p - s, so bytes p < s belong
 // to the left neighbour lane and travel there with one wave shuffle each (6 per unpack).
 constexpr int FLUSH_POINTS = 255;  // a 16-bit field holds 255 byte values
-// a lane-chunk of 64 points is started only while at most this many points have been ADDED since
-// the last unpack (skipped points do not count), so a field never exceeds 191 + 64 values
+// Every alignment class has its own register set, so what must stay <= 255 is the number of points
+// ADDED PER CLASS since the last unpack (skipped points do not count): a lane-chunk of 64 points is
+// started only while no class has more than this many, so a field never exceeds 191 + 64 values.
+// With ~600 points added per wave and four classes, most waves unpack once, at the end.
 constexpr int FLUSH_START_MAX = FLUSH_POINTS - 64;
 
 struct Swar {
@@ -315,8 +317,8 @@ __global__ __launch_bounds__(CSM_THREADS, NHIP_WAVES_PER_SIMD) void csm_correlat
   // (at most) FLUSH_POINTS points
   int32_t c64 = 0;
   while (c64 < n_pts && centre_ok) {
-    int32_t added = 0;
-    for (; c64 < n_pts && added <= FLUSH_START_MAX; c64 += 64) {
+    int32_t added0 = 0, added1 = 0, added2 = 0, added3 = 0;  // per alignment class
+    for (; c64 < n_pts && max(max(added0, added1), max(added2, added3)) <= FLUSH_START_MAX; c64 += 64) {
       const int32_t n = min(n_pts - c64, 64);
       // one point per lane: rotated window cell, and whether this block's strip of its window
       // holds anything but zeros (skip map, nhip_grid.hip)
@@ -333,7 +335,17 @@ __global__ __launch_bounds__(CSM_THREADS, NHIP_WAVES_PER_SIMD) void csm_correlat
       const int32_t vcol = (int32_t)(vcell & 0xffffu), vrow = (int32_t)(vcell >> 16);
       unsigned long long todo = __ballot(vwork != 0u);           // points some wave of the workgroup needs
       const unsigned long long mine = __ballot((vwork >> wave) & 1u);  // points this wave adds
-      added += __builtin_popcountll(mine);
+      {
+        // class of a point = (window start column) & 3: tile origins are multiples of 16, so it does
+        // not depend on the tile the point will be read from
+        const uint32_t vc = (uint32_t)vcol & 3u;
+        const unsigned long long k0 = __ballot(vc == 0u) & mine, k1 = __ballot(vc == 1u) & mine;
+        const unsigned long long k2 = __ballot(vc == 2u) & mine;
+        added0 += __builtin_popcountll(k0);
+        added1 += __builtin_popcountll(k1);
+        added2 += __builtin_popcountll(k2);
+        added3 += __builtin_popcountll(mine) - __builtin_popcountll(k0 | k1 | k2);
+      }
       while (todo) {
         const int32_t j = (int32_t)__builtin_ctzll(todo);
         // remaining points inside the staged tile; e = first remaining point that is not

@@ -144,6 +144,25 @@ def test_long_clouds_cross_staging_batches(gpu, small_bag):
     assert want["sum"].max() > 255 * 1152  # sums beyond what a single unpack interval could hold
 
 
+def test_swar_fields_do_not_overflow_in_one_alignment_class(gpu):
+    """Worst case for the 16-bit SWAR fields: thousands of source points whose windows all start in the
+    same alignment class (x = multiples of 4 cells) and sit on cells of the maximum value 255 (the
+    target is the same set of points, so every hit cell is a blur centre), visited with theta = 0 so
+    nothing spreads them.  The per-class unpack rule must keep every field <= 255 * 255."""
+    rng = np.random.default_rng(99)
+    res = 0.05
+    n = 3000
+    cx = rng.integers(-40, 40, n) * 4            # column = 600 + cx: all in class (600 + cx - 40 + pad) & 3 = const
+    cy = rng.integers(-150, 150, n)
+    pts = np.stack([(cx + 0.5) * res, (cy + 0.5) * res], 1).astype(np.float32)
+    dup = np.concatenate([pts, pts[:1500]])      # exact duplicates too (same cell: counted n times)
+    spec, ospec = _specs(max_shift=40)
+    for th in (0.0, math.pi / 2):                # pi/2: rows and columns swap -> another single class
+        got, want = _check_pairs([dup, pts], [1], [0, 0], [0, 0], [th, th + 1e-3], spec, ospec,
+                                 csm.search_spec(3, 81, 81, DEG))
+        assert want["sum"].max() > 255 * 2000
+
+
 def test_non_finite_points_are_off_grid(gpu, small_bag):
     """NaN / inf / absurd coordinates (a broken range reading) never fault and never score: dropped
     from a target raster, floor-only as source points -- same answer as the oracle."""
