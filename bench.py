@@ -269,14 +269,23 @@ def main():
             os.environ["NHIP_CSM_DENSE"] = "1"
             step()
             fence()
+            lib.nhip_timing_reset()
+            lib.nhip_timing_enable(1)
             t0 = time.perf_counter()
             for _ in range(2):
                 step()
             fence()
             dt = (time.perf_counter() - t0) / 2
+            lib.nhip_timing_enable(0)
+            dk_ms, dk_n = C.c_double(0), C.c_int32(0)
+            _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_CSM, C.byref(dk_ms), C.byref(dk_n)))
+            dense_kernel_ms = dk_ms.value / max(dk_n.value, 1)
+            dense_gbs = bytes_per_launch / (dense_kernel_ms * 1e-3) / 1e9
             same = bool(np.array_equal(d_sums.cpu().numpy(), got_sums) and
                         d_out.cpu().numpy().tobytes() == got.tobytes())
             out["zero_skip"] = {"dense_value": n_pairs / dt, "dense_ms_per_step": 1e3 * dt, "same_result": same,
+                                "dense_kernel_ms": dense_kernel_ms, "dense_roofline_achieved_GBps": dense_gbs,
+                                "dense_roofline_frac": dense_gbs / HBM_PEAK_GBS,
                                 "note": "NHIP_CSM_DENSE=1: all-zero window strips are added like any other; `value` "
                                         "leaves them out (skip map built with the grids), results are identical"}
         finally:
