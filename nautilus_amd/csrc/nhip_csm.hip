@@ -124,7 +124,7 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v,
 //     odd  += w >> 8              (= sum b1 + 256 sum b2 + 65536 sum b3, no overflow <= 255 pts)
 // i.e. 4 full-rate ops per 4 lookups.  The byte alignment s = (window start) & 3 is
 // wave-uniform, so points are accumulated into one of four register sets (one class-filtered
-// sub-loop each) and the sets are unpacked every 192 points into the lane's 28 window-relative
+// sub-loop each) and the sets are unpacked (before any class reaches 255 points) into the lane's 28 window-relative
 // 32-bit sums: byte p of a class-s lane is window column 28*seg + p - s, so bytes p < s belong
 // to the left neighbour lane and travel there with one wave shuffle each (6 per unpack).
 constexpr int FLUSH_POINTS = 255;  // a 16-bit field holds 255 byte values
