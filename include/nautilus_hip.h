@@ -214,6 +214,17 @@ int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_
                          const float *d_pose_aff, float outlier_threshold,
                          const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts,
                          void *stream);
+/* The same search with the normal gate of Solver::GetPointToNormalMatching /
+ * FindClosestPointWithSimilarNormal (solver.cc:177-260; defined but not called at this commit): among
+ * the target points within outlier_threshold, the nearest whose normal satisfies
+ * |n_target . n_source| > min_abs_cosine (NormalsSimilar, math_util.h:46-49; the reference passes
+ * cos(20 deg)); n_source is the source point's normal in the SOURCE frame, as in the reference.
+ * Exactly equal distances go to the lowest target index (the reference's std::sort leaves that open). */
+int nhip_corr_search_normals_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+                                 const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
+                                 const float *d_pose_aff, float outlier_threshold, float min_abs_cosine,
+                                 const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts,
+                                 void *stream);
 int nhip_corr_compact_dev(const float *d_corr_padded, const int64_t *d_cap_offsets,
                           const int32_t *d_counts, int32_t n_blocks, int32_t *d_block_offsets,
                           float *d_corr, int32_t *d_corr_block, void *stream);

@@ -71,6 +71,8 @@ PROTOTYPES = {
     "nhip_resid_lidar_normal_eq_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "nhip_pose_affines": (C.c_int, [_vp, _i32, _vp]),
     "nhip_corr_search_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, _vp, _vp, _vp, _vp]),
+    "nhip_corr_search_normals_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, C.c_float, _vp, _vp, _vp,
+                                               _vp]),
     "nhip_corr_compact_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "nhip_resid_point_to_line_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp,
                                                _vp, _vp, _vp, _vp]),

@@ -27,7 +27,8 @@ def window_pairs(n_scans, window):
 
 
 class IcpBatch:
-    def __init__(self, xy, normals, offsets, block_src, block_tgt, device="cuda:0", outlier_threshold=0.25):
+    def __init__(self, xy, normals, offsets, block_src, block_tgt, device="cuda:0", outlier_threshold=0.25,
+                 min_abs_cosine=None):
         import torch
         self.torch = torch
         self.dev = torch.device(device)
@@ -46,6 +47,9 @@ class IcpBatch:
         self.capacity = int(cap[-1])
         self.d_cap = t(cap, np.int64)
         self.thr = float(outlier_threshold)
+        # None: GetPointToPointMatching; a value (the reference uses cos(20 deg)): the normal gate of
+        # GetPointToNormalMatching / FindClosestPointWithSimilarNormal (solver.cc:177-260)
+        self.min_cos = None if min_abs_cosine is None else float(min_abs_cosine)
         e = lambda n, dt: torch.empty(max(int(n), 1), dtype=dt, device=self.dev)
         self.d_aff = e(4 * self.n_scans, torch.float32)
         self.d_poses = e(3 * self.n_scans, torch.float64)
@@ -71,10 +75,16 @@ class IcpBatch:
     def search(self, sync=True):
         """K5 + compaction.  Returns the number of correspondences (needs one sync to size outputs)."""
         sp = self._stream()
-        check(self.lib.nhip_corr_search_dev(self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(),
-                                            self.d_bsrc.data_ptr(), self.d_btgt.data_ptr(), self.n_blocks,
-                                            self.d_aff.data_ptr(), self.thr, self.d_cap.data_ptr(),
-                                            self.d_padded.data_ptr(), self.d_counts.data_ptr(), sp))
+        if self.min_cos is None:
+            check(self.lib.nhip_corr_search_dev(self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(),
+                                                self.d_bsrc.data_ptr(), self.d_btgt.data_ptr(), self.n_blocks,
+                                                self.d_aff.data_ptr(), self.thr, self.d_cap.data_ptr(),
+                                                self.d_padded.data_ptr(), self.d_counts.data_ptr(), sp))
+        else:
+            check(self.lib.nhip_corr_search_normals_dev(
+                self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(), self.d_bsrc.data_ptr(),
+                self.d_btgt.data_ptr(), self.n_blocks, self.d_aff.data_ptr(), self.thr, self.min_cos,
+                self.d_cap.data_ptr(), self.d_padded.data_ptr(), self.d_counts.data_ptr(), sp))
         check(self.lib.nhip_corr_compact_dev(self.d_padded.data_ptr(), self.d_cap.data_ptr(),
                                              self.d_counts.data_ptr(), self.n_blocks, self.d_boff.data_ptr(),
                                              self.d_corr.data_ptr(), self.d_cblock.data_ptr(), sp))

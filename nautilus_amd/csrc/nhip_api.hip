@@ -404,7 +404,24 @@ int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_
                "corr_search_dev: null pointer");
   NHIP_REQUIRE(n_blocks >= 0 && outlier_threshold > 0, "corr_search_dev: bad size or threshold");
   return launch_corr_search(d_xy, d_normals, d_offsets, d_block_src, d_block_tgt, n_blocks, d_pose_aff,
-                            outlier_threshold, d_cap_offsets, d_corr_padded, d_counts,
+                            outlier_threshold, 0.f, false, d_cap_offsets, d_corr_padded, d_counts,
+                            static_cast<hipStream_t>(stream));
+}
+
+int nhip_corr_search_normals_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+                                 const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
+                                 const float *d_pose_aff, float outlier_threshold, float min_abs_cosine,
+                                 const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts,
+                                 void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_xy && d_normals && d_offsets && d_block_src && d_block_tgt && d_pose_aff && d_cap_offsets &&
+                   d_corr_padded && d_counts,
+               "corr_search_normals_dev: null pointer");
+  NHIP_REQUIRE(n_blocks >= 0 && outlier_threshold > 0, "corr_search_normals_dev: bad size or threshold");
+  NHIP_REQUIRE(min_abs_cosine >= 0.f && min_abs_cosine <= 1.f, "corr_search_normals_dev: min_abs_cosine outside [0, 1]");
+  return launch_corr_search(d_xy, d_normals, d_offsets, d_block_src, d_block_tgt, n_blocks, d_pose_aff,
+                            outlier_threshold, min_abs_cosine, true, d_cap_offsets, d_corr_padded, d_counts,
                             static_cast<hipStream_t>(stream));
 }
 

@@ -97,7 +97,7 @@ int launch_resid_normal_eq(int kind, const float *d_corr, const int32_t *d_block
 
 int launch_corr_search(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
                        const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
-                       const float *d_pose_aff, float thr, const int64_t *d_cap_offsets,
+                       const float *d_pose_aff, float thr, float min_cos, bool gate, const int64_t *d_cap_offsets,
                        float *d_corr_padded, int32_t *d_counts, hipStream_t s);
 
 int launch_corr_compact(const float *d_corr_padded, const int64_t *d_cap_offsets,

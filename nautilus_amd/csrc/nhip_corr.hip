@@ -91,13 +91,19 @@ __device__ __forceinline__ int32_t block_scan_incl(int32_t v, int32_t *s_scan, i
   return v;
 }
 
+// GATE: the normal gate of Solver::GetPointToNormalMatching / FindClosestPointWithSimilarNormal
+// (solver.cc:177-260): candidates are the targets within the threshold whose normal satisfies
+// |n_target . n_source| > min_cos (NormalsSimilar, math_util.h:46-49; n_source stays in the source
+// frame, as in the reference); the nearest candidate wins, ties to the lowest index.
+template <bool GATE>
 __global__ __launch_bounds__(CT) void corr_search_kernel(
     const float2 *__restrict__ xy, const float2 *__restrict__ normals,
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ block_src,
-    const int32_t *__restrict__ block_tgt, const float *__restrict__ pose_aff, float thr,
+    const int32_t *__restrict__ block_tgt, const float *__restrict__ pose_aff, float thr, float min_cos,
     const int64_t *__restrict__ cap_offsets, float4 *__restrict__ corr,
     int32_t *__restrict__ counts) {
   __shared__ float2 s_tgt[TGT_CHUNK];
+  __shared__ float2 s_tgn[GATE ? TGT_CHUNK : 1];  // target normals (gate only)
   __shared__ uint16_t s_sorted[TGT_CHUNK];  // target indices grouped by bucket
   __shared__ uint32_t s_start[NB + 1];      // bucket h = s_sorted[s_start[h] .. s_start[h + 1])
   __shared__ uint32_t s_cur[NB];
@@ -123,6 +129,7 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
     for (int32_t i = tid; i < nt; i += CT) {
       const float2 g = xy[tb + i];
       s_tgt[i] = g;
+      if (GATE) s_tgn[i] = normals[tb + i];
       const float fx = __fmul_rn(g.x, inv_cell), fy = __fmul_rn(g.y, inv_cell);
       if (!(fabsf(fx) < CELL_LIMIT) || !(fabsf(fy) < CELL_LIMIT)) big = 1;
       else atomicAdd(&s_start[cell_hash((int32_t)floorf(fx), (int32_t)floorf(fy))], 1u);
@@ -161,6 +168,7 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
     const int32_t hi = s0 + n_pass;
 #define SRC_INDEX(k) (s0 + (k) * CT + tid)
     float qx[MAX_PER_LANE], qy[MAX_PER_LANE], best[MAX_PER_LANE];
+    float snx[GATE ? MAX_PER_LANE : 1], sny[GATE ? MAX_PER_LANE : 1];
     int32_t bi[MAX_PER_LANE];
     int big = 0;
 #pragma unroll
@@ -170,6 +178,11 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
       qx[k] = qy[k] = 0.f;
       if (SRC_INDEX(k) < hi) {
         const float2 p = xy[sb + SRC_INDEX(k)];
+        if (GATE) {
+          const float2 sn = normals[sb + SRC_INDEX(k)];
+          snx[k] = sn.x;
+          sny[k] = sn.y;
+        }
         qx[k] = __fadd_rn(dot2(C.m00, p.x, C.m01, p.y), C.tx);
         qy[k] = __fadd_rn(dot2(C.m10, p.x, C.m11, p.y), C.ty);
         // (a non-finite query matches nothing on either path; only a huge finite one needs the scan)
@@ -193,8 +206,13 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
               const float2 g = s_tgt[idx];
               const float dx = __fsub_rn(g.x, qx[k]), dy = __fsub_rn(g.y, qy[k]);
               const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
+              bool ok = true;
+              if (GATE) {
+                const float2 gn = s_tgn[idx];
+                ok = __fsqrt_rn(d2) < thr && fabsf(dot2(gn.x, snx[k], gn.y, sny[k])) > min_cos;
+              }
               // the order of visits is arbitrary: (d2, index) lexicographic = "lowest index wins ties"
-              const bool better = d2 < best[k] || (d2 == best[k] && (uint32_t)idx < (uint32_t)bi[k]);
+              const bool better = ok && (d2 < best[k] || (d2 == best[k] && (uint32_t)idx < (uint32_t)bi[k]));
               best[k] = better ? d2 : best[k];
               bi[k] = better ? idx : bi[k];
             }
@@ -205,7 +223,10 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
         const int32_t nc = min(nt - t0, TGT_CHUNK);
         if (!hashed) {  // (a hashed block already holds the whole target cloud in s_tgt)
           __syncthreads();
-          for (int32_t i = tid; i < nc; i += CT) s_tgt[i] = xy[tb + t0 + i];
+          for (int32_t i = tid; i < nc; i += CT) {
+            s_tgt[i] = xy[tb + t0 + i];
+            if (GATE) s_tgn[i] = normals[tb + t0 + i];
+          }
           __syncthreads();
         }
         for (int32_t i = 0; i < nc; i++) {
@@ -214,7 +235,12 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
           for (int k = 0; k < MAX_PER_LANE; k++) {
             const float dx = __fsub_rn(g.x, qx[k]), dy = __fsub_rn(g.y, qy[k]);
             const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
-            const bool better = d2 < best[k];  // strict: the lowest index wins ties
+            bool ok = true;
+            if (GATE) {
+              const float2 gn = s_tgn[i];
+              ok = __fsqrt_rn(d2) < thr && fabsf(dot2(gn.x, snx[GATE ? k : 0], gn.y, sny[GATE ? k : 0])) > min_cos;
+            }
+            const bool better = ok && d2 < best[k];  // strict: the lowest index wins ties
             best[k] = better ? d2 : best[k];
             bi[k] = better ? (t0 + i) : bi[k];
           }
@@ -305,14 +331,20 @@ __global__ __launch_bounds__(CT) void corr_compact_kernel(const float4 *__restri
 
 int launch_corr_search(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
                        const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
-                       const float *d_pose_aff, float thr, const int64_t *d_cap_offsets,
-                       float *d_corr_padded, int32_t *d_counts, hipStream_t s) {
+                       const float *d_pose_aff, float thr, float min_cos, bool gate,
+                       const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts, hipStream_t s) {
   if (n_blocks == 0) return NHIP_OK;
   timer_begin(NHIP_TIMER_CORR, s);
-  hipLaunchKernelGGL(corr_search_kernel, dim3(n_blocks), dim3(CT), 0, s,
-                     reinterpret_cast<const float2 *>(d_xy), reinterpret_cast<const float2 *>(d_normals),
-                     d_offsets, d_block_src, d_block_tgt, d_pose_aff, thr, d_cap_offsets,
-                     reinterpret_cast<float4 *>(d_corr_padded), d_counts);
+  if (gate)
+    hipLaunchKernelGGL(corr_search_kernel<true>, dim3(n_blocks), dim3(CT), 0, s,
+                       reinterpret_cast<const float2 *>(d_xy), reinterpret_cast<const float2 *>(d_normals),
+                       d_offsets, d_block_src, d_block_tgt, d_pose_aff, thr, min_cos, d_cap_offsets,
+                       reinterpret_cast<float4 *>(d_corr_padded), d_counts);
+  else
+    hipLaunchKernelGGL(corr_search_kernel<false>, dim3(n_blocks), dim3(CT), 0, s,
+                       reinterpret_cast<const float2 *>(d_xy), reinterpret_cast<const float2 *>(d_normals),
+                       d_offsets, d_block_src, d_block_tgt, d_pose_aff, thr, 0.f, d_cap_offsets,
+                       reinterpret_cast<float4 *>(d_corr_padded), d_counts);
   timer_end(NHIP_TIMER_CORR, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;

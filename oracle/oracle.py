@@ -108,6 +108,22 @@ def corr_search_batch(xy, normals, offsets, block_src, block_tgt, pose_aff, thr=
     return corr, counts, cap
 
 
+def corr_search_gated_batch(xy, normals, offsets, block_src, block_tgt, pose_aff, thr, min_abs_cosine, n_threads=0):
+    """Solver::GetPointToNormalMatching (nearest target within thr with a similar normal); padded output."""
+    xy, normals = _f32(xy).reshape(-1, 2), _f32(normals).reshape(-1, 2)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    bs, bt = np.ascontiguousarray(block_src, dtype=np.int32), np.ascontiguousarray(block_tgt, dtype=np.int32)
+    cap = np.zeros(len(bs) + 1, dtype=np.int64)
+    cap[1:] = np.cumsum(offsets[bs + 1] - offsets[bs])
+    corr = np.zeros((int(cap[-1]), 8), dtype=np.float32)
+    counts = np.zeros(len(bs), dtype=np.int32)
+    fn = load().orc_corr_search_gated_batch
+    fn.argtypes = [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _i32]
+    _chk(fn(_p(xy), _p(normals), _p(offsets), _p(bs), _p(bt), len(bs), _p(_f32(pose_aff)), float(thr),
+            float(min_abs_cosine), _p(cap), _p(corr), _p(counts), n_threads), "corr_search_gated_batch")
+    return corr, counts, cap
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(_vp)
 

@@ -451,6 +451,65 @@ int32_t orc_corr_search_block(const float *src_xy, const float *src_nrm, int32_t
   return n;
 }
 
+/* Solver::GetPointToNormalMatching + FindClosestPointWithSimilarNormal (solver.cc:177-260; defined,
+ * not called at this commit): FindNeighborPoints collects every target with norm(diff) < threshold
+ * (kdtree.cc:234-251 -- the growing-threshold wrapper always passes CONFIG_outlier_threshold to it,
+ * solver.cc:182-183), they are sorted by distance and the first whose normal is "similar" --
+ * fabs(n_target . n_source) > max_cosine_value, math_util.h:46-49, n_source in the SOURCE frame --
+ * wins.  std::sort is not stable and compares float norms; build-defined here: squared distance,
+ * then the lowest target index. */
+int32_t orc_corr_search_gated_block(const float *src_xy, const float *src_nrm, int32_t n_src,
+                                    const float *tgt_xy, const float *tgt_nrm, int32_t n_tgt,
+                                    const float *src_aff, const float *tgt_aff, float outlier_threshold,
+                                    float min_abs_cosine, float *corr_out, int32_t *match_idx_out) {
+  const Aff2f C = MulF(InverseF(PoseAffineF(tgt_aff)), PoseAffineF(src_aff));
+  int32_t n = 0;
+  for (int32_t p = 0; p < n_src; p++) {
+    const float px = src_xy[2 * p], py = src_xy[2 * p + 1];
+    const float nx = src_nrm[2 * p], ny = src_nrm[2 * p + 1];
+    const float qx = C.m00 * px + C.m01 * py + C.tx;
+    const float qy = C.m10 * px + C.m11 * py + C.ty;
+    float best = 0.f;
+    int32_t bi = -1;
+    for (int32_t t = 0; t < n_tgt; t++) {
+      const float dx = tgt_xy[2 * t] - qx, dy = tgt_xy[2 * t + 1] - qy;
+      const float d2 = dx * dx + dy * dy;
+      if (!(std::sqrt(d2) < outlier_threshold)) continue;
+      const float a = tgt_nrm[2 * t] * nx, b = tgt_nrm[2 * t + 1] * ny;
+      const float dot = a + b;
+      if (!(std::fabs(dot) > min_abs_cosine)) continue;
+      if (bi < 0 || d2 < best) { best = d2; bi = t; }
+    }
+    if (bi < 0) continue;
+    float *c = corr_out + 8 * (size_t)n;
+    c[0] = px; c[1] = py; c[2] = tgt_xy[2 * bi]; c[3] = tgt_xy[2 * bi + 1];
+    c[4] = nx; c[5] = ny; c[6] = tgt_nrm[2 * bi]; c[7] = tgt_nrm[2 * bi + 1];
+    if (match_idx_out) match_idx_out[n] = bi;
+    n++;
+  }
+  return n;
+}
+
+int orc_corr_search_gated_batch(const float *xy, const float *normals, const int32_t *offsets,
+                                const int32_t *block_src, const int32_t *block_tgt, int32_t n_blocks,
+                                const float *pose_aff, float outlier_threshold, float min_abs_cosine,
+                                const int64_t *cap_offsets, float *corr, int32_t *counts, int32_t n_threads) {
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 8)
+#endif
+  for (int32_t b = 0; b < n_blocks; b++) {
+    const int32_t s = block_src[b], t = block_tgt[b];
+    counts[b] = orc_corr_search_gated_block(xy + 2 * (size_t)offsets[s], normals + 2 * (size_t)offsets[s],
+                                            offsets[s + 1] - offsets[s], xy + 2 * (size_t)offsets[t],
+                                            normals + 2 * (size_t)offsets[t], offsets[t + 1] - offsets[t],
+                                            pose_aff + 4 * (size_t)s, pose_aff + 4 * (size_t)t, outlier_threshold,
+                                            min_abs_cosine, corr + 8 * (size_t)cap_offsets[b], nullptr);
+  }
+  (void)n_threads;
+  return 0;
+}
+
 /* Batched driver with the product's layout: scans table + per-block (source scan, target scan). */
 int orc_corr_search_batch(const float *xy, const float *normals, const int32_t *offsets,
                           const int32_t *block_src, const int32_t *block_tgt, int32_t n_blocks,

@@ -147,6 +147,48 @@ def test_corr_search_hash_grid_corner_cases(gpu, thr):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("thr,min_cos", [(0.25, math.cos(math.radians(20.0))), (0.6, 0.5), (0.25, 0.0), (0.05, 0.999)])
+def test_corr_search_with_normal_gate(gpu, small_bag, thr, min_cos):
+    """Solver::GetPointToNormalMatching (solver.cc:177-260): nearest target within the threshold whose
+    normal satisfies |n_t . n_s| > min_cos -- bit-exact rows against the oracle's linear scan, on real
+    scan windows (hash path), oversized and far-away clouds (exhaustive path) and degenerate normals."""
+    from nautilus_amd.correspondence import IcpBatch, window_pairs
+    rng = np.random.default_rng(31)
+    scans = list(small_bag.scans[:12])
+    normals = [n.copy() for n in small_bag.normals[:12]]
+    big = rng.uniform(-4, 4, (2600, 2)).astype(np.float32)                       # > 2048 targets: exhaustive path
+    scans += [big, (big[:900] + rng.normal(0, 0.03, (900, 2))).astype(np.float32),
+              (big[:50] + np.float32(3e7)).astype(np.float32)]                   # huge coordinates: exhaustive path
+    nb = rng.normal(0, 1, big.shape).astype(np.float32)
+    nb /= np.linalg.norm(nb, axis=1, keepdims=True)
+    normals += [nb, nb[:900].copy(), nb[:50].copy()]
+    normals[13][5] = (0.0, 0.0)                                                   # degenerate normal: never similar
+    normals[13][6] = (np.nan, 1.0)
+    xy, off = csm.pack_scans(scans)
+    nrm = np.concatenate(normals).astype(np.float32)
+    bs, bt = window_pairs(12, 3)
+    bs = np.concatenate([bs, [13, 12, 14, 13]]).astype(np.int32)
+    bt = np.concatenate([bt, [12, 13, 14, 13]]).astype(np.int32)
+    poses = np.zeros((len(scans), 3))
+    poses[:12] = small_bag.odom[:12] + rng.normal(0, [0.02, 0.02, 0.004], (12, 3))
+    batch = IcpBatch(xy, nrm, off, bs, bt, outlier_threshold=thr, min_abs_cosine=min_cos)
+    batch.set_poses(poses)
+    n = batch.search()
+    rows, boff = batch.correspondences()
+    want, counts, cap = O.corr_search_gated_batch(xy, nrm, off, bs, bt, O.pose_affines(poses), thr, min_cos)
+    assert np.array_equal(np.diff(boff), counts) and n == counts.sum()
+    for b in range(len(bs)):
+        assert rows[boff[b]:boff[b + 1]].tobytes() == want[cap[b]:cap[b] + counts[b]].tobytes(), (b, thr, min_cos)
+    if min_cos == 0.0 and thr == 0.25:
+        # |dot| > 0 keeps every finite, non-orthogonal pair: nearly the ungated result
+        plain = IcpBatch(xy, nrm, off, bs[:20], bt[:20], outlier_threshold=thr)
+        plain.set_poses(poses)
+        assert abs(plain.search() - int(counts[:20].sum())) <= 0.01 * counts[:20].sum()
+    if thr == 0.25 and min_cos > 0.9:
+        assert 1000 < counts[:len(bs) - 4].sum() < n + 1   # the gate keeps a real subset on scan windows
+
+
+@pytest.mark.gpu
 def test_search_feeds_residuals_and_normal_equations(gpu, small_bag):
     """K5 -> K4 without leaving HBM; normal equations == J^T J, J^T r, r^T r of the oracle's
     autodiff Jacobians on the same correspondences."""
