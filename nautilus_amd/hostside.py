@@ -3,6 +3,7 @@ These stay on the host in the reference as well; they are restated here so the e
 end-to-end test can be driven the way nautilus drives them.  Nothing here is on the measured path.
 
   LCCandidateFilter::GetLCCandidates      /root/reference/src/loop_closure/lc_candidate_filter.cc:35-81
+  LCMatcher::ChiSquareScore / GetPossibleMatches                 src/loop_closure/lc_matcher.cc:48-74
   pose file  "timestamp x y theta"        written solver.cc:565-579, read back main.cc:131-157
   map file   "x1,y1,x2,y2" per line       solver.cc:608-618
   HitlSlamInputMsg (two line segments)    msg/HitlSlamInputMsg.msg:1-4, solver.cc:467-478
@@ -34,6 +35,28 @@ def lc_candidates(poses, scans, min_distance=5.0, min_score=0.70):
                 continue
         if scatter_matrix_score(scans[i]) >= min_score:
             out.append(i)
+    return out
+
+
+def chi_square_score(cov2x2, source_xy, target_xy):
+    """ChiSquareScore (lc_matcher.cc:50-57): d^T cov^-1 d with d = target - source translation, float32
+    matrix as the reference casts it; cov is the cross-covariance block of the two poses."""
+    cov = np.asarray(cov2x2, dtype=np.float32).reshape(2, 2)
+    d = (np.asarray(target_xy, dtype=np.float32) - np.asarray(source_xy, dtype=np.float32)).astype(np.float32)
+    return float(d @ np.linalg.inv(cov) @ d)
+
+
+def lc_possible_matches(source, candidates, poses, covariance_fn, max_score=5000.0):
+    """GetPossibleMatches (lc_matcher.cc:59-74): every other candidate whose chi-square score against
+    `source` is below 5000.  covariance_fn(pairs) -> (n, 2, 2) float32 (PoseGraph.cross_covariances)."""
+    others = [c for c in candidates if c != source]
+    if not others:
+        return []
+    cov = covariance_fn([(source, c) for c in others])
+    out = []
+    for c, m in zip(others, cov):
+        if chi_square_score(m, poses[source][:2], poses[c][:2]) < max_score:
+            out.append(c)
     return out
 
 

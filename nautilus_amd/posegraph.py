@@ -130,6 +130,36 @@ class PoseGraph:
         H = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(3 * N, 3 * N)).tocsc()
         return H, g, cost
 
+    def cross_covariances(self, pairs):
+        """Covariance blocks the way LCMatcher asks Ceres for them (GetCovarianceMatrix,
+        lc_matcher.cc:28-46): the (source pose, target pose) cross block of (J^T J)^-1 of the current
+        problem with the pose just before the earlier of the two held constant instead of pose 0;
+        returns the top-left 2 x 2 (translation) of each 3 x 3 block, float32 like the reference.
+        J^T J comes from the GPU's per-block normal equations; the sparse solves are host work."""
+        import scipy.sparse as sp
+        from scipy.sparse.linalg import splu
+        H, _, _ = self._assemble(self.poses, research=False)
+        H = H.tocsc()
+        out = np.zeros((len(pairs), 2, 2), dtype=np.float32)
+        by_gauge = {}
+        for k, (s_, t_) in enumerate(pairs):
+            by_gauge.setdefault(max(min(int(s_), int(t_)) - 1, 0), []).append(k)
+        for gauge, ks in by_gauge.items():
+            free = np.concatenate([np.arange(0, 3 * gauge), np.arange(3 * gauge + 3, 3 * self.n)])
+            pos = -np.ones(3 * self.n, dtype=np.int64)
+            pos[free] = np.arange(len(free))
+            lu = splu(H[free][:, free].tocsc() + 1e-12 * sp.identity(len(free), format="csc"))
+            for k in ks:
+                s_, t_ = int(pairs[k][0]), int(pairs[k][1])
+                if s_ == gauge or t_ == gauge:
+                    continue  # a constant block has no covariance
+                rhs = np.zeros((len(free), 2))
+                rhs[pos[3 * t_], 0] = 1.0
+                rhs[pos[3 * t_ + 1], 1] = 1.0
+                x = lu.solve(rhs)
+                out[k] = x[[pos[3 * s_], pos[3 * s_ + 1]], :].astype(np.float32)
+        return out
+
     def solve(self, iterations=8, damping=1e-3, verbose=False):
         """Gauss-Newton with Levenberg damping; pose 0 constant (SetParameterBlockConstant, solver.cc:384-386)."""
         import scipy.sparse as sp
