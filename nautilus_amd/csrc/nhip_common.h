@@ -46,12 +46,26 @@ struct GridLayout {
 // CSM_WAVE_ROWS plane rows and reads CSM_ROW_DW aligned dwords of each (nhip_csm.hip).
 constexpr int CSM_WAVE_ROWS = 21;
 constexpr int CSM_ROW_DW = 21;
-// grid-build workspace: 256-byte header, then per target the hit raster (S*S), one occupancy byte per
-// 64x64 tile and one 4-byte list slot per tile
+#ifdef __HIPCC__
+// floor(RN(v / res)) without the division on the common path.  m = RN(v * RN(1 / res)) differs
+// from the correctly rounded quotient by less than |m| * 2^-51, so the two floors can differ only
+// if m lies within that distance of an integer; those lanes (one point in ~10^12) take the division.
+__device__ __forceinline__ double floor_quotient(double v, double res, double inv_res) {
+  const double m = __dmul_rn(v, inv_res);
+  double f = floor(m);
+  const double frac = __dsub_rn(m, f);  // exact
+  const double tol = __dmul_rn(fabs(m), 0x1p-50);
+  if (frac <= tol || __dsub_rn(1.0, frac) <= tol) f = floor(__ddiv_rn(v, res));
+  return f;
+}
+#endif
+
+// grid-build workspace: 256-byte header, then per target one occupancy byte per 64x64 tile and one
+// 4-byte list slot per tile (no hit raster: the blur gathers a tile's hits from the point list)
 constexpr int64_t GRID_WS_HEADER = 256;
 inline int64_t grid_ws_per_target(int32_t S) {
   const int64_t tiles = (S + 63) / 64;
-  return (int64_t)S * S + 5 * tiles * tiles;
+  return 5 * tiles * tiles;
 }
 // bytes per skip-map row: one bit per aligned dword column, whole 8-byte words
 __host__ __device__ constexpr int32_t skip_pitch(int32_t pitch) { return ((pitch / 4 + 63) / 64) * 8; }

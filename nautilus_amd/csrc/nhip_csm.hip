@@ -78,18 +78,6 @@ struct CsmParams {
 // products (Eigen Affine2f * Vector2f on baseline x86-64: no FMA), cell = S/2 +
 // floor(double(v) / res) (cimg_debug.h:31-37).  Cells are clamped to [-h-1, S+h]: beyond that
 // range every lookup of the window falls on the zero border, and so does the clamped window.
-// floor(RN(v / res)) without the division on the common path.  m = RN(v * RN(1 / res)) differs
-// from the correctly rounded quotient by less than |m| * 2^-51, so the two floors can differ only
-// if m lies within that distance of an integer; those lanes (one point in ~10^12) take the division.
-__device__ __forceinline__ double floor_quotient(double v, double res, double inv_res) {
-  const double m = __dmul_rn(v, inv_res);
-  double f = floor(m);
-  const double frac = __dsub_rn(m, f);  // exact
-  const double tol = __dmul_rn(fabs(m), 0x1p-50);
-  if (frac <= tol || __dsub_rn(1.0, frac) <= tol) f = floor(__ddiv_rn(v, res));
-  return f;
-}
-
 __device__ __forceinline__ uint32_t window_cell(float2 q, float cf, float sf, const CsmParams &P,
                                                 int32_t ox, int32_t oy, int32_t cx, int32_t cy) {
   const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));

@@ -7,8 +7,8 @@
 // bit-identical to the CPU formulation).  Stored with a zero border of `pad` cells so the
 // correlation kernel never bounds-checks.
 //
-// HBM-bound byte work: per target, S*S hit bytes written+read, the image and its skip map
-// zero-filled, and the ~20 % of 64x64 tiles within blur reach of a hit computed (kernels below).
+// HBM-bound byte work: per target the image and its skip map are zero-filled and the ~20 % of
+// 64x64 tiles within blur reach of a hit are computed (kernels below); no intermediate raster.
 #include "nhip_common.h"
 
 namespace nhip {
@@ -24,28 +24,34 @@ struct GridKernelTables {
   uint32_t thr[256];
 };
 
-// One block per target scan: mark the cells that contain at least one point.
-__global__ __launch_bounds__(256) void grid_raster_kernel(
+// Cell of a point (cimg_debug.h:31-37: side/2 + floor(x / resolution), float promoted to double);
+// false for non-finite points and cells outside the grid (dropped, cimg_debug.h:48-50).
+__device__ __forceinline__ bool hit_cell(float2 q, int32_t S, double res, double inv_res, int32_t *c, int32_t *r) {
+  if (!(fabsf(q.x) < 1e9f) || !(fabsf(q.y) < 1e9f)) return false;
+  const double fc = floor_quotient((double)q.x, res, inv_res), fr = floor_quotient((double)q.y, res, inv_res);
+  const double half = (double)(S / 2);
+  if (!(fc >= -half && fc < (double)S - half && fr >= -half && fr < (double)S - half)) return false;
+  *c = S / 2 + (int32_t)fc;
+  *r = S / 2 + (int32_t)fr;
+  return true;
+}
+
+// One block per target scan: mark every 64x64 tile whose blur halo contains a hit.  (There is no
+// hit raster: the blur kernel gathers a tile's hits straight from the point list.)
+__global__ __launch_bounds__(256) void grid_occupancy_kernel(
     const float2 *__restrict__ xy, const int32_t *__restrict__ offsets,
-    const int32_t *__restrict__ target_ids, int32_t t0, uint8_t *__restrict__ H,
-    uint8_t *__restrict__ occ, int32_t S, int32_t tiles, int32_t R, double res) {
+    const int32_t *__restrict__ target_ids, int32_t t0, uint8_t *__restrict__ occ, int32_t S, int32_t tiles,
+    int32_t R, double res, double inv_res) {
   const int32_t t = blockIdx.x;
   const int32_t scan = target_ids[t0 + t];
   const int32_t beg = offsets[scan], end = offsets[scan + 1];
-  uint8_t *h = H + (size_t)t * S * S;
   uint8_t *o = occ + (size_t)t * tiles * tiles;
-  const long half = S / 2;
   for (int32_t p = beg + threadIdx.x; p < end; p += blockDim.x) {
-    const float2 q = xy[p];
-    if (!(fabsf(q.x) < 1e9f) || !(fabsf(q.y) < 1e9f)) continue;
-    // cimg_debug.h:31-37: side/2 + floor(x / resolution), float promoted to double
-    const long c = half + (long)floor((double)q.x / res);
-    const long r = half + (long)floor((double)q.y / res);
-    if (c < 0 || c >= S || r < 0 || r >= S) continue;  // cimg_debug.h:48-50
-    h[(size_t)r * S + c] = 1;
+    int32_t c, r;
+    if (!hit_cell(xy[p], S, res, inv_res, &c, &r)) continue;
     // tiles whose (tile + blur halo) contains this cell: at most 2 x 2 (R <= 16 < TILE)
-    const int tx0 = (int)max(c - R, 0l) / TILE, tx1 = (int)min(c + R, (long)S - 1) / TILE;
-    const int ty0 = (int)max(r - R, 0l) / TILE, ty1 = (int)min(r + R, (long)S - 1) / TILE;
+    const int tx0 = max(c - R, 0) / TILE, tx1 = min(c + R, S - 1) / TILE;
+    const int ty0 = max(r - R, 0) / TILE, ty1 = min(r + R, S - 1) / TILE;
     for (int ty = ty0; ty <= ty1; ty++)
       for (int tx = tx0; tx <= tx1; tx++) o[ty * tiles + tx] = 1;
   }
@@ -76,14 +82,17 @@ __global__ __launch_bounds__(256) void grid_tile_list_kernel(const uint8_t *__re
 // dwords.  Grid memory is pre-zeroed.
 constexpr int MAX_TILE_HITS = TH_MAX * TH_MAX;  // every cell of the neighbourhood a hit
 
-__global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restrict__ H,
+__global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict__ xy,
+                                                        const int32_t *__restrict__ offsets,
+                                                        const int32_t *__restrict__ target_ids, int32_t t0,
                                                         const int32_t *__restrict__ count,
                                                         const int32_t *__restrict__ list, int32_t tiles,
                                                         uint8_t *__restrict__ grids, int32_t S,
                                                         int32_t pad, int32_t pitch, int64_t slot_bytes,
-                                                        int32_t R, GridKernelTables tab) {
+                                                        int32_t R, double res, double inv_res, GridKernelTables tab) {
   __shared__ uint32_t sA[TILE][TILE + 1];
   __shared__ uint16_t sHits[MAX_TILE_HITS];
+  __shared__ uint32_t sSeen[(TH_MAX * TH_MAX + 31) / 32];  // one bit per neighbourhood cell: a cell is a hit once
   __shared__ uint32_t sThr[256];
   __shared__ int32_t sTaps[2 * MAX_R + 1];
   __shared__ int32_t sNH;
@@ -95,19 +104,24 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const uint8_t *__restric
     const int32_t entry = list[e];
     const int32_t t = entry / (tiles * tiles), tile = entry % (tiles * tiles);
     const int32_t r0 = (tile / tiles) * TILE, c0 = (tile % tiles) * TILE;
-    const uint8_t *h = H + (size_t)t * S * S;
     uint8_t *g = grids + (size_t)t * slot_bytes;
     __syncthreads();  // the previous entry is done with the LDS arrays
     for (int i = threadIdx.x; i < TILE * (TILE + 1); i += 256) (&sA[0][0])[i] = 0u;
+    for (int i = threadIdx.x; i < (TH_MAX * TH_MAX + 31) / 32; i += 256) sSeen[i] = 0u;
     if (threadIdx.x == 0) sNH = 0;
     __syncthreads();
-    // hits of the neighbourhood -> list (row, column packed; TH <= 96)
-    for (int rr = threadIdx.x / 32; rr < TH; rr += 8) {
-      const int r = r0 + rr - R;
-      if (r < 0 || r >= S) continue;
-      for (int cc = threadIdx.x % 32; cc < TH; cc += 32) {
-        const int c = c0 + cc - R;
-        if (c >= 0 && c < S && h[(size_t)r * S + c]) sHits[atomicAdd(&sNH, 1)] = (uint16_t)((rr << 8) | cc);
+    // hits of the neighbourhood -> list (row, column packed; TH <= 96): every point of the target scan
+    // whose cell falls inside, each cell once
+    {
+      const int32_t scan = target_ids[t0 + t];
+      const int32_t beg = offsets[scan], end = offsets[scan + 1];
+      for (int32_t p = beg + threadIdx.x; p < end; p += 256) {
+        int32_t c, r;
+        if (!hit_cell(xy[p], S, res, inv_res, &c, &r)) continue;
+        const int32_t rr = r - (r0 - R), cc = c - (c0 - R);
+        if (rr < 0 || rr >= TH || cc < 0 || cc >= TH) continue;
+        const uint32_t idx = (uint32_t)(rr * TH + cc), bit = 1u << (idx & 31u);
+        if (!(atomicOr(&sSeen[idx >> 5], bit) & bit)) sHits[atomicAdd(&sNH, 1)] = (uint16_t)((rr << 8) | cc);
       }
     }
     __syncthreads();
@@ -234,7 +248,7 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
   NHIP_REQUIRE(L.K * L.K < (1ll << 32), "grid_build: tap sum overflows 32-bit accumulation");
   NHIP_REQUIRE(L.pitch % 4 == 0, "grid_build: pitch must be a multiple of 4");
   const int tiles = (L.S + TILE - 1) / TILE;
-  // workspace: 256-byte header (list counter) | hit rasters | tile occupancy bytes | tile list
+  // workspace: 256-byte header (list counter) | tile occupancy bytes | tile list
   const int64_t per = grid_ws_per_target(L.S);
   const int64_t chunk = (ws_bytes - GRID_WS_HEADER - 4) / per;
   NHIP_REQUIRE(chunk >= 1, "grid_build: workspace %lld B < one target (%lld B)",
@@ -250,24 +264,25 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     const int32_t n = (int32_t)((n_targets - t0 < chunk) ? (n_targets - t0) : chunk);
     uint8_t *base = static_cast<uint8_t *>(d_ws);
     int32_t *count = reinterpret_cast<int32_t *>(base);
-    uint8_t *H = base + GRID_WS_HEADER;
-    uint8_t *occ = H + (size_t)n * L.S * L.S;
+    uint8_t *occ = base + GRID_WS_HEADER;
     const size_t occ_bytes = (size_t)n * tiles * tiles;
     int32_t *list = reinterpret_cast<int32_t *>(occ + ((occ_bytes + 3) & ~(size_t)3));
     uint8_t *g = d_grids + (size_t)t0 * L.slot_bytes;
-    // counter, rasters and occupancy in one fill; images and skip maps in another
-    NHIP_TRY_HIP(hipMemsetAsync(base, 0, GRID_WS_HEADER + (size_t)n * L.S * L.S + occ_bytes, s));
+    // counter and occupancy in one fill; images and skip maps in another
+    NHIP_TRY_HIP(hipMemsetAsync(base, 0, GRID_WS_HEADER + occ_bytes, s));
     NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.slot_bytes, s));
-    hipLaunchKernelGGL(grid_raster_kernel, dim3(n), dim3(256), 0, s,
+    const double inv_res = 1.0 / spec->res;
+    hipLaunchKernelGGL(grid_occupancy_kernel, dim3(n), dim3(256), 0, s,
                        reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
-                       (int32_t)t0, H, occ, L.S, tiles, L.R, spec->res);
+                       (int32_t)t0, occ, L.S, tiles, L.R, spec->res, inv_res);
     const int32_t n_tiles_total = n * tiles * tiles;
     hipLaunchKernelGGL(grid_tile_list_kernel, dim3((n_tiles_total + 255) / 256), dim3(256), 0, s, occ,
                        n_tiles_total, count, list);
     timer_begin(NHIP_TIMER_GRID, s);
     const int32_t blur_blocks = n_tiles_total < 8192 ? n_tiles_total : 8192;  // persistent over the list
-    hipLaunchKernelGGL(grid_blur_kernel, dim3(blur_blocks), dim3(256), 0, s, H, count, list, tiles, g, L.S, L.pad,
-                       L.pitch, L.slot_bytes, L.R, kt);
+    hipLaunchKernelGGL(grid_blur_kernel, dim3(blur_blocks), dim3(256), 0, s,
+                       reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
+                       tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt);
     const int32_t rows = L.S + 2 * L.pad, mpitch = L.pitch / 4;
     hipLaunchKernelGGL(grid_skipmap_kernel, dim3((mpitch + MT - 1) / MT, (rows + MT - 1) / MT, n), dim3(256), 0, s,
                        occ, g, L.S, tiles, L.pad, L.pitch, rows, L.grid_bytes, L.slot_bytes);
