@@ -169,7 +169,7 @@ def main():
     h_rot0 = torch.empty((n_pairs, 2), dtype=torch.float64).pin_memory()
     d_rot0 = torch.empty((n_pairs, 2), dtype=torch.float64, device=dev)
     d_grids = torch.empty(lib.nhip_grids_bytes(C.byref(spec), len(ids)), dtype=torch.uint8, device=dev)
-    chunk = 128
+    chunk = len(ids)  # the grid-build workspace is a few KB per target: all targets in one pass
     ws_bytes = lib.nhip_grid_workspace_bytes(C.byref(spec), chunk)
     d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     d_keys = torch.empty(n_pairs, dtype=torch.int64, device=dev)

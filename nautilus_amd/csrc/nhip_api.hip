@@ -518,7 +518,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
   g->L = L;
   g->n = n_targets;
   DevBuf ids, ws;
-  const int32_t chunk = n_targets < 64 ? (n_targets > 0 ? n_targets : 1) : 64;
+  const int32_t chunk = n_targets > 0 ? n_targets : 1;  // workspace is ~5 bytes per 64x64 tile: all targets in one pass
   const int64_t ws_bytes = nhip_grid_workspace_bytes(spec, chunk);
   if ((rc = g->grids.alloc((size_t)n_targets * L.slot_bytes + 256)) ||
       (rc = ids.alloc(sizeof(int32_t) * (size_t)(n_targets > 0 ? n_targets : 1))) ||
