@@ -33,3 +33,22 @@ def test_pose_and_map_files_roundtrip(tmp_path):
     assert np.allclose(hostside.read_map_lines(m), [[0, 0, 1.5, 2], [-3.25, 4, 5, 6]])
     seg = hostside.hitl_segments({"line_a_start": (0, 0, 0), "line_a_end": (2, 2, 0), "line_b_start": (1, 0), "line_b_end": (1, 5)})
     assert seg.dtype == np.float32 and seg.tolist() == [[0, 0, 2, 2], [1, 0, 1, 5]]
+
+
+def test_chi_square_gate_mirrors_lc_matcher():
+    """ChiSquareScore / GetPossibleMatches (lc_matcher.cc:48-74) with a stand-in covariance provider:
+    d^T cov^-1 d in float32, a scan never matches itself, threshold 5000."""
+    import numpy as np
+    from nautilus_amd import hostside
+    poses = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.1], [0.0, 30.0, 0.2], [0.5, 0.5, 0.3]])
+    cov = {(0, 1): np.eye(2) * 1e-3, (0, 2): np.eye(2) * 1e-3, (0, 3): np.array([[2e-3, 1e-3], [1e-3, 2e-3]])}
+    calls = []
+
+    def provider(pairs):
+        calls.append(list(pairs))
+        return np.stack([cov[p] for p in pairs]).astype(np.float32)
+    assert abs(hostside.chi_square_score(cov[(0, 1)], poses[0, :2], poses[1, :2]) - 1000.0) < 0.5
+    got = hostside.lc_possible_matches(0, [0, 1, 2, 3], poses, provider)
+    assert calls == [[(0, 1), (0, 2), (0, 3)]]          # one batched covariance request, self excluded
+    assert got == [1, 3]                                  # 1000 and 166.7 pass, 900000 does not
+    assert hostside.lc_possible_matches(2, [2], poses, provider) == []
