@@ -1,21 +1,37 @@
 #!/usr/bin/env python3
 """bench.py -- loop-closure candidate pairs/s on MI355X (BASELINE.json metric).
 
-One "step" = one pass of the hot path over one batch of synthetic input on every rank:
-  host: (cos, sin) of each pair's odometry heading difference (16 B/pair) + async H2D
-  K1  : likelihood grids of the batch's target scans          (nhip_grid_build_dev)
-  K2/3: exhaustive (theta, x, y) correlation + argmax per pair (nhip_csm_match_dev)
-  N>1 : ONE RCCL all-gather of the 16-byte best-pose records   (torch.distributed, backend nccl)
-Workload at every N (weak scaling): BASELINE configs[1] per GPU -- 1,000 dense 1081-beam scans,
-10,000 candidate pairs (10 per target), 61 x 81 x 81 lattice (1 deg / 5 cm over +-30 deg / +-2 m),
-1200 x 1200 grid at 0.05 m.  Scans, pair list and odometry are resident in HBM before the timed
-region; the PCIe-inclusive figure is discussed in DESIGN.md.
+  python bench.py --gpus N --steps K --warmup W [--mode weak|config4]
+
+N = 1 runs in this process.  N > 1 without RANK in the environment starts N fresh child ranks
+(`python -m torch.distributed.run --nproc-per-node N bench.py ...`, one per GPU) BEFORE this process
+touches a GPU, waits for them and relays rank 0's JSON line; with fewer than N visible GPUs it exits
+non-zero (it never falls back to fewer ranks).  Under torch.distributed.run (RANK set) it is one rank.
+
+One "step" = one pass of the hot path over the candidate-pair list of Solver::SolveAutoLC
+(/root/reference/src/optimization/solver.cc:676-700), sharded by target scan over the ranks
+(nautilus_amd/sharding.py):
+  host: (cos, sin) of each local pair's odometry heading difference (16 B/pair) + async H2D
+  K1  : likelihood grids of this rank's target scans             (nhip_grid_build_dev)
+  K2/3: exhaustive (theta, x, y) correlation + argmax per pair   (nhip_csm_match_dev)
+  N>1 : ONE RCCL all-gather of the 16-byte best-pose records (torch.distributed, backend nccl),
+        then a device-side permutation back to the original pair order (identical on every rank)
+Workloads:
+  weak (default): BASELINE configs[1] per GPU -- N x 1,000 dense 1081-beam scans, N x 10,000 candidate
+      pairs (10 per target), 61 x 81 x 81 lattice (1 deg / 5 cm over +-30 deg / +-2 m), 1200 x 1200 grid
+      at 0.05 m.  N = 1 is exactly configs[1].
+  config4: BASELINE configs[3] -- ONE global list of 10,000 scans / 1,000,000 pairs (100 per target),
+      fixed for every N (strong scaling).
+Scans, pair list and odometry are resident in HBM before the timed region; the PCIe-inclusive figure is
+in `secondary.host_buffer_api` and DESIGN.md.
 """
 import argparse
 import ctypes as C
 import json
 import math
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,117 +40,274 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+VALU_PEAK_WAVE_INSTR = 1.2288e12  # 256 CU x 4 SIMD x 2.4 GHz / 2 clk per wave64 VALU instruction (same guide)
+SALU_PEAK_INSTR = 6.144e11     # one scalar instruction per clock per CU
+LDS_READ_PEAK_TBS = 75.0       # ds_read_b32: 128 B/clk/CU
 
 
-def _cpu_model():
-    try:
-        for line in open("/proc/cpuinfo"):
-            if line.startswith("model name"):
-                return line.split(":", 1)[1].strip()
-    except Exception:
-        pass
-    return "unknown"
-
-
-def _traffic(key):
-    """HBM bytes per launch from the committed PMC profile (profiles/traffic.json), or None."""
-    tf = os.path.join(ROOT, "profiles", "traffic.json")
-    try:
-        return json.load(open(tf)).get(key)
-    except Exception:
-        return None
-
-
-def _onchip(n_pairs, n_theta, avg_ms):
-    """VALU-, SALU- and LDS-issue utilisation of csm_correlate_kernel: the instruction counts rocprofv3's SQ
-    counters measured for this workload (profiles/traffic.json <- profiles/r01_pmc_sq_correlate.txt, per
-    10k-pair launch, scaled by the pair count) divided by the kernel time measured live.  LDS read bytes:
-    every LDS instruction that is not a tile-fill store (3 per 16-byte fill load) moves 7/4 dwords per lane.
-    Peaks (MI355X_MICROARCH.md): ds_read_b32 128 B/clk/CU -> ~75 TB/s chip; VALU one wave64 instruction per
-    2 clk per SIMD -> 256 CU x 4 SIMD x 2.4 GHz / 2 = 1.23e12 wave-instr/s; SALU one instruction per clk per
-    CU -> 6.1e11/s."""
-    sq = _traffic("csm_correlate_sq_per_launch_10000pairs")
-    if not sq or n_theta != 61:
-        return None
-    k = n_pairs / 10000.0
-    secs = avg_ms * 1e-3
-    valu, salu = k * sq["SQ_INSTS_VALU"] / secs, k * sq["SQ_INSTS_SALU"] / secs
-    waves = n_pairs * n_theta * 4.0
-    fill_loads = k * sq["SQ_INSTS_VMEM_RD"] - waves * 2 * 17  # minus the point and skip-byte loads of 17 lane-chunks
-    lds_reads = k * sq["SQ_INSTS_LDS"] - 3.0 * fill_loads
-    lds = lds_reads * (7.0 / 4.0) * 256.0 / secs / 1e12
-    # SQ_ACTIVE_INST_VALU counts 4-clock issue slots; 1024 SIMDs x kernel time x clock / 4 are available
-    active = sq.get("SQ_ACTIVE_INST_VALU")
-    valu_busy = (k * active) / (1024.0 * secs * 2.4e9 / 4.0) if active else None
-    return {"valu_issue_slots_busy": valu_busy, "lds_read_TBps": lds, "lds_read_peak_TBps": 75.0, "lds_frac": lds / 75.0,
-            "valu_wave_instr_per_s": valu, "valu_peak_wave_instr_per_s": 1.2288e12, "valu_frac": valu / 1.2288e12,
-            "salu_instr_per_s": salu, "salu_peak_instr_per_s": 6.144e11, "salu_frac": salu / 6.144e11,
-            "wave_wait_frac": sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]}
-
-
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--scans", type=int, default=1000)
-    ap.add_argument("--per-target", type=int, default=10)
-    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--no-resid", action="store_true", help="skip the secondary residual-kernel measurement")
+    ap.add_argument("--mode", choices=["weak", "config4"], default="weak")
+    ap.add_argument("--scans", type=int, default=None, help="scans per GPU (weak, default 1000) / in all (config4, default 10000)")
+    ap.add_argument("--per-target", type=int, default=None, help="pairs per target scan (default 10 weak / 100 config4)")
+    ap.add_argument("--cell-bits", type=int, choices=[8, 16], default=8, help="likelihood-table cell width of the headline leg")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--no-resid", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-drop-in", action="store_true",
                     help="skip the single-pair latency leg (its small launches of the correlation kernel would "
                          "blur that kernel's average in a rocprofv3 --stats summary)")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
-def cpu_baseline(bag, xy, off, ids, src, slot, th0, budget_s):
-    """The oracle (CPU restatement, OpenMP over pairs like the reference's -fopenmp build) timed on
-    this host's cores on a bounded sample of the same workload: whole targets (grid build + their
-    pairs), sized from a one-pair calibration to ~budget_s seconds."""
-    from oracle import oracle as O
-    ospec = O.grid_spec()
-    oss = O.search_spec(61, 81, 81, math.radians(1.0))
-    cores = O.num_threads()
+# ------------------------------------------------------------------------------------------ launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(a, argv):
+    """--gpus N > 1 outside torch.distributed.run: start the N ranks as a child process tree.  Nothing in
+    THIS process has initialised a GPU yet (torch.cuda.device_count() does not, on this image)."""
+    import torch
+    visible = torch.cuda.device_count()
+    if visible < a.gpus:
+        sys.stderr.write("bench.py: --gpus %d requested but %d GPU(s) visible; refusing to run on fewer ranks\n"
+                         % (a.gpus, visible))
+        return 3
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE)
+    out = p.stdout.decode("utf-8", "replace")
+    lines = [l for l in out.splitlines() if l.startswith("{") and '"metric"' in l]
+    if p.returncode != 0 or not lines:
+        sys.stderr.write(out)
+        sys.stderr.write("bench.py: the %d-rank run failed (exit %d)\n" % (a.gpus, p.returncode))
+        return p.returncode or 4
+    print(lines[-1])
+    return 0
+
+
+# ------------------------------------------------------------------------------------------ workload
+class Workload:
+    """One global scan table + candidate-pair list, identical on every rank (seeded)."""
+
+    def __init__(self, mode, world, scans=None, per_target=None, seed=None):
+        from nautilus_amd import csm, synth
+        seed = synth.SEED if seed is None else seed
+        self.mode = mode
+        if mode == "weak":
+            self.scans_per_gpu = scans or 1000
+            self.n_scans = self.scans_per_gpu * world
+            self.per_target = per_target or 10
+            self.scaling = "weak"
+        else:
+            self.n_scans = scans or 10000
+            self.scans_per_gpu = self.n_scans // world
+            self.per_target = per_target or 100
+            self.scaling = "strong"
+        self.bag = synth.SynthBag(self.n_scans, dense=True, seed=seed)
+        assert all(len(s) == synth.N_BEAMS for s in self.bag.scans), "dense world must return all 1081 beams"
+        self.xy, self.off = csm.pack_scans(self.bag.scans)
+        ids = np.arange(self.n_scans, dtype=np.int32)
+        # SURVEY 8(d): sources within 3.5 m (lc_base_max_range, default_config.lua:122) of the target's true
+        # pose and more than 20 scans apart; theta0 = odometry heading difference (solver.cc:636-637)
+        self.src, self.tgt, self.th0 = self.bag.sample_pairs(per_target=self.per_target, targets=ids, max_dist=3.5,
+                                                             min_sep=20, seed=seed)
+        self.n_pairs = len(self.src)
+
+    def describe(self, world):
+        if self.mode == "weak":
+            return ("BASELINE configs[1] per GPU: %d dense 1081-beam scans, %d candidate pairs (%d per target) on each "
+                    "of %d GPU(s), sharded by target from one global list of %d pairs"
+                    % (self.scans_per_gpu, self.n_pairs // world, self.per_target, world, self.n_pairs))
+        return ("BASELINE configs[3]: one global list of %d dense 1081-beam scans / %d candidate pairs (%d per target) "
+                "sharded by target over %d GPU(s)" % (self.n_scans, self.n_pairs, self.per_target, world))
+
+
+class HipMatcher:
+    """This rank's shard on the MI355X: device-resident scans, pair list, grids; step() enqueues the
+    host trig + K1 + K2/K3 and returns the (n_local, 4) int32 record tensor."""
+
+    def __init__(self, wl, shard, device, cell_bits=8):
+        import torch
+        from nautilus_amd import _lib, csm
+        self.torch, self._lib, self.lib = torch, _lib, _lib.load()
+        idx, src, tgt, th0, ids, slot = shard
+        self.n_pairs, self.n_targets = len(src), len(ids)
+        self.src, self.slot, self.ids = src, slot, ids
+        self.spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=cell_bits)
+        self.search = csm.search_spec(61, 81, 81, math.radians(1.0))
+        self.layout = csm.grid_layout(self.spec)
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
+        self.d_xy, self.d_off = t(wl.xy), t(wl.off)
+        self.d_ids, self.d_src, self.d_slot = t(ids), t(src), t(slot)
+        self.d_delta = t(csm.delta_table(self.search))
+        self.h_th0 = np.ascontiguousarray(th0, dtype=np.float64)
+        n = max(self.n_pairs, 1)
+        self.h_rot0 = torch.empty((n, 2), dtype=torch.float64).pin_memory()
+        self.rot0_np = self.h_rot0.numpy()
+        self.d_rot0 = torch.empty((n, 2), dtype=torch.float64, device=device)
+        self.d_grids = torch.empty(self.lib.nhip_grids_bytes(C.byref(self.spec), max(self.n_targets, 1)),
+                                   dtype=torch.uint8, device=device)
+        self.ws_bytes = self.lib.nhip_grid_workspace_bytes(C.byref(self.spec), max(self.n_targets, 1))
+        self.d_ws = torch.empty(self.ws_bytes, dtype=torch.uint8, device=device)
+        self.d_keys = torch.empty(n, dtype=torch.int64, device=device)
+        self.d_out = torch.empty((n, 4), dtype=torch.int32, device=device)
+        self.d_sums = torch.empty(n, dtype=torch.int32, device=device)
+        self.sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def step(self):
+        lib, ck = self.lib, self._lib.check
+        if self.n_pairs == 0:
+            return self.d_out[:0]
+        ck(lib.nhip_csm_rot0(self._lib.ptr(self.h_th0), None, self.n_pairs, self._lib.ptr(self.rot0_np)))
+        self.d_rot0.copy_(self.h_rot0, non_blocking=True)
+        ck(lib.nhip_grid_build_dev(self.d_xy.data_ptr(), self.d_off.data_ptr(), self.d_ids.data_ptr(), self.n_targets,
+                                   C.byref(self.spec), self.d_grids.data_ptr(), self.d_ws.data_ptr(), self.ws_bytes,
+                                   self.sp))
+        ck(lib.nhip_csm_match_dev(self.d_xy.data_ptr(), self.d_off.data_ptr(), self.d_grids.data_ptr(),
+                                  C.byref(self.spec), self.d_src.data_ptr(), self.d_slot.data_ptr(),
+                                  self.d_rot0.data_ptr(), self.d_delta.data_ptr(), None, self.n_pairs,
+                                  C.byref(self.search), self.d_keys.data_ptr(), self.d_out.data_ptr(),
+                                  self.d_sums.data_ptr(), self.sp))
+        return self.d_out[:self.n_pairs]
+
+    def free_grids(self):
+        self.d_grids = None
+        self.torch.cuda.empty_cache()
+
+
+def run_sharded(plan, rank, world, device, matcher, steps, warmup, dist=None, on_timed_start=None):
+    """The timed region of the bench, backend-agnostic (the CPU test drives it over gloo with an injected
+    matcher): W warm-up steps, barrier + synchronize, exactly K steps, barrier + synchronize.  Each step =
+    matcher.step() (this rank's shard) + the ONE all-gather + the permutation to the original order.
+    Returns (max-over-ranks seconds, full (n_pairs, 4) table, per-rank [pairs, targets] table)."""
+    import torch
+    is_cuda = torch.device(device).type == "cuda"
+    buffers = plan.new_buffers(device)
+
+    def fence():
+        if dist is not None and world > 1:
+            dist.barrier()
+        if is_cuda:
+            torch.cuda.synchronize()
+        if dist is not None and world > 1 and is_cuda:
+            dist.barrier()
+
+    def step():
+        return plan.all_gather(matcher.step(), rank, buffers)
+
+    full = None
+    for _ in range(warmup):
+        full = step()
+    fence()
+    if on_timed_start:
+        on_timed_start()
     t0 = time.perf_counter()
-    g0 = O.grid_build_batch(xy, off, ids[:1], ospec, 1)
-    O.csm_match_batch(xy, off, g0, ospec, src[:1], np.zeros(1, np.int32), th0[:1], oss, None, 1)
-    t_one = time.perf_counter() - t0  # one grid + one pair on one core
-    per_target = int(np.sum(slot == 0))
-    t_target = t_one * (1 + per_target) / 2.0  # grid ~ pair cost, amortised below by measuring
-    n_targets = int(max(1, min(len(ids), (budget_s * cores) / max(t_target, 1e-3))))
-    n_targets = max(cores // max(per_target, 1), n_targets)
-    n_targets = min(n_targets, len(ids), 400)  # oracle grids are 1.44 MB each, keep host memory small
-    sel = np.nonzero(slot < n_targets)[0]
-    t0 = time.perf_counter()
-    grids = O.grid_build_batch(xy, off, ids[:n_targets], ospec, cores)
-    t_grid = time.perf_counter() - t0
-    t0 = time.perf_counter()
-    res = O.csm_match_batch(xy, off, grids, ospec, src[sel], slot[sel], th0[sel], oss, None, cores)
-    t_match = time.perf_counter() - t0
-    return {"value": len(sel) / (t_grid + t_match), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": "%d pairs / %d targets of the same workload (grid build %.2f s + match %.2f s), "
-                      "oracle C restatement, OpenMP over pairs" % (len(sel), n_targets, t_grid, t_match),
-            "single_thread_pairs_per_s": 1.0 / max(t_one, 1e-9),
-            "build_flags": "-O3 -fopenmp -DNDEBUG (the reference's CMakeLists.txt:16), -ffp-contract=off",
-            "cpu_model": _cpu_model(),
-            }, sel, res
+    for _ in range(steps):
+        full = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None and world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        # every rank must hold the same table: compare with rank 0's copy
+        ref = full.clone()
+        dist.broadcast(ref, src=0)
+        same = torch.tensor([1 if torch.equal(ref, full) else 0], dtype=torch.int32, device=device)
+        dist.all_reduce(same, op=dist.ReduceOp.MIN)
+        assert int(same.item()) == 1, "ranks disagree on the all-gathered match table"
+    return elapsed, full
 
 
-def main():
-    a = parse()
+# ------------------------------------------------------------------------------------------ helpers
+def _cpu_info():
+    model, phys, threads = "unknown", set(), 0
+    try:
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("processor"):
+                threads += 1
+            elif line.startswith("physical id"):
+                pid = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                cid = line.split(":", 1)[1].strip()
+                phys.add((pid, cid))
+    except Exception:
+        pass
+    return {"cpu_model": model, "hw_threads": threads or os.cpu_count(), "physical_cores": len(phys) or None}
+
+
+def _traffic(key):
+    """Numbers taken from the committed PMC profiles (profiles/traffic.json), or None."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
+def _timer(lib, _lib, tid):
+    ms, n = C.c_double(0), C.c_int32(0)
+    _lib.check(lib.nhip_timing_get(tid, C.byref(ms), C.byref(n)))
+    return ms.value, n.value
+
+
+def onchip_roofline(n_pairs, avg_ms, cell_bits):
+    """What bounds csm_correlate_kernel: it is LDS-resident and VALU-issue bound.  Instruction counts per launch
+    come from rocprofv3's SQ counters on this workload (profiles/traffic.json, per 10k-pair launch, scaled by the
+    pair count); the kernel time is the one measured live in this run."""
+    sq = _traffic("csm_correlate_sq_per_launch_10000pairs_u%d" % cell_bits) or \
+        (_traffic("csm_correlate_sq_per_launch_10000pairs") if cell_bits == 8 else None)
+    if not sq:
+        return None
+    k, secs = n_pairs / 10000.0, avg_ms * 1e-3
+    valu, salu = k * sq["SQ_INSTS_VALU"] / secs, k * sq["SQ_INSTS_SALU"] / secs
+    out = {"valu_wave_instr_per_s": valu, "valu_peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
+           "valu_frac": valu / VALU_PEAK_WAVE_INSTR,
+           "salu_instr_per_s": salu, "salu_peak_instr_per_s": SALU_PEAK_INSTR, "salu_frac": salu / SALU_PEAK_INSTR,
+           "valu_instr_per_launch": k * sq["SQ_INSTS_VALU"], "source": sq.get("source")}
+    if "SQ_WAIT_ANY" in sq and "SQ_WAVE_CYCLES" in sq:
+        out["wave_wait_frac"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+    if "SQ_LDS_BANK_CONFLICT" in sq and "SQ_LDS_IDX_ACTIVE" in sq:
+        out["lds_conflict_cycle_frac"] = sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]
+    return out
+
+
+# ------------------------------------------------------------------------------------------ worker
+def worker(a):
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    use_dist = "RANK" in os.environ
+    if world != a.gpus:
+        if rank == 0:
+            sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d; launch with `python -m torch.distributed.run "
+                             "--nproc-per-node %d bench.py --gpus %d ...` (or plain `python bench.py --gpus %d`)\n"
+                             % (a.gpus, world, a.gpus, a.gpus, a.gpus))
+        return 2
     import torch
     import torch.distributed as dist
-    from nautilus_amd import _lib, csm, synth
+    from nautilus_amd import _lib, csm, sharding, synth
     lib = _lib.load()
-    assert torch.cuda.is_available(), "bench.py needs an MI355X: there is no CPU path"
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
+        sys.stderr.write("bench.py: rank %d needs GPU %d but %d are visible: there is no CPU path\n"
+                         % (rank, local, torch.cuda.device_count() if torch.cuda.is_available() else 0))
+        return 3
     torch.cuda.set_device(local)
     _lib.check(lib.nhip_set_device(local))
     dev = torch.device("cuda", local)
-    use_dist = "RANK" in os.environ  # launched by torch.distributed.run: RCCL group even at N=1
     if use_dist:
         # RCCL prints a version banner on stdout when the communicator is created; keep stdout to
         # the one JSON line by routing fd 1 to stderr until the first collective has run.
@@ -148,232 +321,294 @@ def main():
             sys.stdout.flush()
             os.dup2(saved, 1)
             os.close(saved)
+        assert dist.get_world_size() == world
 
-    # ---- synthetic workload (per rank; seeds differ per rank so shards are not copies)
-    bag = synth.SynthBag(a.scans, dense=True, seed=synth.SEED + 1000 * rank)
-    assert all(len(s) == synth.N_BEAMS for s in bag.scans), "dense world must return all 1081 beams"
-    xy, off = csm.pack_scans(bag.scans)
-    ids = np.arange(a.scans, dtype=np.int32)
-    src, tgt, th0 = bag.sample_pairs(per_target=a.per_target, targets=ids, max_dist=1.5, min_sep=20,
-                                     seed=synth.SEED + 1000 * rank)
-    slot = tgt.astype(np.int32)  # target i -> grid slot i; pairs are already sorted by target
-    n_pairs = len(src)
-    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40)
-    search = csm.search_spec(61, 81, 81, math.radians(1.0))
-    L = csm.grid_layout(spec)
+    wl = Workload(a.mode, world, a.scans, a.per_target)
+    plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, world)
+    shard = plan.shard(rank)
+    m = HipMatcher(wl, shard, dev, a.cell_bits)
 
-    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
-    d_xy, d_off, d_ids, d_src, d_slot = t(xy), t(off), t(ids), t(src), t(slot)
-    d_delta = t(csm.delta_table(search))
-    h_th0 = np.ascontiguousarray(th0, dtype=np.float64)
-    h_rot0 = torch.empty((n_pairs, 2), dtype=torch.float64).pin_memory()
-    d_rot0 = torch.empty((n_pairs, 2), dtype=torch.float64, device=dev)
-    d_grids = torch.empty(lib.nhip_grids_bytes(C.byref(spec), len(ids)), dtype=torch.uint8, device=dev)
-    chunk = len(ids)  # the grid-build workspace is a few KB per target: all targets in one pass
-    ws_bytes = lib.nhip_grid_workspace_bytes(C.byref(spec), chunk)
-    d_ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    d_keys = torch.empty(n_pairs, dtype=torch.int64, device=dev)
-    d_out = torch.empty((n_pairs, 4), dtype=torch.int32, device=dev)
-    d_sums = torch.empty(n_pairs, dtype=torch.int32, device=dev)
-    d_all = torch.empty((world * n_pairs, 4), dtype=torch.int32, device=dev) if use_dist else None
-    stream = torch.cuda.current_stream()
-    sp = C.c_void_p(stream.cuda_stream)
-    rot0_np = h_rot0.numpy()
+    def start_timers():
+        lib.nhip_timing_reset()
+        lib.nhip_timing_enable(1)
 
-    def step():
-        _lib.check(lib.nhip_csm_rot0(_lib.ptr(h_th0), None, n_pairs, _lib.ptr(rot0_np)))
-        d_rot0.copy_(h_rot0, non_blocking=True)
-        _lib.check(lib.nhip_grid_build_dev(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), len(ids),
-                                           C.byref(spec), d_grids.data_ptr(), d_ws.data_ptr(), ws_bytes, sp))
-        _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), d_grids.data_ptr(), C.byref(spec),
-                                          d_src.data_ptr(), d_slot.data_ptr(), d_rot0.data_ptr(),
-                                          d_delta.data_ptr(), None, n_pairs, C.byref(search),
-                                          d_keys.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(), sp))
-        if use_dist:
-            dist.all_gather_into_tensor(d_all, d_out)  # the ONE collective: 16 B per pair
-
-    def fence():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    fence()
-    lib.nhip_timing_reset()
-    lib.nhip_timing_enable(1)
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        step()
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, full = run_sharded(plan, rank, world, dev, m, a.steps, a.warmup, dist if use_dist else None, start_timers)
     lib.nhip_timing_enable(0)
-    if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    k_ms, k_n = C.c_double(0), C.c_int32(0)
-    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_CSM, C.byref(k_ms), C.byref(k_n)))
-    g_ms, g_n = C.c_double(0), C.c_int32(0)
-    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_GRID, C.byref(g_ms), C.byref(g_n)))
+    k_ms, k_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
+    g_ms, g_n = _timer(lib, _lib, _lib.NHIP_TIMER_GRID)
+    avg_ms = k_ms / max(k_n, 1)
 
-    if use_dist:
-        # every rank's block of the gathered table must equal what that rank computed
-        mine = d_all[rank * n_pairs:(rank + 1) * n_pairs]
-        assert torch.equal(mine, d_out), "all-gather returned a different block for this rank"
+    # per-rank load balance: pairs, targets, correlate-kernel ms per step
+    mine = torch.tensor([m.n_pairs, m.n_targets, k_ms / a.steps, g_ms / a.steps], dtype=torch.float64, device=dev)
+    if use_dist and world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank = torch.stack(allr).cpu().numpy()
+    else:
+        per_rank = mine.cpu().numpy()[None]
+    # this rank's block of the gathered table must equal what this rank computed
+    got_local = full.index_select(0, torch.from_numpy(shard[0].astype(np.int64)).to(dev))
+    assert torch.equal(got_local, m.d_out[:m.n_pairs]), "all-gather returned a different block for this rank"
     if rank != 0:
         dist.destroy_process_group()
-        return
+        return 0
 
-    # ---- parity spot check of the timed result against the oracle happens inside cpu_baseline
-    got = d_out.cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
-    got_sums = d_sums.cpu().numpy()
-    lookups_per_pair = search.n_theta * search.nx * search.ny * synth.N_BEAMS  # 432,638,901
-    bytes_per_launch = float(n_pairs) * lookups_per_pair * 1  # 1-byte cells
-    avg_ms = k_ms.value / max(k_n.value, 1)
-    achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
-    traffic = _traffic("csm_correlate_bytes_per_launch_%dpairs" % n_pairs)
+    got = m.d_out[:m.n_pairs].cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
+    got_sums = m.d_sums[:m.n_pairs].cpu().numpy()
+    cell_bytes = a.cell_bits // 8
+    lookups_per_pair = m.search.n_theta * m.search.nx * m.search.ny * synth.N_BEAMS  # 432,638,901
+    alg_bytes = float(m.n_pairs) * lookups_per_pair * cell_bytes  # per launch of rank 0's shard
+    hbm_equiv = alg_bytes / (avg_ms * 1e-3) / 1e9
+    oc = onchip_roofline(m.n_pairs, avg_ms, a.cell_bits)
+    traffic = _traffic("csm_correlate_bytes_per_launch_%dpairs_u%d" % (m.n_pairs, a.cell_bits))
+    L = m.layout
     out = {
         "metric": "loop-closure candidate pairs/sec (1081-beam)",
-        "value": world * n_pairs * a.steps / elapsed,
+        "value": wl.n_pairs * a.steps / elapsed,
         "unit": "pairs/s",
         "n_gpus": world,
         "steps": a.steps,
         "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": wl.scaling,
         "vs_baseline": None,
-        "dtype": "u8",
+        "dtype": "u%d" % a.cell_bits,
         "data": "synthetic",
-        "config": {"workload": "BASELINE configs[1] per GPU: %d dense 1081-beam scans, %d candidate pairs "
-                               "(%d per target), 61x81x81 lattice (1 deg / 5 cm over +-30 deg / +-2 m), "
-                               "1200x1200 u8 log-likelihood grid at 0.05 m; grid build + match + all-gather"
-                               % (a.scans, n_pairs, a.per_target),
-                   "pairs_per_gpu": n_pairs, "scans_per_gpu": a.scans, "lattice": [61, 81, 81],
-                   "grid": [L.side, L.side], "cell_bytes": 1, "collective": "all_gather 16 B/pair" if world > 1 else "none"},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "csm_correlate_kernel<false, false>", "avg_launch_ms": avg_ms, "launches": k_n.value,
-                     "algorithmic_bytes_per_launch": bytes_per_launch,
-                     "note": "algorithmic gather bytes (1 B per grid lookup) / kernel time; the grid is "
-                             "cache/LDS-resident, so this exceeds what HBM itself moves (see traffic)"},
-        "kernels_ms_per_step": {"csm_correlate": k_ms.value / a.steps, "grid_blur_and_skipmap": g_ms.value / a.steps},
-        # what actually bounds the correlate kernel: the tile is LDS-resident, so
-        # the honest ceilings are the LDS read pipe and VALU issue, not HBM.
-        "onchip_roofline": _onchip(n_pairs, search.n_theta, avg_ms),
+        "config": {"workload": wl.describe(world) + "; 61x81x81 lattice (1 deg / 5 cm over +-30 deg / +-2 m), "
+                               "1200x1200 u%d log-likelihood grid at 0.05 m; grid build + match + all-gather" % a.cell_bits,
+                   "mode": a.mode, "pairs_total": wl.n_pairs, "scans_total": wl.n_scans, "lattice": [61, 81, 81],
+                   "grid": [L.side, L.side], "cell_bytes": cell_bytes,
+                   "rccl_world_size": dist.get_world_size() if use_dist else 1,
+                   "collective": "all_gather 16 B/pair" if world > 1 else "none",
+                   "per_rank": [{"pairs": int(r[0]), "targets": int(r[1]), "correlate_ms_per_step": r[2],
+                                 "grid_ms_per_step": r[3]} for r in per_rank]},
+        # What binds the dominant kernel (csm_correlate_kernel) is VALU issue: the tile is LDS-resident and the
+        # HBM traffic is ~0.5 % of peak, so the fraction is priced against the vector-instruction peak.
+        "roofline": {"bound": "valu", "kernel": "csm_correlate_kernel", "avg_launch_ms": avg_ms, "launches": k_n,
+                     "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None, "peak": VALU_PEAK_WAVE_INSTR / 1e12,
+                     "unit": "T wave-instr/s", "frac": oc["valu_frac"] if oc else None, "traffic": traffic,
+                     "note": "VALU wave64 instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/) / kernel time "
+                             "measured live with HIP events on the launch stream; peak = 1024 SIMDs x 2.4 GHz / 2 clk; "
+                             "traffic = HBM bytes per launch from the PMC passes"},
+        # SURVEY 8(d)'s gather-equivalent figure: every lookup of the exhaustive definition priced at one cell.
+        # It exceeds the HBM peak because the lookups are served from LDS: NOT a fraction of a physical ceiling.
+        "roofline_hbm_equiv": {"bound": "hbm", "achieved": hbm_equiv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": hbm_equiv / HBM_PEAK_GBS, "algorithmic_bytes_per_launch": alg_bytes,
+                               "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                               "note": "gather-equivalent: lookups x cell bytes / kernel time; hbm_traffic_frac = measured "
+                                       "HBM bytes per launch / kernel time / 8 TB/s"},
+        "kernels_ms_per_step": {"csm_correlate": k_ms / a.steps, "grid_blur_and_skipmap": g_ms / a.steps},
+        "onchip_roofline": oc,
     }
-    if world == 1:
-        # the same steps with the skip map ignored (every add of the exhaustive definition performed)
+    legs = world == 1 and a.mode == "weak"
+    if legs:
+        out["zero_skip"] = leg_dense(m, lib, _lib, alg_bytes, got, got_sums)
+    if legs and a.cpu_seconds > 0:
         try:
-            os.environ["NHIP_CSM_DENSE"] = "1"
-            step()
-            fence()
-            lib.nhip_timing_reset()
-            lib.nhip_timing_enable(1)
-            t0 = time.perf_counter()
-            for _ in range(2):
-                step()
-            fence()
-            dt = (time.perf_counter() - t0) / 2
-            lib.nhip_timing_enable(0)
-            dk_ms, dk_n = C.c_double(0), C.c_int32(0)
-            _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_CSM, C.byref(dk_ms), C.byref(dk_n)))
-            dense_kernel_ms = dk_ms.value / max(dk_n.value, 1)
-            dense_gbs = bytes_per_launch / (dense_kernel_ms * 1e-3) / 1e9
-            same = bool(np.array_equal(d_sums.cpu().numpy(), got_sums) and
-                        d_out.cpu().numpy().tobytes() == got.tobytes())
-            out["zero_skip"] = {"dense_value": n_pairs / dt, "dense_ms_per_step": 1e3 * dt, "same_result": same,
-                                "dense_kernel_ms": dense_kernel_ms, "dense_roofline_achieved_GBps": dense_gbs,
-                                "dense_roofline_frac": dense_gbs / HBM_PEAK_GBS,
-                                "note": "NHIP_CSM_DENSE=1: all-zero window strips are added like any other; `value` "
-                                        "leaves them out (skip map built with the grids), results are identical"}
-        finally:
-            os.environ.pop("NHIP_CSM_DENSE", None)
-    if world == 1 and a.cpu_seconds > 0:
-        cb, sel, ref = cpu_baseline(bag, xy, off, ids, src, slot, h_th0, a.cpu_seconds)
-        ok = all(np.array_equal(got[f][sel], ref[f]) for f in ("itheta", "ix", "iy")) and \
-            np.array_equal(got_sums[sel], ref["sum"])
-        cb["gpu_matches_oracle_on_sample"] = bool(ok)
-        out["cpu_baseline"] = cb
-        if not ok:
-            print("PARITY FAILURE: GPU result differs from the oracle on the cpu_baseline sample", file=sys.stderr)
-    if world == 1 and not a.no_resid:
-        try:
-            out["secondary"] = {"resid_lidar": bench_residuals(torch, lib, dev, sp, a.cpu_seconds > 0)}
-        except Exception as e:  # secondary measurement must not lose the headline line
-            out["secondary"] = {"resid_lidar_error": repr(e)}
-        try:
-            del d_grids
-            torch.cuda.empty_cache()
-            out["secondary"]["icp_front_half"] = bench_icp(bag, xy, off, a.cpu_seconds > 0)
+            cb, ok = cpu_baseline(wl, shard, got, got_sums, a.cpu_seconds, a.cell_bits)
+            cb["gpu_matches_oracle_on_sample"] = ok
+            out["cpu_baseline"] = cb
+            if not ok:
+                print("PARITY FAILURE: GPU result differs from the oracle on the cpu_baseline sample", file=sys.stderr)
         except Exception as e:
-            out["secondary"]["icp_front_half_error"] = repr(e)
-        try:
-            # PCIe-inclusive: the handle API (host buffers in, host records out; it also allocates and
-            # frees its device memory per call) on the same workload -- never the headline `value`.
-            t0 = time.perf_counter()
-            st = csm.ScanTable(xy, off)
-            gr = csm.LikelihoodGrids(st, ids, spec)
-            hm, hs = csm.match_pairs(st, gr, src, slot, h_th0, search)
-            dt = time.perf_counter() - t0
-            gr.close()
-            st.close()
-            out["secondary"]["host_buffer_api"] = {
-                "pairs_per_s": n_pairs / dt, "seconds": dt,
-                "same_result_as_device_api": bool(np.array_equal(hs, got_sums) and hm.tobytes() == got.tobytes()),
-                "note": "nhip_scans_upload + nhip_grids_build + nhip_csm_match with host pointers, incl. "
-                        "hipMalloc/hipFree and PCIe copies (8.6 MB in, 0.2 MB out)"}
-        except Exception as e:
-            out["secondary"]["host_buffer_api_error"] = repr(e)
-    if world == 1 and not a.no_resid and not a.no_drop_in:
-        try:
-            out["secondary"]["drop_in_two_level"] = bench_drop_in(bag, a.cpu_seconds > 0)
-        except Exception as e:
-            out["secondary"]["drop_in_two_level_error"] = repr(e)
+            out["cpu_baseline_error"] = repr(e)
+    if legs and not a.no_resid:
+        sec = out["secondary"] = {}
+        for name, fn in (("csm_u16" if a.cell_bits == 8 else "csm_u8", lambda: leg_other_cells(wl, shard, dev, a)),
+                         ("resid_lidar", lambda: bench_residuals(torch, lib, dev, m.sp, a.cpu_seconds > 0)),):
+            try:
+                sec[name] = fn()
+            except Exception as e:  # secondary measurements must not lose the headline line
+                sec[name + "_error"] = repr(e)
+        m.free_grids()
+        more = [("icp_front_half", lambda: bench_icp(wl.bag, wl.xy, wl.off, a.cpu_seconds > 0)),
+                ("host_buffer_api", lambda: leg_host_api(wl, shard, m, got, got_sums))]
+        if not a.no_drop_in:
+            more.append(("drop_in_two_level", lambda: bench_drop_in(wl.bag, a.cpu_seconds > 0)))
+            more.append(("config1_cpu_reference", lambda: bench_config1(a.cpu_seconds > 0)))
+        for name, fn in more:
+            try:
+                sec[name] = fn()
+            except Exception as e:
+                sec[name + "_error"] = repr(e)
     print(json.dumps(out))
     if use_dist:
         dist.destroy_process_group()
+    return 0
+
+
+# ------------------------------------------------------------------------------------------ legs
+def leg_dense(m, lib, _lib, alg_bytes, got, got_sums):
+    """The same steps with the skip map ignored (every add of the exhaustive definition performed)."""
+    torch = m.torch
+    try:
+        os.environ["NHIP_CSM_DENSE"] = "1"
+        m.step()
+        torch.cuda.synchronize()
+        lib.nhip_timing_reset()
+        lib.nhip_timing_enable(1)
+        t0 = time.perf_counter()
+        for _ in range(2):
+            m.step()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 2
+        lib.nhip_timing_enable(0)
+        ms, n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
+        same = bool(np.array_equal(m.d_sums[:m.n_pairs].cpu().numpy(), got_sums) and
+                    m.d_out[:m.n_pairs].cpu().numpy().tobytes() == got.tobytes())
+        return {"dense_value": m.n_pairs / dt, "dense_ms_per_step": 1e3 * dt, "same_result": same,
+                "dense_kernel_ms": ms / max(n, 1),
+                "dense_hbm_equiv_GBps": alg_bytes / (ms / max(n, 1) * 1e-3) / 1e9,
+                "note": "NHIP_CSM_DENSE=1: all-zero window strips are added like any other; `value` "
+                        "leaves them out (skip map built with the grids), results are identical"}
+    finally:
+        os.environ.pop("NHIP_CSM_DENSE", None)
+        m.step()  # leave the default-path result in the buffers
+        torch.cuda.synchronize()
+
+
+def leg_other_cells(wl, shard, dev, a, steps=3):
+    """The same workload on the other cell width (16-bit cells meet the 1e-5 score tolerance against an
+    unquantised table, 8-bit cells do not: DESIGN.md section 3)."""
+    import torch
+    from nautilus_amd import _lib
+    bits = 16 if a.cell_bits == 8 else 8
+    lib = _lib.load()
+    m2 = HipMatcher(wl, shard, dev, bits)
+    m2.step()
+    torch.cuda.synchronize()
+    lib.nhip_timing_reset()
+    lib.nhip_timing_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        m2.step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    lib.nhip_timing_enable(0)
+    ms, n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
+    avg = ms / max(n, 1)
+    oc = onchip_roofline(m2.n_pairs, avg, bits)
+    res = {"dtype": "u%d" % bits, "value": m2.n_pairs / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt,
+           "correlate_kernel_ms": avg, "steps": steps,
+           "roofline": {"bound": "valu", "frac": oc["valu_frac"] if oc else None, "peak": VALU_PEAK_WAVE_INSTR / 1e12,
+                        "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None, "unit": "T wave-instr/s"}}
+    m2.free_grids()
+    return res
+
+
+def leg_host_api(wl, shard, m, got, got_sums):
+    """PCIe-inclusive: the handle API (host buffers in, host records out; it also allocates and frees its
+    device memory per call) on the same workload -- never the headline `value`."""
+    from nautilus_amd import csm
+    idx, src, tgt, th0, ids, slot = shard
+    t0 = time.perf_counter()
+    st = csm.ScanTable(wl.xy, wl.off)
+    gr = csm.LikelihoodGrids(st, ids, m.spec)
+    hm, hs = csm.match_pairs(st, gr, src, slot, th0, m.search)
+    dt = time.perf_counter() - t0
+    gr.close()
+    st.close()
+    return {"pairs_per_s": len(src) / dt, "seconds": dt,
+            "same_result_as_device_api": bool(np.array_equal(hs, got_sums) and hm.tobytes() == got.tobytes()),
+            "note": "nhip_scans_upload + nhip_grids_build + nhip_csm_match with host pointers, incl. "
+                    "hipMalloc/hipFree and PCIe copies (8.6 MB in, 0.2 MB out)"}
+
+
+def _median_runs(fn, runs=5):
+    """1 warm-up + `runs` timed runs; returns (median seconds, all seconds, last result)."""
+    res = fn()
+    ts = []
+    for _ in range(runs):
+        t0 = time.perf_counter()
+        res = fn()
+        ts.append(time.perf_counter() - t0)
+    return float(np.median(ts)), ts, res
+
+
+def cpu_baseline(wl, shard, got, got_sums, budget_s, cell_bits):
+    """The oracle (CPU restatement, OpenMP over pairs like the reference's -fopenmp build) timed on this host's
+    cores on a bounded sample of the same workload: whole targets (grid build + their pairs), sized from a
+    one-pair calibration so that 1 warm-up + 5 timed runs fit ~budget_s seconds; the value is the median."""
+    from oracle import oracle as O
+    idx, src, tgt, th0, ids, slot = shard
+    ospec = O.grid_spec(cell_bits=cell_bits)
+    oss = O.search_spec(61, 81, 81, math.radians(1.0))
+    threads = O.num_threads()
+    t0 = time.perf_counter()
+    g0 = O.grid_build_batch(wl.xy, wl.off, ids[:1], ospec, 1)
+    O.csm_match_batch(wl.xy, wl.off, g0, ospec, src[:1], np.zeros(1, np.int32), th0[:1], oss, None, 1)
+    t_one = time.perf_counter() - t0  # one grid + one pair on one core
+    per_target = max(int(np.sum(slot == 0)), 1)
+    t_target = t_one * (1 + per_target) / 2.0
+    per_run = budget_s / 6.5
+    n_targets = int(max(1, (per_run * threads) / max(t_target, 1e-3)))
+    n_targets = max(threads // per_target, n_targets)
+    n_targets = min(n_targets, len(ids), 400)  # oracle grids are 1.44 / 2.88 MB each, keep host memory small
+    sel = np.nonzero(slot < n_targets)[0]
+    state = {}
+
+    def run():
+        t = time.perf_counter()
+        grids = O.grid_build_batch(wl.xy, wl.off, ids[:n_targets], ospec, threads)
+        state["t_grid"] = time.perf_counter() - t
+        t = time.perf_counter()
+        r = O.csm_match_batch(wl.xy, wl.off, grids, ospec, src[sel], slot[sel], th0[sel], oss, None, threads)
+        state["t_match"] = time.perf_counter() - t
+        return r
+
+    med, ts, ref = _median_runs(run, 5)
+    ok = all(np.array_equal(got[f][sel], ref[f]) for f in ("itheta", "ix", "iy")) and \
+        np.array_equal(got_sums[sel], ref["sum"])
+    info = _cpu_info()
+    cb = {"value": len(sel) / med, "unit": "pairs/s", "cores": threads, "kind": "port",
+          "sample": "%d pairs / %d targets of the same workload per run (last run: grid build %.2f s + match %.2f s), "
+                    "oracle C restatement, OpenMP over pairs; median of 5 timed runs after 1 warm-up"
+                    % (len(sel), n_targets, state["t_grid"], state["t_match"]),
+          "runs_s": ts, "single_thread_pairs_per_s": 1.0 / max(t_one, 1e-9),
+          "omp_threads": threads, "physical_cores": info["physical_cores"], "hw_threads": info["hw_threads"],
+          "build_flags": "-O3 -fopenmp -DNDEBUG (the reference's CMakeLists.txt:16), -ffp-contract=off",
+          "cpu_model": info["cpu_model"]}
+    return cb, bool(ok)
 
 
 def bench_drop_in(bag, with_cpu, calls=8):
     """The one-pair call of the reference, CorrelativeScanMatcher(30, 2, 0.3, 0.01).GetTransformation(...)
     (solver.cc:633-638): coarse search on a 0.3 m grid, refinement on the 0.01 m (6000 x 6000) grid around the
-    coarse optimum -- latency per call through the host-buffer API, next to the same two searches on the CPU
-    oracle (the "csm-style restatement" of SURVEY 8d; the real third_party/csm is not in the tree)."""
+    coarse optimum (nhip_csm_get_transformation, the one implementation the C++ header and the Python mirror
+    share) -- latency per call with host buffers, next to the same two searches on the CPU oracle at one thread
+    and at all threads (the "csm-style restatement" of SURVEY 8d; the real third_party/csm is not in the tree)."""
     from nautilus_amd import csm
     m = csm.CorrelativeScanMatcher(30, 2, 0.3, 0.01)
     pairs = [(40 + 7 * i, 37 + 7 * i) for i in range(calls)]
-    m.GetTransformation(bag.scans[pairs[0][0]], bag.scans[pairs[0][1]], bag.odom[pairs[0][0], 2],
-                        bag.odom[pairs[0][1], 2], math.radians(90))
+    args = lambda i, j: (bag.scans[i], bag.scans[j], bag.odom[i, 2], bag.odom[j, 2], math.radians(90))
+    m.GetTransformation(*args(*pairs[0]))
     t0 = time.perf_counter()
-    res = [m.GetTransformation(bag.scans[i], bag.scans[j], bag.odom[i, 2], bag.odom[j, 2], math.radians(90))
-           for i, j in pairs]
+    res = [m.GetTransformation(*args(i, j)) for i, j in pairs]
     dt = (time.perf_counter() - t0) / calls
     out = {"workload": "%d single-pair calls on dense 1081-beam scans: 181x13x13 lattice on a 200x200 grid, then "
                        "21x61x61 on a 6000x6000 grid (36 MB built per call)" % calls,
            "seconds_per_call": dt, "calls_per_s": 1.0 / dt}
     if with_cpu:
         from oracle import oracle as O
-        i, j = pairs[0]
-        a_, b_ = bag.scans[i], bag.scans[j]
+        threads = O.num_threads()
         t0 = time.perf_counter()
-        theta0 = float(csm.angle_mod(np.float64(bag.odom[i, 2]) - np.float64(bag.odom[j, 2])))
-        g1s = O.grid_spec(30.0, 0.3, 2.0, 1e-10)
-        m1 = O.csm_match(a_, O.grid_build(b_, g1s), g1s, theta0, O.search_spec(181, 13, 13, math.radians(1.0)))
-        tx1, ty1 = np.float32((m1.ix - 6) * 0.3), np.float32((m1.iy - 6) * 0.3)
-        th1 = np.float32(theta0 + (m1.itheta - 90) * math.radians(1.0))
-        cx, cy = int(round(float(tx1) / 0.01)), int(round(float(ty1) / 0.01))
-        g2s = O.grid_spec(30.0, 0.01, 2.0, 1e-10)
-        m2 = O.csm_match(a_, O.grid_build(b_, g2s), g2s, float(th1), O.search_spec(21, 61, 61, math.radians(0.1)),
-                         (cx, cy))
+        want = O.two_level_match(*args(*pairs[0]), 30.0, 2.0, 0.3, 0.01)
         dc = time.perf_counter() - t0
-        same = bool(np.float32(res[0][0]) == np.float32(m2.score) and
-                    res[0][1][0][0] == np.float32((cx + m2.ix - 30) * 0.01) and
-                    res[0][1][0][1] == np.float32((cy + m2.iy - 30) * 0.01))
+        same = bool(np.float32(res[0][0]) == np.float32(want[0]) and res[0][1][0][0] == want[1][0][0] and
+                    res[0][1][0][1] == want[1][0][1] and res[0][1][1] == want[1][1])
         out["cpu_baseline"] = {"value": 1.0 / dc, "unit": "calls/s", "cores": 1, "kind": "port",
                                "sample": "1 call, oracle C restatement of the same two-level search, single thread",
                                "gpu_matches_oracle_on_sample": same}
+        # all host threads: one call per thread, each thread runs its whole two-level search
+        k = min(threads, 64)
+        import concurrent.futures as cf
+        t0 = time.perf_counter()
+        with cf.ThreadPoolExecutor(k) as ex:
+            list(ex.map(lambda q: O.two_level_match(*args(*pairs[q % calls]), 30.0, 2.0, 0.3, 0.01), range(k)))
+        dk = time.perf_counter() - t0
+        out["cpu_baseline_all_threads"] = {"value": k / dk, "unit": "calls/s", "cores": k, "kind": "port",
+                                           "sample": "%d concurrent calls (one per thread; ctypes releases the GIL)" % k}
     return out
 
 
@@ -398,7 +633,8 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
         _lib.check(lib.nhip_resid_lidar_dev(0, corr.data_ptr(), cb.data_ptr(), n_corr, bs.data_ptr(), bt.data_ptr(),
                                             n_blocks, poses.data_ptr(), 1000, consts.data_ptr(), res.data_ptr(),
                                             js.data_ptr(), jt.data_ptr(), sp))
-    run()
+    for _ in range(8):  # warm up: clocks, caches, page tables (the legs before this one are host-only)
+        run()
     torch.cuda.synchronize()
     lib.nhip_timing_reset()
     lib.nhip_timing_enable(1)
@@ -406,19 +642,18 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
         run()
     torch.cuda.synchronize()
     lib.nhip_timing_enable(0)
-    ms, n = C.c_double(0), C.c_int32(0)
-    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_RESID, C.byref(ms), C.byref(n)))
-    avg = ms.value / max(n.value, 1)
+    ms, n = _timer(lib, _lib, _lib.NHIP_TIMER_RESID)
+    avg = ms / max(n, 1)
     bytes_alg = 144.0 * n_corr
     gbs = bytes_alg / (avg * 1e-3) / 1e9
     out = {"workload": "configs[2]: %d blocks x %d correspondences, LIDARNormal residual + 2 Jacobians" % (n_blocks, n_per),
-           "correspondences_per_s": n_corr / (avg * 1e-3), "avg_launch_ms": avg,
+           "correspondences_per_s": n_corr / (avg * 1e-3), "avg_launch_ms": avg, "launches": n,
            "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic("resid_lidar_bytes_per_launch_%dcorr" % n_corr),
                         "algorithmic_bytes_per_launch": bytes_alg}}
     try:
         # PCIe-inclusive: the handle API a Ceres EvaluationCallback uses (adapters/slam_residuals_hip.h) -- poses in,
-        # residuals and both Jacobians out to host memory, every evaluation.  Never the figure above.
+        # residuals + J_src + the two non-redundant columns of J_tgt out to pinned host memory, every evaluation.
         h_corr = corr.cpu().numpy()
         h_off = (np.arange(n_blocks + 1, dtype=np.int64) * n_per).astype(np.int32)
         h_bs, h_bt, h_poses = bs.cpu().numpy(), bt.cpu().numpy(), poses.cpu().numpy()
@@ -427,40 +662,51 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
                                                n_blocks, 1000, C.byref(hnd)))
         h_r = np.empty(2 * n_corr)
         h_js, h_jt = np.empty(6 * n_corr), np.empty(6 * n_corr)
-        _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(h_r), _lib.ptr(h_js), _lib.ptr(h_jt)))
+        ev = lambda j: _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(h_r),
+                                                            _lib.ptr(h_js) if j else None, _lib.ptr(h_jt) if j else None))
+        ev(True)
         t0 = time.perf_counter()
-        _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(h_r), _lib.ptr(h_js), _lib.ptr(h_jt)))
-        dt_j = time.perf_counter() - t0
+        for _ in range(3):
+            ev(True)
+        dt_j = (time.perf_counter() - t0) / 3
+        ev(False)
         t0 = time.perf_counter()
-        _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(h_r), None, None))
-        dt_r = time.perf_counter() - t0
+        for _ in range(3):
+            ev(False)
+        dt_r = (time.perf_counter() - t0) / 3
+        same = bool(np.array_equal(h_js, js.cpu().numpy()) and np.array_equal(h_jt, jt.cpu().numpy()))
         lib.nhip_resid_batch_free(hnd)
         out["host_buffer_api"] = {
             "seconds_per_eval_with_jacobians": dt_j, "seconds_per_eval_residuals_only": dt_r,
             "correspondences_per_s_with_jacobians": n_corr / dt_j,
-            "bytes_to_host_with_jacobians": 112.0 * n_corr,
-            "same_result_as_device_api": bool(np.array_equal(h_js, js.cpu().numpy())),
-            "note": "nhip_resid_batch_eval: 24 KB of poses up, 112 B per correspondence down over PCIe into pageable "
-                    "host memory; the per-block normal equations (icp_front_half) move 224 B per BLOCK instead"}
+            "same_result_as_device_api": same,
+            "note": "nhip_resid_batch_eval: 24 KB of poses up; residuals, J_src and the theta column of J_tgt down over "
+                    "PCIe through pinned staging (the x, y columns of J_tgt are -J_src's and are rebuilt on the host); "
+                    "the per-block normal equations (icp_front_half) move 224 B per BLOCK instead"}
         del h_r, h_js, h_jt
     except Exception as e:
         out["host_buffer_api_error"] = repr(e)
     if with_cpu:
         # CPU side of the same blocks: the oracle's Jet<6> autodiff restatement (what
-        # ceres::AutoDiffCostFunction does per block), blocks across OpenMP threads like Ceres' num_threads.
+        # ceres::AutoDiffCostFunction does per block) and the closed-form Jacobians, blocks across OpenMP
+        # threads like Ceres' num_threads.
         from oracle import oracle as O
         k = min(n_blocks, 8 * O.num_threads())
         h_corr = corr[:k * n_per].cpu().numpy()
         h_off = np.arange(k + 1, dtype=np.int32) * n_per
         h_bs, h_bt, h_poses = bs[:k].cpu().numpy(), bt[:k].cpu().numpy(), poses.cpu().numpy()
-        t0 = time.perf_counter()
-        wr, w0, w1 = O.lidar_batch(0, h_corr, h_off, h_bs, h_bt, h_poses, True, O.num_threads())
-        dt = time.perf_counter() - t0
+        med, ts, (wr, w0, w1) = _median_runs(lambda: O.lidar_batch(0, h_corr, h_off, h_bs, h_bt, h_poses, True, O.num_threads()))
         ok = bool(np.allclose(res[:2 * k * n_per].cpu().numpy(), wr, rtol=1e-9, atol=1e-9) and
                   np.allclose(js[:6 * k * n_per].cpu().numpy().reshape(-1, 3), w0, rtol=1e-9, atol=1e-8))
-        out["cpu_baseline"] = {"value": k * n_per / dt, "unit": "correspondences/s", "cores": O.num_threads(), "kind": "port",
-                               "sample": "%d blocks x %d, Jet<6> autodiff restatement, OpenMP over blocks" % (k, n_per),
+        out["cpu_baseline"] = {"value": k * n_per / med, "unit": "correspondences/s", "cores": O.num_threads(), "kind": "port",
+                               "sample": "%d blocks x %d, Jet<6> autodiff restatement, OpenMP over blocks; median of 5" % (k, n_per),
                                "gpu_matches_oracle_on_sample": ok}
+        med_a, _, (ar, a0, a1) = _median_runs(lambda: O.lidar_batch(0, h_corr, h_off, h_bs, h_bt, h_poses, True, O.num_threads(), analytic=True))
+        med_1, _, _ = _median_runs(lambda: O.lidar_batch(0, h_corr[:8 * n_per], h_off[:9], h_bs[:8], h_bt[:8], h_poses, True, 1, analytic=True), 3)
+        out["cpu_baseline_analytic"] = {"value": k * n_per / med_a, "unit": "correspondences/s", "cores": O.num_threads(),
+                                        "kind": "port", "single_thread_value": 8 * n_per / med_1,
+                                        "sample": "same blocks, closed-form Jacobians (SURVEY 8a), OpenMP over blocks; median of 5",
+                                        "matches_autodiff": bool(np.allclose(a0, w0, rtol=1e-9, atol=1e-9) and np.allclose(a1, w1, rtol=1e-9, atol=1e-9))}
     return out
 
 
@@ -484,11 +730,8 @@ def bench_icp(bag, xy, off, with_cpu, window=10, iters=5):
         batch.normal_equations(_lib.NHIP_LIDAR_POINT)
     torch.cuda.synchronize()
     lib.nhip_timing_enable(0)
-    ms, n = C.c_double(0), C.c_int32(0)
-    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_CORR, C.byref(ms), C.byref(n)))
-    t_search = ms.value / max(n.value, 1)
-    _lib.check(lib.nhip_timing_get(_lib.NHIP_TIMER_NORMEQ, C.byref(ms), C.byref(n)))
-    t_neq = ms.value / max(n.value, 1)
+    t_search = (lambda r: r[0] / max(r[1], 1))(_timer(lib, _lib, _lib.NHIP_TIMER_CORR))
+    t_neq = (lambda r: r[0] / max(r[1], 1))(_timer(lib, _lib, _lib.NHIP_TIMER_NORMEQ))
     cand = float(np.sum((off[bs + 1] - off[bs]).astype(np.float64) * (off[bt + 1] - off[bt])))
     pts_in = float(np.sum(off[bs + 1] - off[bs]) + np.sum(off[bt + 1] - off[bt]))
     out = {"workload": "configs[2] shape: %d blocks (window %d) of 1081-point scans" % (len(bs), window),
@@ -508,14 +751,36 @@ def bench_icp(bag, xy, off, with_cpu, window=10, iters=5):
     if with_cpu:
         from oracle import oracle as O
         k = min(len(bs), 4 * O.num_threads())
-        t0 = time.perf_counter()
-        O.corr_search_batch(xy, nrm, off, bs[:k], bt[:k], O.pose_affines(bag.odom), 0.25, O.num_threads())
-        dt = time.perf_counter() - t0
-        out["cpu_baseline"] = {"value": k / dt, "unit": "blocks/s", "cores": O.num_threads(), "kind": "port",
-                               "sample": "%d blocks, oracle linear-scan restatement, OpenMP" % k,
+        aff = O.pose_affines(bag.odom)
+        med, _, _ = _median_runs(lambda: O.corr_search_batch(xy, nrm, off, bs[:k], bt[:k], aff, 0.25, O.num_threads()))
+        out["cpu_baseline"] = {"value": k / med, "unit": "blocks/s", "cores": O.num_threads(), "kind": "port",
+                               "sample": "%d blocks, oracle linear-scan restatement, OpenMP; median of 5" % k,
                                "gpu_blocks_per_s": len(bs) / (t_search * 1e-3)}
     return out
 
 
+def bench_config1(with_cpu):
+    """BASELINE configs[0] (SURVEY 8d 'Config #1'): 200 scans, distance-gated pair list (|dt| < 3.5 m,
+    |i - j| > 20), loop-closure scan matching + pose-graph solve -- the CPU reference row, with the GPU path on
+    the same inputs beside it (examples/slam_loop.py drives both through the same host code)."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import slam_loop
+    out = {"workload": "configs[0]: 200 dense 1081-beam scans, pairs gated at 3.5 m / |i-j| > 20, window 1..10 ICP solve "
+                       "+ loop closure + re-solve"}
+    out["gpu"] = slam_loop.run(n_scans=200, window=10, backend="hip")
+    if with_cpu:
+        out["cpu"] = slam_loop.run(n_scans=200, window=10, backend="oracle")
+        out["cpu"]["kind"] = "port"
+    return out
+
+
+def main(argv=None):
+    argv = sys.argv[1:] if argv is None else argv
+    a = parse(argv)
+    if "RANK" not in os.environ and a.gpus > 1:
+        return launch_ranks(a, argv)
+    return worker(a)
+
+
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -50,7 +50,7 @@ const char *nhip_version(void);
 /* ------------------------------------------------------------------ likelihood grids
  * Replaces the lookup table CorrelativeScanMatcher builds from the target point cloud.
  * Geometry follows cimg_debug.h:20-37; the likelihood model (integer separable Gaussian
- * blur of the hit raster, floor, natural log, 8-bit quantisation) is the build-defined
+ * blur of the hit raster, floor, natural log, 8- or 16-bit quantisation) is the build-defined
  * spec of DESIGN.md section 3. */
 typedef struct nhip_grid_spec {
   double range;       /* scanner range [m]: ctor arg 1 (solver.cc:633); side = floor(2*range/res) */
@@ -58,24 +58,27 @@ typedef struct nhip_grid_spec {
   double sigma;       /* blur sigma in cells */
   double floor_p;     /* likelihood floor before the log (1e-10) */
   int32_t max_shift;  /* largest |cell shift| a search on these grids may use */
-  int32_t reserved;
+  int32_t cell_bits;  /* width of a quantised log-likelihood cell: 8 (or 0: the default) or 16.  8-bit cells
+                         (255 steps of 0.09 nat) are the fast path; 16-bit cells (65535 steps of 3.5e-4 nat)
+                         keep reported scores within 1e-5 relative of an unquantised double table
+                         (cimg_debug.h:19 holds the reference's table as CImg<double>) */
 } nhip_grid_spec_t;
 
 typedef struct nhip_grid_layout {
   int32_t side;        /* S: cells per side (cimg_debug.h:21-22) */
   int32_t pad;         /* zero border on every side: 2*max_shift + 16, multiple of 4 */
-  int32_t pitch;       /* bytes per stored row = S + 2*pad rounded up to a multiple of 16 */
-  int32_t rows;        /* stored rows = S + 2*pad; cell (row, col) is byte (row+pad)*pitch + col+pad */
+  int32_t pitch;       /* bytes per stored row = (S + 2*pad) * cell_bytes rounded up to a multiple of 16 */
+  int32_t rows;        /* stored rows = S + 2*pad; cell (row, col) is at byte (row+pad)*pitch + (col+pad)*cell_bytes */
   int32_t blur_radius; /* R = ceil(3*sigma) */
-  int32_t reserved;
+  int32_t cell_bytes;  /* 1 or 2 */
   int64_t tap_sum;     /* K = sum of the integer blur taps */
   int64_t grid_bytes;  /* pitch*rows: bytes of one stored grid */
   double score_floor;  /* Lf = ln(floor_p): value of cell 0 */
-  double score_step;   /* log-likelihood per quantisation step = -Lf/255 */
+  double score_step;   /* log-likelihood per quantisation step = -Lf/255 (8-bit cells) or -Lf/65535 (16-bit) */
   int64_t skip_bytes;  /* bytes of the skip map stored right after each image: one bit per stored row
                           r and aligned dword column c (bit c&7 of byte c>>3, 8*ceil(pitch/256) bytes per
-                          row) = "stored rows [r, r+21) x dwords [c, c+21) hold a non-zero cell", so the
-                          correlation kernel can leave out window strips that only add zeros (same
+                          row) = "stored rows [r, r+21) x dwords [c, c+21*cell_bytes) hold a non-zero cell",
+                          so the correlation kernel can leave out window strips that only add zeros (same
                           sums, bit for bit) */
   int64_t slot_bytes;  /* grid_bytes + skip_bytes: grid t of a buffer starts at byte t*slot_bytes */
 } nhip_grid_layout_t;
@@ -86,7 +89,8 @@ int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out);
 int64_t nhip_grids_bytes(const nhip_grid_spec_t *spec, int64_t n_grids);
 /* workspace for nhip_grid_build_dev processing `chunk` targets at a time */
 int64_t nhip_grid_workspace_bytes(const nhip_grid_spec_t *spec, int32_t chunk);
-/* integer blur taps (2R+1 values) and the 256-entry quantiser threshold table */
+/* integer blur taps (2R+1 values) and the quantiser threshold table: 256 entries for 8-bit cells,
+ * 65536 for 16-bit cells (thresholds[k] = smallest integer blur sum whose quantised value is >= k) */
 int nhip_grid_tables(const nhip_grid_spec_t *spec, int32_t *taps, uint32_t *thresholds);
 
 /* ------------------------------------------------------------------ search lattice
@@ -241,7 +245,7 @@ int nhip_scans_free(nhip_scans_t *scans);
 int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32_t n_targets,
                      const nhip_grid_spec_t *spec, nhip_grids_t **out);
 int nhip_grids_free(nhip_grids_t *grids);
-/* copy stored (padded) grid `slot` to host: layout.grid_bytes bytes */
+/* copy stored (padded) grid `slot` to host: layout.grid_bytes bytes (uint8 or uint16 cells) */
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 
 /* Batched GetTransformation: theta0[i] = AngleMod(rot_a - rot_b) of pair i;

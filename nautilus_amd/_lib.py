@@ -24,12 +24,12 @@ class NhipError(RuntimeError):
 
 class GridSpec(C.Structure):
     _fields_ = [("range", C.c_double), ("res", C.c_double), ("sigma", C.c_double),
-                ("floor_p", C.c_double), ("max_shift", C.c_int32), ("reserved", C.c_int32)]
+                ("floor_p", C.c_double), ("max_shift", C.c_int32), ("cell_bits", C.c_int32)]
 
 
 class GridLayout(C.Structure):
     _fields_ = [("side", C.c_int32), ("pad", C.c_int32), ("pitch", C.c_int32), ("rows", C.c_int32),
-                ("blur_radius", C.c_int32), ("reserved", C.c_int32), ("tap_sum", C.c_int64),
+                ("blur_radius", C.c_int32), ("cell_bytes", C.c_int32), ("tap_sum", C.c_int64),
                 ("grid_bytes", C.c_int64), ("score_floor", C.c_double), ("score_step", C.c_double),
                 ("skip_bytes", C.c_int64), ("slot_bytes", C.c_int64)]
 

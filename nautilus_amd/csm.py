@@ -19,8 +19,10 @@ MATCH_DTYPE = np.dtype([("itheta", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("score
 assert MATCH_DTYPE.itemsize == C.sizeof(Match) == 16
 
 
-def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40):
-    return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(max_shift), 0)
+def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, cell_bits=8):
+    """cell_bits: 8 (255 quantisation steps over [ln floor_p, 0]) or 16 (65535 steps: scores within 1e-5 of an
+    unquantised table)."""
+    return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(max_shift), int(cell_bits))
 
 
 def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0)):
@@ -98,11 +100,11 @@ class LikelihoodGrids:
                                            C.byref(spec), C.byref(self._h)))
 
     def download(self, slot):
-        """Stored (padded) grid as (rows, pitch) uint8."""
+        """Stored (padded) grid as (rows, pitch / cell_bytes) uint8 or uint16 cells."""
         L = self.layout
         out = np.empty((L.rows, L.pitch), dtype=np.uint8)
         check(_lib.load().nhip_grids_download(self._h, int(slot), ptr(out)))
-        return out
+        return out.view(np.uint16) if L.cell_bytes == 2 else out
 
     def interior(self, slot):
         L = self.layout

@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 
 #include <cstdarg>
+#include <map>
 #include <mutex>
 
 #include "nhip_common.h"
@@ -44,17 +45,21 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   NHIP_REQUIRE(spec->sigma > 0 && spec->sigma <= 16.0 / 3.0, "grid spec: sigma must be in (0, 5.33] cells");
   NHIP_REQUIRE(spec->floor_p > 0 && spec->floor_p < 1, "grid spec: floor_p must be in (0, 1)");
   NHIP_REQUIRE(spec->max_shift >= 0 && spec->max_shift <= 4096, "grid spec: max_shift out of range");
+  NHIP_REQUIRE(spec->cell_bits == 0 || spec->cell_bits == 8 || spec->cell_bits == 16,
+               "grid spec: cell_bits must be 8 or 16 (0 = 8), got %d", spec->cell_bits);
   const double side = floor((spec->range * 2.0) / spec->res);  // cimg_debug.h:21-22
   NHIP_REQUIRE(side >= 1 && side <= 16384, "grid spec: side %g out of range [1, 16384]", side);
   L->S = (int32_t)side;
+  L->cb = spec->cell_bits == 16 ? 2 : 1;
+  L->levels = spec->cell_bits == 16 ? 65535 : 255;
   L->pad = ((2 * spec->max_shift + 16) + 3) & ~3;
-  L->pitch = ((L->S + 2 * L->pad) + 15) & ~15;
+  L->pitch = ((L->S + 2 * L->pad) * L->cb + 15) & ~15;
   L->R = (int32_t)ceil(3.0 * spec->sigma);
   L->grid_bytes = (int64_t)L->pitch * (int64_t)(L->S + 2 * L->pad);
   L->skip_bytes = (((int64_t)skip_pitch(L->pitch) * (int64_t)(L->S + 2 * L->pad)) + 15) & ~15ll;
   L->slot_bytes = L->grid_bytes + L->skip_bytes;
   L->Lf = log(spec->floor_p);
-  L->step = -L->Lf / 255.0;
+  L->step = -L->Lf / (double)L->levels;
   // integer taps: round(16384 * g_i / sum g)
   double g[129], tot = 0.0;
   for (int i = -L->R; i <= L->R; i++) {
@@ -67,15 +72,44 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
 }
 
 // The quantiser of the spec, evaluated directly (used only to build the threshold table).
-static uint32_t quantise_direct(uint64_t V, int64_t K, double floor_p) {
+static uint32_t quantise_direct(uint64_t V, int64_t K, double floor_p, int32_t levels) {
   double v = (double)V / ((double)K * (double)K);
   if (v < floor_p) v = floor_p;
   const double Lf = log(floor_p);
-  const double step = -Lf / 255.0;
+  const double step = -Lf / (double)levels;
   double q = floor((log(v) - Lf) / step + 0.5);
   if (q < 0.0) q = 0.0;
-  if (q > 255.0) q = 255.0;
+  if (q > (double)levels) q = (double)levels;
   return (uint32_t)q;
+}
+
+// thr[k] = smallest integer V in [0, K*K] whose quantised value is >= k (0xffffffff: level never reached).
+// q is non-decreasing in V, so a binary search per level is exact; it starts from a bracket around the
+// closed-form inverse so that the 65535 levels of the 16-bit table cost a few log() calls each.
+static void make_thresholds(int64_t K, double floor_p, int32_t levels, uint32_t *thr) {
+  const uint64_t vmax = (uint64_t)K * (uint64_t)K;
+  const double Lf = log(floor_p), step = -Lf / (double)levels;
+  auto q = [&](uint64_t V) { return quantise_direct(V, K, floor_p, levels); };
+  const uint32_t q0 = q(0), qmax = q(vmax);
+  thr[0] = 0;
+  for (int32_t k = 1; k <= levels; k++) {
+    if (qmax < (uint32_t)k) { thr[k] = 0xffffffffu; continue; }
+    if (q0 >= (uint32_t)k) { thr[k] = 0; continue; }
+    // invariant: q(lo) < k <= q(hi)
+    uint64_t lo = 0, hi = vmax;
+    const double est = (double)vmax * exp(Lf + ((double)k - 0.5) * step);
+    if (est > 2.0 && est < (double)vmax) {
+      const uint64_t e = (uint64_t)est, w = e / 1000000 + 2;  // ~1e-6 relative bracket
+      const uint64_t a = e > w ? e - w : 0, b = e + w < vmax ? e + w : vmax;
+      if (q(a) < (uint32_t)k) lo = a;
+      if (q(b) >= (uint32_t)k) hi = b;
+    }
+    while (hi - lo > 1) {
+      const uint64_t mid = lo + (hi - lo) / 2;
+      if (q(mid) >= (uint32_t)k) hi = mid; else lo = mid;
+    }
+    thr[k] = (uint32_t)hi;
+  }
 }
 
 int make_tables(const nhip_grid_spec_t *spec, const GridLayout &L, GridTables *T) {
@@ -86,25 +120,20 @@ int make_tables(const nhip_grid_spec_t *spec, const GridLayout &L, GridTables *T
     tot += g[i + L.R];
   }
   for (int i = 0; i <= 2 * L.R; i++) T->taps[i] = (int32_t)floor(16384.0 * g[i] / tot + 0.5);
-  // thr[k] = smallest integer V whose quantised value is >= k (V ranges over [0, K*K]).
-  const uint64_t vmax = (uint64_t)L.K * (uint64_t)L.K;
-  T->thr[0] = 0;
-  for (int k = 1; k <= 255; k++) {
-    if (quantise_direct(vmax, L.K, spec->floor_p) < (uint32_t)k) {
-      T->thr[k] = 0xffffffffu;  // unreachable level
-      continue;
-    }
-    uint64_t lo = 0, hi = vmax;  // q(lo) < k <= q(hi) unless q(0) >= k
-    if (quantise_direct(0, L.K, spec->floor_p) >= (uint32_t)k) {
-      T->thr[k] = 0;
-      continue;
-    }
-    while (hi - lo > 1) {
-      const uint64_t mid = lo + (hi - lo) / 2;
-      if (quantise_direct(mid, L.K, spec->floor_p) >= (uint32_t)k) hi = mid; else lo = mid;
-    }
-    T->thr[k] = (uint32_t)hi;
+  if (L.cb == 1) {
+    make_thresholds(L.K, spec->floor_p, 255, T->thr);
+    return NHIP_OK;
   }
+  // 16-bit cells: 65536 entries, computed once per (tap sum, floor) and kept for the life of the process
+  static std::mutex mu;
+  static std::map<std::pair<int64_t, double>, std::vector<uint32_t>> cache;
+  std::lock_guard<std::mutex> lk(mu);
+  auto &v = cache[{L.K, spec->floor_p}];
+  if (v.empty()) {
+    v.resize(65536);
+    make_thresholds(L.K, spec->floor_p, 65535, v.data());
+  }
+  T->thr16 = v.data();
   return NHIP_OK;
 }
 
@@ -225,7 +254,7 @@ int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out) {
   out->pitch = L.pitch;
   out->rows = L.S + 2 * L.pad;
   out->blur_radius = L.R;
-  out->reserved = 0;
+  out->cell_bytes = L.cb;
   out->tap_sum = L.K;
   out->grid_bytes = L.grid_bytes;
   out->score_floor = L.Lf;
@@ -245,7 +274,8 @@ int64_t nhip_grid_workspace_bytes(const nhip_grid_spec_t *spec, int32_t chunk) {
   GridLayout L;
   if (make_layout(spec, &L)) return -1;
   if (chunk < 1) chunk = 1;
-  return GRID_WS_HEADER + 4 + (int64_t)chunk * grid_ws_per_target(L.S);  // header | rasters | tile occupancy | tile list
+  // header | [16-bit threshold table] | tile occupancy | tile list
+  return GRID_WS_HEADER + (L.cb == 2 ? GRID_WS_THR16 : 0) + 4 + (int64_t)chunk * grid_ws_per_target(L.S);
 }
 
 int nhip_grid_tables(const nhip_grid_spec_t *spec, int32_t *taps, uint32_t *thresholds) {
@@ -256,7 +286,8 @@ int nhip_grid_tables(const nhip_grid_spec_t *spec, int32_t *taps, uint32_t *thre
   rc = make_tables(spec, L, &T);
   if (rc) return rc;
   if (taps) memcpy(taps, T.taps, sizeof(int32_t) * (2 * L.R + 1));
-  if (thresholds) memcpy(thresholds, T.thr, sizeof(T.thr));
+  if (thresholds && L.cb == 1) memcpy(thresholds, T.thr, sizeof(T.thr));
+  if (thresholds && L.cb == 2) memcpy(thresholds, T.thr16, sizeof(uint32_t) * 65536);
   return NHIP_OK;
 }
 
@@ -293,7 +324,7 @@ int nhip_match_to_transform(const nhip_match_t *m, const nhip_grid_spec_t *spec,
 }
 
 double nhip_score_from_sum(const nhip_grid_spec_t *spec, int64_t sum, int32_t n_points) {
-  const double Lf = log(spec->floor_p), step = -Lf / 255.0;
+  const double Lf = log(spec->floor_p), step = -Lf / (spec->cell_bits == 16 ? 65535.0 : 255.0);
   if (n_points <= 0) return Lf;
   const double t = step * (double)sum;
   const double u = t / (double)n_points;

@@ -36,6 +36,8 @@ int require_device();
 // ---- grid layout (host) ----
 struct GridLayout {
   int32_t S, pad, pitch, R;
+  int32_t cb;      // bytes per cell: 1 or 2
+  int32_t levels;  // quantisation steps: 255 or 65535
   int64_t K;  // tap sum
   int64_t grid_bytes;  // pitch * rows: the stored image
   int64_t skip_bytes;  // skip_pitch(pitch) * rows rounded up to 16: the skip map that follows the image
@@ -45,7 +47,7 @@ struct GridLayout {
 // Geometry the skip map shares with the correlation kernel: a wave of csm_correlate_kernel owns
 // CSM_WAVE_ROWS plane rows and reads CSM_ROW_DW aligned dwords of each (nhip_csm.hip).
 constexpr int CSM_WAVE_ROWS = 21;
-constexpr int CSM_ROW_DW = 21;
+constexpr int CSM_ROW_DW = 21;  // per cell byte: a 16-bit-cell strip spans 2 * CSM_ROW_DW dwords
 #ifdef __HIPCC__
 // floor(RN(v / res)) without the division on the common path.  m = RN(v * RN(1 / res)) differs
 // from the correctly rounded quotient by less than |m| * 2^-51, so the two floors can differ only
@@ -60,9 +62,11 @@ __device__ __forceinline__ double floor_quotient(double v, double res, double in
 }
 #endif
 
-// grid-build workspace: 256-byte header, then per target one occupancy byte per 64x64 tile and one
-// 4-byte list slot per tile (no hit raster: the blur gathers a tile's hits from the point list)
+// grid-build workspace: 256-byte header, [16-bit cells: the 65536-entry quantiser threshold table,] then per
+// target one occupancy byte per 64x64 tile and one 4-byte list slot per tile (no hit raster: the blur gathers a
+// tile's hits from the point list)
 constexpr int64_t GRID_WS_HEADER = 256;
+constexpr int64_t GRID_WS_THR16 = 65536 * 4;
 inline int64_t grid_ws_per_target(int32_t S) {
   const int64_t tiles = (S + 63) / 64;
   return 5 * tiles * tiles;
@@ -74,7 +78,8 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L);
 // Device-side constant tables of one grid spec (taps + quantiser thresholds), cached.
 struct GridTables {
   int32_t taps[129];
-  uint32_t thr[256];
+  uint32_t thr[256];               // 8-bit cells
+  const uint32_t *thr16 = nullptr;  // 16-bit cells: 65536 entries, owned by a process-wide cache
 };
 int make_tables(const nhip_grid_spec_t *spec, const GridLayout &L, GridTables *T);
 

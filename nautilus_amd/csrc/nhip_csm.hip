@@ -475,6 +475,7 @@ int check_search(const nhip_grid_spec_t *spec, const GridLayout &L, const nhip_s
   NHIP_REQUIRE(L.S + 2 * L.pad < 65536, "search: stored grid side %d does not fit 16-bit cell packing",
                L.S + 2 * L.pad);
   NHIP_REQUIRE(L.pitch % 16 == 0, "search: grid pitch must be a multiple of 16");
+  NHIP_REQUIRE(L.cb == 1, "exhaustive correlation kernel: 8-bit cells only (16-bit grids go through the branch-and-bound matcher)");
   return NHIP_OK;
 }
 

@@ -3,7 +3,7 @@
 // Replaces the lookup table that CorrelativeScanMatcher rasterises from the target cloud
 // (call site src/optimization/solver.cc:633-638; geometry src/visualization/cimg_debug.h:20-64).
 // Spec: hit raster -> exact integer separable Gaussian blur ->
-// floor, natural log, 8-bit quantisation (by an integer threshold table, so the grid is
+// floor, natural log, 8- or 16-bit quantisation (by an integer threshold table, so the grid is
 // bit-identical to the CPU formulation).  Stored with a zero border of `pad` cells so the
 // correlation kernel never bounds-checks.
 //
@@ -82,6 +82,9 @@ __global__ __launch_bounds__(256) void grid_tile_list_kernel(const uint8_t *__re
 // dwords.  Grid memory is pre-zeroed.
 constexpr int MAX_TILE_HITS = TH_MAX * TH_MAX;  // every cell of the neighbourhood a hit
 
+// CB = bytes per cell.  8-bit cells: 256-entry threshold table passed by value (LDS copy); 16-bit cells: the
+// 65536-entry table lives in the workspace (thr16, L2-resident) and is searched in 16 steps.
+template <int CB>
 __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict__ xy,
                                                         const int32_t *__restrict__ offsets,
                                                         const int32_t *__restrict__ target_ids, int32_t t0,
@@ -89,14 +92,15 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
                                                         const int32_t *__restrict__ list, int32_t tiles,
                                                         uint8_t *__restrict__ grids, int32_t S,
                                                         int32_t pad, int32_t pitch, int64_t slot_bytes,
-                                                        int32_t R, double res, double inv_res, GridKernelTables tab) {
+                                                        int32_t R, double res, double inv_res, GridKernelTables tab,
+                                                        const uint32_t *__restrict__ thr16) {
   __shared__ uint32_t sA[TILE][TILE + 1];
   __shared__ uint16_t sHits[MAX_TILE_HITS];
   __shared__ uint32_t sSeen[(TH_MAX * TH_MAX + 31) / 32];  // one bit per neighbourhood cell: a cell is a hit once
   __shared__ uint32_t sThr[256];
   __shared__ int32_t sTaps[2 * MAX_R + 1];
   __shared__ int32_t sNH;
-  sThr[threadIdx.x] = tab.thr[threadIdx.x];
+  if (CB == 1) sThr[threadIdx.x] = tab.thr[threadIdx.x];
   if (threadIdx.x <= 2 * R) sTaps[threadIdx.x] = tab.taps[threadIdx.x];
   const int32_t n_entries = *count;
   const int TH = TILE + 2 * R, NT = 2 * R + 1;
@@ -143,26 +147,39 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
     for (int i = threadIdx.x; i < TILE * (TILE / 4); i += 256) {
       const int r = i / (TILE / 4), c4 = (i % (TILE / 4)) * 4;
       if (r0 + r >= S) continue;
-      uint32_t packed = 0;
+      uint32_t qv[4];
+      uint32_t any = 0;
       for (int b = 0; b < 4; b++) {
         const uint32_t a = sA[r][c4 + b];
         uint32_t q = 0;
         if (a) {
-          // q = #{k in 1..255 : thr[k] <= a}; thr is non-decreasing
-          for (int step = 128; step >= 1; step >>= 1) {
-            const uint32_t n = q + step;
-            if (n <= 255 && sThr[n] <= a) q = n;
+          // q = #{k in 1..levels : thr[k] <= a}; thr is non-decreasing
+          if (CB == 1) {
+            for (int step = 128; step >= 1; step >>= 1) {
+              const uint32_t n = q + step;
+              if (n <= 255 && sThr[n] <= a) q = n;
+            }
+          } else {
+            for (int step = 32768; step >= 1; step >>= 1) {
+              const uint32_t n = q + step;
+              if (n <= 65535 && thr16[n] <= a) q = n;
+            }
           }
         }
-        packed |= q << (8 * b);
+        qv[b] = q;
+        any |= q;
       }
-      if (packed == 0u) continue;  // the grid is pre-zeroed
-      uint8_t *dst = g + (size_t)(r0 + r + pad) * pitch + (c0 + c4 + pad);
-      if (c0 + c4 + 3 < S) {
-        *reinterpret_cast<uint32_t *>(dst) = packed;  // pad, c0, c4 are multiples of 4
+      if (any == 0u) continue;  // the grid is pre-zeroed
+      uint8_t *dst = g + (size_t)(r0 + r + pad) * pitch + (size_t)(c0 + c4 + pad) * CB;
+      if (c0 + c4 + 3 < S) {  // pad, c0, c4 are multiples of 4: a whole aligned dword / qword
+        if (CB == 1) *reinterpret_cast<uint32_t *>(dst) = qv[0] | (qv[1] << 8) | (qv[2] << 16) | (qv[3] << 24);
+        else *reinterpret_cast<uint2 *>(dst) = make_uint2(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16));
       } else {
         for (int b = 0; b < 4; b++)
-          if (c0 + c4 + b < S) dst[b] = (uint8_t)(packed >> (8 * b));
+          if (c0 + c4 + b < S) {
+            if (CB == 1) dst[b] = (uint8_t)qv[b];
+            else reinterpret_cast<uint16_t *>(dst)[b] = (uint16_t)qv[b];
+          }
       }
     }
   }
@@ -179,19 +196,24 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
 // tile; tiles whose footprint touches no occupied blur tile stay on the memset's zeros.
 constexpr int MT = 64;
 constexpr int SK_ROWS = MT + CSM_WAVE_ROWS - 1;  // grid rows feeding one map tile (84)
-static_assert(CSM_ROW_DW - 1 <= 20 && MT == 64, "row mask is built from one 64-lane and one 20-lane ballot");
+static_assert(2 * CSM_ROW_DW - 1 <= 64 && MT == 64, "row mask is built from two 64-lane ballots");
 
+// CB = bytes per cell: a strip row spans ROW_DW = CB * CSM_ROW_DW aligned dwords (21 / 42).  z = target index
+// within the launch (t_base + blockIdx.z: launches are chunked at 65,535 targets).
+template <int CB>
 __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__restrict__ occ,
                                                            uint8_t *__restrict__ grids, int32_t S,
                                                            int32_t tiles, int32_t pad, int32_t pitch,
                                                            int32_t rows, int64_t grid_bytes,
-                                                           int64_t slot_bytes) {
-  __shared__ unsigned long long sH[SK_ROWS];  // per grid row: bit c = a non-zero dword in [c0 + c, c0 + c + 21)
-  const int32_t t = blockIdx.z, tid = threadIdx.x;
+                                                           int64_t slot_bytes, int32_t t_base) {
+  constexpr int ROW_DW = CB * CSM_ROW_DW;
+  constexpr int CPD = 4 / CB;  // cells per dword
+  __shared__ unsigned long long sH[SK_ROWS];  // per grid row: bit c = a non-zero dword in [c0 + c, c0 + c + ROW_DW)
+  const int32_t t = t_base + blockIdx.z, tid = threadIdx.x;
   const int32_t r0 = blockIdx.y * MT, c0 = blockIdx.x * MT;  // first map row / dword column
   // footprint in raster coordinates -> blur tiles that could have written into it
   const int32_t fr0 = r0 - pad, fr1 = r0 + SK_ROWS - 1 - pad;
-  const int32_t fc0 = 4 * c0 - pad, fc1 = 4 * (c0 + MT + CSM_ROW_DW - 1) - 1 - pad;
+  const int32_t fc0 = CPD * c0 - pad, fc1 = CPD * (c0 + MT + ROW_DW - 1) - 1 - pad;
   int any = 0;
   if (fr1 >= 0 && fr0 < S && fc1 >= 0 && fc0 < S) {
     const int32_t ty0 = max(fr0, 0) / TILE, ty1 = min(fr1, S - 1) / TILE;
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__rest
   uint8_t *M = g + grid_bytes;
   const int32_t mpitch = pitch / 4;
   const int wave = tid >> 6, lane = tid & 63;
-  // horizontal: 84-bit non-zero mask of a row (two ballots), then OR over windows of 21 bits
+  // horizontal: (64 + ROW_DW - 1)-bit non-zero mask of a row (two ballots), then OR over windows of ROW_DW bits
   constexpr int UNR = 4;
   for (int32_t rb = wave * UNR; rb < SK_ROWS; rb += 4 * UNR) {
     uint32_t v0[UNR], v1[UNR];
@@ -216,7 +238,7 @@ __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__rest
       if (rb + u < SK_ROWS && r < rows) {
         const uint32_t *row = reinterpret_cast<const uint32_t *>(g + (size_t)r * pitch);
         if (c0 + lane < mpitch) v0[u] = row[c0 + lane];
-        if (lane < CSM_ROW_DW - 1 && c0 + 64 + lane < mpitch) v1[u] = row[c0 + 64 + lane];
+        if (lane < ROW_DW - 1 && c0 + 64 + lane < mpitch) v1[u] = row[c0 + 64 + lane];
       }
     }
 #pragma unroll
@@ -226,8 +248,9 @@ __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__rest
       m |= m >> 1;
       m |= m >> 2;
       m |= m >> 4;                                             // windows of 8
-      const unsigned __int128 m21 = m | (m >> 8) | (m >> 13);  // [c, c+16) U [c+13, c+21)
-      if (lane == 0 && rb + u < SK_ROWS) sH[rb + u] = (unsigned long long)m21;
+      unsigned __int128 mw = m | (m >> 8) | (m >> 13);         // [c, c+16) U [c+13, c+21): windows of 21
+      if (CB == 2) mw |= mw >> 21;                             // windows of 42
+      if (lane == 0 && rb + u < SK_ROWS) sH[rb + u] = (unsigned long long)mw;
     }
   }
   __syncthreads();
@@ -248,11 +271,12 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
   NHIP_REQUIRE(L.K * L.K < (1ll << 32), "grid_build: tap sum overflows 32-bit accumulation");
   NHIP_REQUIRE(L.pitch % 4 == 0, "grid_build: pitch must be a multiple of 4");
   const int tiles = (L.S + TILE - 1) / TILE;
-  // workspace: 256-byte header (list counter) | tile occupancy bytes | tile list
+  // workspace: 256-byte header (list counter) | [16-bit cells: threshold table] | tile occupancy bytes | tile list
   const int64_t per = grid_ws_per_target(L.S);
-  const int64_t chunk = (ws_bytes - GRID_WS_HEADER - 4) / per;
+  const int64_t fixed = GRID_WS_HEADER + (L.cb == 2 ? GRID_WS_THR16 : 0);
+  const int64_t chunk = (ws_bytes - fixed - 4) / per;
   NHIP_REQUIRE(chunk >= 1, "grid_build: workspace %lld B < one target (%lld B)",
-               (long long)ws_bytes, (long long)(per + GRID_WS_HEADER + 4));
+               (long long)ws_bytes, (long long)(per + fixed + 4));
   GridTables T;
   int rc = make_tables(spec, L, &T);
   if (rc) return rc;
@@ -260,16 +284,22 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
   memset(&kt, 0, sizeof(kt));
   for (int i = 0; i <= 2 * L.R; i++) kt.taps[i] = T.taps[i];
   for (int i = 0; i < 256; i++) kt.thr[i] = T.thr[i];
+  uint32_t *d_thr16 = nullptr;
+  if (L.cb == 2) {  // the table travels with the launch (the caller owns the workspace; nothing is allocated here)
+    d_thr16 = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_ws) + GRID_WS_HEADER);
+    NHIP_TRY_HIP(hipMemcpyAsync(d_thr16, T.thr16, GRID_WS_THR16, hipMemcpyHostToDevice, s));
+  }
   for (int64_t t0 = 0; t0 < n_targets; t0 += chunk) {
     const int32_t n = (int32_t)((n_targets - t0 < chunk) ? (n_targets - t0) : chunk);
     uint8_t *base = static_cast<uint8_t *>(d_ws);
     int32_t *count = reinterpret_cast<int32_t *>(base);
-    uint8_t *occ = base + GRID_WS_HEADER;
+    uint8_t *occ = base + fixed;
     const size_t occ_bytes = (size_t)n * tiles * tiles;
     int32_t *list = reinterpret_cast<int32_t *>(occ + ((occ_bytes + 3) & ~(size_t)3));
     uint8_t *g = d_grids + (size_t)t0 * L.slot_bytes;
     // counter and occupancy in one fill; images and skip maps in another
-    NHIP_TRY_HIP(hipMemsetAsync(base, 0, GRID_WS_HEADER + occ_bytes, s));
+    NHIP_TRY_HIP(hipMemsetAsync(base, 0, GRID_WS_HEADER, s));
+    NHIP_TRY_HIP(hipMemsetAsync(occ, 0, occ_bytes, s));
     NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.slot_bytes, s));
     const double inv_res = 1.0 / spec->res;
     hipLaunchKernelGGL(grid_occupancy_kernel, dim3(n), dim3(256), 0, s,
@@ -280,12 +310,26 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
                        n_tiles_total, count, list);
     timer_begin(NHIP_TIMER_GRID, s);
     const int32_t blur_blocks = n_tiles_total < 8192 ? n_tiles_total : 8192;  // persistent over the list
-    hipLaunchKernelGGL(grid_blur_kernel, dim3(blur_blocks), dim3(256), 0, s,
-                       reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
-                       tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt);
     const int32_t rows = L.S + 2 * L.pad, mpitch = L.pitch / 4;
-    hipLaunchKernelGGL(grid_skipmap_kernel, dim3((mpitch + MT - 1) / MT, (rows + MT - 1) / MT, n), dim3(256), 0, s,
-                       occ, g, L.S, tiles, L.pad, L.pitch, rows, L.grid_bytes, L.slot_bytes);
+    if (L.cb == 1)
+      hipLaunchKernelGGL(grid_blur_kernel<1>, dim3(blur_blocks), dim3(256), 0, s,
+                         reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
+                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16);
+    else
+      hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
+                         reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
+                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16);
+    // gridDim.z is limited to 65,535: the targets of a chunk go in slices
+    for (int32_t z0 = 0; z0 < n; z0 += 65535) {
+      const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
+      const dim3 mg((mpitch + MT - 1) / MT, (rows + MT - 1) / MT, nz);
+      if (L.cb == 1)
+        hipLaunchKernelGGL(grid_skipmap_kernel<1>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
+                           L.grid_bytes, L.slot_bytes, z0);
+      else
+        hipLaunchKernelGGL(grid_skipmap_kernel<2>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
+                           L.grid_bytes, L.slot_bytes, z0);
+    }
     timer_end(NHIP_TIMER_GRID, s);
   }
   NHIP_TRY_HIP(hipGetLastError());

@@ -43,7 +43,11 @@ typedef struct {
   double res;       /* cell size in metres                                            */
   double sigma;     /* Gaussian blur sigma, in cells (build-defined, default 2.0)     */
   double floor_p;   /* likelihood floor before the log (build-defined, 1e-10)         */
+  int32_t cell_bits; /* 8 (0 = 8) or 16: width of a quantised log-likelihood cell     */
+  int32_t reserved;
 } orc_grid_spec;
+
+static inline int32_t orc_levels(const orc_grid_spec *gs) { return gs->cell_bits == 16 ? 65535 : 255; }
 
 typedef struct {
   int32_t n_theta;     /* number of rotations, odd; k = 0 .. n_theta-1                 */
@@ -92,29 +96,42 @@ int64_t orc_blur_taps(double sigma, int32_t R, int32_t *taps /* 2R+1 */) {
   return K;
 }
 
-/* 8-bit quantiser of the log-likelihood: q = round((ln(max(v, floor_p)) - Lf) / step),
- * Lf = ln(floor_p), step = -Lf / 255, so q = 0 is the floor and q = 255 is v = 1. */
-static inline uint8_t orc_quantise(uint64_t V, int64_t K, double floor_p) {
+/* Quantiser of the log-likelihood: q = round((ln(max(v, floor_p)) - Lf) / step),
+ * Lf = ln(floor_p), step = -Lf / levels (levels = 255 for 8-bit cells, 65535 for 16-bit cells), so q = 0 is
+ * the floor and q = levels is v = 1. */
+static inline uint32_t orc_quantise(uint64_t V, int64_t K, double floor_p, int32_t levels) {
   double v = (double)V / ((double)K * (double)K);
   if (v < floor_p) v = floor_p;
   double Lf = log(floor_p);
-  double step = -Lf / 255.0;
+  double step = -Lf / (double)levels;
   double q = floor((log(v) - Lf) / step + 0.5);
   if (q < 0.0) q = 0.0;
-  if (q > 255.0) q = 255.0;
-  return (uint8_t)q;
+  if (q > (double)levels) q = (double)levels;
+  return (uint32_t)q;
+}
+
+/* The same likelihood WITHOUT quantisation (test-only reference for the precision of the cell width:
+ * the in-tree evidence for the reference's table is a CImg<double>, cimg_debug.h:19). */
+static inline double orc_loglik(uint64_t V, int64_t K, double floor_p) {
+  double v = (double)V / ((double)K * (double)K);
+  if (v < floor_p) v = floor_p;
+  return log(v);
 }
 
 double orc_score_floor(const orc_grid_spec *gs) { return log(gs->floor_p); }
-double orc_score_step(const orc_grid_spec *gs) { return -log(gs->floor_p) / 255.0; }
+double orc_score_step(const orc_grid_spec *gs) { return -log(gs->floor_p) / (double)orc_levels(gs); }
 
 /*
  * Likelihood grid of one target scan (K1).  out is S*S bytes, row-major [row(y)][col(x)].
  * 1. hit raster H (cimg_debug.h:57-64), 2. separable integer Gaussian blur (exact),
  * 3. clamp, natural log, 8-bit quantisation.
  */
-int orc_grid_build(const float *xy, int32_t n_points, const orc_grid_spec *gs, uint8_t *out) {
+/* out: S*S cells of uint8 (cell_bits 8), uint16 (cell_bits 16), or -- out_f64 != NULL -- double
+ * log-likelihoods without quantisation. */
+static int orc_grid_build_any(const float *xy, int32_t n_points, const orc_grid_spec *gs, void *out,
+                              double *out_f64) {
   const int32_t S = orc_grid_side(gs->range, gs->res);
+  const int32_t levels = orc_levels(gs);
   const int32_t R = orc_blur_radius(gs->sigma);
   if (S <= 0 || R < 0 || R > 64) return -1;
   int32_t taps[2 * 64 + 1];
@@ -149,12 +166,22 @@ int orc_grid_build(const float *xy, int32_t n_points, const orc_grid_spec *gs, u
         if (rr < 0 || rr >= S) continue;
         a += (uint64_t)taps[i + R] * V1[(size_t)rr * S + c];
       }
-      out[(size_t)r * S + c] = orc_quantise(a, K, gs->floor_p);
+      if (out_f64) out_f64[(size_t)r * S + c] = orc_loglik(a, K, gs->floor_p);
+      else if (levels == 255) ((uint8_t *)out)[(size_t)r * S + c] = (uint8_t)orc_quantise(a, K, gs->floor_p, levels);
+      else ((uint16_t *)out)[(size_t)r * S + c] = (uint16_t)orc_quantise(a, K, gs->floor_p, levels);
     }
   }
   free(H);
   free(V1);
   return 0;
+}
+
+int orc_grid_build(const float *xy, int32_t n_points, const orc_grid_spec *gs, void *out) {
+  return orc_grid_build_any(xy, n_points, gs, out, NULL);
+}
+
+int orc_grid_build_f64(const float *xy, int32_t n_points, const orc_grid_spec *gs, double *out) {
+  return orc_grid_build_any(xy, n_points, gs, NULL, out);
 }
 
 /* Rotation k of the search lattice.  theta_k = theta0 + (k - (n-1)/2) * step is applied
@@ -176,10 +203,13 @@ static inline void orc_rotation(double theta0, const orc_search_spec *ss, int32_
  * grid is the S*S table of orc_grid_build.  Out-of-grid lookups contribute the floor (0).
  * Argmax: maximise the integer sum; ties -> smallest linear index (k*nx + ix)*ny + iy.
  */
-int orc_csm_match(const float *src_xy, int32_t n_points, const uint8_t *grid,
+int orc_csm_match(const float *src_xy, int32_t n_points, const void *grid_any,
                   const orc_grid_spec *gs, double theta0, int32_t origin_x, int32_t origin_y,
                   const orc_search_spec *ss, orc_match *out) {
   const int32_t S = orc_grid_side(gs->range, gs->res);
+  const int wide = gs->cell_bits == 16;
+  const uint8_t *grid = (const uint8_t *)grid_any;
+  const uint16_t *grid16 = (const uint16_t *)grid_any;
   const int32_t nx = ss->nx, ny = ss->ny, hx = (nx - 1) / 2, hy = (ny - 1) / 2;
   if (ss->n_theta < 1 || nx < 1 || ny < 1 || !(nx & 1) || !(ny & 1) || !(ss->n_theta & 1))
     return -1;
@@ -209,9 +239,14 @@ int orc_csm_match(const float *src_xy, int32_t n_points, const uint8_t *grid,
       for (int32_t iy = 0; iy < ny; iy++) {
         const int64_t r = r0 + iy;
         if (r < 0 || r >= S) continue;
-        const uint8_t *g = grid + (size_t)r * S + c0;
         int32_t *a = acc + (size_t)iy * nx;
-        for (int32_t ix = ix_lo; ix < ix_hi; ix++) a[ix] += g[ix];
+        if (wide) {
+          const uint16_t *g = grid16 + (size_t)r * S + c0;
+          for (int32_t ix = ix_lo; ix < ix_hi; ix++) a[ix] += g[ix];
+        } else {
+          const uint8_t *g = grid + (size_t)r * S + c0;
+          for (int32_t ix = ix_lo; ix < ix_hi; ix++) a[ix] += g[ix];
+        }
       }
     }
     for (int32_t ix = 0; ix < nx; ix++)
@@ -226,7 +261,7 @@ int orc_csm_match(const float *src_xy, int32_t n_points, const uint8_t *grid,
   out->sum = (int32_t)best_sum;
   {
     const double Lf = log(gs->floor_p);
-    const double step = -Lf / 255.0;
+    const double step = -Lf / (double)orc_levels(gs);
     if (n_points > 0) {
       const double t = step * (double)best_sum;
       const double u = t / (double)n_points;
@@ -241,10 +276,13 @@ int orc_csm_match(const float *src_xy, int32_t n_points, const uint8_t *grid,
 
 /* Full score volume of one pair (for tests that check more than the argmax):
  * sums[(k*nx + ix)*ny + iy]. */
-int orc_csm_scores(const float *src_xy, int32_t n_points, const uint8_t *grid,
+int orc_csm_scores(const float *src_xy, int32_t n_points, const void *grid_any,
                    const orc_grid_spec *gs, double theta0, int32_t origin_x, int32_t origin_y,
                    const orc_search_spec *ss, int32_t *sums) {
   const int32_t S = orc_grid_side(gs->range, gs->res);
+  const int wide = gs->cell_bits == 16;
+  const uint8_t *grid = (const uint8_t *)grid_any;
+  const uint16_t *grid16 = (const uint16_t *)grid_any;
   const int32_t nx = ss->nx, ny = ss->ny, hx = (nx - 1) / 2, hy = (ny - 1) / 2;
   for (int32_t k = 0; k < ss->n_theta; k++) {
     float cf, sf;
@@ -260,7 +298,7 @@ int orc_csm_scores(const float *src_xy, int32_t n_points, const uint8_t *grid,
           const int64_t c = orc_cell(xr, gs->res, S) + origin_x + (ix - hx);
           const int64_t r = orc_cell(yr, gs->res, S) + origin_y + (iy - hy);
           if (c < 0 || c >= S || r < 0 || r >= S) continue;
-          s += grid[(size_t)r * S + c];
+          s += wide ? (int64_t)grid16[(size_t)r * S + c] : (int64_t)grid[(size_t)r * S + c];
         }
         sums[((size_t)k * nx + ix) * ny + iy] = (int32_t)s;
       }
@@ -274,12 +312,14 @@ int orc_csm_scores(const float *src_xy, int32_t n_points, const uint8_t *grid,
  * with -fopenmp (the reference builds with -fopenmp -O3, CMakeLists.txt:16).
  *   xy[offsets[i]..offsets[i+1]) = points of scan i; grids[slot] = S*S bytes.
  */
-int orc_csm_match_batch(const float *xy, const int32_t *offsets, const uint8_t *grids,
+int orc_csm_match_batch(const float *xy, const int32_t *offsets, const void *grids_any,
                         const orc_grid_spec *gs, const int32_t *pair_src,
                         const int32_t *pair_slot, const double *theta0,
                         const int32_t *pair_origin, int32_t n_pairs, const orc_search_spec *ss,
                         orc_match *out, int32_t n_threads) {
   const int32_t S = orc_grid_side(gs->range, gs->res);
+  const size_t cell = gs->cell_bits == 16 ? 2 : 1;
+  const uint8_t *grids = (const uint8_t *)grids_any;
   int rc = 0;
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -289,7 +329,7 @@ int orc_csm_match_batch(const float *xy, const int32_t *offsets, const uint8_t *
     const int32_t s = pair_src[i];
     const int32_t n = offsets[s + 1] - offsets[s];
     int r = orc_csm_match(xy + 2 * (size_t)offsets[s], n,
-                          grids + (size_t)pair_slot[i] * S * S, gs, theta0[i],
+                          grids + (size_t)pair_slot[i] * S * S * cell, gs, theta0[i],
                           pair_origin ? pair_origin[2 * i] : 0,
                           pair_origin ? pair_origin[2 * i + 1] : 0, ss, &out[i]);
     if (r != 0) {
@@ -304,9 +344,11 @@ int orc_csm_match_batch(const float *xy, const int32_t *offsets, const uint8_t *
 }
 
 int orc_grid_build_batch(const float *xy, const int32_t *offsets, const int32_t *target_ids,
-                         int32_t n_targets, const orc_grid_spec *gs, uint8_t *grids,
+                         int32_t n_targets, const orc_grid_spec *gs, void *grids_any,
                          int32_t n_threads) {
   const int32_t S = orc_grid_side(gs->range, gs->res);
+  const size_t cell = gs->cell_bits == 16 ? 2 : 1;
+  uint8_t *grids = (uint8_t *)grids_any;
   int rc = 0;
 #ifdef _OPENMP
   if (n_threads > 0) omp_set_num_threads(n_threads);
@@ -315,7 +357,7 @@ int orc_grid_build_batch(const float *xy, const int32_t *offsets, const int32_t 
   for (int32_t t = 0; t < n_targets; t++) {
     const int32_t s = target_ids[t];
     int r = orc_grid_build(xy + 2 * (size_t)offsets[s], offsets[s + 1] - offsets[s], gs,
-                           grids + (size_t)t * S * S);
+                           grids + (size_t)t * S * S * cell);
     if (r != 0) {
 #ifdef _OPENMP
 #pragma omp atomic write
@@ -325,6 +367,147 @@ int orc_grid_build_batch(const float *xy, const int32_t *offsets, const int32_t 
   }
   (void)n_threads;
   return rc;
+}
+
+
+/*
+ * TEST-ONLY unquantised variant: the same spec on a table of double log-likelihoods (no cell
+ * quantisation), sums in double in point order, first maximum wins.  tests/ use it to MEASURE how far
+ * the 8- and 16-bit tables are from an ideal double table (score deviation, argmax agreement); nothing
+ * is parity-checked bit for bit against it (double sums are order-dependent).
+ */
+typedef struct {
+  int32_t itheta, ix, iy, pad;
+  double score; /* mean log-likelihood at the argmax */
+} orc_match_f64;
+
+int orc_csm_match_f64(const float *src_xy, int32_t n_points, const double *grid,
+                      const orc_grid_spec *gs, double theta0, const orc_search_spec *ss,
+                      orc_match_f64 *out, double *scores /* n_theta*nx*ny mean log-likelihoods, or NULL */) {
+  const int32_t S = orc_grid_side(gs->range, gs->res);
+  const int32_t nx = ss->nx, ny = ss->ny, hx = (nx - 1) / 2, hy = (ny - 1) / 2;
+  const double Lf = log(gs->floor_p);
+  double *acc = (double *)malloc(sizeof(double) * (size_t)nx * ny);
+  if (!acc) return -2;
+  double best = -INFINITY;
+  int32_t bk = 0, bx = 0, by = 0;
+  for (int32_t k = 0; k < ss->n_theta; k++) {
+    float cf, sf;
+    orc_rotation(theta0, ss, k, &cf, &sf);
+    for (size_t i = 0; i < (size_t)nx * ny; i++) acc[i] = 0.0;
+    for (int32_t p = 0; p < n_points; p++) {
+      const float x = src_xy[2 * p], y = src_xy[2 * p + 1];
+      const float ax = cf * x, bx_ = sf * y, ay = sf * x, by_ = cf * y;
+      const float xr = ax - bx_;
+      const float yr = ay + by_;
+      const int64_t c0 = orc_cell(xr, gs->res, S) - hx, r0 = orc_cell(yr, gs->res, S) - hy;
+      for (int32_t iy = 0; iy < ny; iy++) {
+        const int64_t r = r0 + iy;
+        double *a = acc + (size_t)iy * nx;
+        for (int32_t ix = 0; ix < nx; ix++) {
+          const int64_t c = c0 + ix;
+          a[ix] += (r < 0 || r >= S || c < 0 || c >= S) ? Lf : grid[(size_t)r * S + c];
+        }
+      }
+    }
+    for (int32_t ix = 0; ix < nx; ix++)
+      for (int32_t iy = 0; iy < ny; iy++) {
+        const double s = n_points > 0 ? acc[(size_t)iy * nx + ix] / (double)n_points : Lf;
+        if (scores) scores[((size_t)k * nx + ix) * ny + iy] = s;
+        if (s > best) { best = s; bk = k; bx = ix; by = iy; }
+      }
+  }
+  out->itheta = bk; out->ix = bx; out->iy = by; out->pad = 0;
+  out->score = best;
+  free(acc);
+  return 0;
+}
+
+/* One unquantised table per pair's target is built and dropped inside the loop (11.5 MB each). */
+int orc_csm_match_f64_batch(const float *xy, const int32_t *offsets, const int32_t *pair_src,
+                            const int32_t *pair_tgt, const double *theta0, int32_t n_pairs,
+                            const orc_grid_spec *gs, const orc_search_spec *ss, orc_match_f64 *out,
+                            const int32_t *probe /* 3 lattice indices per pair or NULL */,
+                            double *probe_score /* score of the f64 table at `probe` */,
+                            int32_t n_threads) {
+  const int32_t S = orc_grid_side(gs->range, gs->res);
+  int rc = 0;
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 1)
+#endif
+  for (int32_t i = 0; i < n_pairs; i++) {
+    const int32_t s = pair_src[i], t = pair_tgt[i];
+    double *g = (double *)malloc(sizeof(double) * (size_t)S * S);
+    double *vol = probe ? (double *)malloc(sizeof(double) * (size_t)ss->n_theta * ss->nx * ss->ny) : NULL;
+    int r = (g && (!probe || vol)) ? 0 : -2;
+    if (!r) r = orc_grid_build_f64(xy + 2 * (size_t)offsets[t], offsets[t + 1] - offsets[t], gs, g);
+    if (!r) r = orc_csm_match_f64(xy + 2 * (size_t)offsets[s], offsets[s + 1] - offsets[s], g, gs, theta0[i], ss,
+                                  &out[i], vol);
+    if (!r && probe)
+      probe_score[i] = vol[((size_t)probe[3 * i] * ss->nx + probe[3 * i + 1]) * ss->ny + probe[3 * i + 2]];
+    free(g); free(vol);
+    if (r != 0) {
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+      rc = r;
+    }
+  }
+  (void)n_threads;
+  return rc;
+}
+
+/*
+ * The reference-shaped single-pair call, CorrelativeScanMatcher(range, trans_range, low_res,
+ * high_res).GetTransformation(pc_a, pc_b, rot_a, rot_b, rot_restriction) (solver.cc:633-644), as the
+ * build defines it: exhaustive search on the low_res grid over
+ * +-trans_range and +-rot_restriction in 1 degree steps, then exhaustive search on the high_res grid
+ * over +-low_res around the coarse optimum in 0.1 degree steps.  Restated independently of
+ * nhip_csm_get_transformation (csrc/nhip_api.hip), which tests compare with this, float for float.
+ */
+int orc_two_level_match(const float *pc_a, int32_t n_a, const float *pc_b, int32_t n_b, double rot_a,
+                        double rot_b, double rot_restriction, double range, double trans_range,
+                        double low_res, double high_res, double sigma, double floor_p,
+                        int32_t cell_bits, double *score, float *tx, float *ty, float *theta) {
+  const double two_pi = 2.0 * M_PI;
+  double theta0 = rot_a - rot_b;                    /* math_util.h:81-89 AngleDiff */
+  theta0 -= two_pi * rint(theta0 / two_pi);
+  const double coarse_step = M_PI / 180.0;
+  const size_t cell = cell_bits == 16 ? 2 : 1;
+  /* level 1 */
+  const int32_t h1 = (int32_t)floor(trans_range / low_res);
+  orc_grid_spec g1 = {range, low_res, sigma, floor_p, cell_bits, 0};
+  orc_search_spec s1 = {2 * (int32_t)floor(rot_restriction / coarse_step) + 1, 2 * h1 + 1, 2 * h1 + 1, coarse_step};
+  const int32_t S1 = orc_grid_side(range, low_res);
+  void *grid1 = malloc((size_t)S1 * S1 * cell);
+  if (!grid1) return -2;
+  orc_match m1;
+  int rc = orc_grid_build(pc_b, n_b, &g1, grid1);
+  if (!rc) rc = orc_csm_match(pc_a, n_a, grid1, &g1, theta0, 0, 0, &s1, &m1);
+  free(grid1);
+  if (rc) return rc;
+  const float tx1 = (float)((double)(m1.ix - h1) * low_res);
+  const float ty1 = (float)((double)(m1.iy - h1) * low_res);
+  const float th1 = (float)(theta0 + (double)(m1.itheta - (s1.n_theta - 1) / 2) * coarse_step);
+  /* level 2 */
+  const int32_t ratio = (int32_t)lround(low_res / high_res);
+  const int32_t ox = (int32_t)lround((double)tx1 / high_res), oy = (int32_t)lround((double)ty1 / high_res);
+  orc_grid_spec g2 = {range, high_res, sigma, floor_p, cell_bits, 0};
+  orc_search_spec s2 = {21, 2 * ratio + 1, 2 * ratio + 1, coarse_step / 10.0};
+  const int32_t S2 = orc_grid_side(range, high_res);
+  void *grid2 = malloc((size_t)S2 * S2 * cell);
+  if (!grid2) return -2;
+  orc_match m2;
+  rc = orc_grid_build(pc_b, n_b, &g2, grid2);
+  if (!rc) rc = orc_csm_match(pc_a, n_a, grid2, &g2, (double)th1, ox, oy, &s2, &m2);
+  free(grid2);
+  if (rc) return rc;
+  *score = (double)(float)m2.score; /* the product's record carries the score as float */
+  *tx = (float)((double)(ox + m2.ix - ratio) * high_res);
+  *ty = (float)((double)(oy + m2.iy - ratio) * high_res);
+  *theta = (float)((double)th1 + (double)(m2.itheta - 10) * s2.theta_step);
+  return 0;
 }
 
 int orc_num_threads(void) {

@@ -14,7 +14,8 @@ LIB_PATH = os.path.join(_HERE, "liboracle.so")
 
 
 class GridSpec(C.Structure):
-    _fields_ = [("range", C.c_double), ("res", C.c_double), ("sigma", C.c_double), ("floor_p", C.c_double)]
+    _fields_ = [("range", C.c_double), ("res", C.c_double), ("sigma", C.c_double), ("floor_p", C.c_double),
+                ("cell_bits", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SearchSpec(C.Structure):
@@ -28,6 +29,7 @@ class OMatch(C.Structure):
 
 OMATCH_DTYPE = np.dtype([("itheta", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("sum", "<i4"), ("score", "<f8")])
 assert OMATCH_DTYPE.itemsize == C.sizeof(OMatch)
+OMATCH_F64_DTYPE = np.dtype([("itheta", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("pad", "<i4"), ("score", "<f8")])
 
 _lib = None
 _vp, _i32, _f64 = C.c_void_p, C.c_int32, C.c_double
@@ -59,6 +61,14 @@ def load():
                                         C.POINTER(SearchSpec), _vp, _i32]
     lib.orc_grid_build_batch.argtypes = [_vp, _vp, _vp, _i32, C.POINTER(GridSpec), _vp, _i32]
     lib.orc_num_threads.restype = C.c_int
+    lib.orc_grid_build_f64.argtypes = [_vp, _i32, C.POINTER(GridSpec), _vp]
+    lib.orc_csm_match_f64.argtypes = [_vp, _i32, _vp, C.POINTER(GridSpec), _f64, C.POINTER(SearchSpec), _vp, _vp]
+    lib.orc_csm_match_f64_batch.argtypes = [_vp, _vp, _vp, _vp, _vp, _i32, C.POINTER(GridSpec), C.POINTER(SearchSpec),
+                                            _vp, _vp, _vp, _i32]
+    lib.orc_two_level_match.argtypes = [_vp, _i32, _vp, _i32, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _f64,
+                                        _i32, C.POINTER(_f64), C.POINTER(C.c_float), C.POINTER(C.c_float),
+                                        C.POINTER(C.c_float)]
+    lib.orc_lidar_batch_analytic.argtypes = [C.c_int, _vp, _vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _i32]
     lib.orc_dist_to_segment_f.restype = C.c_float
     lib.orc_dist_to_segment_f.argtypes = [C.c_float] * 6
     lib.orc_dist_to_segment_d.restype = _f64
@@ -133,8 +143,12 @@ def _chk(rc, what):
         raise RuntimeError("oracle %s failed: %d" % (what, rc))
 
 
-def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10):
-    return GridSpec(float(range_m), float(res), float(sigma), float(floor_p))
+def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, cell_bits=8):
+    return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(cell_bits), 0)
+
+
+def _cell_dtype(gs):
+    return np.uint16 if gs.cell_bits == 16 else np.uint8
 
 
 def search_spec(n_theta, nx, ny, theta_step):
@@ -148,14 +162,61 @@ def grid_side(gs):
 def grid_build(points, gs):
     pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
     S = grid_side(gs)
-    out = np.zeros((S, S), dtype=np.uint8)
+    out = np.zeros((S, S), dtype=_cell_dtype(gs))
     _chk(load().orc_grid_build(_p(pts), len(pts), C.byref(gs), _p(out)), "grid_build")
     return out
 
 
+def grid_build_f64(points, gs):
+    """Unquantised table of double log-likelihoods (test-only precision reference)."""
+    pts = np.ascontiguousarray(points, dtype=np.float32).reshape(-1, 2)
+    S = grid_side(gs)
+    out = np.zeros((S, S), dtype=np.float64)
+    _chk(load().orc_grid_build_f64(_p(pts), len(pts), C.byref(gs), _p(out)), "grid_build_f64")
+    return out
+
+
+def csm_match_f64(src_points, grid_f64, gs, theta0, ss, want_scores=False):
+    pts = np.ascontiguousarray(src_points, dtype=np.float32).reshape(-1, 2)
+    g = np.ascontiguousarray(grid_f64, dtype=np.float64)
+    out = np.zeros(1, dtype=OMATCH_F64_DTYPE)
+    vol = np.zeros((ss.n_theta, ss.nx, ss.ny)) if want_scores else None
+    _chk(load().orc_csm_match_f64(_p(pts), len(pts), _p(g), C.byref(gs), float(theta0), C.byref(ss), _p(out), _p(vol)),
+         "csm_match_f64")
+    return (out[0], vol) if want_scores else out[0]
+
+
+def csm_match_f64_batch(xy, offsets, pair_src, pair_tgt, theta0, gs, ss, probe=None, n_threads=0):
+    """Unquantised exhaustive match of every pair (its table is built and dropped per pair).  probe: (n, 3)
+    lattice indices (itheta, ix, iy) at which the f64 score is also returned (e.g. a quantised argmax)."""
+    xy = np.ascontiguousarray(xy, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    ps, pt = np.ascontiguousarray(pair_src, dtype=np.int32), np.ascontiguousarray(pair_tgt, dtype=np.int32)
+    th = np.ascontiguousarray(theta0, dtype=np.float64)
+    out = np.zeros(len(ps), dtype=OMATCH_F64_DTYPE)
+    pr = None if probe is None else np.ascontiguousarray(probe, dtype=np.int32).reshape(len(ps), 3)
+    prs = None if probe is None else np.zeros(len(ps))
+    _chk(load().orc_csm_match_f64_batch(_p(xy), _p(offsets), _p(ps), _p(pt), _p(th), len(ps), C.byref(gs), C.byref(ss),
+                                        _p(out), _p(pr), _p(prs), n_threads), "csm_match_f64_batch")
+    return (out, prs) if probe is not None else out
+
+
+def two_level_match(pc_a, pc_b, rot_a, rot_b, rot_restriction, scanner_range=30.0, trans_range=2.0, low_res=0.3,
+                    high_res=0.01, sigma=2.0, floor_p=1e-10, cell_bits=8):
+    """(score, ((tx, ty), theta)) of the reference-shaped single-pair call (solver.cc:633-644)."""
+    a = np.ascontiguousarray(pc_a, dtype=np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(pc_b, dtype=np.float32).reshape(-1, 2)
+    sc, tx, ty, th = C.c_double(0), C.c_float(0), C.c_float(0), C.c_float(0)
+    _chk(load().orc_two_level_match(_p(a), len(a), _p(b), len(b), float(rot_a), float(rot_b), float(rot_restriction),
+                                    float(scanner_range), float(trans_range), float(low_res), float(high_res),
+                                    float(sigma), float(floor_p), int(cell_bits), C.byref(sc), C.byref(tx), C.byref(ty),
+                                    C.byref(th)), "two_level_match")
+    return sc.value, ((np.float32(tx.value), np.float32(ty.value)), np.float32(th.value))
+
+
 def csm_match(src_points, grid, gs, theta0, ss, origin=(0, 0)):
     pts = np.ascontiguousarray(src_points, dtype=np.float32).reshape(-1, 2)
-    g = np.ascontiguousarray(grid, dtype=np.uint8)
+    g = np.ascontiguousarray(grid, dtype=_cell_dtype(gs))
     m = OMatch()
     _chk(load().orc_csm_match(_p(pts), len(pts), _p(g), C.byref(gs), float(theta0), int(origin[0]),
                               int(origin[1]), C.byref(ss), C.byref(m)), "csm_match")
@@ -164,7 +225,7 @@ def csm_match(src_points, grid, gs, theta0, ss, origin=(0, 0)):
 
 def csm_scores(src_points, grid, gs, theta0, ss, origin=(0, 0)):
     pts = np.ascontiguousarray(src_points, dtype=np.float32).reshape(-1, 2)
-    g = np.ascontiguousarray(grid, dtype=np.uint8)
+    g = np.ascontiguousarray(grid, dtype=_cell_dtype(gs))
     out = np.zeros((ss.n_theta, ss.nx, ss.ny), dtype=np.int32)
     _chk(load().orc_csm_scores(_p(pts), len(pts), _p(g), C.byref(gs), float(theta0), int(origin[0]),
                                int(origin[1]), C.byref(ss), _p(out)), "csm_scores")
@@ -176,7 +237,7 @@ def grid_build_batch(xy, offsets, target_ids, gs, n_threads=0):
     offsets = np.ascontiguousarray(offsets, dtype=np.int32)
     target_ids = np.ascontiguousarray(target_ids, dtype=np.int32)
     S = grid_side(gs)
-    out = np.zeros((len(target_ids), S, S), dtype=np.uint8)
+    out = np.zeros((len(target_ids), S, S), dtype=_cell_dtype(gs))
     _chk(load().orc_grid_build_batch(_p(xy), _p(offsets), _p(target_ids), len(target_ids), C.byref(gs),
                                      _p(out), n_threads), "grid_build_batch")
     return out
@@ -185,7 +246,7 @@ def grid_build_batch(xy, offsets, target_ids, gs, n_threads=0):
 def csm_match_batch(xy, offsets, grids, gs, pair_src, pair_slot, theta0, ss, pair_origin=None, n_threads=0):
     xy = np.ascontiguousarray(xy, dtype=np.float32)
     offsets = np.ascontiguousarray(offsets, dtype=np.int32)
-    grids = np.ascontiguousarray(grids, dtype=np.uint8)
+    grids = np.ascontiguousarray(grids, dtype=_cell_dtype(gs))
     pair_src = np.ascontiguousarray(pair_src, dtype=np.int32)
     pair_slot = np.ascontiguousarray(pair_slot, dtype=np.int32)
     theta0 = np.ascontiguousarray(theta0, dtype=np.float64)
@@ -250,7 +311,7 @@ def odometry_block(t_odom, r_odom, tw, rw, pose_i, pose_j, jac=(True, True)):
     return r, j0, j1
 
 
-def lidar_batch(kind, corr, block_offsets, block_src, block_tgt, poses, want_jac=True, n_threads=0):
+def lidar_batch(kind, corr, block_offsets, block_src, block_tgt, poses, want_jac=True, n_threads=0, analytic=False):
     corr = _f32(corr).reshape(-1, 8)
     bo = np.ascontiguousarray(block_offsets, dtype=np.int32)
     bs = np.ascontiguousarray(block_src, dtype=np.int32)
@@ -260,6 +321,6 @@ def lidar_batch(kind, corr, block_offsets, block_src, block_tgt, poses, want_jac
     r = np.zeros(2 * n)
     j0 = np.zeros((2 * n, 3)) if want_jac else None
     j1 = np.zeros((2 * n, 3)) if want_jac else None
-    _chk(load().orc_lidar_batch(kind, _p(corr), _p(bo), _p(bs), _p(bt), len(bs), _p(poses), _p(r), _p(j0),
-                                _p(j1), n_threads), "lidar_batch")
+    fn = load().orc_lidar_batch_analytic if analytic else load().orc_lidar_batch
+    _chk(fn(kind, _p(corr), _p(bo), _p(bs), _p(bt), len(bs), _p(poses), _p(r), _p(j0), _p(j1), n_threads), "lidar_batch")
     return r, j0, j1

@@ -367,6 +367,62 @@ int orc_lidar_batch(int kind, const float *corr, const int32_t *block_offsets,
 
 }  // extern "C"
 
+// Closed-form Jacobians of the two LIDAR functors, for the "residuals analytic (CPU)"
+// baseline of BASELINE.md section 3 and as a second opinion on the autodiff restatement.  With
+// w = R(th_s) p + t_s - t_t, q = R(th_t)^T w, u = R(th_s - th_t) p:
+//   dq/dt_s = R(th_t)^T, dq/dth_s = (-u_y, u_x), dq/dt_t = -R(th_t)^T, dq/dth_t = (q_y, -q_x).
+static void lidar_block_analytic(int kind, const float *c, int n, const double *ps, const double *pt,
+                                 double *res, double *j0, double *j1) {
+  const double cs = std::cos(ps[2]), ss = std::sin(ps[2]), ct = std::cos(pt[2]), st = std::sin(pt[2]);
+  const double cd = cs * ct + ss * st, sd = ss * ct - cs * st;  // cos, sin (th_s - th_t)
+  const double dx = ps[0] - pt[0], dy = ps[1] - pt[1];
+  const double ox = ct * dx + st * dy, oy = -st * dx + ct * dy;  // R(th_t)^T (t_s - t_t)
+  for (int i = 0; i < n; i++) {
+    const float *r = c + 8 * (size_t)i;
+    const double px = r[0], py = r[1], tx = r[2], ty = r[3];
+    const double ux = cd * px - sd * py, uy = sd * px + cd * py;
+    const double qx = ux + ox, qy = uy + oy;
+    // rows of dq/d(source pose) and dq/d(target pose): 2 x 3 each
+    const double qs[2][3] = {{ct, st, -uy}, {-st, ct, ux}};
+    const double qt[2][3] = {{-ct, -st, qy}, {st, -ct, -qx}};
+    if (kind == 1) {
+      res[2 * i] = tx - qx;
+      res[2 * i + 1] = ty - qy;
+      for (int k = 0; k < 3; k++) {
+        if (j0) { j0[6 * i + k] = -qs[0][k]; j0[6 * i + 3 + k] = -qs[1][k]; }
+        if (j1) { j1[6 * i + k] = -qt[0][k]; j1[6 * i + 3 + k] = -qt[1][k]; }
+      }
+    } else {
+      const double snx = r[4], sny = r[5], tnx = r[6], tny = r[7];
+      res[2 * i] = tnx * (qx - tx) + tny * (qy - ty);
+      res[2 * i + 1] = snx * (tx - qx) + sny * (ty - qy);
+      for (int k = 0; k < 3; k++) {
+        if (j0) { j0[6 * i + k] = tnx * qs[0][k] + tny * qs[1][k]; j0[6 * i + 3 + k] = -(snx * qs[0][k] + sny * qs[1][k]); }
+        if (j1) { j1[6 * i + k] = tnx * qt[0][k] + tny * qt[1][k]; j1[6 * i + 3 + k] = -(snx * qt[0][k] + sny * qt[1][k]); }
+      }
+    }
+  }
+}
+
+extern "C" int orc_lidar_batch_analytic(int kind, const float *corr, const int32_t *block_offsets,
+                                        const int32_t *block_src, const int32_t *block_tgt, int32_t n_blocks,
+                                        const double *poses, double *residuals, double *jac_src, double *jac_tgt,
+                                        int32_t n_threads) {
+#ifdef _OPENMP
+  if (n_threads > 0) omp_set_num_threads(n_threads);
+#pragma omp parallel for schedule(dynamic, 4)
+#endif
+  for (int32_t b = 0; b < n_blocks; b++) {
+    const int32_t o = block_offsets[b], n = block_offsets[b + 1] - o;
+    if (n <= 0) continue;
+    lidar_block_analytic(kind, corr + 8 * (size_t)o, n, poses + 3 * (size_t)block_src[b],
+                         poses + 3 * (size_t)block_tgt[b], residuals + 2 * (size_t)o,
+                         jac_src ? jac_src + 6 * (size_t)o : nullptr, jac_tgt ? jac_tgt + 6 * (size_t)o : nullptr);
+  }
+  (void)n_threads;
+  return 0;
+}
+
 // =====================================================================================
 // Correspondence search -- CPU restatement of
 //   Solver::GetPointToPointMatching            src/optimization/solver.cc:132-172

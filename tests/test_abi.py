@@ -46,6 +46,8 @@ def test_grid_layout_follows_cimg_debug():
     assert L.grid_bytes == 1392 * 1392
     assert L.skip_bytes == 48 * 1392 and L.slot_bytes == L.grid_bytes + L.skip_bytes  # 1 bit per row and dword column
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
+    L16 = csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=16))
+    assert L16.cell_bytes == 2 and L16.pitch == 2 * 1392 and L16.rows == 1392 and L16.grid_bytes == 2 * 1392 * 1392
     for (r, res, side) in [(30, 0.3, 200), (30, 0.01, 6000), (10, 0.03, 666)]:
         assert csm.grid_layout(csm.grid_spec(r, res, 2.0, 1e-10, 4)).side == side
 
@@ -76,6 +78,36 @@ def test_threshold_table_reproduces_direct_quantiser():
             V = int(taps[i + R]) * int(taps[j + R])
             q = int(np.searchsorted(thr[1:], V, side="right"))
             assert q == g[20 + i, 20 + j], (i, j, V, q, g[20 + i, 20 + j])
+
+
+def test_threshold_table_16bit_reproduces_direct_quantiser():
+    """The 65536-entry table of the 16-bit cells: thr[k] <= V  <=>  q16(V) >= k, checked against the oracle's direct
+    quantiser on every blur sum a single hit produces and on random sums around the table's entries."""
+    spec = csm.grid_spec(1.0, 0.05, 2.0, 1e-10, 2, cell_bits=16)
+    L = csm.grid_layout(spec)
+    assert L.cell_bytes == 2 and abs(L.score_step + L.score_floor / 65535.0) < 1e-18
+    taps = np.zeros(2 * L.blur_radius + 1, dtype=np.int32)
+    thr = np.zeros(65536, dtype=np.uint32)
+    _lib.check(_lib.load().nhip_grid_tables(C.byref(spec), _lib.ptr(taps), _lib.ptr(thr)))
+    reach = thr[thr != 0xffffffff].astype(np.int64)
+    assert np.all(np.diff(reach) >= 0) and len(reach) > 60000
+    g = O.grid_build(np.array([[0.01, 0.01]], dtype=np.float32), O.grid_spec(1.0, 0.05, 2.0, 1e-10, 16))
+    assert g.dtype == np.uint16
+    R = L.blur_radius
+    for i in range(-R, R + 1):
+        for j in range(-R, R + 1):
+            V = int(taps[i + R]) * int(taps[j + R])
+            q = int(np.searchsorted(thr[1:], V, side="right"))
+            assert q == g[20 + i, 20 + j], (i, j, V, q, g[20 + i, 20 + j])
+    # the entries themselves: q(thr[k]) >= k and q(thr[k] - 1) < k (numpy restatement of the quantiser)
+    K2 = float(L.tap_sum) ** 2
+    Lf = math.log(1e-10)
+
+    def q16(V):
+        v = np.maximum(V.astype(np.float64) / K2, 1e-10)
+        return np.clip(np.floor((np.log(v) - Lf) / (-Lf / 65535.0) + 0.5), 0, 65535)
+    ks = np.nonzero((thr != 0xffffffff) & (thr > 0))[0][::37]
+    assert np.all(q16(thr[ks].astype(np.int64)) >= ks) and np.all(q16(thr[ks].astype(np.int64) - 1) < ks)
 
 
 def test_rot0_and_delta_tables():

@@ -1,0 +1,117 @@
+"""bench.py's multi-GPU plumbing on CPU: the launcher refuses to run on fewer GPUs than asked, and bench's OWN
+sharded step (ShardPlan -> per-rank matcher -> one all-gather -> permutation to the original order,
+bench.run_sharded) is driven over gloo at world size 2 with an injected matcher (the CPU oracle: tests only)."""
+import math
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import bench  # noqa: E402
+from nautilus_amd import sharding, synth  # noqa: E402
+from nautilus_amd.csm import MATCH_DTYPE, pack_scans  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def test_gpus_flag_fails_loudly_without_enough_gpus():
+    """No GPU here: `bench.py --gpus 2` must exit non-zero with a message, never fall back to one rank."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0
+    assert b"--gpus 2" in p.stderr and b"visible" in p.stderr
+    assert b'"metric"' not in p.stdout
+
+
+def test_world_size_mismatch_is_refused():
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300)
+    assert p.returncode != 0 and b"WORLD_SIZE=1" in p.stderr
+
+
+class _OracleMatcher:
+    """Stands in for bench.HipMatcher on CPU: same step() contract (returns this rank's (n_local, 4) int32 records)."""
+
+    def __init__(self, xy, off, shard, gs, ss):
+        idx, src, tgt, th0, ids, slot = shard
+        self.args = (xy, off, ids, src, slot, th0, gs, ss)
+        self.calls = 0
+
+    def step(self):
+        xy, off, ids, src, slot, th0, gs, ss = self.args
+        self.calls += 1
+        out = np.zeros(len(src), dtype=MATCH_DTYPE)
+        if len(src):
+            grids = O.grid_build_batch(xy, off, ids, gs, 1)
+            m = O.csm_match_batch(xy, off, grids, gs, src, slot, th0, ss, None, 1)
+            for f in ("itheta", "ix", "iy"):
+                out[f] = m[f]
+            out["score"] = m["score"].astype(np.float32)
+        return torch.from_numpy(out.view(np.int32).reshape(-1, 4).copy())
+
+
+def _workload():
+    bag = synth.SynthBag(20)
+    xy, off = pack_scans(bag.scans)
+    src, tgt, th0 = bag.sample_pairs(per_target=3, targets=[1, 4, 8, 12, 17], max_dist=3.5, min_sep=1)
+    perm = np.random.default_rng(5).permutation(len(src))  # the global list need not be sorted by target
+    return xy, off, src[perm], tgt[perm], th0[perm]
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        xy, off, src, tgt, th0 = _workload()
+        gs, ss = O.grid_spec(30.0, 0.05, 2.0, 1e-10), O.search_spec(5, 11, 11, math.radians(2))
+        plan = sharding.ShardPlan(src, tgt, th0, world)
+        m = _OracleMatcher(xy, off, plan.shard(rank), gs, ss)
+        elapsed, full = bench.run_sharded(plan, rank, world, "cpu", m, steps=2, warmup=1, dist=dist)
+        q.put((rank, full.numpy().tobytes(), m.calls, elapsed, len(plan.shard(rank)[1])))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_bench_sharded_step_over_gloo_world_2():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len({r[1] for r in res}) == 1, "ranks hold different tables"
+    assert all(r[2] == 3 for r in res), "warm-up + steps = 3 matcher calls per rank"
+    assert res[0][3] == res[1][3] > 0, "elapsed is the max over ranks, identical everywhere"
+    assert res[0][4] + res[1][4] == 15 and min(res[0][4], res[1][4]) >= 6, "pairs are split between the ranks by target"
+    # equal to the unsharded computation in the ORIGINAL (unsorted) pair order
+    xy, off, src, tgt, th0 = _workload()
+    gs, ss = O.grid_spec(30.0, 0.05, 2.0, 1e-10), O.search_spec(5, 11, 11, math.radians(2))
+    one = sharding.ShardPlan(src, tgt, th0, 1)
+    want = one.all_gather(_OracleMatcher(xy, off, one.shard(0), gs, ss).step(), 0)
+    assert res[0][1] == want.numpy().tobytes()
+    got = np.frombuffer(res[0][1], dtype=MATCH_DTYPE)
+    ids = np.unique(tgt)
+    direct = O.csm_match_batch(xy, off, O.grid_build_batch(xy, off, ids, gs), gs, src, np.searchsorted(ids, tgt), th0, ss)
+    assert np.array_equal(got["ix"], direct["ix"]) and np.array_equal(got["itheta"], direct["itheta"])

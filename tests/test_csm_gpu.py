@@ -15,8 +15,9 @@ pytestmark = pytest.mark.gpu
 DEG = math.radians(1.0)
 
 
-def _specs(range_m=30.0, res=0.05, sigma=2.0, max_shift=40):
-    return csm.grid_spec(range_m, res, sigma, 1e-10, max_shift), O.grid_spec(range_m, res, sigma, 1e-10)
+def _specs(range_m=30.0, res=0.05, sigma=2.0, max_shift=40, cell_bits=8):
+    return (csm.grid_spec(range_m, res, sigma, 1e-10, max_shift, cell_bits),
+            O.grid_spec(range_m, res, sigma, 1e-10, cell_bits))
 
 
 def _check_pairs(scans_list, target_ids, pair_src, pair_slot, theta0, spec, ospec, search, origin=None):
@@ -53,6 +54,28 @@ def test_grid_bit_exact_and_border_zero(gpu, small_bag):
         assert not border.any(), "zero border violated"
     grids.close()
     st.close()
+
+
+def test_grid_16bit_cells_bit_exact(gpu, small_bag):
+    """16-bit cells (65535 quantisation steps, 65536-entry threshold table on the device): the stored uint16 image
+    equals the oracle's direct log() quantiser cell for cell; the border stays zero."""
+    for args in ((30.0, 0.05, 2.0, 40), (10.0, 0.03, 1.0, 10), (30.0, 0.3, 2.0, 6)):
+        spec, ospec = _specs(*args, cell_bits=16)
+        st = csm.ScanTable.from_list(small_bag.scans[:10])
+        grids = csm.LikelihoodGrids(st, [2, 7], spec)
+        L = grids.layout
+        assert L.cell_bytes == 2 and L.pitch % 16 == 0 and L.pitch >= 2 * L.rows
+        for slot, sid in enumerate([2, 7]):
+            stored = grids.download(slot)
+            assert stored.dtype == np.uint16
+            want = O.grid_build(small_bag.scans[sid], ospec)
+            assert want.dtype == np.uint16 and want.max() > 50000
+            assert np.array_equal(stored[L.pad:L.pad + L.side, L.pad:L.pad + L.side], want)
+            border = stored[:, :L.rows].copy()
+            border[L.pad:L.pad + L.side, L.pad:L.pad + L.side] = 0
+            assert not border.any(), "zero border violated"
+        grids.close()
+        st.close()
 
 
 @pytest.mark.parametrize("range_m,res,sigma,max_shift", [(30.0, 0.3, 2.0, 6), (10.0, 0.03, 1.0, 10),
