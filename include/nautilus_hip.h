@@ -80,7 +80,13 @@ typedef struct nhip_grid_layout {
                           row) = "stored rows [r, r+21) x dwords [c, c+21*cell_bytes) hold a non-zero cell",
                           so the correlation kernel can leave out window strips that only add zeros (same
                           sums, bit for bit) */
-  int64_t slot_bytes;  /* grid_bytes + skip_bytes: grid t of a buffer starts at byte t*slot_bytes */
+  int64_t slot_bytes;  /* grid_bytes + skip_bytes + pool_bytes: grid t of a buffer starts at byte t*slot_bytes */
+  int64_t pool_bytes;  /* bytes of the max-pooled table stored after the skip map (branch-and-bound bounds):
+                          pool_rows x pool_pitch bytes, entry (i, j) = max of stored cells [8i, 8i+15) x [8j, 8j+15)
+                          (16-bit cells: ceil(max / 257)), so that the sum of pooled entries bounds every score of
+                          an 8 x 8 block of translations from above */
+  int32_t pool_pitch;
+  int32_t pool_rows;
 } nhip_grid_layout_t;
 
 /* Pure host helpers (work without a GPU). */
@@ -103,9 +109,15 @@ typedef struct nhip_search {
   int32_t n_theta;
   int32_t nx;
   int32_t ny;
-  int32_t reserved;
+  int32_t flags;     /* 0, or NHIP_SEARCH_EXHAUSTIVE */
   double theta_step; /* radians */
 } nhip_search_t;
+/* The matcher's result is that of the exhaustive (theta, x, y) search, always.  By default it gets there by
+ * branch and bound: upper bounds of every 8 x 8 block of translations from a max-pooled copy of the table, then
+ * exact sums only for the blocks whose bound reaches the best sum found (indices, sums and scores are identical to
+ * the exhaustive kernel's, bit for bit: tests compare the two).  NHIP_SEARCH_EXHAUSTIVE (or the environment variable
+ * NHIP_CSM_EXHAUSTIVE=1) forces the kernel that performs every add (8-bit cells only). */
+#define NHIP_SEARCH_EXHAUSTIVE 1
 
 /* One result per candidate pair: 16 bytes, the record that is all-gathered across GPUs. */
 typedef struct nhip_match {
@@ -146,7 +158,11 @@ int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_
                        const nhip_search_t *search, uint64_t *d_keys, nhip_match_t *d_out,
                        int32_t *d_sums, void *stream);
 
-/* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy]. */
+/* With NHIP_BNB_STATS=1 in the environment the branch-and-bound matcher counts its work: blocks of 8 x 8
+ * translations whose sums it evaluated exactly, and blocks in all, since the last call (synchronises; resets). */
+int nhip_bnb_stats(uint64_t *evaluated, uint64_t *total);
+
+/* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy] (8-bit cells). */
 int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                         const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
                         const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
@@ -247,6 +263,8 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
 int nhip_grids_free(nhip_grids_t *grids);
 /* copy stored (padded) grid `slot` to host: layout.grid_bytes bytes (uint8 or uint16 cells) */
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
+/* copy the max-pooled table of grid `slot` to host: layout.pool_bytes bytes (pool_rows x pool_pitch) */
+int nhip_grids_download_pool(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 
 /* Batched GetTransformation: theta0[i] = AngleMod(rot_a - rot_b) of pair i;
  * pair_origin: NULL or 2 int32 per pair (search centre in cells). */

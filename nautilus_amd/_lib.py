@@ -13,6 +13,7 @@ LIB_PATH = os.environ.get("NHIP_LIB") or os.path.join(_HERE, "lib", "libnautilus
 
 NHIP_OK, NHIP_ERR_ARG, NHIP_ERR_NODEV, NHIP_ERR_HIP, NHIP_ERR_ALLOC, NHIP_ERR_STATE = 0, -1, -2, -3, -4, -5
 NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1
+NHIP_SEARCH_EXHAUSTIVE = 1
 NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ = 0, 1, 2, 3, 4
 
 
@@ -31,11 +32,12 @@ class GridLayout(C.Structure):
     _fields_ = [("side", C.c_int32), ("pad", C.c_int32), ("pitch", C.c_int32), ("rows", C.c_int32),
                 ("blur_radius", C.c_int32), ("cell_bytes", C.c_int32), ("tap_sum", C.c_int64),
                 ("grid_bytes", C.c_int64), ("score_floor", C.c_double), ("score_step", C.c_double),
-                ("skip_bytes", C.c_int64), ("slot_bytes", C.c_int64)]
+                ("skip_bytes", C.c_int64), ("slot_bytes", C.c_int64), ("pool_bytes", C.c_int64),
+                ("pool_pitch", C.c_int32), ("pool_rows", C.c_int32)]
 
 
 class Search(C.Structure):
-    _fields_ = [("n_theta", C.c_int32), ("nx", C.c_int32), ("ny", C.c_int32), ("reserved", C.c_int32),
+    _fields_ = [("n_theta", C.c_int32), ("nx", C.c_int32), ("ny", C.c_int32), ("flags", C.c_int32),
                 ("theta_step", C.c_double)]
 
 
@@ -64,6 +66,7 @@ PROTOTYPES = {
     "nhip_grid_build_dev": (C.c_int, [_vp, _vp, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
     "nhip_csm_match_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _vp, _vp, _vp, _vp, _vp, _i32,
                                      _P(Search), _vp, _vp, _vp, _vp]),
+    "nhip_bnb_stats": (C.c_int, [_P(C.c_uint64), _P(C.c_uint64)]),
     "nhip_csm_scores_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _i32, _i32, _vp, _vp, _i32, _i32,
                                       _P(Search), _vp, _vp]),
     "nhip_resid_lidar_dev": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp,
@@ -83,6 +86,7 @@ PROTOTYPES = {
     "nhip_grids_build": (C.c_int, [_vp, _vp, _i32, _P(GridSpec), _P(_vp)]),
     "nhip_grids_free": (C.c_int, [_vp]),
     "nhip_grids_download": (C.c_int, [_vp, _i32, _vp]),
+    "nhip_grids_download_pool": (C.c_int, [_vp, _i32, _vp]),
     "nhip_csm_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _P(Search), _vp, _vp]),
     "nhip_csm_scores": (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, _i32, _P(Search), _vp]),
     "nhip_resid_batch_create": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _P(_vp)]),

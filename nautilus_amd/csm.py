@@ -25,8 +25,10 @@ def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, ce
     return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(max_shift), int(cell_bits))
 
 
-def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0)):
-    return Search(int(n_theta), int(nx), int(ny), 0, float(theta_step))
+def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0), exhaustive=False):
+    """exhaustive=True forces the kernel that performs every add; the default (branch and bound) returns the same
+    records bit for bit."""
+    return Search(int(n_theta), int(nx), int(ny), _lib.NHIP_SEARCH_EXHAUSTIVE if exhaustive else 0, float(theta_step))
 
 
 def grid_layout(spec):
@@ -106,6 +108,13 @@ class LikelihoodGrids:
         check(_lib.load().nhip_grids_download(self._h, int(slot), ptr(out)))
         return out.view(np.uint16) if L.cell_bytes == 2 else out
 
+    def pooled(self, slot):
+        """Max-pooled table (pool_rows, pool_pitch) uint8: the branch-and-bound matcher's bounds."""
+        L = self.layout
+        out = np.empty((L.pool_rows, L.pool_pitch), dtype=np.uint8)
+        check(_lib.load().nhip_grids_download_pool(self._h, int(slot), ptr(out)))
+        return out
+
     def interior(self, slot):
         L = self.layout
         return self.download(slot)[L.pad:L.pad + L.side, L.pad:L.pad + L.side]
@@ -134,6 +143,13 @@ def match_pairs(scans, grids, pair_src, pair_slot, theta0, search, pair_origin=N
     check(_lib.load().nhip_csm_match(scans._h, grids._h, ptr(pair_src), ptr(pair_slot), ptr(theta0),
                                      ptr(org), n, C.byref(search), ptr(out), ptr(sums)))
     return out, sums
+
+
+def bnb_stats():
+    """(blocks evaluated exactly, blocks in all) since the last call; needs NHIP_BNB_STATS=1 in the environment."""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    check(_lib.load().nhip_bnb_stats(C.byref(a), C.byref(b)))
+    return a.value, b.value
 
 
 def score_volume(scans, grids, src, slot, theta0, search, origin=(0, 0)):

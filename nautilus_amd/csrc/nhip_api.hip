@@ -57,7 +57,12 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   L->R = (int32_t)ceil(3.0 * spec->sigma);
   L->grid_bytes = (int64_t)L->pitch * (int64_t)(L->S + 2 * L->pad);
   L->skip_bytes = (((int64_t)skip_pitch(L->pitch) * (int64_t)(L->S + 2 * L->pad)) + 15) & ~15ll;
-  L->slot_bytes = L->grid_bytes + L->skip_bytes;
+  // pooled table: one byte per 8 x 8 stored cells, + BNB_MAX_NB rows / + BNB_MAX_NB + 5 columns of zeros so that a
+  // window origin anywhere in the stored image can read its 11 x 16-byte rows without bounds checks
+  L->pool_rows = (L->S + 2 * L->pad + BNB_B - 1) / BNB_B + BNB_MAX_NB + 1;
+  L->pool_pitch = (((L->S + 2 * L->pad + BNB_B - 1) / BNB_B + BNB_MAX_NB + 5) + 15) & ~15;
+  L->pool_bytes = (int64_t)L->pool_rows * L->pool_pitch;
+  L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes;
   L->Lf = log(spec->floor_p);
   L->step = -L->Lf / (double)L->levels;
   // integer taps: round(16384 * g_i / sum g)
@@ -261,6 +266,9 @@ int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out) {
   out->score_step = L.step;
   out->skip_bytes = L.skip_bytes;
   out->slot_bytes = L.slot_bytes;
+  out->pool_bytes = L.pool_bytes;
+  out->pool_pitch = L.pool_pitch;
+  out->pool_rows = L.pool_rows;
   return NHIP_OK;
 }
 
@@ -594,6 +602,14 @@ int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   return NHIP_OK;
 }
 
+int nhip_grids_download_pool(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
+  NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_pool: bad arguments");
+  const GridLayout &L = grids->L;
+  NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes + L.skip_bytes,
+                         (size_t)L.pool_bytes, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
 int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const int32_t *pair_src,
                    const int32_t *pair_slot, const double *theta0, const int32_t *pair_origin,
                    int32_t n_pairs, const nhip_search_t *search, nhip_match_t *out,
@@ -865,6 +881,15 @@ int nhip_allgather_matches(void *comm, const nhip_match_t *d_local, int32_t n_lo
     set_error("allgather_matches: ncclAllGather failed: %s", g_errstr ? g_errstr(st) : "unknown");
     return NHIP_ERR_HIP;
   }
+  return NHIP_OK;
+}
+
+int nhip_bnb_stats(uint64_t *evaluated, uint64_t *total) {
+  unsigned long long v[2];
+  int rc = bnb_stats_read(v);
+  if (rc) return rc;
+  if (evaluated) *evaluated = v[0];
+  if (total) *total = v[1];
   return NHIP_OK;
 }
 

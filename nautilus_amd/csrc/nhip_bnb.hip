@@ -1,0 +1,519 @@
+// nhip_bnb.hip -- K2 + K3 by branch and bound: the argmax (and its sum) of the exhaustive (theta, x, y)
+// correlation, without performing most of its adds.
+//
+// Replaces CorrelativeScanMatcher::GetTransformation (call site src/optimization/solver.cc:633-638), batched
+// over candidate pairs, with exactly the result of csm_correlate_kernel (nhip_csm.hip): maximum integer sum,
+// ties to the smallest linear index (k * nx + ix) * ny + iy.
+//
+// Bound: the plane of translations of one rotation is cut into 8 x 8 blocks (Y, X).  A point whose window origin
+// (top-left lookup cell) is (r, c) reads, for the 64 poses of block (Y, X), stored cells in rows
+// [r + 8Y, r + 8Y + 8) and columns [c + 8X, c + 8X + 8), all inside the 15 x 15 cells that the pooled entry
+// pool[(r >> 3) + Y][(c >> 3) + X] covers (nhip_grid.hip).  So U(k, Y, X) = sum over points of that entry is an
+// upper bound of every sum in the block (16-bit cells: 257 * U, the pool holds ceil(max / 257)).
+// Search: (1) U for all blocks of all rotations -- a gather of 11 x 11 bytes per point and rotation from the
+// LDS-resident pooled table; (2) every wave evaluates its highest-bound block exactly, which gives a lower bound
+// `best` of the optimum; (3) every block with U >= best's sum is evaluated exactly (64 sums, gathered from the
+// stored grid through L2), `best` rising as it goes; blocks with U < best's sum cannot hold the optimum, nor a
+// tie with it, and are never touched.  On the 1081-beam workload ~1 % of the blocks are evaluated.
+//
+// Parallelisation is the transpose of the exhaustive kernel's: LANES ARE POINTS (one point per lane and
+// 64-point chunk), REGISTERS ARE POSES -- byte sums SWAR-packed two per register -- and one transposing
+// reduction (reduce-scatter over the 64 lanes) per rotation / block turns 64 partial sums per pose into one
+// total per lane.  All sums are integers: order-independent, bit-exact against the oracle.
+//
+// One 512-thread workgroup per pair; waves take rotations k = wave, wave + 8, ...; LDS holds the target's
+// pooled table (36 KB at 1200 x 1200) and the bounds (n_theta x 128 dwords).
+#include "nhip_common.h"
+
+namespace nhip {
+
+namespace {
+
+constexpr int BNB_WAVES = 8;
+constexpr int BNB_THREADS = 64 * BNB_WAVES;
+constexpr int NB = BNB_MAX_NB;        // blocks per axis held in registers (11: nx, ny <= 88)
+constexpr int SEG_CHUNKS = 32;        // 64-point chunks between reductions: 32 * 255 * 8 lanes < 65536 (16-bit fields)
+constexpr uint32_t M8 = 0x00ff00ffu;
+
+struct BnbParams {
+  const float2 *xy;
+  const int32_t *offsets;
+  const uint8_t *grids;
+  const int32_t *pair_src;
+  const int32_t *pair_slot;
+  const double *rot0_cs;
+  const double *delta_cs;
+  const int32_t *pair_origin;
+  unsigned long long *keys;
+  unsigned long long *stats;  // optional: [0] blocks evaluated, [1] blocks in all
+  int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
+  int32_t S, pad, pitch, rows, max_shift;
+  int32_t pool_pitch, pool_rows, pairs_per_xcd;
+  int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes;
+  double res, inv_res;
+};
+
+// Window origin (stored-grid row, column of the top-left lookup cell) of point q under rotation (cf, sf): the
+// same arithmetic as window_cell of nhip_csm.hip (spec: DESIGN.md section 3, items 1 and 3).
+__device__ __forceinline__ void window_origin(float2 q, float cf, float sf, const BnbParams &P, int32_t cx, int32_t cy,
+                                              int32_t *prow, int32_t *pcol) {
+  const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
+  const float yr = __fadd_rn(__fmul_rn(sf, q.x), __fmul_rn(cf, q.y));
+  long col = -P.hx - 1, row = -P.hy - 1;  // non-finite points score nothing
+  if ((fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f)) {
+    const long half = P.S / 2;
+    col = half + (long)floor_quotient((double)xr, P.res, P.inv_res) + cx;
+    row = half + (long)floor_quotient((double)yr, P.res, P.inv_res) + cy;
+    col = col < -P.hx - 1 ? -P.hx - 1 : (col > P.S + P.hx ? P.S + P.hx : col);
+    row = row < -P.hy - 1 ? -P.hy - 1 : (row > P.S + P.hy ? P.S + P.hy : row);
+  }
+  *pcol = (int32_t)(col - P.hx + P.pad);
+  *prow = (int32_t)(row - P.hy + P.pad);
+}
+
+__device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
+
+__device__ __forceinline__ unsigned long long shfl_xor_u64b(unsigned long long v, int m) {
+  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  lo = shfl_xor_u32(lo, m);
+  hi = shfl_xor_u32(hi, m);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// One step of a transposing reduction over the lanes: lanes pair up across `mask`; of every two registers the
+// lane keeps the one its own bit selects, adds the partner's copy of the same register, and gives the other away.
+// N registers in, N / 2 out.
+template <int N, int CAP>
+__device__ __forceinline__ void rs_step(uint32_t (&R)[CAP], bool bit, int mask) {
+  static_assert(N <= CAP, "rs_step: more registers than the array holds");
+#pragma unroll
+  for (int i = 0; i < N / 2; i++) {
+    const uint32_t keep = bit ? R[2 * i + 1] : R[2 * i];
+    const uint32_t send = bit ? R[2 * i] : R[2 * i + 1];
+    R[i] = keep + shfl_xor_u32(send, mask);
+  }
+}
+
+// ---- bounds of one rotation ------------------------------------------------------------------------------
+// Returns this lane's two totals of the 128-slot layout: slot v = lane + 64 * i (i = 0, 1) holds packed register
+// r = 32 i + 16 b5 + 8 b4 + 4 b2 + 2 b1 + b0, field b3 (b = bits of the lane) -- see slot_block().
+__device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_t *pool, const float2 *pts, int32_t n_pts,
+                                                float cf, float sf, int32_t cx, int32_t cy, int lane, uint32_t (&tot)[2]) {
+  const int32_t DP = P.pool_pitch;
+  const int32_t zero_a = ((P.rows + BNB_B - 1) / BNB_B) * DP;  // NB + 1 rows of zeros below the pooled image
+  tot[0] = tot[1] = 0u;
+  for (int32_t c0 = 0; c0 < n_pts; c0 += 64 * SEG_CHUNKS) {
+    uint32_t E[NB][3], O[NB][3];  // per block row Y: 12 byte sums = dwords 0..2, even (b0 | b2) and odd (raw, see below)
+#pragma unroll
+    for (int y = 0; y < NB; y++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) E[y][d] = O[y][d] = 0u;
+    const int32_t c1 = min(n_pts, c0 + 64 * SEG_CHUNKS);
+    for (int32_t c = c0; c < c1; c += 64) {
+      int32_t a = zero_a;
+      if (c + lane < n_pts) {
+        int32_t prow, pcol;
+        window_origin(pts[c + lane], cf, sf, P, cx, cy, &prow, &pcol);
+        a = (prow >> 3) * DP + (pcol >> 3);
+      }
+      const uint32_t sh = (uint32_t)(a & 3) * 8u;
+      const uint32_t *q = reinterpret_cast<const uint32_t *>(pool + (a & ~3));
+#pragma unroll
+      for (int y = 0; y < NB; y++) {
+
+        const uint32_t *row = q + (y * DP) / 4;  // DP is a multiple of 16
+        const uint32_t w0 = row[0], w1 = row[1], w2 = row[2], w3 = row[3];
+        const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+        const uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+        // even: b0 | b2 << 16; odd (raw): w >> 8 = b1 + 256 b2 + 65536 b3, repaired after the loop
+        E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
+        E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
+        E[y][2] += n2 & M8; O[y][2] += n2 >> 8;
+      }
+    }
+    // 64 packed registers: R[6 y + d] (y < 10): d < 3 = E[y][d] (X = 4 d, 4 d + 2), d >= 3 = O[y][d - 3] (X = 4 (d - 3) + 1, + 3);
+    // the hi field of O[y][2] is X = 11 (unused): rows 0..2 carry X = 5, 7, 9 of block row 10 there.
+    // R[60..62] = E[10][0..2], R[63] = O[10][0].
+    uint32_t R[64];
+#pragma unroll
+    for (int y = 0; y < NB; y++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) O[y][d] -= (E[y][d] >> 16) << 8;  // now b1 | b3 << 16
+#pragma unroll
+    for (int y = 0; y < 10; y++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) {
+        R[6 * y + d] = E[y][d];
+        R[6 * y + 3 + d] = O[y][d];
+      }
+    R[5] = (O[0][2] & 0xffffu) | (O[10][1] << 16);          // (10, 5)
+    R[11] = (O[1][2] & 0xffffu) | (O[10][1] & 0xffff0000u);  // (10, 7)
+    R[17] = (O[2][2] & 0xffffu) | (O[10][2] << 16);          // (10, 9)
+    R[60] = E[10][0];
+    R[61] = E[10][1];
+    R[62] = E[10][2];
+    R[63] = O[10][0];
+    rs_step<64>(R, lane & 1, 1);
+    rs_step<32>(R, lane & 2, 2);
+    rs_step<16>(R, lane & 4, 4);
+    uint32_t V[16];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      V[2 * i] = R[i] & 0xffffu;
+      V[2 * i + 1] = R[i] >> 16;
+    }
+    rs_step<16>(V, lane & 8, 8);
+    rs_step<8>(V, lane & 16, 16);
+    rs_step<4>(V, lane & 32, 32);
+    tot[0] += V[0];
+    tot[1] += V[1];
+  }
+}
+
+// (block row Y, block column X) of slot v of the 128-slot layout; false for the unused slots.
+__device__ __forceinline__ bool slot_block(int v, int *Y, int *X) {
+  const int lane = v & 63, i = v >> 6;
+  const int r = 32 * i + 16 * ((lane >> 5) & 1) + 8 * ((lane >> 4) & 1) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 1) & 1) + (lane & 1);
+  const int f = (lane >> 3) & 1;
+  if (r >= 60) {
+    *Y = 10;
+    *X = r == 63 ? 1 + 2 * f : 4 * (r - 60) + 2 * f;
+    return true;
+  }
+  const int y = r / 6, d = r % 6;
+  if (d == 5 && f == 1) {  // the relocated values of block row 10
+    *Y = 10;
+    *X = 5 + 2 * y;
+    return y < 3;
+  }
+  *Y = y;
+  *X = d < 3 ? 4 * d + 2 * f : 4 * (d - 3) + 1 + 2 * f;
+  return true;
+}
+
+// ---- exact sums of one 8 x 8 block -----------------------------------------------------------------------
+// Returns the block's best key (sum << 32 | ~linear index) over its valid poses, the same in every lane.
+template <int CB>
+__device__ __forceinline__ unsigned long long eval_block(const BnbParams &P, const uint8_t *grid, const float2 *pts,
+                                                         int32_t n_pts, float cf, float sf, int32_t cx, int32_t cy,
+                                                         int32_t k, int32_t Y, int32_t X, int lane) {
+  uint32_t total = 0u;  // this lane's pose: (dy, dx) below
+  int dy, dx;
+  if (CB == 1) {
+    for (int32_t c0 = 0; c0 < n_pts; c0 += 64 * SEG_CHUNKS) {
+      uint32_t E[8][2], O[8][2];
+#pragma unroll
+      for (int y = 0; y < 8; y++) E[y][0] = E[y][1] = O[y][0] = O[y][1] = 0u;
+      const int32_t c1 = min(n_pts, c0 + 64 * SEG_CHUNKS);
+      for (int32_t c = c0; c < c1; c += 64) {
+        const uint8_t *g = grid;  // lanes without a point read the zero border
+        uint32_t sh = 0u;
+        if (c + lane < n_pts) {
+          int32_t prow, pcol;
+          window_origin(pts[c + lane], cf, sf, P, cx, cy, &prow, &pcol);
+          const int32_t col = pcol + BNB_B * X;
+          g = grid + (size_t)(prow + BNB_B * Y) * P.pitch + (col & ~3);
+          sh = (uint32_t)(col & 3) * 8u;
+        }
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+          const uint32_t *row = reinterpret_cast<const uint32_t *>(g + (size_t)y * P.pitch);
+          const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
+          const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+          E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
+          E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
+        }
+      }
+      uint32_t R[32];  // R[4 y + d]: d = 0: dx 0, 2; 1: dx 1, 3; 2: dx 4, 6; 3: dx 5, 7
+#pragma unroll
+      for (int y = 0; y < 8; y++) {
+        R[4 * y + 0] = E[y][0];
+        R[4 * y + 1] = O[y][0] - ((E[y][0] >> 16) << 8);
+        R[4 * y + 2] = E[y][1];
+        R[4 * y + 3] = O[y][1] - ((E[y][1] >> 16) << 8);
+      }
+      rs_step<32>(R, lane & 1, 1);
+      rs_step<16>(R, lane & 2, 2);
+      rs_step<8>(R, lane & 4, 4);
+      uint32_t V[8];
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        V[2 * i] = R[i] & 0xffffu;
+        V[2 * i + 1] = R[i] >> 16;
+      }
+      rs_step<8>(V, lane & 8, 8);
+      rs_step<4>(V, lane & 16, 16);
+      rs_step<2>(V, lane & 32, 32);
+      total += V[0];
+    }
+    const int r = 8 * (2 * ((lane >> 5) & 1) + ((lane >> 4) & 1)) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 1) & 1) + (lane & 1);
+    const int f = (lane >> 3) & 1, d = r & 3;
+    dy = r >> 2;
+    dx = 4 * (d >> 1) + (d & 1) + 2 * f;
+  } else {
+    uint32_t A[64];  // A[8 y + x]: 32-bit sums (n_pts * 65535 < 2^32 for n_pts <= 65536)
+#pragma unroll
+    for (int i = 0; i < 64; i++) A[i] = 0u;
+    for (int32_t c = 0; c < n_pts; c += 64) {
+      const uint8_t *g = grid;
+      uint32_t sh = 0u;
+      if (c + lane < n_pts) {
+        int32_t prow, pcol;
+        window_origin(pts[c + lane], cf, sf, P, cx, cy, &prow, &pcol);
+        const int32_t col = pcol + BNB_B * X;
+        g = grid + (size_t)(prow + BNB_B * Y) * P.pitch + ((2 * col) & ~3);
+        sh = (uint32_t)(col & 1) * 16u;
+      }
+#pragma unroll
+      for (int y = 0; y < 8; y++) {
+        const uint32_t *row = reinterpret_cast<const uint32_t *>(g + (size_t)y * P.pitch);
+        uint32_t w[5];
+#pragma unroll
+        for (int j = 0; j < 5; j++) w[j] = row[j];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const uint32_t nj = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);
+          A[8 * y + 2 * j] += nj & 0xffffu;
+          A[8 * y + 2 * j + 1] += nj >> 16;
+        }
+      }
+    }
+    rs_step<64>(A, lane & 1, 1);
+    rs_step<32>(A, lane & 2, 2);
+    rs_step<16>(A, lane & 4, 4);
+    rs_step<8>(A, lane & 8, 8);
+    rs_step<4>(A, lane & 16, 16);
+    rs_step<2>(A, lane & 32, 32);
+    total = A[0];  // lane l holds A[l]: bit s of the register index was selected by bit s of the lane
+    dy = lane >> 3;
+    dx = lane & 7;
+  }
+  const int32_t ix = BNB_B * X + dx, iy = BNB_B * Y + dy;
+  unsigned long long key = 0ull;
+  if (ix < P.nx && iy < P.ny) {
+    const uint32_t lin = (uint32_t)((k * P.nx + ix) * P.ny + iy);
+    key = ((unsigned long long)total << 32) | (0xffffffffu - lin);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned long long o = shfl_xor_u64b(key, m);
+    key = o > key ? o : key;
+  }
+  return key;
+}
+
+__device__ __forceinline__ void rotation_k(const BnbParams &P, int32_t pair, int32_t k, float *cf, float *sf) {
+  // R(theta0) * R(delta_k), composed in double with individually rounded ops (as csm_correlate_kernel)
+  const double c0 = P.rot0_cs[2 * pair], s0 = P.rot0_cs[2 * pair + 1];
+  const double cd = P.delta_cs[2 * k], sd = P.delta_cs[2 * k + 1];
+  *cf = __double2float_rn(__dsub_rn(__dmul_rn(c0, cd), __dmul_rn(s0, sd)));
+  *sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
+}
+
+template <int CB>
+__global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
+  extern __shared__ __align__(16) uint8_t smem[];
+  uint8_t *s_pool = smem;                                                       // pool_bytes
+  uint32_t *s_U = reinterpret_cast<uint32_t *>(smem + P.pool_bytes);            // n_theta * 128
+  unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_U + (size_t)P.n_theta * 128);
+  uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_best + 1);
+
+  // block -> pair: the pairs of one target are consecutive; keep them on one XCD (blocks b and b + 8 share one)
+  const uint32_t bid = blockIdx.x;
+  const int32_t pair = (int32_t)((bid & 7u) * (uint32_t)P.pairs_per_xcd + (bid >> 3));
+  if ((int32_t)(bid >> 3) >= P.pairs_per_xcd || pair >= P.n_pairs) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  const int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
+  const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
+  const float2 *pts = P.xy + beg;
+  const uint8_t *grid = P.grids + (size_t)slot * P.slot_bytes;
+  const int32_t cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
+  const int32_t cy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
+  const bool centre_ok = (abs(cx) + P.hx <= P.max_shift) && (abs(cy) + P.hy <= P.max_shift);
+
+  // pose 0 with sum 0 is a lower bound of the optimum (sums are >= 0; if all are 0, pose 0 is the answer)
+  const unsigned long long key0 = 0xffffffffull;
+  if (threadIdx.x == 0) {
+    *s_best = key0;
+    *s_cnt = 0u;
+  }
+  if (!centre_ok || n_pts <= 0) {  // (a centre the stored border cannot cover scores nothing)
+    if (threadIdx.x == 0) P.keys[pair] = key0;
+    return;
+  }
+  {  // the target's pooled table -> LDS
+    const uint4 *gp = reinterpret_cast<const uint4 *>(grid + P.grid_bytes + P.skip_bytes);
+    uint4 *sp = reinterpret_cast<uint4 *>(s_pool);
+    for (int32_t i = threadIdx.x; i < (int32_t)(P.pool_bytes / 16); i += BNB_THREADS) sp[i] = gp[i];
+  }
+  __syncthreads();
+
+  // (1) bounds of every block of every rotation this wave owns; the wave's own best bound
+  const uint32_t scale = CB == 1 ? 1u : 257u;
+  unsigned long long wbest = 0ull;  // (U << 32) | (k << 8 | slot)
+  for (int32_t k = wave; k < P.n_theta; k += BNB_WAVES) {
+    float cf, sf;
+    rotation_k(P, pair, k, &cf, &sf);
+    uint32_t tot[2];
+    coarse_rotation(P, s_pool, pts, n_pts, cf, sf, cx, cy, lane, tot);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      int Y, X;
+      const bool ok = slot_block(lane + 64 * i, &Y, &X) && Y < P.nby && X < P.nbx;
+      const uint32_t u = ok ? tot[i] * scale : 0u;
+      s_U[k * 128 + lane + 64 * i] = u;
+      const unsigned long long cand = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | (lane + 64 * i));
+      wbest = cand > wbest ? cand : wbest;
+    }
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned long long o = shfl_xor_u64b(wbest, m);
+    wbest = o > wbest ? o : wbest;
+  }
+  // (2) seed: the wave's highest-bound block, evaluated exactly
+  uint32_t n_eval = 0u;
+  if ((uint32_t)(wbest >> 32) != 0u) {
+    const int32_t k = (int32_t)((uint32_t)wbest >> 8), v = (int32_t)(wbest & 0xffu);
+    int Y, X;
+    slot_block(v, &Y, &X);
+    float cf, sf;
+    rotation_k(P, pair, k, &cf, &sf);
+    const unsigned long long key = eval_block<CB>(P, grid, pts, n_pts, cf, sf, cx, cy, k, Y, X, lane);
+    if (lane == 0) {
+      atomicMax(s_best, key);
+      s_U[k * 128 + v] = 0u;  // done
+    }
+    n_eval++;
+  }
+  __syncthreads();
+  // (3) every block whose bound reaches the best sum found so far
+  for (int32_t k = wave; k < P.n_theta; k += BNB_WAVES) {
+    float cf = 0.f, sf = 0.f;
+    bool have_rot = false;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const uint32_t u = s_U[k * 128 + lane + 64 * i];
+      uint32_t bsum = (uint32_t)(*(volatile unsigned long long *)s_best >> 32);
+      unsigned long long todo = __ballot(u != 0u && u >= bsum);
+      while (todo) {
+        const int j = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
+        bsum = (uint32_t)(*(volatile unsigned long long *)s_best >> 32);
+        if (uj < bsum) continue;  // the best has risen meanwhile
+        int Y, X;
+        slot_block(j + 64 * i, &Y, &X);
+        if (!have_rot) {
+          rotation_k(P, pair, k, &cf, &sf);
+          have_rot = true;
+        }
+        const unsigned long long key = eval_block<CB>(P, grid, pts, n_pts, cf, sf, cx, cy, k, Y, X, lane);
+        if (lane == 0) atomicMax(s_best, key);
+        n_eval++;
+      }
+    }
+  }
+  if (P.stats && lane == 0) atomicAdd(s_cnt, n_eval);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    P.keys[pair] = *s_best;
+    if (P.stats) {
+      atomicAdd(&P.stats[0], (unsigned long long)*s_cnt);
+      atomicAdd(&P.stats[1], (unsigned long long)(P.n_theta * P.nbx * P.nby));
+    }
+  }
+}
+
+size_t bnb_lds_bytes(const GridLayout &L, const nhip_search_t *search) {
+  return (size_t)L.pool_bytes + (size_t)search->n_theta * 128 * 4 + 16;
+}
+
+}  // namespace
+
+bool bnb_fits(const GridLayout &L, const nhip_search_t *search) {
+  const int nbx = (search->nx + BNB_B - 1) / BNB_B, nby = (search->ny + BNB_B - 1) / BNB_B;
+  // two workgroups per CU when the tables allow it; one workgroup may take the whole 160 KB
+  return nbx <= NB && nby <= NB && bnb_lds_bytes(L, search) <= 160 * 1024 && L.pool_bytes % 16 == 0 &&
+         L.S + 2 * L.pad < 65536 && search->n_theta < (1 << 23);
+}
+
+static unsigned long long *g_bnb_stats = nullptr;  // device counters, allocated on first use when NHIP_BNB_STATS=1
+
+int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                   const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
+                   const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
+                   const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
+                   uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled) {
+  *handled = 0;
+  if (!bnb_fits(L, search)) return NHIP_OK;
+  *handled = 1;
+  if (n_pairs == 0) return NHIP_OK;
+  BnbParams P;
+  memset(&P, 0, sizeof(P));
+  P.xy = reinterpret_cast<const float2 *>(d_xy);
+  P.offsets = d_offsets;
+  P.grids = d_grids;
+  P.pair_src = d_pair_src;
+  P.pair_slot = d_pair_slot;
+  P.rot0_cs = d_rot0_cs;
+  P.delta_cs = d_delta_cs;
+  P.pair_origin = d_pair_origin;
+  P.keys = reinterpret_cast<unsigned long long *>(d_keys);
+  P.n_pairs = n_pairs;
+  P.n_theta = search->n_theta;
+  P.nx = search->nx;
+  P.ny = search->ny;
+  P.hx = (search->nx - 1) / 2;
+  P.hy = (search->ny - 1) / 2;
+  P.nbx = (search->nx + BNB_B - 1) / BNB_B;
+  P.nby = (search->ny + BNB_B - 1) / BNB_B;
+  P.S = L.S;
+  P.pad = L.pad;
+  P.pitch = L.pitch;
+  P.rows = L.S + 2 * L.pad;
+  P.max_shift = spec->max_shift;
+  P.pool_pitch = L.pool_pitch;
+  P.pool_rows = L.pool_rows;
+  P.pairs_per_xcd = (n_pairs + 7) / 8;
+  P.grid_bytes = L.grid_bytes;
+  P.skip_bytes = L.skip_bytes;
+  P.slot_bytes = L.slot_bytes;
+  P.pool_bytes = L.pool_bytes;
+  P.res = spec->res;
+  P.inv_res = 1.0 / spec->res;
+  const char *st = getenv("NHIP_BNB_STATS");
+  if (st && st[0] == '1') {
+    if (!g_bnb_stats) NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_stats), 16));
+    P.stats = g_bnb_stats;
+  }
+  const size_t lds = bnb_lds_bytes(L, search);
+  const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
+  timer_begin(NHIP_TIMER_CSM, s);
+  if (L.cb == 1) {
+    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<1>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(csm_bnb_kernel<1>, dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);
+  } else {
+    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<2>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(csm_bnb_kernel<2>, dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);
+  }
+  timer_end(NHIP_TIMER_CSM, s);
+  NHIP_TRY_HIP(hipGetLastError());
+  launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
+  NHIP_TRY_HIP(hipGetLastError());
+  return NHIP_OK;
+}
+
+// NHIP_BNB_STATS=1: (blocks evaluated exactly, blocks in all) since the last call; resets the counters
+int bnb_stats_read(unsigned long long out[2]) {
+  out[0] = out[1] = 0;
+  if (!g_bnb_stats) return NHIP_OK;
+  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_stats, 16, hipMemcpyDeviceToHost));
+  NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 16));
+  return NHIP_OK;
+}
+
+}  // namespace nhip

@@ -41,9 +41,16 @@ struct GridLayout {
   int64_t K;  // tap sum
   int64_t grid_bytes;  // pitch * rows: the stored image
   int64_t skip_bytes;  // skip_pitch(pitch) * rows rounded up to 16: the skip map that follows the image
-  int64_t slot_bytes;  // grid_bytes + skip_bytes: stride between consecutive grids of a buffer
+  int64_t pool_bytes;  // pool_rows * pool_pitch: the max-pooled table (branch-and-bound bounds) after the skip map
+  int64_t slot_bytes;  // grid_bytes + skip_bytes + pool_bytes: stride between consecutive grids of a buffer
+  int32_t pool_pitch, pool_rows;
   double Lf, step;
 };
+// Branch and bound works on 8 x 8 blocks of translations; a pooled entry covers the 15 x 15 stored cells an 8 x 8
+// block can reach from any window origin with the same (row >> 3, col >> 3).
+constexpr int BNB_B = 8;
+constexpr int BNB_POOL = 2 * BNB_B - 1;
+constexpr int BNB_MAX_NB = 11;  // blocks per axis the kernel's register layout holds: nx, ny <= 88
 // Geometry the skip map shares with the correlation kernel: a wave of csm_correlate_kernel owns
 // CSM_WAVE_ROWS plane rows and reads CSM_ROW_DW aligned dwords of each (nhip_csm.hip).
 constexpr int CSM_WAVE_ROWS = 21;
@@ -97,6 +104,17 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
                      uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s);
+
+// branch-and-bound matcher (nhip_bnb.hip); returns NHIP_ERR_STATE-free: `*handled` = 0 when the lattice does not fit it
+int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                   const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
+                   const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
+                   const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
+                   uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled);
+bool bnb_fits(const GridLayout &L, const nhip_search_t *search);
+int bnb_stats_read(unsigned long long out[2]);
+void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, const int32_t *d_offsets, int32_t n_pairs,
+                         int32_t nx, int32_t ny, const GridLayout &L, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s);
 
 int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                       const nhip_grid_spec_t *spec, const GridLayout &L, int32_t src, int32_t slot,

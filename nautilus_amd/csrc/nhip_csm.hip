@@ -463,7 +463,7 @@ __global__ void csm_finalize_kernel(const unsigned long long *__restrict__ keys,
   if (sums) sums[i] = (int32_t)sum;
 }
 
-int check_search(const nhip_grid_spec_t *spec, const GridLayout &L, const nhip_search_t *search) {
+int check_search(const nhip_grid_spec_t *spec, const GridLayout &L, const nhip_search_t *search, bool exhaustive) {
   NHIP_REQUIRE(search->n_theta >= 1 && (search->n_theta & 1), "search: n_theta must be odd >= 1");
   NHIP_REQUIRE(search->nx >= 1 && (search->nx & 1), "search: nx must be odd >= 1");
   NHIP_REQUIRE(search->ny >= 1 && (search->ny & 1), "search: ny must be odd >= 1");
@@ -475,7 +475,9 @@ int check_search(const nhip_grid_spec_t *spec, const GridLayout &L, const nhip_s
   NHIP_REQUIRE(L.S + 2 * L.pad < 65536, "search: stored grid side %d does not fit 16-bit cell packing",
                L.S + 2 * L.pad);
   NHIP_REQUIRE(L.pitch % 16 == 0, "search: grid pitch must be a multiple of 16");
-  NHIP_REQUIRE(L.cb == 1, "exhaustive correlation kernel: 8-bit cells only (16-bit grids go through the branch-and-bound matcher)");
+  NHIP_REQUIRE(!exhaustive || L.cb == 1,
+               "search: the exhaustive kernel takes 8-bit cells only; 16-bit grids go through the branch-and-bound "
+               "matcher (lattices up to 88 x 88 translations)");
   return NHIP_OK;
 }
 
@@ -505,14 +507,29 @@ void fill_params(CsmParams &P, const nhip_grid_spec_t *spec, const GridLayout &L
 
 }  // namespace
 
+void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, const int32_t *d_offsets, int32_t n_pairs,
+                         int32_t nx, int32_t ny, const GridLayout &L, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s) {
+  hipLaunchKernelGGL(csm_finalize_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s,
+                     reinterpret_cast<const unsigned long long *>(d_keys), d_pair_src, d_offsets, n_pairs, nx, ny, L.Lf,
+                     L.step, d_out, d_sums);
+}
+
 int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
                      uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s) {
-  int rc = check_search(spec, L, search);
+  const char *ex = getenv("NHIP_CSM_EXHAUSTIVE");
+  const bool exhaustive = (search->flags & NHIP_SEARCH_EXHAUSTIVE) || (ex && ex[0] == '1') || !bnb_fits(L, search);
+  int rc = check_search(spec, L, search, exhaustive);
   if (rc) return rc;
   if (n_pairs == 0) return NHIP_OK;
+  if (!exhaustive) {  // branch and bound: the same records, most adds never performed (nhip_bnb.hip)
+    int handled = 0;
+    rc = launch_csm_bnb(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
+                        d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s, &handled);
+    if (rc || handled) return rc;
+  }
   CsmParams P;
   fill_params(P, spec, L, search);
   P.xy = reinterpret_cast<const float2 *>(d_xy);
@@ -547,7 +564,7 @@ int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t
                       const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
                       int32_t origin_y, const nhip_search_t *search, int32_t *d_sums,
                       hipStream_t s) {
-  int rc = check_search(spec, L, search);
+  int rc = check_search(spec, L, search, true);
   if (rc) return rc;
   CsmParams P;
   fill_params(P, spec, L, search);

@@ -262,6 +262,51 @@ __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__rest
   }
 }
 
+// ---- max-pooled table (bounds of the branch-and-bound matcher, nhip_bnb.hip) ---------------------------
+// pool[i][j] = max of the stored cells [8i, 8i + 15) x [8j, 8j + 15) (clipped to the image), one byte: the
+// largest value an 8 x 8 block of translations can read for a point whose window origin has (row >> 3, col >> 3)
+// = (i - Y, j - X).  16-bit cells are scaled to a byte by ceil(max / 257), so 257 * pool >= max.  One block per
+// (pool row, target): vertical max of the 15 stored rows into LDS, then 15-wide horizontal max.  Bands that hold
+// only zeros leave the memset's zeros.
+template <int CB>
+__global__ __launch_bounds__(256) void grid_pool_kernel(uint8_t *__restrict__ grids, int32_t rows, int32_t pitch,
+                                                        int64_t grid_bytes, int64_t skip_bytes, int64_t slot_bytes,
+                                                        int32_t pool_pitch, int32_t t_base) {
+  __shared__ uint32_t sCol[(16384 + 2 * 8208) * 2 / 4 / 4 + 64];  // vertical max, one dword per 4 / CB cells (<= 8208 dwords)
+  const int32_t t = t_base + blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+  const uint8_t *g = grids + (size_t)t * slot_bytes;
+  uint8_t *pool = grids + (size_t)t * slot_bytes + grid_bytes + skip_bytes;
+  const int32_t ndw = pitch / 4;  // dwords per stored row
+  const int32_t r0 = i * BNB_B, r1 = min(r0 + BNB_POOL, rows);
+  int any = 0;
+  for (int32_t c = tid; c < ndw; c += 256) {
+    uint32_t m = 0;
+    for (int32_t r = r0; r < r1; r++) {
+      const uint32_t w = reinterpret_cast<const uint32_t *>(g + (size_t)r * pitch)[c];
+      if (CB == 1) {
+        m = max(m & 0xffu, w & 0xffu) | max(m & 0xff00u, w & 0xff00u) | max(m & 0xff0000u, w & 0xff0000u) |
+            max(m & 0xff000000u, w & 0xff000000u);
+      } else {
+        m = max(m & 0xffffu, w & 0xffffu) | max(m & 0xffff0000u, w & 0xffff0000u);
+      }
+    }
+    sCol[c] = m;
+    any |= (m != 0u);
+  }
+  if (!__syncthreads_or(any)) return;
+  const int32_t cells = rows;                          // stored columns = stored rows (square image)
+  const int32_t nj = (cells + BNB_B - 1) / BNB_B;
+  for (int32_t j = tid; j < nj; j += 256) {
+    uint32_t m = 0;
+    const int32_t c1 = min(j * BNB_B + BNB_POOL, cells);
+    for (int32_t c = j * BNB_B; c < c1; c++) {
+      const uint32_t v = CB == 1 ? (sCol[c >> 2] >> (8 * (c & 3))) & 0xffu : (sCol[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+      m = max(m, v);
+    }
+    if (m) pool[(size_t)i * pool_pitch + j] = (uint8_t)(CB == 1 ? m : (m + 256u) / 257u);
+  }
+}
+
 }  // namespace
 
 int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
@@ -329,6 +374,16 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
       else
         hipLaunchKernelGGL(grid_skipmap_kernel<2>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
                            L.grid_bytes, L.slot_bytes, z0);
+    }
+    for (int32_t z0 = 0; z0 < n; z0 += 65535) {
+      const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
+      const dim3 pg((rows + BNB_B - 1) / BNB_B, nz);
+      if (L.cb == 1)
+        hipLaunchKernelGGL(grid_pool_kernel<1>, pg, dim3(256), 0, s, g, rows, L.pitch, L.grid_bytes, L.skip_bytes,
+                           L.slot_bytes, L.pool_pitch, z0);
+      else
+        hipLaunchKernelGGL(grid_pool_kernel<2>, pg, dim3(256), 0, s, g, rows, L.pitch, L.grid_bytes, L.skip_bytes,
+                           L.slot_bytes, L.pool_pitch, z0);
     }
     timer_end(NHIP_TIMER_GRID, s);
   }

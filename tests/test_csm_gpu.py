@@ -25,6 +25,11 @@ def _check_pairs(scans_list, target_ids, pair_src, pair_slot, theta0, spec, ospe
     st = csm.ScanTable(xy, off)
     grids = csm.LikelihoodGrids(st, target_ids, spec)
     got, sums = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, search, origin)
+    if spec.cell_bits != 16:
+        # the kernel that performs every add and the branch-and-bound matcher return the same records
+        ex = csm.search_spec(search.n_theta, search.nx, search.ny, search.theta_step, exhaustive=True)
+        got_ex, sums_ex = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, ex, origin)
+        assert got_ex.tobytes() == got.tobytes() and np.array_equal(sums_ex, sums)
     ogr = O.grid_build_batch(xy, off, target_ids, ospec)
     oss = O.search_spec(search.n_theta, search.nx, search.ny, search.theta_step)
     want = O.csm_match_batch(xy, off, ogr, ospec, pair_src, pair_slot, theta0, oss, origin)
@@ -452,3 +457,106 @@ def test_zero_strip_skipping_changes_nothing(gpu, small_bag, monkeypatch):
     for f in ("itheta", "ix", "iy"):
         assert np.array_equal(m1[f], want[f])
     grids.close(), st.close()
+
+
+# ---------------------------------------------------------------------------- branch and bound, 16-bit cells
+def _pool_numpy(stored, cell_bits):
+    """pool[i][j] = max of stored[8i : 8i + 15, 8j : 8j + 15] (clipped); 16-bit cells scaled by ceil(max / 257)."""
+    rows = stored.shape[0]
+    n = (rows + 7) // 8
+    out = np.zeros((n, n), dtype=np.int64)
+    for i in range(n):
+        band = stored[8 * i:8 * i + 15, :rows].max(axis=0).astype(np.int64)
+        for j in range(n):
+            out[i, j] = band[8 * j:8 * j + 15].max()
+    return out if cell_bits == 8 else (out + 256) // 257
+
+
+@pytest.mark.parametrize("cell_bits", [8, 16])
+def test_pooled_table_matches_its_definition(gpu, small_bag, cell_bits):
+    spec, _ = _specs(10.0, 0.05, 2.0, 12, cell_bits)
+    st = csm.ScanTable.from_list(small_bag.scans[:4])
+    grids = csm.LikelihoodGrids(st, [1, 3], spec)
+    L = grids.layout
+    for slot in (0, 1):
+        stored = grids.download(slot)[:, :L.rows]
+        pool = grids.pooled(slot)
+        want = _pool_numpy(stored, cell_bits)
+        n = want.shape[0]
+        assert np.array_equal(pool[:n, :n], want) and want.max() >= 250
+        rest = pool.copy()
+        rest[:n, :n] = 0
+        assert not rest.any(), "rows / columns beyond the image must stay zero"
+        if cell_bits == 16:
+            assert np.all(257 * pool[:n, :n].astype(np.int64) >= _pool_numpy(stored, 8))  # 257 * ceil(m / 257) >= m
+    grids.close()
+    st.close()
+
+
+def test_match_16bit_cells_against_oracle(gpu, small_bag):
+    """The 16-bit path end to end (grid, pooled bounds, exact block sums, argmax, score) on several lattices,
+    including search centres and a lattice with partial blocks (21 = 2 * 8 + 5)."""
+    spec, ospec = _specs(max_shift=12, cell_bits=16)
+    src, tgt, th0 = small_bag.sample_pairs(per_target=3, targets=[5, 20, 40], min_sep=2)
+    ids = np.unique(tgt)
+    slot = np.searchsorted(ids, tgt)
+    _check_pairs(small_bag.scans, ids, src, slot, th0, spec, ospec, csm.search_spec(7, 21, 21, 2 * DEG))
+    _check_pairs(small_bag.scans, ids, src, slot, th0, spec, ospec, csm.search_spec(3, 9, 17, 1 * DEG),
+                 origin=np.array([[3, -2]] * len(src), dtype=np.int32))
+    _check_pairs(small_bag.scans, ids, src, slot, th0, spec, ospec, csm.search_spec(1, 1, 1, 1 * DEG))
+
+
+def test_full_lattice_16bit_and_8bit_agree_with_oracle_and_each_other(gpu):
+    """BASELINE config #2 lattice on dense 1081-beam scans, both cell widths bit-exact against their oracles;
+    the branch-and-bound matcher evaluates only a small fraction of the blocks."""
+    import os
+    bag = synth.SynthBag(200, dense=True)
+    src, tgt, th0 = bag.sample_pairs(per_target=3, targets=[30, 90, 150, 199], max_dist=3.5, min_sep=20)
+    ids = np.unique(tgt)
+    slot = np.searchsorted(ids, tgt)
+    search = csm.search_spec(61, 81, 81, DEG)
+    os.environ["NHIP_BNB_STATS"] = "1"
+    try:
+        csm.bnb_stats()
+        for bits in (8, 16):
+            spec, ospec = _specs(cell_bits=bits)
+            _check_pairs(bag.scans, ids, src, slot, th0, spec, ospec, search)
+            ev, tot = csm.bnb_stats()
+            assert tot == len(src) * 61 * 11 * 11
+            assert 0 < ev < 0.1 * tot, "branch and bound evaluated %d of %d blocks" % (ev, tot)
+    finally:
+        os.environ.pop("NHIP_BNB_STATS", None)
+
+
+def test_cell_width_against_unquantised_table(gpu):
+    """How far are the 8- and 16-bit tables from an ideal table of double log-likelihoods (the in-tree evidence for
+    the reference's table is CImg<double>, cimg_debug.h:19)?  On config #2 pairs: 16-bit cells keep every reported
+    score within 1e-5 relative of the unquantised score at the same pose and find the same best pose; 8-bit cells do
+    not meet 1e-5 (documented in DESIGN.md section 3 with these numbers)."""
+    bag = synth.SynthBag(300, dense=True)
+    src, tgt, th0 = bag.sample_pairs(per_target=4, targets=[40, 100, 160, 220, 280], max_dist=3.5, min_sep=20)
+    xy, off = csm.pack_scans(bag.scans)
+    ids = np.unique(tgt)
+    slot = np.searchsorted(ids, tgt)
+    search = csm.search_spec(61, 81, 81, DEG)
+    oss = O.search_spec(61, 81, 81, DEG)
+    st = csm.ScanTable(xy, off)
+    report = {}
+    for bits in (8, 16):
+        spec, ospec = _specs(cell_bits=bits)
+        grids = csm.LikelihoodGrids(st, ids, spec)
+        got, _ = csm.match_pairs(st, grids, src, slot, th0, search)
+        grids.close()
+        probe = np.stack([got["itheta"], got["ix"], got["iy"]], axis=1)
+        ideal, at_probe = O.csm_match_f64_batch(xy, off, src, tgt, th0, ospec, oss, probe=probe)
+        rel = np.abs((got["score"].astype(np.float64) - at_probe) / at_probe)
+        same = (ideal["itheta"] == got["itheta"]) & (ideal["ix"] == got["ix"]) & (ideal["iy"] == got["iy"])
+        # where the quantised argmax differs, the unquantised scores of the two poses are a near-tie
+        gap = np.abs((ideal["score"] - at_probe) / ideal["score"])
+        report[bits] = (float(rel.max()), float(same.mean()), float(gap.max()))
+    st.close()
+    print("cell width vs unquantised table: (max rel score dev, argmax agreement, max rel gap at disagreement)", report)
+    assert report[16][0] < 1e-5 - 5.96e-8 * 0 and report[16][1] == 1.0
+    assert report[16][0] < 2e-6           # float32 record: 6e-8; quantisation: ~3e-7
+    assert report[8][0] < 1e-3 and report[8][2] < 1e-3   # 8-bit: ~1e-4, near-ties only
+    assert report[8][0] > report[16][0]
