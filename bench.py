@@ -137,7 +137,7 @@ class HipMatcher:
     """This rank's shard on the MI355X: device-resident scans, pair list, grids; step() enqueues the
     host trig + K1 + K2/K3 and returns the (n_local, 4) int32 record tensor."""
 
-    def __init__(self, wl, shard, device, cell_bits=8):
+    def __init__(self, wl, shard, device, cell_bits=8, exhaustive=False):
         import torch
         from nautilus_amd import _lib, csm
         self.torch, self._lib, self.lib = torch, _lib, _lib.load()
@@ -145,7 +145,7 @@ class HipMatcher:
         self.n_pairs, self.n_targets = len(src), len(ids)
         self.src, self.slot, self.ids = src, slot, ids
         self.spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=cell_bits)
-        self.search = csm.search_spec(61, 81, 81, math.radians(1.0))
+        self.search = csm.search_spec(61, 81, 81, math.radians(1.0), exhaustive=exhaustive)
         self.layout = csm.grid_layout(self.spec)
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
         self.d_xy, self.d_off = t(wl.xy), t(wl.off)
@@ -264,12 +264,11 @@ def _timer(lib, _lib, tid):
     return ms.value, n.value
 
 
-def onchip_roofline(n_pairs, avg_ms, cell_bits):
-    """What bounds csm_correlate_kernel: it is LDS-resident and VALU-issue bound.  Instruction counts per launch
-    come from rocprofv3's SQ counters on this workload (profiles/traffic.json, per 10k-pair launch, scaled by the
-    pair count); the kernel time is the one measured live in this run."""
-    sq = _traffic("csm_correlate_sq_per_launch_10000pairs_u%d" % cell_bits) or \
-        (_traffic("csm_correlate_sq_per_launch_10000pairs") if cell_bits == 8 else None)
+def onchip_roofline(n_pairs, avg_ms, cell_bits, kernel="bnb"):
+    """What bounds the match kernel (both are cache / LDS resident: HBM traffic is ~1 % of peak): instruction counts
+    per launch come from rocprofv3's SQ counters on this workload (profiles/traffic.json, per 10k-pair launch,
+    scaled by the pair count); the kernel time is the one measured live in this run."""
+    sq = _traffic("csm_%s_sq_per_launch_10000pairs_u%d" % (kernel, cell_bits))
     if not sq:
         return None
     k, secs = n_pairs / 10000.0, avg_ms * 1e-3
@@ -282,6 +281,11 @@ def onchip_roofline(n_pairs, avg_ms, cell_bits):
         out["wave_wait_frac"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
     if "SQ_LDS_BANK_CONFLICT" in sq and "SQ_LDS_IDX_ACTIVE" in sq:
         out["lds_conflict_cycle_frac"] = sq["SQ_LDS_BANK_CONFLICT"] / sq["SQ_LDS_IDX_ACTIVE"]
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in sq:
+        # vector L1: one tag lookup per clock and CU
+        rate = k * sq["TCP_TOTAL_CACHE_ACCESSES_sum"] / secs
+        out["l1_tag_lookups_per_s"] = rate
+        out["l1_tag_frac"] = rate / (256 * 2.4e9)
     return out
 
 
@@ -360,7 +364,11 @@ def worker(a):
     alg_bytes = float(m.n_pairs) * lookups_per_pair * cell_bytes  # per launch of rank 0's shard
     hbm_equiv = alg_bytes / (avg_ms * 1e-3) / 1e9
     oc = onchip_roofline(m.n_pairs, avg_ms, a.cell_bits)
-    traffic = _traffic("csm_correlate_bytes_per_launch_%dpairs_u%d" % (m.n_pairs, a.cell_bits))
+    traffic = _traffic("csm_bnb_bytes_per_launch_%dpairs_u%d" % (m.n_pairs, a.cell_bits))
+    bnb = None
+    if os.environ.get("NHIP_BNB_STATS") == "1":
+        ev, tot = csm.bnb_stats()
+        bnb = {"blocks_evaluated_per_pair": ev / max(m.n_pairs * (a.steps + a.warmup), 1), "fraction_of_blocks": ev / max(tot, 1)}
     L = m.layout
     out = {
         "metric": "loop-closure candidate pairs/sec (1081-beam)",
@@ -383,9 +391,10 @@ def worker(a):
                    "collective": "all_gather 16 B/pair" if world > 1 else "none",
                    "per_rank": [{"pairs": int(r[0]), "targets": int(r[1]), "correlate_ms_per_step": r[2],
                                  "grid_ms_per_step": r[3]} for r in per_rank]},
-        # What binds the dominant kernel (csm_correlate_kernel) is VALU issue: the tile is LDS-resident and the
-        # HBM traffic is ~0.5 % of peak, so the fraction is priced against the vector-instruction peak.
-        "roofline": {"bound": "valu", "kernel": "csm_correlate_kernel", "avg_launch_ms": avg_ms, "launches": k_n,
+        # The dominant kernel (csm_bnb_kernel: bounds from an LDS-resident pooled table, exact sums gathered through
+        # L1/L2) moves ~1 % of the HBM peak; it is priced against the vector-instruction peak, and the L1 tag-lookup
+        # rate that limits its exact-evaluation phase is in onchip_roofline.
+        "roofline": {"bound": "valu", "kernel": "csm_bnb_kernel<%d>" % cell_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
                      "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None, "peak": VALU_PEAK_WAVE_INSTR / 1e12,
                      "unit": "T wave-instr/s", "frac": oc["valu_frac"] if oc else None, "traffic": traffic,
                      "note": "VALU wave64 instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/) / kernel time "
@@ -398,12 +407,13 @@ def worker(a):
                                "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                                "note": "gather-equivalent: lookups x cell bytes / kernel time; hbm_traffic_frac = measured "
                                        "HBM bytes per launch / kernel time / 8 TB/s"},
-        "kernels_ms_per_step": {"csm_correlate": k_ms / a.steps, "grid_blur_and_skipmap": g_ms / a.steps},
+        "kernels_ms_per_step": {"csm_match": k_ms / a.steps, "grid_blur_skipmap_pool": g_ms / a.steps},
         "onchip_roofline": oc,
+        "algorithm": {"name": "branch and bound over 8x8 blocks of translations (max-pooled table bounds), exact: "
+                              "indices, sums and scores identical to the exhaustive kernel's (secondary.exhaustive_u8)",
+                      "stats": bnb},
     }
     legs = world == 1 and a.mode == "weak"
-    if legs:
-        out["zero_skip"] = leg_dense(m, lib, _lib, alg_bytes, got, got_sums)
     if legs and a.cpu_seconds > 0:
         try:
             cb, ok = cpu_baseline(wl, shard, got, got_sums, a.cpu_seconds, a.cell_bits)
@@ -416,6 +426,8 @@ def worker(a):
     if legs and not a.no_resid:
         sec = out["secondary"] = {}
         for name, fn in (("csm_u16" if a.cell_bits == 8 else "csm_u8", lambda: leg_other_cells(wl, shard, dev, a)),
+                         ("exhaustive_u8", lambda: leg_exhaustive(wl, shard, dev, lib, _lib, got if a.cell_bits == 8 else None,
+                                                                  got_sums if a.cell_bits == 8 else None)),
                          ("resid_lidar", lambda: bench_residuals(torch, lib, dev, m.sp, a.cpu_seconds > 0)),):
             try:
                 sec[name] = fn()
@@ -439,33 +451,48 @@ def worker(a):
 
 
 # ------------------------------------------------------------------------------------------ legs
-def leg_dense(m, lib, _lib, alg_bytes, got, got_sums):
-    """The same steps with the skip map ignored (every add of the exhaustive definition performed)."""
-    torch = m.torch
-    try:
-        os.environ["NHIP_CSM_DENSE"] = "1"
-        m.step()
-        torch.cuda.synchronize()
-        lib.nhip_timing_reset()
-        lib.nhip_timing_enable(1)
-        t0 = time.perf_counter()
-        for _ in range(2):
+def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3):
+    """The kernel that performs every add of the exhaustive definition (csm_correlate_kernel: accumulator-stationary,
+    LDS-tiled, SWAR; all-zero window strips left out through the skip map), and the same with the skip map ignored.
+    Same records as the headline, bit for bit."""
+    import torch
+    from nautilus_amd import synth
+    m = HipMatcher(wl, shard, dev, 8, exhaustive=True)
+    lookups = 61 * 81 * 81 * synth.N_BEAMS * float(m.n_pairs)
+    out = {}
+    for name, env in (("skip_map", None), ("every_add", "1")):
+        try:
+            if env:
+                os.environ["NHIP_CSM_DENSE"] = env
             m.step()
-        torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 2
-        lib.nhip_timing_enable(0)
-        ms, n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
-        same = bool(np.array_equal(m.d_sums[:m.n_pairs].cpu().numpy(), got_sums) and
-                    m.d_out[:m.n_pairs].cpu().numpy().tobytes() == got.tobytes())
-        return {"dense_value": m.n_pairs / dt, "dense_ms_per_step": 1e3 * dt, "same_result": same,
-                "dense_kernel_ms": ms / max(n, 1),
-                "dense_hbm_equiv_GBps": alg_bytes / (ms / max(n, 1) * 1e-3) / 1e9,
-                "note": "NHIP_CSM_DENSE=1: all-zero window strips are added like any other; `value` "
-                        "leaves them out (skip map built with the grids), results are identical"}
-    finally:
-        os.environ.pop("NHIP_CSM_DENSE", None)
-        m.step()  # leave the default-path result in the buffers
-        torch.cuda.synchronize()
+            torch.cuda.synchronize()
+            lib.nhip_timing_reset()
+            lib.nhip_timing_enable(1)
+            t0 = time.perf_counter()
+            for _ in range(steps):
+                m.step()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / steps
+            lib.nhip_timing_enable(0)
+            ms, n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
+            avg = ms / max(n, 1)
+            r = {"value": m.n_pairs / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "correlate_kernel_ms": avg,
+                 "hbm_equiv_GBps": lookups / (avg * 1e-3) / 1e9}
+            if got is not None:
+                r["same_result_as_headline"] = bool(np.array_equal(m.d_sums[:m.n_pairs].cpu().numpy(), got_sums) and
+                                                    m.d_out[:m.n_pairs].cpu().numpy().tobytes() == got.tobytes())
+            if not env:
+                oc = onchip_roofline(m.n_pairs, avg, 8, "correlate")
+                r["roofline"] = {"bound": "valu", "kernel": "csm_correlate_kernel<false, false>", "avg_launch_ms": avg,
+                                 "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None,
+                                 "peak": VALU_PEAK_WAVE_INSTR / 1e12, "unit": "T wave-instr/s",
+                                 "frac": oc["valu_frac"] if oc else None}
+                r["onchip_roofline"] = oc
+            out[name] = r
+        finally:
+            os.environ.pop("NHIP_CSM_DENSE", None)
+    m.free_grids()
+    return out
 
 
 def leg_other_cells(wl, shard, dev, a, steps=3):
@@ -540,10 +567,16 @@ def cpu_baseline(wl, shard, got, got_sums, budget_s, cell_bits):
     O.csm_match_batch(wl.xy, wl.off, g0, ospec, src[:1], np.zeros(1, np.int32), th0[:1], oss, None, 1)
     t_one = time.perf_counter() - t0  # one grid + one pair on one core
     per_target = max(int(np.sum(slot == 0)), 1)
-    t_target = t_one * (1 + per_target) / 2.0
-    per_run = budget_s / 6.5
-    n_targets = int(max(1, (per_run * threads) / max(t_target, 1e-3)))
-    n_targets = max(threads // per_target, n_targets)
+    # size the sample from an all-thread probe (the oracle's rate does not scale linearly with the thread count)
+    n_probe = min(len(ids), max(1, (2 * threads) // per_target))
+    sel = np.nonzero(slot < n_probe)[0]
+    t0 = time.perf_counter()
+    gp = O.grid_build_batch(wl.xy, wl.off, ids[:n_probe], ospec, threads)
+    O.csm_match_batch(wl.xy, wl.off, gp, ospec, src[sel], slot[sel], th0[sel], oss, None, threads)
+    t_probe = time.perf_counter() - t0
+    del gp
+    per_run = budget_s / 7.0
+    n_targets = int(max(n_probe, n_probe * per_run / max(t_probe, 1e-3)))
     n_targets = min(n_targets, len(ids), 400)  # oracle grids are 1.44 / 2.88 MB each, keep host memory small
     sel = np.nonzero(slot < n_targets)[0]
     state = {}
@@ -587,13 +620,13 @@ def bench_drop_in(bag, with_cpu, calls=8):
     res = [m.GetTransformation(*args(i, j)) for i, j in pairs]
     dt = (time.perf_counter() - t0) / calls
     out = {"workload": "%d single-pair calls on dense 1081-beam scans: 181x13x13 lattice on a 200x200 grid, then "
-                       "21x61x61 on a 6000x6000 grid (36 MB built per call)" % calls,
+                       "21x61x61 on a 6000x6000 grid of 16-bit cells (72 MB built per call)" % calls,
            "seconds_per_call": dt, "calls_per_s": 1.0 / dt}
     if with_cpu:
         from oracle import oracle as O
         threads = O.num_threads()
         t0 = time.perf_counter()
-        want = O.two_level_match(*args(*pairs[0]), 30.0, 2.0, 0.3, 0.01)
+        want = O.two_level_match(*args(*pairs[0]), 30.0, 2.0, 0.3, 0.01, cell_bits=16)
         dc = time.perf_counter() - t0
         same = bool(np.float32(res[0][0]) == np.float32(want[0]) and res[0][1][0][0] == want[1][0][0] and
                     res[0][1][0][1] == want[1][0][1] and res[0][1][1] == want[1][1])
@@ -605,7 +638,7 @@ def bench_drop_in(bag, with_cpu, calls=8):
         import concurrent.futures as cf
         t0 = time.perf_counter()
         with cf.ThreadPoolExecutor(k) as ex:
-            list(ex.map(lambda q: O.two_level_match(*args(*pairs[q % calls]), 30.0, 2.0, 0.3, 0.01), range(k)))
+            list(ex.map(lambda q: O.two_level_match(*args(*pairs[q % calls]), 30.0, 2.0, 0.3, 0.01, cell_bits=16), range(k)))
         dk = time.perf_counter() - t0
         out["cpu_baseline_all_threads"] = {"value": k / dk, "unit": "calls/s", "cores": k, "kind": "port",
                                            "sample": "%d concurrent calls (one per thread; ctypes releases the GIL)" % k}

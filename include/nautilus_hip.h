@@ -161,6 +161,8 @@ int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_
 /* With NHIP_BNB_STATS=1 in the environment the branch-and-bound matcher counts its work: blocks of 8 x 8
  * translations whose sums it evaluated exactly, and blocks in all, since the last call (synchronises; resets). */
 int nhip_bnb_stats(uint64_t *evaluated, uint64_t *total);
+/* ... and per pair of the last launch (blocks evaluated exactly), before nhip_bnb_stats resets the totals */
+int nhip_bnb_stats_per_pair(uint64_t *evaluated, int32_t n_pairs);
 
 /* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy] (8-bit cells). */
 int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
@@ -275,6 +277,28 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
 int nhip_csm_scores(const nhip_scans_t *scans, const nhip_grids_t *grids, int32_t src, int32_t slot,
                     double theta0, int32_t origin_x, int32_t origin_y, const nhip_search_t *search,
                     int32_t *out_sums);
+
+/* The reference-shaped single-pair call: CorrelativeScanMatcher(scanner_range, trans_range, low_res, high_res)
+ * .GetTransformation(pc_a, pc_b, rot_a, rot_b, rot_restriction) -> (score, ((tx, ty), theta))
+ * (solver.cc:56, 633-644; the class lives in the absent third_party/csm).  Build-defined search:
+ * exhaustive on the low_res grid over +-trans_range and +-rot_restriction in 1 degree steps, then exhaustive on the
+ * high_res grid over +-low_res around the coarse optimum in 0.1 degree steps.  This is the ONE implementation of that
+ * search: the C++ drop-in (adapters/CorrelativeScanMatcher.h) and the Python mirror (nautilus_amd/csm.py) both call it;
+ * oracle/csm_oracle.c restates it independently for the tests.  Host pointers; uploads, builds both grids, matches,
+ * frees.  pc_a / pc_b: n x 2 floats (std::vector<Eigen::Vector2f>). */
+typedef struct nhip_csm_params {
+  double scanner_range; /* ctor arg 1 (30) */
+  double trans_range;   /* ctor arg 2 (2) */
+  double low_res;       /* ctor arg 3 (0.3) */
+  double high_res;      /* ctor arg 4 (0.01) */
+  double sigma;         /* blur sigma in cells (2.0) */
+  double floor_p;       /* likelihood floor (1e-10) */
+  int32_t cell_bits;    /* 8 or 16 (0 = 16: scores within 1e-5 of an unquantised table) */
+  int32_t reserved;
+} nhip_csm_params_t;
+int nhip_csm_get_transformation(const nhip_csm_params_t *params, const float *pc_a, int32_t n_a, const float *pc_b,
+                                int32_t n_b, double rot_a, double rot_b, double rot_restriction, double *score,
+                                float *tx, float *ty, float *theta);
 
 /* Residual batch: all LIDAR residual blocks of one ceres::Problem build (immutable after
  * creation, like the functors' copied vectors, slam_residuals.h:117-120). */

@@ -41,6 +41,12 @@ class Search(C.Structure):
                 ("theta_step", C.c_double)]
 
 
+class CsmParams(C.Structure):
+    _fields_ = [("scanner_range", C.c_double), ("trans_range", C.c_double), ("low_res", C.c_double),
+                ("high_res", C.c_double), ("sigma", C.c_double), ("floor_p", C.c_double), ("cell_bits", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
 class Match(C.Structure):
     _fields_ = [("itheta", C.c_int32), ("ix", C.c_int32), ("iy", C.c_int32), ("score", C.c_float)]
 
@@ -67,6 +73,7 @@ PROTOTYPES = {
     "nhip_csm_match_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _vp, _vp, _vp, _vp, _vp, _i32,
                                      _P(Search), _vp, _vp, _vp, _vp]),
     "nhip_bnb_stats": (C.c_int, [_P(C.c_uint64), _P(C.c_uint64)]),
+    "nhip_bnb_stats_per_pair": (C.c_int, [_vp, _i32]),
     "nhip_csm_scores_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _i32, _i32, _vp, _vp, _i32, _i32,
                                       _P(Search), _vp, _vp]),
     "nhip_resid_lidar_dev": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp,
@@ -89,6 +96,8 @@ PROTOTYPES = {
     "nhip_grids_download_pool": (C.c_int, [_vp, _i32, _vp]),
     "nhip_csm_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _P(Search), _vp, _vp]),
     "nhip_csm_scores": (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, _i32, _P(Search), _vp]),
+    "nhip_csm_get_transformation": (C.c_int, [_P(CsmParams), _vp, _i32, _vp, _i32, _f64, _f64, _f64, _P(_f64),
+                                              _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "nhip_resid_batch_create": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _P(_vp)]),
     "nhip_resid_batch_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "nhip_resid_batch_free": (C.c_int, [_vp]),

@@ -10,8 +10,9 @@
 // Search (build-defined): exhaustive on the low_res grid over
 // +-trans_range and +-rot_restriction (1 degree steps), then exhaustive on the high_res grid over
 // +-low_res around the coarse optimum with 0.1 degree steps -- the coarse-to-fine the ctor's
-// (low_res, high_res) pair implies.  CorrelativeScanMatcherBatch below is the batched form the
-// loop-closure driver should call with the whole candidate-pair list.
+// (low_res, high_res) pair implies; implemented once, in nhip_csm_get_transformation.
+// CorrelativeScanMatcherBatch below is the batched form the loop-closure driver should call with the
+// whole candidate-pair list.
 #ifndef NAUTILUS_HIP_CORRELATIVE_SCAN_MATCHER_H_
 #define NAUTILUS_HIP_CORRELATIVE_SCAN_MATCHER_H_
 
@@ -40,6 +41,12 @@ struct Vec2f {
   float y() const { return v[1]; }
 };
 }  // namespace nautilus_hip
+#endif
+
+// Cell width of the likelihood tables the drop-ins build: 16 keeps scores within 1e-5 of an unquantised table
+// (DESIGN.md section 3); define NAUTILUS_HIP_CELL_BITS=8 for the faster 8-bit tables.
+#ifndef NAUTILUS_HIP_CELL_BITS
+#define NAUTILUS_HIP_CELL_BITS 16
 #endif
 
 namespace nautilus_hip {
@@ -87,47 +94,25 @@ class CorrelativeScanMatcher {
   using Vector2f = nautilus_hip::Vec2f;
 
   CorrelativeScanMatcher(double scanner_range, double trans_range, double low_res, double high_res)
-      : range_(scanner_range), trans_range_(trans_range), low_res_(low_res), high_res_(high_res) {}
+      : params_{scanner_range, trans_range, low_res, high_res, 2.0, 1e-10, NAUTILUS_HIP_CELL_BITS, 0} {}
 
+  // The search is nhip_csm_get_transformation's (the one implementation, behind the C ABI).
   std::pair<double, std::pair<Vector2f, float>> GetTransformation(
       const std::vector<Vector2f> &pointcloud_a, const std::vector<Vector2f> &pointcloud_b,
       double rotation_a, double rotation_b, double rotation_restriction) const {
-    using namespace nautilus_hip;
-    ScansHandle scans({&pointcloud_a, &pointcloud_b});
-    const double theta0 = AngleMod(rotation_a - rotation_b);
-    const double coarse_step = M_PI / 180.0;
-    const int32_t src = 0, slot = 0;
-    // level 1: low_res grid, whole translation range, +-rotation_restriction
-    const int32_t h1 = (int32_t)std::floor(trans_range_ / low_res_);
-    nhip_grid_spec_t spec1 = {range_, low_res_, 2.0, 1e-10, h1, 0};
-    nhip_search_t s1 = {2 * (int32_t)std::floor(rotation_restriction / coarse_step) + 1, 2 * h1 + 1, 2 * h1 + 1, 0,
-                        coarse_step};
-    nhip_match_t m1;
-    {
-      GridsHandle g1(scans, {1}, spec1);
-      Check(nhip_csm_match(scans.h, g1.h, &src, &slot, &theta0, nullptr, 1, &s1, &m1, nullptr), "nhip_csm_match");
-    }
-    float tx1, ty1, th1;
-    Check(nhip_match_to_transform(&m1, &spec1, &s1, theta0, 0, 0, &tx1, &ty1, &th1), "nhip_match_to_transform");
-    // level 2: high_res grid, +-low_res around the coarse optimum, +-1 coarse step in 0.1 steps
-    const int32_t ratio = (int32_t)std::lround(low_res_ / high_res_);
-    const int32_t origin[2] = {(int32_t)std::lround((double)tx1 / high_res_), (int32_t)std::lround((double)ty1 / high_res_)};
-    const int32_t reach = std::max(std::abs(origin[0]), std::abs(origin[1])) + ratio;
-    nhip_grid_spec_t spec2 = {range_, high_res_, 2.0, 1e-10, reach, 0};
-    nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1, 0, coarse_step / 10.0};
-    const double theta1 = th1;
-    nhip_match_t m2;
-    {
-      GridsHandle g2(scans, {1}, spec2);
-      Check(nhip_csm_match(scans.h, g2.h, &src, &slot, &theta1, origin, 1, &s2, &m2, nullptr), "nhip_csm_match");
-    }
+    double score;
     float tx, ty, th;
-    Check(nhip_match_to_transform(&m2, &spec2, &s2, theta1, origin[0], origin[1], &tx, &ty, &th), "nhip_match_to_transform");
-    return {(double)m2.score, {Vector2f(tx, ty), th}};
+    nautilus_hip::Check(
+        nhip_csm_get_transformation(&params_, reinterpret_cast<const float *>(pointcloud_a.data()),
+                                    (int32_t)pointcloud_a.size(), reinterpret_cast<const float *>(pointcloud_b.data()),
+                                    (int32_t)pointcloud_b.size(), rotation_a, rotation_b, rotation_restriction, &score,
+                                    &tx, &ty, &th),
+        "nhip_csm_get_transformation");
+    return {score, {Vector2f(tx, ty), th}};
   }
 
  private:
-  double range_, trans_range_, low_res_, high_res_;
+  nhip_csm_params_t params_;
 };
 
 // Batched form: all scans once, all candidate pairs in one call (what SolveAutoLC's pair list,
@@ -144,7 +129,7 @@ class CorrelativeScanMatcherBatch {
 
   CorrelativeScanMatcherBatch(double scanner_range, double res, const nhip_search_t &search)
       : search_(search) {
-    spec_ = {scanner_range, res, 2.0, 1e-10, std::max(search.nx, search.ny) / 2, 0};
+    spec_ = {scanner_range, res, 2.0, 1e-10, std::max(search.nx, search.ny) / 2, NAUTILUS_HIP_CELL_BITS};
   }
 
   // pairs: (source index, target index) into `clouds`; rotations: world heading of every cloud.

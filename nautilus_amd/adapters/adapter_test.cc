@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -35,7 +36,21 @@ static std::vector<Vec2f> Room(double ox, double oy, double oth) {
     if (!(cond)) { std::printf("FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond); return 1; } \
   } while (0)
 
-int main() {
+static void Dump(const char *dir, const char *name, const std::vector<Vec2f> &pc) {
+  if (!dir) return;
+  const std::string path = std::string(dir) + "/" + name;
+  if (FILE *f = std::fopen(path.c_str(), "wb")) {
+    std::fwrite(pc.data(), sizeof(Vec2f), pc.size(), f);
+    std::fclose(f);
+  }
+}
+
+// argv[1] (optional): directory that receives the point clouds and every matcher result as hex floats, so that
+// tests/test_adapters_gpu.py can compare them with the oracle's restatement float for float.
+int main(int argc, char **argv) {
+  const char *dump = argc > 1 ? argv[1] : nullptr;
+  FILE *results = nullptr;
+  if (dump) results = std::fopen((std::string(dump) + "/results.txt").c_str(), "w");
   int ndev = 0;
   if (nhip_init(&ndev) != NHIP_OK) { std::printf("no GPU: %s\n", nhip_last_error()); return 2; }
   // ---- scan matcher, used exactly as solver.cc:633-644
@@ -48,6 +63,17 @@ int main() {
               th, ax, ay, ath);
   REQUIRE(std::fabs(tx - ax) < 0.03 && std::fabs(ty - ay) < 0.03 && std::fabs(th - ath) < 0.01);
   REQUIRE(trans_pair.first > -8.0 && trans_pair.first <= 0.0);
+  Dump(dump, "pc_a.f32", pc_a);
+  Dump(dump, "pc_b.f32", pc_b);
+  if (results)
+    std::fprintf(results, "get_transformation %a %a %a %a %a %a %a\n", ath + 0.05, 0.0, M_PI / 2, trans_pair.first,
+                 (double)tx, (double)ty, (double)th);
+  {  // a second call with the clouds swapped and a narrower restriction (another lattice shape)
+    auto back = scan_matcher.GetTransformation(pc_b, pc_a, 0.0, ath - 0.02, M_PI / 6);
+    if (results)
+      std::fprintf(results, "get_transformation_swapped %a %a %a %a %a %a %a\n", 0.0, ath - 0.02, M_PI / 6, back.first,
+                   (double)back.second.first(0), (double)back.second.first(1), (double)back.second.second);
+  }
   // batched form, BASELINE lattice
   nhip_search_t search = {61, 81, 81, 0, M_PI / 180.0};
   CorrelativeScanMatcherBatch batch(30.0, 0.05, search);
@@ -56,6 +82,10 @@ int main() {
               res[1].translation(0), res[1].translation(1), res[1].rotation);
   REQUIRE(std::fabs(res[0].translation(0) - ax) <= 0.051 && std::fabs(res[0].translation(1) - ay) <= 0.051);
   REQUIRE(std::fabs(res[0].rotation - ath) <= 0.0176);
+  if (results)
+    for (int i = 0; i < 2; i++)
+      std::fprintf(results, "batch %d %a %a %a %a\n", i, res[i].score, (double)res[i].translation(0),
+                   (double)res[i].translation(1), (double)res[i].rotation);
 
   // ---- residual blocks, used as solver.cc:277-295 + Ceres' evaluation loop would
   auto &B = nautilus_hip::ResidualBatcher::Instance();
@@ -162,6 +192,7 @@ int main() {
     ncclCommDestroy(comm);
     std::printf("allgather of 1000 match records over RCCL (1 rank): ok\n");
   }
+  if (results) std::fclose(results);
   std::printf("ADAPTER_OK\n");
   return 0;
 }

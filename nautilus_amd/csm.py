@@ -170,44 +170,19 @@ def match_to_transform(m, spec, search, theta0, origin=(0, 0)):
 class CorrelativeScanMatcher:
     """Drop-in shape of third_party/csm's class as nautilus uses it (solver.h:18,126; solver.cc:56,633).
 
-    Coarse-to-fine like the ctor's (low_res, high_res) pair implies: an exhaustive search on the
-    low_res grid over +-trans_range / +-rot_restriction, then an exhaustive refinement on the
-    high_res grid around the coarse optimum (build-defined).
-    """
+    The two-level search itself (coarse on the low_res grid, refinement on the high_res grid around the coarse
+    optimum: build-defined) lives behind the C ABI, nhip_csm_get_transformation -- the same
+    entry point the C++ drop-in header calls; nothing is re-derived here."""
 
-    COARSE_THETA_STEP = math.radians(1.0)
-    FINE_THETA_STEPS = 10  # fine rotation step = coarse / 10
-
-    def __init__(self, scanner_range, trans_range, low_res, high_res, sigma=2.0):
-        self.range = float(scanner_range)
-        self.trans_range = float(trans_range)
-        self.low_res = float(low_res)
-        self.high_res = float(high_res)
-        self.sigma = float(sigma)
+    def __init__(self, scanner_range, trans_range, low_res, high_res, sigma=2.0, cell_bits=16):
+        self.params = _lib.CsmParams(float(scanner_range), float(trans_range), float(low_res), float(high_res),
+                                     float(sigma), 1e-10, int(cell_bits), 0)
 
     def GetTransformation(self, pointcloud_a, pointcloud_b, rotation_a, rotation_b, rotation_restriction):
-        scans = ScanTable.from_list([pointcloud_a, pointcloud_b])
-        theta0 = float(angle_mod(np.float64(rotation_a) - np.float64(rotation_b)))
-        # level 1: low_res grid, whole translation range
-        h1 = int(math.floor(self.trans_range / self.low_res))
-        n_th = 2 * int(math.floor(rotation_restriction / self.COARSE_THETA_STEP)) + 1
-        spec1 = grid_spec(self.range, self.low_res, self.sigma, 1e-10, h1)
-        s1 = search_spec(n_th, 2 * h1 + 1, 2 * h1 + 1, self.COARSE_THETA_STEP)
-        g1 = LikelihoodGrids(scans, [1], spec1)
-        m1, _ = match_pairs(scans, g1, [0], [0], [theta0], s1)
-        tx1, ty1, th1 = match_to_transform(m1[0], spec1, s1, theta0)
-        g1.close()
-        # level 2: high_res grid, +-low_res around the coarse optimum, +-1 coarse step in theta
-        ratio = int(round(self.low_res / self.high_res))
-        cx = int(round(float(tx1) / self.high_res))
-        cy = int(round(float(ty1) / self.high_res))
-        h2 = ratio
-        spec2 = grid_spec(self.range, self.high_res, self.sigma, 1e-10, max(abs(cx), abs(cy)) + h2)
-        s2 = search_spec(2 * self.FINE_THETA_STEPS + 1, 2 * h2 + 1, 2 * h2 + 1,
-                         self.COARSE_THETA_STEP / self.FINE_THETA_STEPS)
-        g2 = LikelihoodGrids(scans, [1], spec2)
-        m2, _ = match_pairs(scans, g2, [0], [0], [float(th1)], s2, pair_origin=[[cx, cy]])
-        tx, ty, th = match_to_transform(m2[0], spec2, s2, float(th1), (cx, cy))
-        g2.close()
-        scans.close()
-        return float(m2[0]["score"]), ((tx, ty), th)
+        a = np.ascontiguousarray(pointcloud_a, dtype=np.float32).reshape(-1, 2)
+        b = np.ascontiguousarray(pointcloud_b, dtype=np.float32).reshape(-1, 2)
+        score, tx, ty, th = C.c_double(0), C.c_float(0), C.c_float(0), C.c_float(0)
+        check(_lib.load().nhip_csm_get_transformation(C.byref(self.params), ptr(a), len(a), ptr(b), len(b),
+                                                      float(rotation_a), float(rotation_b), float(rotation_restriction),
+                                                      C.byref(score), C.byref(tx), C.byref(ty), C.byref(th)))
+        return score.value, ((np.float32(tx.value), np.float32(ty.value)), np.float32(th.value))

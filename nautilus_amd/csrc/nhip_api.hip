@@ -2,6 +2,7 @@
 // checking, host-side spec tables, handle objects, in-stream kernel timing.
 #include <dlfcn.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <map>
 #include <mutex>
@@ -684,6 +685,61 @@ int nhip_csm_scores(const nhip_scans_t *scans, const nhip_grids_t *grids, int32_
   return NHIP_OK;
 }
 
+int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, int32_t n_a, const float *pc_b,
+                                int32_t n_b, double rot_a, double rot_b, double rot_restriction, double *score,
+                                float *tx, float *ty, float *theta) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(p && score && tx && ty && theta && n_a >= 0 && n_b >= 0 && (pc_a || n_a == 0) && (pc_b || n_b == 0),
+               "csm_get_transformation: bad arguments");
+  NHIP_REQUIRE(p->low_res > 0 && p->high_res > 0 && p->low_res >= p->high_res && p->trans_range >= 0 && rot_restriction >= 0,
+               "csm_get_transformation: bad search parameters");
+  const int32_t bits = p->cell_bits == 0 ? 16 : p->cell_bits;
+  // scan 0 = A (source), scan 1 = B (target: the lookup table is built from it)
+  std::vector<float> xy(2 * ((size_t)n_a + (size_t)n_b));
+  if (n_a) memcpy(xy.data(), pc_a, sizeof(float) * 2 * (size_t)n_a);
+  if (n_b) memcpy(xy.data() + 2 * (size_t)n_a, pc_b, sizeof(float) * 2 * (size_t)n_b);
+  const int32_t off[3] = {0, n_a, n_a + n_b};
+  nhip_scans_t *scans = nullptr;
+  if ((rc = nhip_scans_upload(xy.data(), off, 2, &scans))) return rc;
+  struct Guard {
+    nhip_scans_t *s;
+    nhip_grids_t *g = nullptr;
+    ~Guard() {
+      if (g) nhip_grids_free(g);
+      nhip_scans_free(s);
+    }
+  } guard{scans};
+  double theta0 = rot_a - rot_b;  // math_util.h:81-89 AngleDiff
+  theta0 -= (2.0 * M_PI) * rint(theta0 / (2.0 * M_PI));
+  const double coarse_step = M_PI / 180.0;
+  const int32_t src = 0, slot = 0, target = 1;
+  // level 1: low_res grid, whole translation range, +-rot_restriction
+  const int32_t h1 = (int32_t)floor(p->trans_range / p->low_res);
+  const nhip_grid_spec_t spec1 = {p->scanner_range, p->low_res, p->sigma, p->floor_p, h1, bits};
+  const nhip_search_t s1 = {2 * (int32_t)floor(rot_restriction / coarse_step) + 1, 2 * h1 + 1, 2 * h1 + 1, 0, coarse_step};
+  nhip_match_t m1;
+  if ((rc = nhip_grids_build(scans, &target, 1, &spec1, &guard.g))) return rc;
+  if ((rc = nhip_csm_match(scans, guard.g, &src, &slot, &theta0, nullptr, 1, &s1, &m1, nullptr))) return rc;
+  nhip_grids_free(guard.g);
+  guard.g = nullptr;
+  float tx1, ty1, th1;
+  if ((rc = nhip_match_to_transform(&m1, &spec1, &s1, theta0, 0, 0, &tx1, &ty1, &th1))) return rc;
+  // level 2: high_res grid, +-low_res around the coarse optimum, +-1 coarse step in 0.1 steps
+  const int32_t ratio = (int32_t)lround(p->low_res / p->high_res);
+  const int32_t origin[2] = {(int32_t)lround((double)tx1 / p->high_res), (int32_t)lround((double)ty1 / p->high_res)};
+  const int32_t reach = std::max(abs(origin[0]), abs(origin[1])) + ratio;
+  const nhip_grid_spec_t spec2 = {p->scanner_range, p->high_res, p->sigma, p->floor_p, reach, bits};
+  const nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1, 0, coarse_step / 10.0};
+  const double theta1 = th1;
+  nhip_match_t m2;
+  if ((rc = nhip_grids_build(scans, &target, 1, &spec2, &guard.g))) return rc;
+  if ((rc = nhip_csm_match(scans, guard.g, &src, &slot, &theta1, origin, 1, &s2, &m2, nullptr))) return rc;
+  if ((rc = nhip_match_to_transform(&m2, &spec2, &s2, theta1, origin[0], origin[1], tx, ty, theta))) return rc;
+  *score = (double)m2.score;
+  return NHIP_OK;
+}
+
 int nhip_resid_batch_create(int kind, const float *corr, const int32_t *block_offsets,
                             const int32_t *block_src, const int32_t *block_tgt, int32_t n_blocks,
                             int32_t n_poses, nhip_resid_batch_t **out) {
@@ -882,6 +938,11 @@ int nhip_allgather_matches(void *comm, const nhip_match_t *d_local, int32_t n_lo
     return NHIP_ERR_HIP;
   }
   return NHIP_OK;
+}
+
+int nhip_bnb_stats_per_pair(uint64_t *evaluated, int32_t n_pairs) {
+  NHIP_REQUIRE(evaluated && n_pairs >= 0, "bnb_stats_per_pair: bad arguments");
+  return bnb_stats_per_pair(reinterpret_cast<unsigned long long *>(evaluated), n_pairs);
 }
 
 int nhip_bnb_stats(uint64_t *evaluated, uint64_t *total) {

@@ -32,8 +32,10 @@ namespace {
 constexpr int BNB_WAVES = 8;
 constexpr int BNB_THREADS = 64 * BNB_WAVES;
 constexpr int NB = BNB_MAX_NB;        // blocks per axis held in registers (11: nx, ny <= 88)
-constexpr int SEG_CHUNKS = 32;        // 64-point chunks between reductions: 32 * 255 * 8 lanes < 65536 (16-bit fields)
+constexpr int SEG_CHUNKS = 32;        // 64-point chunks between reductions: 32 * 255 * 8 lanes < 65536 (16-bit fields); even
+constexpr int QCAP = 1024;            // candidate queue entries per workgroup (overflow is evaluated by the wave that found it)
 constexpr uint32_t M8 = 0x00ff00ffu;
+constexpr int BNB_STATS_PAIRS = 1 << 20;  // per-pair counters kept by NHIP_BNB_STATS=1
 
 struct BnbParams {
   const float2 *xy;
@@ -49,6 +51,7 @@ struct BnbParams {
   int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
   int32_t S, pad, pitch, rows, max_shift;
   int32_t pool_pitch, pool_rows, pairs_per_xcd;
+  int32_t debug;  // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only
   int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes;
   double res, inv_res;
 };
@@ -70,6 +73,13 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
   *pcol = (int32_t)(col - P.hx + P.pad);
   *prow = (int32_t)(row - P.hy + P.pad);
 }
+
+// Rows of the stored grid are read through a buffer descriptor of the pair's grid slot: 12 bytes at a 4-byte-aligned
+// offset in ONE instruction (buffer_load_dwordx3; hipcc splits the same read through a flat pointer into two
+// overlapping 8-byte loads).  Every load instruction costs the L1 one tag lookup per lane and line, and the block
+// evaluation is bound by exactly that.
+typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 
@@ -109,11 +119,14 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
 #pragma unroll
       for (int d = 0; d < 3; d++) E[y][d] = O[y][d] = 0u;
     const int32_t c1 = min(n_pts, c0 + 64 * SEG_CHUNKS);
+    float2 qn = c0 + lane < c1 ? pts[c0 + lane] : make_float2(0.f, 0.f);
     for (int32_t c = c0; c < c1; c += 64) {
+      const float2 pt = qn;
+      if (c + 64 + lane < c1) qn = pts[c + 64 + lane];  // next chunk's point
       int32_t a = zero_a;
       if (c + lane < n_pts) {
         int32_t prow, pcol;
-        window_origin(pts[c + lane], cf, sf, P, cx, cy, &prow, &pcol);
+        window_origin(pt, cf, sf, P, cx, cy, &prow, &pcol);
         a = (prow >> 3) * DP + (pcol >> 3);
       }
       const uint32_t sh = (uint32_t)(a & 3) * 8u;
@@ -199,30 +212,64 @@ __device__ __forceinline__ unsigned long long eval_block(const BnbParams &P, con
                                                          int32_t k, int32_t Y, int32_t X, int lane) {
   uint32_t total = 0u;  // this lane's pose: (dy, dx) below
   int dy, dx;
+  // (stored image + skip map: every offset the evaluation can form lies inside; see nhip_api.hip make_layout)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t *>(grid), 0, (int)(P.grid_bytes + P.skip_bytes < 0x7fffffffll ? P.grid_bytes + P.skip_bytes : 0x7fffffffll),
+      0x00020000);
   if (CB == 1) {
+    // lanes without a point read the zero border (row 0 of the stored image)
+    auto origin = [&](int32_t idx, float2 q, uint32_t *g, uint32_t *sh) {
+      *g = 0u;
+      *sh = 0u;
+      if (idx < n_pts) {
+        int32_t prow, pcol;
+        window_origin(q, cf, sf, P, cx, cy, &prow, &pcol);
+        const int32_t col = pcol + BNB_B * X;
+        *g = (uint32_t)((prow + BNB_B * Y) * P.pitch + (col & ~3));
+        *sh = (uint32_t)(col & 3) * 8u;
+      }
+    };
+    const float2 none = make_float2(0.f, 0.f);
     for (int32_t c0 = 0; c0 < n_pts; c0 += 64 * SEG_CHUNKS) {
       uint32_t E[8][2], O[8][2];
 #pragma unroll
       for (int y = 0; y < 8; y++) E[y][0] = E[y][1] = O[y][0] = O[y][1] = 0u;
       const int32_t c1 = min(n_pts, c0 + 64 * SEG_CHUNKS);
-      for (int32_t c = c0; c < c1; c += 64) {
-        const uint8_t *g = grid;  // lanes without a point read the zero border
-        uint32_t sh = 0u;
-        if (c + lane < n_pts) {
-          int32_t prow, pcol;
-          window_origin(pts[c + lane], cf, sf, P, cx, cy, &prow, &pcol);
-          const int32_t col = pcol + BNB_B * X;
-          g = grid + (size_t)(prow + BNB_B * Y) * P.pitch + (col & ~3);
-          sh = (uint32_t)(col & 3) * 8u;
+      // Two 64-point chunks per iteration, their 16 row loads issued together, and the points of the next
+      // iteration fetched before this one's rows are consumed: the evaluation is bound by the latency of its
+      // dependent loads (point -> window origin -> rows), not by arithmetic.
+      float2 qa = c0 + lane < c1 ? pts[c0 + lane] : none, qb = c0 + 64 + lane < c1 ? pts[c0 + 64 + lane] : none;
+      for (int32_t c = c0; c < c1; c += 128) {
+        const float2 na = c + 128 + lane < c1 ? pts[c + 128 + lane] : none;
+        const float2 nb = c + 192 + lane < c1 ? pts[c + 192 + lane] : none;
+        uint32_t ga, gb, sha, shb;
+        origin(c + lane < c1 ? c + lane : n_pts, qa, &ga, &sha);
+        origin(c + 64 + lane < c1 ? c + 64 + lane : n_pts, qb, &gb, &shb);
+        uint32_t wa[8][3], wb[8][3];
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+          const u32x3 ra = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(ga + (uint32_t)(y * P.pitch)), 0, 0);
+          wa[y][0] = ra.x; wa[y][1] = ra.y; wa[y][2] = ra.z;
         }
 #pragma unroll
         for (int y = 0; y < 8; y++) {
-          const uint32_t *row = reinterpret_cast<const uint32_t *>(g + (size_t)y * P.pitch);
-          const uint32_t w0 = row[0], w1 = row[1], w2 = row[2];
-          const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+          const u32x3 rb = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gb + (uint32_t)(y * P.pitch)), 0, 0);
+          wb[y][0] = rb.x; wb[y][1] = rb.y; wb[y][2] = rb.z;
+        }
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+          const uint32_t n0 = __builtin_amdgcn_alignbit(wa[y][1], wa[y][0], sha), n1 = __builtin_amdgcn_alignbit(wa[y][2], wa[y][1], sha);
           E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
           E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
         }
+#pragma unroll
+        for (int y = 0; y < 8; y++) {
+          const uint32_t n0 = __builtin_amdgcn_alignbit(wb[y][1], wb[y][0], shb), n1 = __builtin_amdgcn_alignbit(wb[y][2], wb[y][1], shb);
+          E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
+          E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
+        }
+        qa = na;
+        qb = nb;
       }
       uint32_t R[32];  // R[4 y + d]: d = 0: dx 0, 2; 1: dx 1, 3; 2: dx 4, 6; 3: dx 5, 7
 #pragma unroll
@@ -254,22 +301,23 @@ __device__ __forceinline__ unsigned long long eval_block(const BnbParams &P, con
     uint32_t A[64];  // A[8 y + x]: 32-bit sums (n_pts * 65535 < 2^32 for n_pts <= 65536)
 #pragma unroll
     for (int i = 0; i < 64; i++) A[i] = 0u;
+    float2 qn = lane < n_pts ? pts[lane] : make_float2(0.f, 0.f);
     for (int32_t c = 0; c < n_pts; c += 64) {
-      const uint8_t *g = grid;
-      uint32_t sh = 0u;
+      const float2 q = qn;
+      if (c + 64 + lane < n_pts) qn = pts[c + 64 + lane];  // next chunk's point: in flight while this one's rows load
+      uint32_t g = 0u, sh = 0u;
       if (c + lane < n_pts) {
         int32_t prow, pcol;
-        window_origin(pts[c + lane], cf, sf, P, cx, cy, &prow, &pcol);
+        window_origin(q, cf, sf, P, cx, cy, &prow, &pcol);
         const int32_t col = pcol + BNB_B * X;
-        g = grid + (size_t)(prow + BNB_B * Y) * P.pitch + ((2 * col) & ~3);
+        g = (uint32_t)((prow + BNB_B * Y) * P.pitch + ((2 * col) & ~3));
         sh = (uint32_t)(col & 1) * 16u;
       }
 #pragma unroll
       for (int y = 0; y < 8; y++) {
-        const uint32_t *row = reinterpret_cast<const uint32_t *>(g + (size_t)y * P.pitch);
-        uint32_t w[5];
-#pragma unroll
-        for (int j = 0; j < 5; j++) w[j] = row[j];
+        const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(g + (uint32_t)(y * P.pitch)), 0, 0);
+        const uint32_t w[5] = {r4.x, r4.y, r4.z, r4.w,
+                               __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(g + (uint32_t)(y * P.pitch) + 16u), 0, 0)};
 #pragma unroll
         for (int j = 0; j < 4; j++) {
           const uint32_t nj = __builtin_amdgcn_alignbit(w[j + 1], w[j], sh);
@@ -315,8 +363,10 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t *s_pool = smem;                                                       // pool_bytes
   uint32_t *s_U = reinterpret_cast<uint32_t *>(smem + P.pool_bytes);            // n_theta * 128
-  unsigned long long *s_best = reinterpret_cast<unsigned long long *>(s_U + (size_t)P.n_theta * 128);
+  unsigned long long *s_queue = reinterpret_cast<unsigned long long *>(s_U + (size_t)P.n_theta * 128);  // QCAP
+  unsigned long long *s_best = s_queue + QCAP;
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_best + 1);
+  uint32_t *s_qn = s_cnt + 1, *s_qhead = s_cnt + 2;
 
   // block -> pair: the pairs of one target are consecutive; keep them on one XCD (blocks b and b + 8 share one)
   const uint32_t bid = blockIdx.x;
@@ -337,6 +387,8 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   if (threadIdx.x == 0) {
     *s_best = key0;
     *s_cnt = 0u;
+    *s_qn = 0u;
+    *s_qhead = 0u;
   }
   if (!centre_ok || n_pts <= 0) {  // (a centre the stored border cannot cover scores nothing)
     if (threadIdx.x == 0) P.keys[pair] = key0;
@@ -374,7 +426,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   }
   // (2) seed: the wave's highest-bound block, evaluated exactly
   uint32_t n_eval = 0u;
-  if ((uint32_t)(wbest >> 32) != 0u) {
+  if ((uint32_t)(wbest >> 32) != 0u && P.debug < 2) {
     const int32_t k = (int32_t)((uint32_t)wbest >> 8), v = (int32_t)(wbest & 0xffu);
     int Y, X;
     slot_block(v, &Y, &X);
@@ -388,31 +440,53 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     n_eval++;
   }
   __syncthreads();
-  // (3) every block whose bound reaches the best sum found so far
-  for (int32_t k = wave; k < P.n_theta; k += BNB_WAVES) {
-    float cf = 0.f, sf = 0.f;
-    bool have_rot = false;
+  // (3) every block whose bound reaches the best sum found so far.  The survivors cluster in a few rotations,
+  // i.e. in a few waves: they go through one queue per workgroup that all eight waves drain.
+  auto evaluate = [&](unsigned long long entry) {
+    const uint32_t u = (uint32_t)(entry >> 32);
+    if (u < (uint32_t)(*(volatile unsigned long long *)s_best >> 32)) return;  // the best has risen meanwhile
+    const int32_t k = (int32_t)((uint32_t)entry >> 8), v = (int32_t)(entry & 0xffu);
+    int Y, X;
+    slot_block(v, &Y, &X);
+    float cf, sf;
+    rotation_k(P, pair, k, &cf, &sf);
+    const unsigned long long key = eval_block<CB>(P, grid, pts, n_pts, cf, sf, cx, cy, k, Y, X, lane);
+    if (lane == 0) atomicMax(s_best, key);
+    n_eval++;
+  };
+  for (int32_t k = wave; k < P.n_theta && P.debug == 0; k += BNB_WAVES) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const uint32_t u = s_U[k * 128 + lane + 64 * i];
-      uint32_t bsum = (uint32_t)(*(volatile unsigned long long *)s_best >> 32);
-      unsigned long long todo = __ballot(u != 0u && u >= bsum);
-      while (todo) {
-        const int j = (int)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const uint32_t uj = (uint32_t)__builtin_amdgcn_readlane((int)u, j);
-        bsum = (uint32_t)(*(volatile unsigned long long *)s_best >> 32);
-        if (uj < bsum) continue;  // the best has risen meanwhile
-        int Y, X;
-        slot_block(j + 64 * i, &Y, &X);
-        if (!have_rot) {
-          rotation_k(P, pair, k, &cf, &sf);
-          have_rot = true;
-        }
-        const unsigned long long key = eval_block<CB>(P, grid, pts, n_pts, cf, sf, cx, cy, k, Y, X, lane);
-        if (lane == 0) atomicMax(s_best, key);
-        n_eval++;
+      const uint32_t bsum = (uint32_t)(*(volatile unsigned long long *)s_best >> 32);
+      const bool cand = u != 0u && u >= bsum;
+      const unsigned long long m = __ballot(cand);
+      if (m == 0ull) continue;
+      uint32_t base = 0u;
+      if (lane == 0) base = atomicAdd(s_qn, (uint32_t)__builtin_popcountll(m));
+      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+      const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+      const unsigned long long entry = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | (lane + 64 * i));
+      if (cand && pos < (uint32_t)QCAP) s_queue[pos] = entry;
+      unsigned long long over = __ballot(cand && pos >= (uint32_t)QCAP);  // queue full: this wave takes them itself
+      while (over) {
+        const int j = (int)__builtin_ctzll(over);
+        over &= over - 1ull;
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)entry, j);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(entry >> 32), j);
+        evaluate(((unsigned long long)hi << 32) | lo);
       }
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t qn = min(*s_qn, (uint32_t)QCAP);
+    while (P.debug == 0) {
+      uint32_t i = 0u;
+      if (lane == 0) i = atomicAdd(s_qhead, 1u);
+      i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+      if (i >= qn) break;
+      evaluate(s_queue[i]);
     }
   }
   if (P.stats && lane == 0) atomicAdd(s_cnt, n_eval);
@@ -422,12 +496,13 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     if (P.stats) {
       atomicAdd(&P.stats[0], (unsigned long long)*s_cnt);
       atomicAdd(&P.stats[1], (unsigned long long)(P.n_theta * P.nbx * P.nby));
+      if (pair < BNB_STATS_PAIRS) P.stats[2 + pair] = *s_cnt;
     }
   }
 }
 
 size_t bnb_lds_bytes(const GridLayout &L, const nhip_search_t *search) {
-  return (size_t)L.pool_bytes + (size_t)search->n_theta * 128 * 4 + 16;
+  return (size_t)L.pool_bytes + (size_t)search->n_theta * 128 * 4 + (size_t)QCAP * 8 + 32;
 }
 
 }  // namespace
@@ -483,9 +558,14 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.pool_bytes = L.pool_bytes;
   P.res = spec->res;
   P.inv_res = 1.0 / spec->res;
+  const char *dbg = getenv("NHIP_BNB_DEBUG");
+  P.debug = dbg ? atoi(dbg) : 0;
   const char *st = getenv("NHIP_BNB_STATS");
   if (st && st[0] == '1') {
-    if (!g_bnb_stats) NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_stats), 16));
+    if (!g_bnb_stats) {
+      NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_stats), 8 * (2 + (size_t)BNB_STATS_PAIRS)));
+      NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 8 * (2 + (size_t)BNB_STATS_PAIRS)));
+    }
     P.stats = g_bnb_stats;
   }
   const size_t lds = bnb_lds_bytes(L, search);
@@ -508,6 +588,12 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
 }
 
 // NHIP_BNB_STATS=1: (blocks evaluated exactly, blocks in all) since the last call; resets the counters
+int bnb_stats_per_pair(unsigned long long *out, int32_t n) {
+  if (!g_bnb_stats || n <= 0) return NHIP_OK;
+  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_stats + 2, 8 * (size_t)(n < BNB_STATS_PAIRS ? n : BNB_STATS_PAIRS), hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
 int bnb_stats_read(unsigned long long out[2]) {
   out[0] = out[1] = 0;
   if (!g_bnb_stats) return NHIP_OK;

@@ -265,45 +265,92 @@ __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__rest
 // ---- max-pooled table (bounds of the branch-and-bound matcher, nhip_bnb.hip) ---------------------------
 // pool[i][j] = max of the stored cells [8i, 8i + 15) x [8j, 8j + 15) (clipped to the image), one byte: the
 // largest value an 8 x 8 block of translations can read for a point whose window origin has (row >> 3, col >> 3)
-// = (i - Y, j - X).  16-bit cells are scaled to a byte by ceil(max / 257), so 257 * pool >= max.  One block per
-// (pool row, target): vertical max of the 15 stored rows into LDS, then 15-wide horizontal max.  Bands that hold
-// only zeros leave the memset's zeros.
+// = (i - Y, j - X).  16-bit cells are scaled to a byte by ceil(max / 257), so 257 * pool >= max.
+// One block per (band of 8 pooled rows, segment of 1024 stored dwords, target): every thread walks the band's
+// 71 stored rows down its dword columns keeping eight running maxima (a stored row feeds at most two pooled
+// rows), the column maxima go to LDS and a 15-cell horizontal max finishes the entries.  Columns whose 64 x 64
+// blur tiles are all unoccupied hold only zeros and are not read (~80 % of a scan's image).
+constexpr int POOL_BAND = 8;                                   // pooled rows per block
+constexpr int POOL_ROWS_IN = POOL_BAND * BNB_B + BNB_POOL - BNB_B;  // 71 stored rows
+constexpr int POOL_SEG_DW = 512;                               // stored dwords per column segment
+constexpr int POOL_HALO_DW = 4;                                // >= 7 cells * 2 bytes / 4
+
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
+  const us2 r = __builtin_elementwise_max(__builtin_bit_cast(us2, a), __builtin_bit_cast(us2, b));
+  return __builtin_bit_cast(uint32_t, r);
+}
+
 template <int CB>
-__global__ __launch_bounds__(256) void grid_pool_kernel(uint8_t *__restrict__ grids, int32_t rows, int32_t pitch,
-                                                        int64_t grid_bytes, int64_t skip_bytes, int64_t slot_bytes,
-                                                        int32_t pool_pitch, int32_t t_base) {
-  __shared__ uint32_t sCol[(16384 + 2 * 8208) * 2 / 4 / 4 + 64];  // vertical max, one dword per 4 / CB cells (<= 8208 dwords)
-  const int32_t t = t_base + blockIdx.y, i = blockIdx.x, tid = threadIdx.x;
+__global__ __launch_bounds__(256) void grid_pool_kernel(const uint8_t *__restrict__ occ, uint8_t *__restrict__ grids,
+                                                        int32_t S, int32_t tiles, int32_t pad, int32_t rows,
+                                                        int32_t pitch, int64_t grid_bytes, int64_t skip_bytes,
+                                                        int64_t slot_bytes, int32_t pool_pitch, int32_t t_base) {
+  // column maxima per pooled row: 8-bit cells as two half-word planes (even bytes, odd bytes), 16-bit cells as is
+  __shared__ uint32_t sM[POOL_BAND][CB == 1 ? 2 : 1][POOL_SEG_DW + POOL_HALO_DW];
+  constexpr int CPD = 4 / CB;  // cells per dword
+  const int32_t t = t_base + blockIdx.z, band = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
   const uint8_t *g = grids + (size_t)t * slot_bytes;
   uint8_t *pool = grids + (size_t)t * slot_bytes + grid_bytes + skip_bytes;
-  const int32_t ndw = pitch / 4;  // dwords per stored row
-  const int32_t r0 = i * BNB_B, r1 = min(r0 + BNB_POOL, rows);
+  const int32_t ndw = pitch / 4;
+  const int32_t dw0 = seg * POOL_SEG_DW, dw1 = min(dw0 + POOL_SEG_DW + POOL_HALO_DW, ndw);
+  const int32_t r0 = band * POOL_BAND * BNB_B;
+  // blur tiles the band's rows can touch
+  const int32_t ty0 = max(r0 - pad, 0) / TILE, ty1 = min(r0 + POOL_ROWS_IN - 1 - pad, S - 1) / TILE;
+  const bool rows_in = r0 + POOL_ROWS_IN - 1 - pad >= 0 && r0 - pad < S;
   int any = 0;
-  for (int32_t c = tid; c < ndw; c += 256) {
-    uint32_t m = 0;
-    for (int32_t r = r0; r < r1; r++) {
-      const uint32_t w = reinterpret_cast<const uint32_t *>(g + (size_t)r * pitch)[c];
-      if (CB == 1) {
-        m = max(m & 0xffu, w & 0xffu) | max(m & 0xff00u, w & 0xff00u) | max(m & 0xff0000u, w & 0xff0000u) |
-            max(m & 0xff000000u, w & 0xff000000u);
-      } else {
-        m = max(m & 0xffffu, w & 0xffffu) | max(m & 0xffff0000u, w & 0xffff0000u);
+  for (int32_t c = dw0 + tid; c < dw1; c += 256) {
+    uint32_t me[POOL_BAND], mo[POOL_BAND];
+#pragma unroll
+    for (int i = 0; i < POOL_BAND; i++) me[i] = mo[i] = 0u;
+    const int32_t rc = c * CPD - pad;  // raster column of the dword's first cell (a dword never straddles tiles)
+    bool live = rows_in && rc >= 0 && rc < S;
+    if (live) {
+      int o = 0;
+      for (int32_t ty = ty0; ty <= ty1; ty++) o |= occ[((size_t)t * tiles + ty) * tiles + rc / TILE];
+      live = o != 0;
+    }
+    if (live) {
+#pragma unroll
+      for (int rr = 0; rr < POOL_ROWS_IN; rr++) {
+        // (rows past the image re-read its last row: zero border)
+        const uint32_t w = reinterpret_cast<const uint32_t *>(g + (size_t)min(r0 + rr, rows - 1) * pitch)[c];
+        const uint32_t we = CB == 1 ? (w & 0x00ff00ffu) : w, wo = CB == 1 ? ((w >> 8) & 0x00ff00ffu) : 0u;
+        // pooled rows i with 8 i <= rr < 8 i + 15
+#pragma unroll
+        for (int i = 0; i < POOL_BAND; i++) {
+          if (BNB_B * i <= rr && rr < BNB_B * i + BNB_POOL) {
+            me[i] = pk_max_u16(me[i], we);
+            if (CB == 1) mo[i] = pk_max_u16(mo[i], wo);
+          }
+        }
       }
     }
-    sCol[c] = m;
-    any |= (m != 0u);
+#pragma unroll
+    for (int i = 0; i < POOL_BAND; i++) {
+      sM[i][0][c - dw0] = me[i];
+      if (CB == 1) sM[i][1][c - dw0] = mo[i];
+      any |= (me[i] | mo[i]) != 0u;
+    }
   }
-  if (!__syncthreads_or(any)) return;
-  const int32_t cells = rows;                          // stored columns = stored rows (square image)
+  if (!__syncthreads_or(any)) return;  // the memset's zeros stand
+  const int32_t cells = rows;          // stored columns = stored rows (square image)
   const int32_t nj = (cells + BNB_B - 1) / BNB_B;
-  for (int32_t j = tid; j < nj; j += 256) {
+  constexpr int JSEG = POOL_SEG_DW * CPD / BNB_B;  // pooled entries per segment
+  const int32_t j0 = seg * JSEG;
+  for (int32_t e = tid; e < POOL_BAND * JSEG; e += 256) {
+    const int32_t i = e / JSEG, j = j0 + e % JSEG;
+    if (j >= nj || band * POOL_BAND + i >= (rows + BNB_B - 1) / BNB_B) continue;
     uint32_t m = 0;
     const int32_t c1 = min(j * BNB_B + BNB_POOL, cells);
     for (int32_t c = j * BNB_B; c < c1; c++) {
-      const uint32_t v = CB == 1 ? (sCol[c >> 2] >> (8 * (c & 3))) & 0xffu : (sCol[c >> 1] >> (16 * (c & 1))) & 0xffffu;
+      const int32_t d = c / CPD - dw0;
+      uint32_t v;
+      if (CB == 1) v = (sM[i][c & 1][d] >> (8 * (c & 2))) & 0xffu;  // byte c&3 of the dword: plane c&1, half-word (c>>1)&1
+      else v = (sM[i][0][d] >> (16 * (c & 1))) & 0xffffu;
       m = max(m, v);
     }
-    if (m) pool[(size_t)i * pool_pitch + j] = (uint8_t)(CB == 1 ? m : (m + 256u) / 257u);
+    if (m) pool[(size_t)(band * POOL_BAND + i) * pool_pitch + j] = (uint8_t)(CB == 1 ? m : (m + 256u) / 257u);
   }
 }
 
@@ -377,13 +424,14 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     }
     for (int32_t z0 = 0; z0 < n; z0 += 65535) {
       const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
-      const dim3 pg((rows + BNB_B - 1) / BNB_B, nz);
+      const int32_t pooled_rows = (rows + BNB_B - 1) / BNB_B;
+      const dim3 pg((pooled_rows + POOL_BAND - 1) / POOL_BAND, (mpitch + POOL_SEG_DW - 1) / POOL_SEG_DW, nz);
       if (L.cb == 1)
-        hipLaunchKernelGGL(grid_pool_kernel<1>, pg, dim3(256), 0, s, g, rows, L.pitch, L.grid_bytes, L.skip_bytes,
-                           L.slot_bytes, L.pool_pitch, z0);
+        hipLaunchKernelGGL(grid_pool_kernel<1>, pg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, rows, L.pitch,
+                           L.grid_bytes, L.skip_bytes, L.slot_bytes, L.pool_pitch, z0);
       else
-        hipLaunchKernelGGL(grid_pool_kernel<2>, pg, dim3(256), 0, s, g, rows, L.pitch, L.grid_bytes, L.skip_bytes,
-                           L.slot_bytes, L.pool_pitch, z0);
+        hipLaunchKernelGGL(grid_pool_kernel<2>, pg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, rows, L.pitch,
+                           L.grid_bytes, L.skip_bytes, L.slot_bytes, L.pool_pitch, z0);
     }
     timer_end(NHIP_TIMER_GRID, s);
   }

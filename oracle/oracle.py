@@ -258,8 +258,15 @@ def csm_match_batch(xy, offsets, grids, gs, pair_src, pair_slot, theta0, ss, pai
     return out
 
 
+_NUM_THREADS = None
+
+
 def num_threads():
-    return load().orc_num_threads()
+    """OpenMP threads available to the oracle (read once: the batch drivers call omp_set_num_threads)."""
+    global _NUM_THREADS
+    if _NUM_THREADS is None:
+        _NUM_THREADS = load().orc_num_threads()
+    return _NUM_THREADS
 
 
 def dist_to_segment_f(p, a, b):

@@ -22,10 +22,45 @@ def test_adapter_headers_mirror_reference_signatures():
 
 
 @pytest.mark.gpu
-def test_adapter_binary_on_gpu(gpu):
+def test_adapter_binary_on_gpu(gpu, tmp_path):
+    """Runs the C++ drop-ins as solver.cc would, then compares what the C++ CorrelativeScanMatcher and
+    CorrelativeScanMatcherBatch returned with the oracle's independent restatement of the same searches on the same
+    point clouds: scores, translations and rotations equal as floats (the C++ host ships the implementation the
+    oracle has seen)."""
+    import math
+    import numpy as np
+    from oracle import oracle as O
     if not os.path.exists(BIN):
         subprocess.check_call(["make", "-C", os.path.dirname(BIN)])
-    p = subprocess.run([BIN], capture_output=True, text=True, timeout=300)
+    p = subprocess.run([BIN, str(tmp_path)], capture_output=True, text=True, timeout=300)
     print(p.stdout, p.stderr)
     assert p.returncode == 0, p.stdout + p.stderr
     assert "ADAPTER_OK" in p.stdout
+    pc = {n: np.fromfile(os.path.join(tmp_path, "pc_%s.f32" % n), dtype=np.float32).reshape(-1, 2) for n in "ab"}
+    assert len(pc["a"]) > 500 and len(pc["b"]) == len(pc["a"])
+    rows = [l.split() for l in open(os.path.join(tmp_path, "results.txt"))]
+    hexf = lambda x: float.fromhex(x)
+    seen = set()
+    for r in rows:
+        if r[0].startswith("get_transformation"):
+            rot_a, rot_b, restrict, score, tx, ty, th = map(hexf, r[1:])
+            a, b = (pc["a"], pc["b"]) if r[0] == "get_transformation" else (pc["b"], pc["a"])
+            want = O.two_level_match(a, b, rot_a, rot_b, restrict, 30.0, 2.0, 0.3, 0.01, cell_bits=16)
+            assert score == want[0] and np.float32(tx) == want[1][0][0] and np.float32(ty) == want[1][0][1]
+            assert np.float32(th) == want[1][1], (r[0], th, want)
+            seen.add(r[0])
+        elif r[0] == "batch":
+            i = int(r[1])
+            score, tx, ty, th = map(hexf, r[2:])
+            # CorrelativeScanMatcherBatch(30, 0.05, {61, 81, 81, 1 deg}): pairs (0 -> 1) and (1 -> 0), headings (ath - 0.03, 0)
+            ath = 0.21
+            src, tgt = (pc["a"], pc["b"]) if i == 0 else (pc["b"], pc["a"])
+            d = (ath - 0.03) if i == 0 else -(ath - 0.03)
+            theta0 = d - 2 * math.pi * round(d / (2 * math.pi))
+            gs, ss = O.grid_spec(30.0, 0.05, 2.0, 1e-10, 16), O.search_spec(61, 81, 81, math.pi / 180.0)
+            m = O.csm_match(src, O.grid_build(tgt, gs), gs, theta0, ss)
+            assert score == float(np.float32(m.score))
+            assert np.float32(tx) == np.float32((m.ix - 40) * 0.05) and np.float32(ty) == np.float32((m.iy - 40) * 0.05)
+            assert np.float32(th) == np.float32(theta0 + (m.itheta - 30) * (math.pi / 180.0))
+            seen.add("batch%d" % i)
+    assert seen == {"get_transformation", "get_transformation_swapped", "batch0", "batch1"}

@@ -10,7 +10,21 @@ def short(n):
     return n[:60]
 
 d = sys.argv[1]
-if "--pmc" in sys.argv:
+if "--per-dispatch" in sys.argv:
+    # one line per dispatch of kernels whose name contains the given substring: counters side by side
+    sub = sys.argv[sys.argv.index("--per-dispatch") + 1]
+    rows = collections.OrderedDict()
+    for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if sub not in r["Kernel_Name"]:
+                continue
+            key = (int(r["Dispatch_Id"]), short(r["Kernel_Name"]))
+            rows.setdefault(key, {})[r["Counter_Name"]] = float(r["Counter_Value"])
+    names = sorted({c for v in rows.values() for c in v})
+    print("dispatch kernel " + " ".join(names))
+    for (did, k), v in sorted(rows.items()):
+        print("%d %s " % (did, k) + " ".join("%.4g" % v.get(c, float("nan")) for c in names))
+elif "--pmc" in sys.argv:
     agg = collections.defaultdict(lambda: collections.defaultdict(float))
     cnt = collections.defaultdict(int)
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
