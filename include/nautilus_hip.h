@@ -308,7 +308,24 @@ int nhip_resid_batch_create(int kind, const float *corr, const int32_t *block_of
 /* poses: n_poses*3 doubles.  residuals: 2*n_corr; jac_src / jac_tgt: 6*n_corr or NULL. */
 int nhip_resid_batch_eval(nhip_resid_batch_t *batch, const double *poses, double *residuals,
                           double *jac_src, double *jac_tgt);
+/* The same evaluation with the target Jacobian in compact form: jac_tgt_theta holds 2 doubles per correspondence,
+ * the theta column of its two rows.  The x and y columns of J_tgt are exactly the negated x and y columns of J_src
+ * (dq/dt_t = -dq/dt_s), so a consumer rebuilds row i as (-J_src[i][0], -J_src[i][1], jac_tgt_theta[i]) while it
+ * copies its slice: 80 instead of 112 bytes per correspondence cross PCIe. */
+int nhip_resid_batch_eval_compact(nhip_resid_batch_t *batch, const double *poses, double *residuals,
+                                  double *jac_src, double *jac_tgt_theta);
+/* ONE block of the batch at explicitly given parameter blocks (source_pose[3], target_pose[3]): what a
+ * ceres::CostFunction::Evaluate() called outside the batched evaluation point needs (Problem::Evaluate,
+ * Covariance::Compute, a rejected trial step).  residuals: 2 n_b doubles; jac_src / jac_tgt: n_b x 2 rows of 3
+ * doubles, either may be NULL. */
+int nhip_resid_batch_eval_block(nhip_resid_batch_t *batch, int32_t block, const double *source_pose,
+                                const double *target_pose, double *residuals, double *jac_src, double *jac_tgt);
 int nhip_resid_batch_free(nhip_resid_batch_t *batch);
+
+/* Page-locked host memory for buffers that cross PCIe every evaluation (device-to-host copies into pinned memory
+ * run at the link rate; into pageable memory at about half of it). */
+int nhip_host_alloc(size_t bytes, void **out);
+int nhip_host_free(void *p);
 
 /* Host-pointer forms of the two small functor families (OdometryResidual, slam_residuals.h:18-40:
  * one block per consecutive pose pair, solver.cc:370-387; PointToLineResidual, :180-200: HITL blocks,

@@ -100,7 +100,11 @@ PROTOTYPES = {
                                               _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "nhip_resid_batch_create": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _P(_vp)]),
     "nhip_resid_batch_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "nhip_resid_batch_eval_compact": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "nhip_resid_batch_eval_block": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "nhip_resid_batch_free": (C.c_int, [_vp]),
+    "nhip_host_alloc": (C.c_int, [C.c_size_t, _P(_vp)]),
+    "nhip_host_free": (C.c_int, [_vp]),
     "nhip_resid_odometry": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _i32, _vp, _vp, _vp]),
     "nhip_resid_point_to_line": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
                                            _vp, _vp, _vp]),

@@ -4,8 +4,10 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <atomic>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -106,12 +108,24 @@ int main(int argc, char **argv) {
   std::vector<double> r(600), j0(1800), j1(1800);
   double *jac[2] = {j0.data(), j1.data()};
   double const *params[2] = {poses[0], poses[1]};
-  REQUIRE(!c0->Evaluate(params, r.data(), jac));  // not prepared: fails loudly, no CPU fallback
-  B.Bind(c0, poses[0], poses[1]);
-  B.Bind(c1, poses[0], poses[1]);
-  B.Bind(c2, poses[2], poses[0]);
+  // No Bind, no PrepareForEvaluation: the block learns its parameter blocks from this call and is evaluated alone on
+  // the GPU at the parameters passed in (what ceres::Problem::Evaluate or Covariance::Compute would trigger).
+  REQUIRE(c0->Evaluate(params, r.data(), jac));
+  REQUIRE(B.slow_path_calls() == 1);
+  const std::vector<double> r_one = r, j0_one = j0, j1_one = j1;
+  {  // the one-line form of solver.cc:280-283 for the other two blocks
+    struct FakeProblem {
+      int added = 0;
+      int AddResidualBlock(nautilus_hip::CostFunctionBase *, void *, double *, double *) { return ++added; }
+    } problem;
+    REQUIRE(nautilus_hip::AddResidualBlock(problem, c1, (void *)nullptr, poses[0], poses[1]) == 1);
+    REQUIRE(nautilus_hip::AddResidualBlock(problem, c2, (void *)nullptr, poses[2], poses[0]) == 2);
+  }
   B.PrepareForEvaluation(true, true);
   REQUIRE(c0->Evaluate(params, r.data(), jac));
+  REQUIRE(B.slow_path_calls() == 1);  // served from the batch
+  // batched (compact target Jacobian rebuilt from J_src) == single-block (full target Jacobian from the kernel), bit for bit
+  REQUIRE(r == r_one && j0 == j0_one && j1 == j1_one);
   // central differences through the same path (residual-only evaluations)
   double maxerr = 0;
   for (int k = 0; k < 3; k++) {
@@ -128,6 +142,51 @@ int main(int argc, char **argv) {
   double *only_tgt[2] = {nullptr, j1.data()};  // constant first block: NULL jacobian (solver.cc:384-386)
   REQUIRE(c1->Evaluate(params, r.data(), only_tgt));
   REQUIRE(std::fabs(r[0] - (tp[0](0) - (std::cos(0.05) * sp[0](0) - std::sin(0.05) * sp[0](1) + 0.1))) < 1e-12);
+  {
+    // Evaluate() at a point OTHER than the prepared one (a rejected trial step, Covariance::Compute): must return the
+    // values AT THAT POINT, not the cached ones.  Reference: prepare at the moved point and compare.
+    const long before = B.slow_path_calls();
+    double moved[3] = {poses[0][0] + 0.3, poses[0][1] - 0.2, poses[0][2] + 0.1};
+    double const *at_moved[2] = {moved, poses[1]};
+    std::vector<double> rs(600), js0(1800), js1(1800);
+    double *jm[2] = {js0.data(), js1.data()};
+    REQUIRE(c0->Evaluate(at_moved, rs.data(), jm));
+    REQUIRE(B.slow_path_calls() == before + 1);
+    REQUIRE(rs != r_one);
+    const double keep[3] = {poses[0][0], poses[0][1], poses[0][2]};
+    std::memcpy(poses[0], moved, sizeof(moved));
+    B.PrepareForEvaluation(true, true);
+    REQUIRE(c0->Evaluate(params, r.data(), jac));
+    REQUIRE(r == rs && j0 == js0 && j1 == js1);
+    std::memcpy(poses[0], keep, sizeof(keep));
+    B.PrepareForEvaluation(true, true);
+  }
+  {
+    // Ceres calls Evaluate() from hardware_concurrency() threads (solver.cc:271): 16 threads, every block many times
+    const long before = B.slow_path_calls();
+    nautilus_hip::BatchedCost *blocks[3] = {c0, c1, c2};
+    double const *bp[3][2] = {{poses[0], poses[1]}, {poses[0], poses[1]}, {poses[2], poses[0]}};
+    std::vector<std::vector<double>> want_r(3, std::vector<double>(600)), want_j(3, std::vector<double>(3600));
+    for (int q = 0; q < 3; q++) {
+      double *jq[2] = {want_j[q].data(), want_j[q].data() + 1800};
+      REQUIRE(blocks[q]->Evaluate(bp[q], want_r[q].data(), jq));
+    }
+    std::atomic<int> bad{0};
+    std::vector<std::thread> pool;
+    for (int t = 0; t < 16; t++)
+      pool.emplace_back([&, t]() {
+        std::vector<double> rr(600), jj(3600);
+        double *jq[2] = {jj.data(), jj.data() + 1800};
+        for (int it = 0; it < 200; it++) {
+          const int q = (t + it) % 3;
+          if (!blocks[q]->Evaluate(bp[q], rr.data(), jq) || rr != want_r[q] || jj != want_j[q]) bad++;
+        }
+      });
+    for (auto &th : pool) th.join();
+    REQUIRE(bad == 0);
+    REQUIRE(B.slow_path_calls() == before);  // all 3200 calls took the lock-free path
+    std::printf("resid: 16 threads x 200 Evaluate() calls on the prepared batch: identical, lock-free\n");
+  }
   delete c0; delete c1; delete c2;
   B.Reset();
 
@@ -143,8 +202,7 @@ int main(int argc, char **argv) {
   REQUIRE(o0->num_residuals() == 3 && l0->num_residuals() == 3);
   double zero[3] = {0, 0, 0};
   B.Bind(o0, poses[0], poses[1]);
-  B.Bind(o1, poses[1], poses[2]);
-  B.Bind(l0, zero, zero);
+  B.Bind(l0, zero, zero);  // o1 stays unbound: it binds itself on its first Evaluate()
   B.PrepareForEvaluation(true, true);
   double ro[3], joi[9], joj[9];
   double *ojac[2] = {joi, joj};
@@ -153,14 +211,23 @@ int main(int argc, char **argv) {
   REQUIRE(std::fabs(ro[1] - 2.0 * (-0.2 + (double)-0.1f - 0.0)) < 1e-14);
   REQUIRE(std::fabs(ro[2] - 5.0 * (0.05 + (double)0.2f)) < 1e-14);
   REQUIRE(joi[0] == 2.0 && joi[4] == 2.0 && std::fabs(joi[8] - 5.0) < 1e-14 && joj[0] == -2.0 && joi[1] == 0.0);
-  REQUIRE(o1->Evaluate(params, ro, ojac));
+  double const *params12[2] = {poses[1], poses[2]};
+  REQUIRE(o1->Evaluate(params12, ro, ojac));  // unbound: single-factor evaluation at the parameters passed in
   {  // angle wrap: 0 + (-3) - (-0.4) = -2.6 stays; weights differ per factor
     REQUIRE(std::fabs(ro[2] - 0.5 * (double)(0.0 + (double)-3.0f + 0.4)) < 1e-14);
     REQUIRE(std::fabs(ro[0] - (0.0 + (double)-0.3f - 1.0)) < 1e-14);
   }
   double rl[3], jl0[9], jl1[9];
   double *ljac[2] = {jl0, jl1};
-  REQUIRE(l0->Evaluate(params, rl, ljac));
+  double const *zparams[2] = {zero, zero};
+  REQUIRE(l0->Evaluate(zparams, rl, ljac));
+  {  // the same block at another pose, outside the prepared point: shifted up by 0.25
+    double up[3] = {0.0, 0.25, 0.0};
+    double const *uparams[2] = {up, zero};
+    double ru[3];
+    REQUIRE(l0->Evaluate(uparams, ru, nullptr));
+    REQUIRE(std::fabs(ru[0] - 0.75) < 1e-12);
+  }
   // identity poses: distance to the segment itself: 0.5 above the middle, sqrt(2) past the end, sqrt(4+1/16)
   REQUIRE(std::fabs(rl[0] - 0.5) < 1e-12 && std::fabs(rl[1] - std::sqrt(2.0)) < 1e-12);
   REQUIRE(std::fabs(rl[2] - std::sqrt(4.0 + 0.0625)) < 1e-12);

@@ -13,16 +13,23 @@
 // a process-wide nautilus_hip::ResidualBatcher, which evaluates ALL blocks of a family in one pass
 // on the MI355X (nhip_resid_*) and from which each block's Evaluate() copies its slice.
 //
-// Ceres 1.14 hook (the lines solver.cc needs):
-//   options.evaluation_callback = &nautilus_hip::ResidualBatcher::Instance();   // BuildOptions()
-//   nautilus_hip::ResidualBatcher::Instance().Bind(cost_fn, pose_a, pose_b);    // next to AddResidualBlock
-//   nautilus_hip::ResidualBatcher::Instance().Reset();                          // CeresInformation::ResetProblem
-// PrepareForEvaluation() (called by Ceres once per evaluation point, with the user's parameter
-// blocks up to date) gathers the bound double[3] blocks, runs the batches and downloads results.
-// There is no CPU fallback: Evaluate() on a batch that has not been prepared returns false.
+// Ceres 1.14 hook: the ONE line the batched evaluation needs is
+//   options.evaluation_callback = &nautilus_hip::ResidualBatcher::Instance();   // BuildOptions(), solver.cc:266-275
+// PrepareForEvaluation() (called by Ceres once per evaluation point, with the user's parameter blocks up to date)
+// gathers the double[3] blocks, runs the batches and downloads the results into pinned memory; Evaluate() copies
+// its slice without taking a lock.  Parameter blocks are learned from each block's first Evaluate() (Ceres
+// evaluates at the user's own blocks when the callback is set) or, without that first single-block pass, from
+//   nautilus_hip::AddResidualBlock(problem, cost, NULL, pose_a, pose_b);        // instead of problem.AddResidualBlock
+// Blocks of a problem that is rebuilt (CeresInformation::ResetProblem) are dropped with
+//   nautilus_hip::ResidualBatcher::Instance().Reset();
+// Evaluate() at parameter values other than the prepared ones -- ceres::Problem::Evaluate, Covariance::Compute
+// (LCMatcher::GetCovarianceMatrix, lc_matcher.cc:28-46), GradientChecker, or no callback at all -- is detected by
+// comparing the values and served by a single-block evaluation on the GPU at the parameters passed in.
+// There is no CPU fallback.
 #ifndef NAUTILUS_HIP_SLAM_RESIDUALS_H_
 #define NAUTILUS_HIP_SLAM_RESIDUALS_H_
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <map>
@@ -75,7 +82,6 @@ struct PoseTable {
   std::map<const double *, int32_t> index;
   std::vector<const double *> ptrs;
   int32_t Id(const double *p) {
-    if (!p) throw std::runtime_error("nautilus_hip: residual block without bound parameter blocks (call Bind)");
     auto it = index.find(p);
     if (it != index.end()) return it->second;
     index[p] = (int32_t)ptrs.size();
@@ -89,19 +95,47 @@ struct PoseTable {
   }
 };
 
+// Page-locked array of doubles (nhip_host_alloc): the results cross PCIe every evaluation.
+struct PinnedDoubles {
+  double *p = nullptr;
+  size_t cap = 0;
+  void reserve(size_t n) {
+    if (n <= cap) return;
+    release();
+    Check(nhip_host_alloc(sizeof(double) * n, reinterpret_cast<void **>(&p)), "nhip_host_alloc");
+    cap = n;
+  }
+  void release() {
+    if (p) nhip_host_free(p);
+    p = nullptr;
+    cap = 0;
+  }
+  double *data() { return p; }
+  const double *data() const { return p; }
+};
+
 class BatchedCost;
 
 // Collects the residual blocks of one ceres::Problem build and evaluates each family in one pass.
+//
+// Threading: blocks are registered and bound while the problem is built (one thread).  PrepareForEvaluation runs
+// on one thread with no Evaluate() in flight (the ceres::EvaluationCallback contract); afterwards Evaluate() may be
+// called from any number of threads at once: the fast path only READS the prepared arrays and takes no lock.
+// An Evaluate() that arrives at parameter values other than the prepared ones (Problem::Evaluate,
+// Covariance::Compute, GradientChecker, a solver without the callback) or for a block whose parameter blocks are
+// not known yet is served by a single-block evaluation on the GPU at exactly the parameters passed in (slow path,
+// serialised by a mutex) -- never by stale values, never by the CPU.
 class ResidualBatcher : public EvaluationCallbackBase {
  public:
   static ResidualBatcher &Instance() {
-    static ResidualBatcher b;
-    return b;
+    static ResidualBatcher *b = new ResidualBatcher();  // never destroyed: pinned memory must not outlive the HIP runtime
+    return *b;
   }
 
   // CeresInformation::ResetProblem() (data_structures.h:111-116) starts a new problem: drop everything.
   void Reset() {
     std::lock_guard<std::mutex> lk(mu_);
+    prepared_.store(false, std::memory_order_release);
     for (int k = 0; k < 2; k++) {
       if (batch_[k]) nhip_resid_batch_free(batch_[k]);
       batch_[k] = nullptr;
@@ -109,11 +143,15 @@ class ResidualBatcher : public EvaluationCallbackBase {
       offsets_[k].assign(1, 0);
       bsrc_[k].clear();
       btgt_[k].clear();
+      jtt_[k].release();
     }
-    for (int f = 0; f < 4; f++) { pa_[f].clear(); pb_[f].clear(); res_[f].clear(); j0_[f].clear(); j1_[f].clear(); }
+    for (int f = 0; f < 4; f++) {
+      pa_[f].clear(); pb_[f].clear(); ia_[f].clear(); ib_[f].clear(); poses_a_[f].clear(); poses_b_[f].clear();
+      res_[f].release(); j0_[f].release(); j1_[f].release();
+    }
     t_odom_.clear(); r_odom_.clear(); tw_.clear(); rw_.clear();
     seg_.clear(); p2l_pts_.clear(); p2l_block_.clear(); p2l_off_.assign(1, 0);
-    prepared_ = false;
+    slow_calls_ = 0;
   }
 
   int RegisterLidar(int kind, const std::vector<Vec2f> &sp, const std::vector<Vec2f> &tp,
@@ -144,113 +182,201 @@ class ResidualBatcher : public EvaluationCallbackBase {
     return NewBlock(kPointToLine);
   }
 
-  // The parameter blocks handed to AddResidualBlock(cost, NULL, pose_a, pose_b) (solver.cc:280-283).
+  // The parameter blocks handed to AddResidualBlock(cost, NULL, pose_a, pose_b) (solver.cc:280-283).  Optional:
+  // an unbound block learns them from its first Evaluate() (with ceres::EvaluationCallback set, Ceres evaluates at
+  // the user's own parameter blocks), at the price of one single-block GPU evaluation per block on that first pass.
+  // nautilus_hip::AddResidualBlock() below binds and adds in one line.
   void Bind(const CostFunctionBase *cost, double *pose_a, double *pose_b);
 
   // ceres::EvaluationCallback: one GPU pass per family per evaluation point.
   void PrepareForEvaluation(bool evaluate_jacobians, bool /*new_evaluation_point*/) override {
     std::lock_guard<std::mutex> lk(mu_);
+    prepared_.store(false, std::memory_order_release);
     const bool J = evaluate_jacobians;
     for (int k = 0; k < 2; k++) {  // LIDARNormal / LIDARPoint
       const int32_t nb = (int32_t)pa_[k].size();
       if (nb == 0) continue;
       PoseTable T;
-      std::vector<int32_t> bs(nb), bt(nb);
-      for (int32_t b = 0; b < nb; b++) { bs[b] = T.Id(pa_[k][b]); bt[b] = T.Id(pb_[k][b]); }
-      if (!batch_[k] || bs != bsrc_[k] || bt != btgt_[k]) {
-        if (batch_[k]) nhip_resid_batch_free(batch_[k]);
-        batch_[k] = nullptr;
-        Check(nhip_resid_batch_create(k, corr_[k].data(), offsets_[k].data(), bs.data(), bt.data(), nb,
-                                      (int32_t)T.ptrs.size(), &batch_[k]), "nhip_resid_batch_create");
-        bsrc_[k] = bs;
-        btgt_[k] = bt;
-      }
+      BuildIndices(k, &T);
+      EnsureLidarBatch(k, (int32_t)T.ptrs.size());
       const std::vector<double> poses = T.Gather();
+      SnapshotPoses(k, poses);
       const size_t n = (size_t)offsets_[k].back();
-      res_[k].resize(2 * n);
-      if (J) { j0_[k].resize(6 * n); j1_[k].resize(6 * n); }
-      Check(nhip_resid_batch_eval(batch_[k], poses.data(), res_[k].data(), J ? j0_[k].data() : nullptr,
-                                  J ? j1_[k].data() : nullptr), "nhip_resid_batch_eval");
+      res_[k].reserve(2 * n);
+      if (J) {
+        j0_[k].reserve(6 * n);
+        jtt_[k].reserve(2 * n);
+        Check(nhip_resid_batch_eval_compact(batch_[k], poses.data(), res_[k].data(), j0_[k].data(), jtt_[k].data()),
+              "nhip_resid_batch_eval_compact");
+      } else {
+        Check(nhip_resid_batch_eval(batch_[k], poses.data(), res_[k].data(), nullptr, nullptr), "nhip_resid_batch_eval");
+      }
     }
     if (!pa_[kOdometry].empty()) {
       const int32_t n = (int32_t)pa_[kOdometry].size();
       PoseTable T;
-      std::vector<int32_t> pi(n), pj(n);
-      for (int32_t f = 0; f < n; f++) { pi[f] = T.Id(pa_[kOdometry][f]); pj[f] = T.Id(pb_[kOdometry][f]); }
+      BuildIndices(kOdometry, &T);
       const std::vector<double> poses = T.Gather();
-      std::vector<double> &r = res_[kOdometry], &ji = j0_[kOdometry], &jj = j1_[kOdometry];
-      r.resize(3 * (size_t)n);
-      if (J) { ji.resize(9 * (size_t)n); jj.resize(9 * (size_t)n); }
+      SnapshotPoses(kOdometry, poses);
+      res_[kOdometry].reserve(3 * (size_t)n);
+      if (J) { j0_[kOdometry].reserve(9 * (size_t)n); j1_[kOdometry].reserve(9 * (size_t)n); }
+      double *r = res_[kOdometry].data(), *ji = j0_[kOdometry].data(), *jj = j1_[kOdometry].data();
       // unit weights on the device, each factor's own weights applied here (w * x is one rounding either way)
-      Check(nhip_resid_odometry(t_odom_.data(), r_odom_.data(), pi.data(), pj.data(), n, 1.0, 1.0, poses.data(),
-                                (int32_t)T.ptrs.size(), r.data(), J ? ji.data() : nullptr, J ? jj.data() : nullptr),
+      Check(nhip_resid_odometry(t_odom_.data(), r_odom_.data(), ia_[kOdometry].data(), ib_[kOdometry].data(), n, 1.0, 1.0,
+                                poses.data(), (int32_t)T.ptrs.size(), r, J ? ji : nullptr, J ? jj : nullptr),
             "nhip_resid_odometry");
-      for (int32_t f = 0; f < n; f++) {
-        const double w[3] = {tw_[f], tw_[f], rw_[f]};
-        for (int row = 0; row < 3; row++) {
-          r[3 * f + row] *= w[row];
-          if (J) for (int c = 0; c < 3; c++) { ji[9 * f + 3 * row + c] *= w[row]; jj[9 * f + 3 * row + c] *= w[row]; }
-        }
-      }
+      for (int32_t f = 0; f < n; f++) ApplyOdometryWeights(f, r + 3 * f, J ? ji + 9 * f : nullptr, J ? jj + 9 * f : nullptr);
     }
     if (!pa_[kPointToLine].empty()) {
       const int32_t nb = (int32_t)pa_[kPointToLine].size();
       PoseTable TP, TL;
-      std::vector<int32_t> bp(nb), bl(nb);
-      for (int32_t b = 0; b < nb; b++) { bp[b] = TP.Id(pa_[kPointToLine][b]); bl[b] = TL.Id(pb_[kPointToLine][b]); }
+      std::vector<int32_t> &bp = ia_[kPointToLine], &bl = ib_[kPointToLine];
+      bp.resize(nb); bl.resize(nb);
+      for (int32_t b = 0; b < nb; b++) { bp[b] = TP.Id(Bound(pa_[kPointToLine][b])); bl[b] = TL.Id(Bound(pb_[kPointToLine][b])); }
       const std::vector<double> poses = TP.Gather(), lines = TL.Gather();
+      poses_a_[kPointToLine] = poses;
+      poses_b_[kPointToLine] = lines;
       const size_t n = p2l_block_.size();
-      res_[kPointToLine].resize(n);
-      if (J) { j0_[kPointToLine].resize(3 * n); j1_[kPointToLine].resize(3 * n); }
+      res_[kPointToLine].reserve(n);
+      if (J) { j0_[kPointToLine].reserve(3 * n); j1_[kPointToLine].reserve(3 * n); }
       Check(nhip_resid_point_to_line(seg_.data(), p2l_pts_.data(), p2l_block_.data(), (int64_t)n, bp.data(), bl.data(),
                                      nb, poses.data(), (int32_t)TP.ptrs.size(), lines.data(), (int32_t)TL.ptrs.size(),
                                      res_[kPointToLine].data(), J ? j0_[kPointToLine].data() : nullptr,
                                      J ? j1_[kPointToLine].data() : nullptr), "nhip_resid_point_to_line");
     }
-    prepared_ = true;
     have_jac_ = evaluate_jacobians;
+    prepared_.store(true, std::memory_order_release);
   }
 
-  // Copies block `b`'s slice; false if the batch was not prepared (no CPU fallback).
-  bool Fetch(int family, int b, double *residuals, double **jacobians) const {
-    std::lock_guard<std::mutex> lk(mu_);
-    if (!prepared_) return false;
-    size_t r_off, r_n;  // residual rows of this block
-    if (family <= kLidarPoint) { r_off = 2 * (size_t)offsets_[family][b]; r_n = 2 * (size_t)(offsets_[family][b + 1] - offsets_[family][b]); }
-    else if (family == kOdometry) { r_off = 3 * (size_t)b; r_n = 3; }
-    else { r_off = (size_t)p2l_off_[b]; r_n = (size_t)(p2l_off_[b + 1] - p2l_off_[b]); }
-    std::memcpy(residuals, &res_[family][r_off], sizeof(double) * r_n);
-    if (jacobians) {
-      if ((jacobians[0] || jacobians[1]) && !have_jac_) return false;
-      if (jacobians[0]) std::memcpy(jacobians[0], &j0_[family][3 * r_off], sizeof(double) * 3 * r_n);
-      if (jacobians[1]) std::memcpy(jacobians[1], &j1_[family][3 * r_off], sizeof(double) * 3 * r_n);
+  // Block `b`'s residuals (and Jacobians) at `parameters`.  Fast path: the prepared arrays, no lock.
+  bool Fetch(int family, int b, double const *const *parameters, double *residuals, double **jacobians) {
+    const bool want_j = jacobians && (jacobians[0] || jacobians[1]);
+    if (prepared_.load(std::memory_order_acquire) && pa_[family][b] && (!want_j || have_jac_) &&
+        SameParameters(family, b, parameters)) {
+      CopyPrepared(family, b, residuals, jacobians);
+      return true;
     }
-    return true;
+    return EvaluateOne(family, b, parameters, residuals, jacobians);
   }
+
+  long slow_path_calls() const { return slow_calls_; }
 
  private:
   ResidualBatcher() { offsets_[0].assign(1, 0); offsets_[1].assign(1, 0); p2l_off_.assign(1, 0); }
   int NewBlock(int family) {
     pa_[family].push_back(nullptr);
     pb_[family].push_back(nullptr);
-    prepared_ = false;
+    prepared_.store(false, std::memory_order_release);
     return (int)pa_[family].size() - 1;
   }
-  mutable std::mutex mu_;
+  // unbound blocks read a dummy pose until their first Evaluate() binds them (their prepared values are never used)
+  const double *Bound(const double *p) const { static const double zero[3] = {0, 0, 0}; return p ? p : zero; }
+  void BuildIndices(int f, PoseTable *T) {
+    const size_t nb = pa_[f].size();
+    ia_[f].resize(nb); ib_[f].resize(nb);
+    for (size_t b = 0; b < nb; b++) { ia_[f][b] = T->Id(Bound(pa_[f][b])); ib_[f][b] = T->Id(Bound(pb_[f][b])); }
+  }
+  void SnapshotPoses(int f, const std::vector<double> &poses) { poses_a_[f] = poses; }
+  void EnsureLidarBatch(int k, int32_t n_poses) {
+    if (!batch_[k] || ia_[k] != bsrc_[k] || ib_[k] != btgt_[k]) {
+      if (batch_[k]) nhip_resid_batch_free(batch_[k]);
+      batch_[k] = nullptr;
+      Check(nhip_resid_batch_create(k, corr_[k].data(), offsets_[k].data(), ia_[k].data(), ib_[k].data(),
+                                    (int32_t)ia_[k].size(), n_poses, &batch_[k]), "nhip_resid_batch_create");
+      bsrc_[k] = ia_[k];
+      btgt_[k] = ib_[k];
+    }
+  }
+  void ApplyOdometryWeights(int32_t f, double *r, double *ji, double *jj) const {
+    const double w[3] = {tw_[f], tw_[f], rw_[f]};
+    for (int row = 0; row < 3; row++) {
+      r[row] *= w[row];
+      if (ji) for (int c = 0; c < 3; c++) ji[3 * row + c] *= w[row];
+      if (jj) for (int c = 0; c < 3; c++) jj[3 * row + c] *= w[row];
+    }
+  }
+  // Were the prepared values computed at exactly these parameter values?
+  bool SameParameters(int f, int b, double const *const *parameters) const {
+    const double *a = &poses_a_[f][3 * (size_t)ia_[f][b]];
+    const double *c = (f == kPointToLine) ? &poses_b_[f][3 * (size_t)ib_[f][b]] : &poses_a_[f][3 * (size_t)ib_[f][b]];
+    return std::memcmp(a, parameters[0], 3 * sizeof(double)) == 0 && std::memcmp(c, parameters[1], 3 * sizeof(double)) == 0;
+  }
+  void Rows(int family, int b, size_t *r_off, size_t *r_n) const {
+    if (family <= kLidarPoint) { *r_off = 2 * (size_t)offsets_[family][b]; *r_n = 2 * (size_t)(offsets_[family][b + 1] - offsets_[family][b]); }
+    else if (family == kOdometry) { *r_off = 3 * (size_t)b; *r_n = 3; }
+    else { *r_off = (size_t)p2l_off_[b]; *r_n = (size_t)(p2l_off_[b + 1] - p2l_off_[b]); }
+  }
+  void CopyPrepared(int family, int b, double *residuals, double **jacobians) const {
+    size_t r_off, r_n;
+    Rows(family, b, &r_off, &r_n);
+    std::memcpy(residuals, res_[family].data() + r_off, sizeof(double) * r_n);
+    if (!jacobians) return;
+    const double *js = j0_[family].data() + 3 * r_off;
+    if (jacobians[0]) std::memcpy(jacobians[0], js, sizeof(double) * 3 * r_n);
+    if (jacobians[1]) {
+      if (family <= kLidarPoint) {
+        // rows of J_tgt: the negated x, y entries of J_src's row and the shipped theta entry
+        const double *th = jtt_[family].data() + r_off;
+        double *jt = jacobians[1];
+        for (size_t i = 0; i < r_n; i++) { jt[3 * i] = -js[3 * i]; jt[3 * i + 1] = -js[3 * i + 1]; jt[3 * i + 2] = th[i]; }
+      } else {
+        std::memcpy(jacobians[1], j1_[family].data() + 3 * r_off, sizeof(double) * 3 * r_n);
+      }
+    }
+  }
+  // Slow path: this block alone, on the GPU, at the parameters passed in.
+  bool EvaluateOne(int family, int b, double const *const *parameters, double *residuals, double **jacobians) {
+    std::lock_guard<std::mutex> lk(mu_);
+    slow_calls_++;
+    if (!pa_[family][b]) {  // first sight of this block's parameter blocks
+      pa_[family][b] = parameters[0];
+      pb_[family][b] = parameters[1];
+      prepared_.store(false, std::memory_order_release);  // the next PrepareForEvaluation batches it
+    }
+    double *j0 = jacobians ? jacobians[0] : nullptr, *j1 = jacobians ? jacobians[1] : nullptr;
+    if (family <= kLidarPoint) {
+      if (!batch_[family]) {
+        PoseTable T;
+        BuildIndices(family, &T);
+        EnsureLidarBatch(family, (int32_t)T.ptrs.size());
+      }
+      return nhip_resid_batch_eval_block(batch_[family], b, parameters[0], parameters[1], residuals, j0, j1) == NHIP_OK;
+    }
+    if (family == kOdometry) {
+      double two[6];
+      std::memcpy(two, parameters[0], 24); std::memcpy(two + 3, parameters[1], 24);
+      const int32_t i0 = 0, i1 = 1;
+      if (nhip_resid_odometry(&t_odom_[2 * b], &r_odom_[b], &i0, &i1, 1, 1.0, 1.0, two, 2, residuals, j0, j1) != NHIP_OK) return false;
+      ApplyOdometryWeights(b, residuals, j0, j1);
+      return true;
+    }
+    const int32_t zero = 0;
+    const int32_t n = p2l_off_[b + 1] - p2l_off_[b];
+    std::vector<int32_t> blk((size_t)n, 0);
+    return nhip_resid_point_to_line(&seg_[4 * b], &p2l_pts_[2 * (size_t)p2l_off_[b]], blk.data(), n, &zero, &zero, 1,
+                                    parameters[0], 1, parameters[1], 1, residuals, j0, j1) == NHIP_OK;
+  }
+
+  std::mutex mu_;
+  std::atomic<bool> prepared_{false};
+  bool have_jac_ = false;
+  long slow_calls_ = 0;
   // LIDAR families
   std::vector<float> corr_[2];
   std::vector<int32_t> offsets_[2], bsrc_[2], btgt_[2];
   nhip_resid_batch_t *batch_[2] = {nullptr, nullptr};
+  PinnedDoubles jtt_[2];  // theta column of J_tgt, 2 per correspondence
   // odometry
   std::vector<float> t_odom_, r_odom_;
   std::vector<double> tw_, rw_;
   // point-to-line
   std::vector<float> seg_, p2l_pts_;
   std::vector<int32_t> p2l_block_, p2l_off_;
-  // per family: bound parameter blocks and the last evaluation
+  // per family: bound parameter blocks, their indices into the last gathered pose table(s), the last evaluation
   std::vector<const double *> pa_[4], pb_[4];
-  std::vector<double> res_[4], j0_[4], j1_[4];
-  bool prepared_ = false, have_jac_ = false;
+  std::vector<int32_t> ia_[4], ib_[4];
+  std::vector<double> poses_a_[4], poses_b_[4];
+  PinnedDoubles res_[4], j0_[4], j1_[4];
   friend class BatchedCost;
 };
 
@@ -263,8 +389,8 @@ class BatchedCost : public CostFunctionBase {
     mutable_parameter_block_sizes()->push_back(3);
     set_num_residuals(num_residuals);
   }
-  bool Evaluate(double const *const * /*parameters*/, double *residuals, double **jacobians) const override {
-    return ResidualBatcher::Instance().Fetch(family_, block_, residuals, jacobians);
+  bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const override {
+    return ResidualBatcher::Instance().Fetch(family_, block_, parameters, residuals, jacobians);
   }
   int family() const { return family_; }
   int block() const { return block_; }
@@ -280,7 +406,16 @@ inline void ResidualBatcher::Bind(const CostFunctionBase *cost, double *pose_a, 
   std::lock_guard<std::mutex> lk(mu_);
   pa_[c->family()][c->block()] = pose_a;
   pb_[c->family()][c->block()] = pose_b;
-  prepared_ = false;
+  prepared_.store(false, std::memory_order_release);
+}
+
+// problem.AddResidualBlock(cost, loss, pose_a, pose_b) and the binding in one call: the one-line form of
+// solver.cc:280-283, 291-293, 378, 521, 528 that avoids the single-block first pass of unbound blocks.
+template <class Problem, class Loss>
+inline auto AddResidualBlock(Problem &problem, CostFunctionBase *cost, Loss *loss, double *pose_a, double *pose_b)
+    -> decltype(problem.AddResidualBlock(cost, loss, pose_a, pose_b)) {
+  ResidualBatcher::Instance().Bind(cost, pose_a, pose_b);
+  return problem.AddResidualBlock(cost, loss, pose_a, pose_b);
 }
 
 inline void CheckSizes(const std::vector<Vec2f> &sp, const std::vector<Vec2f> &tp, const std::vector<Vec2f> &sn,

@@ -215,7 +215,10 @@ struct nhip_grids {
 };
 
 struct nhip_resid_batch {
-  nhip::DevBuf corr, corr_block, block_src, block_tgt, consts, poses, res, jsrc, jtgt;
+  nhip::DevBuf corr, corr_block, block_src, block_tgt, consts, poses, res, jsrc, jtgt, jtt;
+  nhip::DevBuf one_poses, one_consts, one_idx;  // single-block evaluation: 2 poses, 8 constants, {0, 1}
+  std::vector<int32_t> h_offsets;
+  std::mutex one_mu;
   int kind = 0;
   int32_t n_blocks = 0, n_poses = 0;
   int64_t n_corr = 0;
@@ -765,6 +768,20 @@ int nhip_resid_batch_create(int kind, const float *corr, const int32_t *block_of
   B->n_blocks = n_blocks;
   B->n_poses = n_poses;
   B->n_corr = n_corr;
+  B->h_offsets.assign(block_offsets, block_offsets + n_blocks + 1);
+  if ((rc = B->jtt.alloc(sizeof(double) * 2 * (size_t)n_corr)) || (rc = B->one_poses.alloc(sizeof(double) * 6)) ||
+      (rc = B->one_consts.alloc(sizeof(double) * 8)) || (rc = B->one_idx.alloc(sizeof(int32_t) * 2))) {
+    delete B;
+    return rc;
+  }
+  {
+    const int32_t idx[2] = {0, 1};
+    hipError_t e0 = hipMemcpy(B->one_idx.p, idx, sizeof(idx), hipMemcpyHostToDevice);
+    if (e0 != hipSuccess) {
+      delete B;
+      return hip_fail(e0, "resid_batch_create memcpy", __FILE__, __LINE__);
+    }
+  }
   if ((rc = B->corr.alloc(sizeof(float) * 8 * (size_t)n_corr)) || (rc = B->corr_block.alloc(sizeof(int32_t) * (size_t)n_corr)) ||
       (rc = B->block_src.alloc(sizeof(int32_t) * (size_t)n_blocks)) || (rc = B->block_tgt.alloc(sizeof(int32_t) * (size_t)n_blocks)) ||
       (rc = B->consts.alloc(sizeof(double) * 8 * (size_t)n_blocks)) || (rc = B->poses.alloc(sizeof(double) * 3 * (size_t)n_poses)) ||
@@ -807,6 +824,73 @@ int nhip_resid_batch_eval(nhip_resid_batch_t *B, const double *poses, double *re
   NHIP_TRY_HIP(hipMemcpy(residuals, B->res.p, sizeof(double) * 2 * (size_t)B->n_corr, hipMemcpyDeviceToHost));
   if (jac_src) NHIP_TRY_HIP(hipMemcpy(jac_src, B->jsrc.p, sizeof(double) * 6 * (size_t)B->n_corr, hipMemcpyDeviceToHost));
   if (jac_tgt) NHIP_TRY_HIP(hipMemcpy(jac_tgt, B->jtgt.p, sizeof(double) * 6 * (size_t)B->n_corr, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_resid_batch_eval_compact(nhip_resid_batch_t *B, const double *poses, double *residuals, double *jac_src,
+                                  double *jac_tgt_theta) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(B && poses && residuals && jac_src && jac_tgt_theta, "resid_batch_eval_compact: bad arguments");
+  if (B->n_corr == 0) return NHIP_OK;
+  NHIP_TRY_HIP(hipMemcpy(B->poses.p, poses, sizeof(double) * 3 * (size_t)B->n_poses, hipMemcpyHostToDevice));
+  rc = launch_resid_lidar(B->kind, static_cast<const float *>(B->corr.p), static_cast<const int32_t *>(B->corr_block.p),
+                          B->n_corr, static_cast<const int32_t *>(B->block_src.p),
+                          static_cast<const int32_t *>(B->block_tgt.p), B->n_blocks,
+                          static_cast<const double *>(B->poses.p), B->n_poses, static_cast<double *>(B->consts.p),
+                          static_cast<double *>(B->res.p), static_cast<double *>(B->jsrc.p), nullptr, nullptr,
+                          static_cast<double *>(B->jtt.p), 0);
+  if (rc) return rc;
+  // three copies on the stream the kernel ran on; into pinned memory (nhip_host_alloc) they run at the PCIe rate
+  NHIP_TRY_HIP(hipMemcpyAsync(residuals, B->res.p, sizeof(double) * 2 * (size_t)B->n_corr, hipMemcpyDeviceToHost, nullptr));
+  NHIP_TRY_HIP(hipMemcpyAsync(jac_src, B->jsrc.p, sizeof(double) * 6 * (size_t)B->n_corr, hipMemcpyDeviceToHost, nullptr));
+  NHIP_TRY_HIP(hipMemcpyAsync(jac_tgt_theta, B->jtt.p, sizeof(double) * 2 * (size_t)B->n_corr, hipMemcpyDeviceToHost, nullptr));
+  NHIP_TRY_HIP(hipStreamSynchronize(nullptr));
+  return NHIP_OK;
+}
+
+int nhip_resid_batch_eval_block(nhip_resid_batch_t *B, int32_t block, const double *source_pose,
+                                const double *target_pose, double *residuals, double *jac_src, double *jac_tgt) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(B && source_pose && target_pose && residuals, "resid_batch_eval_block: bad arguments");
+  NHIP_REQUIRE(block >= 0 && block < B->n_blocks, "resid_batch_eval_block: block %d out of range", block);
+  const int64_t o = B->h_offsets[block], n = B->h_offsets[block + 1] - o;
+  double two[6];
+  memcpy(two, source_pose, 3 * sizeof(double));
+  memcpy(two + 3, target_pose, 3 * sizeof(double));
+  std::lock_guard<std::mutex> lk(B->one_mu);  // one scratch set per batch: callers on several threads take turns
+  NHIP_TRY_HIP(hipMemcpy(B->one_poses.p, two, sizeof(two), hipMemcpyHostToDevice));
+  // the block's slice of the batch; its rows carry block id `block`, the one set of constants sits at index 0
+  rc = launch_resid_lidar(B->kind, static_cast<const float *>(B->corr.p) + 8 * o,
+                          static_cast<const int32_t *>(B->corr_block.p) + o, n,
+                          static_cast<const int32_t *>(B->one_idx.p), static_cast<const int32_t *>(B->one_idx.p) + 1, 1,
+                          static_cast<const double *>(B->one_poses.p), 2, static_cast<double *>(B->one_consts.p),
+                          static_cast<double *>(B->res.p) + 2 * o, jac_src ? static_cast<double *>(B->jsrc.p) + 6 * o : nullptr,
+                          jac_tgt ? static_cast<double *>(B->jtgt.p) + 6 * o : nullptr, nullptr, nullptr, block);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(residuals, static_cast<double *>(B->res.p) + 2 * o, sizeof(double) * 2 * (size_t)n, hipMemcpyDeviceToHost));
+  if (jac_src) NHIP_TRY_HIP(hipMemcpy(jac_src, static_cast<double *>(B->jsrc.p) + 6 * o, sizeof(double) * 6 * (size_t)n, hipMemcpyDeviceToHost));
+  if (jac_tgt) NHIP_TRY_HIP(hipMemcpy(jac_tgt, static_cast<double *>(B->jtgt.p) + 6 * o, sizeof(double) * 6 * (size_t)n, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_host_alloc(size_t bytes, void **out) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(out, "host_alloc: null out");
+  *out = nullptr;
+  hipError_t e = hipHostMalloc(out, bytes ? bytes : 16, hipHostMallocDefault);
+  if (e != hipSuccess) {
+    *out = nullptr;
+    set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    return NHIP_ERR_ALLOC;
+  }
+  return NHIP_OK;
+}
+
+int nhip_host_free(void *p) {
+  if (p) NHIP_TRY_HIP(hipHostFree(p));
   return NHIP_OK;
 }
 

@@ -107,8 +107,12 @@ __device__ __forceinline__ void rs_step(uint32_t (&R)[CAP], bool bit, int mask) 
 // ---- bounds of one rotation ------------------------------------------------------------------------------
 // Returns this lane's two totals of the 128-slot layout: slot v = lane + 64 * i (i = 0, 1) holds packed register
 // r = 32 i + 16 b5 + 8 b4 + 4 b2 + 2 b1 + b0, field b3 (b = bits of the lane) -- see slot_block().
-__device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_t *pool, const float2 *pts, int32_t n_pts,
-                                                float cf, float sf, int32_t cx, int32_t cy, int lane, uint32_t (&tot)[2]) {
+// POOL_LDS: the pooled table is staged in LDS (`pool`); otherwise it is read from the grid slot in global memory
+// through the buffer descriptor `prs` (tables of large grids, e.g. the 6000 x 6000 grid of the two-level drop-in).
+template <bool POOL_LDS>
+__device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_t *pool, __amdgpu_buffer_rsrc_t prs,
+                                                const float2 *pts, int32_t n_pts, float cf, float sf, int32_t cx,
+                                                int32_t cy, int lane, uint32_t (&tot)[2]) {
   const int32_t DP = P.pool_pitch;
   const int32_t zero_a = ((P.rows + BNB_B - 1) / BNB_B) * DP;  // NB + 1 rows of zeros below the pooled image
   tot[0] = tot[1] = 0u;
@@ -133,9 +137,14 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
       const uint32_t *q = reinterpret_cast<const uint32_t *>(pool + (a & ~3));
 #pragma unroll
       for (int y = 0; y < NB; y++) {
-
-        const uint32_t *row = q + (y * DP) / 4;  // DP is a multiple of 16
-        const uint32_t w0 = row[0], w1 = row[1], w2 = row[2], w3 = row[3];
+        uint32_t w0, w1, w2, w3;
+        if (POOL_LDS) {
+          const uint32_t *row = q + (y * DP) / 4;  // DP is a multiple of 16
+          w0 = row[0]; w1 = row[1]; w2 = row[2]; w3 = row[3];
+        } else {
+          const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(prs, (a & ~3) + y * DP, 0, 0);
+          w0 = r4.x; w1 = r4.y; w2 = r4.z; w3 = r4.w;
+        }
         const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
         const uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, sh);
         // even: b0 | b2 << 16; odd (raw): w >> 8 = b1 + 256 b2 + 65536 b3, repaired after the loop
@@ -358,11 +367,11 @@ __device__ __forceinline__ void rotation_k(const BnbParams &P, int32_t pair, int
   *sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
 }
 
-template <int CB>
+template <int CB, bool POOL_LDS>
 __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint8_t *s_pool = smem;                                                       // pool_bytes
-  uint32_t *s_U = reinterpret_cast<uint32_t *>(smem + P.pool_bytes);            // n_theta * 128
+  uint8_t *s_pool = smem;                                                       // pool_bytes (POOL_LDS)
+  uint32_t *s_U = reinterpret_cast<uint32_t *>(smem + (POOL_LDS ? P.pool_bytes : 0));  // n_theta * 128
   unsigned long long *s_queue = reinterpret_cast<unsigned long long *>(s_U + (size_t)P.n_theta * 128);  // QCAP
   unsigned long long *s_best = s_queue + QCAP;
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_best + 1);
@@ -394,11 +403,13 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     if (threadIdx.x == 0) P.keys[pair] = key0;
     return;
   }
-  {  // the target's pooled table -> LDS
+  if (POOL_LDS) {  // the target's pooled table -> LDS
     const uint4 *gp = reinterpret_cast<const uint4 *>(grid + P.grid_bytes + P.skip_bytes);
     uint4 *sp = reinterpret_cast<uint4 *>(s_pool);
     for (int32_t i = threadIdx.x; i < (int32_t)(P.pool_bytes / 16); i += BNB_THREADS) sp[i] = gp[i];
   }
+  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<uint8_t *>(grid + P.grid_bytes + P.skip_bytes), 0, (int)P.pool_bytes, 0x00020000);
   __syncthreads();
 
   // (1) bounds of every block of every rotation this wave owns; the wave's own best bound
@@ -408,7 +419,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     float cf, sf;
     rotation_k(P, pair, k, &cf, &sf);
     uint32_t tot[2];
-    coarse_rotation(P, s_pool, pts, n_pts, cf, sf, cx, cy, lane, tot);
+    coarse_rotation<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, tot);
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       int Y, X;
@@ -501,17 +512,18 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   }
 }
 
-size_t bnb_lds_bytes(const GridLayout &L, const nhip_search_t *search) {
-  return (size_t)L.pool_bytes + (size_t)search->n_theta * 128 * 4 + (size_t)QCAP * 8 + 32;
+size_t bnb_lds_bytes(const GridLayout &L, const nhip_search_t *search, bool pool_lds) {
+  return (pool_lds ? (size_t)L.pool_bytes : 0) + (size_t)search->n_theta * 128 * 4 + (size_t)QCAP * 8 + 32;
 }
+constexpr size_t LDS_MAX = 160 * 1024;
 
 }  // namespace
 
 bool bnb_fits(const GridLayout &L, const nhip_search_t *search) {
   const int nbx = (search->nx + BNB_B - 1) / BNB_B, nby = (search->ny + BNB_B - 1) / BNB_B;
-  // two workgroups per CU when the tables allow it; one workgroup may take the whole 160 KB
-  return nbx <= NB && nby <= NB && bnb_lds_bytes(L, search) <= 160 * 1024 && L.pool_bytes % 16 == 0 &&
-         L.S + 2 * L.pad < 65536 && search->n_theta < (1 << 23);
+  // (the pooled table goes to LDS when it fits beside the bounds; else it is read from global memory)
+  return nbx <= NB && nby <= NB && bnb_lds_bytes(L, search, false) <= LDS_MAX && L.pool_bytes % 16 == 0 &&
+         L.pool_bytes < 0x7fffffffll && L.S + 2 * L.pad < 65536 && search->n_theta < (1 << 23);
 }
 
 static unsigned long long *g_bnb_stats = nullptr;  // device counters, allocated on first use when NHIP_BNB_STATS=1
@@ -568,18 +580,21 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     }
     P.stats = g_bnb_stats;
   }
-  const size_t lds = bnb_lds_bytes(L, search);
+  const bool pool_lds = bnb_lds_bytes(L, search, true) <= LDS_MAX;
+  const size_t lds = bnb_lds_bytes(L, search, pool_lds);
   const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
   timer_begin(NHIP_TIMER_CSM, s);
-  if (L.cb == 1) {
-    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<1>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(csm_bnb_kernel<1>, dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);
-  } else {
-    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<2>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    hipLaunchKernelGGL(csm_bnb_kernel<2>, dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);
-  }
+#define NHIP_BNB_LAUNCH(CB, PL)                                                                                  \
+  do {                                                                                                           \
+    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL>),                     \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+    hipLaunchKernelGGL((csm_bnb_kernel<CB, PL>), dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);          \
+  } while (0)
+  if (L.cb == 1 && pool_lds) NHIP_BNB_LAUNCH(1, true);
+  else if (L.cb == 1) NHIP_BNB_LAUNCH(1, false);
+  else if (pool_lds) NHIP_BNB_LAUNCH(2, true);
+  else NHIP_BNB_LAUNCH(2, false);
+#undef NHIP_BNB_LAUNCH
   timer_end(NHIP_TIMER_CSM, s);
   NHIP_TRY_HIP(hipGetLastError());
   launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);

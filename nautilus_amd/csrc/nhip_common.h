@@ -126,7 +126,8 @@ int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t
 int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_block, int64_t n_corr,
                        const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                        const double *d_poses, int32_t n_poses, double *d_block_consts,
-                       double *d_res, double *d_jsrc, double *d_jtgt, hipStream_t s);
+                       double *d_res, double *d_jsrc, double *d_jtgt, hipStream_t s, double *d_jtgt_theta = nullptr,
+                       int32_t block_base = 0);
 
 int launch_resid_normal_eq(int kind, const float *d_corr, const int32_t *d_block_offsets,
                            const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,

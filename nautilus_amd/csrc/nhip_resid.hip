@@ -66,7 +66,8 @@ template <int KIND, bool WANT_J>
 __global__ __launch_bounds__(RT) void resid_lidar_kernel(
     const float4 *__restrict__ corr, const int32_t *__restrict__ corr_block, int64_t n_corr,
     const double *__restrict__ consts, double2 *__restrict__ residuals,
-    double2 *__restrict__ jac_src, double2 *__restrict__ jac_tgt) {
+    double2 *__restrict__ jac_src, double2 *__restrict__ jac_tgt, double2 *__restrict__ jac_tgt_theta,
+    int32_t block_base) {
   __shared__ double2 s_j[WANT_J ? 2 * 3 * RT : 1];
   const int64_t i0 = (int64_t)blockIdx.x * RT;
   const int64_t i = i0 + threadIdx.x;
@@ -76,7 +77,7 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
   if (live) {
     const float4 a = corr[2 * i];      // source point, target point
     const float4 n = corr[2 * i + 1];  // source normal, target normal
-    const double2 *c = reinterpret_cast<const double2 *>(consts + 8 * (size_t)corr_block[i]);
+    const double2 *c = reinterpret_cast<const double2 *>(consts + 8 * (size_t)(corr_block[i] - block_base));
     const double2 c01 = c[0], c23 = c[1], c45 = c[2], c67 = c[3];
     const double l00 = c01.x, l01 = c01.y, l10 = c23.x, l11 = c23.y;
     const double i00 = c67.x, i01 = c67.y, i10 = -i01, i11 = i00;
@@ -115,6 +116,9 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
       }
     }
     store_stream(&residuals[i], make_double2(r0, r1));
+    // the theta column of the target Jacobian on its own: its x, y columns are the negated x, y columns of the
+    // source Jacobian (dq/dt_t = -dq/dt_s), so a host that rebuilds them needs only these two values
+    if (WANT_J && jac_tgt_theta) store_stream(&jac_tgt_theta[i], make_double2(jt[2], jt[5]));
   }
   if (WANT_J) {
     // transpose through LDS: lane t holds 3 double2 per Jacobian; the block's 3*RT double2
@@ -389,7 +393,8 @@ __global__ void resid_odometry_kernel(const float2 *__restrict__ t_odom,
 int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_block, int64_t n_corr,
                        const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                        const double *d_poses, int32_t n_poses, double *d_block_consts,
-                       double *d_res, double *d_jsrc, double *d_jtgt, hipStream_t s) {
+                       double *d_res, double *d_jsrc, double *d_jtgt, hipStream_t s, double *d_jtgt_theta,
+                       int32_t block_base) {
   NHIP_REQUIRE(kind == NHIP_LIDAR_NORMAL || kind == NHIP_LIDAR_POINT, "resid_lidar: bad kind %d",
                kind);
   NHIP_REQUIRE(n_corr >= 0 && n_blocks >= 0 && n_poses >= 0, "resid_lidar: negative size");
@@ -400,22 +405,23 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
   const float4 *corr = reinterpret_cast<const float4 *>(d_corr);
   double2 *res = reinterpret_cast<double2 *>(d_res);
   double2 *js = reinterpret_cast<double2 *>(d_jsrc), *jt = reinterpret_cast<double2 *>(d_jtgt);
-  const bool want_j = d_jsrc || d_jtgt;
+  const bool want_j = d_jsrc || d_jtgt || d_jtgt_theta;
+  double2 *jtt = reinterpret_cast<double2 *>(d_jtgt_theta);
   timer_begin(NHIP_TIMER_RESID, s);
   if (kind == NHIP_LIDAR_NORMAL) {
     if (want_j)
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_NORMAL, true>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt);
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base);
     else
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_NORMAL, false>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt);
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base);
   } else {
     if (want_j)
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_POINT, true>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt);
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base);
     else
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_POINT, false>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt);
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base);
   }
   timer_end(NHIP_TIMER_RESID, s);
   NHIP_TRY_HIP(hipGetLastError());
