@@ -793,17 +793,26 @@ def bench_icp(bag, xy, off, with_cpu, window=10, iters=5):
 
 
 def bench_config1(with_cpu):
-    """BASELINE configs[0] (SURVEY 8d 'Config #1'): 200 scans, distance-gated pair list (|dt| < 3.5 m,
-    |i - j| > 20), loop-closure scan matching + pose-graph solve -- the CPU reference row, with the GPU path on
-    the same inputs beside it (examples/slam_loop.py drives both through the same host code)."""
+    """BASELINE configs[0] (SURVEY 8d 'Config #1'): 200 scans, candidate pairs from the scatter score + geometric gate
+    (|dt| < 3.5 m, |i - j| > 20), loop-closure scan matching, pose-graph solves (growing window 1..10), a HITL message
+    and its re-solve -- the CPU reference row (the oracle's backend: Jet<6> autodiff residuals, linear-scan
+    correspondences and the exhaustive scan matcher under OpenMP), with the GPU path on the same inputs beside it.
+    examples/slam_loop.py drives both through the same host code (scipy sparse solves included in both)."""
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import slam_loop
-    out = {"workload": "configs[0]: 200 dense 1081-beam scans, pairs gated at 3.5 m / |i-j| > 20, window 1..10 ICP solve "
-                       "+ loop closure + re-solve"}
-    out["gpu"] = slam_loop.run(n_scans=200, window=10, backend="hip")
+    kw = dict(n_scans=200, window=10, min_scatter_score=0.3, cell_bits=16)
+    out = {"workload": "configs[0]: 200 dense 1081-beam scans; growing-window ICP solve 1..10 (LIDARNormalResidual on all "
+                       "points), scatter-score candidates + geometric pair gate, 61x81x81 scan matching on 16-bit tables, "
+                       "constraints + re-solve, one HITL message + re-solve"}
+    slam_loop.run(n_scans=40, window=2, hitl=False, min_scatter_score=0.3)  # warm up the GPU path
+    out["gpu"] = slam_loop.run(**kw)
     if with_cpu:
-        out["cpu"] = slam_loop.run(n_scans=200, window=10, backend="oracle")
-        out["cpu"]["kind"] = "port"
+        from oracle import oracle as O
+        from oracle.cpu_backend import OracleBackend
+        out["cpu"] = slam_loop.run(backend=OracleBackend(), **kw)
+        out["cpu"].update({"kind": "port", "cores": O.num_threads()})
+        out["wall_clock_ratio_cpu_over_gpu"] = out["cpu"]["t_total_s"] / max(out["gpu"]["t_total_s"], 1e-9)
+        out["same_trajectory"] = bool(abs(out["cpu"]["err_hitl_m"] - out["gpu"]["err_hitl_m"]) < 1e-6)
     return out
 
 

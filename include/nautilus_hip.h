@@ -251,6 +251,18 @@ int nhip_corr_compact_dev(const float *d_corr_padded, const int64_t *d_cap_offse
                           const int32_t *d_counts, int32_t n_blocks, int32_t *d_block_offsets,
                           float *d_corr, int32_t *d_corr_block, void *stream);
 
+/* Loop-closure candidate gating, the step before the matcher.
+ * nhip_lc_scatter_scores*: LCCandidateFilter's ComputeScatterMatrixScore (lc_candidate_filter.cc:22-51) for every
+ * scan: float mean and scatter matrix summed in point order (the reference's float sums, bit for bit), min / max
+ * eigenvalue (closed form in double); one double per scan, NaN for an empty scan.
+ * nhip_lc_pair_gate*: for n candidate nodes (indices into poses[n_poses][3]), flags[i*n + j] = 1 iff candidates i and
+ * j are different nodes more than min_separation apart in index whose translations (as Vector2f) are closer than
+ * max_range -- a geometric stand-in for LCMatcher's per-pair ceres::Covariance test (lc_matcher.cc:28-74). */
+int nhip_lc_scatter_scores_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, double *d_scores,
+                               void *stream);
+int nhip_lc_pair_gate_dev(const double *d_poses, const int32_t *d_candidates, int32_t n_candidates, double max_range,
+                          int32_t min_separation, uint8_t *d_flags, void *stream);
+
 /* ------------------------------------------------------------------ handle API (host pointers) */
 typedef struct nhip_scans nhip_scans_t;
 typedef struct nhip_grids nhip_grids_t;
@@ -277,6 +289,11 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
 int nhip_csm_scores(const nhip_scans_t *scans, const nhip_grids_t *grids, int32_t src, int32_t slot,
                     double theta0, int32_t origin_x, int32_t origin_y, const nhip_search_t *search,
                     int32_t *out_sums);
+
+/* Host-pointer forms of the candidate gating. */
+int nhip_lc_scatter_scores(const nhip_scans_t *scans, double *scores /* n_scans */);
+int nhip_lc_pair_gate(const double *poses, int32_t n_poses, const int32_t *candidates, int32_t n_candidates,
+                      double max_range, int32_t min_separation, uint8_t *flags /* n_candidates^2 */);
 
 /* The reference-shaped single-pair call: CorrelativeScanMatcher(scanner_range, trans_range, low_res, high_res)
  * .GetTransformation(pc_a, pc_b, rot_a, rot_b, rot_restriction) -> (score, ((tx, ty), theta))

@@ -688,6 +688,59 @@ int nhip_csm_scores(const nhip_scans_t *scans, const nhip_grids_t *grids, int32_
   return NHIP_OK;
 }
 
+int nhip_lc_scatter_scores_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, double *d_scores,
+                               void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(n_scans >= 0 && (n_scans == 0 || (d_xy && d_offsets && d_scores)), "lc_scatter_scores_dev: bad arguments");
+  return launch_lc_scatter_scores(d_xy, d_offsets, n_scans, d_scores, static_cast<hipStream_t>(stream));
+}
+
+int nhip_lc_pair_gate_dev(const double *d_poses, const int32_t *d_candidates, int32_t n_candidates, double max_range,
+                          int32_t min_separation, uint8_t *d_flags, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(n_candidates >= 0 && (n_candidates == 0 || (d_poses && d_candidates && d_flags)),
+               "lc_pair_gate_dev: bad arguments");
+  return launch_lc_pair_gate(d_poses, d_candidates, n_candidates, max_range, min_separation, d_flags,
+                             static_cast<hipStream_t>(stream));
+}
+
+int nhip_lc_scatter_scores(const nhip_scans_t *scans, double *scores) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(scans && (scores || scans->n_scans == 0), "lc_scatter_scores: bad arguments");
+  if (scans->n_scans == 0) return NHIP_OK;
+  DevBuf d;
+  if ((rc = d.alloc(sizeof(double) * (size_t)scans->n_scans))) return rc;
+  rc = launch_lc_scatter_scores(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p),
+                                scans->n_scans, static_cast<double *>(d.p), nullptr);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(scores, d.p, sizeof(double) * (size_t)scans->n_scans, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_lc_pair_gate(const double *poses, int32_t n_poses, const int32_t *candidates, int32_t n, double max_range,
+                      int32_t min_separation, uint8_t *flags) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(n >= 0 && n_poses >= 0 && (n == 0 || (poses && candidates && flags)), "lc_pair_gate: bad arguments");
+  for (int32_t i = 0; i < n; i++)
+    NHIP_REQUIRE(candidates[i] >= 0 && candidates[i] < n_poses, "lc_pair_gate: candidate %d out of range", candidates[i]);
+  if (n == 0) return NHIP_OK;
+  DevBuf dp, dc, df;
+  if ((rc = dp.alloc(sizeof(double) * 3 * (size_t)n_poses)) || (rc = dc.alloc(sizeof(int32_t) * (size_t)n)) ||
+      (rc = df.alloc((size_t)n * n)))
+    return rc;
+  NHIP_TRY_HIP(hipMemcpy(dp.p, poses, sizeof(double) * 3 * (size_t)n_poses, hipMemcpyHostToDevice));
+  NHIP_TRY_HIP(hipMemcpy(dc.p, candidates, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+  rc = launch_lc_pair_gate(static_cast<const double *>(dp.p), static_cast<const int32_t *>(dc.p), n, max_range,
+                           min_separation, static_cast<uint8_t *>(df.p), nullptr);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(flags, df.p, (size_t)n * n, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
 int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, int32_t n_a, const float *pc_b,
                                 int32_t n_b, double rot_a, double rot_b, double rot_restriction, double *score,
                                 float *tx, float *ty, float *theta) {

@@ -143,6 +143,10 @@ int launch_corr_compact(const float *d_corr_padded, const int64_t *d_cap_offsets
                         const int32_t *d_counts, int32_t n_blocks, int32_t *d_block_offsets,
                         float *d_corr, int32_t *d_corr_block, hipStream_t s);
 
+int launch_lc_scatter_scores(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, double *d_scores, hipStream_t s);
+int launch_lc_pair_gate(const double *d_poses, const int32_t *d_cand, int32_t n, double max_range, int32_t min_sep,
+                        uint8_t *d_flags, hipStream_t s);
+
 int launch_resid_point_to_line(const float *d_segments, const float *d_points,
                                const int32_t *d_point_block, int64_t n_points,
                                const int32_t *d_block_pose, const int32_t *d_block_line,

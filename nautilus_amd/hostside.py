@@ -38,6 +38,44 @@ def lc_candidates(poses, scans, min_distance=5.0, min_score=0.70):
     return out
 
 
+def scatter_scores(backend, xy, offsets):
+    """ComputeScatterMatrixScore of EVERY scan in one pass of the backend (product: nhip_lc_scatter_scores)."""
+    return backend.scatter_scores(xy, offsets)
+
+
+def lc_candidates_from_scores(poses, scores, min_distance=5.0, min_score=0.70):
+    """GetLCCandidates (lc_candidate_filter.cc:64-81) on precomputed scores: walk the nodes in order, skip nodes
+    closer than 5 m (float norm of the Vector2f translations, :53-62) to the last accepted scan, accept a node whose
+    score is >= 0.70.  The walk is sequential (each accept depends on the previous one) and stays on the host."""
+    out = []
+    P = np.asarray(poses, dtype=np.float64)
+    for i in range(len(scores)):
+        if out:
+            d = P[i, :2].astype(np.float32) - P[out[-1], :2].astype(np.float32)
+            if np.float32(np.sqrt(np.float32(d[0] * d[0]) + np.float32(d[1] * d[1]))) < min_distance:
+                continue
+        if scores[i] >= min_score:
+            out.append(i)
+    return out
+
+
+def geometric_pair_gate(poses, candidates, max_range=3.5, min_separation=20, backend=None):
+    """All candidate pairs (later node = source, earlier = target) that pass the geometric gate: closer than
+    max_range (lc_base_max_range, default_config.lua:122) and more than min_separation nodes apart -- in place of
+    LCMatcher::GetPossibleMatches' per-pair ceres::Covariance (lc_matcher.cc:28-74).  With a backend the n x n
+    flags come from it (product: nhip_lc_pair_gate); the unordered pairs are then read off on the host."""
+    cand = np.asarray(candidates, dtype=np.int32)
+    if len(cand) == 0:
+        return np.zeros(0, np.int32), np.zeros(0, np.int32)
+    if backend is None:
+        from .posegraph import HipBackend
+        backend = HipBackend()
+    flags = backend.pair_gate(poses, cand, max_range, min_separation)
+    i, j = np.nonzero(flags)
+    keep = cand[i] > cand[j]
+    return cand[i[keep]].astype(np.int32), cand[j[keep]].astype(np.int32)
+
+
 def chi_square_score(cov2x2, source_xy, target_xy):
     """ChiSquareScore (lc_matcher.cc:50-57): d^T cov^-1 d with d = target - source translation, float32
     matrix as the reference casts it; cov is the cross-covariance block of the two poses."""
@@ -58,6 +96,48 @@ def lc_possible_matches(source, candidates, poses, covariance_fn, max_score=5000
         if chi_square_score(m, poses[source][:2], poses[c][:2]) < max_score:
             out.append(c)
     return out
+
+
+def distance_to_line_segment_f32(points, seg):
+    """DistanceToLineSegment<float> (slam_util.h:92-110) for an (n, 2) float32 array: Hyperplane::Through normal,
+    projection inside the endpoints' closed x and y intervals -> |signed distance|, else nearest endpoint."""
+    f = np.float32
+    p = np.asarray(points, dtype=f).reshape(-1, 2)
+    x0, y0, x1, y1 = (f(v) for v in seg)
+    dx, dy = f(x1 - x0), f(y1 - y0)
+    nx, ny = f(-dy), dx
+    ln = f(np.sqrt(f(f(nx * nx) + f(ny * ny))))
+    nx, ny = f(nx / ln), f(ny / ln)
+    off = f(-f(f(x0 * nx) + f(y0 * ny)))
+    sd = (p[:, 0] * nx + p[:, 1] * ny + off).astype(f)
+    prx, pry = (p[:, 0] - sd * nx).astype(f), (p[:, 1] - sd * ny).astype(f)
+    between = lambda v, a, b: ((v >= a) & (v <= b)) | ((v >= b) & (v <= a))
+    inside = between(prx, x0, x1) & between(pry, y0, y1)
+    d0 = np.sqrt((p[:, 0] - x0) ** 2 + (p[:, 1] - y0) ** 2).astype(f)
+    d1 = np.sqrt((p[:, 0] - x1) ** 2 + (p[:, 1] - y1) ** 2).astype(f)
+    return np.where(inside, np.abs(sd), np.minimum(d0, d1)).astype(f)
+
+
+def hitl_relevant_poses(poses, scans, line_a, line_b, line_width=0.05, point_threshold=10):
+    """GetRelevantPosesForHITL (solver.cc:479-513): per node, the points (scan frame) whose world position under the
+    node's pose (Affine2f, float) lies within hitl_line_width of line a -- else of line b; a node with at least
+    hitl_pose_point_threshold points on a joins line_a_poses, else with that many on b joins line_b_poses.
+    Returns (a_poses, b_poses): lists of (node index, points (k, 2) float32)."""
+    a_poses, b_poses = [], []
+    for i, pts in enumerate(scans):
+        pts = np.asarray(pts, dtype=np.float32).reshape(-1, 2)
+        if len(pts) == 0:
+            continue
+        c, s = np.float32(np.cos(poses[i][2])), np.float32(np.sin(poses[i][2]))
+        tx, ty = np.float32(poses[i][0]), np.float32(poses[i][1])
+        w = np.stack([c * pts[:, 0] - s * pts[:, 1] + tx, s * pts[:, 0] + c * pts[:, 1] + ty], axis=1).astype(np.float32)
+        on_a = distance_to_line_segment_f32(w, line_a) <= line_width
+        on_b = ~on_a & (distance_to_line_segment_f32(w, line_b) <= line_width)
+        if on_a.sum() >= point_threshold:
+            a_poses.append((i, pts[on_a]))
+        elif on_b.sum() >= point_threshold:
+            b_poses.append((i, pts[on_b]))
+    return a_poses, b_poses
 
 
 def write_poses(path, timestamps, poses):

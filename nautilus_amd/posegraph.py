@@ -8,10 +8,15 @@ batched API instead:
   * odometry factors (OdometryResidual, slam_residuals.h:18-40; AddOdomFactors solver.cc:370-387)
     and loop-closure constraints from the scan matcher ("Add Odometry residual using the returned
     relative transform", the TODO at solver.cc:651-660), both evaluated by nhip_resid_odometry_dev;
-  * Gauss-Newton with Levenberg damping on the assembled sparse 3N x 3N system (scipy.sparse on the
-    host: N poses x 3, a few thousand unknowns), first pose held constant (solver.cc:384-386).
+  * HITL constraints (solver.cc:479-559): PointToLineResidual blocks of the points the user's two
+    segments select, every block against line_a and one shared `chosen_line_pose` parameter block
+    (AddHITLResiduals, solver.cc:515-532), evaluated by nhip_resid_point_to_line;
+  * Gauss-Newton with Levenberg damping on the assembled sparse system (scipy.sparse on the
+    host: N poses x 3 + 3 per HITL constraint), first pose held constant (solver.cc:384-386).
 Only the linear solve and the bookkeeping are host work; every residual, Jacobian and nearest
-neighbour comes from the HIP kernels.
+neighbour comes from the backend -- HipBackend (the product: libnautilus_hip) unless a test or the
+bench's cpu_baseline leg injects another one (oracle/cpu_backend.py times the same loop on the CPU
+restatement; the product never imports it).
 """
 import ctypes as C
 import math
@@ -29,32 +34,101 @@ def compose(pose, rel):
     return np.array([pose[0] + c * rel[0] - s * rel[1], pose[1] + s * rel[0] + c * rel[1], pose[2] + rel[2]])
 
 
+class HipBackend:
+    """Every evaluation on the MI355X through the C ABI."""
+    name = "hip"
+
+    def __init__(self, device="cuda:0"):
+        import torch
+        self.torch, self.dev, self.lib = torch, torch.device(device), _lib.load()
+
+    def icp(self, xy, normals, offsets, block_src, block_tgt, outlier_threshold):
+        return _HipIcp(IcpBatch(xy, normals, offsets, block_src, block_tgt, str(self.dev), outlier_threshold))
+
+    def odometry(self, pose_i, pose_j, t_odom, r_odom, tw, rw, poses):
+        """OdometryResidual blocks at `poses` (n, 3): residuals (F, 3), Jacobians (F, 3, 3) x 2."""
+        n = len(pose_i)
+        r, ji, jj = np.empty((n, 3)), np.empty((n, 3, 3)), np.empty((n, 3, 3))
+        P = np.ascontiguousarray(poses, dtype=np.float64)
+        check(self.lib.nhip_resid_odometry(_lib.ptr(t_odom), _lib.ptr(r_odom), _lib.ptr(pose_i), _lib.ptr(pose_j), n,
+                                           float(tw), float(rw), _lib.ptr(P), len(P), _lib.ptr(r), _lib.ptr(ji), _lib.ptr(jj)))
+        return r, ji, jj
+
+    def point_to_line(self, segments, points, point_block, block_pose, block_line, poses, line_poses):
+        """PointToLineResidual blocks: residuals (n,), d/d pose (n, 3), d/d line_pose (n, 3)."""
+        n = len(points)
+        r, j0, j1 = np.empty(n), np.empty((n, 3)), np.empty((n, 3))
+        P, Lp = np.ascontiguousarray(poses, dtype=np.float64), np.ascontiguousarray(line_poses, dtype=np.float64)
+        check(self.lib.nhip_resid_point_to_line(_lib.ptr(segments), _lib.ptr(points), _lib.ptr(point_block), n,
+                                                _lib.ptr(block_pose), _lib.ptr(block_line), len(block_pose), _lib.ptr(P), len(P),
+                                                _lib.ptr(Lp), len(Lp), _lib.ptr(r), _lib.ptr(j0), _lib.ptr(j1)))
+        return r, j0, j1
+
+    def scatter_scores(self, xy, offsets):
+        """LCCandidateFilter's scatter-matrix score of every scan (nhip_lc_scatter_scores)."""
+        from . import csm
+        st = csm.ScanTable(xy, offsets)
+        out = np.empty(st.n_scans)
+        check(self.lib.nhip_lc_scatter_scores(st._h, _lib.ptr(out)))
+        st.close()
+        return out
+
+    def pair_gate(self, poses, candidates, max_range, min_separation):
+        P = np.ascontiguousarray(poses, dtype=np.float64)
+        cand = np.ascontiguousarray(candidates, dtype=np.int32)
+        flags = np.zeros((len(cand), len(cand)), dtype=np.uint8)
+        check(self.lib.nhip_lc_pair_gate(_lib.ptr(P), len(P), _lib.ptr(cand), len(cand), float(max_range),
+                                         int(min_separation), _lib.ptr(flags)))
+        return flags
+
+    def match(self, xy, offsets, pair_src, pair_tgt, theta0, cell_bits=8):
+        """Batched loop-closure scan matching (BASELINE config #2 lattice): (records, spec, search)."""
+        from . import csm
+        spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits)
+        search = csm.search_spec(61, 81, 81, math.radians(1.0))
+        ids = np.unique(pair_tgt)
+        st = csm.ScanTable(xy, offsets)
+        grids = csm.LikelihoodGrids(st, ids, spec)
+        m, _ = csm.match_pairs(st, grids, pair_src, np.searchsorted(ids, pair_tgt).astype(np.int32), theta0, search)
+        grids.close()
+        st.close()
+        return m, spec, search
+
+
+class _HipIcp:
+    def __init__(self, batch):
+        self.b = batch
+        self.block_src, self.block_tgt = batch.block_src, batch.block_tgt
+
+    def set_poses(self, poses):
+        self.b.set_poses(poses)
+
+    def search(self):
+        return self.b.search()
+
+    def normal_equations(self, kind):
+        return self.b.normal_equations(kind).cpu().numpy()
+
+    @property
+    def n_corr(self):
+        return self.b.n_corr
+
+
 class OdometryFactors:
     """Batched OdometryResidual blocks: r = (w_t (T_i + T_odom - T_j), w_r wrap(th_i + R_odom - th_j))."""
 
-    def __init__(self, pose_i, pose_j, t_odom, r_odom, tw=1.0, rw=1.0, device="cuda:0"):
-        import torch
-        self.torch, self.dev = torch, torch.device(device)
+    def __init__(self, pose_i, pose_j, t_odom, r_odom, tw=1.0, rw=1.0):
         self.n = len(pose_i)
         self.pose_i = np.ascontiguousarray(pose_i, dtype=np.int32)
         self.pose_j = np.ascontiguousarray(pose_j, dtype=np.int32)
-        t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(self.dev)
-        self.d_i, self.d_j = t(self.pose_i, np.int32), t(self.pose_j, np.int32)
-        self.d_t, self.d_r = t(np.reshape(t_odom, (-1, 2)), np.float32), t(r_odom, np.float32)
+        self.t_odom = np.ascontiguousarray(np.reshape(t_odom, (-1, 2)), dtype=np.float32)
+        self.r_odom = np.ascontiguousarray(r_odom, dtype=np.float32)
         self.tw, self.rw = float(tw), float(rw)
-        self.d_res = torch.empty(3 * max(self.n, 1), dtype=torch.float64, device=self.dev)
-        self.d_ji = torch.empty(9 * max(self.n, 1), dtype=torch.float64, device=self.dev)
-        self.d_jj = torch.empty(9 * max(self.n, 1), dtype=torch.float64, device=self.dev)
 
-    def evaluate(self, d_poses):
+    def evaluate(self, backend, poses):
         if self.n == 0:
             return np.zeros((0, 3)), np.zeros((0, 3, 3)), np.zeros((0, 3, 3))
-        sp = C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
-        check(_lib.load().nhip_resid_odometry_dev(self.d_t.data_ptr(), self.d_r.data_ptr(), self.d_i.data_ptr(),
-                                                  self.d_j.data_ptr(), self.n, self.tw, self.rw, d_poses.data_ptr(),
-                                                  self.d_res.data_ptr(), self.d_ji.data_ptr(), self.d_jj.data_ptr(), sp))
-        return (self.d_res.cpu().numpy().reshape(-1, 3), self.d_ji.cpu().numpy().reshape(-1, 3, 3),
-                self.d_jj.cpu().numpy().reshape(-1, 3, 3))
+        return backend.odometry(self.pose_i, self.pose_j, self.t_odom, self.r_odom, self.tw, self.rw, poses)
 
 
 def odometry_factors_from_poses(odom, **kw):
@@ -78,31 +152,61 @@ def loop_closure_factors(poses, pairs_src, pairs_tgt, rel, **kw):
                            np.asarray(r_odom), **kw)
 
 
+class HitlConstraint:
+    """HitlLCConstraint (data_structures.h:41-51) + its residual blocks (AddHITLResiduals, solver.cc:515-532): the
+    points GetRelevantPosesForHITL selected on line a and on line b, EVERY block a PointToLineResidual against
+    line_a, all sharing one extra parameter block `chosen_line_pose` (initialised to zero)."""
+
+    def __init__(self, line_a, line_b, a_poses, b_poses):
+        self.line_a = np.ascontiguousarray(line_a, dtype=np.float32).reshape(4)
+        self.line_b = np.ascontiguousarray(line_b, dtype=np.float32).reshape(4)
+        self.blocks = [(int(i), np.ascontiguousarray(p, dtype=np.float32).reshape(-1, 2)) for i, p in list(a_poses) + list(b_poses)]
+        self.n_a, self.n_b = len(a_poses), len(b_poses)
+        self.chosen_line_pose = np.zeros(3)
+
+    def arrays(self, line_index):
+        nb = len(self.blocks)
+        seg = np.tile(self.line_a, (nb, 1)).astype(np.float32)
+        pts = np.concatenate([p for _, p in self.blocks]).astype(np.float32) if nb else np.zeros((0, 2), np.float32)
+        pb = np.concatenate([np.full(len(p), k, np.int32) for k, (_, p) in enumerate(self.blocks)]) if nb else np.zeros(0, np.int32)
+        bp = np.array([i for i, _ in self.blocks], dtype=np.int32)
+        bl = np.full(nb, line_index, dtype=np.int32)
+        return seg, pts, pb, bp, bl
+
+
 class PoseGraph:
     def __init__(self, xy, normals, offsets, odom, window=10, kind=_lib.NHIP_LIDAR_POINT, outlier_threshold=0.25,
-                 odom_weights=(1.0, 1.0), device="cuda:0", initial=None):
+                 odom_weights=(1.0, 1.0), device="cuda:0", initial=None, backend=None):
         self.n = len(odom)
         self.kind = kind
+        self.backend = backend if backend is not None else HipBackend(device)
         bs, bt = window_pairs(self.n, window)
-        self.icp = IcpBatch(xy, normals, offsets, bs, bt, device, outlier_threshold)
-        self.odo = odometry_factors_from_poses(odom, tw=odom_weights[0], rw=odom_weights[1], device=device)
+        self.icp = self.backend.icp(xy, normals, offsets, bs, bt, outlier_threshold)
+        self.odo = odometry_factors_from_poses(odom, tw=odom_weights[0], rw=odom_weights[1])
         self.lc = None
+        self.hitl = []
         # odometry factors always come from `odom`; the estimate may start elsewhere (previous window pass)
         self.poses = np.array(odom if initial is None else initial, dtype=np.float64)
 
     def add_loop_closures(self, pairs_src, pairs_tgt, rel, weights=(10.0, 10.0)):
-        self.lc = loop_closure_factors(self.poses, pairs_src, pairs_tgt, rel, tw=weights[0], rw=weights[1],
-                                       device=str(self.icp.dev))
+        self.lc = loop_closure_factors(self.poses, pairs_src, pairs_tgt, rel, tw=weights[0], rw=weights[1])
 
-    def _assemble(self, poses, research):
+    def add_hitl(self, constraint):
+        self.hitl.append(constraint)
+
+    @property
+    def n_unknowns(self):
+        return 3 * self.n + 3 * len(self.hitl)
+
+    def _assemble(self, poses, lines, research):
         import scipy.sparse as sp
-        N = self.n
+        N, NU = self.n, self.n_unknowns
         self.icp.set_poses(poses)
         if research:
             self.icp.search()  # correspondences are rebuilt per solve, like each window pass of the reference
-        neq = self.icp.normal_equations(self.kind).cpu().numpy()
+        neq = self.icp.normal_equations(self.kind)
         rows, cols, vals = [], [], []
-        g = np.zeros(3 * N)
+        g = np.zeros(NU)
         cost = 0.5 * float(neq[:, 27].sum()) if len(neq) else 0.0
         iu = np.triu_indices(6)
         bs, bt = self.icp.block_src, self.icp.block_tgt
@@ -117,7 +221,7 @@ class PoseGraph:
         for fac in (self.odo, self.lc):
             if fac is None or fac.n == 0:
                 continue
-            r, ji, jj = fac.evaluate(self.icp.d_poses)
+            r, ji, jj = fac.evaluate(self.backend, poses)
             J = np.concatenate([ji, jj], axis=2)  # (F, 3, 6)
             Hf = np.einsum("fki,fkj->fij", J, J)
             gf = np.einsum("fki,fk->fi", J, r)
@@ -127,19 +231,35 @@ class PoseGraph:
             vals.append(Hf.ravel())
             np.add.at(g, idf.ravel(), gf.ravel())
             cost += 0.5 * float((r * r).sum())
-        H = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(3 * N, 3 * N)).tocsc()
+        for c, con in enumerate(self.hitl):
+            seg, pts, pb, bp, bl = con.arrays(c)
+            if len(pts) == 0:
+                continue
+            r, j0, j1 = self.backend.point_to_line(seg, pts, pb, bp, bl, poses, lines)
+            J = np.concatenate([j0, j1], axis=1)  # (n, 6): d/d pose of the point's node, d/d chosen_line_pose
+            ids = np.concatenate([3 * bp[pb][:, None] + np.arange(3), np.full((len(pts), 1), 3 * N + 3 * c) + np.arange(3)], axis=1)
+            Hp = np.einsum("ni,nj->nij", J, J)
+            rows.append(np.repeat(ids, 6, axis=1).ravel())
+            cols.append(np.tile(ids, (1, 6)).ravel())
+            vals.append(Hp.ravel())
+            np.add.at(g, ids.ravel(), (J * r[:, None]).ravel())
+            cost += 0.5 * float((r * r).sum())
+        H = sp.coo_matrix((np.concatenate(vals), (np.concatenate(rows), np.concatenate(cols))), shape=(NU, NU)).tocsc()
         return H, g, cost
+
+    def _lines(self):
+        return np.array([c.chosen_line_pose for c in self.hitl], dtype=np.float64).reshape(-1, 3)
 
     def cross_covariances(self, pairs):
         """Covariance blocks the way LCMatcher asks Ceres for them (GetCovarianceMatrix,
         lc_matcher.cc:28-46): the (source pose, target pose) cross block of (J^T J)^-1 of the current
         problem with the pose just before the earlier of the two held constant instead of pose 0;
         returns the top-left 2 x 2 (translation) of each 3 x 3 block, float32 like the reference.
-        J^T J comes from the GPU's per-block normal equations; the sparse solves are host work."""
+        J^T J comes from the backend's per-block normal equations; the sparse solves are host work."""
         import scipy.sparse as sp
         from scipy.sparse.linalg import splu
-        H, _, _ = self._assemble(self.poses, research=False)
-        H = H.tocsc()
+        H, _, _ = self._assemble(self.poses, self._lines(), research=False)
+        H = H.tocsc()[:3 * self.n][:, :3 * self.n]
         out = np.zeros((len(pairs), 2, 2), dtype=np.float32)
         by_gauge = {}
         for k, (s_, t_) in enumerate(pairs):
@@ -164,41 +284,50 @@ class PoseGraph:
         """Gauss-Newton with Levenberg damping; pose 0 constant (SetParameterBlockConstant, solver.cc:384-386)."""
         import scipy.sparse as sp
         from scipy.sparse.linalg import spsolve
-        poses = self.poses.copy()
-        H, g, cost = self._assemble(poses, research=True)
+        poses, lines = self.poses.copy(), self._lines()
+        H, g, cost = self._assemble(poses, lines, research=True)
         history = [cost]
-        free = np.arange(3, 3 * self.n)
+        NU = self.n_unknowns
+        free = np.arange(3, NU)
         lam = damping
         for it in range(iterations):
             Hf = H[free][:, free]
-            step = np.zeros(3 * self.n)
+            step = np.zeros(NU)
             step[free] = spsolve(Hf + lam * sp.diags(Hf.diagonal() + 1e-9), -g[free])
-            trial = poses + step.reshape(-1, 3)
-            H2, g2, cost2 = self._assemble(trial, research=False)
+            trial = poses + step[:3 * self.n].reshape(-1, 3)
+            trial_lines = lines + step[3 * self.n:].reshape(-1, 3)
+            H2, g2, cost2 = self._assemble(trial, trial_lines, research=False)
             if cost2 < cost:
-                poses, H, g, cost, lam = trial, H2, g2, cost2, max(lam * 0.3, 1e-9)
+                poses, lines, H, g, cost, lam = trial, trial_lines, H2, g2, cost2, max(lam * 0.3, 1e-9)
             else:
                 lam *= 10.0
-                H, g, cost = self._assemble(poses, research=False)
+                H, g, cost = self._assemble(poses, lines, research=False)
             history.append(cost)
             if verbose:
                 print("iter %d cost %.6g lambda %.2g" % (it, cost, lam))
         self.poses = poses
+        for c, con in enumerate(self.hitl):
+            con.chosen_line_pose = lines[c].copy()
         return poses, history
 
 
 def solve_growing_window(xy, normals, offsets, odom, window_min=1, window_max=10, iterations=4,
                          kind=_lib.NHIP_LIDAR_POINT, outlier_threshold=0.25, odom_weights=(1.0, 1.0),
-                         device="cuda:0", verbose=False):
+                         device="cuda:0", verbose=False, backend=None, initial=None, hitl=(), loop_closures=None):
     """Solver::OptimizeOverGrowingWindow (solver.cc:339-355): for every window size from
-    lidar_constraint_amount_min to _max the problem is rebuilt -- odometry factors plus fresh
-    correspondences for all (i, j) blocks of the window, searched at the current estimate -- and solved.
-    Returns (PoseGraph of the last pass, poses, total correspondences of the last pass)."""
-    poses = np.array(odom, dtype=np.float64)
+    lidar_constraint_amount_min to _max the problem is rebuilt -- odometry factors, HITL residuals
+    (AddHITLResiduals) plus fresh correspondences for all (i, j) blocks of the window, searched at the current
+    estimate -- and solved.  Returns (PoseGraph of the last pass, poses)."""
+    poses = np.array(odom if initial is None else initial, dtype=np.float64)
+    backend = backend if backend is not None else HipBackend(device)
     pg = None
     for w in range(window_min, window_max + 1):
         pg = PoseGraph(xy, normals, offsets, odom, window=w, kind=kind, outlier_threshold=outlier_threshold,
-                       odom_weights=odom_weights, device=device, initial=poses)
+                       odom_weights=odom_weights, device=device, initial=poses, backend=backend)
+        for con in hitl:
+            pg.add_hitl(con)
+        if loop_closures is not None:
+            pg.add_loop_closures(*loop_closures)
         poses, hist = pg.solve(iterations=iterations, verbose=verbose)
         if verbose:
             print("window %d: cost %.6g -> %.6g" % (w, hist[0], hist[-1]))

@@ -134,6 +134,27 @@ def corr_search_gated_batch(xy, normals, offsets, block_src, block_tgt, pose_aff
     return corr, counts, cap
 
 
+def scatter_matrix_scores(xy, offsets):
+    """ComputeScatterMatrixScore (lc_candidate_filter.cc:35-51) of every scan."""
+    xy = np.ascontiguousarray(xy, dtype=np.float32)
+    offsets = np.ascontiguousarray(offsets, dtype=np.int32)
+    out = np.zeros(len(offsets) - 1)
+    fn = load().orc_scatter_matrix_scores
+    fn.argtypes, fn.restype = [_vp, _vp, _i32, _vp], None
+    fn(_p(xy), _p(offsets), len(offsets) - 1, _p(out))
+    return out
+
+
+def pair_gate(poses, candidates, max_range, min_separation):
+    poses = np.ascontiguousarray(poses, dtype=np.float64)
+    cand = np.ascontiguousarray(candidates, dtype=np.int32)
+    flags = np.zeros((len(cand), len(cand)), dtype=np.uint8)
+    fn = load().orc_pair_gate
+    fn.argtypes, fn.restype = [_vp, _vp, _i32, _f64, _i32, _vp], None
+    fn(_p(poses), _p(cand), len(cand), float(max_range), int(min_separation), _p(flags))
+    return flags
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(_vp)
 

@@ -588,3 +588,55 @@ int orc_corr_search_batch(const float *xy, const float *normals, const int32_t *
 }
 
 }  // extern "C"
+
+
+// =====================================================================================
+// Loop-closure candidate gating -- CPU restatement of
+//   src/loop_closure/lc_candidate_filter.cc:22-51  ComputeMean, ComputeScatterMatrixScore
+// (float accumulators, point order; built with -ffp-contract=off so products and sums round individually, as Eigen's
+// Vector2f / Matrix2f expressions do on baseline x86-64).  The reference takes the eigenvalues with Eigen's iterative
+// EigenSolver<Matrix2f>; here, as in the product, they are the closed form of the symmetric 2 x 2 matrix in double
+// (agreement to float rounding; Eigen is not in the image).  The pair gate is the build's geometric stand-in for
+// LCMatcher::GetPossibleMatches (lc_matcher.cc:59-74).
+extern "C" {
+
+double orc_scatter_matrix_score(const float *xy, int32_t n) {
+  float mx = 0.f, my = 0.f;
+  for (int32_t i = 0; i < n; i++) { mx += xy[2 * i]; my += xy[2 * i + 1]; }
+  const float inv = (float)(1.0 / (double)n);
+  mx = inv * mx; my = inv * my;
+  float a = 0.f, b = 0.f, c = 0.f, d = 0.f;
+  for (int32_t i = 0; i < n; i++) {
+    const float dx = xy[2 * i] - mx, dy = xy[2 * i + 1] - my;
+    const float xx = dx * dx, xy_ = dx * dy, yx = dy * dx, yy = dy * dy;
+    a += xx; b += xy_; c += yx; d += yy;
+  }
+  const double A = a, B = b, C = c, D = d;
+  const double half_tr = 0.5 * (A + D), half_df = 0.5 * (A - D);
+  const double p1 = half_df * half_df, p2 = B * C;
+  const double disc = p1 + p2;
+  const double root = std::sqrt(disc < 0.0 ? 0.0 : disc);
+  const double e1 = half_tr + root, e2 = half_tr - root;
+  const double lo = e1 < e2 ? e1 : e2, hi = e1 < e2 ? e2 : e1;
+  return lo / hi;
+}
+
+void orc_scatter_matrix_scores(const float *xy, const int32_t *offsets, int32_t n_scans, double *scores) {
+  for (int32_t s = 0; s < n_scans; s++)
+    scores[s] = orc_scatter_matrix_score(xy + 2 * (size_t)offsets[s], offsets[s + 1] - offsets[s]);
+}
+
+void orc_pair_gate(const double *poses, const int32_t *cand, int32_t n, double max_range, int32_t min_sep, uint8_t *flags) {
+  const float mr = (float)max_range;
+  for (int32_t i = 0; i < n; i++)
+    for (int32_t j = 0; j < n; j++) {
+      const int32_t a = cand[i], b = cand[j];
+      const float dx = (float)poses[3 * b] - (float)poses[3 * a], dy = (float)poses[3 * b + 1] - (float)poses[3 * a + 1];
+      const float xx = dx * dx, yy = dy * dy;
+      const float dist = std::sqrt(xx + yy);
+      const int32_t sep = a > b ? a - b : b - a;
+      flags[(size_t)i * n + j] = (a != b && sep > min_sep && dist < mr) ? 1 : 0;
+    }
+}
+
+}  // extern "C"

@@ -552,3 +552,51 @@ def test_cell_width_against_unquantised_table(gpu):
     assert report[16][0] < 1e-5           # measured 4e-6 (float32 record: 6e-8)
     assert report[8][0] < 1e-3 and report[8][2] < 1e-3   # 8-bit: ~1e-4, near-ties only
     assert report[8][0] > report[16][0]
+
+
+def test_config4_per_gpu_share(gpu):
+    """BASELINE configs[3] (10k scans, 1M pairs over 8 GPUs) at one GPU's share: 1250 scans, 125,000 candidate pairs
+    (100 per target) through bench.py's own sharded step at world size 1.  Checks: the branch-and-bound matcher and
+    the kernel that performs every add return the same 125,000 records and sums; an oracle sample is bit-exact;
+    properties that hold at any size: pairs of the same (source, target, theta0) get the same record, a pair matched
+    against itself peaks at the lattice centre, scores are the formula of their sums."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from nautilus_amd import sharding
+    wl = bench.Workload("config4", 8, scans=1250, per_target=100)
+    assert wl.n_pairs == 125000 and wl.n_scans == 1250
+    # self pairs and duplicates replace the first pairs of the list (same targets, so the partition is unchanged)
+    wl.src[:50] = wl.tgt[:50]
+    wl.th0[:50] = 0.0
+    wl.src[50:100], wl.th0[50:100] = wl.src[100:150], wl.th0[100:150]
+    wl.tgt[50:100] = wl.tgt[100:150]
+    plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
+    dev = torch.device("cuda", 0)
+    m = bench.HipMatcher(wl, plan.shard(0), dev, 8)
+    elapsed, full = bench.run_sharded(plan, 0, 1, dev, m, steps=1, warmup=0)
+    rec = full.cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
+    sums = np.empty(wl.n_pairs, np.int32)
+    sums[plan.order] = m.d_sums[:m.n_pairs].cpu().numpy()
+    m.free_grids()
+    mx = bench.HipMatcher(wl, plan.shard(0), dev, 8, exhaustive=True)
+    _, full_x = bench.run_sharded(plan, 0, 1, dev, mx, steps=1, warmup=0)
+    assert torch.equal(full, full_x), "branch and bound differs from the exhaustive kernel"
+    mx.free_grids()
+    # self pairs: rotation 0 (k = 30), no shift (ix = iy = 40)
+    assert np.all(rec["itheta"][:50] == 30) and np.all(rec["ix"][:50] == 40) and np.all(rec["iy"][:50] == 40)
+    assert rec[50:100].tobytes() == rec[100:150].tobytes()
+    Lf, step = math.log(1e-10), -math.log(1e-10) / 255.0
+    assert np.array_equal(rec["score"], (Lf + step * sums.astype(np.float64) / 1081.0).astype(np.float32))
+    assert np.all((rec["itheta"] >= 0) & (rec["itheta"] < 61) & (rec["ix"] >= 0) & (rec["ix"] < 81) & (rec["iy"] < 81))
+    # oracle sample
+    sel = np.r_[0:4, 60:64, np.random.default_rng(0).choice(wl.n_pairs, 40, replace=False)]
+    ospec, oss = O.grid_spec(), O.search_spec(61, 81, 81, DEG)
+    ids = np.unique(wl.tgt[sel])
+    og = O.grid_build_batch(wl.xy, wl.off, ids, ospec)
+    want = O.csm_match_batch(wl.xy, wl.off, og, ospec, wl.src[sel], np.searchsorted(ids, wl.tgt[sel]), wl.th0[sel], oss)
+    for f in ("itheta", "ix", "iy"):
+        assert np.array_equal(rec[f][sel], want[f])
+    assert np.array_equal(sums[sel], want["sum"])

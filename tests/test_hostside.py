@@ -52,3 +52,32 @@ def test_chi_square_gate_mirrors_lc_matcher():
     assert calls == [[(0, 1), (0, 2), (0, 3)]]          # one batched covariance request, self excluded
     assert got == [1, 3]                                  # 1000 and 166.7 pass, 900000 does not
     assert hostside.lc_possible_matches(2, [2], poses, provider) == []
+
+
+def test_hitl_relevant_poses_mirror_get_relevant_poses_for_hitl():
+    """GetRelevantPosesForHITL (solver.cc:479-513): float world points, DistanceToLineSegment<float> <= 0.05, a point
+    on line a is not tested against line b, a pose needs 10 points and joins a before b."""
+    from oracle import oracle as O
+    rng = np.random.default_rng(1)
+    line_a, line_b = np.array([0, 0, 10, 0], np.float32), np.array([0, 5, 10, 5], np.float32)
+    on_a = np.stack([np.linspace(1, 9, 30), rng.uniform(-0.04, 0.04, 30)], 1)
+    on_b = np.stack([np.linspace(1, 9, 12), 5 + rng.uniform(-0.04, 0.04, 12)], 1)
+    few_a = on_a[:9]
+    off = rng.uniform(1, 4, (50, 2))
+    poses = np.array([[0, 0, 0], [1.0, 0.5, 0.3], [0, 0, 0], [0, 0, 0]], dtype=float)
+
+    def to_scan(world, pose):  # inverse pose: world -> scan frame
+        c, s = np.cos(-pose[2]), np.sin(-pose[2])
+        d = world - pose[:2]
+        return np.stack([c * d[:, 0] - s * d[:, 1], s * d[:, 0] + c * d[:, 1]], 1).astype(np.float32)
+    scans = [to_scan(np.concatenate([on_a, on_b, off]), poses[0]), to_scan(np.concatenate([on_b, off]), poses[1]),
+             to_scan(np.concatenate([few_a, off]), poses[2]), np.zeros((0, 2), np.float32)]
+    a_poses, b_poses = hostside.hitl_relevant_poses(poses, scans, line_a, line_b)
+    assert [i for i, _ in a_poses] == [0] and [i for i, _ in b_poses] == [1]   # pose 0 has both: it joins a only
+    assert len(a_poses[0][1]) == 30 and len(b_poses[0][1]) == 12
+    # the float distance used for the selection is the oracle's DistanceToLineSegment<float> (the six KATs pin it)
+    w = np.array([[1.0, 1.0], [0.0, 2.0], [4.0, 4.0], [-2.0, -2.0], [2.0, 2.0], [2.5, 0.1]], np.float32)
+    seg = np.array([0, 0, 2, 2], np.float32)
+    got = hostside.distance_to_line_segment_f32(w, seg)
+    want = np.array([O.dist_to_segment_f(p, seg[:2], seg[2:]) for p in w], np.float32)
+    assert np.array_equal(got, want)

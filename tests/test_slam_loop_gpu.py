@@ -6,18 +6,43 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_loop_closure_reduces_trajectory_error(gpu):
+def _slam_loop():
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples"))
     import slam_loop
-    out = slam_loop.run(n_scans=320, window=5)
+    return slam_loop
+
+
+def test_loop_closure_and_hitl_reduce_trajectory_error(gpu):
+    """BASELINE configs[4] shape on one GPU at test size: growing window 1..10 (solver.cc:335-356), candidate scans
+    from the GPU scatter score + geometric pair gate, batched scan matching, constraints, re-solve, then a HITL
+    message (two segments on one wall) handled as Solver::HitlCallback does (solver.cc:479-559)."""
+    out = _slam_loop().run(n_scans=420, window=10, min_scatter_score=0.3)
     print(out)
-    assert out["icp_correspondences"] > 100000
-    assert out["lc_accepted"] >= 10
+    assert out["window"] == 10 and out["icp_correspondences"] > 500000
+    assert out["lc_candidate_scans"] >= 10 and out["lc_candidates"] >= 5 and out["lc_accepted"] >= 3
     assert out["lc_rel_err_m"] < 0.08           # matcher recovers the relative transform to about a cell
     assert out["err_icp_m"] < 0.25 * out["err_odometry_m"]   # growing-window ICP on point-to-plane residuals
     assert out["err_lc_m"] < 0.25 * out["err_odometry_m"]    # constraints at one-cell (5 cm) resolution do no harm
+    # the HITL constraint found both groups of poses and its blocks moved the shared line pose, without harm
+    assert out["hitl_line_a_poses"] >= 5 and out["hitl_line_b_poses"] >= 5 and out["hitl_points"] >= 200
+    assert any(abs(v) > 1e-6 for v in out["hitl_chosen_line_pose"])
+    assert out["err_hitl_m"] < 0.25 * out["err_odometry_m"]
+
+
+def test_same_loop_on_the_cpu_backend_agrees(gpu):
+    """The loop driven through the oracle's CPU backend (tests / bench only) and through the product: the same
+    host code, the same correspondences and candidate pairs, trajectories equal to solver precision."""
+    from oracle.cpu_backend import OracleBackend
+    sl = _slam_loop()
+    a = sl.run(n_scans=120, window=3, min_scatter_score=0.3, hitl=False, cell_bits=8)
+    b = sl.run(n_scans=120, window=3, min_scatter_score=0.3, hitl=False, cell_bits=8, backend=OracleBackend())
+    print(a, b)
+    assert a["backend"] == "hip" and b["backend"] == "oracle"
+    assert a["icp_correspondences"] == b["icp_correspondences"] and a["lc_candidates"] == b["lc_candidates"]
+    assert a["lc_accepted"] == b["lc_accepted"]
+    assert abs(a["err_icp_m"] - b["err_icp_m"]) < 1e-6 and abs(a.get("err_lc_m", 0) - b.get("err_lc_m", 0)) < 1e-6
 
 
 def test_cross_covariance_blocks_match_dense_inverse(gpu):
@@ -32,7 +57,7 @@ def test_cross_covariance_blocks_match_dense_inverse(gpu):
     pg.solve(iterations=3)
     pairs = [(30, 5), (5, 30), (12, 13), (1, 39), (7, 0)]
     got = pg.cross_covariances(pairs)
-    H, _, _ = pg._assemble(pg.poses, research=False)
+    H, _, _ = pg._assemble(pg.poses, pg._lines(), research=False)
     Hd = H.toarray()
     for (s_, t_), g in zip(pairs, got):
         gauge = max(min(s_, t_) - 1, 0)
