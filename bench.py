@@ -693,10 +693,12 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
         hnd = C.c_void_p()
         _lib.check(lib.nhip_resid_batch_create(0, _lib.ptr(h_corr), _lib.ptr(h_off), _lib.ptr(h_bs), _lib.ptr(h_bt),
                                                n_blocks, 1000, C.byref(hnd)))
-        h_r = np.empty(2 * n_corr)
-        h_js, h_jt = np.empty(6 * n_corr), np.empty(6 * n_corr)
-        ev = lambda j: _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(h_r),
-                                                            _lib.ptr(h_js) if j else None, _lib.ptr(h_jt) if j else None))
+        # pinned result buffers (what the C++ adapter allocates with nhip_host_alloc)
+        pin = lambda n: torch.empty(n, dtype=torch.float64).pin_memory().numpy()
+        h_r, h_js, h_jtt = pin(2 * n_corr), pin(6 * n_corr), pin(2 * n_corr)
+        ev = lambda j: _lib.check(lib.nhip_resid_batch_eval_compact(hnd, _lib.ptr(h_poses), _lib.ptr(h_r), _lib.ptr(h_js),
+                                                                    _lib.ptr(h_jtt))) if j else \
+            _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(h_r), None, None))
         ev(True)
         t0 = time.perf_counter()
         for _ in range(3):
@@ -707,16 +709,27 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
         for _ in range(3):
             ev(False)
         dt_r = (time.perf_counter() - t0) / 3
-        same = bool(np.array_equal(h_js, js.cpu().numpy()) and np.array_equal(h_jt, jt.cpu().numpy()))
+        jt_h = jt.cpu().numpy().reshape(-1, 3)
+        same = bool(np.array_equal(h_js, js.cpu().numpy()) and np.array_equal(h_jtt, jt_h[:, 2]) and
+                    np.array_equal(jt_h[:, :2], -h_js.reshape(-1, 3)[:, :2]))
+        # the old form: full J_tgt into pageable memory
+        p_r, p_js, p_jt = np.empty(2 * n_corr), np.empty(6 * n_corr), np.empty(6 * n_corr)
+        full = lambda: _lib.check(lib.nhip_resid_batch_eval(hnd, _lib.ptr(h_poses), _lib.ptr(p_r), _lib.ptr(p_js), _lib.ptr(p_jt)))
+        full()
+        t0 = time.perf_counter()
+        full()
+        dt_full = time.perf_counter() - t0
+        del p_r, p_js, p_jt
         lib.nhip_resid_batch_free(hnd)
         out["host_buffer_api"] = {
             "seconds_per_eval_with_jacobians": dt_j, "seconds_per_eval_residuals_only": dt_r,
-            "correspondences_per_s_with_jacobians": n_corr / dt_j,
+            "correspondences_per_s_with_jacobians": n_corr / dt_j, "bytes_to_host_with_jacobians": 80.0 * n_corr,
+            "seconds_per_eval_full_jacobians_pageable": dt_full,
             "same_result_as_device_api": same,
             "note": "nhip_resid_batch_eval: 24 KB of poses up; residuals, J_src and the theta column of J_tgt down over "
                     "PCIe through pinned staging (the x, y columns of J_tgt are -J_src's and are rebuilt on the host); "
                     "the per-block normal equations (icp_front_half) move 224 B per BLOCK instead"}
-        del h_r, h_js, h_jt
+        del h_r, h_js, h_jtt
     except Exception as e:
         out["host_buffer_api_error"] = repr(e)
     if with_cpu:
@@ -800,7 +813,8 @@ def bench_config1(with_cpu):
     examples/slam_loop.py drives both through the same host code (scipy sparse solves included in both)."""
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import slam_loop
-    kw = dict(n_scans=200, window=10, min_scatter_score=0.3, cell_bits=16)
+    # 0.4 m between scans: the 200 scans cover 1.3 laps of the room, so the bag closes its loop
+    kw = dict(n_scans=200, window=10, min_scatter_score=0.3, cell_bits=16, spacing=0.4)
     out = {"workload": "configs[0]: 200 dense 1081-beam scans; growing-window ICP solve 1..10 (LIDARNormalResidual on all "
                        "points), scatter-score candidates + geometric pair gate, 61x81x81 scan matching on 16-bit tables, "
                        "constraints + re-solve, one HITL message + re-solve"}

