@@ -163,6 +163,8 @@ class HipMatcher:
         self.d_keys = torch.empty(n, dtype=torch.int64, device=device)
         self.d_out = torch.empty((n, 4), dtype=torch.int32, device=device)
         self.d_sums = torch.empty(n, dtype=torch.int32, device=device)
+        self.ws_csm = self.lib.nhip_csm_workspace_bytes(self.n_pairs)
+        self.d_ws_csm = torch.empty(self.ws_csm, dtype=torch.uint8, device=device)
         self.sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def step(self):
@@ -178,7 +180,7 @@ class HipMatcher:
                                   C.byref(self.spec), self.d_src.data_ptr(), self.d_slot.data_ptr(),
                                   self.d_rot0.data_ptr(), self.d_delta.data_ptr(), None, self.n_pairs,
                                   C.byref(self.search), self.d_keys.data_ptr(), self.d_out.data_ptr(),
-                                  self.d_sums.data_ptr(), self.sp))
+                                  self.d_sums.data_ptr(), self.d_ws_csm.data_ptr(), self.ws_csm, self.sp))
         return self.d_out[:self.n_pairs]
 
     def free_grids(self):

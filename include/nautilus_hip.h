@@ -150,13 +150,18 @@ int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32
  * d_rot0_cs: 2 doubles (cos, sin theta0) per pair; d_delta_cs: 2 doubles per lattice rotation.
  * d_pair_origin: NULL, or 2 int32 per pair = (x, y) cell offset of the search centre (used by
  * the fine level of a coarse-to-fine search); |origin| + half-width must be <= max_shift.
- * d_keys: n_pairs uint64 scratch; d_out: n_pairs records; d_sums: n_pairs int32 or NULL. */
+ * d_keys: n_pairs uint64 scratch; d_out: n_pairs records; d_sums: n_pairs int32 or NULL.
+ * d_workspace: NULL, or nhip_csm_workspace_bytes(n_pairs) bytes of scratch for the branch-and-bound matcher's
+ * grid-wide candidate lists: with it, small batches (<= 2048 pairs) have the exact evaluations of all pairs spread
+ * over the whole chip by a second kernel instead of each pair's workgroup evaluating its own -- same records
+ * either way. */
 int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                        const nhip_grid_spec_t *spec, const int32_t *d_pair_src,
                        const int32_t *d_pair_slot, const double *d_rot0_cs,
                        const double *d_delta_cs, const int32_t *d_pair_origin, int32_t n_pairs,
                        const nhip_search_t *search, uint64_t *d_keys, nhip_match_t *d_out,
-                       int32_t *d_sums, void *stream);
+                       int32_t *d_sums, void *d_workspace, int64_t workspace_bytes, void *stream);
+int64_t nhip_csm_workspace_bytes(int32_t n_pairs);
 
 /* With NHIP_BNB_STATS=1 in the environment the branch-and-bound matcher counts its work: blocks of 8 x 8
  * translations whose sums it evaluated exactly, and blocks in all, since the last call (synchronises; resets). */

@@ -364,20 +364,23 @@ int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_
                        const int32_t *d_pair_slot, const double *d_rot0_cs,
                        const double *d_delta_cs, const int32_t *d_pair_origin, int32_t n_pairs,
                        const nhip_search_t *search, uint64_t *d_keys, nhip_match_t *d_out,
-                       int32_t *d_sums, void *stream) {
+                       int32_t *d_sums, void *d_workspace, int64_t workspace_bytes, void *stream) {
   int rc = require_device();
   if (rc) return rc;
   NHIP_REQUIRE(d_xy && d_offsets && d_grids && d_pair_src && d_pair_slot && d_rot0_cs && d_delta_cs &&
                    d_keys && d_out && search,
                "csm_match_dev: null pointer");
+  NHIP_REQUIRE(workspace_bytes >= 0 && (d_workspace || workspace_bytes == 0), "csm_match_dev: bad workspace");
   NHIP_REQUIRE(n_pairs >= 0, "csm_match_dev: n_pairs < 0");
   GridLayout L;
   rc = make_layout(spec, &L);
   if (rc) return rc;
   return launch_csm_match(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs,
                           d_delta_cs, d_pair_origin, n_pairs, search, d_keys, d_out, d_sums,
-                          static_cast<hipStream_t>(stream));
+                          static_cast<hipStream_t>(stream), d_workspace, workspace_bytes);
 }
+
+int64_t nhip_csm_workspace_bytes(int32_t n_pairs) { return bnb_workspace_bytes(n_pairs); }
 
 int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                         const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
@@ -635,7 +638,9 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
   std::vector<double> rot0(2 * (size_t)n_pairs), delta(2 * (size_t)search->n_theta);
   if ((rc = nhip_csm_rot0(theta0, nullptr, n_pairs, rot0.data()))) return rc;
   if ((rc = nhip_csm_delta_table(search, delta.data()))) return rc;
-  DevBuf d_src, d_slot, d_rot0, d_delta, d_keys, d_out, d_sums, d_org;
+  DevBuf d_src, d_slot, d_rot0, d_delta, d_keys, d_out, d_sums, d_org, d_ws;
+  const int64_t ws_bytes = bnb_workspace_bytes(n_pairs);
+  if ((rc = d_ws.alloc((size_t)ws_bytes))) return rc;
   if (pair_origin) {
     if ((rc = d_org.alloc(sizeof(int32_t) * 2 * (size_t)n_pairs))) return rc;
     NHIP_TRY_HIP(hipMemcpy(d_org.p, pair_origin, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice));
@@ -654,7 +659,7 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
                         static_cast<const int32_t *>(d_src.p), static_cast<const int32_t *>(d_slot.p),
                         static_cast<const double *>(d_rot0.p), static_cast<const double *>(d_delta.p),
                         pair_origin ? static_cast<const int32_t *>(d_org.p) : nullptr, n_pairs, search, static_cast<uint64_t *>(d_keys.p), static_cast<nhip_match_t *>(d_out.p),
-                        static_cast<int32_t *>(d_sums.p), nullptr);
+                        static_cast<int32_t *>(d_sums.p), nullptr, d_ws.p, ws_bytes);
   if (rc) return rc;
   NHIP_TRY_HIP(hipMemcpy(out, d_out.p, sizeof(nhip_match_t) * (size_t)n_pairs, hipMemcpyDeviceToHost));
   if (out_sums) NHIP_TRY_HIP(hipMemcpy(out_sums, d_sums.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost));

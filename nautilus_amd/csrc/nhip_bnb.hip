@@ -48,6 +48,9 @@ struct BnbParams {
   const int32_t *pair_origin;
   unsigned long long *keys;
   unsigned long long *stats;  // optional: [0] blocks evaluated, [1] blocks in all
+  uint4 *cand_list;           // optional global candidate lists (caller's workspace), one per XCD so that a pair's
+  uint32_t *cand_count;       //   candidates are evaluated where its grid is L2-resident: {U, pair, k << 8 | slot, 0};
+  uint32_t cand_cap;          //   8 fill counters (32 bytes apart); entries per list
   int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
   int32_t S, pad, pitch, rows, max_shift;
   int32_t pool_pitch, pool_rows, pairs_per_xcd;
@@ -394,7 +397,8 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   // pose 0 with sum 0 is a lower bound of the optimum (sums are >= 0; if all are 0, pose 0 is the answer)
   const unsigned long long key0 = 0xffffffffull;
   if (threadIdx.x == 0) {
-    *s_best = key0;
+    // (NHIP_BNB_DEBUG=3, experiments only: start from the keys a previous launch left = the ideal threshold)
+    *s_best = P.debug == 3 ? (P.keys[pair] & 0xffffffff00000000ull) : key0;
     *s_cnt = 0u;
     *s_qn = 0u;
     *s_qhead = 0u;
@@ -465,12 +469,27 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     if (lane == 0) atomicMax(s_best, key);
     n_eval++;
   };
-  for (int32_t k = wave; k < P.n_theta && P.debug == 0; k += BNB_WAVES) {
+  for (int32_t k = wave; k < P.n_theta && (P.debug == 0 || P.debug == 3); k += BNB_WAVES) {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const uint32_t u = s_U[k * 128 + lane + 64 * i];
       const uint32_t bsum = (uint32_t)(*(volatile unsigned long long *)s_best >> 32);
-      const bool cand = u != 0u && u >= bsum;
+      bool cand = u != 0u && u >= bsum;
+      if (P.cand_list) {
+        // the grid-wide list: a second kernel evaluates it with every wave of the chip (a pair whose landscape is
+        // flat has thousands of survivors, most pairs a few dozen); what does not fit stays with this workgroup
+        const unsigned long long gm = __ballot(cand);
+        if (gm == 0ull) continue;
+        const uint32_t xcd = bid & 7u;
+        uint32_t gbase = 0u;
+        if (lane == 0) gbase = atomicAdd(P.cand_count + 8 * xcd, (uint32_t)__builtin_popcountll(gm));
+        gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+        const uint32_t gpos = gbase + (uint32_t)__builtin_popcountll(gm & ((1ull << lane) - 1ull));
+        if (cand && gpos < P.cand_cap) {
+          P.cand_list[(size_t)xcd * P.cand_cap + gpos] = make_uint4(u, (uint32_t)pair, (uint32_t)((k << 8) | (lane + 64 * i)), 0u);
+          cand = false;
+        }
+      }
       const unsigned long long m = __ballot(cand);
       if (m == 0ull) continue;
       uint32_t base = 0u;
@@ -492,7 +511,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   __syncthreads();
   {
     const uint32_t qn = min(*s_qn, (uint32_t)QCAP);
-    while (P.debug == 0) {
+    while (P.debug == 0 || P.debug == 3) {
       uint32_t i = 0u;
       if (lane == 0) i = atomicAdd(s_qhead, 1u);
       i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
@@ -512,6 +531,44 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   }
 }
 
+// Second kernel of the two-kernel form: the candidates of ALL pairs, one wave per candidate, every wave of the chip.
+// A candidate is skipped when the pair's best sum (keys[pair], raised by the seeds and by candidates evaluated
+// before it) has passed its bound.
+template <int CB>
+__global__ __launch_bounds__(256, 4) void csm_bnb_eval_kernel(BnbParams P) {
+  const int lane = threadIdx.x & 63;
+  // workgroup b works on the list of XCD b & 7 (blocks b and b + 8 share an XCD): the waves of that XCD stride over it
+  const uint32_t xcd = blockIdx.x & 7u;
+  const uint32_t wave_id = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6), n_waves = (gridDim.x >> 3) * 4u;
+  const uint32_t filled = P.cand_count[8 * xcd];
+  const uint32_t count = filled < P.cand_cap ? filled : P.cand_cap;
+  const uint4 *list = P.cand_list + (size_t)xcd * P.cand_cap;
+  uint32_t n_eval = 0u;
+  for (uint32_t i = wave_id; i < count; i += n_waves) {
+    const uint4 c = list[i];
+    const int32_t pair = (int32_t)c.y;
+    const unsigned long long best = __hip_atomic_load(&P.keys[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c.x < (uint32_t)(best >> 32)) continue;
+    const int32_t k = (int32_t)(c.z >> 8), v = (int32_t)(c.z & 0xffu);
+    int Y, X;
+    slot_block(v, &Y, &X);
+    const int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
+    const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
+    const uint8_t *grid = P.grids + (size_t)slot * P.slot_bytes;
+    const int32_t cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
+    const int32_t cy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
+    float cf, sf;
+    rotation_k(P, pair, k, &cf, &sf);
+    const unsigned long long key = eval_block<CB>(P, grid, P.xy + beg, n_pts, cf, sf, cx, cy, k, Y, X, lane);
+    if (lane == 0) {
+      atomicMax(&P.keys[pair], key);
+      if (P.stats && pair < BNB_STATS_PAIRS) atomicAdd(&P.stats[2 + pair], 1ull);
+    }
+    n_eval++;
+  }
+  if (P.stats && lane == 0 && n_eval) atomicAdd(&P.stats[0], (unsigned long long)n_eval);
+}
+
 size_t bnb_lds_bytes(const GridLayout &L, const nhip_search_t *search, bool pool_lds) {
   return (pool_lds ? (size_t)L.pool_bytes : 0) + (size_t)search->n_theta * 128 * 4 + (size_t)QCAP * 8 + 32;
 }
@@ -528,11 +585,17 @@ bool bnb_fits(const GridLayout &L, const nhip_search_t *search) {
 
 static unsigned long long *g_bnb_stats = nullptr;  // device counters, allocated on first use when NHIP_BNB_STATS=1
 
+constexpr int64_t BNB_WS_HEADER = 256;  // eight fill counters, 32 bytes apart
+int64_t bnb_workspace_bytes(int32_t n_pairs) {
+  return BNB_WS_HEADER + 8 * ((((int64_t)(n_pairs > 0 ? n_pairs : 0) + 7) / 8) * 192 + 64) * 16;
+}
+
 int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                    const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                    const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                    const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
-                   uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled) {
+                   uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled,
+                   void *d_workspace, int64_t workspace_bytes) {
   *handled = 0;
   if (!bnb_fits(L, search)) return NHIP_OK;
   *handled = 1;
@@ -580,6 +643,20 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     }
     P.stats = g_bnb_stats;
   }
+  // Two-kernel form (candidates of all pairs through per-XCD lists in the caller's workspace, evaluated by every
+  // wave of the chip): for SMALL batches, where a pair with thousands of survivors would keep one workgroup busy
+  // for milliseconds while the rest of the chip idles.  With thousands of pairs in flight the chip is full either
+  // way and evaluating a pair's candidates inside its own workgroup is the faster form (measured: 17.3 vs 19.8 ms
+  // per 10,000 pairs; the evaluation is bound by L1 tag lookups, not by balance).  NHIP_BNB_KERNELS=1|2 forces one.
+  const char *force = getenv("NHIP_BNB_KERNELS");
+  const bool two = force ? force[0] == '2' : n_pairs <= 2048;
+  if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * 16 * 8 && two) {
+    P.cand_count = static_cast<uint32_t *>(d_workspace);
+    P.cand_list = reinterpret_cast<uint4 *>(static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER);
+    const int64_t cap = (workspace_bytes - BNB_WS_HEADER) / 16 / 8;  // entries per XCD list
+    P.cand_cap = (uint32_t)(cap < 0x0fffffffll ? cap : 0x0fffffffll);
+    NHIP_TRY_HIP(hipMemsetAsync(d_workspace, 0, BNB_WS_HEADER, s));
+  }
   const bool pool_lds = bnb_lds_bytes(L, search, true) <= LDS_MAX;
   const size_t lds = bnb_lds_bytes(L, search, pool_lds);
   const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
@@ -595,6 +672,11 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   else if (pool_lds) NHIP_BNB_LAUNCH(2, true);
   else NHIP_BNB_LAUNCH(2, false);
 #undef NHIP_BNB_LAUNCH
+  if (P.cand_list && (P.debug == 0 || P.debug == 3)) {
+    const uint32_t eval_blocks = 256 * 16;  // 16 workgroups of four waves per CU's worth; waves stride over the list
+    if (L.cb == 1) hipLaunchKernelGGL(csm_bnb_eval_kernel<1>, dim3(eval_blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL(csm_bnb_eval_kernel<2>, dim3(eval_blocks), dim3(256), 0, s, P);
+  }
   timer_end(NHIP_TIMER_CSM, s);
   NHIP_TRY_HIP(hipGetLastError());
   launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);

@@ -103,14 +103,17 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
-                     uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s);
+                     uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s,
+                     void *d_workspace = nullptr, int64_t workspace_bytes = 0);
 
 // branch-and-bound matcher (nhip_bnb.hip); returns NHIP_ERR_STATE-free: `*handled` = 0 when the lattice does not fit it
 int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                    const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                    const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                    const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
-                   uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled);
+                   uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled,
+                   void *d_workspace = nullptr, int64_t workspace_bytes = 0);
+int64_t bnb_workspace_bytes(int32_t n_pairs);
 bool bnb_fits(const GridLayout &L, const nhip_search_t *search);
 int bnb_stats_read(unsigned long long out[2]);
 int bnb_stats_per_pair(unsigned long long *out, int32_t n);

@@ -518,7 +518,8 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
-                     uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s) {
+                     uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s,
+                     void *d_workspace, int64_t workspace_bytes) {
   const char *ex = getenv("NHIP_CSM_EXHAUSTIVE");
   const bool exhaustive = (search->flags & NHIP_SEARCH_EXHAUSTIVE) || (ex && ex[0] == '1') || !bnb_fits(L, search);
   int rc = check_search(spec, L, search, exhaustive);
@@ -527,7 +528,7 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
   if (!exhaustive) {  // branch and bound: the same records, most adds never performed (nhip_bnb.hip)
     int handled = 0;
     rc = launch_csm_bnb(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
-                        d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s, &handled);
+                        d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s, &handled, d_workspace, workspace_bytes);
     if (rc || handled) return rc;
   }
   CsmParams P;

@@ -388,10 +388,23 @@ def test_device_pointer_api_on_torch_stream(gpu, small_bag):
         sp = C.c_void_p(stream.cuda_stream)
         _lib.check(lib.nhip_grid_build_dev(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), 2, C.byref(spec),
                                            d_grids.data_ptr(), d_ws.data_ptr(), ws_bytes, sp))
+        # without a workspace (each pair's workgroup evaluates its own candidates) ...
         _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), d_grids.data_ptr(), C.byref(spec),
                                           d_src.data_ptr(), d_slot.data_ptr(), d_rot0.data_ptr(),
                                           d_delta.data_ptr(), None, 4, C.byref(search), d_keys.data_ptr(),
-                                          d_out.data_ptr(), d_sums.data_ptr(), sp))
+                                          d_out.data_ptr(), d_sums.data_ptr(), None, 0, sp))
+        stream.synchronize()
+        first = (d_out.cpu().numpy().copy(), d_sums.cpu().numpy().copy())
+        # ... and with the grid-wide candidate list (a tiny one too: what does not fit stays with the workgroup)
+        for nbytes in (lib.nhip_csm_workspace_bytes(4), 256 + 8 * 16 * 8):
+            d_cws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            d_out.zero_()
+            _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), d_grids.data_ptr(), C.byref(spec),
+                                              d_src.data_ptr(), d_slot.data_ptr(), d_rot0.data_ptr(),
+                                              d_delta.data_ptr(), None, 4, C.byref(search), d_keys.data_ptr(),
+                                              d_out.data_ptr(), d_sums.data_ptr(), d_cws.data_ptr(), nbytes, sp))
+            stream.synchronize()
+            assert np.array_equal(d_out.cpu().numpy(), first[0]) and np.array_equal(d_sums.cpu().numpy(), first[1])
     stream.synchronize()
     got = d_out.cpu().numpy().view(csm.MATCH_DTYPE)
     ogr = O.grid_build_batch(xy, off, ids, ospec)
@@ -585,6 +598,14 @@ def test_config4_per_gpu_share(gpu):
     _, full_x = bench.run_sharded(plan, 0, 1, dev, mx, steps=1, warmup=0)
     assert torch.equal(full, full_x), "branch and bound differs from the exhaustive kernel"
     mx.free_grids()
+    os.environ["NHIP_BNB_KERNELS"] = "2"  # candidates of all pairs through the grid-wide lists (default: small batches only)
+    try:
+        m1 = bench.HipMatcher(wl, plan.shard(0), dev, 8)
+        _, full_1 = bench.run_sharded(plan, 0, 1, dev, m1, steps=1, warmup=0)
+        assert torch.equal(full, full_1), "one-kernel and two-kernel forms differ"
+        m1.free_grids()
+    finally:
+        os.environ.pop("NHIP_BNB_KERNELS", None)
     # self pairs: rotation 0 (k = 30), no shift (ix = iy = 40)
     assert np.all(rec["itheta"][:50] == 30) and np.all(rec["ix"][:50] == 40) and np.all(rec["iy"][:50] == 40)
     assert rec[50:100].tobytes() == rec[100:150].tobytes()

@@ -14,7 +14,7 @@ plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
 out = {}
 for bits in (8, 16):
     m = bench.HipMatcher(wl, plan.shard(0), torch.device("cuda", 0), bits)
-    for dbg in ("0", "1", "2"):
+    for dbg in ("0", "3", "1", "2"):
         os.environ["NHIP_BNB_DEBUG"] = dbg
         m.step(); torch.cuda.synchronize(); csm.bnb_stats()
         lib.nhip_timing_reset(); lib.nhip_timing_enable(1)
