@@ -33,6 +33,10 @@ constexpr int BNB_WAVES = 8;
 constexpr int BNB_THREADS = 64 * BNB_WAVES;
 constexpr int NB = BNB_MAX_NB;        // blocks per axis held in registers (11: nx, ny <= 88)
 constexpr int SEG_CHUNKS = 32;        // 64-point chunks between reductions: 32 * 255 * 8 lanes < 65536 (16-bit fields); even
+#ifndef NHIP_BNB_EVAL_CHUNKS
+#define NHIP_BNB_EVAL_CHUNKS 2
+#endif
+constexpr int EVAL_CHUNKS = NHIP_BNB_EVAL_CHUNKS;  // 64-point chunks whose row loads a block evaluation keeps in flight
 constexpr int QCAP = 1024;            // candidate queue entries per workgroup (overflow is evaluated by the wave that found it)
 constexpr uint32_t M8 = 0x00ff00ffu;
 constexpr int BNB_STATS_PAIRS = 1 << 20;  // per-pair counters kept by NHIP_BNB_STATS=1
@@ -83,6 +87,17 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
 // evaluation is bound by exactly that.
 typedef uint32_t u32x3 __attribute__((ext_vector_type(3)));
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// Buffer descriptor of a wave-uniform range.  The inputs pass through readfirstlane so that hipcc can PROVE the
+// descriptor uniform and keeps it in SGPRs: a descriptor it parks in VGPRs costs a serialising "waterfall" loop of
+// ~10 instructions around every single buffer load.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base, int64_t bytes) {
+  const uint64_t a = reinterpret_cast<uint64_t>(base);
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)a);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(a >> 32));
+  const int n = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7fffffffll ? bytes : 0x7fffffffll));
+  return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
+}
 
 __device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 
@@ -216,6 +231,22 @@ __device__ __forceinline__ bool slot_block(int v, int *Y, int *X) {
   return true;
 }
 
+// Byte offset (into the grid slot) of the aligned dword that holds the first cell of a point's 8 x 8 patch of block
+// (Y, X), and the bit shift of that cell inside it (8-bit cells).  Lanes without a point read the zero border
+// (row 0 of the stored image).
+__device__ __forceinline__ void patch_origin(const BnbParams &P, bool live, float2 q, float cf, float sf, int32_t cx,
+                                             int32_t cy, int32_t Y, int32_t X, uint32_t *g, uint32_t *sh) {
+  *g = 0u;
+  *sh = 0u;
+  if (live) {
+    int32_t prow, pcol;
+    window_origin(q, cf, sf, P, cx, cy, &prow, &pcol);
+    const int32_t col = pcol + BNB_B * X;
+    *g = (uint32_t)((prow + BNB_B * Y) * P.pitch + (col & ~3));
+    *sh = (uint32_t)(col & 3) * 8u;
+  }
+}
+
 // ---- exact sums of one 8 x 8 block -----------------------------------------------------------------------
 // Returns the block's best key (sum << 32 | ~linear index) over its valid poses, the same in every lane.
 template <int CB>
@@ -225,63 +256,55 @@ __device__ __forceinline__ unsigned long long eval_block(const BnbParams &P, con
   uint32_t total = 0u;  // this lane's pose: (dy, dx) below
   int dy, dx;
   // (stored image + skip map: every offset the evaluation can form lies inside; see nhip_api.hip make_layout)
-  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t *>(grid), 0, (int)(P.grid_bytes + P.skip_bytes < 0x7fffffffll ? P.grid_bytes + P.skip_bytes : 0x7fffffffll),
-      0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(grid, P.grid_bytes + P.skip_bytes);
   if (CB == 1) {
-    // lanes without a point read the zero border (row 0 of the stored image)
-    auto origin = [&](int32_t idx, float2 q, uint32_t *g, uint32_t *sh) {
-      *g = 0u;
-      *sh = 0u;
-      if (idx < n_pts) {
-        int32_t prow, pcol;
-        window_origin(q, cf, sf, P, cx, cy, &prow, &pcol);
-        const int32_t col = pcol + BNB_B * X;
-        *g = (uint32_t)((prow + BNB_B * Y) * P.pitch + (col & ~3));
-        *sh = (uint32_t)(col & 3) * 8u;
-      }
-    };
     const float2 none = make_float2(0.f, 0.f);
     for (int32_t c0 = 0; c0 < n_pts; c0 += 64 * SEG_CHUNKS) {
       uint32_t E[8][2], O[8][2];
 #pragma unroll
       for (int y = 0; y < 8; y++) E[y][0] = E[y][1] = O[y][0] = O[y][1] = 0u;
       const int32_t c1 = min(n_pts, c0 + 64 * SEG_CHUNKS);
-      // Two 64-point chunks per iteration, their 16 row loads issued together, and the points of the next
-      // iteration fetched before this one's rows are consumed: the evaluation is bound by the latency of its
-      // dependent loads (point -> window origin -> rows), not by arithmetic.
-      float2 qa = c0 + lane < c1 ? pts[c0 + lane] : none, qb = c0 + 64 + lane < c1 ? pts[c0 + 64 + lane] : none;
-      for (int32_t c = c0; c < c1; c += 128) {
-        const float2 na = c + 128 + lane < c1 ? pts[c + 128 + lane] : none;
-        const float2 nb = c + 192 + lane < c1 ? pts[c + 192 + lane] : none;
-        uint32_t ga, gb, sha, shb;
-        origin(c + lane < c1 ? c + lane : n_pts, qa, &ga, &sha);
-        origin(c + 64 + lane < c1 ? c + 64 + lane : n_pts, qb, &gb, &shb);
-        uint32_t wa[8][3], wb[8][3];
+      // EVAL_CHUNKS 64-point chunks per iteration, their row loads issued together, and the points of the next
+      // iteration fetched before this one's rows are consumed (the dependent chain is point -> window origin -> rows).
+      float qx[EVAL_CHUNKS], qy[EVAL_CHUNKS];  // (plain floats: arrays of float2 end up in scratch)
 #pragma unroll
-        for (int y = 0; y < 8; y++) {
-          const u32x3 ra = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(ga + (uint32_t)(y * P.pitch)), 0, 0);
-          wa[y][0] = ra.x; wa[y][1] = ra.y; wa[y][2] = ra.z;
+      for (int u = 0; u < EVAL_CHUNKS; u++) {
+        const float2 q = c0 + 64 * u + lane < c1 ? pts[c0 + 64 * u + lane] : none;
+        qx[u] = q.x;
+        qy[u] = q.y;
+      }
+      for (int32_t c = c0; c < c1; c += 64 * EVAL_CHUNKS) {
+        float nx[EVAL_CHUNKS], ny[EVAL_CHUNKS];
+#pragma unroll
+        for (int u = 0; u < EVAL_CHUNKS; u++) {
+          const int32_t idx = c + 64 * (EVAL_CHUNKS + u) + lane;
+          const float2 q = idx < c1 ? pts[idx] : none;
+          nx[u] = q.x;
+          ny[u] = q.y;
+        }
+        uint32_t g[EVAL_CHUNKS], sh[EVAL_CHUNKS], w[EVAL_CHUNKS][8][3];
+#pragma unroll
+        for (int u = 0; u < EVAL_CHUNKS; u++) {
+          const int32_t idx = c + 64 * u + lane;
+          patch_origin(P, idx < c1, make_float2(qx[u], qy[u]), cf, sf, cx, cy, Y, X, &g[u], &sh[u]);
+#pragma unroll
+          for (int y = 0; y < 8; y++) {
+            const u32x3 r = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(g[u] + (uint32_t)(y * P.pitch)), 0, 0);
+            w[u][y][0] = r.x; w[u][y][1] = r.y; w[u][y][2] = r.z;
+          }
         }
 #pragma unroll
-        for (int y = 0; y < 8; y++) {
-          const u32x3 rb = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gb + (uint32_t)(y * P.pitch)), 0, 0);
-          wb[y][0] = rb.x; wb[y][1] = rb.y; wb[y][2] = rb.z;
-        }
+        for (int u = 0; u < EVAL_CHUNKS; u++) {
 #pragma unroll
-        for (int y = 0; y < 8; y++) {
-          const uint32_t n0 = __builtin_amdgcn_alignbit(wa[y][1], wa[y][0], sha), n1 = __builtin_amdgcn_alignbit(wa[y][2], wa[y][1], sha);
-          E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
-          E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
+          for (int y = 0; y < 8; y++) {
+            const uint32_t n0 = __builtin_amdgcn_alignbit(w[u][y][1], w[u][y][0], sh[u]);
+            const uint32_t n1 = __builtin_amdgcn_alignbit(w[u][y][2], w[u][y][1], sh[u]);
+            E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
+            E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
+          }
+          qx[u] = nx[u];
+          qy[u] = ny[u];
         }
-#pragma unroll
-        for (int y = 0; y < 8; y++) {
-          const uint32_t n0 = __builtin_amdgcn_alignbit(wb[y][1], wb[y][0], shb), n1 = __builtin_amdgcn_alignbit(wb[y][2], wb[y][1], shb);
-          E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
-          E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
-        }
-        qa = na;
-        qb = nb;
       }
       uint32_t R[32];  // R[4 y + d]: d = 0: dx 0, 2; 1: dx 1, 3; 2: dx 4, 6; 3: dx 5, 7
 #pragma unroll
@@ -412,8 +435,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     uint4 *sp = reinterpret_cast<uint4 *>(s_pool);
     for (int32_t i = threadIdx.x; i < (int32_t)(P.pool_bytes / 16); i += BNB_THREADS) sp[i] = gp[i];
   }
-  const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
-      const_cast<uint8_t *>(grid + P.grid_bytes + P.skip_bytes), 0, (int)P.pool_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(grid + P.grid_bytes + P.skip_bytes, P.pool_bytes);
   __syncthreads();
 
   // (1) bounds of every block of every rotation this wave owns; the wave's own best bound
