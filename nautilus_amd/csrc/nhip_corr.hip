@@ -116,10 +116,13 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
   float4 *out = corr + 2 * (size_t)cap_offsets[b];
   int32_t written = 0;  // rows already emitted by earlier source passes (uniform)
 
-  // cells 0.1 % wider than the threshold: |dx| < thr * (1 + 1e-6) for every target that passes
-  // sqrt(d2) < thr, and float cell coordinates below 2^20 are exact to 1e-1 cell
+  // Cells 0.1 % wider than the threshold: two points closer than thr are less than 0.999 cells apart per axis.  A
+  // float cell coordinate fx = g * inv_cell carries a relative error of ~1.2e-7 (inv_cell and the product are each
+  // rounded), so the computed coordinates of such a pair differ by less than 0.999 + 2.4e-7 |fx|: below 1 -- the
+  // pair lands in the same or in adjacent cells and the 3 x 3 visit finds it -- as long as |fx| < 4166.
+  // Larger coordinates (beyond 4096 cells = 1 km at the 0.25 m threshold) take the exhaustive scan.
   const float inv_cell = __fdiv_rn(1.0f, __fmul_rn(thr, 1.001f));
-  constexpr float CELL_LIMIT = 1048576.0f;
+  constexpr float CELL_LIMIT = 4096.0f;
   bool hashed = nt <= TGT_CHUNK && thr > 0.f && inv_cell < 3.0e38f;
   if (hashed) {
     // stage + bucket the whole target cloud once

@@ -147,6 +147,36 @@ def test_corr_search_hash_grid_corner_cases(gpu, thr):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("offset_m", [800.0, 1030.0, 5000.0])
+def test_corr_search_large_coordinates(gpu, small_bag, offset_m):
+    """Clouds far from the origin: float cell coordinates lose the margin the hash grid's 3 x 3 visit relies on at
+    ~4166 cells (1 km at the 0.25 m threshold), so beyond 4096 cells the kernel takes the exhaustive scan.  800 m
+    stays on the hash path, 1030 m and 5 km do not; all return the exhaustive scan's rows, bit for bit."""
+    from nautilus_amd.correspondence import IcpBatch
+    rng = np.random.default_rng(5)
+    shift = np.array([offset_m, -0.7 * offset_m], dtype=np.float32)
+    scans = [(small_bag.scans[i] + shift).astype(np.float32) for i in (3, 4, 5, 6)]
+    # dense rows of targets a hair apart around the threshold distance from the sources
+    row = np.stack([np.linspace(0, 30, 1500), np.zeros(1500)], 1).astype(np.float32) + shift
+    scans += [row, (row + np.float32([0.2499, 0.0])).astype(np.float32), (row + rng.normal(0, 0.15, row.shape)).astype(np.float32)]
+    normals = [rng.normal(0, 1, s_.shape).astype(np.float32) for s_ in scans]
+    xy, off = csm.pack_scans(scans)
+    nrm = np.concatenate(normals)
+    bs = np.array([1, 2, 3, 0, 5, 6, 4], np.int32)
+    bt = np.array([0, 1, 2, 3, 4, 4, 6], np.int32)
+    poses = np.zeros((len(scans), 3))
+    poses[:4] = small_bag.odom[3:7] - small_bag.odom[3]
+    batch = IcpBatch(xy, nrm, off, bs, bt, outlier_threshold=0.25)
+    batch.set_poses(poses)
+    n = batch.search()
+    rows, boff = batch.correspondences()
+    want, counts, cap = O.corr_search_batch(xy, nrm, off, bs, bt, O.pose_affines(poses), 0.25)
+    assert np.array_equal(np.diff(boff), counts) and n == counts.sum() and counts.sum() > 1000
+    for b in range(len(bs)):
+        assert rows[boff[b]:boff[b + 1]].tobytes() == want[cap[b]:cap[b] + counts[b]].tobytes(), (b, offset_m)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("thr,min_cos", [(0.25, math.cos(math.radians(20.0))), (0.6, 0.5), (0.25, 0.0), (0.05, 0.999)])
 def test_corr_search_with_normal_gate(gpu, small_bag, thr, min_cos):
     """Solver::GetPointToNormalMatching (solver.cc:177-260): nearest target within the threshold whose
