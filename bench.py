@@ -77,7 +77,7 @@ def launch_ranks(a, argv):
     THIS process has initialised a GPU yet (torch.cuda.device_count() does not, on this image)."""
     import torch
     visible = torch.cuda.device_count()
-    if visible < a.gpus:
+    if visible < a.gpus and os.environ.get("NHIP_BENCH_REHEARSAL") != "1":
         sys.stderr.write("bench.py: --gpus %d requested but %d GPU(s) visible; refusing to run on fewer ranks\n"
                          % (a.gpus, visible))
         return 3
@@ -307,6 +307,11 @@ def worker(a):
     import torch.distributed as dist
     from nautilus_amd import _lib, csm, sharding, synth
     lib = _lib.load()
+    # Rehearsal only (a one-GPU box): NHIP_BENCH_REHEARSAL=1 lets the ranks share GPU 0 and run the collective over
+    # gloo -- the whole multi-rank code path except RCCL itself.  Never a measurement: the JSON says so.
+    rehearsal = os.environ.get("NHIP_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local = 0
     if not torch.cuda.is_available() or torch.cuda.device_count() <= local:
         sys.stderr.write("bench.py: rank %d needs GPU %d but %d are visible: there is no CPU path\n"
                          % (rank, local, torch.cuda.device_count() if torch.cuda.is_available() else 0))
@@ -320,7 +325,10 @@ def worker(a):
         saved = os.dup(1)
         os.dup2(2, 1)
         try:
-            dist.init_process_group("nccl", device_id=dev)
+            if rehearsal:
+                dist.init_process_group("gloo")
+            else:
+                dist.init_process_group("nccl", device_id=dev)
             dist.barrier()
             torch.cuda.synchronize()
         finally:
@@ -390,6 +398,7 @@ def worker(a):
                    "mode": a.mode, "pairs_total": wl.n_pairs, "scans_total": wl.n_scans, "lattice": [61, 81, 81],
                    "grid": [L.side, L.side], "cell_bytes": cell_bytes,
                    "rccl_world_size": dist.get_world_size() if use_dist else 1,
+                   "collective_backend": ("gloo (REHEARSAL on a shared GPU: not a measurement)" if rehearsal else "nccl (RCCL)") if use_dist else None,
                    "collective": "all_gather 16 B/pair" if world > 1 else "none",
                    "per_rank": [{"pairs": int(r[0]), "targets": int(r[1]), "correlate_ms_per_step": r[2],
                                  "grid_ms_per_step": r[3]} for r in per_rank]},
