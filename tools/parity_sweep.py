@@ -1,7 +1,9 @@
 """Extended randomized parity sweep of the scan matcher, HIP path vs oracle (not part of the suite):
     gpurun -- python tools/parity_sweep.py 400
 Random grid geometry / blur / lattice / search centre / dense, sparse and clustered clouds; grids,
-indices and integer sums must be bit-exact.  Round 1: 400 configurations, all equal."""
+indices and integer sums must be bit-exact, for both cell widths, through the branch-and-bound matcher (lattices up
+to 88 x 88) AND the kernel that performs every add (8-bit cells).  Round 1: 400 configurations, all equal;
+round 2: 400 configurations x {8, 16}-bit, all equal."""
 import math, sys, time
 import numpy as np
 import os
@@ -22,7 +24,8 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     if range_m / res > 900: res = range_m / 600
     n_theta = 2 * int(rng.integers(0, 6)) + 1
     step = float(rng.choice([0.25, 1.0, 3.0])) * DEG
-    spec = csm.grid_spec(range_m, res, sigma, 1e-10, max(hx, hy) + 12); ospec = O.grid_spec(range_m, res, sigma, 1e-10)
+    bits = 16 if (seed % 2 and max(hx, hy) <= 43) else 8   # 16-bit cells need the branch-and-bound matcher's lattice limit
+    spec = csm.grid_spec(range_m, res, sigma, 1e-10, max(hx, hy) + 12, bits); ospec = O.grid_spec(range_m, res, sigma, 1e-10, bits)
     search = csm.search_spec(n_theta, 2 * hx + 1, 2 * hy + 1, step)
     n_pairs = int(rng.integers(1, 20))
     ids = np.unique(rng.integers(0, 64, int(rng.integers(1, 6)))).astype(np.int32)
@@ -37,6 +40,10 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     xy, off = csm.pack_scans(scans)
     st = csm.ScanTable(xy, off); grids = csm.LikelihoodGrids(st, ids, spec)
     got, sums = csm.match_pairs(st, grids, src, slot, th0, search, origin)
+    if bits == 8:
+        ex = csm.search_spec(n_theta, 2 * hx + 1, 2 * hy + 1, step, exhaustive=True)
+        got_x, sums_x = csm.match_pairs(st, grids, src, slot, th0, ex, origin)
+        assert got_x.tobytes() == got.tobytes() and np.array_equal(sums_x, sums), ("bnb vs exhaustive", seed)
     ogr = O.grid_build_batch(xy, off, ids, ospec)
     for s_, i_ in enumerate(ids):
         assert np.array_equal(grids.interior(s_), ogr[s_]), ("grid", seed, s_)
