@@ -80,13 +80,20 @@ typedef struct nhip_grid_layout {
                           row) = "stored rows [r, r+21) x dwords [c, c+21*cell_bytes) hold a non-zero cell",
                           so the correlation kernel can leave out window strips that only add zeros (same
                           sums, bit for bit) */
-  int64_t slot_bytes;  /* grid_bytes + skip_bytes + pool_bytes: grid t of a buffer starts at byte t*slot_bytes */
+  int64_t slot_bytes;  /* grid_bytes + skip_bytes + pool_bytes + pool4_bytes: grid t of a buffer starts at byte
+                          t*slot_bytes */
   int64_t pool_bytes;  /* bytes of the max-pooled table stored after the skip map (branch-and-bound bounds):
                           pool_rows x pool_pitch bytes, entry (i, j) = max of stored cells [8i, 8i+15) x [8j, 8j+15)
                           (16-bit cells: ceil(max / 257)), so that the sum of pooled entries bounds every score of
                           an 8 x 8 block of translations from above */
   int32_t pool_pitch;
   int32_t pool_rows;
+  int64_t pool4_bytes; /* the second-level table, stored after the first: pool4_rows x pool4_pitch bytes.  With
+                          P4[i][j] = max of stored cells [4i, 4i+7) x [4j, 4j+7) (16-bit cells: ceil(max / 257)), the
+                          bounds of the 4 x 4 sub-blocks of a block of translations, byte (i, 2j) holds P4[i][j] and
+                          byte (i, 2j+1) holds P4[i+1][j]: one read returns both sub-block rows */
+  int32_t pool4_pitch;
+  int32_t pool4_rows;
 } nhip_grid_layout_t;
 
 /* Pure host helpers (work without a GPU). */
@@ -164,9 +171,16 @@ int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_
 int64_t nhip_csm_workspace_bytes(int32_t n_pairs);
 
 /* With NHIP_BNB_STATS=1 in the environment the branch-and-bound matcher counts its work: blocks of 8 x 8
- * translations whose sums it evaluated exactly, and blocks in all, since the last call (synchronises; resets). */
+ * translations whose sums it evaluated exactly (four 4 x 4 sub-blocks count as one block), and blocks in all, since
+ * the last call (synchronises; resets). */
 int nhip_bnb_stats(uint64_t *evaluated, uint64_t *total);
-/* ... and per pair of the last launch (blocks evaluated exactly), before nhip_bnb_stats resets the totals */
+/* ... by level: out[0..3] = {blocks evaluated whole, blocks in all, candidate blocks refined through their four
+ * sub-block bounds, 4 x 4 sub-blocks evaluated exactly}; out[4..10] = shader-clock sums of the matcher's kernel:
+ * wave time in the candidate phase, of which window origins / sub-block bounds / exact sums, the slowest wave of
+ * each pair, seed phase and bound phase (per workgroup); out[11..15] reserved (synchronises; resets) */
+int nhip_bnb_stats_levels(uint64_t out[16]);
+/* ... and per pair of the last launch (4 x 4 sub-blocks evaluated exactly, a whole block counting four), before
+ * nhip_bnb_stats resets the totals */
 int nhip_bnb_stats_per_pair(uint64_t *evaluated, int32_t n_pairs);
 
 /* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy] (8-bit cells). */
@@ -284,6 +298,8 @@ int nhip_grids_free(nhip_grids_t *grids);
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* copy the max-pooled table of grid `slot` to host: layout.pool_bytes bytes (pool_rows x pool_pitch) */
 int nhip_grids_download_pool(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
+/* the same for the second-level table: layout.pool4_bytes bytes (pool4_rows x pool4_pitch) */
+int nhip_grids_download_pool4(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 
 /* Batched GetTransformation: theta0[i] = AngleMod(rot_a - rot_b) of pair i;
  * pair_origin: NULL or 2 int32 per pair (search centre in cells). */

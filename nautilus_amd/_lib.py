@@ -33,7 +33,8 @@ class GridLayout(C.Structure):
                 ("blur_radius", C.c_int32), ("cell_bytes", C.c_int32), ("tap_sum", C.c_int64),
                 ("grid_bytes", C.c_int64), ("score_floor", C.c_double), ("score_step", C.c_double),
                 ("skip_bytes", C.c_int64), ("slot_bytes", C.c_int64), ("pool_bytes", C.c_int64),
-                ("pool_pitch", C.c_int32), ("pool_rows", C.c_int32)]
+                ("pool_pitch", C.c_int32), ("pool_rows", C.c_int32), ("pool4_bytes", C.c_int64),
+                ("pool4_pitch", C.c_int32), ("pool4_rows", C.c_int32)]
 
 
 class Search(C.Structure):
@@ -75,6 +76,7 @@ PROTOTYPES = {
     "nhip_csm_workspace_bytes": (_i64, [_i32]),
     "nhip_bnb_stats": (C.c_int, [_P(C.c_uint64), _P(C.c_uint64)]),
     "nhip_bnb_stats_per_pair": (C.c_int, [_vp, _i32]),
+    "nhip_bnb_stats_levels": (C.c_int, [_P(C.c_uint64)]),
     "nhip_csm_scores_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _i32, _i32, _vp, _vp, _i32, _i32,
                                       _P(Search), _vp, _vp]),
     "nhip_resid_lidar_dev": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp,
@@ -95,6 +97,7 @@ PROTOTYPES = {
     "nhip_grids_free": (C.c_int, [_vp]),
     "nhip_grids_download": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_pool": (C.c_int, [_vp, _i32, _vp]),
+    "nhip_grids_download_pool4": (C.c_int, [_vp, _i32, _vp]),
     "nhip_csm_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _P(Search), _vp, _vp]),
     "nhip_csm_scores": (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, _i32, _P(Search), _vp]),
     "nhip_lc_scatter_scores_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),

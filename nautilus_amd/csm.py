@@ -108,11 +108,17 @@ class LikelihoodGrids:
         check(_lib.load().nhip_grids_download(self._h, int(slot), ptr(out)))
         return out.view(np.uint16) if L.cell_bytes == 2 else out
 
-    def pooled(self, slot):
-        """Max-pooled table (pool_rows, pool_pitch) uint8: the branch-and-bound matcher's bounds."""
+    def pooled(self, slot, level=1):
+        """Max-pooled table uint8, the branch-and-bound matcher's bounds: level 1 (pool_rows, pool_pitch), 15 x 15
+        cells at stride 8; level 2 (pool4_rows, pool4_pitch), 7 x 7 cells at stride 4 as byte pairs
+        {P4[i][j], P4[i + 1][j]}."""
         L = self.layout
-        out = np.empty((L.pool_rows, L.pool_pitch), dtype=np.uint8)
-        check(_lib.load().nhip_grids_download_pool(self._h, int(slot), ptr(out)))
+        if level == 1:
+            out = np.empty((L.pool_rows, L.pool_pitch), dtype=np.uint8)
+            check(_lib.load().nhip_grids_download_pool(self._h, int(slot), ptr(out)))
+        else:
+            out = np.empty((L.pool4_rows, L.pool4_pitch), dtype=np.uint8)
+            check(_lib.load().nhip_grids_download_pool4(self._h, int(slot), ptr(out)))
         return out
 
     def interior(self, slot):
@@ -150,6 +156,15 @@ def bnb_stats():
     a, b = C.c_uint64(0), C.c_uint64(0)
     check(_lib.load().nhip_bnb_stats(C.byref(a), C.byref(b)))
     return a.value, b.value
+
+
+def bnb_stats_levels():
+    """{whole blocks evaluated, blocks in all, candidates refined, 4 x 4 sub-blocks evaluated} since the last call."""
+    v = (C.c_uint64 * 16)()
+    check(_lib.load().nhip_bnb_stats_levels(v))
+    return {"blocks_whole": v[0], "blocks_total": v[1], "candidates_refined": v[2], "sub_blocks": v[3],
+            "clk_wave_phase3": v[4], "clk_origins": v[5], "clk_sub_bounds": v[6], "clk_exact": v[7],
+            "clk_slowest_wave": v[8], "clk_seeds": v[9], "clk_bounds": v[10]}
 
 
 def score_volume(scans, grids, src, slot, theta0, search, origin=(0, 0)):

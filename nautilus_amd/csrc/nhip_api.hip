@@ -63,7 +63,13 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   L->pool_rows = (L->S + 2 * L->pad + BNB_B - 1) / BNB_B + BNB_MAX_NB + 1;
   L->pool_pitch = (((L->S + 2 * L->pad + BNB_B - 1) / BNB_B + BNB_MAX_NB + 5) + 15) & ~15;
   L->pool_bytes = (int64_t)L->pool_rows * L->pool_pitch;
-  L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes;
+  // second-level table: per 4 x 4 stored cells a PAIR of bytes {P4[i][j], P4[i + 1][j]} (the two sub-block rows of a
+  // block in one read); a block's sub-blocks reach 2 * BNB_MAX_NB entries past the origin's, and a strip of three
+  // blocks is read as 16 bytes from a 4-byte-aligned offset
+  L->pool4_rows = (L->S + 2 * L->pad + BNB_B4 - 1) / BNB_B4 + 2 * BNB_MAX_NB + 2;
+  L->pool4_pitch = ((2 * ((L->S + 2 * L->pad + BNB_B4 - 1) / BNB_B4 + 2 * BNB_MAX_NB + 2) + 16) + 15) & ~15;
+  L->pool4_bytes = (int64_t)L->pool4_rows * L->pool4_pitch;
+  L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes;
   L->Lf = log(spec->floor_p);
   L->step = -L->Lf / (double)L->levels;
   // integer taps: round(16384 * g_i / sum g)
@@ -273,6 +279,9 @@ int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out) {
   out->pool_bytes = L.pool_bytes;
   out->pool_pitch = L.pool_pitch;
   out->pool_rows = L.pool_rows;
+  out->pool4_bytes = L.pool4_bytes;
+  out->pool4_pitch = L.pool4_pitch;
+  out->pool4_rows = L.pool4_rows;
   return NHIP_OK;
 }
 
@@ -614,6 +623,14 @@ int nhip_grids_download_pool(const nhip_grids_t *grids, int32_t slot, uint8_t *o
   const GridLayout &L = grids->L;
   NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes + L.skip_bytes,
                          (size_t)L.pool_bytes, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_grids_download_pool4(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
+  NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_pool4: bad arguments");
+  const GridLayout &L = grids->L;
+  NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes + L.skip_bytes + L.pool_bytes,
+                         (size_t)L.pool4_bytes, hipMemcpyDeviceToHost));
   return NHIP_OK;
 }
 
@@ -1088,11 +1105,20 @@ int nhip_bnb_stats_per_pair(uint64_t *evaluated, int32_t n_pairs) {
 }
 
 int nhip_bnb_stats(uint64_t *evaluated, uint64_t *total) {
-  unsigned long long v[2];
+  unsigned long long v[16];
   int rc = bnb_stats_read(v);
   if (rc) return rc;
-  if (evaluated) *evaluated = v[0];
+  if (evaluated) *evaluated = v[0] + (v[3] + 3) / 4;  // in blocks: four sub-blocks = one block
   if (total) *total = v[1];
+  return NHIP_OK;
+}
+
+int nhip_bnb_stats_levels(uint64_t out[16]) {
+  NHIP_REQUIRE(out != nullptr, "bnb_stats_levels: null out");
+  unsigned long long v[16];
+  int rc = bnb_stats_read(v);
+  if (rc) return rc;
+  for (int i = 0; i < 16; i++) out[i] = v[i];
   return NHIP_OK;
 }
 

@@ -39,7 +39,8 @@ constexpr int SEG_CHUNKS = 32;        // 64-point chunks between reductions: 32 
 constexpr int EVAL_CHUNKS = NHIP_BNB_EVAL_CHUNKS;  // 64-point chunks whose row loads a block evaluation keeps in flight
 constexpr int QCAP = 1024;            // candidate queue entries per workgroup (overflow is evaluated by the wave that found it)
 constexpr uint32_t M8 = 0x00ff00ffu;
-constexpr int BNB_STATS_PAIRS = 1 << 20;  // per-pair counters kept by NHIP_BNB_STATS=1
+constexpr int BNB_STATS_PAIRS = 1 << 20;
+constexpr int BNB_STATS_HEAD = 16;       // totals: 4 counts, then shader-clock sums of the by-rotation kernel (see nhip_bnb_stats_levels)  // per-pair counters kept by NHIP_BNB_STATS=1
 
 struct BnbParams {
   const float2 *xy;
@@ -51,15 +52,21 @@ struct BnbParams {
   const double *delta_cs;
   const int32_t *pair_origin;
   unsigned long long *keys;
-  unsigned long long *stats;  // optional: [0] blocks evaluated, [1] blocks in all
+  unsigned long long *stats;  // optional: [0] blocks evaluated whole, [1] blocks in all, [2] candidates refined,
+                              //   [3] 4 x 4 sub-blocks evaluated; then one count of candidates per pair
   uint4 *cand_list;           // optional global candidate lists (caller's workspace), one per XCD so that a pair's
   uint32_t *cand_count;       //   candidates are evaluated where its grid is L2-resident: {U, pair, k << 8 | slot, 0};
   uint32_t cand_cap;          //   8 fill counters (32 bytes apart); entries per list
   int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
   int32_t S, pad, pitch, rows, max_shift;
   int32_t pool_pitch, pool_rows, pairs_per_xcd;
-  int32_t debug;  // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only
-  int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes;
+  int32_t pool4_pitch;
+  int32_t whole_min;    // sub-blocks alive from which an 8-bit block is evaluated whole (3; NHIP_BNB_WHOLE_MIN)
+  int32_t general_all;  // the general instantiation takes every pair (two-kernel form, NHIP_BNB_QUEUE=1)
+  int32_t levels;  // 2: candidates are refined through the 4 x 4 sub-block bounds; 1: evaluated whole (NHIP_BNB_LEVELS)
+  int32_t debug;   // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only,
+                   // 4 = phase 3 without exact sums, 5 = phase 3 without sub-block bounds and exact sums
+  int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes, pool4_bytes;
   double res, inv_res;
 };
 
@@ -98,6 +105,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void *base,
   const int n = __builtin_amdgcn_readfirstlane((int)(bytes < 0x7fffffffll ? bytes : 0x7fffffffll));
   return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void *>(((uint64_t)hi << 32) | lo), 0, n, 0x00020000);
 }
+
+__device__ __forceinline__ uint32_t idx_guard(bool live, uint32_t v) { return live ? v : 0u; }
 
 __device__ __forceinline__ uint32_t shfl_xor_u32(uint32_t v, int m) { return (uint32_t)__shfl_xor((int)v, m, 64); }
 
@@ -385,6 +394,439 @@ __device__ __forceinline__ unsigned long long eval_block(const BnbParams &P, con
   return key;
 }
 
+// ---- second level: bounds of the four 4 x 4 sub-blocks of block (Y, X) ------------------------------------
+// Sub-block (sy, sx) of a point with window origin (r, c) reads stored rows [r + 8Y + 4sy, + 4) and columns
+// [c + 8X + 4sx, + 4): inside the 7 x 7 cells of P4[(r >> 2) + 2Y + sy][(c >> 2) + 2X + sx].  The table holds the
+// byte pair {P4[i][j], P4[i + 1][j]} at (i, 2j): the four entries of a block are four consecutive bytes, ONE 8-byte
+// load per point from a 4-byte-aligned offset -- against eight 12-byte loads for the block's exact sums.
+// Returns the bounds (already scaled to the cell width) of sub-block q = 2 sy + sx in out[q], the same in every lane.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void sub_bounds(const BnbParams &P, __amdgpu_buffer_rsrc_t p4, const float2 *pts, int32_t n_pts,
+                                           float cf, float sf, int32_t cx, int32_t cy, int32_t Y, int32_t X, int lane,
+                                           uint32_t scale, uint32_t (&out)[4]) {
+  const int32_t DP = P.pool4_pitch;
+  uint32_t A[4] = {0u, 0u, 0u, 0u};  // 32-bit sums, one per sub-block
+  constexpr int U = 4;               // chunks whose loads are in flight together
+  for (int32_t c = 0; c < n_pts; c += 64 * U) {
+    uint32_t a[U];
+    u32x2 w[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const int32_t idx = c + 64 * u + lane;
+      a[u] = 0u;  // (no point: the table's first bytes lie in the zero border)
+      if (idx < n_pts) {
+        int32_t prow, pcol;
+        window_origin(pts[idx], cf, sf, P, cx, cy, &prow, &pcol);
+        a[u] = (uint32_t)(((prow >> 2) + 2 * Y) * DP + 2 * ((pcol >> 2) + 2 * X));
+      }
+      w[u] = __builtin_amdgcn_raw_buffer_load_b64(p4, (int)(a[u] & ~3u), 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+      const uint32_t n = idx_guard(c + 64 * u + lane < n_pts, __builtin_amdgcn_alignbit(w[u].y, w[u].x, (a[u] & 2u) * 8u));
+      A[0] += n & 0xffu;          // (sy 0, sx 0)
+      A[2] += (n >> 8) & 0xffu;   // (sy 1, sx 0)
+      A[1] += (n >> 16) & 0xffu;  // (sy 0, sx 1)
+      A[3] += n >> 24;            // (sy 1, sx 1)
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) A[q] += shfl_xor_u32(A[q], m);
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++) out[q] = A[q] * scale;
+}
+
+// ---- exact sums of one 4 x 4 sub-block ----------------------------------------------------------------------
+// As eval_block on rows [4 sy, 4 sy + 4) and columns [4 sx, 4 sx + 4) of block (Y, X): four loads per point.
+template <int CB>
+__device__ __forceinline__ unsigned long long eval_sub(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc, const float2 *pts,
+                                                       int32_t n_pts, float cf, float sf, int32_t cx, int32_t cy,
+                                                       int32_t k, int32_t Y, int32_t X, int32_t sy, int32_t sx, int lane) {
+  uint32_t total = 0u;
+  int dy, dx;
+  const float2 none = make_float2(0.f, 0.f);
+  constexpr int U = 4;  // chunks whose loads are in flight together
+  if (CB == 1) {
+    static_assert(SEG_CHUNKS % U == 0, "segments are whole iterations");
+    for (int32_t c0 = 0; c0 < n_pts; c0 += 64 * SEG_CHUNKS) {
+      uint32_t E[4], O[4];
+#pragma unroll
+      for (int y = 0; y < 4; y++) E[y] = O[y] = 0u;
+      const int32_t c1 = min(n_pts, c0 + 64 * SEG_CHUNKS);
+      for (int32_t c = c0; c < c1; c += 64 * U) {
+        uint32_t sh[U];
+        u32x2 w[U][4];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+          const int32_t idx = c + 64 * u + lane;
+          uint32_t g;
+          patch_origin(P, idx < c1, idx < c1 ? pts[idx] : none, cf, sf, cx, cy, Y, X, &g, &sh[u]);
+          if (idx < c1) g += (uint32_t)(BNB_B4 * sy * P.pitch + BNB_B4 * sx);
+#pragma unroll
+          for (int y = 0; y < 4; y++) w[u][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(g + (uint32_t)(y * P.pitch)), 0, 0);
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++)
+#pragma unroll
+          for (int y = 0; y < 4; y++) {
+            const uint32_t n = __builtin_amdgcn_alignbit(w[u][y].y, w[u][y].x, sh[u]);
+            E[y] += n & M8;
+            O[y] += n >> 8;
+          }
+      }
+      uint32_t R[8];  // R[2 y + d]: d = 0: dx 0, 2; d = 1: dx 1, 3
+#pragma unroll
+      for (int y = 0; y < 4; y++) {
+        R[2 * y] = E[y];
+        R[2 * y + 1] = O[y] - ((E[y] >> 16) << 8);
+      }
+      rs_step<8>(R, lane & 1, 1);
+      rs_step<4>(R, lane & 2, 2);
+      rs_step<2>(R, lane & 4, 4);
+      uint32_t V[2] = {R[0] & 0xffffu, R[0] >> 16};
+      rs_step<2>(V, lane & 8, 8);
+      V[0] += shfl_xor_u32(V[0], 16);
+      V[0] += shfl_xor_u32(V[0], 32);
+      total += V[0];
+    }
+    dy = ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1);
+    dx = (lane & 1) + 2 * ((lane >> 3) & 1);
+  } else {
+    uint32_t A[16];  // A[4 y + x]
+#pragma unroll
+    for (int i = 0; i < 16; i++) A[i] = 0u;
+    for (int32_t c = 0; c < n_pts; c += 64 * U) {
+      uint32_t sh[U];
+      u32x3 w[U][4];
+#pragma unroll
+      for (int u = 0; u < U; u++) {
+        const int32_t idx = c + 64 * u + lane;
+        uint32_t g = 0u;
+        sh[u] = 0u;
+        if (idx < n_pts) {
+          int32_t prow, pcol;
+          window_origin(pts[idx], cf, sf, P, cx, cy, &prow, &pcol);
+          const int32_t col = pcol + BNB_B * X + BNB_B4 * sx;
+          g = (uint32_t)((prow + BNB_B * Y + BNB_B4 * sy) * P.pitch + ((2 * col) & ~3));
+          sh[u] = (uint32_t)(col & 1) * 16u;
+        }
+#pragma unroll
+        for (int y = 0; y < 4; y++) w[u][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(g + (uint32_t)(y * P.pitch)), 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < U; u++)
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          const uint32_t n0 = __builtin_amdgcn_alignbit(w[u][y].y, w[u][y].x, sh[u]);
+          const uint32_t n1 = __builtin_amdgcn_alignbit(w[u][y].z, w[u][y].y, sh[u]);
+          A[4 * y + 0] += n0 & 0xffffu;
+          A[4 * y + 1] += n0 >> 16;
+          A[4 * y + 2] += n1 & 0xffffu;
+          A[4 * y + 3] += n1 >> 16;
+        }
+    }
+    rs_step<16>(A, lane & 1, 1);
+    rs_step<8>(A, lane & 2, 2);
+    rs_step<4>(A, lane & 4, 4);
+    rs_step<2>(A, lane & 8, 8);
+    A[0] += shfl_xor_u32(A[0], 16);
+    A[0] += shfl_xor_u32(A[0], 32);
+    total = A[0];  // lane l holds A[l & 15]
+    dy = (lane >> 2) & 3;
+    dx = lane & 3;
+  }
+  const int32_t ix = BNB_B * X + BNB_B4 * sx + dx, iy = BNB_B * Y + BNB_B4 * sy + dy;
+  unsigned long long key = 0ull;
+  if (ix < P.nx && iy < P.ny) {
+    const uint32_t lin = (uint32_t)((k * P.nx + ix) * P.ny + iy);
+    key = ((unsigned long long)total << 32) | (0xffffffffu - lin);
+  }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {  // (lanes 16.. hold copies)
+    const unsigned long long o = shfl_xor_u64b(key, m);
+    key = o > key ? o : key;
+  }
+  return key;
+}
+
+// ==== the same three passes with the window origins of one rotation held in registers ======================
+// All candidates of rotation k share the 1081 window origins; computing them (a point load, two double-precision
+// floor quotients) per candidate made every pass a chain of dependent latencies.  A wave that owns rotation k keeps
+// them packed (row << 16 | column; both < 65536) in OC registers -- scans of up to 64 * OC points -- and a pass
+// becomes: all loads of nine chunks issued back to back, then the adds.  Lanes without a point hold origin (0, 0):
+// every patch of theirs lies in the zero border (8 * NB + 7 < pad) and pooled entries there are zero.
+constexpr int OC = 18;
+
+__device__ __forceinline__ void cache_origins(const BnbParams &P, const float2 *pts, int32_t n_pts, float cf, float sf,
+                                              int32_t cx, int32_t cy, int lane, uint32_t (&org)[OC]) {
+  // (rolled: the origin arithmetic holds a division on its rare path; the arrays rotate so that indices stay static.
+  //  The points of the next D chunks are in flight while one chunk's origins are computed.)
+  constexpr int D = 6;
+  float px[D], py[D];
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+    const float2 q = 64 * d + lane < n_pts ? pts[64 * d + lane] : make_float2(0.f, 0.f);
+    px[d] = q.x;
+    py[d] = q.y;
+  }
+#pragma unroll 1
+  for (int c = 0; c < OC; c++) {
+    const int32_t idx = 64 * c + lane;
+    const float2 pt = make_float2(px[0], py[0]);
+    const float2 qn = idx + 64 * D < n_pts ? pts[idx + 64 * D] : make_float2(0.f, 0.f);
+#pragma unroll
+    for (int d = 0; d < D - 1; d++) {
+      px[d] = px[d + 1];
+      py[d] = py[d + 1];
+    }
+    px[D - 1] = qn.x;
+    py[D - 1] = qn.y;
+    uint32_t o = 0u;
+    if (idx < n_pts) {
+      int32_t prow, pcol;
+      window_origin(pt, cf, sf, P, cx, cy, &prow, &pcol);
+      o = ((uint32_t)prow << 16) | (uint32_t)pcol;
+    }
+#pragma unroll
+    for (int i = 0; i < OC - 1; i++) org[i] = org[i + 1];
+    org[OC - 1] = o;
+  }
+}
+
+// Sub-block bounds of a strip of up to three blocks (Y, X0), (Y, X0 + 1), (Y, X0 + 2): their twelve table bytes are
+// consecutive, ONE 16-byte load per point.  out[4 t + q]: block X0 + t, sub-block q = 2 sy + sx.
+__device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buffer_rsrc_t p4, const uint32_t (&org)[OC],
+                                               int32_t nch, int32_t Y, int32_t X0, uint32_t scale, uint32_t (&out)[12]) {
+  const uint32_t DP = (uint32_t)P.pool4_pitch;
+  const uint32_t off = (uint32_t)(2 * Y) * DP + (uint32_t)(4 * X0);
+  uint32_t E[3] = {0u, 0u, 0u}, O[3] = {0u, 0u, 0u};  // 16-bit fields: 18 chunks * 255 * 8 lanes < 65536
+  constexpr int H = OC / 2;
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    if (H * h >= nch) continue;
+    u32x4 w[H];
+    uint32_t sh[H];
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+      const uint32_t o = org[H * h + j];
+      // (lanes without a point: origin (0, 0), whose entries lie in the zero border)
+      const uint32_t a = (o >> 18) * DP + 2u * ((o >> 2) & 0x3fffu) + off;
+      sh[j] = (a & 2u) * 8u;
+      w[j] = __builtin_amdgcn_raw_buffer_load_b128(p4, (int)(a & ~3u), 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < H; j++) {
+      const uint32_t n0 = __builtin_amdgcn_alignbit(w[j].y, w[j].x, sh[j]);
+      const uint32_t n1 = __builtin_amdgcn_alignbit(w[j].z, w[j].y, sh[j]);
+      const uint32_t n2 = __builtin_amdgcn_alignbit(w[j].w, w[j].z, sh[j]);
+      // bytes of n_t: (sy 0, sx 0), (sy 1, sx 0), (sy 0, sx 1), (sy 1, sx 1) of block X0 + t
+      E[0] += n0 & M8; O[0] += (n0 >> 8) & M8;
+      E[1] += n1 & M8; O[1] += (n1 >> 8) & M8;
+      E[2] += n2 & M8; O[2] += (n2 >> 8) & M8;
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 8; m <<= 1) {
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+      E[t] += shfl_xor_u32(E[t], m);
+      O[t] += shfl_xor_u32(O[t], m);
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 3; t++) {
+    out[4 * t + 0] = E[t] & 0xffffu;  // (0, 0)
+    out[4 * t + 1] = E[t] >> 16;      // (0, 1)
+    out[4 * t + 2] = O[t] & 0xffffu;  // (1, 0)
+    out[4 * t + 3] = O[t] >> 16;      // (1, 1)
+  }
+#pragma unroll
+  for (int m = 8; m < 64; m <<= 1) {
+#pragma unroll
+    for (int q = 0; q < 12; q++) out[q] += shfl_xor_u32(out[q], m);
+  }
+#pragma unroll
+  for (int q = 0; q < 12; q++) out[q] *= scale;
+}
+
+template <int CB>
+__device__ __forceinline__ unsigned long long eval_sub_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
+                                                         const uint32_t (&org)[OC], int32_t nch, int32_t k, int32_t Y,
+                                                         int32_t X, int32_t sy, int32_t sx, int lane) {
+  uint32_t total;
+  int dy, dx;
+  const uint32_t pitch = (uint32_t)P.pitch;
+  const uint32_t off = (uint32_t)(BNB_B * Y + BNB_B4 * sy) * pitch + (uint32_t)(BNB_B * X + BNB_B4 * sx) * (uint32_t)CB;
+  constexpr int U = CB == 1 ? 6 : 3;  // chunks per round: 24 (12) row loads in flight
+  static_assert(OC % U == 0, "whole rounds");
+  if (CB == 1) {
+    // (18 chunks * 255 * 8 lanes < 65536: the packed fields hold a whole scan)
+    uint32_t E[4] = {0u, 0u, 0u, 0u}, O[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int r = 0; r < OC / U; r++) {
+      if (U * r >= nch) continue;
+      u32x2 w[U][4];
+      uint32_t sh[U];
+#pragma unroll
+      for (int j = 0; j < U; j++) {
+        const uint32_t o = org[U * r + j];
+        const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
+        sh[j] = (g & 3u) * 8u;
+#pragma unroll
+        for (int y = 0; y < 4; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < U; j++)
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          const uint32_t n = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+          E[y] += n & M8;
+          O[y] += n >> 8;
+        }
+    }
+    uint32_t R[8];  // R[2 y + d]: d = 0: dx 0, 2; d = 1: dx 1, 3
+#pragma unroll
+    for (int y = 0; y < 4; y++) {
+      R[2 * y] = E[y];
+      R[2 * y + 1] = O[y] - ((E[y] >> 16) << 8);
+    }
+    rs_step<8>(R, lane & 1, 1);
+    rs_step<4>(R, lane & 2, 2);
+    rs_step<2>(R, lane & 4, 4);
+    uint32_t V[2] = {R[0] & 0xffffu, R[0] >> 16};
+    rs_step<2>(V, lane & 8, 8);
+    V[0] += shfl_xor_u32(V[0], 16);
+    V[0] += shfl_xor_u32(V[0], 32);
+    total = V[0];
+    dy = ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1);
+    dx = (lane & 1) + 2 * ((lane >> 3) & 1);
+  } else {
+    uint32_t A[16];  // A[4 y + x]
+#pragma unroll
+    for (int i = 0; i < 16; i++) A[i] = 0u;
+#pragma unroll
+    for (int r = 0; r < OC / U; r++) {
+      if (U * r >= nch) continue;
+      u32x3 w[U][4];
+      uint32_t sh[U];
+#pragma unroll
+      for (int j = 0; j < U; j++) {
+        const uint32_t o = org[U * r + j];
+        const uint32_t g = (o >> 16) * pitch + 2u * (o & 0xffffu) + off;
+        sh[j] = (g & 2u) * 8u;
+#pragma unroll
+        for (int y = 0; y < 4; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < U; j++)
+#pragma unroll
+        for (int y = 0; y < 4; y++) {
+          const uint32_t n0 = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+          const uint32_t n1 = __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
+          A[4 * y + 0] += n0 & 0xffffu;
+          A[4 * y + 1] += n0 >> 16;
+          A[4 * y + 2] += n1 & 0xffffu;
+          A[4 * y + 3] += n1 >> 16;
+        }
+    }
+    rs_step<16>(A, lane & 1, 1);
+    rs_step<8>(A, lane & 2, 2);
+    rs_step<4>(A, lane & 4, 4);
+    rs_step<2>(A, lane & 8, 8);
+    A[0] += shfl_xor_u32(A[0], 16);
+    A[0] += shfl_xor_u32(A[0], 32);
+    total = A[0];  // lane l holds A[l & 15]
+    dy = (lane >> 2) & 3;
+    dx = lane & 3;
+  }
+  const int32_t ix = BNB_B * X + BNB_B4 * sx + dx, iy = BNB_B * Y + BNB_B4 * sy + dy;
+  unsigned long long key = 0ull;
+  if (ix < P.nx && iy < P.ny) {
+    const uint32_t lin = (uint32_t)((k * P.nx + ix) * P.ny + iy);
+    key = ((unsigned long long)total << 32) | (0xffffffffu - lin);
+  }
+#pragma unroll
+  for (int m = 8; m >= 1; m >>= 1) {  // (lanes 16.. hold copies)
+    const unsigned long long o = shfl_xor_u64b(key, m);
+    key = o > key ? o : key;
+  }
+  return key;
+}
+
+// whole 8 x 8 block, 8-bit cells (16-bit cells take their four sub-blocks: the same number of loads)
+__device__ __forceinline__ unsigned long long eval_block_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
+                                                           const uint32_t (&org)[OC], int32_t nch, int32_t k, int32_t Y,
+                                                           int32_t X, int lane) {
+  const uint32_t pitch = (uint32_t)P.pitch;
+  const uint32_t off = (uint32_t)(BNB_B * Y) * pitch + (uint32_t)(BNB_B * X);
+  constexpr int U = 2;
+  uint32_t E[8][2], O[8][2];
+#pragma unroll
+  for (int y = 0; y < 8; y++) E[y][0] = E[y][1] = O[y][0] = O[y][1] = 0u;
+#pragma unroll
+  for (int r = 0; r < OC / U; r++) {
+    if (U * r >= nch) continue;
+    u32x3 w[U][8];
+    uint32_t sh[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) {
+      const uint32_t o = org[U * r + j];
+      const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
+      sh[j] = (g & 3u) * 8u;
+#pragma unroll
+      for (int y = 0; y < 8; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++)
+#pragma unroll
+      for (int y = 0; y < 8; y++) {
+        const uint32_t n0 = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+        const uint32_t n1 = __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
+        E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
+        E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
+      }
+  }
+  uint32_t R[32];  // R[4 y + d]: d = 0: dx 0, 2; 1: dx 1, 3; 2: dx 4, 6; 3: dx 5, 7
+#pragma unroll
+  for (int y = 0; y < 8; y++) {
+    R[4 * y + 0] = E[y][0];
+    R[4 * y + 1] = O[y][0] - ((E[y][0] >> 16) << 8);
+    R[4 * y + 2] = E[y][1];
+    R[4 * y + 3] = O[y][1] - ((E[y][1] >> 16) << 8);
+  }
+  rs_step<32>(R, lane & 1, 1);
+  rs_step<16>(R, lane & 2, 2);
+  rs_step<8>(R, lane & 4, 4);
+  uint32_t V[8];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    V[2 * i] = R[i] & 0xffffu;
+    V[2 * i + 1] = R[i] >> 16;
+  }
+  rs_step<8>(V, lane & 8, 8);
+  rs_step<4>(V, lane & 16, 16);
+  rs_step<2>(V, lane & 32, 32);
+  const int r = 8 * (2 * ((lane >> 5) & 1) + ((lane >> 4) & 1)) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 1) & 1) + (lane & 1);
+  const int f = (lane >> 3) & 1, d = r & 3;
+  const int dy = r >> 2, dx = 4 * (d >> 1) + (d & 1) + 2 * f;
+  const int32_t ix = BNB_B * X + dx, iy = BNB_B * Y + dy;
+  unsigned long long key = 0ull;
+  if (ix < P.nx && iy < P.ny) {
+    const uint32_t lin = (uint32_t)((k * P.nx + ix) * P.ny + iy);
+    key = ((unsigned long long)V[0] << 32) | (0xffffffffu - lin);
+  }
+#pragma unroll
+  for (int m = 32; m >= 1; m >>= 1) {
+    const unsigned long long o = shfl_xor_u64b(key, m);
+    key = o > key ? o : key;
+  }
+  return key;
+}
+
 __device__ __forceinline__ void rotation_k(const BnbParams &P, int32_t pair, int32_t k, float *cf, float *sf) {
   // R(theta0) * R(delta_k), composed in double with individually rounded ops (as csm_correlate_kernel)
   const double c0 = P.rot0_cs[2 * pair], s0 = P.rot0_cs[2 * pair + 1];
@@ -393,7 +835,88 @@ __device__ __forceinline__ void rotation_k(const BnbParams &P, int32_t pair, int
   *sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
 }
 
-template <int CB, bool POOL_LDS>
+// ---- one candidate block: refine through the sub-block bounds, or evaluate whole --------------------------
+// `best` is the pair's running best key (LDS of the pair's workgroup, or keys[pair] in global memory for the
+// two-kernel form).  A sub-block is skipped only if its bound is below the best SUM found so far: it cannot hold
+// the optimum nor a tie with it.  n[0] whole blocks evaluated, n[1] candidates refined, n[2] sub-blocks evaluated.
+struct PairCtx {
+  const uint8_t *grid;
+  const float2 *pts;
+  int32_t n_pts, cx, cy, pair;
+};
+
+template <bool GLOBAL>
+__device__ __forceinline__ uint32_t best_sum(unsigned long long *best) {
+  unsigned long long b;
+  if (GLOBAL) b = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else b = *(volatile unsigned long long *)best;
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));  // one value for the whole wave
+}
+
+template <int CB, bool GLOBAL>
+__device__ __forceinline__ void process_candidate(const BnbParams &P, const PairCtx &C, int32_t k, int32_t v, int lane,
+                                                  unsigned long long *best, uint32_t (&n)[3]) {
+  const int Y = v / NB, X = v - NB * Y;  // v: block index NB * Y + X
+  float cf, sf;
+  rotation_k(P, C.pair, k, &cf, &sf);
+  if (P.levels >= 2) {
+    const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(C.grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
+    uint32_t sb[4];
+    sub_bounds(P, p4, C.pts, C.n_pts, cf, sf, C.cx, C.cy, Y, X, lane, CB == 1 ? 1u : 257u, sb);
+    n[1]++;
+    const uint32_t bsum = best_sum<GLOBAL>(best);
+    int alive = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) alive += (sb[q] != 0u && sb[q] >= bsum) ? 1 : 0;
+    if (alive == 0) return;
+    if (alive <= 2) {
+      const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(C.grid, P.grid_bytes + P.skip_bytes);
+#pragma unroll 1
+      for (int q = 0; q < 4; q++) {
+        const uint32_t b = q == 0 ? sb[0] : (q == 1 ? sb[1] : (q == 2 ? sb[2] : sb[3]));  // (no indexed array: scratch)
+        if (b == 0u || b < best_sum<GLOBAL>(best)) continue;
+        const unsigned long long key = eval_sub<CB>(P, rsrc, C.pts, C.n_pts, cf, sf, C.cx, C.cy, k, Y, X, q >> 1, q & 1, lane);
+        if (lane == 0) atomicMax(best, key);
+        n[2]++;
+      }
+      return;
+    }
+  }
+  const unsigned long long key = eval_block<CB>(P, C.grid, C.pts, C.n_pts, cf, sf, C.cx, C.cy, k, Y, X, lane);
+  if (lane == 0) atomicMax(best, key);
+  n[0]++;
+}
+
+// ... with the rotation's origins in registers (LDS-resident best) and the block's four sub-block bounds at hand
+template <int CB>
+__device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
+                                                    const uint32_t (&org)[OC], int32_t nch, int32_t k, int32_t Y, int32_t X,
+                                                    uint32_t sb0, uint32_t sb1, uint32_t sb2, uint32_t sb3, int lane,
+                                                    unsigned long long *best, uint32_t (&n)[3]) {
+  const uint32_t bsum = best_sum<false>(best);
+  const int alive = (sb0 != 0u && sb0 >= bsum) + (sb1 != 0u && sb1 >= bsum) + (sb2 != 0u && sb2 >= bsum) +
+                    (sb3 != 0u && sb3 >= bsum);
+  if (alive == 0) return;
+  if (CB == 1 && alive >= P.whole_min) {
+    const unsigned long long key = eval_block_c(P, rsrc, org, nch, k, Y, X, lane);
+    if (lane == 0) atomicMax(best, key);
+    n[0]++;
+    return;
+  }
+#pragma unroll 1
+  for (int q = 0; q < 4; q++) {
+    const uint32_t b = q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3));
+    if (b == 0u || b < best_sum<false>(best)) continue;
+    const unsigned long long key = eval_sub_c<CB>(P, rsrc, org, nch, k, Y, X, q >> 1, q & 1, lane);
+    if (lane == 0) atomicMax(best, key);
+    n[2]++;
+  }
+}
+
+// BY_ROT: the pairs whose scan fits the register-held origins (n_pts <= 64 * OC), rotation by rotation; the other
+// instantiation takes the longer scans -- or, with P.general_all (two-kernel form, NHIP_BNB_QUEUE=1), every pair.
+// Both are launched; a workgroup whose pair belongs to the other one returns at once.
+template <int CB, bool POOL_LDS, bool BY_ROT>
 __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   extern __shared__ __align__(16) uint8_t smem[];
   uint8_t *s_pool = smem;                                                       // pool_bytes (POOL_LDS)
@@ -416,13 +939,16 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   const int32_t cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
   const int32_t cy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
   const bool centre_ok = (abs(cx) + P.hx <= P.max_shift) && (abs(cy) + P.hy <= P.max_shift);
+  if (BY_ROT != (n_pts <= 64 * OC && !P.general_all)) return;  // the other instantiation's pair
 
   // pose 0 with sum 0 is a lower bound of the optimum (sums are >= 0; if all are 0, pose 0 is the answer)
   const unsigned long long key0 = 0xffffffffull;
+  const long long t_start = P.stats ? clock64() : 0;
   if (threadIdx.x == 0) {
+    if (BY_ROT) s_queue[0] = 0ull;
     // (NHIP_BNB_DEBUG=3, experiments only: start from the keys a previous launch left = the ideal threshold)
     *s_best = P.debug == 3 ? (P.keys[pair] & 0xffffffff00000000ull) : key0;
-    *s_cnt = 0u;
+    s_cnt[0] = s_cnt[3] = s_cnt[4] = 0u;
     *s_qn = 0u;
     *s_qhead = 0u;
   }
@@ -446,13 +972,16 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     rotation_k(P, pair, k, &cf, &sf);
     uint32_t tot[2];
     coarse_rotation<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, tot);
+    if (lane < 128 - NB * NB) s_U[k * 128 + NB * NB + lane] = 0u;  // (the row's unused tail)
 #pragma unroll
     for (int i = 0; i < 2; i++) {
+      // the bounds go to LDS in block order: entry b = NB * Y + X, so that neighbours in X are neighbours in b
       int Y, X;
-      const bool ok = slot_block(lane + 64 * i, &Y, &X) && Y < P.nby && X < P.nbx;
-      const uint32_t u = ok ? tot[i] * scale : 0u;
-      s_U[k * 128 + lane + 64 * i] = u;
-      const unsigned long long cand = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | (lane + 64 * i));
+      if (!slot_block(lane + 64 * i, &Y, &X)) continue;
+      const uint32_t u = (Y < P.nby && X < P.nbx) ? tot[i] * scale : 0u;
+      const int b = NB * Y + X;
+      s_U[k * 128 + b] = u;
+      const unsigned long long cand = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | b);
       wbest = cand > wbest ? cand : wbest;
     }
   }
@@ -462,93 +991,200 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     wbest = o > wbest ? o : wbest;
   }
   // (2) seed: the wave's highest-bound block, evaluated exactly
-  uint32_t n_eval = 0u;
-  if ((uint32_t)(wbest >> 32) != 0u && P.debug < 2) {
-    const int32_t k = (int32_t)((uint32_t)wbest >> 8), v = (int32_t)(wbest & 0xffu);
-    int Y, X;
-    slot_block(v, &Y, &X);
-    float cf, sf;
-    rotation_k(P, pair, k, &cf, &sf);
-    const unsigned long long key = eval_block<CB>(P, grid, pts, n_pts, cf, sf, cx, cy, k, Y, X, lane);
-    if (lane == 0) {
-      atomicMax(s_best, key);
-      s_U[k * 128 + v] = 0u;  // done
-    }
-    n_eval++;
-  }
-  __syncthreads();
-  // (3) every block whose bound reaches the best sum found so far.  The survivors cluster in a few rotations,
-  // i.e. in a few waves: they go through one queue per workgroup that all eight waves drain.
-  auto evaluate = [&](unsigned long long entry) {
-    const uint32_t u = (uint32_t)(entry >> 32);
-    if (u < (uint32_t)(*(volatile unsigned long long *)s_best >> 32)) return;  // the best has risen meanwhile
-    const int32_t k = (int32_t)((uint32_t)entry >> 8), v = (int32_t)(entry & 0xffu);
-    int Y, X;
-    slot_block(v, &Y, &X);
-    float cf, sf;
-    rotation_k(P, pair, k, &cf, &sf);
-    const unsigned long long key = eval_block<CB>(P, grid, pts, n_pts, cf, sf, cx, cy, k, Y, X, lane);
-    if (lane == 0) atomicMax(s_best, key);
-    n_eval++;
-  };
-  for (int32_t k = wave; k < P.n_theta && (P.debug == 0 || P.debug == 3); k += BNB_WAVES) {
+  uint32_t n_work[3] = {0u, 0u, 0u};
+  PairCtx C;
+  C.grid = grid;
+  C.pts = pts;
+  C.n_pts = n_pts;
+  C.cx = cx;
+  C.cy = cy;
+  C.pair = pair;
+  // Scans of up to 64 * OC points: a wave owns a rotation at a time and keeps its window origins in registers.
+  // Longer scans (and the two-kernel form) take the general path below.
+  if (BY_ROT) {
+    const int32_t nch = (n_pts + 63) >> 6;
+    uint32_t org[OC];
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const uint32_t u = s_U[k * 128 + lane + 64 * i];
-      const uint32_t bsum = (uint32_t)(*(volatile unsigned long long *)s_best >> 32);
-      bool cand = u != 0u && u >= bsum;
-      if (P.cand_list) {
-        // the grid-wide list: a second kernel evaluates it with every wave of the chip (a pair whose landscape is
-        // flat has thousands of survivors, most pairs a few dozen); what does not fit stays with this workgroup
-        const unsigned long long gm = __ballot(cand);
-        if (gm == 0ull) continue;
-        const uint32_t xcd = bid & 7u;
-        uint32_t gbase = 0u;
-        if (lane == 0) gbase = atomicAdd(P.cand_count + 8 * xcd, (uint32_t)__builtin_popcountll(gm));
-        gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
-        const uint32_t gpos = gbase + (uint32_t)__builtin_popcountll(gm & ((1ull << lane) - 1ull));
-        if (cand && gpos < P.cand_cap) {
-          P.cand_list[(size_t)xcd * P.cand_cap + gpos] = make_uint4(u, (uint32_t)pair, (uint32_t)((k << 8) | (lane + 64 * i)), 0u);
-          cand = false;
+    for (int c = 0; c < OC; c++) org[c] = 0u;
+    // First pass (2): the wave's own highest-bound block, alone -- the seeds give `best` a good lower bound before
+    // anything is pruned against it.  Then (3): rotations handed out one at a time; every block of the rotation whose
+    // bound reaches the best sum found so far goes through its sub-block bounds and, where those hold, exact sums.
+    bool first = true;
+    // (NHIP_BNB_STATS=1: shader-clock sums -- wave time in phase 3 by part, and the workgroup's wall time)
+    long long t_org = 0, t_strip = 0, t_eval = 0, t_busy = 0, t_mark = 0;
+    const long long t_phase1 = P.stats ? clock64() : 0;
+    for (;;) {
+      int32_t k;
+      uint32_t u0, u1;
+      if (first) {
+        const int32_t v = (int32_t)(wbest & 0xffu);
+        const uint32_t ub = P.debug < 2 ? (uint32_t)(wbest >> 32) : 0u;
+        k = (int32_t)((uint32_t)wbest >> 8);
+        u0 = (v == lane) ? ub : 0u;
+        u1 = (v == lane + 64) ? ub : 0u;
+      } else {
+        if (!(P.debug == 0 || P.debug >= 3)) break;
+        k = 0;
+        if (lane == 0) k = (int32_t)atomicAdd(s_qhead, 1u);
+        k = __builtin_amdgcn_readfirstlane(k);
+        if (k >= P.n_theta) break;
+        u0 = s_U[k * 128 + lane];
+        u1 = s_U[k * 128 + 64 + lane];
+      }
+      const uint32_t bsum = best_sum<false>(s_best);
+      unsigned long long m0 = __ballot(u0 != 0u && u0 >= bsum), m1 = __ballot(u1 != 0u && u1 >= bsum && lane + 64 < NB * NB);
+      if ((m0 | m1) != 0ull) {
+        float cf, sf;
+        rotation_k(P, pair, k, &cf, &sf);
+        if (P.stats) t_mark = clock64();
+        cache_origins(P, pts, n_pts, cf, sf, cx, cy, lane, org);
+        if (P.stats) t_org += clock64() - t_mark;
+        const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(grid, P.grid_bytes + P.skip_bytes);
+        const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
+        // candidates in block order b = NB * Y + X; neighbours in X (up to three) share one pass over the table
+        while ((m0 | m1) != 0ull) {
+          const int b0 = m0 ? (int)__builtin_ctzll(m0) : 64 + (int)__builtin_ctzll(m1);
+          const int Y = b0 / NB, X0 = b0 - NB * Y;
+          int len = 1;
+          while (len < 3 && X0 + len < NB) {
+            const int b = b0 + len;
+            if (!(((b < 64 ? m0 >> b : m1 >> (b - 64)) & 1ull))) break;
+            len++;
+          }
+          uint32_t sb[12];
+          if (P.debug == 5) {  // (timing: origins only)
+            m0 = m1 = 0ull;
+            break;
+          }
+          if (P.levels >= 2) {
+            if (P.stats) t_mark = clock64();
+            strip_bounds_c(P, p4, org, nch, Y, X0, CB == 1 ? 1u : 257u, sb);
+            if (P.stats) t_strip += clock64() - t_mark;
+            n_work[1] += (uint32_t)len;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 12; q++) sb[q] = 0xffffffffu;
+          }
+#pragma unroll 1
+          for (int t = 0; t < len; t++) {
+            const int b = b0 + t;
+            if (b < 64) m0 &= ~(1ull << b);
+            else m1 &= ~(1ull << (b - 64));
+            const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)(b < 64 ? u0 : u1), b & 63);
+            if (ub < best_sum<false>(s_best) || (P.debug == 4 && !first)) continue;  // the best has risen meanwhile
+            // (selects, not an indexed array: that would live in scratch)
+            const uint32_t s0 = t == 0 ? sb[0] : (t == 1 ? sb[4] : sb[8]), s1 = t == 0 ? sb[1] : (t == 1 ? sb[5] : sb[9]);
+            const uint32_t s2 = t == 0 ? sb[2] : (t == 1 ? sb[6] : sb[10]), s3 = t == 0 ? sb[3] : (t == 1 ? sb[7] : sb[11]);
+            if (P.stats) t_mark = clock64();
+            process_candidate_c<CB>(P, rsrc, org, nch, k, Y, X0 + t, s0, s1, s2, s3, lane, s_best, n_work);
+            if (P.stats) t_eval += clock64() - t_mark;
+            if (first && lane == 0) s_U[k * 128 + b] = 0u;  // done
+          }
         }
       }
-      const unsigned long long m = __ballot(cand);
-      if (m == 0ull) continue;
-      uint32_t base = 0u;
-      if (lane == 0) base = atomicAdd(s_qn, (uint32_t)__builtin_popcountll(m));
-      base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
-      const unsigned long long entry = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | (lane + 64 * i));
-      if (cand && pos < (uint32_t)QCAP) s_queue[pos] = entry;
-      unsigned long long over = __ballot(cand && pos >= (uint32_t)QCAP);  // queue full: this wave takes them itself
-      while (over) {
-        const int j = (int)__builtin_ctzll(over);
-        over &= over - 1ull;
-        const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)entry, j);
-        const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(entry >> 32), j);
-        evaluate(((unsigned long long)hi << 32) | lo);
+      if (first) {
+        first = false;
+        __syncthreads();
+        if (P.stats) t_busy = clock64();
       }
     }
-  }
-  __syncthreads();
-  {
-    const uint32_t qn = min(*s_qn, (uint32_t)QCAP);
-    while (P.debug == 0 || P.debug == 3) {
-      uint32_t i = 0u;
-      if (lane == 0) i = atomicAdd(s_qhead, 1u);
-      i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-      if (i >= qn) break;
-      evaluate(s_queue[i]);
+    if (P.stats && lane == 0) {
+      const long long now = clock64();
+      atomicAdd(&P.stats[4], (unsigned long long)(now - t_busy));       // wave time in phase 3 (until out of work)
+      atomicAdd(&P.stats[5], (unsigned long long)t_org);
+      atomicAdd(&P.stats[6], (unsigned long long)t_strip);
+      atomicAdd(&P.stats[7], (unsigned long long)t_eval);
+      atomicMax(reinterpret_cast<unsigned long long *>(s_queue), (unsigned long long)(now - t_busy));  // slowest wave
+      if (wave == 0) {
+        atomicAdd(&P.stats[9], (unsigned long long)(t_busy - t_phase1));  // seeds (wave 0's view)
+        atomicAdd(&P.stats[10], (unsigned long long)(t_phase1 - t_start)); // bounds
+      }
     }
+  } else {
+  if ((uint32_t)(wbest >> 32) != 0u && P.debug < 2) {
+      const int32_t k = (int32_t)((uint32_t)wbest >> 8), v = (int32_t)(wbest & 0xffu);
+      const int Y = v / NB, X = v - NB * Y;
+      float cf, sf;
+      rotation_k(P, pair, k, &cf, &sf);
+      const unsigned long long key = eval_block<CB>(P, grid, pts, n_pts, cf, sf, cx, cy, k, Y, X, lane);
+      if (lane == 0) {
+        atomicMax(s_best, key);
+        s_U[k * 128 + v] = 0u;  // done
+      }
+      n_work[0]++;
+    }
+    __syncthreads();
+    // (3) every block whose bound reaches the best sum found so far.  The survivors cluster in a few rotations,
+    // i.e. in a few waves: they go through one queue per workgroup that all eight waves drain.
+    for (int32_t k = wave; k < P.n_theta && (P.debug == 0 || P.debug == 3); k += BNB_WAVES) {
+  #pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const uint32_t u = s_U[k * 128 + lane + 64 * i];
+        const uint32_t bsum = (uint32_t)(*(volatile unsigned long long *)s_best >> 32);
+        bool cand = u != 0u && u >= bsum;
+        if (P.cand_list) {
+          // the grid-wide list: a second kernel evaluates it with every wave of the chip (a pair whose landscape is
+          // flat has thousands of survivors, most pairs a few dozen); what does not fit stays with this workgroup
+          const unsigned long long gm = __ballot(cand);
+          if (gm == 0ull) continue;
+          const uint32_t xcd = bid & 7u;
+          uint32_t gbase = 0u;
+          if (lane == 0) gbase = atomicAdd(P.cand_count + 8 * xcd, (uint32_t)__builtin_popcountll(gm));
+          gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
+          const uint32_t gpos = gbase + (uint32_t)__builtin_popcountll(gm & ((1ull << lane) - 1ull));
+          if (cand && gpos < P.cand_cap) {
+            P.cand_list[(size_t)xcd * P.cand_cap + gpos] = make_uint4(u, (uint32_t)pair, (uint32_t)((k << 8) | (lane + 64 * i)), 0u);
+            cand = false;
+          }
+        }
+        const unsigned long long m = __ballot(cand);
+        if (m == 0ull) continue;
+        uint32_t base = 0u;
+        if (lane == 0) base = atomicAdd(s_qn, (uint32_t)__builtin_popcountll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+        const unsigned long long entry = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | (lane + 64 * i));
+        if (cand && pos < (uint32_t)QCAP) s_queue[pos] = entry;
+        unsigned long long over = __ballot(cand && pos >= (uint32_t)QCAP);  // queue full: this wave takes them itself
+        while (over) {
+          const int j = (int)__builtin_ctzll(over);
+          over &= over - 1ull;
+          const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)entry, j);
+          const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(entry >> 32), j);
+          if (hi >= best_sum<false>(s_best))  // (the best may have risen meanwhile)
+            process_candidate<CB, false>(P, C, (int32_t)(lo >> 8), (int32_t)(lo & 0xffu), lane, s_best, n_work);
+        }
+      }
+    }
+    __syncthreads();
+    {
+      const uint32_t qn = min(*s_qn, (uint32_t)QCAP);
+      while (P.debug == 0 || P.debug == 3) {
+        uint32_t i = 0u;
+        if (lane == 0) i = atomicAdd(s_qhead, 1u);
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        if (i >= qn) break;
+        const unsigned long long entry = s_queue[i];
+        if ((uint32_t)(entry >> 32) >= best_sum<false>(s_best))
+          process_candidate<CB, false>(P, C, (int32_t)((uint32_t)entry >> 8), (int32_t)(entry & 0xffu), lane, s_best, n_work);
+      }
+    }
+}
+  if (P.stats && lane == 0) {
+    atomicAdd(&s_cnt[0], n_work[0]);
+    atomicAdd(&s_cnt[3], n_work[1]);
+    atomicAdd(&s_cnt[4], n_work[2]);
   }
-  if (P.stats && lane == 0) atomicAdd(s_cnt, n_eval);
   __syncthreads();
   if (threadIdx.x == 0) {
     P.keys[pair] = *s_best;
+    if (P.stats && BY_ROT) atomicAdd(&P.stats[8], s_queue[0]);  // sum over pairs of the slowest wave's phase 3
     if (P.stats) {
-      atomicAdd(&P.stats[0], (unsigned long long)*s_cnt);
+      atomicAdd(&P.stats[0], (unsigned long long)s_cnt[0]);
       atomicAdd(&P.stats[1], (unsigned long long)(P.n_theta * P.nbx * P.nby));
-      if (pair < BNB_STATS_PAIRS) P.stats[2 + pair] = *s_cnt;
+      atomicAdd(&P.stats[2], (unsigned long long)s_cnt[3]);
+      atomicAdd(&P.stats[3], (unsigned long long)s_cnt[4]);
+      if (pair < BNB_STATS_PAIRS) P.stats[BNB_STATS_HEAD + pair] = 4ull * s_cnt[0] + s_cnt[4];
     }
   }
 }
@@ -565,30 +1201,34 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_eval_kernel(BnbParams P) {
   const uint32_t filled = P.cand_count[8 * xcd];
   const uint32_t count = filled < P.cand_cap ? filled : P.cand_cap;
   const uint4 *list = P.cand_list + (size_t)xcd * P.cand_cap;
-  uint32_t n_eval = 0u;
+  uint32_t n_work[3] = {0u, 0u, 0u};
   for (uint32_t i = wave_id; i < count; i += n_waves) {
     const uint4 c = list[i];
     const int32_t pair = (int32_t)c.y;
     const unsigned long long best = __hip_atomic_load(&P.keys[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (c.x < (uint32_t)(best >> 32)) continue;
     const int32_t k = (int32_t)(c.z >> 8), v = (int32_t)(c.z & 0xffu);
-    int Y, X;
-    slot_block(v, &Y, &X);
     const int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
-    const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
-    const uint8_t *grid = P.grids + (size_t)slot * P.slot_bytes;
-    const int32_t cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
-    const int32_t cy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
-    float cf, sf;
-    rotation_k(P, pair, k, &cf, &sf);
-    const unsigned long long key = eval_block<CB>(P, grid, P.xy + beg, n_pts, cf, sf, cx, cy, k, Y, X, lane);
-    if (lane == 0) {
-      atomicMax(&P.keys[pair], key);
-      if (P.stats && pair < BNB_STATS_PAIRS) atomicAdd(&P.stats[2 + pair], 1ull);
-    }
-    n_eval++;
+    const int32_t beg = P.offsets[src];
+    PairCtx C;
+    C.grid = P.grids + (size_t)slot * P.slot_bytes;
+    C.pts = P.xy + beg;
+    C.n_pts = P.offsets[src + 1] - beg;
+    C.cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
+    C.cy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
+    C.pair = pair;
+    uint32_t n[3] = {0u, 0u, 0u};
+    process_candidate<CB, true>(P, C, k, v, lane, &P.keys[pair], n);
+    if (P.stats && lane == 0 && pair < BNB_STATS_PAIRS) atomicAdd(&P.stats[BNB_STATS_HEAD + pair], 4ull * n[0] + n[2]);
+    n_work[0] += n[0];
+    n_work[1] += n[1];
+    n_work[2] += n[2];
   }
-  if (P.stats && lane == 0 && n_eval) atomicAdd(&P.stats[0], (unsigned long long)n_eval);
+  if (P.stats && lane == 0) {
+    if (n_work[0]) atomicAdd(&P.stats[0], (unsigned long long)n_work[0]);
+    if (n_work[1]) atomicAdd(&P.stats[2], (unsigned long long)n_work[1]);
+    if (n_work[2]) atomicAdd(&P.stats[3], (unsigned long long)n_work[2]);
+  }
 }
 
 size_t bnb_lds_bytes(const GridLayout &L, const nhip_search_t *search, bool pool_lds) {
@@ -653,6 +1293,14 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.skip_bytes = L.skip_bytes;
   P.slot_bytes = L.slot_bytes;
   P.pool_bytes = L.pool_bytes;
+  P.pool4_bytes = L.pool4_bytes;
+  P.pool4_pitch = L.pool4_pitch;
+  const char *lv = getenv("NHIP_BNB_LEVELS");  // (1: without the sub-block bounds -- measurements only; same results)
+  P.levels = lv && lv[0] == '1' ? 1 : 2;
+  const char *wm = getenv("NHIP_BNB_WHOLE_MIN");
+  P.whole_min = wm ? atoi(wm) : 3;
+  const char *qe = getenv("NHIP_BNB_QUEUE");  // (the general path for every scan: tests, measurements)
+  P.general_all = qe && qe[0] == '1';
   P.res = spec->res;
   P.inv_res = 1.0 / spec->res;
   const char *dbg = getenv("NHIP_BNB_DEBUG");
@@ -660,8 +1308,8 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const char *st = getenv("NHIP_BNB_STATS");
   if (st && st[0] == '1') {
     if (!g_bnb_stats) {
-      NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_stats), 8 * (2 + (size_t)BNB_STATS_PAIRS)));
-      NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 8 * (2 + (size_t)BNB_STATS_PAIRS)));
+      NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_stats), 8 * (BNB_STATS_HEAD + (size_t)BNB_STATS_PAIRS)));
+      NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 8 * (BNB_STATS_HEAD + (size_t)BNB_STATS_PAIRS)));
     }
     P.stats = g_bnb_stats;
   }
@@ -671,28 +1319,35 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   // way and evaluating a pair's candidates inside its own workgroup is the faster form (measured: 17.3 vs 19.8 ms
   // per 10,000 pairs; the evaluation is bound by L1 tag lookups, not by balance).  NHIP_BNB_KERNELS=1|2 forces one.
   const char *force = getenv("NHIP_BNB_KERNELS");
-  const bool two = force ? force[0] == '2' : n_pairs <= 2048;
+  const bool two = force ? force[0] == '2' : n_pairs <= 64;
   if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * 16 * 8 && two) {
     P.cand_count = static_cast<uint32_t *>(d_workspace);
     P.cand_list = reinterpret_cast<uint4 *>(static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER);
     const int64_t cap = (workspace_bytes - BNB_WS_HEADER) / 16 / 8;  // entries per XCD list
     P.cand_cap = (uint32_t)(cap < 0x0fffffffll ? cap : 0x0fffffffll);
+    P.general_all = 1;
     NHIP_TRY_HIP(hipMemsetAsync(d_workspace, 0, BNB_WS_HEADER, s));
   }
   const bool pool_lds = bnb_lds_bytes(L, search, true) <= LDS_MAX;
   const size_t lds = bnb_lds_bytes(L, search, pool_lds);
   const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
   timer_begin(NHIP_TIMER_CSM, s);
+#define NHIP_BNB_LAUNCH1(CB, PL, BR)                                                                             \
+  do {                                                                                                           \
+    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL, BR>),                 \
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+    hipLaunchKernelGGL((csm_bnb_kernel<CB, PL, BR>), dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);      \
+  } while (0)
 #define NHIP_BNB_LAUNCH(CB, PL)                                                                                  \
   do {                                                                                                           \
-    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL>),                     \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-    hipLaunchKernelGGL((csm_bnb_kernel<CB, PL>), dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);          \
+    if (!P.general_all) NHIP_BNB_LAUNCH1(CB, PL, true);                                                          \
+    NHIP_BNB_LAUNCH1(CB, PL, false);                                                                             \
   } while (0)
   if (L.cb == 1 && pool_lds) NHIP_BNB_LAUNCH(1, true);
   else if (L.cb == 1) NHIP_BNB_LAUNCH(1, false);
   else if (pool_lds) NHIP_BNB_LAUNCH(2, true);
   else NHIP_BNB_LAUNCH(2, false);
+#undef NHIP_BNB_LAUNCH1
 #undef NHIP_BNB_LAUNCH
   if (P.cand_list && (P.debug == 0 || P.debug == 3)) {
     const uint32_t eval_blocks = 256 * 16;  // 16 workgroups of four waves per CU's worth; waves stride over the list
@@ -709,15 +1364,15 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
 // NHIP_BNB_STATS=1: (blocks evaluated exactly, blocks in all) since the last call; resets the counters
 int bnb_stats_per_pair(unsigned long long *out, int32_t n) {
   if (!g_bnb_stats || n <= 0) return NHIP_OK;
-  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_stats + 2, 8 * (size_t)(n < BNB_STATS_PAIRS ? n : BNB_STATS_PAIRS), hipMemcpyDeviceToHost));
+  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_stats + BNB_STATS_HEAD, 8 * (size_t)(n < BNB_STATS_PAIRS ? n : BNB_STATS_PAIRS), hipMemcpyDeviceToHost));
   return NHIP_OK;
 }
 
-int bnb_stats_read(unsigned long long out[2]) {
-  out[0] = out[1] = 0;
+int bnb_stats_read(unsigned long long out[16]) {
+  for (int i = 0; i < BNB_STATS_HEAD; i++) out[i] = 0;
   if (!g_bnb_stats) return NHIP_OK;
-  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_stats, 16, hipMemcpyDeviceToHost));
-  NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 16));
+  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_stats, 8 * BNB_STATS_HEAD, hipMemcpyDeviceToHost));
+  NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 8 * BNB_STATS_HEAD));
   return NHIP_OK;
 }
 

@@ -42,8 +42,10 @@ struct GridLayout {
   int64_t grid_bytes;  // pitch * rows: the stored image
   int64_t skip_bytes;  // skip_pitch(pitch) * rows rounded up to 16: the skip map that follows the image
   int64_t pool_bytes;  // pool_rows * pool_pitch: the max-pooled table (branch-and-bound bounds) after the skip map
-  int64_t slot_bytes;  // grid_bytes + skip_bytes + pool_bytes: stride between consecutive grids of a buffer
+  int64_t pool4_bytes; // pool4_rows * pool4_pitch: the stride-4 pooled table (second bound level) after the first
+  int64_t slot_bytes;  // grid_bytes + skip_bytes + pool_bytes + pool4_bytes: stride between consecutive grids of a buffer
   int32_t pool_pitch, pool_rows;
+  int32_t pool4_pitch, pool4_rows;
   double Lf, step;
 };
 // Branch and bound works on 8 x 8 blocks of translations; a pooled entry covers the 15 x 15 stored cells an 8 x 8
@@ -51,6 +53,9 @@ struct GridLayout {
 constexpr int BNB_B = 8;
 constexpr int BNB_POOL = 2 * BNB_B - 1;
 constexpr int BNB_MAX_NB = 11;  // blocks per axis the kernel's register layout holds: nx, ny <= 88
+// Second level: the four 4 x 4 sub-blocks of a block, bounded from a table pooled over 7 x 7 cells at stride 4.
+constexpr int BNB_B4 = 4;
+constexpr int BNB_POOL4 = 2 * BNB_B4 - 1;
 // Geometry the skip map shares with the correlation kernel: a wave of csm_correlate_kernel owns
 // CSM_WAVE_ROWS plane rows and reads CSM_ROW_DW aligned dwords of each (nhip_csm.hip).
 constexpr int CSM_WAVE_ROWS = 21;
@@ -115,7 +120,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
                    void *d_workspace = nullptr, int64_t workspace_bytes = 0);
 int64_t bnb_workspace_bytes(int32_t n_pairs);
 bool bnb_fits(const GridLayout &L, const nhip_search_t *search);
-int bnb_stats_read(unsigned long long out[2]);
+int bnb_stats_read(unsigned long long out[16]);
 int bnb_stats_per_pair(unsigned long long *out, int32_t n);
 void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, const int32_t *d_offsets, int32_t n_pairs,
                          int32_t nx, int32_t ny, const GridLayout &L, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s);

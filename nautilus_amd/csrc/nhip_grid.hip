@@ -262,18 +262,19 @@ __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__rest
   }
 }
 
-// ---- max-pooled table (bounds of the branch-and-bound matcher, nhip_bnb.hip) ---------------------------
-// pool[i][j] = max of the stored cells [8i, 8i + 15) x [8j, 8j + 15) (clipped to the image), one byte: the
-// largest value an 8 x 8 block of translations can read for a point whose window origin has (row >> 3, col >> 3)
-// = (i - Y, j - X).  16-bit cells are scaled to a byte by ceil(max / 257), so 257 * pool >= max.
-// One block per (band of 8 pooled rows, segment of 1024 stored dwords, target): every thread walks the band's
-// 71 stored rows down its dword columns keeping eight running maxima (a stored row feeds at most two pooled
-// rows), the column maxima go to LDS and a 15-cell horizontal max finishes the entries.  Columns whose 64 x 64
-// blur tiles are all unoccupied hold only zeros and are not read (~80 % of a scan's image).
-constexpr int POOL_BAND = 8;                                   // pooled rows per block
-constexpr int POOL_ROWS_IN = POOL_BAND * BNB_B + BNB_POOL - BNB_B;  // 71 stored rows
-constexpr int POOL_SEG_DW = 512;                               // stored dwords per column segment
-constexpr int POOL_HALO_DW = 4;                                // >= 7 cells * 2 bytes / 4
+// ---- max-pooled tables (bounds of the branch-and-bound matcher, nhip_bnb.hip) --------------------------
+// Level 1 (ST = 8): pool[i][j] = max of the stored cells [8i, 8i + 15) x [8j, 8j + 15) (clipped to the image), one
+// byte: the largest value an 8 x 8 block of translations can read for a point whose window origin has
+// (row >> 3, col >> 3) = (i - Y, j - X).  Level 2 (ST = 4): [4i, 4i + 7) x [4j, 4j + 7), the same for a 4 x 4
+// sub-block, stored as byte pairs {P4[i][j], P4[i + 1][j]} (the two sub-block rows of a block in one read).
+// 16-bit cells are scaled to a byte by ceil(max / 257), so 257 * pool >= max.
+// One block per (band of 8 pooled rows, segment of 512 stored dwords, target): every thread walks the band's
+// 8 ST + ST - 1 stored rows down its dword columns keeping eight running maxima (a stored row feeds at most two
+// pooled rows), the column maxima go to LDS and a (2 ST - 1)-cell horizontal max finishes the entries.  Columns whose
+// 64 x 64 blur tiles are all unoccupied hold only zeros and are not read (~80 % of a scan's image).
+constexpr int POOL_BAND = 8;       // pooled rows per block
+constexpr int POOL_SEG_DW = 512;   // stored dwords per column segment
+constexpr int POOL_HALO_DW = 4;    // >= 7 cells * 2 bytes / 4
 
 typedef unsigned short us2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
@@ -281,23 +282,25 @@ __device__ __forceinline__ uint32_t pk_max_u16(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, r);
 }
 
-template <int CB>
+template <int CB, int ST>
 __global__ __launch_bounds__(256) void grid_pool_kernel(const uint8_t *__restrict__ occ, uint8_t *__restrict__ grids,
                                                         int32_t S, int32_t tiles, int32_t pad, int32_t rows,
-                                                        int32_t pitch, int64_t grid_bytes, int64_t skip_bytes,
-                                                        int64_t slot_bytes, int32_t pool_pitch, int32_t t_base) {
+                                                        int32_t pitch, int64_t table_offset, int64_t slot_bytes,
+                                                        int32_t pool_pitch, int32_t t_base) {
+  constexpr int WIN = 2 * ST - 1;                    // cells a pooled entry spans per axis
+  constexpr int ROWS_IN = POOL_BAND * ST + ST - 1;   // stored rows a band of pooled rows reads
   // column maxima per pooled row: 8-bit cells as two half-word planes (even bytes, odd bytes), 16-bit cells as is
   __shared__ uint32_t sM[POOL_BAND][CB == 1 ? 2 : 1][POOL_SEG_DW + POOL_HALO_DW];
   constexpr int CPD = 4 / CB;  // cells per dword
   const int32_t t = t_base + blockIdx.z, band = blockIdx.x, seg = blockIdx.y, tid = threadIdx.x;
   const uint8_t *g = grids + (size_t)t * slot_bytes;
-  uint8_t *pool = grids + (size_t)t * slot_bytes + grid_bytes + skip_bytes;
+  uint8_t *pool = grids + (size_t)t * slot_bytes + table_offset;
   const int32_t ndw = pitch / 4;
   const int32_t dw0 = seg * POOL_SEG_DW, dw1 = min(dw0 + POOL_SEG_DW + POOL_HALO_DW, ndw);
-  const int32_t r0 = band * POOL_BAND * BNB_B;
+  const int32_t r0 = band * POOL_BAND * ST;
   // blur tiles the band's rows can touch
-  const int32_t ty0 = max(r0 - pad, 0) / TILE, ty1 = min(r0 + POOL_ROWS_IN - 1 - pad, S - 1) / TILE;
-  const bool rows_in = r0 + POOL_ROWS_IN - 1 - pad >= 0 && r0 - pad < S;
+  const int32_t ty0 = max(r0 - pad, 0) / TILE, ty1 = min(r0 + ROWS_IN - 1 - pad, S - 1) / TILE;
+  const bool rows_in = r0 + ROWS_IN - 1 - pad >= 0 && r0 - pad < S;
   int any = 0;
   for (int32_t c = dw0 + tid; c < dw1; c += 256) {
     uint32_t me[POOL_BAND], mo[POOL_BAND];
@@ -312,14 +315,14 @@ __global__ __launch_bounds__(256) void grid_pool_kernel(const uint8_t *__restric
     }
     if (live) {
 #pragma unroll
-      for (int rr = 0; rr < POOL_ROWS_IN; rr++) {
+      for (int rr = 0; rr < ROWS_IN; rr++) {
         // (rows past the image re-read its last row: zero border)
         const uint32_t w = reinterpret_cast<const uint32_t *>(g + (size_t)min(r0 + rr, rows - 1) * pitch)[c];
         const uint32_t we = CB == 1 ? (w & 0x00ff00ffu) : w, wo = CB == 1 ? ((w >> 8) & 0x00ff00ffu) : 0u;
-        // pooled rows i with 8 i <= rr < 8 i + 15
+        // pooled rows i with ST i <= rr < ST i + WIN
 #pragma unroll
         for (int i = 0; i < POOL_BAND; i++) {
-          if (BNB_B * i <= rr && rr < BNB_B * i + BNB_POOL) {
+          if (ST * i <= rr && rr < ST * i + WIN) {
             me[i] = pk_max_u16(me[i], we);
             if (CB == 1) mo[i] = pk_max_u16(mo[i], wo);
           }
@@ -335,22 +338,45 @@ __global__ __launch_bounds__(256) void grid_pool_kernel(const uint8_t *__restric
   }
   if (!__syncthreads_or(any)) return;  // the memset's zeros stand
   const int32_t cells = rows;          // stored columns = stored rows (square image)
-  const int32_t nj = (cells + BNB_B - 1) / BNB_B;
-  constexpr int JSEG = POOL_SEG_DW * CPD / BNB_B;  // pooled entries per segment
+  const int32_t nj = (cells + ST - 1) / ST;
+  constexpr int JSEG = POOL_SEG_DW * CPD / ST;  // pooled entries per segment
   const int32_t j0 = seg * JSEG;
   for (int32_t e = tid; e < POOL_BAND * JSEG; e += 256) {
     const int32_t i = e / JSEG, j = j0 + e % JSEG;
-    if (j >= nj || band * POOL_BAND + i >= (rows + BNB_B - 1) / BNB_B) continue;
+    if (j >= nj || band * POOL_BAND + i >= (rows + ST - 1) / ST) continue;
     uint32_t m = 0;
-    const int32_t c1 = min(j * BNB_B + BNB_POOL, cells);
-    for (int32_t c = j * BNB_B; c < c1; c++) {
+    const int32_t c1 = min(j * ST + WIN, cells);
+    for (int32_t c = j * ST; c < c1; c++) {
       const int32_t d = c / CPD - dw0;
       uint32_t v;
       if (CB == 1) v = (sM[i][c & 1][d] >> (8 * (c & 2))) & 0xffu;  // byte c&3 of the dword: plane c&1, half-word (c>>1)&1
       else v = (sM[i][0][d] >> (16 * (c & 1))) & 0xffffu;
       m = max(m, v);
     }
-    if (m) pool[(size_t)(band * POOL_BAND + i) * pool_pitch + j] = (uint8_t)(CB == 1 ? m : (m + 256u) / 257u);
+    if (m) {
+      const uint8_t v = (uint8_t)(CB == 1 ? m : (m + 256u) / 257u);
+      const int32_t pi = band * POOL_BAND + i;
+      if (ST == BNB_B) {
+        pool[(size_t)pi * pool_pitch + j] = v;
+      } else {  // pairs: (i, 2j) = P4[i][j], (i, 2j + 1) = P4[i + 1][j]
+        pool[(size_t)pi * pool_pitch + 2 * j] = v;
+        if (pi > 0) pool[(size_t)(pi - 1) * pool_pitch + 2 * j + 1] = v;
+      }
+    }
+  }
+}
+
+template <int CB, int ST>
+void launch_pool(const uint8_t *occ, uint8_t *g, const GridLayout &L, int32_t tiles, int32_t n, hipStream_t s) {
+  const int32_t rows = L.S + 2 * L.pad, mpitch = L.pitch / 4;
+  const int32_t pooled_rows = (rows + ST - 1) / ST;
+  const int64_t off = L.grid_bytes + L.skip_bytes + (ST == BNB_B ? 0 : L.pool_bytes);
+  const int32_t pp = ST == BNB_B ? L.pool_pitch : L.pool4_pitch;
+  for (int32_t z0 = 0; z0 < n; z0 += 65535) {  // gridDim.z is limited to 65,535
+    const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
+    const dim3 pg((pooled_rows + POOL_BAND - 1) / POOL_BAND, (mpitch + POOL_SEG_DW - 1) / POOL_SEG_DW, nz);
+    hipLaunchKernelGGL((grid_pool_kernel<CB, ST>), pg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, rows, L.pitch, off,
+                       L.slot_bytes, pp, z0);
   }
 }
 
@@ -422,16 +448,12 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
         hipLaunchKernelGGL(grid_skipmap_kernel<2>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
                            L.grid_bytes, L.slot_bytes, z0);
     }
-    for (int32_t z0 = 0; z0 < n; z0 += 65535) {
-      const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
-      const int32_t pooled_rows = (rows + BNB_B - 1) / BNB_B;
-      const dim3 pg((pooled_rows + POOL_BAND - 1) / POOL_BAND, (mpitch + POOL_SEG_DW - 1) / POOL_SEG_DW, nz);
-      if (L.cb == 1)
-        hipLaunchKernelGGL(grid_pool_kernel<1>, pg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, rows, L.pitch,
-                           L.grid_bytes, L.skip_bytes, L.slot_bytes, L.pool_pitch, z0);
-      else
-        hipLaunchKernelGGL(grid_pool_kernel<2>, pg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, rows, L.pitch,
-                           L.grid_bytes, L.skip_bytes, L.slot_bytes, L.pool_pitch, z0);
+    if (L.cb == 1) {
+      launch_pool<1, BNB_B>(occ, g, L, tiles, n, s);
+      launch_pool<1, BNB_B4>(occ, g, L, tiles, n, s);
+    } else {
+      launch_pool<2, BNB_B>(occ, g, L, tiles, n, s);
+      launch_pool<2, BNB_B4>(occ, g, L, tiles, n, s);
     }
     timer_end(NHIP_TIMER_GRID, s);
   }

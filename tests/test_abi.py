@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Match) == 16
     assert C.sizeof(_lib.GridSpec) == 40
     assert C.sizeof(_lib.Search) == 24
-    assert C.sizeof(_lib.GridLayout) == 88  # + pool_bytes, pool_pitch, pool_rows (branch-and-bound table)
+    assert C.sizeof(_lib.GridLayout) == 104  # + pool_* and pool4_* (branch-and-bound tables, levels 1 and 2)
 
 
 def test_grid_layout_follows_cimg_debug():
@@ -47,7 +47,9 @@ def test_grid_layout_follows_cimg_debug():
     assert L.skip_bytes == 48 * 1392  # 1 bit per row and dword column
     # pooled table: one byte per 8 x 8 cells + zero rows / columns for the reach of an 11 x 11-block lattice
     assert L.pool_rows == 174 + 12 and L.pool_pitch == 192 and L.pool_bytes == 186 * 192
-    assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes and L.slot_bytes % 16 == 0
+    # second level: a byte pair per 4 x 4 cells + the reach of 22 sub-blocks + a 16-byte read from an aligned offset
+    assert L.pool4_rows == 348 + 24 and L.pool4_pitch == 768 and L.pool4_bytes == 372 * 768
+    assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes and L.slot_bytes % 16 == 0
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
     L16 = csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=16))
     assert L16.cell_bytes == 2 and L16.pitch == 2 * 1392 and L16.rows == 1392 and L16.grid_bytes == 2 * 1392 * 1392

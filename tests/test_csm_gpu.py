@@ -25,6 +25,20 @@ def _check_pairs(scans_list, target_ids, pair_src, pair_slot, theta0, spec, ospe
     st = csm.ScanTable(xy, off)
     grids = csm.LikelihoodGrids(st, target_ids, spec)
     got, sums = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, search, origin)
+    # every form of the matcher returns the same records: batches of <= 64 pairs take the two-kernel form by default
+    # (general kernel + grid-wide candidate lists); NHIP_BNB_KERNELS=1 forces the single kernel, which works rotation
+    # by rotation with register-held origins for scans of <= 1152 points and through the workgroup queue otherwise
+    # (NHIP_BNB_QUEUE=1: always); NHIP_BNB_LEVELS=1 leaves out the sub-block bounds
+    import os
+    for env in ({"NHIP_BNB_KERNELS": "1"}, {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_LEVELS": "1"},
+                {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_QUEUE": "1"}, {"NHIP_BNB_KERNELS": "2", "NHIP_BNB_LEVELS": "1"}):
+        os.environ.update(env)
+        try:
+            got_v, sums_v = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, search, origin)
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+        assert got_v.tobytes() == got.tobytes() and np.array_equal(sums_v, sums), env
     if spec.cell_bits != 16:
         # the kernel that performs every add and the branch-and-bound matcher return the same records
         ex = csm.search_spec(search.n_theta, search.nx, search.ny, search.theta_step, exhaustive=True)
@@ -465,15 +479,17 @@ def test_zero_strip_skipping_changes_nothing(gpu, small_bag, monkeypatch):
 
 
 # ---------------------------------------------------------------------------- branch and bound, 16-bit cells
-def _pool_numpy(stored, cell_bits):
-    """pool[i][j] = max of stored[8i : 8i + 15, 8j : 8j + 15] (clipped); 16-bit cells scaled by ceil(max / 257)."""
+def _pool_numpy(stored, cell_bits, stride=8):
+    """pool[i][j] = max of stored[8i : 8i + 15, 8j : 8j + 15] (clipped; stride 4: [4i : 4i + 7, 4j : 4j + 7]);
+    16-bit cells scaled by ceil(max / 257)."""
     rows = stored.shape[0]
-    n = (rows + 7) // 8
+    n = (rows + stride - 1) // stride
+    win = 2 * stride - 1
     out = np.zeros((n, n), dtype=np.int64)
     for i in range(n):
-        band = stored[8 * i:8 * i + 15, :rows].max(axis=0).astype(np.int64)
+        band = stored[stride * i:stride * i + win, :rows].max(axis=0).astype(np.int64)
         for j in range(n):
-            out[i, j] = band[8 * j:8 * j + 15].max()
+            out[i, j] = band[stride * j:stride * j + win].max()
     return out if cell_bits == 8 else (out + 256) // 257
 
 
@@ -494,6 +510,19 @@ def test_pooled_table_matches_its_definition(gpu, small_bag, cell_bits):
         assert not rest.any(), "rows / columns beyond the image must stay zero"
         if cell_bits == 16:
             assert np.all(257 * pool[:n, :n].astype(np.int64) >= _pool_numpy(stored, 8))  # 257 * ceil(m / 257) >= m
+        # second level: 7 x 7 cells at stride 4
+        # second level: 7 x 7 cells at stride 4, stored as byte pairs {P4[i][j], P4[i + 1][j]}
+        pairs = grids.pooled(slot, level=2)
+        want4 = _pool_numpy(stored, cell_bits, stride=4)
+        n4 = want4.shape[0]
+        assert pairs.shape == (L.pool4_rows, L.pool4_pitch)
+        assert np.array_equal(pairs[:n4, 0:2 * n4:2], want4)
+        assert np.array_equal(pairs[:n4 - 1, 1:2 * n4:2], want4[1:]) and not pairs[n4 - 1, 1::2].any()
+        rest = pairs.copy()
+        rest[:n4, :2 * n4] = 0
+        assert not rest.any()
+        # a level-1 entry covers its four level-2 entries
+        assert np.all(pool[:n, :n][:n4 // 2, :n4 // 2] >= want4[:2 * (n4 // 2):2, :2 * (n4 // 2):2])
     grids.close()
     st.close()
 
@@ -526,9 +555,17 @@ def test_full_lattice_16bit_and_8bit_agree_with_oracle_and_each_other(gpu):
         for bits in (8, 16):
             spec, ospec = _specs(cell_bits=bits)
             _check_pairs(bag.scans, ids, src, slot, th0, spec, ospec, search)
-            ev, tot = csm.bnb_stats()
+            csm.bnb_stats()  # (reset: _check_pairs ran the matcher in several forms)
+            st = csm.ScanTable.from_list(bag.scans)
+            grids = csm.LikelihoodGrids(st, ids, spec)
+            csm.match_pairs(st, grids, src, slot, th0, search)
+            grids.close(), st.close()
+            lv = csm.bnb_stats_levels()
+            tot, ev = lv["blocks_total"], lv["blocks_whole"] + lv["sub_blocks"] / 4
             assert tot == len(src) * 61 * 11 * 11
             assert 0 < ev < 0.1 * tot, "branch and bound evaluated %d of %d blocks" % (ev, tot)
+            # the second level: most candidate blocks are settled by their four sub-block bounds
+            assert lv["candidates_refined"] > 0 and lv["sub_blocks"] < 2 * lv["candidates_refined"]
     finally:
         os.environ.pop("NHIP_BNB_STATS", None)
 

@@ -14,8 +14,9 @@ plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
 out = {}
 for bits in (8, 16):
     m = bench.HipMatcher(wl, plan.shard(0), torch.device("cuda", 0), bits)
-    for dbg in ("0", "3", "1", "2"):
-        os.environ["NHIP_BNB_DEBUG"] = dbg
+    for dbg in ("0", "L1", "3", "4", "5", "1", "2"):
+        os.environ["NHIP_BNB_LEVELS"] = "1" if dbg == "L1" else "2"   # L1: full run without the sub-block bounds
+        os.environ["NHIP_BNB_DEBUG"] = "0" if dbg == "L1" else dbg
         m.step(); torch.cuda.synchronize(); csm.bnb_stats()
         lib.nhip_timing_reset(); lib.nhip_timing_enable(1)
         for _ in range(3):
@@ -25,7 +26,8 @@ for bits in (8, 16):
         g_ms, g_n = bench._timer(lib, _lib, _lib.NHIP_TIMER_GRID)
         per = np.zeros(m.n_pairs, dtype=np.uint64)
         _lib.check(lib.nhip_bnb_stats_per_pair(_lib.ptr(per), m.n_pairs))
-        ev, tot = csm.bnb_stats()
+        lv = csm.bnb_stats_levels()
+        ev, tot = lv["blocks_whole"] + lv["sub_blocks"] / 4, lv["blocks_total"]
         if dbg == "0":
             d = np.linalg.norm(wl.bag.truth[wl.src, :2] - wl.bag.truth[wl.tgt, :2], axis=1)
             q = np.percentile(per, [50, 90, 99, 99.9, 100])
@@ -33,7 +35,11 @@ for bits in (8, 16):
             out["u%d_blocks_by_distance" % bits] = {("%.0f-%.0fm" % (a, a + 1)): float(per[(d >= a) & (d < a + 1)].mean()) for a in range(4)}
             out["u%d_share_of_blocks_in_top_1pct_pairs" % bits] = float(np.sort(per)[-len(per) // 100:].sum() / max(per.sum(), 1))
         out["u%d_debug%s" % (bits, dbg)] = {"kernel_ms": ms / n, "grid_ms": g_ms / max(g_n, 1), "blocks_eval_per_pair": ev / 3 / m.n_pairs,
-                                           "frac": ev / max(tot, 1)}
+                                           "frac": ev / max(tot, 1), "whole_per_pair": lv["blocks_whole"] / 3 / m.n_pairs,
+                                           "refined_per_pair": lv["candidates_refined"] / 3 / m.n_pairs,
+                                           "sub_blocks_per_pair": lv["sub_blocks"] / 3 / m.n_pairs,
+                                           "clk_per_pair": {k_: v_ / 3 / m.n_pairs for k_, v_ in lv.items() if k_.startswith("clk_")}}
     m.free_grids()
 os.environ.pop("NHIP_BNB_DEBUG")
+os.environ.pop("NHIP_BNB_LEVELS")
 print(json.dumps(out, indent=1))
