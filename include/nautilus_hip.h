@@ -182,6 +182,10 @@ int nhip_bnb_stats_levels(uint64_t out[16]);
 /* ... and per pair of the last launch (4 x 4 sub-blocks evaluated exactly, a whole block counting four), before
  * nhip_bnb_stats resets the totals */
 int nhip_bnb_stats_per_pair(uint64_t *evaluated, int32_t n_pairs);
+/* With NHIP_BNB_TIMELINE=1: per pair of the last launch four 100 MHz timestamps of its workgroup -- start, bounds
+ * done, seeds done, end (the top 16 bits of the last one hold the hardware id of the CU it ran on); after the
+ * n_pairs records two more values: first start and last end of the second kernel.  ticks: 4*n_pairs + 2 values */
+int nhip_bnb_timeline(uint64_t *ticks, int32_t n_pairs);
 
 /* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy] (8-bit cells). */
 int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,

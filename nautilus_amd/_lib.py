@@ -76,6 +76,7 @@ PROTOTYPES = {
     "nhip_csm_workspace_bytes": (_i64, [_i32]),
     "nhip_bnb_stats": (C.c_int, [_P(C.c_uint64), _P(C.c_uint64)]),
     "nhip_bnb_stats_per_pair": (C.c_int, [_vp, _i32]),
+    "nhip_bnb_timeline": (C.c_int, [_vp, _i32]),
     "nhip_bnb_stats_levels": (C.c_int, [_P(C.c_uint64)]),
     "nhip_csm_scores_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _i32, _i32, _vp, _vp, _i32, _i32,
                                       _P(Search), _vp, _vp]),

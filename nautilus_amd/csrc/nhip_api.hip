@@ -1104,6 +1104,11 @@ int nhip_bnb_stats_per_pair(uint64_t *evaluated, int32_t n_pairs) {
   return bnb_stats_per_pair(reinterpret_cast<unsigned long long *>(evaluated), n_pairs);
 }
 
+int nhip_bnb_timeline(uint64_t *ticks, int32_t n_pairs) {
+  NHIP_REQUIRE(ticks && n_pairs >= 0, "bnb_timeline: bad arguments");
+  return bnb_timeline_read(reinterpret_cast<unsigned long long *>(ticks), n_pairs);
+}
+
 int nhip_bnb_stats(uint64_t *evaluated, uint64_t *total) {
   unsigned long long v[16];
   int rc = bnb_stats_read(v);

@@ -37,10 +37,20 @@ constexpr int SEG_CHUNKS = 32;        // 64-point chunks between reductions: 32 
 #define NHIP_BNB_EVAL_CHUNKS 2
 #endif
 constexpr int EVAL_CHUNKS = NHIP_BNB_EVAL_CHUNKS;  // 64-point chunks whose row loads a block evaluation keeps in flight
+constexpr int MAX_ROT = 340;          // rotations per search: QCAP * 4 bytes hold their 12 bytes of ordering data
 constexpr int QCAP = 1024;            // candidate queue entries per workgroup (overflow is evaluated by the wave that found it)
 constexpr uint32_t M8 = 0x00ff00ffu;
 constexpr int BNB_STATS_PAIRS = 1 << 20;
 constexpr int BNB_STATS_HEAD = 16;       // totals: 4 counts, then shader-clock sums of the by-rotation kernel (see nhip_bnb_stats_levels)  // per-pair counters kept by NHIP_BNB_STATS=1
+
+// One rotation of a pair with many candidates, handed to other waves: (pair, rotation) and the mask of its 121
+// candidate blocks, in four 64-bit words that each carry their own "written" bit -- so the hand-over needs nothing
+// but relaxed device-scope atomics on single words (an acquire / release at device scope invalidates / writes
+// back the XCD's whole L2 on this chip), and the taker simply waits until all four have arrived.
+struct RotEntry {
+  unsigned long long w[4];  // each: bit 63 = written; w[0]: pair << 24 | rotation; w[1..3]: candidate blocks 0..40, 41..81, 82..120
+};
+constexpr unsigned long long ROT_WRITTEN = 1ull << 63;
 
 struct BnbParams {
   const float2 *xy;
@@ -52,17 +62,21 @@ struct BnbParams {
   const double *delta_cs;
   const int32_t *pair_origin;
   unsigned long long *keys;
+  unsigned long long *timeline;  // optional (NHIP_BNB_TIMELINE=1): per pair 4 x 100 MHz ticks: start, bounds, seeds, end
   unsigned long long *stats;  // optional: [0] blocks evaluated whole, [1] blocks in all, [2] candidates refined,
                               //   [3] 4 x 4 sub-blocks evaluated; then one count of candidates per pair
-  uint4 *cand_list;           // optional global candidate lists (caller's workspace), one per XCD so that a pair's
-  uint32_t *cand_count;       //   candidates are evaluated where its grid is L2-resident: {U, pair, k << 8 | slot, 0};
-  uint32_t cand_cap;          //   8 fill counters (32 bytes apart); entries per list
+  RotEntry *rot_list;          // optional lists of (pair, rotation) work items in the caller's workspace, one per XCD so
+  uint32_t *rot_count;        //   that a pair's rotations are worked where its grid is L2-resident; per XCD 32 bytes of
+  uint32_t rot_cap;           //   counters {filled, next}; entries per list
+  uint32_t heavy_min;         // candidates from which a ROTATION is handed over ...
+  uint32_t keep_ranks;        // ... unless it is among the pair's first keep_ranks rotations in best-first order
+  uint32_t donate;            // 1: the lists are drained inside the first kernel, by every wave that has finished its own pair
   int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
   int32_t S, pad, pitch, rows, max_shift;
   int32_t pool_pitch, pool_rows, pairs_per_xcd;
   int32_t pool4_pitch;
   int32_t whole_min;    // sub-blocks alive from which an 8-bit block is evaluated whole (3; NHIP_BNB_WHOLE_MIN)
-  int32_t general_all;  // the general instantiation takes every pair (two-kernel form, NHIP_BNB_QUEUE=1)
+  int32_t general_all;  // the general instantiation takes every pair (NHIP_BNB_QUEUE=1)
   int32_t levels;  // 2: candidates are refined through the 4 x 4 sub-block bounds; 1: evaluated whole (NHIP_BNB_LEVELS)
   int32_t debug;   // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only,
                    // 4 = phase 3 without exact sums, 5 = phase 3 without sub-block bounds and exact sums
@@ -133,53 +147,60 @@ __device__ __forceinline__ void rs_step(uint32_t (&R)[CAP], bool bit, int mask) 
 
 // ---- bounds of one rotation ------------------------------------------------------------------------------
 // Returns this lane's two totals of the 128-slot layout: slot v = lane + 64 * i (i = 0, 1) holds packed register
-// r = 32 i + 16 b5 + 8 b4 + 4 b2 + 2 b1 + b0, field b3 (b = bits of the lane) -- see slot_block().
+// r = 32 i + 16 b5 + 8 b4 + 4 b3 + 2 b1 + b0, field b2 (b = bits of the lane) -- see slot_block().
 // POOL_LDS: the pooled table is staged in LDS (`pool`); otherwise it is read from the grid slot in global memory
 // through the buffer descriptor `prs` (tables of large grids, e.g. the 6000 x 6000 grid of the two-level drop-in).
+//
+// Consecutive beams hit the same wall: on a 1081-beam scan 5 to 10 consecutive points share a pooled entry
+// (8 x 8 cells = 40 cm), and every one of them would gather the same 11 x 11 bytes.  So the points are first
+// run-length compressed: a lane whose pooled offset differs from its predecessor's (or that starts a group of 8
+// lanes) is the head of a run and writes (offset, run length <= 8) to the wave's list in LDS; the gather then
+// works on list entries, 64 at a time, and adds every byte `length` times (one multiply-add in place of the add).
+// Field widths: a lane gathers at most 4 entries = 32 points between reductions, as 32 points did before.
+constexpr int RUN_MAX = 8;        // longest run: 4 entries * 8 points * 255 * 8 lanes < 65536 (16-bit fields)
+constexpr int SEG_PASSES = 4;     // gather passes between reductions
+constexpr int LIST_ENTRIES = 128; // ring of pending entries per wave (a chunk appends <= 64, 64 are consumed at a time)
+
 template <bool POOL_LDS>
 __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_t *pool, __amdgpu_buffer_rsrc_t prs,
                                                 const float2 *pts, int32_t n_pts, float cf, float sf, int32_t cx,
-                                                int32_t cy, int lane, uint32_t (&tot)[2]) {
+                                                int32_t cy, int lane, uint32_t *list, uint32_t (&tot)[2]) {
   const int32_t DP = P.pool_pitch;
-  const int32_t zero_a = ((P.rows + BNB_B - 1) / BNB_B) * DP;  // NB + 1 rows of zeros below the pooled image
+  const uint32_t zero_a = (uint32_t)(((P.rows + BNB_B - 1) / BNB_B) * DP);  // NB + 1 rows of zeros below the pooled image
   tot[0] = tot[1] = 0u;
-  for (int32_t c0 = 0; c0 < n_pts; c0 += 64 * SEG_CHUNKS) {
-    uint32_t E[NB][3], O[NB][3];  // per block row Y: 12 byte sums = dwords 0..2, even (b0 | b2) and odd (raw, see below)
+  uint32_t E[NB][3], O[NB][3];  // per block row Y: 12 byte sums = dwords 0..2, even (b0 | b2) and odd (raw, see below)
 #pragma unroll
-    for (int y = 0; y < NB; y++)
+  for (int y = 0; y < NB; y++)
 #pragma unroll
-      for (int d = 0; d < 3; d++) E[y][d] = O[y][d] = 0u;
-    const int32_t c1 = min(n_pts, c0 + 64 * SEG_CHUNKS);
-    float2 qn = c0 + lane < c1 ? pts[c0 + lane] : make_float2(0.f, 0.f);
-    for (int32_t c = c0; c < c1; c += 64) {
-      const float2 pt = qn;
-      if (c + 64 + lane < c1) qn = pts[c + 64 + lane];  // next chunk's point
-      int32_t a = zero_a;
-      if (c + lane < n_pts) {
-        int32_t prow, pcol;
-        window_origin(pt, cf, sf, P, cx, cy, &prow, &pcol);
-        a = (prow >> 3) * DP + (pcol >> 3);
+    for (int d = 0; d < 3; d++) E[y][d] = O[y][d] = 0u;
+  uint32_t head = 0u, tail = 0u;  // ring positions (wave-uniform)
+  int passes = 0;
+
+  // 64 list entries: every lane gathers the 11 x 12 bytes of its entry, weighted by the run length
+  auto gather = [&](uint32_t entry) {
+    const uint32_t a = entry & 0x07ffffffu, cnt = entry >> 27;
+    const uint32_t sh = (a & 3u) * 8u;
+    const uint32_t *q = reinterpret_cast<const uint32_t *>(pool + (a & ~3u));
+#pragma unroll
+    for (int y = 0; y < NB; y++) {
+      uint32_t w0, w1, w2, w3;
+      if (POOL_LDS) {
+        const uint32_t *row = q + (y * DP) / 4;  // DP is a multiple of 16
+        w0 = row[0]; w1 = row[1]; w2 = row[2]; w3 = row[3];
+      } else {
+        const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((a & ~3u) + (uint32_t)(y * DP)), 0, 0);
+        w0 = r4.x; w1 = r4.y; w2 = r4.z; w3 = r4.w;
       }
-      const uint32_t sh = (uint32_t)(a & 3) * 8u;
-      const uint32_t *q = reinterpret_cast<const uint32_t *>(pool + (a & ~3));
-#pragma unroll
-      for (int y = 0; y < NB; y++) {
-        uint32_t w0, w1, w2, w3;
-        if (POOL_LDS) {
-          const uint32_t *row = q + (y * DP) / 4;  // DP is a multiple of 16
-          w0 = row[0]; w1 = row[1]; w2 = row[2]; w3 = row[3];
-        } else {
-          const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(prs, (a & ~3) + y * DP, 0, 0);
-          w0 = r4.x; w1 = r4.y; w2 = r4.z; w3 = r4.w;
-        }
-        const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
-        const uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, sh);
-        // even: b0 | b2 << 16; odd (raw): w >> 8 = b1 + 256 b2 + 65536 b3, repaired after the loop
-        E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
-        E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
-        E[y][2] += n2 & M8; O[y][2] += n2 >> 8;
-      }
+      const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+      const uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+      // even: b0 | b2 << 16; odd (raw): w >> 8 = b1 + 256 b2 + 65536 b3, repaired at the reduction
+      E[y][0] += __umul24(n0 & M8, cnt); O[y][0] += __umul24(n0 >> 8, cnt);
+      E[y][1] += __umul24(n1 & M8, cnt); O[y][1] += __umul24(n1 >> 8, cnt);
+      E[y][2] += __umul24(n2 & M8, cnt); O[y][2] += __umul24(n2 >> 8, cnt);
     }
+  };
+  // the transposing reduction of the 128 packed sums (see the layout above); clears the accumulators
+  auto reduce = [&]() {
     // 64 packed registers: R[6 y + d] (y < 10): d < 3 = E[y][d] (X = 4 d, 4 d + 2), d >= 3 = O[y][d - 3] (X = 4 (d - 3) + 1, + 3);
     // the hi field of O[y][2] is X = 11 (unused): rows 0..2 carry X = 5, 7, 9 of block row 10 there.
     // R[60..62] = E[10][0..2], R[63] = O[10][0].
@@ -204,26 +225,76 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
     R[63] = O[10][0];
     rs_step<64>(R, lane & 1, 1);
     rs_step<32>(R, lane & 2, 2);
-    rs_step<16>(R, lane & 4, 4);
-    uint32_t V[16];
+    uint32_t V[32];
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 16; i++) {
       V[2 * i] = R[i] & 0xffffu;
       V[2 * i + 1] = R[i] >> 16;
     }
+    rs_step<32>(V, lane & 4, 4);
     rs_step<16>(V, lane & 8, 8);
     rs_step<8>(V, lane & 16, 16);
     rs_step<4>(V, lane & 32, 32);
     tot[0] += V[0];
     tot[1] += V[1];
+#pragma unroll
+    for (int y = 0; y < NB; y++)
+#pragma unroll
+      for (int d = 0; d < 3; d++) E[y][d] = O[y][d] = 0u;
+  };
+
+  float2 qn = lane < n_pts ? pts[lane] : make_float2(0.f, 0.f);
+  for (int32_t c = 0;; c += 64) {
+    const bool more = c < n_pts;  // (one more turn after the last chunk drains the list)
+    if (more) {
+      const float2 pt = qn;
+      if (c + 64 + lane < n_pts) qn = pts[c + 64 + lane];  // next chunk's point
+      const bool live = c + lane < n_pts;
+      uint32_t a = zero_a;
+      if (live) {
+        int32_t prow, pcol;
+        window_origin(pt, cf, sf, P, cx, cy, &prow, &pcol);
+        a = (uint32_t)((prow >> 3) * DP + (pcol >> 3));
+      }
+      // runs of equal offsets inside groups of RUN_MAX lanes
+      const uint32_t prev = (uint32_t)__shfl_up((int)a, 1, 64);
+      const bool is_head = (lane & (RUN_MAX - 1)) == 0 || a != prev;
+      const unsigned long long H = __ballot(is_head);
+      const uint32_t Hh = (lane & 32) ? (uint32_t)(H >> 32) : (uint32_t)H;  // the half of H that holds the lane's group
+      const uint32_t g = (Hh >> (lane & 31 & ~(RUN_MAX - 1))) & ((1u << RUN_MAX) - 1u);
+      const uint32_t rest = g >> ((lane & (RUN_MAX - 1)) + 1);
+      const uint32_t cnt = rest ? (uint32_t)__builtin_ctz(rest) + 1u : (uint32_t)(RUN_MAX - (lane & (RUN_MAX - 1)));
+      const unsigned long long He = __ballot(is_head && live);  // (lanes past the scan's end emit nothing)
+      if (is_head && live) {
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(He >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)He, 0u));
+        list[(tail + before) & (LIST_ENTRIES - 1)] = a | (cnt << 27);
+      }
+      tail += (uint32_t)__builtin_popcountll(He);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // (last turn: also when nothing is pending but unreduced passes are -- an all-zero pass brings the reduction)
+    while (tail - head >= 64u || (!more && (tail != head || passes != 0))) {
+      const uint32_t avail = tail - head;
+      // (lanes past the list gather the zero rows with length 0)
+      gather((uint32_t)lane < avail ? list[(head + (uint32_t)lane) & (LIST_ENTRIES - 1)] : zero_a);
+      head += avail < 64u ? avail : 64u;
+      passes++;
+      if (passes == SEG_PASSES || (!more && tail == head)) {
+        reduce();
+        passes = 0;
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+    if (!more) break;
   }
 }
 
 // (block row Y, block column X) of slot v of the 128-slot layout; false for the unused slots.
 __device__ __forceinline__ bool slot_block(int v, int *Y, int *X) {
   const int lane = v & 63, i = v >> 6;
-  const int r = 32 * i + 16 * ((lane >> 5) & 1) + 8 * ((lane >> 4) & 1) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 1) & 1) + (lane & 1);
-  const int f = (lane >> 3) & 1;
+  const int r = 32 * i + 16 * ((lane >> 5) & 1) + 8 * ((lane >> 4) & 1) + 4 * ((lane >> 3) & 1) + 2 * ((lane >> 1) & 1) + (lane & 1);
+  const int f = (lane >> 2) & 1;
   if (r >= 60) {
     *Y = 10;
     *X = r == 63 ? 1 + 2 * f : 4 * (r - 60) + 2 * f;
@@ -852,8 +923,13 @@ __device__ __forceinline__ uint32_t best_sum(unsigned long long *best) {
   else b = *(volatile unsigned long long *)best;
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));  // one value for the whole wave
 }
+// the same with the place decided at run time (one copy of the candidate code serves the pair's own workgroup, whose
+// best lives in LDS, and the takers of handed-over rotations, who share it through keys[pair])
+__device__ __forceinline__ uint32_t best_sum_rt(unsigned long long *best, bool global) {
+  return global ? best_sum<true>(best) : best_sum<false>(best);
+}
 
-template <int CB, bool GLOBAL>
+template <int CB>
 __device__ __forceinline__ void process_candidate(const BnbParams &P, const PairCtx &C, int32_t k, int32_t v, int lane,
                                                   unsigned long long *best, uint32_t (&n)[3]) {
   const int Y = v / NB, X = v - NB * Y;  // v: block index NB * Y + X
@@ -864,7 +940,7 @@ __device__ __forceinline__ void process_candidate(const BnbParams &P, const Pair
     uint32_t sb[4];
     sub_bounds(P, p4, C.pts, C.n_pts, cf, sf, C.cx, C.cy, Y, X, lane, CB == 1 ? 1u : 257u, sb);
     n[1]++;
-    const uint32_t bsum = best_sum<GLOBAL>(best);
+    const uint32_t bsum = best_sum<false>(best);
     int alive = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) alive += (sb[q] != 0u && sb[q] >= bsum) ? 1 : 0;
@@ -874,7 +950,7 @@ __device__ __forceinline__ void process_candidate(const BnbParams &P, const Pair
 #pragma unroll 1
       for (int q = 0; q < 4; q++) {
         const uint32_t b = q == 0 ? sb[0] : (q == 1 ? sb[1] : (q == 2 ? sb[2] : sb[3]));  // (no indexed array: scratch)
-        if (b == 0u || b < best_sum<GLOBAL>(best)) continue;
+        if (b == 0u || b < best_sum<false>(best)) continue;
         const unsigned long long key = eval_sub<CB>(P, rsrc, C.pts, C.n_pts, cf, sf, C.cx, C.cy, k, Y, X, q >> 1, q & 1, lane);
         if (lane == 0) atomicMax(best, key);
         n[2]++;
@@ -889,32 +965,121 @@ __device__ __forceinline__ void process_candidate(const BnbParams &P, const Pair
 
 // ... with the rotation's origins in registers (LDS-resident best) and the block's four sub-block bounds at hand
 template <int CB>
-__device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
+__device__ __forceinline__ void process_candidate_c(const BnbParams &P, bool global, __amdgpu_buffer_rsrc_t rsrc,
                                                     const uint32_t (&org)[OC], int32_t nch, int32_t k, int32_t Y, int32_t X,
                                                     uint32_t sb0, uint32_t sb1, uint32_t sb2, uint32_t sb3, int lane,
                                                     unsigned long long *best, uint32_t (&n)[3]) {
-  const uint32_t bsum = best_sum<false>(best);
+  const uint32_t bsum = best_sum_rt(best, global);
   const int alive = (sb0 != 0u && sb0 >= bsum) + (sb1 != 0u && sb1 >= bsum) + (sb2 != 0u && sb2 >= bsum) +
                     (sb3 != 0u && sb3 >= bsum);
   if (alive == 0) return;
   if (CB == 1 && alive >= P.whole_min) {
     const unsigned long long key = eval_block_c(P, rsrc, org, nch, k, Y, X, lane);
-    if (lane == 0) atomicMax(best, key);
+    if (lane == 0) atomicMax(best, key);  // (generic address: LDS or global)
     n[0]++;
     return;
   }
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     const uint32_t b = q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3));
-    if (b == 0u || b < best_sum<false>(best)) continue;
+    if (b == 0u || b < best_sum_rt(best, global)) continue;
     const unsigned long long key = eval_sub_c<CB>(P, rsrc, org, nch, k, Y, X, q >> 1, q & 1, lane);
     if (lane == 0) atomicMax(best, key);
     n[2]++;
   }
 }
 
+// ---- one rotation of one pair: its candidate blocks (masks m0 | m1 over block index b = NB * Y + X, bounds u0 / u1
+// lane-wise) through sub-block bounds and exact sums, origins held in registers.  `done`: the workgroup's bound row
+// of this rotation, where finished blocks are zeroed (seeds), or null.
+struct PhaseClocks {
+  long long org, strip, eval;
+};
+
+template <int CB>
+__device__ __forceinline__ void rotation_pass(const BnbParams &P, bool global, const PairCtx &C, int32_t k, uint32_t u0, uint32_t u1,
+                                              unsigned long long m0, unsigned long long m1, int lane,
+                                              unsigned long long *best, uint32_t *done, uint32_t (&org)[OC],
+                                              uint32_t (&n_work)[3], PhaseClocks &clk) {
+  const int32_t nch = (C.n_pts + 63) >> 6;
+  long long t_mark = 0;
+  float cf, sf;
+  rotation_k(P, C.pair, k, &cf, &sf);
+  if (P.stats) t_mark = clock64();
+  cache_origins(P, C.pts, C.n_pts, cf, sf, C.cx, C.cy, lane, org);
+  if (P.stats) clk.org += clock64() - t_mark;
+  const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(C.grid, P.grid_bytes + P.skip_bytes);
+  const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(C.grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
+  // candidates in block order b = NB * Y + X; neighbours in X (up to three) share one pass over the table
+  while ((m0 | m1) != 0ull) {
+    const int b0 = m0 ? (int)__builtin_ctzll(m0) : 64 + (int)__builtin_ctzll(m1);
+    const int Y = b0 / NB, X0 = b0 - NB * Y;
+    int len = 1;
+    while (len < 3 && X0 + len < NB) {
+      const int b = b0 + len;
+      if (!(((b < 64 ? m0 >> b : m1 >> (b - 64)) & 1ull))) break;
+      len++;
+    }
+    uint32_t sb[12];
+    if (P.debug == 5) break;  // (timing: origins only)
+    if (P.levels >= 2) {
+      if (P.stats) t_mark = clock64();
+      strip_bounds_c(P, p4, org, nch, Y, X0, CB == 1 ? 1u : 257u, sb);
+      if (P.stats) clk.strip += clock64() - t_mark;
+      n_work[1] += (uint32_t)len;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 12; q++) sb[q] = 0xffffffffu;
+    }
+#pragma unroll 1
+    for (int t = 0; t < len; t++) {
+      const int b = b0 + t;
+      if (b < 64) m0 &= ~(1ull << b);
+      else m1 &= ~(1ull << (b - 64));
+      const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)(b < 64 ? u0 : u1), b & 63);
+      if (ub < best_sum_rt(best, global) || (P.debug == 4 && !done)) continue;  // the best has risen meanwhile
+      // (selects, not an indexed array: that would live in scratch)
+      const uint32_t s0 = t == 0 ? sb[0] : (t == 1 ? sb[4] : sb[8]), s1 = t == 0 ? sb[1] : (t == 1 ? sb[5] : sb[9]);
+      const uint32_t s2 = t == 0 ? sb[2] : (t == 1 ? sb[6] : sb[10]), s3 = t == 0 ? sb[3] : (t == 1 ? sb[7] : sb[11]);
+      if (P.stats) t_mark = clock64();
+      process_candidate_c<CB>(P, global, rsrc, org, nch, k, Y, X0 + t, s0, s1, s2, s3, lane, best, n_work);
+      if (P.stats) clk.eval += clock64() - t_mark;
+      if (done && lane == 0) done[b] = 0u;
+    }
+  }
+}
+
+// ---- hand-over entries
+__device__ __forceinline__ void read_entry(const RotEntry *ent, int32_t *pair, int32_t *k, unsigned long long *m0,
+                                           unsigned long long *m1) {
+  // (its pusher is between taking the slot and storing the words: a few hundred nanoseconds at most)
+  unsigned long long w[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    unsigned long long *p = const_cast<unsigned long long *>(&ent->w[i]);
+    while (((w[i] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ROT_WRITTEN) == 0ull)
+      __builtin_amdgcn_s_sleep(2);
+    w[i] &= ~ROT_WRITTEN;
+  }
+  *pair = (int32_t)(w[0] >> 24);
+  *k = (int32_t)(w[0] & 0xffffffull);
+  *m0 = w[1] | (w[2] << 41);          // blocks 0..63
+  *m1 = (w[2] >> 23) | (w[3] << 18);  // blocks 64..120
+}
+
+__device__ __forceinline__ void pair_context(const BnbParams &P, int32_t pair, PairCtx *C) {
+  const int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
+  const int32_t beg = P.offsets[src];
+  C->grid = P.grids + (size_t)slot * P.slot_bytes;
+  C->pts = P.xy + beg;
+  C->n_pts = P.offsets[src + 1] - beg;
+  C->cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
+  C->cy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
+  C->pair = pair;
+}
+
 // BY_ROT: the pairs whose scan fits the register-held origins (n_pts <= 64 * OC), rotation by rotation; the other
-// instantiation takes the longer scans -- or, with P.general_all (two-kernel form, NHIP_BNB_QUEUE=1), every pair.
+// instantiation takes the longer scans -- or, with P.general_all (NHIP_BNB_QUEUE=1), every pair.
 // Both are launched; a workgroup whose pair belongs to the other one returns at once.
 template <int CB, bool POOL_LDS, bool BY_ROT>
 __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
@@ -925,6 +1090,14 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   unsigned long long *s_best = s_queue + QCAP;
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_best + 1);
   uint32_t *s_qn = s_cnt + 1, *s_qhead = s_cnt + 2;
+  unsigned long long *s_slow = s_best + 4;  // (stats: the slowest wave's time in the candidate phase)
+  // phase 1 only: per wave a ring of LIST_ENTRIES run-length entries, in the queue's space
+  uint32_t *s_list = reinterpret_cast<uint32_t *>(s_queue);
+  static_assert(BNB_WAVES * LIST_ENTRIES * 4 <= QCAP * 4, "the run lists fit the first half of the queue");
+  // by-rotation kernel: per rotation its highest bound (<< 32 | k), and the rotations in descending order of it,
+  // in the second half of the queue's space (n_theta <= MAX_ROT)
+  unsigned long long *s_kmax = s_queue + QCAP / 2;
+  uint32_t *s_order = reinterpret_cast<uint32_t *>(s_kmax + MAX_ROT);
 
   // block -> pair: the pairs of one target are consecutive; keep them on one XCD (blocks b and b + 8 share one)
   const uint32_t bid = blockIdx.x;
@@ -944,10 +1117,13 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   // pose 0 with sum 0 is a lower bound of the optimum (sums are >= 0; if all are 0, pose 0 is the answer)
   const unsigned long long key0 = 0xffffffffull;
   const long long t_start = P.stats ? clock64() : 0;
+  if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair] = wall_clock64();
   if (threadIdx.x == 0) {
-    if (BY_ROT) s_queue[0] = 0ull;
+    *s_slow = 0ull;
     // (NHIP_BNB_DEBUG=3, experiments only: start from the keys a previous launch left = the ideal threshold)
     *s_best = P.debug == 3 ? (P.keys[pair] & 0xffffffff00000000ull) : key0;
+    // (helpers raise it with atomics once the pair has handed over: every access inside this kernel is an atomic)
+    if (BY_ROT && P.donate) __hip_atomic_store(&P.keys[pair], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_cnt[0] = s_cnt[3] = s_cnt[4] = 0u;
     *s_qn = 0u;
     *s_qhead = 0u;
@@ -971,8 +1147,9 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     float cf, sf;
     rotation_k(P, pair, k, &cf, &sf);
     uint32_t tot[2];
-    coarse_rotation<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, tot);
+    coarse_rotation<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, s_list + wave * LIST_ENTRIES, tot);
     if (lane < 128 - NB * NB) s_U[k * 128 + NB * NB + lane] = 0u;  // (the row's unused tail)
+    uint32_t umax = 0u;
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       // the bounds go to LDS in block order: entry b = NB * Y + X, so that neighbours in X are neighbours in b
@@ -981,8 +1158,17 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
       const uint32_t u = (Y < P.nby && X < P.nbx) ? tot[i] * scale : 0u;
       const int b = NB * Y + X;
       s_U[k * 128 + b] = u;
+      umax = u > umax ? u : umax;
       const unsigned long long cand = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | b);
       wbest = cand > wbest ? cand : wbest;
+    }
+    if (BY_ROT) {
+#pragma unroll
+      for (int m = 32; m >= 1; m >>= 1) {
+        const uint32_t o = shfl_xor_u32(umax, m);
+        umax = o > umax ? o : umax;
+      }
+      if (lane == 0) s_kmax[k] = ((unsigned long long)umax << 32) | (uint32_t)k;
     }
   }
 #pragma unroll
@@ -991,7 +1177,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     wbest = o > wbest ? o : wbest;
   }
   // (2) seed: the wave's highest-bound block, evaluated exactly
-  uint32_t n_work[3] = {0u, 0u, 0u};
+  uint32_t n_work[3] = {0u, 0u, 0u}, n_help[3] = {0u, 0u, 0u};  // (work on the own pair; on pairs helped)
   PairCtx C;
   C.grid = grid;
   C.pts = pts;
@@ -1002,102 +1188,163 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   // Scans of up to 64 * OC points: a wave owns a rotation at a time and keeps its window origins in registers.
   // Longer scans (and the two-kernel form) take the general path below.
   if (BY_ROT) {
-    const int32_t nch = (n_pts + 63) >> 6;
     uint32_t org[OC];
 #pragma unroll
     for (int c = 0; c < OC; c++) org[c] = 0u;
-    // First pass (2): the wave's own highest-bound block, alone -- the seeds give `best` a good lower bound before
-    // anything is pruned against it.  Then (3): rotations handed out one at a time; every block of the rotation whose
-    // bound reaches the best sum found so far goes through its sub-block bounds and, where those hold, exact sums.
-    bool first = true;
     // (NHIP_BNB_STATS=1: shader-clock sums -- wave time in phase 3 by part, and the workgroup's wall time)
-    long long t_org = 0, t_strip = 0, t_eval = 0, t_busy = 0, t_mark = 0;
+    PhaseClocks clk = {0, 0, 0};
+    long long t_busy = 0, t_wall = 0, t_own = 0;
     const long long t_phase1 = P.stats ? clock64() : 0;
+    if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair + 1] = wall_clock64();
+    const uint32_t xcd = bid & 7u;
+    bool offload = false;
+    // One loop, one copy of the candidate code (it is large; three inlined copies did not fit the instruction
+    // cache and halved the speed of everything).  A wave's work items, in this order:
+    //  SEED  the wave's own highest-bound block, alone: the seeds give `best` a good lower bound before anything is
+    //        pruned against it; then the workgroup orders its rotations by their highest bound;
+    //  OWN   rotations of the own pair handed out one at a time, best first: every block of the rotation whose bound
+    //        reaches the best sum found so far goes through its sub-block bounds and, where those hold, exact sums.
+    //        A flat landscape leaves thousands of candidates: past the pair's first keep_ranks rotations -- by then
+    //        the best sum has settled, so whoever works a rotation prunes as well as this workgroup would -- a
+    //        rotation with many candidates goes to the hand-over list of this XCD instead;
+    //  HELP  out of own work: rotations other pairs have handed over, until the list is empty (an entry pushed later
+    //        is taken by a later wave -- at the latest by its pusher, which comes through here after its last push
+    //        -- so the list is empty when the kernel ends).
+    enum { SEED, OWN, HELP };
+    int state = SEED;
     for (;;) {
-      int32_t k;
-      uint32_t u0, u1;
-      if (first) {
-        const int32_t v = (int32_t)(wbest & 0xffu);
-        const uint32_t ub = P.debug < 2 ? (uint32_t)(wbest >> 32) : 0u;
-        k = (int32_t)((uint32_t)wbest >> 8);
-        u0 = (v == lane) ? ub : 0u;
-        u1 = (v == lane + 64) ? ub : 0u;
-      } else {
-        if (!(P.debug == 0 || P.debug >= 3)) break;
-        k = 0;
-        if (lane == 0) k = (int32_t)atomicAdd(s_qhead, 1u);
-        k = __builtin_amdgcn_readfirstlane(k);
-        if (k >= P.n_theta) break;
+      bool have = false, global = false;
+      PairCtx Ci = C;
+      int32_t k = 0;
+      uint32_t u0 = 0u, u1 = 0u;
+      unsigned long long m0 = 0ull, m1 = 0ull;
+      unsigned long long *best = s_best;
+      uint32_t *done = nullptr;
+      if (state == SEED) {
+        if ((uint32_t)(wbest >> 32) != 0u && P.debug < 2) {
+          const int32_t v = (int32_t)(wbest & 0xffu);
+          const uint32_t ub = (uint32_t)(wbest >> 32);
+          k = (int32_t)((uint32_t)wbest >> 8);
+          u0 = v == lane ? ub : 0u;
+          u1 = v == lane + 64 ? ub : 0u;
+          m0 = v < 64 ? 1ull << v : 0ull;
+          m1 = v < 64 ? 0ull : 1ull << (v - 64);
+          done = s_U + k * 128;
+          have = true;
+        }
+      } else if (state == OWN) {
+        int32_t rank = P.n_theta;
+        if (P.debug == 0 || P.debug >= 3) {
+          if (lane == 0) rank = (int32_t)atomicAdd(s_qhead, 1u);
+          rank = __builtin_amdgcn_readfirstlane(rank);
+        }
+        if (rank >= P.n_theta) {
+          state = HELP;
+          if (P.stats) t_own = clock64();
+          continue;
+        }
+        k = (int32_t)s_order[rank];
         u0 = s_U[k * 128 + lane];
         u1 = s_U[k * 128 + 64 + lane];
-      }
-      const uint32_t bsum = best_sum<false>(s_best);
-      unsigned long long m0 = __ballot(u0 != 0u && u0 >= bsum), m1 = __ballot(u1 != 0u && u1 >= bsum && lane + 64 < NB * NB);
-      if ((m0 | m1) != 0ull) {
-        float cf, sf;
-        rotation_k(P, pair, k, &cf, &sf);
-        if (P.stats) t_mark = clock64();
-        cache_origins(P, pts, n_pts, cf, sf, cx, cy, lane, org);
-        if (P.stats) t_org += clock64() - t_mark;
-        const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(grid, P.grid_bytes + P.skip_bytes);
-        const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
-        // candidates in block order b = NB * Y + X; neighbours in X (up to three) share one pass over the table
-        while ((m0 | m1) != 0ull) {
-          const int b0 = m0 ? (int)__builtin_ctzll(m0) : 64 + (int)__builtin_ctzll(m1);
-          const int Y = b0 / NB, X0 = b0 - NB * Y;
-          int len = 1;
-          while (len < 3 && X0 + len < NB) {
-            const int b = b0 + len;
-            if (!(((b < 64 ? m0 >> b : m1 >> (b - 64)) & 1ull))) break;
-            len++;
+        const uint32_t bsum = best_sum<false>(s_best);
+        m0 = __ballot(u0 != 0u && u0 >= bsum);
+        m1 = __ballot(u1 != 0u && u1 >= bsum && lane + 64 < NB * NB);
+        if ((m0 | m1) == 0ull) continue;
+        if (P.rot_list && (uint32_t)rank >= P.keep_ranks &&
+            (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1)) >= P.heavy_min) {
+          uint32_t e = 0u;
+          if (lane == 0) {
+            // the pair's best so far, where the takers find it (every access to keys[] inside the kernel is an atomic)
+            if (P.donate) atomicMax(&P.keys[pair], *(volatile unsigned long long *)s_best);
+            e = atomicAdd(P.rot_count + 8 * xcd, 1u);
           }
-          uint32_t sb[12];
-          if (P.debug == 5) {  // (timing: origins only)
-            m0 = m1 = 0ull;
-            break;
-          }
-          if (P.levels >= 2) {
-            if (P.stats) t_mark = clock64();
-            strip_bounds_c(P, p4, org, nch, Y, X0, CB == 1 ? 1u : 257u, sb);
-            if (P.stats) t_strip += clock64() - t_mark;
-            n_work[1] += (uint32_t)len;
-          } else {
-#pragma unroll
-            for (int q = 0; q < 12; q++) sb[q] = 0xffffffffu;
-          }
-#pragma unroll 1
-          for (int t = 0; t < len; t++) {
-            const int b = b0 + t;
-            if (b < 64) m0 &= ~(1ull << b);
-            else m1 &= ~(1ull << (b - 64));
-            const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)(b < 64 ? u0 : u1), b & 63);
-            if (ub < best_sum<false>(s_best) || (P.debug == 4 && !first)) continue;  // the best has risen meanwhile
-            // (selects, not an indexed array: that would live in scratch)
-            const uint32_t s0 = t == 0 ? sb[0] : (t == 1 ? sb[4] : sb[8]), s1 = t == 0 ? sb[1] : (t == 1 ? sb[5] : sb[9]);
-            const uint32_t s2 = t == 0 ? sb[2] : (t == 1 ? sb[6] : sb[10]), s3 = t == 0 ? sb[3] : (t == 1 ? sb[7] : sb[11]);
-            if (P.stats) t_mark = clock64();
-            process_candidate_c<CB>(P, rsrc, org, nch, k, Y, X0 + t, s0, s1, s2, s3, lane, s_best, n_work);
-            if (P.stats) t_eval += clock64() - t_mark;
-            if (first && lane == 0) s_U[k * 128 + b] = 0u;  // done
+          e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+          if (e < P.rot_cap) {
+            if (lane < 4) {  // four words, each with its own "written" bit
+              const unsigned long long M41 = (1ull << 41) - 1ull;
+              const unsigned long long word = lane == 0   ? ((unsigned long long)(uint32_t)pair << 24) | (uint32_t)k
+                                              : lane == 1 ? (m0 & M41)
+                                              : lane == 2 ? ((m0 >> 41) | (m1 << 23)) & M41
+                                                          : (m1 >> 18);
+              __hip_atomic_store(&P.rot_list[(size_t)xcd * P.rot_cap + e].w[lane], word | ROT_WRITTEN, __ATOMIC_RELAXED,
+                                 __HIP_MEMORY_SCOPE_AGENT);
+            }
+            offload = true;
+            continue;
+          }  // (list full: the rotation stays here)
+        }
+        have = true;
+      } else {
+        if (!(P.rot_list && P.donate)) break;
+        uint32_t *alloc = P.rot_count + 8 * xcd, *next = alloc + 1;
+        uint32_t i = 0xffffffffu;
+        if (lane == 0) {
+          for (;;) {
+            uint32_t n = __hip_atomic_load(next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t a = __hip_atomic_load(alloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (n >= (a < P.rot_cap ? a : P.rot_cap)) break;
+            if (__hip_atomic_compare_exchange_strong(next, &n, n + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+              i = n;
+              break;
+            }
           }
         }
+        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        if (i == 0xffffffffu) break;
+        int32_t pair2;
+        read_entry(P.rot_list + (size_t)xcd * P.rot_cap + i, &pair2, &k, &m0, &m1);
+        pair_context(P, pair2, &Ci);
+        u0 = u1 = 0xffffffffu;  // (no block bounds: every candidate goes on to its sub-block bounds)
+        best = &P.keys[pair2];
+        global = true;
+        have = true;
       }
-      if (first) {
-        first = false;
+      if (have) {
+        uint32_t n_item[3] = {0u, 0u, 0u};
+        rotation_pass<CB>(P, global, Ci, k, u0, u1, m0, m1, lane, best, done, org, n_item, clk);
+        if (global) {
+          if (P.stats && lane == 0 && Ci.pair < BNB_STATS_PAIRS)
+            atomicAdd(&P.stats[BNB_STATS_HEAD + Ci.pair], 4ull * n_item[0] + n_item[2]);
+          n_help[0] += n_item[0];
+          n_help[1] += n_item[1];
+          n_help[2] += n_item[2];
+        } else {
+          n_work[0] += n_item[0];
+          n_work[1] += n_item[1];
+          n_work[2] += n_item[2];
+        }
+      }
+      if (state == SEED) {
         __syncthreads();
-        if (P.stats) t_busy = clock64();
+        if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair + 2] = wall_clock64();
+        if (P.stats) {
+          t_busy = clock64();
+          t_wall = wall_clock64();
+        }
+        // best first: the rotations in descending order of their highest bound (rank by counting: n_theta^2 compares)
+        for (int32_t kk = threadIdx.x; kk < P.n_theta; kk += BNB_THREADS) {
+          const unsigned long long mine = s_kmax[kk];
+          int32_t rank = 0;
+          for (int32_t j = 0; j < P.n_theta; j++) rank += s_kmax[j] > mine ? 1 : 0;
+          s_order[rank] = (uint32_t)kk;
+        }
+        __syncthreads();
+        state = OWN;
       }
     }
     if (P.stats && lane == 0) {
-      const long long now = clock64();
+      const long long now = t_own ? t_own : clock64();
+      if (t_own) atomicAdd(&P.stats[13], (unsigned long long)(clock64() - t_own));  // wave time helping
       atomicAdd(&P.stats[4], (unsigned long long)(now - t_busy));       // wave time in phase 3 (until out of work)
-      atomicAdd(&P.stats[5], (unsigned long long)t_org);
-      atomicAdd(&P.stats[6], (unsigned long long)t_strip);
-      atomicAdd(&P.stats[7], (unsigned long long)t_eval);
-      atomicMax(reinterpret_cast<unsigned long long *>(s_queue), (unsigned long long)(now - t_busy));  // slowest wave
+      atomicAdd(&P.stats[11], (unsigned long long)(wall_clock64() - t_wall));  // the same in 100 MHz ticks
+      atomicAdd(&P.stats[5], (unsigned long long)clk.org);
+      atomicAdd(&P.stats[6], (unsigned long long)clk.strip);
+      atomicAdd(&P.stats[7], (unsigned long long)clk.eval);
+      atomicMax(s_slow, (unsigned long long)(now - t_busy));  // slowest wave
       if (wave == 0) {
         atomicAdd(&P.stats[9], (unsigned long long)(t_busy - t_phase1));  // seeds (wave 0's view)
         atomicAdd(&P.stats[10], (unsigned long long)(t_phase1 - t_start)); // bounds
+        if (offload) atomicAdd(&P.stats[12], 1ull);
       }
     }
   } else {
@@ -1122,21 +1369,6 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         const uint32_t u = s_U[k * 128 + lane + 64 * i];
         const uint32_t bsum = (uint32_t)(*(volatile unsigned long long *)s_best >> 32);
         bool cand = u != 0u && u >= bsum;
-        if (P.cand_list) {
-          // the grid-wide list: a second kernel evaluates it with every wave of the chip (a pair whose landscape is
-          // flat has thousands of survivors, most pairs a few dozen); what does not fit stays with this workgroup
-          const unsigned long long gm = __ballot(cand);
-          if (gm == 0ull) continue;
-          const uint32_t xcd = bid & 7u;
-          uint32_t gbase = 0u;
-          if (lane == 0) gbase = atomicAdd(P.cand_count + 8 * xcd, (uint32_t)__builtin_popcountll(gm));
-          gbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)gbase);
-          const uint32_t gpos = gbase + (uint32_t)__builtin_popcountll(gm & ((1ull << lane) - 1ull));
-          if (cand && gpos < P.cand_cap) {
-            P.cand_list[(size_t)xcd * P.cand_cap + gpos] = make_uint4(u, (uint32_t)pair, (uint32_t)((k << 8) | (lane + 64 * i)), 0u);
-            cand = false;
-          }
-        }
         const unsigned long long m = __ballot(cand);
         if (m == 0ull) continue;
         uint32_t base = 0u;
@@ -1152,7 +1384,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
           const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)entry, j);
           const uint32_t hi = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(entry >> 32), j);
           if (hi >= best_sum<false>(s_best))  // (the best may have risen meanwhile)
-            process_candidate<CB, false>(P, C, (int32_t)(lo >> 8), (int32_t)(lo & 0xffu), lane, s_best, n_work);
+            process_candidate<CB>(P, C, (int32_t)(lo >> 8), (int32_t)(lo & 0xffu), lane, s_best, n_work);
         }
       }
     }
@@ -1166,7 +1398,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         if (i >= qn) break;
         const unsigned long long entry = s_queue[i];
         if ((uint32_t)(entry >> 32) >= best_sum<false>(s_best))
-          process_candidate<CB, false>(P, C, (int32_t)((uint32_t)entry >> 8), (int32_t)(entry & 0xffu), lane, s_best, n_work);
+          process_candidate<CB>(P, C, (int32_t)((uint32_t)entry >> 8), (int32_t)(entry & 0xffu), lane, s_best, n_work);
       }
     }
 }
@@ -1174,51 +1406,64 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     atomicAdd(&s_cnt[0], n_work[0]);
     atomicAdd(&s_cnt[3], n_work[1]);
     atomicAdd(&s_cnt[4], n_work[2]);
+    if (n_help[0]) atomicAdd(&P.stats[0], (unsigned long long)n_help[0]);
+    if (n_help[1]) atomicAdd(&P.stats[2], (unsigned long long)n_help[1]);
+    if (n_help[2]) atomicAdd(&P.stats[3], (unsigned long long)n_help[2]);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    P.keys[pair] = *s_best;
-    if (P.stats && BY_ROT) atomicAdd(&P.stats[8], s_queue[0]);  // sum over pairs of the slowest wave's phase 3
+    if (BY_ROT && P.donate) atomicMax(&P.keys[pair], *s_best);  // (helpers may have raised it already)
+    else P.keys[pair] = *s_best;
+    if (P.timeline && pair < BNB_STATS_PAIRS) {
+      uint32_t hw;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+      uint32_t xcc;
+      asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+      P.timeline[4 * pair + 3] = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)(hw & 0xffffu) << 48);
+      (void)xcc;
+    }
+    if (P.stats && BY_ROT) atomicAdd(&P.stats[8], *s_slow);  // sum over pairs of the slowest wave's phase 3
     if (P.stats) {
       atomicAdd(&P.stats[0], (unsigned long long)s_cnt[0]);
       atomicAdd(&P.stats[1], (unsigned long long)(P.n_theta * P.nbx * P.nby));
       atomicAdd(&P.stats[2], (unsigned long long)s_cnt[3]);
       atomicAdd(&P.stats[3], (unsigned long long)s_cnt[4]);
-      if (pair < BNB_STATS_PAIRS) P.stats[BNB_STATS_HEAD + pair] = 4ull * s_cnt[0] + s_cnt[4];
+      if (pair < BNB_STATS_PAIRS) atomicAdd(&P.stats[BNB_STATS_HEAD + pair], 4ull * s_cnt[0] + s_cnt[4]);
     }
   }
 }
 
-// Second kernel of the two-kernel form: the candidates of ALL pairs, one wave per candidate, every wave of the chip.
-// A candidate is skipped when the pair's best sum (keys[pair], raised by the seeds and by candidates evaluated
-// before it) has passed its bound.
+// Second kernel: the rotations of the pairs with many candidates, one wave per (pair, rotation), every wave of the
+// chip.  The pair's running best is keys[pair] (left by its workgroup after the seeds, raised by every wave that
+// works on the pair); a block is skipped when that has passed its bound.
 template <int CB>
-__global__ __launch_bounds__(256, 4) void csm_bnb_eval_kernel(BnbParams P) {
+__global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
   const int lane = threadIdx.x & 63;
-  // workgroup b works on the list of XCD b & 7 (blocks b and b + 8 share an XCD): the waves of that XCD stride over it
+  // workgroup b works on the list of XCD b & 7 (blocks b and b + 8 share an XCD)
   const uint32_t xcd = blockIdx.x & 7u;
-  const uint32_t wave_id = (blockIdx.x >> 3) * 4u + (threadIdx.x >> 6), n_waves = (gridDim.x >> 3) * 4u;
-  const uint32_t filled = P.cand_count[8 * xcd];
-  const uint32_t count = filled < P.cand_cap ? filled : P.cand_cap;
-  const uint4 *list = P.cand_list + (size_t)xcd * P.cand_cap;
+  const uint32_t filled = P.rot_count[8 * xcd];
+  const uint32_t count = filled < P.rot_cap ? filled : P.rot_cap;
+  const RotEntry *list = P.rot_list + (size_t)xcd * P.rot_cap;
   uint32_t n_work[3] = {0u, 0u, 0u};
-  for (uint32_t i = wave_id; i < count; i += n_waves) {
-    const uint4 c = list[i];
-    const int32_t pair = (int32_t)c.y;
-    const unsigned long long best = __hip_atomic_load(&P.keys[pair], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (c.x < (uint32_t)(best >> 32)) continue;
-    const int32_t k = (int32_t)(c.z >> 8), v = (int32_t)(c.z & 0xffu);
-    const int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
-    const int32_t beg = P.offsets[src];
+  uint32_t org[OC];
+#pragma unroll
+  for (int c = 0; c < OC; c++) org[c] = 0u;
+  PhaseClocks clk = {0, 0, 0};
+  const long long t0 = P.stats ? clock64() : 0;
+  for (;;) {
+    uint32_t i = 0u;
+    if (lane == 0) i = atomicAdd(P.rot_count + 8 * xcd + 1, 1u);
+    i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+    if (i >= count) break;
+    int32_t pair, k;
+    unsigned long long m0, m1;
+    read_entry(list + i, &pair, &k, &m0, &m1);
     PairCtx C;
-    C.grid = P.grids + (size_t)slot * P.slot_bytes;
-    C.pts = P.xy + beg;
-    C.n_pts = P.offsets[src + 1] - beg;
-    C.cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
-    C.cy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
-    C.pair = pair;
+    pair_context(P, pair, &C);
     uint32_t n[3] = {0u, 0u, 0u};
-    process_candidate<CB, true>(P, C, k, v, lane, &P.keys[pair], n);
+    // (no block bounds here: 0xffffffff lets every candidate through to its sub-block bounds, which are checked
+    //  against the best as it stands in keys[pair])
+    rotation_pass<CB>(P, true, C, k, 0xffffffffu, 0xffffffffu, m0, m1, lane, &P.keys[pair], nullptr, org, n, clk);
     if (P.stats && lane == 0 && pair < BNB_STATS_PAIRS) atomicAdd(&P.stats[BNB_STATS_HEAD + pair], 4ull * n[0] + n[2]);
     n_work[0] += n[0];
     n_work[1] += n[1];
@@ -1228,11 +1473,15 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_eval_kernel(BnbParams P) {
     if (n_work[0]) atomicAdd(&P.stats[0], (unsigned long long)n_work[0]);
     if (n_work[1]) atomicAdd(&P.stats[2], (unsigned long long)n_work[1]);
     if (n_work[2]) atomicAdd(&P.stats[3], (unsigned long long)n_work[2]);
+    atomicAdd(&P.stats[13], (unsigned long long)(clock64() - t0));  // wave time in the second kernel
+    atomicAdd(&P.stats[5], (unsigned long long)clk.org);
+    atomicAdd(&P.stats[6], (unsigned long long)clk.strip);
+    atomicAdd(&P.stats[7], (unsigned long long)clk.eval);
   }
 }
 
 size_t bnb_lds_bytes(const GridLayout &L, const nhip_search_t *search, bool pool_lds) {
-  return (pool_lds ? (size_t)L.pool_bytes : 0) + (size_t)search->n_theta * 128 * 4 + (size_t)QCAP * 8 + 32;
+  return (pool_lds ? (size_t)L.pool_bytes : 0) + (size_t)search->n_theta * 128 * 4 + (size_t)QCAP * 8 + 64;
 }
 constexpr size_t LDS_MAX = 160 * 1024;
 
@@ -1242,14 +1491,16 @@ bool bnb_fits(const GridLayout &L, const nhip_search_t *search) {
   const int nbx = (search->nx + BNB_B - 1) / BNB_B, nby = (search->ny + BNB_B - 1) / BNB_B;
   // (the pooled table goes to LDS when it fits beside the bounds; else it is read from global memory)
   return nbx <= NB && nby <= NB && bnb_lds_bytes(L, search, false) <= LDS_MAX && L.pool_bytes % 16 == 0 &&
-         L.pool_bytes < 0x7fffffffll && L.S + 2 * L.pad < 65536 && search->n_theta < (1 << 23);
+         L.pool_bytes < 0x7fffffffll && L.S + 2 * L.pad < 65536 && search->n_theta <= MAX_ROT;
 }
 
+static unsigned long long *g_bnb_timeline = nullptr;
 static unsigned long long *g_bnb_stats = nullptr;  // device counters, allocated on first use when NHIP_BNB_STATS=1
 
-constexpr int64_t BNB_WS_HEADER = 256;  // eight fill counters, 32 bytes apart
+constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, next entry to work}
+// room for 16 rotations per pair on average (what does not fit is worked by the pair's own workgroup)
 int64_t bnb_workspace_bytes(int32_t n_pairs) {
-  return BNB_WS_HEADER + 8 * ((((int64_t)(n_pairs > 0 ? n_pairs : 0) + 7) / 8) * 192 + 64) * 16;
+  return BNB_WS_HEADER + 8 * ((((int64_t)(n_pairs > 0 ? n_pairs : 0) + 7) / 8) * 16 + 64) * (int64_t)sizeof(RotEntry);
 }
 
 int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
@@ -1313,20 +1564,40 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     }
     P.stats = g_bnb_stats;
   }
-  // Two-kernel form (candidates of all pairs through per-XCD lists in the caller's workspace, evaluated by every
-  // wave of the chip): for SMALL batches, where a pair with thousands of survivors would keep one workgroup busy
-  // for milliseconds while the rest of the chip idles.  With thousands of pairs in flight the chip is full either
-  // way and evaluating a pair's candidates inside its own workgroup is the faster form (measured: 17.3 vs 19.8 ms
-  // per 10,000 pairs; the evaluation is bound by L1 tag lookups, not by balance).  NHIP_BNB_KERNELS=1|2 forces one.
+  const char *tl = getenv("NHIP_BNB_TIMELINE");
+  if (tl && tl[0] == '1') {
+    if (!g_bnb_timeline) NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_timeline), 32 * (size_t)BNB_STATS_PAIRS + 16));
+    P.timeline = g_bnb_timeline;
+    const unsigned long long init[2] = {~0ull, 0ull};  // the second kernel's first start and last end
+    NHIP_TRY_HIP(hipMemcpyAsync(g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS, init, 16, hipMemcpyHostToDevice, s));
+  }
+  // Work sharing.  A flat landscape leaves a pair thousands of candidates (the median pair: ~30): its workgroup would
+  // be busy for milliseconds -- 5 to 7 ms for the worst of 10,000 pairs, a third of the launch spent on a tail with
+  // the chip nearly empty.  A pair with >= heavy_min candidates after bounds and seeds hands its rotations (with
+  // their bounds) to per-XCD lists in the caller's workspace, and
+  //  - large batches: every wave that has finished its own pair takes entries off the list before it exits
+  //    (`donate`; the candidate phase, bound by L1 lookups, keeps overlapping the other workgroups' VALU-bound bounds);
+  //  - batches of <= 64 pairs (the drop-in's GetTransformation is a batch of one): the workgroups do not fill the
+  //    chip, every pair hands over everything, and a second kernel works the lists with every wave of the chip.
+  // NHIP_BNB_KERNELS=1: no hand-over, =2: second kernel for everything; NHIP_BNB_HEAVY_MIN=<candidates>.
   const char *force = getenv("NHIP_BNB_KERNELS");
-  const bool two = force ? force[0] == '2' : n_pairs <= 64;
-  if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * 16 * 8 && two) {
-    P.cand_count = static_cast<uint32_t *>(d_workspace);
-    P.cand_list = reinterpret_cast<uint4 *>(static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER);
-    const int64_t cap = (workspace_bytes - BNB_WS_HEADER) / 16 / 8;  // entries per XCD list
-    P.cand_cap = (uint32_t)(cap < 0x0fffffffll ? cap : 0x0fffffffll);
-    P.general_all = 1;
+  const char *hm = getenv("NHIP_BNB_HEAVY_MIN");
+  const bool second = force ? force[0] == '2' : n_pairs <= 64;
+  const char *kr = getenv("NHIP_BNB_KEEP_RANKS");
+  P.heavy_min = hm ? (uint32_t)atoi(hm) : (second ? 1u : 12u);
+  P.keep_ranks = kr ? (uint32_t)atoi(kr) : (second ? 8u : 16u);
+  P.donate = second ? 0u : 1u;
+  if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * (int64_t)sizeof(RotEntry) && !(force && force[0] == '1') &&
+      !P.general_all) {
+    P.rot_count = static_cast<uint32_t *>(d_workspace);
+    P.rot_list = reinterpret_cast<RotEntry *>(static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER);
+    const int64_t cap = (workspace_bytes - BNB_WS_HEADER) / (int64_t)sizeof(RotEntry) / 8;  // entries per XCD list
+    P.rot_cap = (uint32_t)(cap < 0x0fffffffll ? cap : 0x0fffffffll);
     NHIP_TRY_HIP(hipMemsetAsync(d_workspace, 0, BNB_WS_HEADER, s));
+    // (an entry is zero until its word is stored: the lists are zeroed once per launch)
+    NHIP_TRY_HIP(hipMemsetAsync(P.rot_list, 0, (size_t)P.rot_cap * 8 * sizeof(RotEntry), s));
+  } else {
+    P.donate = 0u;
   }
   const bool pool_lds = bnb_lds_bytes(L, search, true) <= LDS_MAX;
   const size_t lds = bnb_lds_bytes(L, search, pool_lds);
@@ -1336,6 +1607,11 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   do {                                                                                                           \
     NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL, BR>),                 \
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
+    if (P.stats && getenv("NHIP_BNB_OCCUPANCY")) {                                                               \
+      int nb = -1;                                                                                               \
+      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, csm_bnb_kernel<CB, PL, BR>, BNB_THREADS, lds);     \
+      fprintf(stderr, "csm_bnb_kernel<%d,%d,%d>: lds %zu B, %d workgroups per CU\n", CB, (int)PL, (int)BR, lds, nb); \
+    }                                                                                                            \
     hipLaunchKernelGGL((csm_bnb_kernel<CB, PL, BR>), dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);      \
   } while (0)
 #define NHIP_BNB_LAUNCH(CB, PL)                                                                                  \
@@ -1349,10 +1625,10 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   else NHIP_BNB_LAUNCH(2, false);
 #undef NHIP_BNB_LAUNCH1
 #undef NHIP_BNB_LAUNCH
-  if (P.cand_list && (P.debug == 0 || P.debug == 3)) {
-    const uint32_t eval_blocks = 256 * 16;  // 16 workgroups of four waves per CU's worth; waves stride over the list
-    if (L.cb == 1) hipLaunchKernelGGL(csm_bnb_eval_kernel<1>, dim3(eval_blocks), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL(csm_bnb_eval_kernel<2>, dim3(eval_blocks), dim3(256), 0, s, P);
+  if (P.rot_list && !P.donate && (P.debug == 0 || P.debug >= 3)) {
+    const uint32_t rot_blocks = 256 * 4;  // four workgroups of four waves per CU; the waves take entries off the lists
+    if (L.cb == 1) hipLaunchKernelGGL(csm_bnb_rot_kernel<1>, dim3(rot_blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL(csm_bnb_rot_kernel<2>, dim3(rot_blocks), dim3(256), 0, s, P);
   }
   timer_end(NHIP_TIMER_CSM, s);
   NHIP_TRY_HIP(hipGetLastError());
@@ -1365,6 +1641,15 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
 int bnb_stats_per_pair(unsigned long long *out, int32_t n) {
   if (!g_bnb_stats || n <= 0) return NHIP_OK;
   NHIP_TRY_HIP(hipMemcpy(out, g_bnb_stats + BNB_STATS_HEAD, 8 * (size_t)(n < BNB_STATS_PAIRS ? n : BNB_STATS_PAIRS), hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int bnb_timeline_read(unsigned long long *out, int32_t n) {
+  if (!g_bnb_timeline || n <= 0) return NHIP_OK;
+  if (n > BNB_STATS_PAIRS) n = BNB_STATS_PAIRS;
+  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_timeline, 32 * (size_t)n, hipMemcpyDeviceToHost));
+  // (the last pair's slot is followed by the second kernel's first start / last end)
+  NHIP_TRY_HIP(hipMemcpy(out + 4 * (size_t)n, g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS, 16, hipMemcpyDeviceToHost));
   return NHIP_OK;
 }
 

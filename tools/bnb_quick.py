@@ -1,0 +1,21 @@
+#!/usr/bin/env python3
+"""Kernel time of the branch-and-bound matcher on the bench workload under the environment given (GPU box)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import bench
+from nautilus_amd import _lib, sharding
+lib = _lib.load()
+wl = bench.Workload("weak", 1, int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 10)
+plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
+for bits in (8, 16):
+    m = bench.HipMatcher(wl, plan.shard(0), torch.device("cuda", 0), bits)
+    m.step(); torch.cuda.synchronize()
+    lib.nhip_timing_reset(); lib.nhip_timing_enable(1)
+    for _ in range(5):
+        m.step()
+    torch.cuda.synchronize(); lib.nhip_timing_enable(0)
+    ms, n = bench._timer(lib, _lib, _lib.NHIP_TIMER_CSM)
+    print("u%d kernel_ms %.3f" % (bits, ms / n), flush=True)
+    m.free_grids()
