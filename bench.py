@@ -377,8 +377,13 @@ def worker(a):
     traffic = _traffic("csm_bnb_bytes_per_launch_%dpairs_u%d" % (m.n_pairs, a.cell_bits))
     bnb = None
     if os.environ.get("NHIP_BNB_STATS") == "1":
-        ev, tot = csm.bnb_stats()
-        bnb = {"blocks_evaluated_per_pair": ev / max(m.n_pairs * (a.steps + a.warmup), 1), "fraction_of_blocks": ev / max(tot, 1)}
+        lv = csm.bnb_stats_levels()
+        launches = max(m.n_pairs * (a.steps + a.warmup), 1)
+        ev = lv["blocks_whole"] + lv["sub_blocks"] / 4.0
+        bnb = {"blocks_evaluated_per_pair": ev / launches, "fraction_of_poses_evaluated": ev / max(lv["blocks_total"], 1),
+               "whole_blocks_per_pair": lv["blocks_whole"] / launches, "sub_blocks_per_pair": lv["sub_blocks"] / launches,
+               "candidate_blocks_refined_per_pair": lv["candidates_refined"] / launches,
+               "pairs_that_handed_rotations_over": lv["pairs_handed_over"] / max(a.steps + a.warmup, 1)}
     L = m.layout
     out = {
         "metric": "loop-closure candidate pairs/sec (1081-beam)",
@@ -405,7 +410,7 @@ def worker(a):
         # The dominant kernel (csm_bnb_kernel: bounds from an LDS-resident pooled table, exact sums gathered through
         # L1/L2) moves ~1 % of the HBM peak; it is priced against the vector-instruction peak, and the L1 tag-lookup
         # rate that limits its exact-evaluation phase is in onchip_roofline.
-        "roofline": {"bound": "valu", "kernel": "csm_bnb_kernel<%d>" % cell_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
+        "roofline": {"bound": "valu", "kernel": "csm_bnb_kernel<%d, true, true>" % cell_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
                      "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None, "peak": VALU_PEAK_WAVE_INSTR / 1e12,
                      "unit": "T wave-instr/s", "frac": oc["valu_frac"] if oc else None, "traffic": traffic,
                      "note": "VALU wave64 instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/) / kernel time "
@@ -420,8 +425,10 @@ def worker(a):
                                        "HBM bytes per launch / kernel time / 8 TB/s"},
         "kernels_ms_per_step": {"csm_match": k_ms / a.steps, "grid_blur_skipmap_pool": g_ms / a.steps},
         "onchip_roofline": oc,
-        "algorithm": {"name": "branch and bound over 8x8 blocks of translations (max-pooled table bounds), exact: "
-                              "indices, sums and scores identical to the exhaustive kernel's (secondary.exhaustive_u8)",
+        "algorithm": {"name": "branch and bound, exact: bounds of 8x8 blocks of translations from a max-pooled table "
+                              "(run-length compressed points), 4x4 sub-block bounds from a second table, exact sums for "
+                              "the sub-blocks that remain; indices, sums and scores identical to the exhaustive kernel's "
+                              "(secondary.exhaustive_u8)",
                       "stats": bnb},
     }
     legs = world == 1 and a.mode == "weak"

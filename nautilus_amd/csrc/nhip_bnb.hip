@@ -10,11 +10,14 @@
 // [r + 8Y, r + 8Y + 8) and columns [c + 8X, c + 8X + 8), all inside the 15 x 15 cells that the pooled entry
 // pool[(r >> 3) + Y][(c >> 3) + X] covers (nhip_grid.hip).  So U(k, Y, X) = sum over points of that entry is an
 // upper bound of every sum in the block (16-bit cells: 257 * U, the pool holds ceil(max / 257)).
-// Search: (1) U for all blocks of all rotations -- a gather of 11 x 11 bytes per point and rotation from the
-// LDS-resident pooled table; (2) every wave evaluates its highest-bound block exactly, which gives a lower bound
-// `best` of the optimum; (3) every block with U >= best's sum is evaluated exactly (64 sums, gathered from the
-// stored grid through L2), `best` rising as it goes; blocks with U < best's sum cannot hold the optimum, nor a
-// tie with it, and are never touched.  On the 1081-beam workload ~1 % of the blocks are evaluated.
+// Search: (1) U for all blocks of all rotations -- a gather of 11 x 11 bytes per RUN of points that share a pooled
+// entry (consecutive beams do: run-length compression cuts the gathers ~5x) from the LDS-resident pooled table;
+// (2) every wave evaluates its highest-bound block exactly, which gives a lower bound `best` of the optimum;
+// (3) rotation by rotation, best first: every block with U >= best's sum is refined through the bounds of its four
+// 4 x 4 sub-blocks (second table, pooled over 7 x 7 cells at stride 4: one 16-byte read per point serves a strip of
+// three neighbouring blocks) and exact sums are gathered from the stored grid only for the sub-blocks whose bound
+// still reaches `best`, which rises as it goes.  Blocks and sub-blocks with a bound below best's sum cannot hold the
+// optimum, nor a tie with it, and are never touched.  On the 1081-beam workload 0.36 % of the poses are evaluated.
 //
 // Parallelisation is the transpose of the exhaustive kernel's: LANES ARE POINTS (one point per lane and
 // 64-point chunk), REGISTERS ARE POSES -- byte sums SWAR-packed two per register -- and one transposing
@@ -43,14 +46,11 @@ constexpr uint32_t M8 = 0x00ff00ffu;
 constexpr int BNB_STATS_PAIRS = 1 << 20;
 constexpr int BNB_STATS_HEAD = 16;       // totals: 4 counts, then shader-clock sums of the by-rotation kernel (see nhip_bnb_stats_levels)  // per-pair counters kept by NHIP_BNB_STATS=1
 
-// One rotation of a pair with many candidates, handed to other waves: (pair, rotation) and the mask of its 121
-// candidate blocks, in four 64-bit words that each carry their own "written" bit -- so the hand-over needs nothing
-// but relaxed device-scope atomics on single words (an acquire / release at device scope invalidates / writes
-// back the XCD's whole L2 on this chip), and the taker simply waits until all four have arrived.
+// One rotation of a pair with many candidates, handed to the second kernel: (pair, rotation) and the mask of its
+// 121 candidate blocks.
 struct RotEntry {
-  unsigned long long w[4];  // each: bit 63 = written; w[0]: pair << 24 | rotation; w[1..3]: candidate blocks 0..40, 41..81, 82..120
+  unsigned long long w[4];  // w[0]: pair << 24 | rotation; w[1..3]: candidate blocks 0..40, 41..81, 82..120
 };
-constexpr unsigned long long ROT_WRITTEN = 1ull << 63;
 
 struct BnbParams {
   const float2 *xy;
@@ -68,9 +68,8 @@ struct BnbParams {
   RotEntry *rot_list;          // optional lists of (pair, rotation) work items in the caller's workspace, one per XCD so
   uint32_t *rot_count;        //   that a pair's rotations are worked where its grid is L2-resident; per XCD 32 bytes of
   uint32_t rot_cap;           //   counters {filled, next}; entries per list
-  uint32_t heavy_min;         // candidates from which a ROTATION is handed over ...
-  uint32_t keep_ranks;        // ... unless it is among the pair's first keep_ranks rotations in best-first order
-  uint32_t donate;            // 1: the lists are drained inside the first kernel, by every wave that has finished its own pair
+  uint32_t heavy_min;         // candidates (after the seeds) from which a PAIR hands its rotations over ...
+  uint32_t keep_ranks;        // ... except its first keep_ranks rotations in best-first order (one per wave)
   int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
   int32_t S, pad, pitch, rows, max_shift;
   int32_t pool_pitch, pool_rows, pairs_per_xcd;
@@ -634,7 +633,8 @@ constexpr int OC = 18;
 
 __device__ __forceinline__ void cache_origins(const BnbParams &P, const float2 *pts, int32_t n_pts, float cf, float sf,
                                               int32_t cx, int32_t cy, int lane, uint32_t (&org)[OC]) {
-  // (rolled: the origin arithmetic holds a division on its rare path; the arrays rotate so that indices stay static.
+  // (rolled: the origin arithmetic holds a division on its rare path; the arrays rotate so that indices stay static --
+  //  indexing org[] with the loop counter puts it into indexed scratch memory: measured 2x slower for the whole kernel.
   //  The points of the next D chunks are in flight while one chunk's origins are computed.)
   constexpr int D = 6;
   float px[D], py[D];
@@ -1052,19 +1052,11 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, bool global, c
 // ---- hand-over entries
 __device__ __forceinline__ void read_entry(const RotEntry *ent, int32_t *pair, int32_t *k, unsigned long long *m0,
                                            unsigned long long *m1) {
-  // (its pusher is between taking the slot and storing the words: a few hundred nanoseconds at most)
-  unsigned long long w[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    unsigned long long *p = const_cast<unsigned long long *>(&ent->w[i]);
-    while (((w[i] = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) & ROT_WRITTEN) == 0ull)
-      __builtin_amdgcn_s_sleep(2);
-    w[i] &= ~ROT_WRITTEN;
-  }
-  *pair = (int32_t)(w[0] >> 24);
-  *k = (int32_t)(w[0] & 0xffffffull);
-  *m0 = w[1] | (w[2] << 41);          // blocks 0..63
-  *m1 = (w[2] >> 23) | (w[3] << 18);  // blocks 64..120
+  const unsigned long long w0 = ent->w[0], w1 = ent->w[1], w2 = ent->w[2], w3 = ent->w[3];
+  *pair = (int32_t)(w0 >> 24);
+  *k = (int32_t)(w0 & 0xffffffull);
+  *m0 = w1 | (w2 << 41);          // blocks 0..63
+  *m1 = (w2 >> 23) | (w3 << 18);  // blocks 64..120
 }
 
 __device__ __forceinline__ void pair_context(const BnbParams &P, int32_t pair, PairCtx *C) {
@@ -1122,8 +1114,6 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     *s_slow = 0ull;
     // (NHIP_BNB_DEBUG=3, experiments only: start from the keys a previous launch left = the ideal threshold)
     *s_best = P.debug == 3 ? (P.keys[pair] & 0xffffffff00000000ull) : key0;
-    // (helpers raise it with atomics once the pair has handed over: every access inside this kernel is an atomic)
-    if (BY_ROT && P.donate) __hip_atomic_store(&P.keys[pair], key0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_cnt[0] = s_cnt[3] = s_cnt[4] = 0u;
     *s_qn = 0u;
     *s_qhead = 0u;
@@ -1177,7 +1167,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     wbest = o > wbest ? o : wbest;
   }
   // (2) seed: the wave's highest-bound block, evaluated exactly
-  uint32_t n_work[3] = {0u, 0u, 0u}, n_help[3] = {0u, 0u, 0u};  // (work on the own pair; on pairs helped)
+  uint32_t n_work[3] = {0u, 0u, 0u};
   PairCtx C;
   C.grid = grid;
   C.pts = pts;
@@ -1193,7 +1183,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     for (int c = 0; c < OC; c++) org[c] = 0u;
     // (NHIP_BNB_STATS=1: shader-clock sums -- wave time in phase 3 by part, and the workgroup's wall time)
     PhaseClocks clk = {0, 0, 0};
-    long long t_busy = 0, t_wall = 0, t_own = 0;
+    long long t_busy = 0, t_wall = 0;
     const long long t_phase1 = P.stats ? clock64() : 0;
     if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair + 1] = wall_clock64();
     const uint32_t xcd = bid & 7u;
@@ -1201,24 +1191,21 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     // One loop, one copy of the candidate code (it is large; three inlined copies did not fit the instruction
     // cache and halved the speed of everything).  A wave's work items, in this order:
     //  SEED  the wave's own highest-bound block, alone: the seeds give `best` a good lower bound before anything is
-    //        pruned against it; then the workgroup orders its rotations by their highest bound;
-    //  OWN   rotations of the own pair handed out one at a time, best first: every block of the rotation whose bound
+    //        pruned against it; then the workgroup orders its rotations by their highest bound and counts the
+    //        candidates the seeds have left;
+    //  OWN   rotations of the pair handed out one at a time, best first: every block of the rotation whose bound
     //        reaches the best sum found so far goes through its sub-block bounds and, where those hold, exact sums.
-    //        A flat landscape leaves thousands of candidates: past the pair's first keep_ranks rotations -- by then
-    //        the best sum has settled, so whoever works a rotation prunes as well as this workgroup would -- a
-    //        rotation with many candidates goes to the hand-over list of this XCD instead;
-    //  HELP  out of own work: rotations other pairs have handed over, until the list is empty (an entry pushed later
-    //        is taken by a later wave -- at the latest by its pusher, which comes through here after its last push
-    //        -- so the list is empty when the kernel ends).
-    enum { SEED, OWN, HELP };
+    //        A pair with a flat landscape (>= heavy_min candidates; see launch_csm_bnb) works only its first
+    //        keep_ranks rotations here and hands the others -- the rotation and the mask of its candidate blocks --
+    //        to the list of this XCD for the second kernel.
+    enum { SEED, OWN };
     int state = SEED;
+    bool heavy = false;  // (the pair hands its rotations over)
     for (;;) {
-      bool have = false, global = false;
-      PairCtx Ci = C;
+      bool have = false;
       int32_t k = 0;
       uint32_t u0 = 0u, u1 = 0u;
       unsigned long long m0 = 0ull, m1 = 0ull;
-      unsigned long long *best = s_best;
       uint32_t *done = nullptr;
       if (state == SEED) {
         if ((uint32_t)(wbest >> 32) != 0u && P.debug < 2) {
@@ -1238,11 +1225,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
           if (lane == 0) rank = (int32_t)atomicAdd(s_qhead, 1u);
           rank = __builtin_amdgcn_readfirstlane(rank);
         }
-        if (rank >= P.n_theta) {
-          state = HELP;
-          if (P.stats) t_own = clock64();
-          continue;
-        }
+        if (rank >= P.n_theta) break;
         k = (int32_t)s_order[rank];
         u0 = s_U[k * 128 + lane];
         u1 = s_U[k * 128 + 64 + lane];
@@ -1250,70 +1233,28 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         m0 = __ballot(u0 != 0u && u0 >= bsum);
         m1 = __ballot(u1 != 0u && u1 >= bsum && lane + 64 < NB * NB);
         if ((m0 | m1) == 0ull) continue;
-        if (P.rot_list && (uint32_t)rank >= P.keep_ranks &&
-            (uint32_t)(__builtin_popcountll(m0) + __builtin_popcountll(m1)) >= P.heavy_min) {
+        if (heavy && (uint32_t)rank >= P.keep_ranks) {
           uint32_t e = 0u;
           if (lane == 0) {
-            // the pair's best so far, where the takers find it (every access to keys[] inside the kernel is an atomic)
-            if (P.donate) atomicMax(&P.keys[pair], *(volatile unsigned long long *)s_best);
             e = atomicAdd(P.rot_count + 8 * xcd, 1u);
           }
           e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
           if (e < P.rot_cap) {
-            if (lane < 4) {  // four words, each with its own "written" bit
+            if (lane < 4) {
               const unsigned long long M41 = (1ull << 41) - 1ull;
               const unsigned long long word = lane == 0   ? ((unsigned long long)(uint32_t)pair << 24) | (uint32_t)k
                                               : lane == 1 ? (m0 & M41)
                                               : lane == 2 ? ((m0 >> 41) | (m1 << 23)) & M41
                                                           : (m1 >> 18);
-              __hip_atomic_store(&P.rot_list[(size_t)xcd * P.rot_cap + e].w[lane], word | ROT_WRITTEN, __ATOMIC_RELAXED,
-                                 __HIP_MEMORY_SCOPE_AGENT);
+              P.rot_list[(size_t)xcd * P.rot_cap + e].w[lane] = word;
             }
             offload = true;
             continue;
           }  // (list full: the rotation stays here)
         }
         have = true;
-      } else {
-        if (!(P.rot_list && P.donate)) break;
-        uint32_t *alloc = P.rot_count + 8 * xcd, *next = alloc + 1;
-        uint32_t i = 0xffffffffu;
-        if (lane == 0) {
-          for (;;) {
-            uint32_t n = __hip_atomic_load(next, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const uint32_t a = __hip_atomic_load(alloc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (n >= (a < P.rot_cap ? a : P.rot_cap)) break;
-            if (__hip_atomic_compare_exchange_strong(next, &n, n + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-              i = n;
-              break;
-            }
-          }
-        }
-        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
-        if (i == 0xffffffffu) break;
-        int32_t pair2;
-        read_entry(P.rot_list + (size_t)xcd * P.rot_cap + i, &pair2, &k, &m0, &m1);
-        pair_context(P, pair2, &Ci);
-        u0 = u1 = 0xffffffffu;  // (no block bounds: every candidate goes on to its sub-block bounds)
-        best = &P.keys[pair2];
-        global = true;
-        have = true;
       }
-      if (have) {
-        uint32_t n_item[3] = {0u, 0u, 0u};
-        rotation_pass<CB>(P, global, Ci, k, u0, u1, m0, m1, lane, best, done, org, n_item, clk);
-        if (global) {
-          if (P.stats && lane == 0 && Ci.pair < BNB_STATS_PAIRS)
-            atomicAdd(&P.stats[BNB_STATS_HEAD + Ci.pair], 4ull * n_item[0] + n_item[2]);
-          n_help[0] += n_item[0];
-          n_help[1] += n_item[1];
-          n_help[2] += n_item[2];
-        } else {
-          n_work[0] += n_item[0];
-          n_work[1] += n_item[1];
-          n_work[2] += n_item[2];
-        }
-      }
+      if (have) rotation_pass<CB>(P, false, C, k, u0, u1, m0, m1, lane, s_best, done, org, n_work, clk);
       if (state == SEED) {
         __syncthreads();
         if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair + 2] = wall_clock64();
@@ -1328,13 +1269,24 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
           for (int32_t j = 0; j < P.n_theta; j++) rank += s_kmax[j] > mine ? 1 : 0;
           s_order[rank] = (uint32_t)kk;
         }
+        // ... and how many candidates the seeds have left: a flat landscape leaves thousands (the median pair: ~30)
+        if (P.rot_list) {
+          const uint32_t bsum = best_sum<false>(s_best);
+          uint32_t mine = 0u;
+          for (int32_t kk = wave; kk < P.n_theta; kk += BNB_WAVES) {
+            const uint32_t c0 = s_U[kk * 128 + lane], c1 = s_U[kk * 128 + 64 + lane];
+            mine += (uint32_t)__builtin_popcountll(__ballot(c0 != 0u && c0 >= bsum)) +
+                    (uint32_t)__builtin_popcountll(__ballot(c1 != 0u && c1 >= bsum && lane + 64 < NB * NB));
+          }
+          if (lane == 0) atomicAdd(s_qn, mine);
+        }
         __syncthreads();
+        heavy = P.rot_list && *s_qn >= P.heavy_min;
         state = OWN;
       }
     }
     if (P.stats && lane == 0) {
-      const long long now = t_own ? t_own : clock64();
-      if (t_own) atomicAdd(&P.stats[13], (unsigned long long)(clock64() - t_own));  // wave time helping
+      const long long now = clock64();
       atomicAdd(&P.stats[4], (unsigned long long)(now - t_busy));       // wave time in phase 3 (until out of work)
       atomicAdd(&P.stats[11], (unsigned long long)(wall_clock64() - t_wall));  // the same in 100 MHz ticks
       atomicAdd(&P.stats[5], (unsigned long long)clk.org);
@@ -1406,14 +1358,10 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     atomicAdd(&s_cnt[0], n_work[0]);
     atomicAdd(&s_cnt[3], n_work[1]);
     atomicAdd(&s_cnt[4], n_work[2]);
-    if (n_help[0]) atomicAdd(&P.stats[0], (unsigned long long)n_help[0]);
-    if (n_help[1]) atomicAdd(&P.stats[2], (unsigned long long)n_help[1]);
-    if (n_help[2]) atomicAdd(&P.stats[3], (unsigned long long)n_help[2]);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    if (BY_ROT && P.donate) atomicMax(&P.keys[pair], *s_best);  // (helpers may have raised it already)
-    else P.keys[pair] = *s_best;
+    P.keys[pair] = *s_best;  // (a pair that handed rotations over: the second kernel raises it from here)
     if (P.timeline && pair < BNB_STATS_PAIRS) {
       uint32_t hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -1571,33 +1519,29 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     const unsigned long long init[2] = {~0ull, 0ull};  // the second kernel's first start and last end
     NHIP_TRY_HIP(hipMemcpyAsync(g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS, init, 16, hipMemcpyHostToDevice, s));
   }
-  // Work sharing.  A flat landscape leaves a pair thousands of candidates (the median pair: ~30): its workgroup would
-  // be busy for milliseconds -- 5 to 7 ms for the worst of 10,000 pairs, a third of the launch spent on a tail with
-  // the chip nearly empty.  A pair with >= heavy_min candidates after bounds and seeds hands its rotations (with
-  // their bounds) to per-XCD lists in the caller's workspace, and
-  //  - large batches: every wave that has finished its own pair takes entries off the list before it exits
-  //    (`donate`; the candidate phase, bound by L1 lookups, keeps overlapping the other workgroups' VALU-bound bounds);
-  //  - batches of <= 64 pairs (the drop-in's GetTransformation is a batch of one): the workgroups do not fill the
-  //    chip, every pair hands over everything, and a second kernel works the lists with every wave of the chip.
-  // NHIP_BNB_KERNELS=1: no hand-over, =2: second kernel for everything; NHIP_BNB_HEAVY_MIN=<candidates>.
+  // Work sharing.  A flat landscape leaves a pair thousands of candidates (the median pair: ~30): alone on the
+  // chip its workgroup is busy for 3 ms (the median pair: 0.2 ms), and a batch that does not fill the chip many
+  // times over waits for it.  Such a pair (>= heavy_min candidates after bounds and seeds) works only its first
+  // keep_ranks rotations in best-first order (one per wave) itself and hands the others, with the masks of their
+  // candidate blocks, to per-XCD lists in the caller's workspace; a second kernel works the lists with every wave of
+  // the chip, sharing the pair's running best through keys[pair].  Measured (tools/bnb_heavy.py, bnb_quick.py): the
+  // heaviest pair alone 3.0 -> 1.2 ms; 30 pairs 0.80 -> 0.60 ms; 500 pairs + the heaviest 3.35 -> 1.5 ms.
+  // From ~1000 pairs on the chip is full anyway and handing over only loses pruning and L2 locality (2,000 pairs
+  // 6.7 -> 7.6 ms, 10,000 pairs 10.4 -> 10.5 ms), so large batches do not.  (Also tried: letting the waves of
+  // finished workgroups take entries inside the first kernel, with and without persistent workgroups -- never a gain.)
+  // NHIP_BNB_KERNELS=1: never, =2: always; NHIP_BNB_HEAVY_MIN=<candidates>, NHIP_BNB_KEEP_RANKS=<n>.
   const char *force = getenv("NHIP_BNB_KERNELS");
   const char *hm = getenv("NHIP_BNB_HEAVY_MIN");
-  const bool second = force ? force[0] == '2' : n_pairs <= 64;
   const char *kr = getenv("NHIP_BNB_KEEP_RANKS");
-  P.heavy_min = hm ? (uint32_t)atoi(hm) : (second ? 1u : 12u);
-  P.keep_ranks = kr ? (uint32_t)atoi(kr) : (second ? 8u : 16u);
-  P.donate = second ? 0u : 1u;
-  if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * (int64_t)sizeof(RotEntry) && !(force && force[0] == '1') &&
-      !P.general_all) {
+  const bool second = force ? force[0] == '2' : n_pairs < 1024;
+  P.heavy_min = hm ? (uint32_t)atoi(hm) : (n_pairs <= 64 ? 1u : 384u);
+  P.keep_ranks = kr ? (uint32_t)atoi(kr) : 8u;
+  if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * (int64_t)sizeof(RotEntry) && second && !P.general_all) {
     P.rot_count = static_cast<uint32_t *>(d_workspace);
     P.rot_list = reinterpret_cast<RotEntry *>(static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER);
     const int64_t cap = (workspace_bytes - BNB_WS_HEADER) / (int64_t)sizeof(RotEntry) / 8;  // entries per XCD list
     P.rot_cap = (uint32_t)(cap < 0x0fffffffll ? cap : 0x0fffffffll);
     NHIP_TRY_HIP(hipMemsetAsync(d_workspace, 0, BNB_WS_HEADER, s));
-    // (an entry is zero until its word is stored: the lists are zeroed once per launch)
-    NHIP_TRY_HIP(hipMemsetAsync(P.rot_list, 0, (size_t)P.rot_cap * 8 * sizeof(RotEntry), s));
-  } else {
-    P.donate = 0u;
   }
   const bool pool_lds = bnb_lds_bytes(L, search, true) <= LDS_MAX;
   const size_t lds = bnb_lds_bytes(L, search, pool_lds);
@@ -1625,7 +1569,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   else NHIP_BNB_LAUNCH(2, false);
 #undef NHIP_BNB_LAUNCH1
 #undef NHIP_BNB_LAUNCH
-  if (P.rot_list && !P.donate && (P.debug == 0 || P.debug >= 3)) {
+  if (P.rot_list && (P.debug == 0 || P.debug >= 3)) {
     const uint32_t rot_blocks = 256 * 4;  // four workgroups of four waves per CU; the waves take entries off the lists
     if (L.cb == 1) hipLaunchKernelGGL(csm_bnb_rot_kernel<1>, dim3(rot_blocks), dim3(256), 0, s, P);
     else hipLaunchKernelGGL(csm_bnb_rot_kernel<2>, dim3(rot_blocks), dim3(256), 0, s, P);

@@ -28,7 +28,7 @@ def med(kernel, counter):
 
 out = {"source": "tools/profile_round.sh: rocprofv3 --pmc passes of `bench.py --steps 3 --warmup 1 --cpu-seconds 0 --no-drop-in`; "
                  "bytes = (FETCH_SIZE*2 + WRITE_SIZE)*1024 per dispatch"}
-names = {"csm_bnb_kernel<1, true>": ("bnb", 8), "csm_bnb_kernel<2, true>": ("bnb", 16),
+names = {"csm_bnb_kernel<1, true, true>": ("bnb", 8), "csm_bnb_kernel<2, true, true>": ("bnb", 16),
          "csm_correlate_kernel<false, false>": ("correlate", 8)}
 for k, (tag, bits) in names.items():
     f, w = med(k, "FETCH_SIZE"), med(k, "WRITE_SIZE")
