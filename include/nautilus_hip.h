@@ -120,10 +120,12 @@ typedef struct nhip_search {
   double theta_step; /* radians */
 } nhip_search_t;
 /* The matcher's result is that of the exhaustive (theta, x, y) search, always.  By default it gets there by
- * branch and bound: upper bounds of every 8 x 8 block of translations from a max-pooled copy of the table, then
- * exact sums only for the blocks whose bound reaches the best sum found (indices, sums and scores are identical to
- * the exhaustive kernel's, bit for bit: tests compare the two).  NHIP_SEARCH_EXHAUSTIVE (or the environment variable
- * NHIP_CSM_EXHAUSTIVE=1) forces the kernel that performs every add (8-bit cells only). */
+ * branch and bound: upper bounds of every 8 x 8 block of translations from a max-pooled copy of the table, bounds
+ * of the 4 x 4 sub-blocks of the blocks that reach the best sum found from a second one, then exact sums only for
+ * the sub-blocks whose bound still reaches it (indices, sums and scores are identical to the exhaustive kernel's,
+ * bit for bit: tests compare the two).  NHIP_SEARCH_EXHAUSTIVE (or the environment variable NHIP_CSM_EXHAUSTIVE=1)
+ * forces the kernel that performs every add (8-bit cells only; also taken for lattices of more than 88 x 88
+ * translations or more than 340 rotations). */
 #define NHIP_SEARCH_EXHAUSTIVE 1
 
 /* One result per candidate pair: 16 bytes, the record that is all-gathered across GPUs. */
@@ -146,7 +148,8 @@ double nhip_score_from_sum(const nhip_grid_spec_t *spec, int64_t sum, int32_t n_
 /* ------------------------------------------------------------------ device-pointer API */
 /* K1: build likelihood grids for n_targets scans (scan ids in d_target_ids) into
  * d_grids (nhip_grids_bytes(spec, n_targets) bytes): slot t = position in d_target_ids, at byte
- * t * slot_bytes, holds the stored image (grid_bytes) followed by its skip map (skip_bytes).
+ * t * slot_bytes, holds the stored image (grid_bytes) followed by its skip map (skip_bytes) and the two
+ * max-pooled tables (pool_bytes, pool4_bytes).
  * d_xy: float2 points of all scans, d_offsets: n_scans+1 prefix offsets (in points). */
 int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
                         int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
@@ -159,9 +162,10 @@ int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32
  * the fine level of a coarse-to-fine search); |origin| + half-width must be <= max_shift.
  * d_keys: n_pairs uint64 scratch; d_out: n_pairs records; d_sums: n_pairs int32 or NULL.
  * d_workspace: NULL, or nhip_csm_workspace_bytes(n_pairs) bytes of scratch for the branch-and-bound matcher's
- * grid-wide candidate lists: with it, small batches (<= 2048 pairs) have the exact evaluations of all pairs spread
- * over the whole chip by a second kernel instead of each pair's workgroup evaluating its own -- same records
- * either way. */
+ * hand-over lists: with it, in batches of < 1024 pairs a pair whose landscape is flat (hundreds of candidate blocks
+ * after bounds and seeds; in batches of <= 64 pairs, e.g. a single GetTransformation call, every pair) hands all but
+ * its first 8 rotations to a second kernel that works them with every wave of the chip instead of keeping its one
+ * workgroup busy for milliseconds -- same records either way. */
 int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                        const nhip_grid_spec_t *spec, const int32_t *d_pair_src,
                        const int32_t *d_pair_slot, const double *d_rot0_cs,
