@@ -74,6 +74,7 @@ struct BnbParams {
   int32_t S, pad, pitch, rows, max_shift;
   int32_t pool_pitch, pool_rows, pairs_per_xcd;
   int32_t pool4_pitch;
+  int32_t lds_first;    // bytes of the kernel's first LDS region: max(pooled table if staged, origins)
   int32_t whole_min;    // sub-blocks alive from which an 8-bit block is evaluated whole (3; NHIP_BNB_WHOLE_MIN)
   int32_t general_all;  // the general instantiation takes every pair (NHIP_BNB_QUEUE=1)
   int32_t levels;  // 2: candidates are refined through the 4 x 4 sub-block bounds; 1: evaluated whole (NHIP_BNB_LEVELS)
@@ -623,19 +624,27 @@ __device__ __forceinline__ unsigned long long eval_sub(const BnbParams &P, __amd
   return key;
 }
 
-// ==== the same three passes with the window origins of one rotation held in registers ======================
+// ==== the same three passes with the window origins of one rotation kept by the wave ========================
 // All candidates of rotation k share the 1081 window origins; computing them (a point load, two double-precision
 // floor quotients) per candidate made every pass a chain of dependent latencies.  A wave that owns rotation k keeps
-// them packed (row << 16 | column; both < 65536) in OC registers -- scans of up to 64 * OC points -- and a pass
-// becomes: all loads of nine chunks issued back to back, then the adds.  Lanes without a point hold origin (0, 0):
-// every patch of theirs lies in the zero border (8 * NB + 7 < pad) and pooled entries there are zero.
-constexpr int OC = 18;
+// them packed (row << 16 | column; both < 65536) in LDS -- OCL chunks of 64, scans of up to 64 * OCL points, in the
+// space of the pooled table, which the workgroup no longer needs once its bounds are done -- and a pass becomes:
+// all loads of six to nine chunks issued back to back, then the adds.  (Held in 18 registers they were spilled:
+// the register allocator kept the array in scratch memory and the kernel wrote 7 GB of it per launch.)  Lanes
+// without a point hold origin (0, 0): every patch of theirs lies in the zero border (8 * NB + 7 < pad) and pooled
+// entries there are zero.
+constexpr int OC = 18;                      // chunks the passes are unrolled for
+constexpr int OCL = 17;                     // chunks held: 1088 points (a 1081-beam scan)
+constexpr int ORG_WAVE = OCL * 64;          // words of LDS per wave
+constexpr int ORG_LDS = BNB_WAVES * ORG_WAVE * 4;  // bytes per workgroup (34,816: the 1200 x 1200 grid's pooled table is 35,712)
+
+// (origin of chunk c for this lane; `org` points at the lane's word of chunk 0)
+__device__ __forceinline__ uint32_t origin_of(const uint32_t *org, int c) { return c < OCL ? org[64 * c] : 0u; }
 
 __device__ __forceinline__ void cache_origins(const BnbParams &P, const float2 *pts, int32_t n_pts, float cf, float sf,
-                                              int32_t cx, int32_t cy, int lane, uint32_t (&org)[OC]) {
-  // (rolled: the origin arithmetic holds a division on its rare path; the arrays rotate so that indices stay static --
-  //  indexing org[] with the loop counter puts it into indexed scratch memory: measured 2x slower for the whole kernel.
-  //  The points of the next D chunks are in flight while one chunk's origins are computed.)
+                                              int32_t cx, int32_t cy, int lane, uint32_t *org) {
+  // (rolled: the origin arithmetic holds a division on its rare path.  The points of the next D chunks are in flight
+  //  while one chunk's origins are computed; that array rotates so that its indices stay static.)
   constexpr int D = 6;
   float px[D], py[D];
 #pragma unroll
@@ -645,7 +654,7 @@ __device__ __forceinline__ void cache_origins(const BnbParams &P, const float2 *
     py[d] = q.y;
   }
 #pragma unroll 1
-  for (int c = 0; c < OC; c++) {
+  for (int c = 0; c < OCL; c++) {
     const int32_t idx = 64 * c + lane;
     const float2 pt = make_float2(px[0], py[0]);
     const float2 qn = idx + 64 * D < n_pts ? pts[idx + 64 * D] : make_float2(0.f, 0.f);
@@ -662,15 +671,16 @@ __device__ __forceinline__ void cache_origins(const BnbParams &P, const float2 *
       window_origin(pt, cf, sf, P, cx, cy, &prow, &pcol);
       o = ((uint32_t)prow << 16) | (uint32_t)pcol;
     }
-#pragma unroll
-    for (int i = 0; i < OC - 1; i++) org[i] = org[i + 1];
-    org[OC - 1] = o;
+    org[64 * c] = o;
   }
+  // (the wave reads only its own words back: LDS operations of one wave are performed in order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
 }
 
 // Sub-block bounds of a strip of up to three blocks (Y, X0), (Y, X0 + 1), (Y, X0 + 2): their twelve table bytes are
 // consecutive, ONE 16-byte load per point.  out[4 t + q]: block X0 + t, sub-block q = 2 sy + sx.
-__device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buffer_rsrc_t p4, const uint32_t (&org)[OC],
+__device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buffer_rsrc_t p4, const uint32_t *org,
                                                int32_t nch, int32_t Y, int32_t X0, uint32_t scale, uint32_t (&out)[12]) {
   const uint32_t DP = (uint32_t)P.pool4_pitch;
   const uint32_t off = (uint32_t)(2 * Y) * DP + (uint32_t)(4 * X0);
@@ -683,7 +693,7 @@ __device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buff
     uint32_t sh[H];
 #pragma unroll
     for (int j = 0; j < H; j++) {
-      const uint32_t o = org[H * h + j];
+      const uint32_t o = origin_of(org, H * h + j);
       // (lanes without a point: origin (0, 0), whose entries lie in the zero border)
       const uint32_t a = (o >> 18) * DP + 2u * ((o >> 2) & 0x3fffu) + off;
       sh[j] = (a & 2u) * 8u;
@@ -726,7 +736,7 @@ __device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buff
 
 template <int CB>
 __device__ __forceinline__ unsigned long long eval_sub_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
-                                                         const uint32_t (&org)[OC], int32_t nch, int32_t k, int32_t Y,
+                                                         const uint32_t *org, int32_t nch, int32_t k, int32_t Y,
                                                          int32_t X, int32_t sy, int32_t sx, int lane) {
   uint32_t total;
   int dy, dx;
@@ -744,7 +754,7 @@ __device__ __forceinline__ unsigned long long eval_sub_c(const BnbParams &P, __a
       uint32_t sh[U];
 #pragma unroll
       for (int j = 0; j < U; j++) {
-        const uint32_t o = org[U * r + j];
+        const uint32_t o = origin_of(org, U * r + j);
         const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
         sh[j] = (g & 3u) * 8u;
 #pragma unroll
@@ -786,7 +796,7 @@ __device__ __forceinline__ unsigned long long eval_sub_c(const BnbParams &P, __a
       uint32_t sh[U];
 #pragma unroll
       for (int j = 0; j < U; j++) {
-        const uint32_t o = org[U * r + j];
+        const uint32_t o = origin_of(org, U * r + j);
         const uint32_t g = (o >> 16) * pitch + 2u * (o & 0xffffu) + off;
         sh[j] = (g & 2u) * 8u;
 #pragma unroll
@@ -830,7 +840,7 @@ __device__ __forceinline__ unsigned long long eval_sub_c(const BnbParams &P, __a
 
 // whole 8 x 8 block, 8-bit cells (16-bit cells take their four sub-blocks: the same number of loads)
 __device__ __forceinline__ unsigned long long eval_block_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
-                                                           const uint32_t (&org)[OC], int32_t nch, int32_t k, int32_t Y,
+                                                           const uint32_t *org, int32_t nch, int32_t k, int32_t Y,
                                                            int32_t X, int lane) {
   const uint32_t pitch = (uint32_t)P.pitch;
   const uint32_t off = (uint32_t)(BNB_B * Y) * pitch + (uint32_t)(BNB_B * X);
@@ -845,7 +855,7 @@ __device__ __forceinline__ unsigned long long eval_block_c(const BnbParams &P, _
     uint32_t sh[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
-      const uint32_t o = org[U * r + j];
+      const uint32_t o = origin_of(org, U * r + j);
       const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
       sh[j] = (g & 3u) * 8u;
 #pragma unroll
@@ -966,7 +976,7 @@ __device__ __forceinline__ void process_candidate(const BnbParams &P, const Pair
 // ... with the rotation's origins in registers (LDS-resident best) and the block's four sub-block bounds at hand
 template <int CB>
 __device__ __forceinline__ void process_candidate_c(const BnbParams &P, bool global, __amdgpu_buffer_rsrc_t rsrc,
-                                                    const uint32_t (&org)[OC], int32_t nch, int32_t k, int32_t Y, int32_t X,
+                                                    const uint32_t *org, int32_t nch, int32_t k, int32_t Y, int32_t X,
                                                     uint32_t sb0, uint32_t sb1, uint32_t sb2, uint32_t sb3, int lane,
                                                     unsigned long long *best, uint32_t (&n)[3]) {
   const uint32_t bsum = best_sum_rt(best, global);
@@ -999,7 +1009,7 @@ struct PhaseClocks {
 template <int CB>
 __device__ __forceinline__ void rotation_pass(const BnbParams &P, bool global, const PairCtx &C, int32_t k, uint32_t u0, uint32_t u1,
                                               unsigned long long m0, unsigned long long m1, int lane,
-                                              unsigned long long *best, uint32_t *done, uint32_t (&org)[OC],
+                                              unsigned long long *best, uint32_t *done, uint32_t *org,
                                               uint32_t (&n_work)[3], PhaseClocks &clk) {
   const int32_t nch = (C.n_pts + 63) >> 6;
   long long t_mark = 0;
@@ -1076,8 +1086,10 @@ __device__ __forceinline__ void pair_context(const BnbParams &P, int32_t pair, P
 template <int CB, bool POOL_LDS, bool BY_ROT>
 __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   extern __shared__ __align__(16) uint8_t smem[];
-  uint8_t *s_pool = smem;                                                       // pool_bytes (POOL_LDS)
-  uint32_t *s_U = reinterpret_cast<uint32_t *>(smem + (POOL_LDS ? P.pool_bytes : 0));  // n_theta * 128
+  // first region: the pooled table (POOL_LDS) while the bounds are computed, then the waves' window origins
+  uint8_t *s_pool = smem;
+  uint32_t *s_org = reinterpret_cast<uint32_t *>(smem);
+  uint32_t *s_U = reinterpret_cast<uint32_t *>(smem + P.lds_first);  // n_theta * 128
   unsigned long long *s_queue = reinterpret_cast<unsigned long long *>(s_U + (size_t)P.n_theta * 128);  // QCAP
   unsigned long long *s_best = s_queue + QCAP;
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_best + 1);
@@ -1104,7 +1116,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   const int32_t cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
   const int32_t cy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
   const bool centre_ok = (abs(cx) + P.hx <= P.max_shift) && (abs(cy) + P.hy <= P.max_shift);
-  if (BY_ROT != (n_pts <= 64 * OC && !P.general_all)) return;  // the other instantiation's pair
+  if (BY_ROT != (n_pts <= 64 * OCL && !P.general_all)) return;  // the other instantiation's pair
 
   // pose 0 with sum 0 is a lower bound of the optimum (sums are >= 0; if all are 0, pose 0 is the answer)
   const unsigned long long key0 = 0xffffffffull;
@@ -1178,9 +1190,9 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   // Scans of up to 64 * OC points: a wave owns a rotation at a time and keeps its window origins in registers.
   // Longer scans (and the two-kernel form) take the general path below.
   if (BY_ROT) {
-    uint32_t org[OC];
-#pragma unroll
-    for (int c = 0; c < OC; c++) org[c] = 0u;
+    // (the pooled table's space becomes the origins' once every wave is done with its bounds)
+    __syncthreads();
+    uint32_t *org = s_org + wave * ORG_WAVE + lane;
     // (NHIP_BNB_STATS=1: shader-clock sums -- wave time in phase 3 by part, and the workgroup's wall time)
     PhaseClocks clk = {0, 0, 0};
     long long t_busy = 0, t_wall = 0;
@@ -1393,9 +1405,8 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
   const uint32_t count = filled < P.rot_cap ? filled : P.rot_cap;
   const RotEntry *list = P.rot_list + (size_t)xcd * P.rot_cap;
   uint32_t n_work[3] = {0u, 0u, 0u};
-  uint32_t org[OC];
-#pragma unroll
-  for (int c = 0; c < OC; c++) org[c] = 0u;
+  __shared__ uint32_t s_org2[4 * ORG_WAVE];
+  uint32_t *org = s_org2 + (threadIdx.x >> 6) * ORG_WAVE + lane;
   PhaseClocks clk = {0, 0, 0};
   const long long t0 = P.stats ? clock64() : 0;
   for (;;) {
@@ -1428,8 +1439,12 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
   }
 }
 
+size_t bnb_lds_first(const GridLayout &L, bool pool_lds) {
+  const size_t pool = pool_lds ? (size_t)L.pool_bytes : 0;
+  return pool > (size_t)ORG_LDS ? pool : (size_t)ORG_LDS;
+}
 size_t bnb_lds_bytes(const GridLayout &L, const nhip_search_t *search, bool pool_lds) {
-  return (pool_lds ? (size_t)L.pool_bytes : 0) + (size_t)search->n_theta * 128 * 4 + (size_t)QCAP * 8 + 64;
+  return bnb_lds_first(L, pool_lds) + (size_t)search->n_theta * 128 * 4 + (size_t)QCAP * 8 + 64;
 }
 constexpr size_t LDS_MAX = 160 * 1024;
 
@@ -1545,6 +1560,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   }
   const bool pool_lds = bnb_lds_bytes(L, search, true) <= LDS_MAX;
   const size_t lds = bnb_lds_bytes(L, search, pool_lds);
+  P.lds_first = (int32_t)bnb_lds_first(L, pool_lds);
   const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
   timer_begin(NHIP_TIMER_CSM, s);
 #define NHIP_BNB_LAUNCH1(CB, PL, BR)                                                                             \
