@@ -125,7 +125,7 @@ typedef struct nhip_search {
  * the sub-blocks whose bound still reaches it (indices, sums and scores are identical to the exhaustive kernel's,
  * bit for bit: tests compare the two).  NHIP_SEARCH_EXHAUSTIVE (or the environment variable NHIP_CSM_EXHAUSTIVE=1)
  * forces the kernel that performs every add (8-bit cells only; also taken for lattices of more than 88 x 88
- * translations or more than 340 rotations). */
+ * translations, or more rotations than fit the LDS beside the bounds: ~230). */
 #define NHIP_SEARCH_EXHAUSTIVE 1
 
 /* One result per candidate pair: 16 bytes, the record that is all-gathered across GPUs. */

@@ -79,7 +79,8 @@ struct BnbParams {
   int32_t general_all;  // the general instantiation takes every pair (NHIP_BNB_QUEUE=1)
   int32_t levels;  // 2: candidates are refined through the 4 x 4 sub-block bounds; 1: evaluated whole (NHIP_BNB_LEVELS)
   int32_t debug;   // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only,
-                   // 4 = phase 3 without exact sums, 5 = phase 3 without sub-block bounds and exact sums
+                   // 4 = phase 3 without exact sums, 5 = phase 3 without sub-block bounds and exact sums,
+                   // 26 / 27 = bounds only, without their reductions / gathers
   int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes, pool4_bytes;
   double res, inv_res;
 };
@@ -277,10 +278,10 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
     while (tail - head >= 64u || (!more && (tail != head || passes != 0))) {
       const uint32_t avail = tail - head;
       // (lanes past the list gather the zero rows with length 0)
-      gather((uint32_t)lane < avail ? list[(head + (uint32_t)lane) & (LIST_ENTRIES - 1)] : zero_a);
+      if (P.debug != 27) gather((uint32_t)lane < avail ? list[(head + (uint32_t)lane) & (LIST_ENTRIES - 1)] : zero_a);
       head += avail < 64u ? avail : 64u;
       passes++;
-      if (passes == SEG_PASSES || (!more && tail == head)) {
+      if ((passes == SEG_PASSES || (!more && tail == head)) && P.debug != 26) {
         reduce();
         passes = 0;
       }
@@ -685,9 +686,12 @@ __device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buff
   const uint32_t DP = (uint32_t)P.pool4_pitch;
   const uint32_t off = (uint32_t)(2 * Y) * DP + (uint32_t)(4 * X0);
   uint32_t E[3] = {0u, 0u, 0u}, O[3] = {0u, 0u, 0u};  // 16-bit fields: 18 chunks * 255 * 8 lanes < 65536
-  constexpr int H = OC / 2;
+#ifndef NHIP_BNB_STRIP_ROUNDS
+#define NHIP_BNB_STRIP_ROUNDS 2
+#endif
+  constexpr int H = OC / NHIP_BNB_STRIP_ROUNDS;  // chunks whose loads are in flight together
 #pragma unroll
-  for (int h = 0; h < 2; h++) {
+  for (int h = 0; h < NHIP_BNB_STRIP_ROUNDS; h++) {
     if (H * h >= nch) continue;
     u32x4 w[H];
     uint32_t sh[H];
@@ -742,7 +746,13 @@ __device__ __forceinline__ unsigned long long eval_sub_c(const BnbParams &P, __a
   int dy, dx;
   const uint32_t pitch = (uint32_t)P.pitch;
   const uint32_t off = (uint32_t)(BNB_B * Y + BNB_B4 * sy) * pitch + (uint32_t)(BNB_B * X + BNB_B4 * sx) * (uint32_t)CB;
-  constexpr int U = CB == 1 ? 6 : 3;  // chunks per round: 24 (12) row loads in flight
+#ifndef NHIP_BNB_SUB_U8
+#define NHIP_BNB_SUB_U8 6
+#endif
+#ifndef NHIP_BNB_SUB_U16
+#define NHIP_BNB_SUB_U16 3
+#endif
+  constexpr int U = CB == 1 ? NHIP_BNB_SUB_U8 : NHIP_BNB_SUB_U16;  // chunks per round: 4 U row loads in flight
   static_assert(OC % U == 0, "whole rounds");
   if (CB == 1) {
     // (18 chunks * 255 * 8 lanes < 65536: the packed fields hold a whole scan)
@@ -844,7 +854,10 @@ __device__ __forceinline__ unsigned long long eval_block_c(const BnbParams &P, _
                                                            int32_t X, int lane) {
   const uint32_t pitch = (uint32_t)P.pitch;
   const uint32_t off = (uint32_t)(BNB_B * Y) * pitch + (uint32_t)(BNB_B * X);
-  constexpr int U = 2;
+#ifndef NHIP_BNB_BLOCK_U
+#define NHIP_BNB_BLOCK_U 2
+#endif
+  constexpr int U = NHIP_BNB_BLOCK_U;
   uint32_t E[8][2], O[8][2];
 #pragma unroll
   for (int y = 0; y < 8; y++) E[y][0] = E[y][1] = O[y][0] = O[y][1] = 0u;
@@ -1233,7 +1246,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         }
       } else if (state == OWN) {
         int32_t rank = P.n_theta;
-        if (P.debug == 0 || P.debug >= 3) {
+        if (P.debug == 0 || (P.debug >= 3 && P.debug < 26)) {
           if (lane == 0) rank = (int32_t)atomicAdd(s_qhead, 1u);
           rank = __builtin_amdgcn_readfirstlane(rank);
         }
@@ -1585,7 +1598,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   else NHIP_BNB_LAUNCH(2, false);
 #undef NHIP_BNB_LAUNCH1
 #undef NHIP_BNB_LAUNCH
-  if (P.rot_list && (P.debug == 0 || P.debug >= 3)) {
+  if (P.rot_list && (P.debug == 0 || (P.debug >= 3 && P.debug < 26))) {
     const uint32_t rot_blocks = 256 * 4;  // four workgroups of four waves per CU; the waves take entries off the lists
     if (L.cb == 1) hipLaunchKernelGGL(csm_bnb_rot_kernel<1>, dim3(rot_blocks), dim3(256), 0, s, P);
     else hipLaunchKernelGGL(csm_bnb_rot_kernel<2>, dim3(rot_blocks), dim3(256), 0, s, P);

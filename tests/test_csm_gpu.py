@@ -28,7 +28,7 @@ def _check_pairs(scans_list, target_ids, pair_src, pair_slot, theta0, spec, ospe
     # every form of the matcher returns the same records: in batches of < 1024 pairs a pair with many candidates hands
     # rotations to a second kernel (<= 64 pairs: every pair does); NHIP_BNB_KERNELS=1 keeps everything in the pair's
     # workgroup, =2 hands over in any batch; the single kernel works rotation by rotation with register-held origins
-    # for scans of <= 1152 points and through the workgroup queue otherwise (NHIP_BNB_QUEUE=1: always);
+    # for scans of <= 1088 points and through the workgroup queue otherwise (NHIP_BNB_QUEUE=1: always);
     # NHIP_BNB_LEVELS=1 leaves out the sub-block bounds
     import os
     for env in ({"NHIP_BNB_KERNELS": "1"}, {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_LEVELS": "1"},

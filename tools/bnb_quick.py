@@ -7,7 +7,7 @@ import torch
 import bench
 from nautilus_amd import _lib, sharding
 if os.environ.get("NHIP_LIB_ALT"):  # (A/B experiments: a second build of the library)
-    _lib.LIB_PATH = os.path.join(ROOT, "nautilus_amd", "lib", "alt", "libnautilus_hip.so")
+    _lib.LIB_PATH = os.path.join(ROOT, "nautilus_amd", "lib", "alt_" + os.environ["NHIP_LIB_ALT"], "libnautilus_hip.so")
 lib = _lib.load()
 wl = bench.Workload("weak", 1, int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 10)
 plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
