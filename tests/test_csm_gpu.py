@@ -188,6 +188,21 @@ def test_long_clouds_cross_staging_batches(gpu, small_bag):
     assert want["sum"].max() > 255 * 1152  # sums beyond what a single unpack interval could hold
 
 
+def test_scan_lengths_around_the_held_origins(gpu, small_bag):
+    """The matcher keeps a rotation's window origins for scans of up to 17 * 64 = 1088 points (by-rotation kernel);
+    longer scans take the general kernel.  Lengths on both sides of that limit, of a 64-point chunk and of the
+    16-lane runs of the compressed bounds phase, 8- and 16-bit cells, in ONE batch (both kernels run)."""
+    pool = np.concatenate([small_bag.scans[i] for i in (3, 4, 5, 6)])
+    lengths = [1, 15, 16, 17, 63, 64, 65, 1023, 1024, 1025, 1087, 1088, 1089, 1151, 1152, 1153]
+    scans = [np.ascontiguousarray(pool[7 * i:7 * i + n]) for i, n in enumerate(lengths)] + [small_bag.scans[8]]
+    tgt = len(scans) - 1
+    src = list(range(len(lengths)))
+    th0 = [0.01 * (i - 8) for i in src]
+    for bits in (8, 16):
+        spec, ospec = _specs(max_shift=12, cell_bits=bits)
+        _check_pairs(scans, [tgt], src, [0] * len(src), th0, spec, ospec, csm.search_spec(5, 25, 25, DEG))
+
+
 def test_swar_fields_do_not_overflow_in_one_alignment_class(gpu):
     """Worst case for the 16-bit SWAR fields: thousands of source points whose windows all start in the
     same alignment class (x = multiples of 4 cells) and sit on cells of the maximum value 255 (the
