@@ -91,16 +91,19 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
                                               int32_t *prow, int32_t *pcol) {
   const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
   const float yr = __fadd_rn(__fmul_rn(sf, q.x), __fmul_rn(cf, q.y));
-  long col = -P.hx - 1, row = -P.hy - 1;  // non-finite points score nothing
+  int32_t col = -P.hx - 1, row = -P.hy - 1;  // non-finite points score nothing
   if ((fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f)) {
-    const long half = P.S / 2;
-    col = half + (long)floor_quotient((double)xr, P.res, P.inv_res) + cx;
-    row = half + (long)floor_quotient((double)yr, P.res, P.inv_res) + cy;
-    col = col < -P.hx - 1 ? -P.hx - 1 : (col > P.S + P.hx ? P.S + P.hx : col);
-    row = row < -P.hy - 1 ? -P.hy - 1 : (row > P.S + P.hy ? P.S + P.hy : row);
+    // col = clamp(S / 2 + floor(xr / res) + cx, -hx - 1, S + hx), as window_cell of nhip_csm.hip -- with the clamp
+    // applied to the (integer-valued) double before the conversion, so that the rest is 32-bit arithmetic
+    const int32_t half = P.S / 2;
+    double fx = floor_quotient((double)xr, P.res, P.inv_res), fy = floor_quotient((double)yr, P.res, P.inv_res);
+    fx = fmin(fmax(fx, (double)(-P.hx - 1 - half - cx)), (double)(P.S + P.hx - half - cx));
+    fy = fmin(fmax(fy, (double)(-P.hy - 1 - half - cy)), (double)(P.S + P.hy - half - cy));
+    col = half + (int32_t)fx + cx;
+    row = half + (int32_t)fy + cy;
   }
-  *pcol = (int32_t)(col - P.hx + P.pad);
-  *prow = (int32_t)(row - P.hy + P.pad);
+  *pcol = col - P.hx + P.pad;
+  *prow = row - P.hy + P.pad;
 }
 
 // Rows of the stored grid are read through a buffer descriptor of the pair's grid slot: 12 bytes at a 4-byte-aligned
