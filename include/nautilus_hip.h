@@ -79,7 +79,8 @@ typedef struct nhip_grid_layout {
                           r and aligned dword column c (bit c&7 of byte c>>3, 8*ceil(pitch/256) bytes per
                           row) = "stored rows [r, r+21) x dwords [c, c+21*cell_bytes) hold a non-zero cell",
                           so the correlation kernel can leave out window strips that only add zeros (same
-                          sums, bit for bit) */
+                          sums, bit for bit).  Built for 8-bit cells only (the kernel that reads it takes no
+                          others); the space stays zero for 16-bit cells */
   int64_t slot_bytes;  /* grid_bytes + skip_bytes + pool_bytes + pool4_bytes: grid t of a buffer starts at byte
                           t*slot_bytes */
   int64_t pool_bytes;  /* bytes of the max-pooled table stored after the skip map (branch-and-bound bounds):

@@ -437,16 +437,13 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16);
-    // gridDim.z is limited to 65,535: the targets of a chunk go in slices
-    for (int32_t z0 = 0; z0 < n; z0 += 65535) {
+    // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernel that
+    // performs every add, which takes 8-bit cells only: 16-bit grids leave theirs zero.)
+    for (int32_t z0 = 0; z0 < n && L.cb == 1; z0 += 65535) {
       const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
       const dim3 mg((mpitch + MT - 1) / MT, (rows + MT - 1) / MT, nz);
-      if (L.cb == 1)
-        hipLaunchKernelGGL(grid_skipmap_kernel<1>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
-                           L.grid_bytes, L.slot_bytes, z0);
-      else
-        hipLaunchKernelGGL(grid_skipmap_kernel<2>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
-                           L.grid_bytes, L.slot_bytes, z0);
+      hipLaunchKernelGGL(grid_skipmap_kernel<1>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
+                         L.grid_bytes, L.slot_bytes, z0);
     }
     if (L.cb == 1) {
       launch_pool<1, BNB_B>(occ, g, L, tiles, n, s);
