@@ -949,10 +949,12 @@ __device__ __forceinline__ uint32_t best_sum(unsigned long long *best) {
   else b = *(volatile unsigned long long *)best;
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));  // one value for the whole wave
 }
-// the same with the place decided at run time (one copy of the candidate code serves the pair's own workgroup, whose
-// best lives in LDS, and the takers of handed-over rotations, who share it through keys[pair])
-__device__ __forceinline__ uint32_t best_sum_rt(unsigned long long *best, bool global) {
-  return global ? best_sum<true>(best) : best_sum<false>(best);
+// One copy of the candidate code serves the pair's own workgroup, whose best lives in LDS, and the takers of
+// handed-over rotations, who share it through keys[pair]: between two looks at a best that lives in global memory
+// (a device-scope atomic load: microseconds under load) the taker works with its copy, raised by its own finds; a
+// stale copy only costs pruning, never the result.
+__device__ __forceinline__ uint32_t best_sum_cached(unsigned long long *best, bool global, uint32_t copy) {
+  return global ? copy : best_sum<false>(best);
 }
 
 template <int CB>
@@ -994,23 +996,25 @@ template <int CB>
 __device__ __forceinline__ void process_candidate_c(const BnbParams &P, bool global, __amdgpu_buffer_rsrc_t rsrc,
                                                     const uint32_t *org, int32_t nch, int32_t k, int32_t Y, int32_t X,
                                                     uint32_t sb0, uint32_t sb1, uint32_t sb2, uint32_t sb3, int lane,
-                                                    unsigned long long *best, uint32_t (&n)[3]) {
-  const uint32_t bsum = best_sum_rt(best, global);
+                                                    unsigned long long *best, uint32_t &bcopy, uint32_t (&n)[3]) {
+  const uint32_t bsum = best_sum_cached(best, global, bcopy);
   const int alive = (sb0 != 0u && sb0 >= bsum) + (sb1 != 0u && sb1 >= bsum) + (sb2 != 0u && sb2 >= bsum) +
                     (sb3 != 0u && sb3 >= bsum);
   if (alive == 0) return;
   if (CB == 1 && alive >= P.whole_min) {
     const unsigned long long key = eval_block_c(P, rsrc, org, nch, k, Y, X, lane);
     if (lane == 0) atomicMax(best, key);  // (generic address: LDS or global)
+    bcopy = max(bcopy, (uint32_t)(key >> 32));
     n[0]++;
     return;
   }
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     const uint32_t b = q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3));
-    if (b == 0u || b < best_sum_rt(best, global)) continue;
+    if (b == 0u || b < best_sum_cached(best, global, bcopy)) continue;
     const unsigned long long key = eval_sub_c<CB>(P, rsrc, org, nch, k, Y, X, q >> 1, q & 1, lane);
     if (lane == 0) atomicMax(best, key);
+    bcopy = max(bcopy, (uint32_t)(key >> 32));
     n[2]++;
   }
 }
@@ -1047,6 +1051,7 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, bool global, c
       len++;
     }
     uint32_t sb[12];
+    uint32_t bcopy = global ? best_sum<true>(best) : 0u;  // (one look per strip at a best in global memory)
     if (P.debug == 5) break;  // (timing: origins only)
     if (P.levels >= 2) {
       if (P.stats) t_mark = clock64();
@@ -1063,12 +1068,12 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, bool global, c
       if (b < 64) m0 &= ~(1ull << b);
       else m1 &= ~(1ull << (b - 64));
       const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)(b < 64 ? u0 : u1), b & 63);
-      if (ub < best_sum_rt(best, global) || (P.debug == 4 && !done)) continue;  // the best has risen meanwhile
+      if (ub < best_sum_cached(best, global, bcopy) || (P.debug == 4 && !done)) continue;  // the best has risen meanwhile
       // (selects, not an indexed array: that would live in scratch)
       const uint32_t s0 = t == 0 ? sb[0] : (t == 1 ? sb[4] : sb[8]), s1 = t == 0 ? sb[1] : (t == 1 ? sb[5] : sb[9]);
       const uint32_t s2 = t == 0 ? sb[2] : (t == 1 ? sb[6] : sb[10]), s3 = t == 0 ? sb[3] : (t == 1 ? sb[7] : sb[11]);
       if (P.stats) t_mark = clock64();
-      process_candidate_c<CB>(P, global, rsrc, org, nch, k, Y, X0 + t, s0, s1, s2, s3, lane, best, n_work);
+      process_candidate_c<CB>(P, global, rsrc, org, nch, k, Y, X0 + t, s0, s1, s2, s3, lane, best, bcopy, n_work);
       if (P.stats) clk.eval += clock64() - t_mark;
       if (done && lane == 0) done[b] = 0u;
     }
