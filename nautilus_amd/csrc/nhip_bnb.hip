@@ -135,17 +135,25 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64b(unsigned long long v
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// One step of a transposing reduction over the lanes: lanes pair up across `mask`; of every two registers the
+// One step of a transposing reduction over the lanes: lanes pair up across MASK; of every two registers the
 // lane keeps the one its own bit selects, adds the partner's copy of the same register, and gives the other away.
-// N registers in, N / 2 out.
-template <int N, int CAP>
-__device__ __forceinline__ void rs_step(uint32_t (&R)[CAP], bool bit, int mask) {
+// N registers in, N / 2 out.  Partners inside a quad (MASK 1, 2) are reached with a DPP quad permutation -- no LDS
+// round trip; the others with ds_bpermute.
+template <int MASK>
+__device__ __forceinline__ uint32_t shfl_xor_c(uint32_t v) {
+  if (MASK == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
+  if (MASK == 2) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0x4E, 0xF, 0xF, true);  // quad_perm [2, 3, 0, 1]
+  return shfl_xor_u32(v, MASK);
+}
+
+template <int N, int MASK, int CAP>
+__device__ __forceinline__ void rs_step(uint32_t (&R)[CAP], bool bit) {
   static_assert(N <= CAP, "rs_step: more registers than the array holds");
 #pragma unroll
   for (int i = 0; i < N / 2; i++) {
     const uint32_t keep = bit ? R[2 * i + 1] : R[2 * i];
     const uint32_t send = bit ? R[2 * i] : R[2 * i + 1];
-    R[i] = keep + shfl_xor_u32(send, mask);
+    R[i] = keep + shfl_xor_c<MASK>(send);
   }
 }
 
@@ -227,18 +235,18 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
     R[61] = E[10][1];
     R[62] = E[10][2];
     R[63] = O[10][0];
-    rs_step<64>(R, lane & 1, 1);
-    rs_step<32>(R, lane & 2, 2);
+    rs_step<64, 1>(R, lane & 1);
+    rs_step<32, 2>(R, lane & 2);
     uint32_t V[32];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
       V[2 * i] = R[i] & 0xffffu;
       V[2 * i + 1] = R[i] >> 16;
     }
-    rs_step<32>(V, lane & 4, 4);
-    rs_step<16>(V, lane & 8, 8);
-    rs_step<8>(V, lane & 16, 16);
-    rs_step<4>(V, lane & 32, 32);
+    rs_step<32, 4>(V, lane & 4);
+    rs_step<16, 8>(V, lane & 8);
+    rs_step<8, 16>(V, lane & 16);
+    rs_step<4, 32>(V, lane & 32);
     tot[0] += V[0];
     tot[1] += V[1];
 #pragma unroll
@@ -398,18 +406,18 @@ __device__ __forceinline__ unsigned long long eval_block(const BnbParams &P, con
         R[4 * y + 2] = E[y][1];
         R[4 * y + 3] = O[y][1] - ((E[y][1] >> 16) << 8);
       }
-      rs_step<32>(R, lane & 1, 1);
-      rs_step<16>(R, lane & 2, 2);
-      rs_step<8>(R, lane & 4, 4);
+      rs_step<32, 1>(R, lane & 1);
+      rs_step<16, 2>(R, lane & 2);
+      rs_step<8, 4>(R, lane & 4);
       uint32_t V[8];
 #pragma unroll
       for (int i = 0; i < 4; i++) {
         V[2 * i] = R[i] & 0xffffu;
         V[2 * i + 1] = R[i] >> 16;
       }
-      rs_step<8>(V, lane & 8, 8);
-      rs_step<4>(V, lane & 16, 16);
-      rs_step<2>(V, lane & 32, 32);
+      rs_step<8, 8>(V, lane & 8);
+      rs_step<4, 16>(V, lane & 16);
+      rs_step<2, 32>(V, lane & 32);
       total += V[0];
     }
     const int r = 8 * (2 * ((lane >> 5) & 1) + ((lane >> 4) & 1)) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 1) & 1) + (lane & 1);
@@ -445,12 +453,12 @@ __device__ __forceinline__ unsigned long long eval_block(const BnbParams &P, con
         }
       }
     }
-    rs_step<64>(A, lane & 1, 1);
-    rs_step<32>(A, lane & 2, 2);
-    rs_step<16>(A, lane & 4, 4);
-    rs_step<8>(A, lane & 8, 8);
-    rs_step<4>(A, lane & 16, 16);
-    rs_step<2>(A, lane & 32, 32);
+    rs_step<64, 1>(A, lane & 1);
+    rs_step<32, 2>(A, lane & 2);
+    rs_step<16, 4>(A, lane & 4);
+    rs_step<8, 8>(A, lane & 8);
+    rs_step<4, 16>(A, lane & 16);
+    rs_step<2, 32>(A, lane & 32);
     total = A[0];  // lane l holds A[l]: bit s of the register index was selected by bit s of the lane
     dy = lane >> 3;
     dx = lane & 7;
@@ -559,11 +567,11 @@ __device__ __forceinline__ unsigned long long eval_sub(const BnbParams &P, __amd
         R[2 * y] = E[y];
         R[2 * y + 1] = O[y] - ((E[y] >> 16) << 8);
       }
-      rs_step<8>(R, lane & 1, 1);
-      rs_step<4>(R, lane & 2, 2);
-      rs_step<2>(R, lane & 4, 4);
+      rs_step<8, 1>(R, lane & 1);
+      rs_step<4, 2>(R, lane & 2);
+      rs_step<2, 4>(R, lane & 4);
       uint32_t V[2] = {R[0] & 0xffffu, R[0] >> 16};
-      rs_step<2>(V, lane & 8, 8);
+      rs_step<2, 8>(V, lane & 8);
       V[0] += shfl_xor_u32(V[0], 16);
       V[0] += shfl_xor_u32(V[0], 32);
       total += V[0];
@@ -604,10 +612,10 @@ __device__ __forceinline__ unsigned long long eval_sub(const BnbParams &P, __amd
           A[4 * y + 3] += n1 >> 16;
         }
     }
-    rs_step<16>(A, lane & 1, 1);
-    rs_step<8>(A, lane & 2, 2);
-    rs_step<4>(A, lane & 4, 4);
-    rs_step<2>(A, lane & 8, 8);
+    rs_step<16, 1>(A, lane & 1);
+    rs_step<8, 2>(A, lane & 2);
+    rs_step<4, 4>(A, lane & 4);
+    rs_step<2, 8>(A, lane & 8);
     A[0] += shfl_xor_u32(A[0], 16);
     A[0] += shfl_xor_u32(A[0], 32);
     total = A[0];  // lane l holds A[l & 15]
@@ -788,11 +796,11 @@ __device__ __forceinline__ unsigned long long eval_sub_c(const BnbParams &P, __a
       R[2 * y] = E[y];
       R[2 * y + 1] = O[y] - ((E[y] >> 16) << 8);
     }
-    rs_step<8>(R, lane & 1, 1);
-    rs_step<4>(R, lane & 2, 2);
-    rs_step<2>(R, lane & 4, 4);
+    rs_step<8, 1>(R, lane & 1);
+    rs_step<4, 2>(R, lane & 2);
+    rs_step<2, 4>(R, lane & 4);
     uint32_t V[2] = {R[0] & 0xffffu, R[0] >> 16};
-    rs_step<2>(V, lane & 8, 8);
+    rs_step<2, 8>(V, lane & 8);
     V[0] += shfl_xor_u32(V[0], 16);
     V[0] += shfl_xor_u32(V[0], 32);
     total = V[0];
@@ -827,10 +835,10 @@ __device__ __forceinline__ unsigned long long eval_sub_c(const BnbParams &P, __a
           A[4 * y + 3] += n1 >> 16;
         }
     }
-    rs_step<16>(A, lane & 1, 1);
-    rs_step<8>(A, lane & 2, 2);
-    rs_step<4>(A, lane & 4, 4);
-    rs_step<2>(A, lane & 8, 8);
+    rs_step<16, 1>(A, lane & 1);
+    rs_step<8, 2>(A, lane & 2);
+    rs_step<4, 4>(A, lane & 4);
+    rs_step<2, 8>(A, lane & 8);
     A[0] += shfl_xor_u32(A[0], 16);
     A[0] += shfl_xor_u32(A[0], 32);
     total = A[0];  // lane l holds A[l & 15]
@@ -895,18 +903,18 @@ __device__ __forceinline__ unsigned long long eval_block_c(const BnbParams &P, _
     R[4 * y + 2] = E[y][1];
     R[4 * y + 3] = O[y][1] - ((E[y][1] >> 16) << 8);
   }
-  rs_step<32>(R, lane & 1, 1);
-  rs_step<16>(R, lane & 2, 2);
-  rs_step<8>(R, lane & 4, 4);
+  rs_step<32, 1>(R, lane & 1);
+  rs_step<16, 2>(R, lane & 2);
+  rs_step<8, 4>(R, lane & 4);
   uint32_t V[8];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
     V[2 * i] = R[i] & 0xffffu;
     V[2 * i + 1] = R[i] >> 16;
   }
-  rs_step<8>(V, lane & 8, 8);
-  rs_step<4>(V, lane & 16, 16);
-  rs_step<2>(V, lane & 32, 32);
+  rs_step<8, 8>(V, lane & 8);
+  rs_step<4, 16>(V, lane & 16);
+  rs_step<2, 32>(V, lane & 32);
   const int r = 8 * (2 * ((lane >> 5) & 1) + ((lane >> 4) & 1)) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 1) & 1) + (lane & 1);
   const int f = (lane >> 3) & 1, d = r & 3;
   const int dy = r >> 2, dx = 4 * (d >> 1) + (d & 1) + 2 * f;
