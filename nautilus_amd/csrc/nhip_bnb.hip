@@ -865,8 +865,9 @@ __device__ __forceinline__ unsigned long long eval_block_c(const BnbParams &P, _
                                                            int32_t X, int lane) {
   const uint32_t pitch = (uint32_t)P.pitch;
   const uint32_t off = (uint32_t)(BNB_B * Y) * pitch + (uint32_t)(BNB_B * X);
+// (one chunk's eight row loads in flight: with two the 32 accumulators + 48 row registers spill, measured 5 % slower)
 #ifndef NHIP_BNB_BLOCK_U
-#define NHIP_BNB_BLOCK_U 2
+#define NHIP_BNB_BLOCK_U 1
 #endif
   constexpr int U = NHIP_BNB_BLOCK_U;
   uint32_t E[8][2], O[8][2];
@@ -957,12 +958,13 @@ __device__ __forceinline__ uint32_t best_sum(unsigned long long *best) {
   else b = *(volatile unsigned long long *)best;
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));  // one value for the whole wave
 }
-// One copy of the candidate code serves the pair's own workgroup, whose best lives in LDS, and the takers of
-// handed-over rotations, who share it through keys[pair]: between two looks at a best that lives in global memory
-// (a device-scope atomic load: microseconds under load) the taker works with its copy, raised by its own finds; a
-// stale copy only costs pruning, never the result.
-__device__ __forceinline__ uint32_t best_sum_cached(unsigned long long *best, bool global, uint32_t copy) {
-  return global ? copy : best_sum<false>(best);
+// The pair's own workgroup keeps its best in LDS (GLOBAL = false: csm_bnb_kernel); the takers of handed-over
+// rotations share it through keys[pair] (GLOBAL = true: csm_bnb_rot_kernel).  Between two looks at a best that
+// lives in global memory (a device-scope atomic load: microseconds under load) a taker works with its copy, raised
+// by its own finds; a stale copy only costs pruning, never the result.
+template <bool GLOBAL>
+__device__ __forceinline__ uint32_t best_sum_cached(unsigned long long *best, uint32_t copy) {
+  return GLOBAL ? copy : best_sum<false>(best);
 }
 
 template <int CB>
@@ -1000,29 +1002,29 @@ __device__ __forceinline__ void process_candidate(const BnbParams &P, const Pair
 }
 
 // ... with the rotation's origins in registers (LDS-resident best) and the block's four sub-block bounds at hand
-template <int CB>
-__device__ __forceinline__ void process_candidate_c(const BnbParams &P, bool global, __amdgpu_buffer_rsrc_t rsrc,
+template <int CB, bool GLOBAL>
+__device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
                                                     const uint32_t *org, int32_t nch, int32_t k, int32_t Y, int32_t X,
                                                     uint32_t sb0, uint32_t sb1, uint32_t sb2, uint32_t sb3, int lane,
                                                     unsigned long long *best, uint32_t &bcopy, uint32_t (&n)[3]) {
-  const uint32_t bsum = best_sum_cached(best, global, bcopy);
+  const uint32_t bsum = best_sum_cached<GLOBAL>(best, bcopy);
   const int alive = (sb0 != 0u && sb0 >= bsum) + (sb1 != 0u && sb1 >= bsum) + (sb2 != 0u && sb2 >= bsum) +
                     (sb3 != 0u && sb3 >= bsum);
   if (alive == 0) return;
   if (CB == 1 && alive >= P.whole_min) {
     const unsigned long long key = eval_block_c(P, rsrc, org, nch, k, Y, X, lane);
     if (lane == 0) atomicMax(best, key);  // (generic address: LDS or global)
-    bcopy = max(bcopy, (uint32_t)(key >> 32));
+    if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
     n[0]++;
     return;
   }
 #pragma unroll 1
   for (int q = 0; q < 4; q++) {
     const uint32_t b = q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3));
-    if (b == 0u || b < best_sum_cached(best, global, bcopy)) continue;
+    if (b == 0u || b < best_sum_cached<GLOBAL>(best, bcopy)) continue;
     const unsigned long long key = eval_sub_c<CB>(P, rsrc, org, nch, k, Y, X, q >> 1, q & 1, lane);
     if (lane == 0) atomicMax(best, key);
-    bcopy = max(bcopy, (uint32_t)(key >> 32));
+    if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
     n[2]++;
   }
 }
@@ -1034,8 +1036,8 @@ struct PhaseClocks {
   long long org, strip, eval;
 };
 
-template <int CB>
-__device__ __forceinline__ void rotation_pass(const BnbParams &P, bool global, const PairCtx &C, int32_t k, uint32_t u0, uint32_t u1,
+template <int CB, bool GLOBAL>
+__device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx &C, int32_t k, uint32_t u0, uint32_t u1,
                                               unsigned long long m0, unsigned long long m1, int lane,
                                               unsigned long long *best, uint32_t *done, uint32_t *org,
                                               uint32_t (&n_work)[3], PhaseClocks &clk) {
@@ -1059,7 +1061,7 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, bool global, c
       len++;
     }
     uint32_t sb[12];
-    uint32_t bcopy = global ? best_sum<true>(best) : 0u;  // (one look per strip at a best in global memory)
+    uint32_t bcopy = GLOBAL ? best_sum<true>(best) : 0u;  // (one look per strip at a best in global memory)
     if (P.debug == 5) break;  // (timing: origins only)
     if (P.levels >= 2) {
       if (P.stats) t_mark = clock64();
@@ -1076,12 +1078,12 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, bool global, c
       if (b < 64) m0 &= ~(1ull << b);
       else m1 &= ~(1ull << (b - 64));
       const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)(b < 64 ? u0 : u1), b & 63);
-      if (ub < best_sum_cached(best, global, bcopy) || (P.debug == 4 && !done)) continue;  // the best has risen meanwhile
+      if (ub < best_sum_cached<GLOBAL>(best, bcopy) || (P.debug == 4 && !done)) continue;  // the best has risen meanwhile
       // (selects, not an indexed array: that would live in scratch)
       const uint32_t s0 = t == 0 ? sb[0] : (t == 1 ? sb[4] : sb[8]), s1 = t == 0 ? sb[1] : (t == 1 ? sb[5] : sb[9]);
       const uint32_t s2 = t == 0 ? sb[2] : (t == 1 ? sb[6] : sb[10]), s3 = t == 0 ? sb[3] : (t == 1 ? sb[7] : sb[11]);
       if (P.stats) t_mark = clock64();
-      process_candidate_c<CB>(P, global, rsrc, org, nch, k, Y, X0 + t, s0, s1, s2, s3, lane, best, bcopy, n_work);
+      process_candidate_c<CB, GLOBAL>(P, rsrc, org, nch, k, Y, X0 + t, s0, s1, s2, s3, lane, best, bcopy, n_work);
       if (P.stats) clk.eval += clock64() - t_mark;
       if (done && lane == 0) done[b] = 0u;
     }
@@ -1295,7 +1297,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         }
         have = true;
       }
-      if (have) rotation_pass<CB>(P, false, C, k, u0, u1, m0, m1, lane, s_best, done, org, n_work, clk);
+      if (have) rotation_pass<CB, false>(P, C, k, u0, u1, m0, m1, lane, s_best, done, org, n_work, clk);
       if (state == SEED) {
         __syncthreads();
         if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair + 2] = wall_clock64();
@@ -1451,7 +1453,7 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
     uint32_t n[3] = {0u, 0u, 0u};
     // (no block bounds here: 0xffffffff lets every candidate through to its sub-block bounds, which are checked
     //  against the best as it stands in keys[pair])
-    rotation_pass<CB>(P, true, C, k, 0xffffffffu, 0xffffffffu, m0, m1, lane, &P.keys[pair], nullptr, org, n, clk);
+    rotation_pass<CB, true>(P, C, k, 0xffffffffu, 0xffffffffu, m0, m1, lane, &P.keys[pair], nullptr, org, n, clk);
     if (P.stats && lane == 0 && pair < BNB_STATS_PAIRS) atomicAdd(&P.stats[BNB_STATS_HEAD + pair], 4ull * n[0] + n[2]);
     n_work[0] += n[0];
     n_work[1] += n[1];
