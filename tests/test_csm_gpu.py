@@ -203,6 +203,39 @@ def test_scan_lengths_around_the_held_origins(gpu, small_bag):
         _check_pairs(scans, [tgt], src, [0] * len(src), th0, spec, ospec, csm.search_spec(5, 25, 25, DEG))
 
 
+def test_hand_over_policies_agree_on_a_large_batch(gpu, small_bag):
+    """1,500 pairs (past the 1,024 from which pairs keep their rotations): every hand-over policy -- none, pairs with
+    >= 8 candidates from their third rotation on, every pair everything -- returns the records of the kernel that
+    performs every add, byte for byte; so does a 1,000-pair batch (below the limit: the default policy hands over)."""
+    import os
+    n = len(small_bag.scans)
+    rng = np.random.default_rng(5)
+    src = rng.integers(0, n, 1500).astype(np.int32)
+    tgt = rng.integers(0, n, 1500).astype(np.int32)
+    th0 = rng.uniform(-0.3, 0.3, 1500)
+    ids = np.unique(tgt)
+    slot = np.searchsorted(ids, tgt).astype(np.int32)
+    spec, _ = _specs(max_shift=20)
+    search = csm.search_spec(21, 41, 41, DEG)
+    st = csm.ScanTable.from_list(small_bag.scans)
+    grids = csm.LikelihoodGrids(st, ids, spec)
+    ex = csm.search_spec(21, 41, 41, DEG, exhaustive=True)
+    want, want_sums = csm.match_pairs(st, grids, src, slot, th0, ex)
+    for count in (1500, 1000):
+        for env in ({}, {"NHIP_BNB_KERNELS": "1"},
+                    {"NHIP_BNB_KERNELS": "2", "NHIP_BNB_HEAVY_MIN": "8", "NHIP_BNB_KEEP_RANKS": "2"},
+                    {"NHIP_BNB_KERNELS": "2", "NHIP_BNB_HEAVY_MIN": "1", "NHIP_BNB_KEEP_RANKS": "0"}):
+            os.environ.update(env)
+            try:
+                got, sums = csm.match_pairs(st, grids, src[:count], slot[:count], th0[:count], search)
+            finally:
+                for k_ in env:
+                    os.environ.pop(k_, None)
+            assert got.tobytes() == want[:count].tobytes() and np.array_equal(sums, want_sums[:count]), (count, env)
+    grids.close()
+    st.close()
+
+
 def test_swar_fields_do_not_overflow_in_one_alignment_class(gpu):
     """Worst case for the 16-bit SWAR fields: thousands of source points whose windows all start in the
     same alignment class (x = multiples of 4 cells) and sit on cells of the maximum value 255 (the
