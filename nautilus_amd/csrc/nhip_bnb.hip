@@ -1570,11 +1570,12 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   // times over waits for it.  Such a pair (>= heavy_min candidates after bounds and seeds) works only its first
   // keep_ranks rotations in best-first order (one per wave) itself and hands the others, with the masks of their
   // candidate blocks, to per-XCD lists in the caller's workspace; a second kernel works the lists with every wave of
-  // the chip, sharing the pair's running best through keys[pair].  Measured (tools/bnb_heavy.py, bnb_quick.py): the
-  // heaviest pair alone 3.0 -> 1.2 ms; 30 pairs 0.80 -> 0.60 ms; 500 pairs + the heaviest 3.35 -> 1.5 ms.
-  // From ~1000 pairs on the chip is full anyway and handing over only loses pruning and L2 locality (2,000 pairs
-  // 6.7 -> 7.6 ms, 10,000 pairs 10.4 -> 10.5 ms), so large batches do not.  (Also tried: letting the waves of
-  // finished workgroups take entries inside the first kernel, with and without persistent workgroups -- never a gain.)
+  // the chip, sharing the pair's running best through keys[pair].  Measured (tools/bnb_heavy.py, bnb_quick.py;
+  // profiles/r02_bnb_heavy.json): the heaviest pair alone 2.2 -> 0.94 ms; 30 pairs 0.80 -> 0.45 ms; 500 pairs + the
+  // three heaviest 2.5 -> 1.3 ms.  From ~1000 pairs on the chip is full anyway and handing over only loses pruning
+  // and L2 locality (2,000 pairs 4.6 -> 7.3 ms, 10,000 pairs unchanged), so large batches do not.  (Also tried:
+  // letting the waves of finished workgroups take entries inside the first kernel, and persistent workgroups -- never
+  // a gain.)
   // NHIP_BNB_KERNELS=1: never, =2: always; NHIP_BNB_HEAVY_MIN=<candidates>, NHIP_BNB_KEEP_RANKS=<n>.
   const char *force = getenv("NHIP_BNB_KERNELS");
   const char *hm = getenv("NHIP_BNB_HEAVY_MIN");
