@@ -943,7 +943,7 @@ __device__ __forceinline__ void rotation_k(const BnbParams &P, int32_t pair, int
 
 // ---- one candidate block: refine through the sub-block bounds, or evaluate whole --------------------------
 // `best` is the pair's running best key (LDS of the pair's workgroup, or keys[pair] in global memory for the
-// two-kernel form).  A sub-block is skipped only if its bound is below the best SUM found so far: it cannot hold
+// rotations handed to the second kernel).  A sub-block is skipped only if its bound is below the best SUM found so far: it cannot hold
 // the optimum nor a tie with it.  n[0] whole blocks evaluated, n[1] candidates refined, n[2] sub-blocks evaluated.
 struct PairCtx {
   const uint8_t *grid;
@@ -1218,8 +1218,8 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   C.cx = cx;
   C.cy = cy;
   C.pair = pair;
-  // Scans of up to 64 * OC points: a wave owns a rotation at a time and keeps its window origins in registers.
-  // Longer scans (and the two-kernel form) take the general path below.
+  // Scans of up to 64 * OCL points: a wave owns a rotation at a time and keeps its window origins in LDS.
+  // Longer scans take the general path below.
   if (BY_ROT) {
     // (the pooled table's space becomes the origins' once every wave is done with its bounds)
     __syncthreads();
@@ -1230,7 +1230,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     const long long t_phase1 = P.stats ? clock64() : 0;
     if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair + 1] = wall_clock64();
     const uint32_t xcd = bid & 7u;
-    bool offload = false;
+    bool handed_over = false;
     // One loop, one copy of the candidate code (it is large; three inlined copies did not fit the instruction
     // cache and halved the speed of everything).  A wave's work items, in this order:
     //  SEED  the wave's own highest-bound block, alone: the seeds give `best` a good lower bound before anything is
@@ -1291,7 +1291,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
                                                           : (m1 >> 18);
               P.rot_list[(size_t)xcd * P.rot_cap + e].w[lane] = word;
             }
-            offload = true;
+            handed_over = true;
             continue;
           }  // (list full: the rotation stays here)
         }
@@ -1339,7 +1339,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
       if (wave == 0) {
         atomicAdd(&P.stats[9], (unsigned long long)(t_busy - t_phase1));  // seeds (wave 0's view)
         atomicAdd(&P.stats[10], (unsigned long long)(t_phase1 - t_start)); // bounds
-        if (offload) atomicAdd(&P.stats[12], 1ull);
+        if (handed_over) atomicAdd(&P.stats[12], 1ull);
       }
     }
   } else {
