@@ -3,7 +3,7 @@
 Random grid geometry / blur / lattice / search centre / dense, sparse and clustered clouds; grids,
 indices and integer sums must be bit-exact, for both cell widths, through the branch-and-bound matcher (lattices up
 to 88 x 88) AND the kernel that performs every add (8-bit cells).  Round 1: 400 configurations, all equal;
-round 2: 400 configurations x {8, 16}-bit, all equal."""
+round 2: 3000 configurations x {8, 16}-bit, all equal (210 s)."""
 import math, sys, time
 import numpy as np
 import os
