@@ -54,7 +54,10 @@ def parse(argv=None):
     ap.add_argument("--mode", choices=["weak", "config4"], default="weak")
     ap.add_argument("--scans", type=int, default=None, help="scans per GPU (weak, default 1000) / in all (config4, default 10000)")
     ap.add_argument("--per-target", type=int, default=None, help="pairs per target scan (default 10 weak / 100 config4)")
-    ap.add_argument("--cell-bits", type=int, choices=[8, 16], default=8, help="likelihood-table cell width of the headline leg")
+    ap.add_argument("--cell-bits", type=int, choices=[8, 16], default=16,
+                    help="likelihood-table cell width of the headline leg: 16-bit cells keep reported scores within 1e-5 "
+                         "relative of an unquantised table (the north star's tolerance); 8-bit cells are the faster "
+                         "path for callers that only gate on a threshold (secondary.csm_u8)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-resid", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-drop-in", action="store_true",
@@ -447,9 +450,17 @@ def worker(a):
             out["cpu_baseline_error"] = repr(e)
     if legs and not a.no_resid:
         sec = out["secondary"] = {}
-        for name, fn in (("csm_u16" if a.cell_bits == 8 else "csm_u8", lambda: leg_other_cells(wl, shard, dev, a)),
-                         ("exhaustive_u8", lambda: leg_exhaustive(wl, shard, dev, lib, _lib, got if a.cell_bits == 8 else None,
-                                                                  got_sums if a.cell_bits == 8 else None)),
+        u8 = {"rec": (got, got_sums) if a.cell_bits == 8 else None}  # the 8-bit branch-and-bound records, whichever leg has them
+
+        def other_cells():
+            r = leg_other_cells(wl, shard, dev, a)
+            rec = r.pop("_records")
+            if a.cell_bits == 16:
+                u8["rec"] = rec
+            return r
+        for name, fn in (("csm_u16" if a.cell_bits == 8 else "csm_u8", other_cells),
+                         ("exhaustive_u8", lambda: leg_exhaustive(wl, shard, dev, lib, _lib, u8["rec"][0] if u8["rec"] else None,
+                                                                  u8["rec"][1] if u8["rec"] else None)),
                          ("resid_lidar", lambda: bench_residuals(torch, lib, dev, m.sp, a.cpu_seconds > 0)),):
             try:
                 sec[name] = fn()
@@ -501,8 +512,8 @@ def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3):
             r = {"value": m.n_pairs / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "correlate_kernel_ms": avg,
                  "hbm_equiv_GBps": lookups / (avg * 1e-3) / 1e9}
             if got is not None:
-                r["same_result_as_headline"] = bool(np.array_equal(m.d_sums[:m.n_pairs].cpu().numpy(), got_sums) and
-                                                    m.d_out[:m.n_pairs].cpu().numpy().tobytes() == got.tobytes())
+                r["same_result_as_branch_and_bound_u8"] = bool(np.array_equal(m.d_sums[:m.n_pairs].cpu().numpy(), got_sums) and
+                                                               m.d_out[:m.n_pairs].cpu().numpy().tobytes() == got.tobytes())
             if not env:
                 oc = onchip_roofline(m.n_pairs, avg, 8, "correlate")
                 r["roofline"] = {"bound": "valu", "kernel": "csm_correlate_kernel<false, false>", "avg_launch_ms": avg,
@@ -521,7 +532,7 @@ def leg_other_cells(wl, shard, dev, a, steps=3):
     """The same workload on the other cell width (16-bit cells meet the 1e-5 score tolerance against an
     unquantised table, 8-bit cells do not: DESIGN.md section 3)."""
     import torch
-    from nautilus_amd import _lib
+    from nautilus_amd import _lib, csm
     bits = 16 if a.cell_bits == 8 else 8
     lib = _lib.load()
     m2 = HipMatcher(wl, shard, dev, bits)
@@ -538,7 +549,8 @@ def leg_other_cells(wl, shard, dev, a, steps=3):
     ms, n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
     avg = ms / max(n, 1)
     oc = onchip_roofline(m2.n_pairs, avg, bits)
-    res = {"dtype": "u%d" % bits, "value": m2.n_pairs / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt,
+    rec = (m2.d_out[:m2.n_pairs].cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1).copy(), m2.d_sums[:m2.n_pairs].cpu().numpy().copy())
+    res = {"_records": rec, "dtype": "u%d" % bits, "value": m2.n_pairs / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt,
            "correlate_kernel_ms": avg, "steps": steps,
            "roofline": {"bound": "valu", "frac": oc["valu_frac"] if oc else None, "peak": VALU_PEAK_WAVE_INSTR / 1e12,
                         "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None, "unit": "T wave-instr/s"}}
