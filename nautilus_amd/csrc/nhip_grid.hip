@@ -22,6 +22,7 @@ constexpr int TH_MAX = TILE + 2 * MAX_R;  // 96
 struct GridKernelTables {
   int32_t taps[2 * MAX_R + 1];
   uint32_t thr[256];
+  float q16_a, q16_b;  // 16-bit cells: q ~ q16_a * ln(sum) + q16_b, the first guess of the table search
 };
 
 // Cell of a point (cimg_debug.h:31-37: side/2 + floor(x / resolution), float promoted to double);
@@ -160,9 +161,28 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
               if (n <= 255 && sThr[n] <= a) q = n;
             }
           } else {
-            for (int step = 32768; step >= 1; step >>= 1) {
-              const uint32_t n = q + step;
-              if (n <= 65535 && thr16[n] <= a) q = n;
+            // the thresholds grow exponentially: a first guess from ln(a) lands within a step or two of the answer,
+            // which the table then settles exactly (three or four dependent loads instead of sixteen); a guess
+            // that does not settle within a few steps falls back to the binary search
+            const float gf = tab.q16_a * __logf((float)a) + tab.q16_b;
+            uint32_t gq = gf <= 0.f ? 0u : (gf >= 65535.f ? 65535u : (uint32_t)gf);
+            int it = 0;
+            while (gq < 65535u && it < 6 && thr16[gq + 1] <= a) {
+              gq++;
+              it++;
+            }
+            while (gq > 0u && it < 12 && thr16[gq] > a) {
+              gq--;
+              it++;
+            }
+            const bool settled = (gq == 0u || thr16[gq] <= a) && (gq == 65535u || thr16[gq + 1] > a);
+            if (settled) {
+              q = gq;
+            } else {
+              for (int step = 32768; step >= 1; step >>= 1) {
+                const uint32_t n = q + step;
+                if (n <= 65535 && thr16[n] <= a) q = n;
+              }
             }
           }
         }
@@ -402,6 +422,16 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
   memset(&kt, 0, sizeof(kt));
   for (int i = 0; i <= 2 * L.R; i++) kt.taps[i] = T.taps[i];
   for (int i = 0; i < 256; i++) kt.thr[i] = T.thr[i];
+  if (L.cb == 2) {
+    // fit of the guess through two entries at the top of the table, where the integer thresholds are large and their
+    // rounding does not matter (through thr16[16384] = 9 the guess was 75 steps off); a hint only: the table decides
+    const double t1 = (double)T.thr16[57344], t2 = (double)T.thr16[65535];
+    if (t1 >= 1.0 && t2 > t1) {
+      const double a = (65535.0 - 57344.0) / (log(t2) - log(t1));
+      kt.q16_a = (float)a;
+      kt.q16_b = (float)(57344.0 - a * log(t1));
+    }
+  }
   uint32_t *d_thr16 = nullptr;
   if (L.cb == 2) {  // the table travels with the launch (the caller owns the workspace; nothing is allocated here)
     d_thr16 = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_ws) + GRID_WS_HEADER);
