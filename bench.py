@@ -147,7 +147,9 @@ class HipMatcher:
         idx, src, tgt, th0, ids, slot = shard
         self.n_pairs, self.n_targets = len(src), len(ids)
         self.src, self.slot, self.ids = src, slot, ids
-        self.spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=cell_bits)
+        # (the kernel that performs every add reads the skip maps; the branch-and-bound matcher does not, and 16-bit
+        #  grids are built without them unless asked)
+        self.spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=cell_bits, skip_map=exhaustive)
         self.search = csm.search_spec(61, 81, 81, math.radians(1.0), exhaustive=exhaustive)
         self.layout = csm.grid_layout(self.spec)
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
@@ -450,17 +452,19 @@ def worker(a):
             out["cpu_baseline_error"] = repr(e)
     if legs and not a.no_resid:
         sec = out["secondary"] = {}
-        u8 = {"rec": (got, got_sums) if a.cell_bits == 8 else None}  # the 8-bit branch-and-bound records, whichever leg has them
+        recs = {a.cell_bits: (got, got_sums)}  # the branch-and-bound records by cell width
 
         def other_cells():
             r = leg_other_cells(wl, shard, dev, a)
-            rec = r.pop("_records")
-            if a.cell_bits == 16:
-                u8["rec"] = rec
+            recs[24 - a.cell_bits] = r.pop("_records")
             return r
+
+        def exhaustive(bits):
+            rec = recs.get(bits)
+            return leg_exhaustive(wl, shard, dev, lib, _lib, rec[0] if rec else None, rec[1] if rec else None, bits=bits)
         for name, fn in (("csm_u16" if a.cell_bits == 8 else "csm_u8", other_cells),
-                         ("exhaustive_u8", lambda: leg_exhaustive(wl, shard, dev, lib, _lib, u8["rec"][0] if u8["rec"] else None,
-                                                                  u8["rec"][1] if u8["rec"] else None)),
+                         ("exhaustive_u16", lambda: exhaustive(16)),
+                         ("exhaustive_u8", lambda: exhaustive(8)),
                          ("resid_lidar", lambda: bench_residuals(torch, lib, dev, m.sp, a.cpu_seconds > 0)),):
             try:
                 sec[name] = fn()
@@ -484,13 +488,14 @@ def worker(a):
 
 
 # ------------------------------------------------------------------------------------------ legs
-def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3):
-    """The kernel that performs every add of the exhaustive definition (csm_correlate_kernel: accumulator-stationary,
-    LDS-tiled, SWAR; all-zero window strips left out through the skip map), and the same with the skip map ignored.
-    Same records as the headline, bit for bit."""
+def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3, bits=8):
+    """The kernel that performs every add of the exhaustive definition -- SURVEY 8(d)'s work -- (csm_correlate_kernel
+    for 8-bit, csm_correlate16_kernel for 16-bit cells: accumulator-stationary, LDS-tiled; all-zero window strips left
+    out through the skip map), and the same with the skip map ignored.  Same records as the branch-and-bound
+    matcher at that cell width, bit for bit."""
     import torch
     from nautilus_amd import synth
-    m = HipMatcher(wl, shard, dev, 8, exhaustive=True)
+    m = HipMatcher(wl, shard, dev, bits, exhaustive=True)
     lookups = 61 * 81 * 81 * synth.N_BEAMS * float(m.n_pairs)
     out = {}
     for name, env in (("skip_map", None), ("every_add", "1")):
@@ -510,13 +515,16 @@ def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3):
             ms, n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
             avg = ms / max(n, 1)
             r = {"value": m.n_pairs / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt, "correlate_kernel_ms": avg,
-                 "hbm_equiv_GBps": lookups / (avg * 1e-3) / 1e9}
+                 "dtype": "u%d" % bits, "hbm_equiv_GBps": lookups * (bits // 8) / (avg * 1e-3) / 1e9,
+                 "lookups_per_s": lookups / (avg * 1e-3)}
             if got is not None:
-                r["same_result_as_branch_and_bound_u8"] = bool(np.array_equal(m.d_sums[:m.n_pairs].cpu().numpy(), got_sums) and
-                                                               m.d_out[:m.n_pairs].cpu().numpy().tobytes() == got.tobytes())
+                r["same_result_as_branch_and_bound_u%d" % bits] = bool(
+                    np.array_equal(m.d_sums[:m.n_pairs].cpu().numpy(), got_sums) and
+                    m.d_out[:m.n_pairs].cpu().numpy().tobytes() == got.tobytes())
             if not env:
-                oc = onchip_roofline(m.n_pairs, avg, 8, "correlate")
-                r["roofline"] = {"bound": "valu", "kernel": "csm_correlate_kernel<false, false>", "avg_launch_ms": avg,
+                oc = onchip_roofline(m.n_pairs, avg, bits, "correlate")
+                r["roofline"] = {"bound": "valu", "avg_launch_ms": avg,
+                                 "kernel": "csm_correlate_kernel<false, false>" if bits == 8 else "csm_correlate16_kernel<false, false>",
                                  "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None,
                                  "peak": VALU_PEAK_WAVE_INSTR / 1e12, "unit": "T wave-instr/s",
                                  "frac": oc["valu_frac"] if oc else None}

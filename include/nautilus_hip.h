@@ -58,11 +58,20 @@ typedef struct nhip_grid_spec {
   double sigma;       /* blur sigma in cells */
   double floor_p;     /* likelihood floor before the log (1e-10) */
   int32_t max_shift;  /* largest |cell shift| a search on these grids may use */
-  int32_t cell_bits;  /* width of a quantised log-likelihood cell: 8 (or 0: the default) or 16.  8-bit cells
-                         (255 steps of 0.09 nat) are the fast path; 16-bit cells (65535 steps of 3.5e-4 nat)
-                         keep reported scores within 1e-5 relative of an unquantised double table
-                         (cimg_debug.h:19 holds the reference's table as CImg<double>) */
+  int32_t cell_bits;  /* width of a quantised log-likelihood cell: 16 (or 0: the default) or 8.  16-bit cells
+                         (65535 steps of 3.5e-4 nat) keep reported scores within 1e-5 relative of an unquantised
+                         double table (cimg_debug.h:19 holds the reference's table as CImg<double>); 8-bit cells
+                         (255 steps of 0.09 nat, scores within 1e-3) are the explicit opt-in for callers that only
+                         gate on a threshold */
+  int32_t flags;      /* 0, or NHIP_GRID_SKIP_MAP */
+  int32_t reserved;   /* 0 */
 } nhip_grid_spec_t;
+/* NHIP_GRID_SKIP_MAP: the slots of 16-bit grids carry a skip map too (8-bit grids always do).  Only the kernel that
+ * performs every add reads it (NHIP_SEARCH_EXHAUSTIVE, lattices beyond the branch-and-bound matcher's envelope);
+ * without it that kernel adds every window strip, zero or not -- same records, ~1.5x the time.  The flag describes
+ * the buffer: pass the same spec to the build and to the match.  The handle API builds missing maps itself the first
+ * time an exhaustive search needs them. */
+#define NHIP_GRID_SKIP_MAP 1
 
 typedef struct nhip_grid_layout {
   int32_t side;        /* S: cells per side (cimg_debug.h:21-22) */
@@ -79,8 +88,8 @@ typedef struct nhip_grid_layout {
                           r and aligned dword column c (bit c&7 of byte c>>3, 8*ceil(pitch/256) bytes per
                           row) = "stored rows [r, r+21) x dwords [c, c+21*cell_bytes) hold a non-zero cell",
                           so the correlation kernel can leave out window strips that only add zeros (same
-                          sums, bit for bit).  Built for 8-bit cells only (the kernel that reads it takes no
-                          others); the space stays zero for 16-bit cells */
+                          sums, bit for bit).  Built for 8-bit cells always, for 16-bit cells when the spec carries
+                          NHIP_GRID_SKIP_MAP (the branch-and-bound matcher never reads it); zero otherwise */
   int64_t slot_bytes;  /* grid_bytes + skip_bytes + pool_bytes + pool4_bytes: grid t of a buffer starts at byte
                           t*slot_bytes */
   int64_t pool_bytes;  /* bytes of the max-pooled table stored after the skip map (branch-and-bound bounds):
@@ -125,8 +134,11 @@ typedef struct nhip_search {
  * of the 4 x 4 sub-blocks of the blocks that reach the best sum found from a second one, then exact sums only for
  * the sub-blocks whose bound still reaches it (indices, sums and scores are identical to the exhaustive kernel's,
  * bit for bit: tests compare the two).  NHIP_SEARCH_EXHAUSTIVE (or the environment variable NHIP_CSM_EXHAUSTIVE=1)
- * forces the kernel that performs every add (8-bit cells only; also taken for lattices of more than 88 x 88
- * translations, or more rotations than fit the LDS beside the bounds: ~230). */
+ * forces the kernel that performs every add (csm_correlate_kernel for 8-bit, csm_correlate16_kernel for 16-bit cells;
+ * also taken for lattices of more than 88 x 88 translations, or more rotations than fit the LDS beside the bounds:
+ * ~230 -- e.g. GetTransformation with a rotation restriction of pi).
+ * Scan length: sums are reported as int32, so with 16-bit cells a scan may hold at most 32,768 points (8-bit:
+ * 8,421,504); the handle API checks it, callers of the _dev entry points must. */
 #define NHIP_SEARCH_EXHAUSTIVE 1
 
 /* One result per candidate pair: 16 bytes, the record that is all-gathered across GPUs. */
@@ -192,7 +204,7 @@ int nhip_bnb_stats_per_pair(uint64_t *evaluated, int32_t n_pairs);
  * n_pairs records two more values: first start and last end of the second kernel.  ticks: 4*n_pairs + 2 values */
 int nhip_bnb_timeline(uint64_t *ticks, int32_t n_pairs);
 
-/* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy] (8-bit cells). */
+/* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy]. */
 int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                         const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
                         const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
@@ -305,6 +317,8 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
 int nhip_grids_free(nhip_grids_t *grids);
 /* copy stored (padded) grid `slot` to host: layout.grid_bytes bytes (uint8 or uint16 cells) */
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
+/* copy the skip map of grid `slot` to host: layout.skip_bytes bytes (rows x 8*ceil(pitch/256) bytes, then padding) */
+int nhip_grids_download_skip_map(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* copy the max-pooled table of grid `slot` to host: layout.pool_bytes bytes (pool_rows x pool_pitch) */
 int nhip_grids_download_pool(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* the same for the second-level table: layout.pool4_bytes bytes (pool4_rows x pool4_pitch) */

@@ -14,6 +14,7 @@ LIB_PATH = os.environ.get("NHIP_LIB") or os.path.join(_HERE, "lib", "libnautilus
 NHIP_OK, NHIP_ERR_ARG, NHIP_ERR_NODEV, NHIP_ERR_HIP, NHIP_ERR_ALLOC, NHIP_ERR_STATE = 0, -1, -2, -3, -4, -5
 NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1
 NHIP_SEARCH_EXHAUSTIVE = 1
+NHIP_GRID_SKIP_MAP = 1
 NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ = 0, 1, 2, 3, 4
 
 
@@ -25,7 +26,8 @@ class NhipError(RuntimeError):
 
 class GridSpec(C.Structure):
     _fields_ = [("range", C.c_double), ("res", C.c_double), ("sigma", C.c_double),
-                ("floor_p", C.c_double), ("max_shift", C.c_int32), ("cell_bits", C.c_int32)]
+                ("floor_p", C.c_double), ("max_shift", C.c_int32), ("cell_bits", C.c_int32),
+                ("flags", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GridLayout(C.Structure):
@@ -97,6 +99,7 @@ PROTOTYPES = {
     "nhip_grids_build": (C.c_int, [_vp, _vp, _i32, _P(GridSpec), _P(_vp)]),
     "nhip_grids_free": (C.c_int, [_vp]),
     "nhip_grids_download": (C.c_int, [_vp, _i32, _vp]),
+    "nhip_grids_download_skip_map": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_pool": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_pool4": (C.c_int, [_vp, _i32, _vp]),
     "nhip_csm_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _P(Search), _vp, _vp]),

@@ -129,7 +129,7 @@ class CorrelativeScanMatcherBatch {
 
   CorrelativeScanMatcherBatch(double scanner_range, double res, const nhip_search_t &search)
       : search_(search) {
-    spec_ = {scanner_range, res, 2.0, 1e-10, std::max(search.nx, search.ny) / 2, NAUTILUS_HIP_CELL_BITS};
+    spec_ = {scanner_range, res, 2.0, 1e-10, std::max(search.nx, search.ny) / 2, NAUTILUS_HIP_CELL_BITS, 0, 0};
   }
 
   // pairs: (source index, target index) into `clouds`; rotations: world heading of every cloud.

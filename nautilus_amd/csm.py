@@ -19,10 +19,12 @@ MATCH_DTYPE = np.dtype([("itheta", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("score
 assert MATCH_DTYPE.itemsize == C.sizeof(Match) == 16
 
 
-def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, cell_bits=8):
+def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, cell_bits=8, skip_map=False):
     """cell_bits: 8 (255 quantisation steps over [ln floor_p, 0]) or 16 (65535 steps: scores within 1e-5 of an
-    unquantised table)."""
-    return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(max_shift), int(cell_bits))
+    unquantised table).  skip_map: 16-bit grids carry a skip map too (only the kernel that performs
+    every add reads it; LikelihoodGrids builds a missing one the first time such a search needs it)."""
+    return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(max_shift), int(cell_bits),
+                    _lib.NHIP_GRID_SKIP_MAP if skip_map else 0, 0)
 
 
 def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0), exhaustive=False):
@@ -107,6 +109,15 @@ class LikelihoodGrids:
         out = np.empty((L.rows, L.pitch), dtype=np.uint8)
         check(_lib.load().nhip_grids_download(self._h, int(slot), ptr(out)))
         return out.view(np.uint16) if L.cell_bytes == 2 else out
+
+    def skip_map(self, slot):
+        """The slot's skip map as (rows, bytes per map row) uint8: bit c & 7 of byte c >> 3 of row r = "stored rows
+        [r, r + 21) x aligned dwords [c, c + 21 * cell_bytes) hold a non-zero cell"."""
+        L = self.layout
+        out = np.empty(L.skip_bytes, dtype=np.uint8)
+        check(_lib.load().nhip_grids_download_skip_map(self._h, int(slot), ptr(out)))
+        mp = 8 * ((L.pitch // 4 + 63) // 64)
+        return out[:L.rows * mp].reshape(L.rows, mp)
 
     def pooled(self, slot, level=1):
         """Max-pooled table uint8, the branch-and-bound matcher's bounds: level 1 (pool_rows, pool_pitch), 15 x 15

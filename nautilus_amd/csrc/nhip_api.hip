@@ -48,6 +48,8 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   NHIP_REQUIRE(spec->max_shift >= 0 && spec->max_shift <= 4096, "grid spec: max_shift out of range");
   NHIP_REQUIRE(spec->cell_bits == 0 || spec->cell_bits == 8 || spec->cell_bits == 16,
                "grid spec: cell_bits must be 8 or 16 (0 = 8), got %d", spec->cell_bits);
+  NHIP_REQUIRE((spec->flags & ~NHIP_GRID_SKIP_MAP) == 0 && spec->reserved == 0, "grid spec: unknown flags %d / reserved %d",
+               spec->flags, spec->reserved);
   const double side = floor((spec->range * 2.0) / spec->res);  // cimg_debug.h:21-22
   NHIP_REQUIRE(side >= 1 && side <= 16384, "grid spec: side %g out of range [1, 16384]", side);
   L->S = (int32_t)side;
@@ -218,6 +220,7 @@ struct nhip_grids {
   nhip_grid_spec_t spec;
   nhip::GridLayout L;
   int32_t n = 0;
+  std::mutex mu;  // (the late skip-map build)
 };
 
 struct nhip_resid_batch {
@@ -618,6 +621,14 @@ int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   return NHIP_OK;
 }
 
+int nhip_grids_download_skip_map(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
+  NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_skip_map: bad arguments");
+  const GridLayout &L = grids->L;
+  NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes,
+                         (size_t)L.skip_bytes, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
 int nhip_grids_download_pool(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_pool: bad arguments");
   const GridLayout &L = grids->L;
@@ -631,6 +642,22 @@ int nhip_grids_download_pool4(const nhip_grids_t *grids, int32_t slot, uint8_t *
   const GridLayout &L = grids->L;
   NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes + L.skip_bytes + L.pool_bytes,
                          (size_t)L.pool4_bytes, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+// 16-bit grids are built without skip maps unless their spec asks (the branch-and-bound matcher never reads them).
+// The first search on a handle that takes the kernel that performs every add builds them, once.
+static int ensure_skip_maps(const nhip_grids_t *grids, const nhip_search_t *search) {
+  nhip_grids *g = const_cast<nhip_grids *>(grids);
+  if (g->L.cb != 2 || (g->spec.flags & NHIP_GRID_SKIP_MAP) || g->n == 0) return NHIP_OK;
+  NHIP_REQUIRE(search->n_theta >= 1 && search->nx >= 1 && search->ny >= 1, "search: empty lattice");
+  if (!csm_takes_exhaustive(g->L, search)) return NHIP_OK;
+  std::lock_guard<std::mutex> lock(g->mu);
+  if (g->spec.flags & NHIP_GRID_SKIP_MAP) return NHIP_OK;
+  int rc = launch_skipmap_build(static_cast<uint8_t *>(g->grids.p), g->n, g->L, nullptr);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipStreamSynchronize(nullptr));
+  g->spec.flags |= NHIP_GRID_SKIP_MAP;
   return NHIP_OK;
 }
 
@@ -652,6 +679,14 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
                    pair_origin[2 * i], pair_origin[2 * i + 1], grids->spec.max_shift);
   }
   if (n_pairs == 0) return NHIP_OK;
+  // sums are reported as int32: the longest scan whose largest possible sum fits
+  const int64_t max_pts = 0x7fffffffll / (grids->L.cb == 2 ? 65535 : 255);
+  for (int32_t i = 0; i < n_pairs; i++) {
+    const int64_t n_i = (int64_t)scans->h_offsets[pair_src[i] + 1] - scans->h_offsets[pair_src[i]];
+    NHIP_REQUIRE(n_i <= max_pts, "csm_match: pair %d: scan %d has %lld points; with %d-bit cells at most %lld fit the "
+                 "int32 sums", i, pair_src[i], (long long)n_i, 8 * grids->L.cb, (long long)max_pts);
+  }
+  if ((rc = ensure_skip_maps(grids, search))) return rc;
   std::vector<double> rot0(2 * (size_t)n_pairs), delta(2 * (size_t)search->n_theta);
   if ((rc = nhip_csm_rot0(theta0, nullptr, n_pairs, rot0.data()))) return rc;
   if ((rc = nhip_csm_delta_table(search, delta.data()))) return rc;
@@ -690,6 +725,11 @@ int nhip_csm_scores(const nhip_scans_t *scans, const nhip_grids_t *grids, int32_
   if (rc) return rc;
   NHIP_REQUIRE(scans && grids && search && out_sums, "csm_scores: bad arguments");
   NHIP_REQUIRE(src >= 0 && src < scans->n_scans && slot >= 0 && slot < grids->n, "csm_scores: index out of range");
+  {
+    nhip_search_t ex = *search;
+    ex.flags |= NHIP_SEARCH_EXHAUSTIVE;  // (the volume always comes from the kernel that performs every add)
+    if ((rc = ensure_skip_maps(grids, &ex))) return rc;
+  }
   double rot0[2];
   std::vector<double> delta(2 * (size_t)search->n_theta);
   if ((rc = nhip_csm_rot0(&theta0, nullptr, 1, rot0))) return rc;
@@ -794,7 +834,7 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   const int32_t src = 0, slot = 0, target = 1;
   // level 1: low_res grid, whole translation range, +-rot_restriction
   const int32_t h1 = (int32_t)floor(p->trans_range / p->low_res);
-  const nhip_grid_spec_t spec1 = {p->scanner_range, p->low_res, p->sigma, p->floor_p, h1, bits};
+  const nhip_grid_spec_t spec1 = {p->scanner_range, p->low_res, p->sigma, p->floor_p, h1, bits, 0, 0};
   const nhip_search_t s1 = {2 * (int32_t)floor(rot_restriction / coarse_step) + 1, 2 * h1 + 1, 2 * h1 + 1, 0, coarse_step};
   nhip_match_t m1;
   if ((rc = nhip_grids_build(scans, &target, 1, &spec1, &guard.g))) return rc;
@@ -807,7 +847,7 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   const int32_t ratio = (int32_t)lround(p->low_res / p->high_res);
   const int32_t origin[2] = {(int32_t)lround((double)tx1 / p->high_res), (int32_t)lround((double)ty1 / p->high_res)};
   const int32_t reach = std::max(abs(origin[0]), abs(origin[1])) + ratio;
-  const nhip_grid_spec_t spec2 = {p->scanner_range, p->high_res, p->sigma, p->floor_p, reach, bits};
+  const nhip_grid_spec_t spec2 = {p->scanner_range, p->high_res, p->sigma, p->floor_p, reach, bits, 0, 0};
   const nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1, 0, coarse_step / 10.0};
   const double theta1 = th1;
   nhip_match_t m2;

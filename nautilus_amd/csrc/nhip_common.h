@@ -132,6 +132,21 @@ int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t
                       int32_t origin_y, const nhip_search_t *search, int32_t *d_sums,
                       hipStream_t s);
 
+// the kernel that performs every add, 16-bit cells (nhip_csm16.hip); called by launch_csm_match / launch_csm_scores
+int launch_csm16_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                       const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
+                       const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
+                       const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
+                       uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s);
+int launch_csm16_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                        const nhip_grid_spec_t *spec, const GridLayout &L, int32_t src, int32_t slot,
+                        const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x, int32_t origin_y,
+                        const nhip_search_t *search, int32_t *d_sums, hipStream_t s);
+// skip maps of n finished 16-bit grids (the handle API's late build; occupancy unknown: every map tile is computed)
+int launch_skipmap_build(uint8_t *d_grids, int32_t n_grids, const GridLayout &L, hipStream_t s);
+// true when a search on these grids takes the kernel that performs every add
+bool csm_takes_exhaustive(const GridLayout &L, const nhip_search_t *search);
+
 int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_block, int64_t n_corr,
                        const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                        const double *d_poses, int32_t n_poses, double *d_block_consts,

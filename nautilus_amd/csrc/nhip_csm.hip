@@ -21,11 +21,13 @@
 //
 // No bounds checks: grids carry a zero border of pad = 2*max_shift+16 cells and rotated cells
 // are clamped to one cell outside the window-overlap range (a clamped point only sees border).
-#include "nhip_common.h"
+#include "nhip_csm_shared.h"
 
 namespace nhip {
 
 namespace {
+
+using namespace csm;
 
 #ifndef NHIP_WG_WAVES
 #define NHIP_WG_WAVES 1
@@ -52,55 +54,6 @@ constexpr int TILE_ROWS = NHIP_TILE_ROWS;
 constexpr int FILL_INFLIGHT = NHIP_FILL_INFLIGHT;  // 16-byte tile-fill loads a lane keeps in flight
 constexpr int ROW_BYTES = SEGS * SEG_COLS; // bytes of a tile row one point touches from its aligned start (84)
 constexpr int COL_SPAN = LP - ROW_BYTES;   // max (pcol - tile_col0) of a covered point (128)
-
-struct CsmParams {
-  const float2 *xy;
-  const int32_t *offsets;
-  const uint8_t *grids;
-  const int32_t *pair_src;
-  const int32_t *pair_slot;
-  const double *rot0_cs;
-  const double *delta_cs;
-  const int32_t *pair_origin;  // optional (x, y) cell offset of each pair's search centre
-  unsigned long long *keys;
-  int32_t *volume;  // full score volume (scores kernel only)
-  int32_t n_pairs, n_theta, nx, ny, hx, hy, npbx, npby;
-  int32_t S, pad, pitch, rows, max_shift;
-  int32_t single_src, single_slot;  // scores kernel: the one pair
-  int32_t single_ox, single_oy;
-  int32_t dense;  // 1: ignore the skip maps (every strip is added, zero or not)
-  int64_t grid_bytes, slot_bytes;
-  double res, inv_res;
-};
-
-// Stored-grid coordinates (row, col) of the top-left cell of point q's window under rotation
-// (cf, sf), packed (row << 16) | col.  Spec: rotate in float with individually rounded
-// products (Eigen Affine2f * Vector2f on baseline x86-64: no FMA), cell = S/2 +
-// floor(double(v) / res) (cimg_debug.h:31-37).  Cells are clamped to [-h-1, S+h]: beyond that
-// range every lookup of the window falls on the zero border, and so does the clamped window.
-__device__ __forceinline__ uint32_t window_cell(float2 q, float cf, float sf, const CsmParams &P,
-                                                int32_t ox, int32_t oy, int32_t cx, int32_t cy) {
-  const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
-  const float yr = __fadd_rn(__fmul_rn(sf, q.x), __fmul_rn(cf, q.y));
-  long col = -P.hx - 1, row = -P.hy - 1;  // non-finite points score nothing
-  if ((fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f)) {
-    const long half = P.S / 2;
-    col = half + (long)floor_quotient((double)xr, P.res, P.inv_res) + cx;
-    row = half + (long)floor_quotient((double)yr, P.res, P.inv_res) + cy;
-    col = col < -P.hx - 1 ? -P.hx - 1 : (col > P.S + P.hx ? P.S + P.hx : col);
-    row = row < -P.hy - 1 ? -P.hy - 1 : (row > P.S + P.hy ? P.S + P.hy : row);
-  }
-  const uint32_t pcol = (uint32_t)(col - P.hx + ox + P.pad);
-  const uint32_t prow = (uint32_t)(row - P.hy + oy + P.pad);
-  return (prow << 16) | pcol;
-}
-
-__device__ __forceinline__ unsigned long long shfl_xor_u64(unsigned long long v, int m) {
-  uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
-  lo = __shfl_xor(lo, m, 64);
-  hi = __shfl_xor(hi, m, 64);
-  return ((unsigned long long)hi << 32) | lo;
-}
 
 // ---- SWAR byte accumulation -------------------------------------------------------------
 // gfx950 issues plain VOP2 integer ops (v_add_u32, v_and_b32, v_lshrrev_b32) at 2 clk per
@@ -221,14 +174,6 @@ __device__ __forceinline__ void swar_flush(Swar &A, uint32_t (&acc)[SEG_COLS], b
     }
   }
   swar_clear(A);
-}
-
-// Where to put point j inside a fresh tile: ahead of the direction the beam sweep is moving.
-__device__ __forceinline__ int32_t place(int32_t here, int32_t ahead, int32_t span) {
-  const int32_t d = ahead - here;
-  const int32_t off = d > 2 ? span / 8 : (d < -2 ? span - span / 8 : span / 2);
-  const int32_t a = here - off;
-  return a < 0 ? 0 : a;
 }
 
 #ifndef NHIP_WAVES_PER_SIMD
@@ -475,9 +420,7 @@ int check_search(const nhip_grid_spec_t *spec, const GridLayout &L, const nhip_s
   NHIP_REQUIRE(L.S + 2 * L.pad < 65536, "search: stored grid side %d does not fit 16-bit cell packing",
                L.S + 2 * L.pad);
   NHIP_REQUIRE(L.pitch % 16 == 0, "search: grid pitch must be a multiple of 16");
-  NHIP_REQUIRE(!exhaustive || L.cb == 1,
-               "search: the exhaustive kernel takes 8-bit cells only; 16-bit grids go through the branch-and-bound "
-               "matcher (lattices up to 88 x 88 translations)");
+  (void)exhaustive;  // (both cell widths have a kernel that performs every add: this file and nhip_csm16.hip)
   return NHIP_OK;
 }
 
@@ -507,6 +450,11 @@ void fill_params(CsmParams &P, const nhip_grid_spec_t *spec, const GridLayout &L
 
 }  // namespace
 
+bool csm_takes_exhaustive(const GridLayout &L, const nhip_search_t *search) {
+  const char *ex = getenv("NHIP_CSM_EXHAUSTIVE");
+  return (search->flags & NHIP_SEARCH_EXHAUSTIVE) || (ex && ex[0] == '1') || !bnb_fits(L, search);
+}
+
 void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, const int32_t *d_offsets, int32_t n_pairs,
                          int32_t nx, int32_t ny, const GridLayout &L, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s) {
   hipLaunchKernelGGL(csm_finalize_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s,
@@ -520,8 +468,7 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
                      uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s,
                      void *d_workspace, int64_t workspace_bytes) {
-  const char *ex = getenv("NHIP_CSM_EXHAUSTIVE");
-  const bool exhaustive = (search->flags & NHIP_SEARCH_EXHAUSTIVE) || (ex && ex[0] == '1') || !bnb_fits(L, search);
+  const bool exhaustive = csm_takes_exhaustive(L, search);
   int rc = check_search(spec, L, search, exhaustive);
   if (rc) return rc;
   if (n_pairs == 0) return NHIP_OK;
@@ -531,6 +478,9 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                         d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s, &handled, d_workspace, workspace_bytes);
     if (rc || handled) return rc;
   }
+  if (L.cb == 2)
+    return launch_csm16_match(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
+                              d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s);
   CsmParams P;
   fill_params(P, spec, L, search);
   P.xy = reinterpret_cast<const float2 *>(d_xy);
@@ -567,6 +517,9 @@ int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t
                       hipStream_t s) {
   int rc = check_search(spec, L, search, true);
   if (rc) return rc;
+  if (L.cb == 2)
+    return launch_csm16_scores(d_xy, d_offsets, d_grids, spec, L, src, slot, d_rot0_cs, d_delta_cs, origin_x, origin_y,
+                               search, d_sums, s);
   CsmParams P;
   fill_params(P, spec, L, search);
   P.xy = reinterpret_cast<const float2 *>(d_xy);

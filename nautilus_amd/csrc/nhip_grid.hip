@@ -218,8 +218,9 @@ constexpr int MT = 64;
 constexpr int SK_ROWS = MT + CSM_WAVE_ROWS - 1;  // grid rows feeding one map tile (84)
 static_assert(2 * CSM_ROW_DW - 1 <= 64 && MT == 64, "row mask is built from two 64-lane ballots");
 
-// CB = bytes per cell: a strip row spans ROW_DW = CB * CSM_ROW_DW aligned dwords (21 / 42).  z = target index
-// within the launch (t_base + blockIdx.z: launches are chunked at 65,535 targets).
+// CB = bytes per cell: a strip row spans ROW_DW = CB * CSM_ROW_DW aligned dwords (21 / 42; csm_correlate16_kernel
+// starts its strips at 8-byte-aligned columns and looks up the even dword).  z = target index within the launch
+// (t_base + blockIdx.z: launches are chunked at 65,535 targets).
 template <int CB>
 __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__restrict__ occ,
                                                            uint8_t *__restrict__ grids, int32_t S,
@@ -234,8 +235,8 @@ __global__ __launch_bounds__(256) void grid_skipmap_kernel(const uint8_t *__rest
   // footprint in raster coordinates -> blur tiles that could have written into it
   const int32_t fr0 = r0 - pad, fr1 = r0 + SK_ROWS - 1 - pad;
   const int32_t fc0 = CPD * c0 - pad, fc1 = CPD * (c0 + MT + ROW_DW - 1) - 1 - pad;
-  int any = 0;
-  if (fr1 >= 0 && fr0 < S && fc1 >= 0 && fc0 < S) {
+  int any = occ ? 0 : 1;  // (no occupancy bytes: the late build of the handle API computes every tile)
+  if (occ && fr1 >= 0 && fr0 < S && fc1 >= 0 && fc0 < S) {
     const int32_t ty0 = max(fr0, 0) / TILE, ty1 = min(fr1, S - 1) / TILE;
     const int32_t tx0 = max(fc0, 0) / TILE, tx1 = min(fc1, S - 1) / TILE;
     const int32_t ntx = tx1 - tx0 + 1, nt = (ty1 - ty0 + 1) * ntx;
@@ -467,13 +468,19 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16);
-    // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernel that
-    // performs every add, which takes 8-bit cells only: 16-bit grids leave theirs zero.)
-    for (int32_t z0 = 0; z0 < n && L.cb == 1; z0 += 65535) {
+    // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernels that
+    // perform every add; the branch-and-bound matcher never reads it, so 16-bit grids -- its product path -- carry
+    // one only when the spec asks.)
+    const bool want_map = L.cb == 1 || (spec->flags & NHIP_GRID_SKIP_MAP);
+    for (int32_t z0 = 0; z0 < n && want_map; z0 += 65535) {
       const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
       const dim3 mg((mpitch + MT - 1) / MT, (rows + MT - 1) / MT, nz);
-      hipLaunchKernelGGL(grid_skipmap_kernel<1>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
-                         L.grid_bytes, L.slot_bytes, z0);
+      if (L.cb == 1)
+        hipLaunchKernelGGL(grid_skipmap_kernel<1>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
+                           L.grid_bytes, L.slot_bytes, z0);
+      else
+        hipLaunchKernelGGL(grid_skipmap_kernel<2>, mg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, L.pitch, rows,
+                           L.grid_bytes, L.slot_bytes, z0);
     }
     if (L.cb == 1) {
       launch_pool<1, BNB_B>(occ, g, L, tiles, n, s);
@@ -483,6 +490,23 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
       launch_pool<2, BNB_B4>(occ, g, L, tiles, n, s);
     }
     timer_end(NHIP_TIMER_GRID, s);
+  }
+  NHIP_TRY_HIP(hipGetLastError());
+  return NHIP_OK;
+}
+
+int launch_skipmap_build(uint8_t *d_grids, int32_t n_grids, const GridLayout &L, hipStream_t s) {
+  const int32_t rows = L.S + 2 * L.pad, mpitch = L.pitch / 4;
+  const int tiles = (L.S + TILE - 1) / TILE;
+  for (int32_t z0 = 0; z0 < n_grids; z0 += 65535) {
+    const int32_t nz = n_grids - z0 < 65535 ? n_grids - z0 : 65535;
+    const dim3 mg((mpitch + MT - 1) / MT, (rows + MT - 1) / MT, nz);
+    if (L.cb == 1)
+      hipLaunchKernelGGL(grid_skipmap_kernel<1>, mg, dim3(256), 0, s, static_cast<const uint8_t *>(nullptr), d_grids, L.S,
+                         tiles, L.pad, L.pitch, rows, L.grid_bytes, L.slot_bytes, z0);
+    else
+      hipLaunchKernelGGL(grid_skipmap_kernel<2>, mg, dim3(256), 0, s, static_cast<const uint8_t *>(nullptr), d_grids, L.S,
+                         tiles, L.pad, L.pitch, rows, L.grid_bytes, L.slot_bytes, z0);
   }
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Match) == 16
-    assert C.sizeof(_lib.GridSpec) == 40
+    assert C.sizeof(_lib.GridSpec) == 48  # + flags, reserved
     assert C.sizeof(_lib.Search) == 24
     assert C.sizeof(_lib.GridLayout) == 104  # + pool_* and pool4_* (branch-and-bound tables, levels 1 and 2)
 

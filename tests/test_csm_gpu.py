@@ -41,11 +41,17 @@ def _check_pairs(scans_list, target_ids, pair_src, pair_slot, theta0, spec, ospe
             for k_ in env:
                 os.environ.pop(k_, None)
         assert got_v.tobytes() == got.tobytes() and np.array_equal(sums_v, sums), env
-    if spec.cell_bits != 16:
-        # the kernel that performs every add and the branch-and-bound matcher return the same records
-        ex = csm.search_spec(search.n_theta, search.nx, search.ny, search.theta_step, exhaustive=True)
-        got_ex, sums_ex = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, ex, origin)
-        assert got_ex.tobytes() == got.tobytes() and np.array_equal(sums_ex, sums)
+    # the kernel that performs every add (csm_correlate_kernel / csm_correlate16_kernel by cell width) and the
+    # branch-and-bound matcher return the same records; so does that kernel with every zero strip added
+    ex = csm.search_spec(search.n_theta, search.nx, search.ny, search.theta_step, exhaustive=True)
+    got_ex, sums_ex = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, ex, origin)
+    assert got_ex.tobytes() == got.tobytes() and np.array_equal(sums_ex, sums)
+    os.environ["NHIP_CSM_DENSE"] = "1"
+    try:
+        got_d, sums_d = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, ex, origin)
+    finally:
+        os.environ.pop("NHIP_CSM_DENSE", None)
+    assert got_d.tobytes() == got.tobytes() and np.array_equal(sums_d, sums)
     ogr = O.grid_build_batch(xy, off, target_ids, ospec)
     oss = O.search_spec(search.n_theta, search.nx, search.ny, search.theta_step)
     want = O.csm_match_batch(xy, off, ogr, ospec, pair_src, pair_slot, theta0, oss, origin)
@@ -141,15 +147,68 @@ def test_match_full_lattice_recovers_ground_truth(gpu):
 
 def test_score_volume_bit_exact(gpu, small_bag):
     """Every one of the n_theta*nx*ny sums, not just the argmax; non-square plane."""
-    spec, ospec = _specs(max_shift=12)
+    for bits in (8, 16):
+        spec, ospec = _specs(max_shift=12, cell_bits=bits)
+        st = csm.ScanTable.from_list(small_bag.scans)
+        grids = csm.LikelihoodGrids(st, [12], spec)
+        search = csm.search_spec(5, 25, 9, 3 * DEG)
+        got = csm.score_volume(st, grids, 14, 0, 0.03, search)
+        want = O.csm_scores(small_bag.scans[14], O.grid_build(small_bag.scans[12], ospec), ospec, 0.03,
+                            O.search_spec(5, 25, 9, 3 * DEG))
+        assert np.array_equal(got, want)
+        assert got.max() > 0
+        grids.close()
+        st.close()
+
+
+def test_score_volume_16bit_full_plane_every_alignment_class(gpu, small_bag):
+    """csm_correlate16_kernel keeps two parity sets of (raw, hi) accumulators and four alignment classes (window start
+    column mod 4), with the cells left of a lane's 28 travelling to its neighbour: EVERY sum of full 81 x 81 planes
+    (all three lanes of a row, the neighbour exchanges, rows up to 80 = four strips) against the oracle, for search
+    centres that put the windows into each class, with the skip map and with every strip added."""
+    import os
+    spec, ospec = _specs(max_shift=44, cell_bits=16)
     st = csm.ScanTable.from_list(small_bag.scans)
     grids = csm.LikelihoodGrids(st, [12], spec)
-    search = csm.search_spec(5, 25, 9, 3 * DEG)
-    got = csm.score_volume(st, grids, 14, 0, 0.03, search)
-    want = O.csm_scores(small_bag.scans[14], O.grid_build(small_bag.scans[12], ospec), ospec, 0.03,
-                        O.search_spec(5, 25, 9, 3 * DEG))
+    og = O.grid_build(small_bag.scans[12], ospec)
+    search, oss = csm.search_spec(3, 81, 81, 2 * DEG), O.search_spec(3, 81, 81, 2 * DEG)
+    for origin in ((0, 0), (1, -2), (2, 3), (3, 1)):
+        want = O.csm_scores(small_bag.scans[14], og, ospec, -0.02, oss, origin)
+        got = csm.score_volume(st, grids, 14, 0, -0.02, search, origin)
+        assert np.array_equal(got, want), origin
+        assert want.max() > 65535 * 50
+    os.environ["NHIP_CSM_DENSE"] = "1"
+    try:
+        got = csm.score_volume(st, grids, 14, 0, -0.02, search, (3, 1))
+    finally:
+        os.environ.pop("NHIP_CSM_DENSE", None)
     assert np.array_equal(got, want)
-    assert got.max() > 0
+    grids.close()
+    st.close()
+
+
+def test_lattices_beyond_the_branch_and_bound_envelope_16bit(gpu, small_bag):
+    """solver.cc:633-638 accepts any doubles: at the default cell width (16 bits) lattices of more than 88 x 88
+    translations (here 97 x 101) or more rotations than the matcher's bounds fit in LDS (361 = +-180 degrees) take
+    csm_correlate16_kernel and return the oracle's records; a spec that asks for skip maps at build time and a handle
+    that builds them late agree."""
+    src, tgt, th0 = small_bag.sample_pairs(per_target=2, targets=[9, 30], min_sep=2)
+    ids = np.unique(tgt)
+    slot = np.searchsorted(ids, tgt)
+    spec, ospec = _specs(30.0, 0.05, 2.0, 60, cell_bits=16)
+    got, _ = _check_pairs(small_bag.scans, ids, src, slot, th0, spec, ospec, csm.search_spec(3, 97, 101, 2 * DEG))
+    got361, _ = _check_pairs(small_bag.scans, ids, src, slot, th0, spec, ospec, csm.search_spec(361, 9, 9, DEG))
+    st = csm.ScanTable.from_list(small_bag.scans)
+    with_map = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 60, 16, skip_map=True)
+    grids = csm.LikelihoodGrids(st, ids, with_map)
+    again, _ = csm.match_pairs(st, grids, src, slot, th0, csm.search_spec(3, 97, 101, 2 * DEG))
+    assert again.tobytes() == got.tobytes()
+    # the map behind a 16-bit image against its definition: rows [r, r + 21) x dwords [c, c + 42)
+    L = grids.layout
+    stored = grids.download(0)
+    got_map = grids.skip_map(0)
+    bits = np.unpackbits(got_map, axis=1, bitorder="little")[:, :L.pitch // 4]
+    assert np.array_equal(bits, skip_map_definition(stored.view(np.uint8).reshape(L.rows, L.pitch), width=42))
     grids.close()
     st.close()
 
@@ -488,18 +547,18 @@ def test_device_pointer_api_on_torch_stream(gpu, small_bag):
         assert not np.unpackbits(got_map, axis=1, bitorder="little")[:, L.pitch // 4:].any()
 
 
-def skip_map_definition(stored):
+def skip_map_definition(stored, width=21):
     """include/nautilus_hip.h (nhip_grid_layout_t.skip_bytes): bit (r, c) = any non-zero cell in stored rows
-    [r, r + 21) x aligned dwords [c, c + 21), clipped to the image."""
+    [r, r + 21) x aligned dwords [c, c + 21 * cell_bytes), clipped to the image.  stored: (rows, pitch) bytes."""
     rows, pitch = stored.shape
     nz = stored.reshape(rows, pitch // 4, 4).any(axis=2)
-    big = np.zeros((rows + 21, pitch // 4 + 21), dtype=np.int64)
+    big = np.zeros((rows + 21, pitch // 4 + width), dtype=np.int64)
     big[:rows, :pitch // 4] = nz
     I = np.zeros((big.shape[0] + 1, big.shape[1] + 1), dtype=np.int64)
     I[1:, 1:] = big.cumsum(0).cumsum(1)
     r = np.arange(rows)[:, None]
     c = np.arange(pitch // 4)[None, :]
-    cnt = I[r + 21, c + 21] - I[r, c + 21] - I[r + 21, c] + I[r, c]
+    cnt = I[r + 21, c + width] - I[r, c + width] - I[r + 21, c] + I[r, c]
     return (cnt > 0).astype(np.uint8)
 
 
@@ -654,7 +713,8 @@ def test_cell_width_against_unquantised_table(gpu):
     assert report[8][0] > report[16][0]
 
 
-def test_config4_per_gpu_share(gpu):
+@pytest.mark.parametrize("cell_bits", [16, 8])
+def test_config4_per_gpu_share(gpu, cell_bits):
     """BASELINE configs[3] (10k scans, 1M pairs over 8 GPUs) at one GPU's share: 1250 scans, 125,000 candidate pairs
     (100 per target) through bench.py's own sharded step at world size 1.  Checks: the branch-and-bound matcher and
     the kernel that performs every add return the same 125,000 records and sums; an oracle sample is bit-exact;
@@ -675,19 +735,19 @@ def test_config4_per_gpu_share(gpu):
     wl.tgt[50:100] = wl.tgt[100:150]
     plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
     dev = torch.device("cuda", 0)
-    m = bench.HipMatcher(wl, plan.shard(0), dev, 8)
+    m = bench.HipMatcher(wl, plan.shard(0), dev, cell_bits)
     elapsed, full = bench.run_sharded(plan, 0, 1, dev, m, steps=1, warmup=0)
     rec = full.cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
     sums = np.empty(wl.n_pairs, np.int32)
     sums[plan.order] = m.d_sums[:m.n_pairs].cpu().numpy()
     m.free_grids()
-    mx = bench.HipMatcher(wl, plan.shard(0), dev, 8, exhaustive=True)
+    mx = bench.HipMatcher(wl, plan.shard(0), dev, cell_bits, exhaustive=True)
     _, full_x = bench.run_sharded(plan, 0, 1, dev, mx, steps=1, warmup=0)
     assert torch.equal(full, full_x), "branch and bound differs from the exhaustive kernel"
     mx.free_grids()
     os.environ["NHIP_BNB_KERNELS"] = "2"  # candidates of all pairs through the grid-wide lists (default: small batches only)
     try:
-        m1 = bench.HipMatcher(wl, plan.shard(0), dev, 8)
+        m1 = bench.HipMatcher(wl, plan.shard(0), dev, cell_bits)
         _, full_1 = bench.run_sharded(plan, 0, 1, dev, m1, steps=1, warmup=0)
         assert torch.equal(full, full_1), "one-kernel and two-kernel forms differ"
         m1.free_grids()
@@ -696,15 +756,70 @@ def test_config4_per_gpu_share(gpu):
     # self pairs: rotation 0 (k = 30), no shift (ix = iy = 40)
     assert np.all(rec["itheta"][:50] == 30) and np.all(rec["ix"][:50] == 40) and np.all(rec["iy"][:50] == 40)
     assert rec[50:100].tobytes() == rec[100:150].tobytes()
-    Lf, step = math.log(1e-10), -math.log(1e-10) / 255.0
+    Lf, step = math.log(1e-10), -math.log(1e-10) / (255.0 if cell_bits == 8 else 65535.0)
     assert np.array_equal(rec["score"], (Lf + step * sums.astype(np.float64) / 1081.0).astype(np.float32))
     assert np.all((rec["itheta"] >= 0) & (rec["itheta"] < 61) & (rec["ix"] >= 0) & (rec["ix"] < 81) & (rec["iy"] < 81))
     # oracle sample
     sel = np.r_[0:4, 60:64, np.random.default_rng(0).choice(wl.n_pairs, 40, replace=False)]
-    ospec, oss = O.grid_spec(), O.search_spec(61, 81, 81, DEG)
+    ospec, oss = O.grid_spec(cell_bits=cell_bits), O.search_spec(61, 81, 81, DEG)
     ids = np.unique(wl.tgt[sel])
     og = O.grid_build_batch(wl.xy, wl.off, ids, ospec)
     want = O.csm_match_batch(wl.xy, wl.off, og, ospec, wl.src[sel], np.searchsorted(ids, wl.tgt[sel]), wl.th0[sel], oss)
     for f in ("itheta", "ix", "iy"):
         assert np.array_equal(rec[f][sel], want[f])
     assert np.array_equal(sums[sel], want["sum"])
+
+
+def test_config2_full_size_16bit_branch_and_bound_equals_every_add(gpu):
+    """BASELINE configs[1] at full size and at the cell width of the headline (16 bits): 1,000 dense 1081-beam scans,
+    10,000 candidate pairs, 61 x 81 x 81 lattice, 1200 x 1200 tables -- the branch-and-bound matcher (the product path
+    bench.py times) and csm_correlate16_kernel (every add of the exhaustive definition) return the same 10,000 records
+    and integer sums, byte for byte; a sample agrees with the oracle."""
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from nautilus_amd import sharding
+    wl = bench.Workload("weak", 1)
+    assert wl.n_pairs == 10000 and wl.n_scans == 1000
+    plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
+    dev = torch.device("cuda", 0)
+    m = bench.HipMatcher(wl, plan.shard(0), dev, 16)
+    _, full = bench.run_sharded(plan, 0, 1, dev, m, steps=1, warmup=0)
+    sums = m.d_sums[:m.n_pairs].clone()
+    m.free_grids()
+    mx = bench.HipMatcher(wl, plan.shard(0), dev, 16, exhaustive=True)
+    _, full_x = bench.run_sharded(plan, 0, 1, dev, mx, steps=1, warmup=0)
+    assert torch.equal(full, full_x), "branch and bound differs from the kernel that performs every add (16-bit cells)"
+    assert torch.equal(sums, mx.d_sums[:mx.n_pairs])
+    mx.free_grids()
+    rec = full.cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
+    hsums = np.empty(wl.n_pairs, np.int32)
+    hsums[plan.order] = sums.cpu().numpy()
+    sel = np.random.default_rng(1).choice(wl.n_pairs, 24, replace=False)
+    ospec, oss = O.grid_spec(cell_bits=16), O.search_spec(61, 81, 81, DEG)
+    ids = np.unique(wl.tgt[sel])
+    og = O.grid_build_batch(wl.xy, wl.off, ids, ospec)
+    want = O.csm_match_batch(wl.xy, wl.off, og, ospec, wl.src[sel], np.searchsorted(ids, wl.tgt[sel]), wl.th0[sel], oss)
+    for f in ("itheta", "ix", "iy"):
+        assert np.array_equal(rec[f][sel], want[f])
+    assert np.array_equal(hsums[sel], want["sum"])
+    assert np.array_equal(rec["score"][sel], want["score"].astype(np.float32))
+
+
+def test_drop_in_call_with_rotation_restriction_pi(gpu, small_bag):
+    """/root/reference/src/optimization/solver.cc:633-638 passes DegToRad(90); the class accepts any restriction.  At
+    the drop-in's default cell width a restriction of pi (361 coarse rotations: beyond what the branch-and-bound
+    matcher's bounds fit in LDS) and a constructor with trans_range / low_res > 44 (97 x 97 coarse translations) go
+    through csm_correlate16_kernel and agree with the oracle's two-level restatement, float for float."""
+    a, b = small_bag.scans[17][::3], small_bag.scans[15][::3]
+    rot_a, rot_b = small_bag.odom[17, 2], small_bag.odom[15, 2]
+    m = csm.CorrelativeScanMatcher(30, 2, 0.3, 0.01)
+    got = m.GetTransformation(a, b, rot_a, rot_b, math.pi)
+    want = O.two_level_match(a, b, rot_a, rot_b, math.pi, 30.0, 2.0, 0.3, 0.01, cell_bits=16)
+    assert got[0] == want[0] and got[1][0][0] == want[1][0][0] and got[1][0][1] == want[1][0][1] and got[1][1] == want[1][1]
+    m2 = csm.CorrelativeScanMatcher(30, 4.8, 0.1, 0.05)   # coarse level: +-48 cells
+    got = m2.GetTransformation(a, b, rot_a, rot_b, math.radians(30))
+    want = O.two_level_match(a, b, rot_a, rot_b, math.radians(30), 30.0, 4.8, 0.1, 0.05, cell_bits=16)
+    assert got[0] == want[0] and got[1][0][0] == want[1][0][0] and got[1][0][1] == want[1][0][1] and got[1][1] == want[1][1]
