@@ -381,7 +381,7 @@ def worker(a):
     oc = onchip_roofline(m.n_pairs, avg_ms, a.cell_bits)
     traffic = _traffic("csm_bnb_bytes_per_launch_%dpairs_u%d" % (m.n_pairs, a.cell_bits))
     bnb = None
-    if os.environ.get("NHIP_BNB_STATS") == "1":
+    if os.environ.get("NHIP_BNB_STATS") == "1" and os.environ.get("NHIP_BNB_INSTRUMENT") == "1":
         lv = csm.bnb_stats_levels()
         launches = max(m.n_pairs * (a.steps + a.warmup), 1)
         ev = lv["blocks_whole"] + lv["sub_blocks"] / 4.0

@@ -90,8 +90,8 @@ typedef struct nhip_grid_layout {
                           so the correlation kernel can leave out window strips that only add zeros (same
                           sums, bit for bit).  Built for 8-bit cells always, for 16-bit cells when the spec carries
                           NHIP_GRID_SKIP_MAP (the branch-and-bound matcher never reads it); zero otherwise */
-  int64_t slot_bytes;  /* grid_bytes + skip_bytes + pool_bytes + pool4_bytes: grid t of a buffer starts at byte
-                          t*slot_bytes */
+  int64_t slot_bytes;  /* grid_bytes + skip_bytes + pool_bytes + pool4_bytes + hi_bytes: grid t of a buffer starts at
+                          byte t*slot_bytes */
   int64_t pool_bytes;  /* bytes of the max-pooled table stored after the skip map (branch-and-bound bounds):
                           pool_rows x pool_pitch bytes, entry (i, j) = max of stored cells [8i, 8i+15) x [8j, 8j+15)
                           (16-bit cells: ceil(max / 257)), so that the sum of pooled entries bounds every score of
@@ -104,6 +104,13 @@ typedef struct nhip_grid_layout {
                           byte (i, 2j+1) holds P4[i+1][j]: one read returns both sub-block rows */
   int32_t pool4_pitch;
   int32_t pool4_rows;
+  int64_t hi_bytes;    /* 16-bit cells only (else 0): after the second table, the plane of the cells' HIGH BYTES, rows x
+                          hi_pitch bytes, byte (r+pad)*hi_pitch + (c+pad) = cell (r, c) >> 8.  The branch-and-bound matcher
+                          takes its exact block sums on this plane at the cost of 8-bit cells -- 256*sum(high bytes) +
+                          255*points bounds a pose's 16-bit sum from above -- and reads 16-bit cells for the few poses
+                          whose bound still reaches the best sum: same records, bit for bit */
+  int32_t hi_pitch;
+  int32_t reserved;
 } nhip_grid_layout_t;
 
 /* Pure host helpers (work without a GPU). */
@@ -317,6 +324,8 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
 int nhip_grids_free(nhip_grids_t *grids);
 /* copy stored (padded) grid `slot` to host: layout.grid_bytes bytes (uint8 or uint16 cells) */
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
+/* copy the plane of high bytes of grid `slot` (16-bit cells) to host: layout.hi_bytes bytes (rows x hi_pitch) */
+int nhip_grids_download_hi_plane(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* copy the skip map of grid `slot` to host: layout.skip_bytes bytes (rows x 8*ceil(pitch/256) bytes, then padding) */
 int nhip_grids_download_skip_map(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* copy the max-pooled table of grid `slot` to host: layout.pool_bytes bytes (pool_rows x pool_pitch) */

@@ -36,7 +36,8 @@ class GridLayout(C.Structure):
                 ("grid_bytes", C.c_int64), ("score_floor", C.c_double), ("score_step", C.c_double),
                 ("skip_bytes", C.c_int64), ("slot_bytes", C.c_int64), ("pool_bytes", C.c_int64),
                 ("pool_pitch", C.c_int32), ("pool_rows", C.c_int32), ("pool4_bytes", C.c_int64),
-                ("pool4_pitch", C.c_int32), ("pool4_rows", C.c_int32)]
+                ("pool4_pitch", C.c_int32), ("pool4_rows", C.c_int32), ("hi_bytes", C.c_int64),
+                ("hi_pitch", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Search(C.Structure):
@@ -100,6 +101,7 @@ PROTOTYPES = {
     "nhip_grids_free": (C.c_int, [_vp]),
     "nhip_grids_download": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_skip_map": (C.c_int, [_vp, _i32, _vp]),
+    "nhip_grids_download_hi_plane": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_pool": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_pool4": (C.c_int, [_vp, _i32, _vp]),
     "nhip_csm_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _P(Search), _vp, _vp]),

@@ -110,6 +110,13 @@ class LikelihoodGrids:
         check(_lib.load().nhip_grids_download(self._h, int(slot), ptr(out)))
         return out.view(np.uint16) if L.cell_bytes == 2 else out
 
+    def hi_plane(self, slot):
+        """16-bit grids: the stored plane of the cells' high bytes, (rows, hi_pitch) uint8."""
+        L = self.layout
+        out = np.empty((L.rows, L.hi_pitch), dtype=np.uint8)
+        check(_lib.load().nhip_grids_download_hi_plane(self._h, int(slot), ptr(out)))
+        return out
+
     def skip_map(self, slot):
         """The slot's skip map as (rows, bytes per map row) uint8: bit c & 7 of byte c >> 3 of row r = "stored rows
         [r, r + 21) x aligned dwords [c, c + 21 * cell_bytes) hold a non-zero cell"."""

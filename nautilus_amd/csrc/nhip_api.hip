@@ -71,7 +71,12 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   L->pool4_rows = (L->S + 2 * L->pad + BNB_B4 - 1) / BNB_B4 + 2 * BNB_MAX_NB + 2;
   L->pool4_pitch = ((2 * ((L->S + 2 * L->pad + BNB_B4 - 1) / BNB_B4 + 2 * BNB_MAX_NB + 2) + 16) + 15) & ~15;
   L->pool4_bytes = (int64_t)L->pool4_rows * L->pool4_pitch;
-  L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes;
+  // 16-bit cells: the plane of their high bytes, one byte per cell at the 8-bit pitch.  The matcher sums exact 8 x 8
+  // and 4 x 4 blocks on this plane at the cost of 8-bit cells (256 * sum(hi) + 255 * points bounds a pose's sum from
+  // above) and reads 16-bit cells only for the poses that bound still admits (nhip_bnb.hip)
+  L->hi_pitch = L->cb == 2 ? (((L->S + 2 * L->pad) + 15) & ~15) : 0;
+  L->hi_bytes = (int64_t)L->hi_pitch * (int64_t)(L->S + 2 * L->pad);
+  L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes + L->hi_bytes;
   L->Lf = log(spec->floor_p);
   L->step = -L->Lf / (double)L->levels;
   // integer taps: round(16384 * g_i / sum g)
@@ -285,6 +290,9 @@ int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out) {
   out->pool4_bytes = L.pool4_bytes;
   out->pool4_pitch = L.pool4_pitch;
   out->pool4_rows = L.pool4_rows;
+  out->hi_bytes = L.hi_bytes;
+  out->hi_pitch = L.hi_pitch;
+  out->reserved = 0;
   return NHIP_OK;
 }
 
@@ -618,6 +626,16 @@ int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download: bad arguments");
   NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * grids->L.slot_bytes,
                          (size_t)grids->L.grid_bytes, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_grids_download_hi_plane(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
+  NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_hi_plane: bad arguments");
+  const GridLayout &L = grids->L;
+  NHIP_REQUIRE(L.hi_bytes > 0, "grids_download_hi_plane: 8-bit grids have no plane of high bytes");
+  NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes +
+                                  L.skip_bytes + L.pool_bytes + L.pool4_bytes,
+                         (size_t)L.hi_bytes, hipMemcpyDeviceToHost));
   return NHIP_OK;
 }
 

@@ -26,11 +26,41 @@
 //
 // One 512-thread workgroup per pair; waves take rotations k = wave, wave + 8, ...; LDS holds the target's
 // pooled table (36 KB at 1200 x 1200) and the bounds (n_theta x 128 dwords).
-#include "nhip_common.h"
+#include <atomic>
+#include <mutex>
+
+#include "nhip_bnb_params.h"
+
+// This file is compiled twice.  NHIP_BNB_INSTR = 0 (nhip_bnb.hip itself): the product kernels -- no statistics, no
+// timestamps, no debug switches in the code -- and the host side.  NHIP_BNB_INSTR = 1 (nhip_bnb_instr.hip includes this
+// file): the same kernels with the instrumentation compiled in, launched only when NHIP_BNB_INSTRUMENT=1 is set in
+// the environment (tools/bnb_*.py, the tests that count evaluated blocks, bench.py's algorithm.stats).
+#ifndef NHIP_BNB_INSTR
+#define NHIP_BNB_INSTR 0
+#endif
+#ifndef NHIP_BNB_RS_DPP
+#define NHIP_BNB_RS_DPP 1   // 0: every step beyond the quad through ds_bpermute (measurement)
+#endif
+#ifndef NHIP_BNB_F32_ORIGINS
+#define NHIP_BNB_F32_ORIGINS 1  // 0: window origins through two double-precision quotients (measurement)
+#endif
+#if NHIP_BNB_INSTR
+#define csm_bnb_kernel csm_bnb_kernel_instr          // (their own names in profiles)
+#define csm_bnb_rot_kernel csm_bnb_rot_kernel_instr
+#define BNB_STATS(P) ((P).stats)
+#define BNB_TIMELINE(P) ((P).timeline)
+#define BNB_DEBUG(P) ((P).debug)
+#else
+#define BNB_STATS(P) (static_cast<unsigned long long *>(nullptr))
+#define BNB_TIMELINE(P) (static_cast<unsigned long long *>(nullptr))
+#define BNB_DEBUG(P) 0
+#endif
 
 namespace nhip {
 
 namespace {
+
+using namespace bnb;
 
 constexpr int BNB_WAVES = 8;
 constexpr int BNB_THREADS = 64 * BNB_WAVES;
@@ -46,44 +76,25 @@ constexpr uint32_t M8 = 0x00ff00ffu;
 constexpr int BNB_STATS_PAIRS = 1 << 20;
 constexpr int BNB_STATS_HEAD = 16;       // totals: 4 counts, then shader-clock sums of the by-rotation kernel (see nhip_bnb_stats_levels)  // per-pair counters kept by NHIP_BNB_STATS=1
 
-// One rotation of a pair with many candidates, handed to the second kernel: (pair, rotation) and the mask of its
-// 121 candidate blocks.
-struct RotEntry {
-  unsigned long long w[4];  // w[0]: pair << 24 | rotation; w[1..3]: candidate blocks 0..40, 41..81, 82..120
-};
-
-struct BnbParams {
-  const float2 *xy;
-  const int32_t *offsets;
-  const uint8_t *grids;
-  const int32_t *pair_src;
-  const int32_t *pair_slot;
-  const double *rot0_cs;
-  const double *delta_cs;
-  const int32_t *pair_origin;
-  unsigned long long *keys;
-  unsigned long long *timeline;  // optional (NHIP_BNB_TIMELINE=1): per pair 4 x 100 MHz ticks: start, bounds, seeds, end
-  unsigned long long *stats;  // optional: [0] blocks evaluated whole, [1] blocks in all, [2] candidates refined,
-                              //   [3] 4 x 4 sub-blocks evaluated; then one count of candidates per pair
-  RotEntry *rot_list;          // optional lists of (pair, rotation) work items in the caller's workspace, one per XCD so
-  uint32_t *rot_count;        //   that a pair's rotations are worked where its grid is L2-resident; per XCD 32 bytes of
-  uint32_t rot_cap;           //   counters {filled, next}; entries per list
-  uint32_t heavy_min;         // candidates (after the seeds) from which a PAIR hands its rotations over ...
-  uint32_t keep_ranks;        // ... except its first keep_ranks rotations in best-first order (one per wave)
-  int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
-  int32_t S, pad, pitch, rows, max_shift;
-  int32_t pool_pitch, pool_rows, pairs_per_xcd;
-  int32_t pool4_pitch;
-  int32_t lds_first;    // bytes of the kernel's first LDS region: max(pooled table if staged, origins)
-  int32_t whole_min;    // sub-blocks alive from which an 8-bit block is evaluated whole (3; NHIP_BNB_WHOLE_MIN)
-  int32_t general_all;  // the general instantiation takes every pair (NHIP_BNB_QUEUE=1)
-  int32_t levels;  // 2: candidates are refined through the 4 x 4 sub-block bounds; 1: evaluated whole (NHIP_BNB_LEVELS)
-  int32_t debug;   // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only,
-                   // 4 = phase 3 without exact sums, 5 = phase 3 without sub-block bounds and exact sums,
-                   // 26 / 27 = bounds only, without their reductions / gathers
-  int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes, pool4_bytes;
-  double res, inv_res;
-};
+// floor(double(v) / res) clamped to [lo, hi], as the spec defines it (cimg_debug.h:31-37: float promoted to double,
+// double division) -- from single-precision arithmetic.  m = RN(v * RN_f32(1 / res)) differs from the true quotient q
+// by at most |q| * 2^-23 (one rounding of the reciprocal, one of the product), and the spec's RN_double(q) by 2^-53 |q|
+// more: the floors can differ only if m lies within that distance of an integer.  Lanes within |m| * 2^-22 of one
+// (twice the bound; about one coordinate in 2,000 on the 1200-cell grid) take the double-precision path, so the result
+// is the spec's, always.  From |m| >= 2^22 on (no fraction bits left to test) the cell is far outside any grid
+// (sides <= 16384) on either path and the clamp decides; v_cvt_i32_f32 saturates.
+__device__ __forceinline__ int32_t cell_floor(float v, const BnbParams &P, int32_t lo, int32_t hi) {
+  const float m = __fmul_rn(v, P.inv_res_f);
+  const float f = floorf(m);
+  const float frac = __fsub_rn(m, f);  // exact
+  const float tol = __fmul_rn(fabsf(m), 0x1p-22f);
+  int32_t c = (int32_t)f;
+  if (!NHIP_BNB_F32_ORIGINS || (fabsf(m) < 0x1p22f && (frac <= tol || __fsub_rn(1.0f, frac) <= tol))) {
+    const double d = floor_quotient((double)v, P.res, P.inv_res);
+    c = (int32_t)fmin(fmax(d, -2147483000.0), 2147483000.0);
+  }
+  return min(max(c, lo), hi);
+}
 
 // Window origin (stored-grid row, column of the top-left lookup cell) of point q under rotation (cf, sf): the
 // same arithmetic as window_cell of nhip_csm.hip (spec: DESIGN.md section 3, items 1 and 3).
@@ -94,13 +105,10 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
   int32_t col = -P.hx - 1, row = -P.hy - 1;  // non-finite points score nothing
   if ((fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f)) {
     // col = clamp(S / 2 + floor(xr / res) + cx, -hx - 1, S + hx), as window_cell of nhip_csm.hip -- with the clamp
-    // applied to the (integer-valued) double before the conversion, so that the rest is 32-bit arithmetic
+    // applied to the quotient's floor, so that everything stays in 32-bit arithmetic
     const int32_t half = P.S / 2;
-    double fx = floor_quotient((double)xr, P.res, P.inv_res), fy = floor_quotient((double)yr, P.res, P.inv_res);
-    fx = fmin(fmax(fx, (double)(-P.hx - 1 - half - cx)), (double)(P.S + P.hx - half - cx));
-    fy = fmin(fmax(fy, (double)(-P.hy - 1 - half - cy)), (double)(P.S + P.hy - half - cy));
-    col = half + (int32_t)fx + cx;
-    row = half + (int32_t)fy + cy;
+    col = half + cell_floor(xr, P, -P.hx - 1 - half - cx, P.S + P.hx - half - cx) + cx;
+    row = half + cell_floor(yr, P, -P.hy - 1 - half - cy, P.S + P.hy - half - cy) + cy;
   }
   *pcol = col - P.hx + P.pad;
   *prow = row - P.hy + P.pad;
@@ -137,8 +145,14 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64b(unsigned long long v
 
 // One step of a transposing reduction over the lanes: lanes pair up across MASK; of every two registers the
 // lane keeps the one its own bit selects, adds the partner's copy of the same register, and gives the other away.
-// N registers in, N / 2 out.  Partners inside a quad (MASK 1, 2) are reached with a DPP quad permutation -- no LDS
-// round trip; the others with ds_bpermute.
+// N registers in, N / 2 out.  No step goes through LDS:
+//   MASK 1, 2   partners inside a quad: DPP quad permutation fused into the add;
+//   MASK 4, 8   partners inside a row of 16 lanes: two DPP adds with complementary BANK masks (a bank = 4 lanes) --
+//               lanes whose bit is clear add register 2i of the lane MASK above (row_ror:16 - MASK), the others
+//               register 2i + 1 of the lane MASK below (row_ror:MASK); no select instructions at all;
+//   MASK 16, 32 partners in another row / the other half of the wave: v_permlane16_swap / v_permlane32_swap
+//               exchange the odd rows (upper half) of register 2i with the even rows (lower half) of register
+//               2i + 1, after which the two registers hold own and partner's copy lane by lane: one add.
 template <int MASK>
 __device__ __forceinline__ uint32_t shfl_xor_c(uint32_t v) {
   if (MASK == 1) return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, 0xB1, 0xF, 0xF, true);  // quad_perm [1, 0, 3, 2]
@@ -146,15 +160,54 @@ __device__ __forceinline__ uint32_t shfl_xor_c(uint32_t v) {
   return shfl_xor_u32(v, MASK);
 }
 
+template <int MASK>
+__device__ __forceinline__ uint32_t rs_pair(uint32_t x, uint32_t y, bool bit) {
+  if (NHIP_BNB_RS_DPP && MASK == 4) {
+    uint32_t r;
+    // (s_nop 1: a DPP operand written by the previous vector instruction needs two wait states)
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
+                 "v_add_u32_dpp %0, %2, %2 row_ror:4 row_mask:0xf bank_mask:0xa"
+                 : "=&v"(r) : "v"(x), "v"(y));
+    return r;
+  }
+  if (NHIP_BNB_RS_DPP && MASK == 8) {
+    uint32_t r;
+    asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
+                 "v_add_u32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
+                 : "=&v"(r) : "v"(x), "v"(y));
+    return r;
+  }
+  if (NHIP_BNB_RS_DPP && MASK == 16) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(x, y, false, false);
+    return sw[0] + sw[1];
+  }
+  if (NHIP_BNB_RS_DPP && MASK == 32) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
+    return sw[0] + sw[1];
+  }
+  const uint32_t keep = bit ? y : x, send = bit ? x : y;
+  return keep + shfl_xor_c<MASK>(send);
+}
+
 template <int N, int MASK, int CAP>
 __device__ __forceinline__ void rs_step(uint32_t (&R)[CAP], bool bit) {
   static_assert(N <= CAP, "rs_step: more registers than the array holds");
 #pragma unroll
-  for (int i = 0; i < N / 2; i++) {
-    const uint32_t keep = bit ? R[2 * i + 1] : R[2 * i];
-    const uint32_t send = bit ? R[2 * i] : R[2 * i + 1];
-    R[i] = keep + shfl_xor_c<MASK>(send);
+  for (int i = 0; i < N / 2; i++) R[i] = rs_pair<MASK>(R[2 * i], R[2 * i + 1], bit);
+}
+
+// sum over the lane pairs MASK apart of one register (the tail of a reduction whose copies may coincide)
+template <int MASK>
+__device__ __forceinline__ uint32_t add_xor(uint32_t v) {
+  if (NHIP_BNB_RS_DPP && MASK == 16) {
+    const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return sw[0] + sw[1];
   }
+  if (NHIP_BNB_RS_DPP && MASK == 32) {
+    const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return sw[0] + sw[1];
+  }
+  return v + shfl_xor_u32(v, MASK);
 }
 
 // ---- bounds of one rotation ------------------------------------------------------------------------------
@@ -269,7 +322,12 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
         a = (uint32_t)((prow >> 3) * DP + (pcol >> 3));
       }
       // runs of equal offsets inside groups of RUN_MAX lanes
+      // (the predecessor inside the row of 16 lanes: a DPP shift, no LDS round trip; a row's first lane is a head anyway)
+#if NHIP_BNB_RS_DPP
+      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
+#else
       const uint32_t prev = (uint32_t)__shfl_up((int)a, 1, 64);
+#endif
       const bool is_head = (lane & (RUN_MAX - 1)) == 0 || a != prev;
       const unsigned long long H = __ballot(is_head);
       const uint32_t Hh = (lane & 32) ? (uint32_t)(H >> 32) : (uint32_t)H;  // the half of H that holds the lane's group
@@ -289,10 +347,10 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
     while (tail - head >= 64u || (!more && (tail != head || passes != 0))) {
       const uint32_t avail = tail - head;
       // (lanes past the list gather the zero rows with length 0)
-      if (P.debug != 27) gather((uint32_t)lane < avail ? list[(head + (uint32_t)lane) & (LIST_ENTRIES - 1)] : zero_a);
+      if (BNB_DEBUG(P) != 27) gather((uint32_t)lane < avail ? list[(head + (uint32_t)lane) & (LIST_ENTRIES - 1)] : zero_a);
       head += avail < 64u ? avail : 64u;
       passes++;
-      if ((passes == SEG_PASSES || (!more && tail == head)) && P.debug != 26) {
+      if ((passes == SEG_PASSES || (!more && tail == head)) && BNB_DEBUG(P) != 26) {
         reduce();
         passes = 0;
       }
@@ -572,8 +630,8 @@ __device__ __forceinline__ unsigned long long eval_sub(const BnbParams &P, __amd
       rs_step<2, 4>(R, lane & 4);
       uint32_t V[2] = {R[0] & 0xffffu, R[0] >> 16};
       rs_step<2, 8>(V, lane & 8);
-      V[0] += shfl_xor_u32(V[0], 16);
-      V[0] += shfl_xor_u32(V[0], 32);
+      V[0] = add_xor<16>(V[0]);
+      V[0] = add_xor<32>(V[0]);
       total += V[0];
     }
     dy = ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1);
@@ -616,8 +674,8 @@ __device__ __forceinline__ unsigned long long eval_sub(const BnbParams &P, __amd
     rs_step<8, 2>(A, lane & 2);
     rs_step<4, 4>(A, lane & 4);
     rs_step<2, 8>(A, lane & 8);
-    A[0] += shfl_xor_u32(A[0], 16);
-    A[0] += shfl_xor_u32(A[0], 32);
+    A[0] = add_xor<16>(A[0]);
+    A[0] = add_xor<32>(A[0]);
     total = A[0];  // lane l holds A[l & 15]
     dy = (lane >> 2) & 3;
     dx = lane & 3;
@@ -749,121 +807,80 @@ __device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buff
   for (int q = 0; q < 12; q++) out[q] *= scale;
 }
 
-template <int CB>
-__device__ __forceinline__ unsigned long long eval_sub_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
-                                                         const uint32_t *org, int32_t nch, int32_t k, int32_t Y,
-                                                         int32_t X, int32_t sy, int32_t sx, int lane) {
-  uint32_t total;
-  int dy, dx;
-  const uint32_t pitch = (uint32_t)P.pitch;
-  const uint32_t off = (uint32_t)(BNB_B * Y + BNB_B4 * sy) * pitch + (uint32_t)(BNB_B * X + BNB_B4 * sx) * (uint32_t)CB;
+// ---- the pair's running best
+template <bool GLOBAL>
+__device__ __forceinline__ uint32_t best_sum(unsigned long long *best) {
+  unsigned long long b;
+  if (GLOBAL) b = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  else b = *(volatile unsigned long long *)best;
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));  // one value for the whole wave
+}
+// The pair's own workgroup keeps its best in LDS (GLOBAL = false: csm_bnb_kernel); the takers of handed-over
+// rotations share it through keys[pair] (GLOBAL = true: csm_bnb_rot_kernel).  Between two looks at a best that
+// lives in global memory (a device-scope atomic load: microseconds under load) a taker works with its copy, raised
+// by its own finds; a stale copy only costs pruning, never the result.
+template <bool GLOBAL>
+__device__ __forceinline__ uint32_t best_sum_cached(unsigned long long *best, uint32_t copy) {
+  return GLOBAL ? copy : best_sum<false>(best);
+}
+
+// Exact sums on an 8-BIT plane (the stored image of 8-bit grids; the plane of high bytes of 16-bit grids) of pitch
+// `pitch`, for the rotation whose origins the wave holds.
+// 4 x 4 sub-block (sy, sx) of block (Y, X): four 8-byte row loads per point.  Returns the sum of this lane's pose
+// (*dy, *dx inside the sub-block; lanes 16.. hold copies of lanes 0..15).
+__device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint32_t pitch, const uint32_t *org, int32_t nch,
+                                              int32_t Y, int32_t X, int32_t sy, int32_t sx, int lane, int *dy, int *dx) {
+  const uint32_t off = (uint32_t)(BNB_B * Y + BNB_B4 * sy) * pitch + (uint32_t)(BNB_B * X + BNB_B4 * sx);
 #ifndef NHIP_BNB_SUB_U8
 #define NHIP_BNB_SUB_U8 6
 #endif
-#ifndef NHIP_BNB_SUB_U16
-#define NHIP_BNB_SUB_U16 3
-#endif
-  constexpr int U = CB == 1 ? NHIP_BNB_SUB_U8 : NHIP_BNB_SUB_U16;  // chunks per round: 4 U row loads in flight
+  constexpr int U = NHIP_BNB_SUB_U8;  // chunks per round: 4 U row loads in flight
   static_assert(OC % U == 0, "whole rounds");
-  if (CB == 1) {
-    // (18 chunks * 255 * 8 lanes < 65536: the packed fields hold a whole scan)
-    uint32_t E[4] = {0u, 0u, 0u, 0u}, O[4] = {0u, 0u, 0u, 0u};
+  // (18 chunks * 255 * 8 lanes < 65536: the packed fields hold a whole scan)
+  uint32_t E[4] = {0u, 0u, 0u, 0u}, O[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
-    for (int r = 0; r < OC / U; r++) {
-      if (U * r >= nch) continue;
-      u32x2 w[U][4];
-      uint32_t sh[U];
+  for (int r = 0; r < OC / U; r++) {
+    if (U * r >= nch) continue;
+    u32x2 w[U][4];
+    uint32_t sh[U];
 #pragma unroll
-      for (int j = 0; j < U; j++) {
-        const uint32_t o = origin_of(org, U * r + j);
-        const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
-        sh[j] = (g & 3u) * 8u;
+    for (int j = 0; j < U; j++) {
+      const uint32_t o = origin_of(org, U * r + j);
+      const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
+      sh[j] = (g & 3u) * 8u;
 #pragma unroll
-        for (int y = 0; y < 4; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
+      for (int y = 0; y < 4; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < U; j++)
+#pragma unroll
+      for (int y = 0; y < 4; y++) {
+        const uint32_t n = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+        E[y] += n & M8;
+        O[y] += n >> 8;
       }
-#pragma unroll
-      for (int j = 0; j < U; j++)
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-          const uint32_t n = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
-          E[y] += n & M8;
-          O[y] += n >> 8;
-        }
-    }
-    uint32_t R[8];  // R[2 y + d]: d = 0: dx 0, 2; d = 1: dx 1, 3
-#pragma unroll
-    for (int y = 0; y < 4; y++) {
-      R[2 * y] = E[y];
-      R[2 * y + 1] = O[y] - ((E[y] >> 16) << 8);
-    }
-    rs_step<8, 1>(R, lane & 1);
-    rs_step<4, 2>(R, lane & 2);
-    rs_step<2, 4>(R, lane & 4);
-    uint32_t V[2] = {R[0] & 0xffffu, R[0] >> 16};
-    rs_step<2, 8>(V, lane & 8);
-    V[0] += shfl_xor_u32(V[0], 16);
-    V[0] += shfl_xor_u32(V[0], 32);
-    total = V[0];
-    dy = ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1);
-    dx = (lane & 1) + 2 * ((lane >> 3) & 1);
-  } else {
-    uint32_t A[16];  // A[4 y + x]
-#pragma unroll
-    for (int i = 0; i < 16; i++) A[i] = 0u;
-#pragma unroll
-    for (int r = 0; r < OC / U; r++) {
-      if (U * r >= nch) continue;
-      u32x3 w[U][4];
-      uint32_t sh[U];
-#pragma unroll
-      for (int j = 0; j < U; j++) {
-        const uint32_t o = origin_of(org, U * r + j);
-        const uint32_t g = (o >> 16) * pitch + 2u * (o & 0xffffu) + off;
-        sh[j] = (g & 2u) * 8u;
-#pragma unroll
-        for (int y = 0; y < 4; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
-      }
-#pragma unroll
-      for (int j = 0; j < U; j++)
-#pragma unroll
-        for (int y = 0; y < 4; y++) {
-          const uint32_t n0 = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
-          const uint32_t n1 = __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
-          A[4 * y + 0] += n0 & 0xffffu;
-          A[4 * y + 1] += n0 >> 16;
-          A[4 * y + 2] += n1 & 0xffffu;
-          A[4 * y + 3] += n1 >> 16;
-        }
-    }
-    rs_step<16, 1>(A, lane & 1);
-    rs_step<8, 2>(A, lane & 2);
-    rs_step<4, 4>(A, lane & 4);
-    rs_step<2, 8>(A, lane & 8);
-    A[0] += shfl_xor_u32(A[0], 16);
-    A[0] += shfl_xor_u32(A[0], 32);
-    total = A[0];  // lane l holds A[l & 15]
-    dy = (lane >> 2) & 3;
-    dx = lane & 3;
   }
-  const int32_t ix = BNB_B * X + BNB_B4 * sx + dx, iy = BNB_B * Y + BNB_B4 * sy + dy;
-  unsigned long long key = 0ull;
-  if (ix < P.nx && iy < P.ny) {
-    const uint32_t lin = (uint32_t)((k * P.nx + ix) * P.ny + iy);
-    key = ((unsigned long long)total << 32) | (0xffffffffu - lin);
-  }
+  uint32_t R[8];  // R[2 y + d]: d = 0: dx 0, 2; d = 1: dx 1, 3
 #pragma unroll
-  for (int m = 8; m >= 1; m >>= 1) {  // (lanes 16.. hold copies)
-    const unsigned long long o = shfl_xor_u64b(key, m);
-    key = o > key ? o : key;
+  for (int y = 0; y < 4; y++) {
+    R[2 * y] = E[y];
+    R[2 * y + 1] = O[y] - ((E[y] >> 16) << 8);
   }
-  return key;
+  rs_step<8, 1>(R, lane & 1);
+  rs_step<4, 2>(R, lane & 2);
+  rs_step<2, 4>(R, lane & 4);
+  uint32_t V[2] = {R[0] & 0xffffu, R[0] >> 16};
+  rs_step<2, 8>(V, lane & 8);
+  V[0] = add_xor<16>(V[0]);
+  V[0] = add_xor<32>(V[0]);
+  *dy = ((lane >> 1) & 1) + 2 * ((lane >> 2) & 1);
+  *dx = (lane & 1) + 2 * ((lane >> 3) & 1);
+  return V[0];
 }
 
-// whole 8 x 8 block, 8-bit cells (16-bit cells take their four sub-blocks: the same number of loads)
-__device__ __forceinline__ unsigned long long eval_block_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
-                                                           const uint32_t *org, int32_t nch, int32_t k, int32_t Y,
-                                                           int32_t X, int lane) {
-  const uint32_t pitch = (uint32_t)P.pitch;
+// whole 8 x 8 block (Y, X): eight 12-byte row loads per point; lane l holds the sum of pose (*dy, *dx) of the block
+__device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uint32_t pitch, const uint32_t *org, int32_t nch,
+                                                int32_t Y, int32_t X, int lane, int *dy, int *dx) {
   const uint32_t off = (uint32_t)(BNB_B * Y) * pitch + (uint32_t)(BNB_B * X);
 // (one chunk's eight row loads in flight: with two the 32 accumulators + 48 row registers spill, measured 5 % slower)
 #ifndef NHIP_BNB_BLOCK_U
@@ -918,19 +935,89 @@ __device__ __forceinline__ unsigned long long eval_block_c(const BnbParams &P, _
   rs_step<2, 32>(V, lane & 32);
   const int r = 8 * (2 * ((lane >> 5) & 1) + ((lane >> 4) & 1)) + 4 * ((lane >> 2) & 1) + 2 * ((lane >> 1) & 1) + (lane & 1);
   const int f = (lane >> 3) & 1, d = r & 3;
-  const int dy = r >> 2, dx = 4 * (d >> 1) + (d & 1) + 2 * f;
-  const int32_t ix = BNB_B * X + dx, iy = BNB_B * Y + dy;
+  *dy = r >> 2;
+  *dx = 4 * (d >> 1) + (d & 1) + 2 * f;
+  return V[0];
+}
+
+// the best key (sum << 32 | ~linear index) over the lanes' poses (ix, iy) of rotation k, the same in every lane
+__device__ __forceinline__ unsigned long long best_key(const BnbParams &P, int32_t k, int32_t ix, int32_t iy, uint32_t total,
+                                                       int top) {
   unsigned long long key = 0ull;
   if (ix < P.nx && iy < P.ny) {
     const uint32_t lin = (uint32_t)((k * P.nx + ix) * P.ny + iy);
-    key = ((unsigned long long)V[0] << 32) | (0xffffffffu - lin);
+    key = ((unsigned long long)total << 32) | (0xffffffffu - lin);
   }
 #pragma unroll
   for (int m = 32; m >= 1; m >>= 1) {
+    if (m > top) continue;
     const unsigned long long o = shfl_xor_u64b(key, m);
     key = o > key ? o : key;
   }
   return key;
+}
+
+// ---- 16-bit cells: a pose's exact sum from the stored image -------------------------------------------------
+// sum and max over the 64 lanes, no LDS: DPP inside a row of 16, permlane swaps across rows
+__device__ __forceinline__ uint32_t wave_sum(uint32_t v) {
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);   // quad_perm [1, 0, 3, 2]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);   // quad_perm [2, 3, 0, 1]
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false);  // row_ror:4
+  v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false);  // row_ror:8
+  v = add_xor<16>(v);
+  return add_xor<32>(v);
+}
+__device__ __forceinline__ uint32_t wave_max(uint32_t v) {
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, false));
+  v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, false));
+  v = max(v, shfl_xor_u32(v, 16));
+  return max(v, shfl_xor_u32(v, 32));
+}
+
+// sum over the scan's points of the 16-bit cell that pose (ix, iy) of the rotation reads: one 2-byte load per point
+__device__ __forceinline__ uint32_t pose_sum16(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc16, const uint32_t *org,
+                                               int32_t nch, int32_t ix, int32_t iy) {
+  const uint32_t pitch = (uint32_t)P.pitch;
+  const uint32_t off = (uint32_t)iy * pitch + 2u * (uint32_t)ix;
+  uint32_t acc = 0u;  // (17 chunks * 65535 fits)
+#pragma unroll
+  for (int c = 0; c < OCL; c++) {
+    if (c >= nch) continue;
+    const uint32_t o = origin_of(org, c);
+    acc += (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc16, (int)((o >> 16) * pitch + 2u * (o & 0xffffu) + off), 0, 0);
+  }
+  return wave_sum(acc);
+}
+
+// Two stages for 16-bit cells.  `hsum` is the lane's pose sum over the plane of HIGH bytes (what sub_sums8 /
+// block_sums8 return on that plane, at the cost of 8-bit cells); a cell is 256 * high + low with low <= 255, so
+//     256 * hsum + 255 * points  >=  the pose's 16-bit sum.
+// Only poses whose bound reaches the best sum found so far can hold the optimum or a tie with it; their exact sums
+// are read from the 16-bit image, highest bound first (it raises the best fastest), until no pose of the block is
+// left above it.  Near the optimum that is a handful of poses; elsewhere none.  Returns the number evaluated.
+template <bool GLOBAL>
+__device__ __forceinline__ uint32_t refine16(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc16, const uint32_t *org,
+                                             int32_t nch, int32_t n_pts, int32_t k, int32_t ix, int32_t iy, uint32_t hsum,
+                                             bool mine, int lane, unsigned long long *best, uint32_t &bcopy) {
+  const bool valid = mine && ix < P.nx && iy < P.ny;
+  uint32_t ub = valid ? 256u * hsum + 255u * (uint32_t)n_pts : 0u;  // (points <= 1088: no overflow)
+  uint32_t n_eval = 0u;
+  for (;;) {
+    const uint32_t top = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max(ub));
+    if (top == 0u || top < best_sum_cached<GLOBAL>(best, bcopy)) break;
+    const int j = (int)__builtin_ctzll(__ballot(ub == top));  // (top != 0: a lane holds it)
+    const int32_t jx = __builtin_amdgcn_readlane(ix, j), jy = __builtin_amdgcn_readlane(iy, j);
+    const uint32_t sum = pose_sum16(P, rsrc16, org, nch, jx, jy);
+    const uint32_t lin = (uint32_t)((k * P.nx + jx) * P.ny + jy);
+    const unsigned long long key = ((unsigned long long)sum << 32) | (0xffffffffu - lin);
+    if (lane == 0) atomicMax(best, key);  // (generic address: LDS or global)
+    if (GLOBAL) bcopy = max(bcopy, sum);
+    if (lane == j) ub = 0u;
+    n_eval++;
+  }
+  return n_eval;
 }
 
 __device__ __forceinline__ void rotation_k(const BnbParams &P, int32_t pair, int32_t k, float *cf, float *sf) {
@@ -950,22 +1037,6 @@ struct PairCtx {
   const float2 *pts;
   int32_t n_pts, cx, cy, pair;
 };
-
-template <bool GLOBAL>
-__device__ __forceinline__ uint32_t best_sum(unsigned long long *best) {
-  unsigned long long b;
-  if (GLOBAL) b = __hip_atomic_load(best, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  else b = *(volatile unsigned long long *)best;
-  return (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(b >> 32));  // one value for the whole wave
-}
-// The pair's own workgroup keeps its best in LDS (GLOBAL = false: csm_bnb_kernel); the takers of handed-over
-// rotations share it through keys[pair] (GLOBAL = true: csm_bnb_rot_kernel).  Between two looks at a best that
-// lives in global memory (a device-scope atomic load: microseconds under load) a taker works with its copy, raised
-// by its own finds; a stale copy only costs pruning, never the result.
-template <bool GLOBAL>
-__device__ __forceinline__ uint32_t best_sum_cached(unsigned long long *best, uint32_t copy) {
-  return GLOBAL ? copy : best_sum<false>(best);
-}
 
 template <int CB>
 __device__ __forceinline__ void process_candidate(const BnbParams &P, const PairCtx &C, int32_t k, int32_t v, int lane,
@@ -1001,20 +1072,30 @@ __device__ __forceinline__ void process_candidate(const BnbParams &P, const Pair
   n[0]++;
 }
 
-// ... with the rotation's origins in registers (LDS-resident best) and the block's four sub-block bounds at hand
+// ... with the rotation's origins held by the wave and the block's four sub-block bounds at hand.  `rsrc` is the
+// 8-bit plane the exact block sums are taken on (8-bit grids: the image; 16-bit grids: the plane of high bytes) and
+// `pitch8` its pitch; `rsrc16` the 16-bit image (CB == 2).
 template <int CB, bool GLOBAL>
-__device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc,
-                                                    const uint32_t *org, int32_t nch, int32_t k, int32_t Y, int32_t X,
+__device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc, uint32_t pitch8,
+                                                    __amdgpu_buffer_rsrc_t rsrc16, const uint32_t *org, int32_t nch,
+                                                    int32_t n_pts, int32_t k, int32_t Y, int32_t X,
                                                     uint32_t sb0, uint32_t sb1, uint32_t sb2, uint32_t sb3, int lane,
                                                     unsigned long long *best, uint32_t &bcopy, uint32_t (&n)[3]) {
   const uint32_t bsum = best_sum_cached<GLOBAL>(best, bcopy);
   const int alive = (sb0 != 0u && sb0 >= bsum) + (sb1 != 0u && sb1 >= bsum) + (sb2 != 0u && sb2 >= bsum) +
                     (sb3 != 0u && sb3 >= bsum);
   if (alive == 0) return;
-  if (CB == 1 && alive >= P.whole_min) {
-    const unsigned long long key = eval_block_c(P, rsrc, org, nch, k, Y, X, lane);
-    if (lane == 0) atomicMax(best, key);  // (generic address: LDS or global)
-    if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
+  if (alive >= P.whole_min) {
+    int dy, dx;
+    const uint32_t total = block_sums8(rsrc, pitch8, org, nch, Y, X, lane, &dy, &dx);
+    const int32_t ix = BNB_B * X + dx, iy = BNB_B * Y + dy;
+    if (CB == 1) {
+      const unsigned long long key = best_key(P, k, ix, iy, total, 32);
+      if (lane == 0) atomicMax(best, key);  // (generic address: LDS or global)
+      if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
+    } else {
+      refine16<GLOBAL>(P, rsrc16, org, nch, n_pts, k, ix, iy, total, true, lane, best, bcopy);
+    }
     n[0]++;
     return;
   }
@@ -1022,9 +1103,16 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
   for (int q = 0; q < 4; q++) {
     const uint32_t b = q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3));
     if (b == 0u || b < best_sum_cached<GLOBAL>(best, bcopy)) continue;
-    const unsigned long long key = eval_sub_c<CB>(P, rsrc, org, nch, k, Y, X, q >> 1, q & 1, lane);
-    if (lane == 0) atomicMax(best, key);
-    if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
+    int dy, dx;
+    const uint32_t total = sub_sums8(rsrc, pitch8, org, nch, Y, X, q >> 1, q & 1, lane, &dy, &dx);
+    const int32_t ix = BNB_B * X + BNB_B4 * (q & 1) + dx, iy = BNB_B * Y + BNB_B4 * (q >> 1) + dy;
+    if (CB == 1) {
+      const unsigned long long key = best_key(P, k, ix, iy, total, 8);  // (lanes 16.. hold copies)
+      if (lane == 0) atomicMax(best, key);
+      if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
+    } else {
+      refine16<GLOBAL>(P, rsrc16, org, nch, n_pts, k, ix, iy, total, lane < 16, lane, best, bcopy);
+    }
     n[2]++;
   }
 }
@@ -1045,10 +1133,15 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
   long long t_mark = 0;
   float cf, sf;
   rotation_k(P, C.pair, k, &cf, &sf);
-  if (P.stats) t_mark = clock64();
+  if (BNB_STATS(P)) t_mark = clock64();
   cache_origins(P, C.pts, C.n_pts, cf, sf, C.cx, C.cy, lane, org);
-  if (P.stats) clk.org += clock64() - t_mark;
-  const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(C.grid, P.grid_bytes + P.skip_bytes);
+  if (BNB_STATS(P)) clk.org += clock64() - t_mark;
+  // (stored image + skip map: every offset an evaluation can form lies inside; see nhip_api.hip make_layout)
+  const __amdgpu_buffer_rsrc_t rsrc16 = uniform_rsrc(C.grid, P.grid_bytes + P.skip_bytes);
+  // the 8-bit plane of the exact block sums: the image itself, or the high bytes of 16-bit cells (+ the 16 bytes a row
+  // load may reach past the plane's last cell: the next slot, or the buffer's read slack)
+  const __amdgpu_buffer_rsrc_t rsrc = CB == 1 ? rsrc16 : uniform_rsrc(C.grid + P.hi_offset, P.hi_bytes + 16);
+  const uint32_t pitch8 = CB == 1 ? (uint32_t)P.pitch : (uint32_t)P.hi_pitch;
   const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(C.grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
   // candidates in block order b = NB * Y + X; neighbours in X (up to three) share one pass over the table
   while ((m0 | m1) != 0ull) {
@@ -1062,11 +1155,11 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
     }
     uint32_t sb[12];
     uint32_t bcopy = GLOBAL ? best_sum<true>(best) : 0u;  // (one look per strip at a best in global memory)
-    if (P.debug == 5) break;  // (timing: origins only)
+    if (BNB_DEBUG(P) == 5) break;  // (timing: origins only)
     if (P.levels >= 2) {
-      if (P.stats) t_mark = clock64();
+      if (BNB_STATS(P)) t_mark = clock64();
       strip_bounds_c(P, p4, org, nch, Y, X0, CB == 1 ? 1u : 257u, sb);
-      if (P.stats) clk.strip += clock64() - t_mark;
+      if (BNB_STATS(P)) clk.strip += clock64() - t_mark;
       n_work[1] += (uint32_t)len;
     } else {
 #pragma unroll
@@ -1078,13 +1171,14 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
       if (b < 64) m0 &= ~(1ull << b);
       else m1 &= ~(1ull << (b - 64));
       const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)(b < 64 ? u0 : u1), b & 63);
-      if (ub < best_sum_cached<GLOBAL>(best, bcopy) || (P.debug == 4 && !done)) continue;  // the best has risen meanwhile
+      if (ub < best_sum_cached<GLOBAL>(best, bcopy) || (BNB_DEBUG(P) == 4 && !done)) continue;  // the best has risen meanwhile
       // (selects, not an indexed array: that would live in scratch)
       const uint32_t s0 = t == 0 ? sb[0] : (t == 1 ? sb[4] : sb[8]), s1 = t == 0 ? sb[1] : (t == 1 ? sb[5] : sb[9]);
       const uint32_t s2 = t == 0 ? sb[2] : (t == 1 ? sb[6] : sb[10]), s3 = t == 0 ? sb[3] : (t == 1 ? sb[7] : sb[11]);
-      if (P.stats) t_mark = clock64();
-      process_candidate_c<CB, GLOBAL>(P, rsrc, org, nch, k, Y, X0 + t, s0, s1, s2, s3, lane, best, bcopy, n_work);
-      if (P.stats) clk.eval += clock64() - t_mark;
+      if (BNB_STATS(P)) t_mark = clock64();
+      process_candidate_c<CB, GLOBAL>(P, rsrc, pitch8, rsrc16, org, nch, C.n_pts, k, Y, X0 + t, s0, s1, s2, s3, lane, best,
+                                      bcopy, n_work);
+      if (BNB_STATS(P)) clk.eval += clock64() - t_mark;
       if (done && lane == 0) done[b] = 0u;
     }
   }
@@ -1151,12 +1245,18 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
 
   // pose 0 with sum 0 is a lower bound of the optimum (sums are >= 0; if all are 0, pose 0 is the answer)
   const unsigned long long key0 = 0xffffffffull;
-  const long long t_start = P.stats ? clock64() : 0;
-  if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair] = wall_clock64();
+  // The general instantiation (scans too long for the by-rotation form) keeps its work counters in the product build
+  // too, behind this pointer, which the product host code leaves null.  With them compiled out, hipcc 7.2 -O3 produced
+  // a kernel that never returned on scans of more than 1088 points under NHIP_BNB_LEVELS=1 (every candidate block
+  // evaluated whole; tools/bnb_hang_probe2.py reproduces it; with the counters compiled in and switched off, as in
+  // every earlier build, the same source runs through 3,000 sweep configurations).  Cause not found: the counters stay.
+  unsigned long long *const stats_g = (NHIP_BNB_INSTR || !BY_ROT) ? P.stats : nullptr;
+  const long long t_start = BNB_STATS(P) ? clock64() : 0;
+  if (BNB_TIMELINE(P) && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) BNB_TIMELINE(P)[4 * pair] = wall_clock64();
   if (threadIdx.x == 0) {
     *s_slow = 0ull;
     // (NHIP_BNB_DEBUG=3, experiments only: start from the keys a previous launch left = the ideal threshold)
-    *s_best = P.debug == 3 ? (P.keys[pair] & 0xffffffff00000000ull) : key0;
+    *s_best = BNB_DEBUG(P) == 3 ? (P.keys[pair] & 0xffffffff00000000ull) : key0;
     s_cnt[0] = s_cnt[3] = s_cnt[4] = 0u;
     *s_qn = 0u;
     *s_qhead = 0u;
@@ -1227,8 +1327,8 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     // (NHIP_BNB_STATS=1: shader-clock sums -- wave time in phase 3 by part, and the workgroup's wall time)
     PhaseClocks clk = {0, 0, 0};
     long long t_busy = 0, t_wall = 0;
-    const long long t_phase1 = P.stats ? clock64() : 0;
-    if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair + 1] = wall_clock64();
+    const long long t_phase1 = BNB_STATS(P) ? clock64() : 0;
+    if (BNB_TIMELINE(P) && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) BNB_TIMELINE(P)[4 * pair + 1] = wall_clock64();
     const uint32_t xcd = bid & 7u;
     bool handed_over = false;
     // One loop, one copy of the candidate code (it is large; three inlined copies did not fit the instruction
@@ -1251,7 +1351,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
       unsigned long long m0 = 0ull, m1 = 0ull;
       uint32_t *done = nullptr;
       if (state == SEED) {
-        if ((uint32_t)(wbest >> 32) != 0u && P.debug < 2) {
+        if ((uint32_t)(wbest >> 32) != 0u && BNB_DEBUG(P) < 2) {
           const int32_t v = (int32_t)(wbest & 0xffu);
           const uint32_t ub = (uint32_t)(wbest >> 32);
           k = (int32_t)((uint32_t)wbest >> 8);
@@ -1264,7 +1364,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         }
       } else if (state == OWN) {
         int32_t rank = P.n_theta;
-        if (P.debug == 0 || (P.debug >= 3 && P.debug < 26)) {
+        if (BNB_DEBUG(P) == 0 || (BNB_DEBUG(P) >= 3 && BNB_DEBUG(P) < 26)) {
           if (lane == 0) rank = (int32_t)atomicAdd(s_qhead, 1u);
           rank = __builtin_amdgcn_readfirstlane(rank);
         }
@@ -1300,8 +1400,8 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
       if (have) rotation_pass<CB, false>(P, C, k, u0, u1, m0, m1, lane, s_best, done, org, n_work, clk);
       if (state == SEED) {
         __syncthreads();
-        if (P.timeline && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) P.timeline[4 * pair + 2] = wall_clock64();
-        if (P.stats) {
+        if (BNB_TIMELINE(P) && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) BNB_TIMELINE(P)[4 * pair + 2] = wall_clock64();
+        if (BNB_STATS(P)) {
           t_busy = clock64();
           t_wall = wall_clock64();
         }
@@ -1328,22 +1428,22 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         state = OWN;
       }
     }
-    if (P.stats && lane == 0) {
+    if (BNB_STATS(P) && lane == 0) {
       const long long now = clock64();
-      atomicAdd(&P.stats[4], (unsigned long long)(now - t_busy));       // wave time in phase 3 (until out of work)
-      atomicAdd(&P.stats[11], (unsigned long long)(wall_clock64() - t_wall));  // the same in 100 MHz ticks
-      atomicAdd(&P.stats[5], (unsigned long long)clk.org);
-      atomicAdd(&P.stats[6], (unsigned long long)clk.strip);
-      atomicAdd(&P.stats[7], (unsigned long long)clk.eval);
+      atomicAdd(&BNB_STATS(P)[4], (unsigned long long)(now - t_busy));       // wave time in phase 3 (until out of work)
+      atomicAdd(&BNB_STATS(P)[11], (unsigned long long)(wall_clock64() - t_wall));  // the same in 100 MHz ticks
+      atomicAdd(&BNB_STATS(P)[5], (unsigned long long)clk.org);
+      atomicAdd(&BNB_STATS(P)[6], (unsigned long long)clk.strip);
+      atomicAdd(&BNB_STATS(P)[7], (unsigned long long)clk.eval);
       atomicMax(s_slow, (unsigned long long)(now - t_busy));  // slowest wave
       if (wave == 0) {
-        atomicAdd(&P.stats[9], (unsigned long long)(t_busy - t_phase1));  // seeds (wave 0's view)
-        atomicAdd(&P.stats[10], (unsigned long long)(t_phase1 - t_start)); // bounds
-        if (handed_over) atomicAdd(&P.stats[12], 1ull);
+        atomicAdd(&BNB_STATS(P)[9], (unsigned long long)(t_busy - t_phase1));  // seeds (wave 0's view)
+        atomicAdd(&BNB_STATS(P)[10], (unsigned long long)(t_phase1 - t_start)); // bounds
+        if (handed_over) atomicAdd(&BNB_STATS(P)[12], 1ull);
       }
     }
   } else {
-  if ((uint32_t)(wbest >> 32) != 0u && P.debug < 2) {
+  if ((uint32_t)(wbest >> 32) != 0u && BNB_DEBUG(P) < 2) {
       const int32_t k = (int32_t)((uint32_t)wbest >> 8), v = (int32_t)(wbest & 0xffu);
       const int Y = v / NB, X = v - NB * Y;
       float cf, sf;
@@ -1358,7 +1458,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     __syncthreads();
     // (3) every block whose bound reaches the best sum found so far.  The survivors cluster in a few rotations,
     // i.e. in a few waves: they go through one queue per workgroup that all eight waves drain.
-    for (int32_t k = wave; k < P.n_theta && (P.debug == 0 || P.debug == 3); k += BNB_WAVES) {
+    for (int32_t k = wave; k < P.n_theta && (BNB_DEBUG(P) == 0 || BNB_DEBUG(P) == 3); k += BNB_WAVES) {
   #pragma unroll
       for (int i = 0; i < 2; i++) {
         const uint32_t u = s_U[k * 128 + lane + 64 * i];
@@ -1386,7 +1486,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     __syncthreads();
     {
       const uint32_t qn = min(*s_qn, (uint32_t)QCAP);
-      while (P.debug == 0 || P.debug == 3) {
+      while (BNB_DEBUG(P) == 0 || BNB_DEBUG(P) == 3) {
         uint32_t i = 0u;
         if (lane == 0) i = atomicAdd(s_qhead, 1u);
         i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
@@ -1397,7 +1497,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
       }
     }
 }
-  if (P.stats && lane == 0) {
+  if (stats_g && lane == 0) {
     atomicAdd(&s_cnt[0], n_work[0]);
     atomicAdd(&s_cnt[3], n_work[1]);
     atomicAdd(&s_cnt[4], n_work[2]);
@@ -1405,21 +1505,21 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   __syncthreads();
   if (threadIdx.x == 0) {
     P.keys[pair] = *s_best;  // (a pair that handed rotations over: the second kernel raises it from here)
-    if (P.timeline && pair < BNB_STATS_PAIRS) {
+    if (BNB_TIMELINE(P) && pair < BNB_STATS_PAIRS) {
       uint32_t hw;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       uint32_t xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      P.timeline[4 * pair + 3] = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)(hw & 0xffffu) << 48);
+      BNB_TIMELINE(P)[4 * pair + 3] = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)(hw & 0xffffu) << 48);
       (void)xcc;
     }
-    if (P.stats && BY_ROT) atomicAdd(&P.stats[8], *s_slow);  // sum over pairs of the slowest wave's phase 3
-    if (P.stats) {
-      atomicAdd(&P.stats[0], (unsigned long long)s_cnt[0]);
-      atomicAdd(&P.stats[1], (unsigned long long)(P.n_theta * P.nbx * P.nby));
-      atomicAdd(&P.stats[2], (unsigned long long)s_cnt[3]);
-      atomicAdd(&P.stats[3], (unsigned long long)s_cnt[4]);
-      if (pair < BNB_STATS_PAIRS) atomicAdd(&P.stats[BNB_STATS_HEAD + pair], 4ull * s_cnt[0] + s_cnt[4]);
+    if (BNB_STATS(P) && BY_ROT) atomicAdd(&BNB_STATS(P)[8], *s_slow);  // sum over pairs of the slowest wave's phase 3
+    if (stats_g) {
+      atomicAdd(&stats_g[0], (unsigned long long)s_cnt[0]);
+      atomicAdd(&stats_g[1], (unsigned long long)(P.n_theta * P.nbx * P.nby));
+      atomicAdd(&stats_g[2], (unsigned long long)s_cnt[3]);
+      atomicAdd(&stats_g[3], (unsigned long long)s_cnt[4]);
+      if (pair < BNB_STATS_PAIRS) atomicAdd(&stats_g[BNB_STATS_HEAD + pair], 4ull * s_cnt[0] + s_cnt[4]);
     }
   }
 }
@@ -1439,7 +1539,7 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
   __shared__ uint32_t s_org2[4 * ORG_WAVE];
   uint32_t *org = s_org2 + (threadIdx.x >> 6) * ORG_WAVE + lane;
   PhaseClocks clk = {0, 0, 0};
-  const long long t0 = P.stats ? clock64() : 0;
+  const long long t0 = BNB_STATS(P) ? clock64() : 0;
   for (;;) {
     uint32_t i = 0u;
     if (lane == 0) i = atomicAdd(P.rot_count + 8 * xcd + 1, 1u);
@@ -1454,21 +1554,85 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
     // (no block bounds here: 0xffffffff lets every candidate through to its sub-block bounds, which are checked
     //  against the best as it stands in keys[pair])
     rotation_pass<CB, true>(P, C, k, 0xffffffffu, 0xffffffffu, m0, m1, lane, &P.keys[pair], nullptr, org, n, clk);
-    if (P.stats && lane == 0 && pair < BNB_STATS_PAIRS) atomicAdd(&P.stats[BNB_STATS_HEAD + pair], 4ull * n[0] + n[2]);
+    if (BNB_STATS(P) && lane == 0 && pair < BNB_STATS_PAIRS) atomicAdd(&BNB_STATS(P)[BNB_STATS_HEAD + pair], 4ull * n[0] + n[2]);
     n_work[0] += n[0];
     n_work[1] += n[1];
     n_work[2] += n[2];
   }
-  if (P.stats && lane == 0) {
-    if (n_work[0]) atomicAdd(&P.stats[0], (unsigned long long)n_work[0]);
-    if (n_work[1]) atomicAdd(&P.stats[2], (unsigned long long)n_work[1]);
-    if (n_work[2]) atomicAdd(&P.stats[3], (unsigned long long)n_work[2]);
-    atomicAdd(&P.stats[13], (unsigned long long)(clock64() - t0));  // wave time in the second kernel
-    atomicAdd(&P.stats[5], (unsigned long long)clk.org);
-    atomicAdd(&P.stats[6], (unsigned long long)clk.strip);
-    atomicAdd(&P.stats[7], (unsigned long long)clk.eval);
+  if (BNB_STATS(P) && lane == 0) {
+    if (n_work[0]) atomicAdd(&BNB_STATS(P)[0], (unsigned long long)n_work[0]);
+    if (n_work[1]) atomicAdd(&BNB_STATS(P)[2], (unsigned long long)n_work[1]);
+    if (n_work[2]) atomicAdd(&BNB_STATS(P)[3], (unsigned long long)n_work[2]);
+    atomicAdd(&BNB_STATS(P)[13], (unsigned long long)(clock64() - t0));  // wave time in the second kernel
+    atomicAdd(&BNB_STATS(P)[5], (unsigned long long)clk.org);
+    atomicAdd(&BNB_STATS(P)[6], (unsigned long long)clk.strip);
+    atomicAdd(&BNB_STATS(P)[7], (unsigned long long)clk.eval);
   }
 }
+
+}  // namespace
+
+// ---- the kernel launches of one batch (compiled in both builds)
+namespace bnb {
+
+namespace {
+// hipFuncSetAttribute once per instantiation and LDS size reached (not per launch)
+template <int CB, bool PL, bool BR>
+int launch_main(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
+  static std::atomic<size_t> lds_set{0};
+  if (lds > lds_set.load(std::memory_order_relaxed)) {
+    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL, BR>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    lds_set.store(lds, std::memory_order_relaxed);
+  }
+#if NHIP_BNB_INSTR
+  if (P.stats && getenv("NHIP_BNB_OCCUPANCY")) {
+    int nb = -1;
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, csm_bnb_kernel<CB, PL, BR>, BNB_THREADS, lds);
+    fprintf(stderr, "csm_bnb_kernel<%d,%d,%d>: lds %zu B, %d workgroups per CU\n", CB, (int)PL, (int)BR, lds, nb);
+  }
+#endif
+  hipLaunchKernelGGL((csm_bnb_kernel<CB, PL, BR>), dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);
+  return NHIP_OK;
+}
+
+template <int CB, bool PL>
+int launch_both(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
+  // both instantiations are launched; a workgroup whose pair belongs to the other one returns at once
+  if (!P.general_all) {
+    int rc = launch_main<CB, PL, true>(P, lds, blocks, s);
+    if (rc) return rc;
+  }
+  return launch_main<CB, PL, false>(P, lds, blocks, s);
+}
+}  // namespace
+
+#if NHIP_BNB_INSTR
+int launch_bnb_kernels_instr(const BnbParams &P, int cb, bool pool_lds, size_t lds, int64_t blocks, bool second_kernel,
+                             hipStream_t s) {
+#else
+int launch_bnb_kernels(const BnbParams &P, int cb, bool pool_lds, size_t lds, int64_t blocks, bool second_kernel,
+                       hipStream_t s) {
+#endif
+  int rc;
+  if (cb == 1 && pool_lds) rc = launch_both<1, true>(P, lds, blocks, s);
+  else if (cb == 1) rc = launch_both<1, false>(P, lds, blocks, s);
+  else if (pool_lds) rc = launch_both<2, true>(P, lds, blocks, s);
+  else rc = launch_both<2, false>(P, lds, blocks, s);
+  if (rc) return rc;
+  if (second_kernel) {
+    const uint32_t rot_blocks = 256 * 4;  // four workgroups of four waves per CU; the waves take entries off the lists
+    if (cb == 1) hipLaunchKernelGGL(csm_bnb_rot_kernel<1>, dim3(rot_blocks), dim3(256), 0, s, P);
+    else hipLaunchKernelGGL(csm_bnb_rot_kernel<2>, dim3(rot_blocks), dim3(256), 0, s, P);
+  }
+  return NHIP_OK;
+}
+
+}  // namespace bnb
+
+#if !NHIP_BNB_INSTR
+// ---- host side (product build only)
+namespace {
 
 size_t bnb_lds_first(const GridLayout &L, bool pool_lds) {
   const size_t pool = pool_lds ? (size_t)L.pool_bytes : 0;
@@ -1488,13 +1652,22 @@ bool bnb_fits(const GridLayout &L, const nhip_search_t *search) {
          L.pool_bytes < 0x7fffffffll && L.S + 2 * L.pad < 65536 && search->n_theta <= MAX_ROT;
 }
 
+// Instrumentation buffers (NHIP_BNB_INSTRUMENT=1 only): process-wide, allocated on first use, guarded by g_instr_mu
+static std::mutex g_instr_mu;
 static unsigned long long *g_bnb_timeline = nullptr;
-static unsigned long long *g_bnb_stats = nullptr;  // device counters, allocated on first use when NHIP_BNB_STATS=1
+static unsigned long long *g_bnb_stats = nullptr;
 
 constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, next entry to work}
 // room for 16 rotations per pair on average (what does not fit is worked by the pair's own workgroup)
 int64_t bnb_workspace_bytes(int32_t n_pairs) {
   return BNB_WS_HEADER + 8 * ((((int64_t)(n_pairs > 0 ? n_pairs : 0) + 7) / 8) * 16 + 64) * (int64_t)sizeof(RotEntry);
+}
+
+// NHIP_BNB_INSTRUMENT=1 selects the instrumented build of the kernels; only then are NHIP_BNB_STATS, NHIP_BNB_TIMELINE
+// and NHIP_BNB_DEBUG (timing experiments: WRONG results) read at all.
+static bool instrumented() {
+  const char *e = getenv("NHIP_BNB_INSTRUMENT");
+  return e && e[0] == '1';
 }
 
 int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
@@ -1540,30 +1713,39 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.pool_bytes = L.pool_bytes;
   P.pool4_bytes = L.pool4_bytes;
   P.pool4_pitch = L.pool4_pitch;
-  const char *lv = getenv("NHIP_BNB_LEVELS");  // (1: without the sub-block bounds -- measurements only; same results)
+  P.hi_offset = L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes;
+  P.hi_bytes = L.hi_bytes;
+  P.hi_pitch = L.hi_pitch;
+  // Policies that never change the records (tests run the matcher in every form and compare): read per launch.
+  const char *lv = getenv("NHIP_BNB_LEVELS");  // (1: without the sub-block bounds)
   P.levels = lv && lv[0] == '1' ? 1 : 2;
   const char *wm = getenv("NHIP_BNB_WHOLE_MIN");
   P.whole_min = wm ? atoi(wm) : 3;
-  const char *qe = getenv("NHIP_BNB_QUEUE");  // (the general path for every scan: tests, measurements)
+  const char *qe = getenv("NHIP_BNB_QUEUE");  // (the general path for every scan)
   P.general_all = qe && qe[0] == '1';
   P.res = spec->res;
   P.inv_res = 1.0 / spec->res;
-  const char *dbg = getenv("NHIP_BNB_DEBUG");
-  P.debug = dbg ? atoi(dbg) : 0;
-  const char *st = getenv("NHIP_BNB_STATS");
-  if (st && st[0] == '1') {
-    if (!g_bnb_stats) {
-      NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_stats), 8 * (BNB_STATS_HEAD + (size_t)BNB_STATS_PAIRS)));
-      NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 8 * (BNB_STATS_HEAD + (size_t)BNB_STATS_PAIRS)));
+  P.inv_res_f = (float)P.inv_res;
+  const bool instr = instrumented();
+  if (instr) {
+    std::lock_guard<std::mutex> lock(g_instr_mu);
+    const char *dbg = getenv("NHIP_BNB_DEBUG");
+    P.debug = dbg ? atoi(dbg) : 0;
+    const char *st = getenv("NHIP_BNB_STATS");
+    if (st && st[0] == '1') {
+      if (!g_bnb_stats) {
+        NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_stats), 8 * (BNB_STATS_HEAD + (size_t)BNB_STATS_PAIRS)));
+        NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 8 * (BNB_STATS_HEAD + (size_t)BNB_STATS_PAIRS)));
+      }
+      P.stats = g_bnb_stats;
     }
-    P.stats = g_bnb_stats;
-  }
-  const char *tl = getenv("NHIP_BNB_TIMELINE");
-  if (tl && tl[0] == '1') {
-    if (!g_bnb_timeline) NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_timeline), 32 * (size_t)BNB_STATS_PAIRS + 16));
-    P.timeline = g_bnb_timeline;
-    const unsigned long long init[2] = {~0ull, 0ull};  // the second kernel's first start and last end
-    NHIP_TRY_HIP(hipMemcpyAsync(g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS, init, 16, hipMemcpyHostToDevice, s));
+    const char *tl = getenv("NHIP_BNB_TIMELINE");
+    if (tl && tl[0] == '1') {
+      if (!g_bnb_timeline) NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_timeline), 32 * (size_t)BNB_STATS_PAIRS + 16));
+      P.timeline = g_bnb_timeline;
+      const unsigned long long init[2] = {~0ull, 0ull};  // the second kernel's first start and last end
+      NHIP_TRY_HIP(hipMemcpyAsync(g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS, init, 16, hipMemcpyHostToDevice, s));
+    }
   }
   // Work sharing.  A flat landscape leaves a pair thousands of candidates (the median pair: ~30): alone on the
   // chip its workgroup is busy for 3 ms (the median pair: 0.2 ms), and a batch that does not fill the chip many
@@ -1594,34 +1776,11 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const size_t lds = bnb_lds_bytes(L, search, pool_lds);
   P.lds_first = (int32_t)bnb_lds_first(L, pool_lds);
   const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
+  const bool second_kernel = P.rot_list && (P.debug == 0 || (P.debug >= 3 && P.debug < 26));
   timer_begin(NHIP_TIMER_CSM, s);
-#define NHIP_BNB_LAUNCH1(CB, PL, BR)                                                                             \
-  do {                                                                                                           \
-    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL, BR>),                 \
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                     \
-    if (P.stats && getenv("NHIP_BNB_OCCUPANCY")) {                                                               \
-      int nb = -1;                                                                                               \
-      (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, csm_bnb_kernel<CB, PL, BR>, BNB_THREADS, lds);     \
-      fprintf(stderr, "csm_bnb_kernel<%d,%d,%d>: lds %zu B, %d workgroups per CU\n", CB, (int)PL, (int)BR, lds, nb); \
-    }                                                                                                            \
-    hipLaunchKernelGGL((csm_bnb_kernel<CB, PL, BR>), dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);      \
-  } while (0)
-#define NHIP_BNB_LAUNCH(CB, PL)                                                                                  \
-  do {                                                                                                           \
-    if (!P.general_all) NHIP_BNB_LAUNCH1(CB, PL, true);                                                          \
-    NHIP_BNB_LAUNCH1(CB, PL, false);                                                                             \
-  } while (0)
-  if (L.cb == 1 && pool_lds) NHIP_BNB_LAUNCH(1, true);
-  else if (L.cb == 1) NHIP_BNB_LAUNCH(1, false);
-  else if (pool_lds) NHIP_BNB_LAUNCH(2, true);
-  else NHIP_BNB_LAUNCH(2, false);
-#undef NHIP_BNB_LAUNCH1
-#undef NHIP_BNB_LAUNCH
-  if (P.rot_list && (P.debug == 0 || (P.debug >= 3 && P.debug < 26))) {
-    const uint32_t rot_blocks = 256 * 4;  // four workgroups of four waves per CU; the waves take entries off the lists
-    if (L.cb == 1) hipLaunchKernelGGL(csm_bnb_rot_kernel<1>, dim3(rot_blocks), dim3(256), 0, s, P);
-    else hipLaunchKernelGGL(csm_bnb_rot_kernel<2>, dim3(rot_blocks), dim3(256), 0, s, P);
-  }
+  const int rc = instr ? bnb::launch_bnb_kernels_instr(P, L.cb, pool_lds, lds, blocks, second_kernel, s)
+                       : bnb::launch_bnb_kernels(P, L.cb, pool_lds, lds, blocks, second_kernel, s);
+  if (rc) return rc;
   timer_end(NHIP_TIMER_CSM, s);
   NHIP_TRY_HIP(hipGetLastError());
   launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
@@ -1652,5 +1811,7 @@ int bnb_stats_read(unsigned long long out[16]) {
   NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 8 * BNB_STATS_HEAD));
   return NHIP_OK;
 }
+
+#endif  // !NHIP_BNB_INSTR
 
 }  // namespace nhip

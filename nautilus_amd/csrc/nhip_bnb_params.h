@@ -1,0 +1,59 @@
+// nhip_bnb_params.h -- kernel parameters of the branch-and-bound matcher, shared by its two translation units:
+// nhip_bnb.hip (the product kernels) and nhip_bnb_instr.hip (the same kernels with their instrumentation compiled in).
+#pragma once
+#include "nhip_common.h"
+
+namespace nhip {
+namespace bnb {
+
+// One rotation of a pair with many candidates, handed to the second kernel: (pair, rotation) and the mask of its
+// 121 candidate blocks.
+struct RotEntry {
+  unsigned long long w[4];  // w[0]: pair << 24 | rotation; w[1..3]: candidate blocks 0..40, 41..81, 82..120
+};
+
+struct BnbParams {
+  const float2 *xy;
+  const int32_t *offsets;
+  const uint8_t *grids;
+  const int32_t *pair_src;
+  const int32_t *pair_slot;
+  const double *rot0_cs;
+  const double *delta_cs;
+  const int32_t *pair_origin;
+  unsigned long long *keys;
+  unsigned long long *timeline;  // optional (NHIP_BNB_TIMELINE=1): per pair 4 x 100 MHz ticks: start, bounds, seeds, end
+  unsigned long long *stats;  // optional: [0] blocks evaluated whole, [1] blocks in all, [2] candidates refined,
+                              //   [3] 4 x 4 sub-blocks evaluated; then one count of candidates per pair
+  RotEntry *rot_list;          // optional lists of (pair, rotation) work items in the caller's workspace, one per XCD so
+  uint32_t *rot_count;        //   that a pair's rotations are worked where its grid is L2-resident; per XCD 32 bytes of
+  uint32_t rot_cap;           //   counters {filled, next}; entries per list
+  uint32_t heavy_min;         // candidates (after the seeds) from which a PAIR hands its rotations over ...
+  uint32_t keep_ranks;        // ... except its first keep_ranks rotations in best-first order (one per wave)
+  int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
+  int32_t S, pad, pitch, rows, max_shift;
+  int32_t pool_pitch, pool_rows, pairs_per_xcd;
+  int32_t pool4_pitch;
+  int32_t lds_first;    // bytes of the kernel's first LDS region: max(pooled table if staged, origins)
+  int32_t whole_min;    // sub-blocks alive from which an 8-bit block is evaluated whole (3; NHIP_BNB_WHOLE_MIN)
+  int32_t general_all;  // the general instantiation takes every pair (NHIP_BNB_QUEUE=1)
+  int32_t levels;  // 2: candidates are refined through the 4 x 4 sub-block bounds; 1: evaluated whole (NHIP_BNB_LEVELS)
+  int32_t debug;   // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only,
+                   // 4 = phase 3 without exact sums, 5 = phase 3 without sub-block bounds and exact sums,
+                   // 26 / 27 = bounds only, without their reductions / gathers
+  int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes, pool4_bytes;
+  int64_t hi_offset, hi_bytes;  // 16-bit grids: the plane of high bytes inside a slot
+  int32_t hi_pitch;
+  double res, inv_res;
+  float inv_res_f;  // RN_f32(1 / res): the single-precision path of the window origins
+};
+
+// Launches the matcher's kernel(s) for one batch: the product build, or (nhip_bnb_instr.hip) the build that honours
+// P.stats / P.timeline / P.debug.  lds: dynamic LDS bytes of csm_bnb_kernel; blocks: its grid.
+int launch_bnb_kernels(const BnbParams &P, int cb, bool pool_lds, size_t lds, int64_t blocks, bool second_kernel,
+                       hipStream_t s);
+int launch_bnb_kernels_instr(const BnbParams &P, int cb, bool pool_lds, size_t lds, int64_t blocks, bool second_kernel,
+                             hipStream_t s);
+
+}  // namespace bnb
+}  // namespace nhip

@@ -43,7 +43,9 @@ struct GridLayout {
   int64_t skip_bytes;  // skip_pitch(pitch) * rows rounded up to 16: the skip map that follows the image
   int64_t pool_bytes;  // pool_rows * pool_pitch: the max-pooled table (branch-and-bound bounds) after the skip map
   int64_t pool4_bytes; // pool4_rows * pool4_pitch: the stride-4 pooled table (second bound level) after the first
-  int64_t slot_bytes;  // grid_bytes + skip_bytes + pool_bytes + pool4_bytes: stride between consecutive grids of a buffer
+  int64_t hi_bytes;    // 16-bit cells: hi_pitch * rows, the plane of high bytes after the second pooled table; else 0
+  int32_t hi_pitch;    // bytes per row of that plane (the 8-bit pitch of the same grid)
+  int64_t slot_bytes;  // grid_bytes + skip_bytes + pool_bytes + pool4_bytes + hi_bytes: stride between consecutive grids
   int32_t pool_pitch, pool_rows;
   int32_t pool4_pitch, pool4_rows;
   double Lf, step;

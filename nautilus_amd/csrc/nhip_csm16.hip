@@ -24,8 +24,12 @@
 //    PARITY sets of 15 (raw, hi) pairs -- 60 registers; classes 2 and 3 shift the pair index by one, and their
 //    first dword (like the low cell of class 1's) belongs to the left neighbour lane's last x-shifts: it is added
 //    into pair 14 of the lane's own set and travels there with a wave shuffle at the end.
-// The tile is 48 rows x 424 bytes = 20 KB per wave: 8 one-wave workgroups per CU (two per SIMD) against the
-// 8-bit kernel's 16.
+// LDS is what limits the waves here: a tile of 48 rows x 424 bytes per one-wave workgroup (the 8-bit kernel's shape)
+// is 20 KB -- 8 waves per CU.  Four waves (84 plane rows: one 81 x 81 plane) sharing ONE 96-row tile (40.7 KB) put
+// 16 waves on a CU, and the shared fills more than pay for the barriers: measured on 3,000 config #2 pairs
+// (gpurun_out r3_c16_variants*.jsonl, tools/c16_variants.sh) 49.6 ms with one wave per 48-row tile, 45.0 / 43.5 with two
+// per 64 / 72 rows, 41.1 / 43.0 / 46.4 with four per 120 / 112 / 104 rows (12 waves per CU), 37.9 with four per 96 rows;
+// letting hipcc fold the high-half shift into SDWA adds: 40.6.
 #include "nhip_csm_shared.h"
 
 namespace nhip {
@@ -35,7 +39,7 @@ namespace {
 using namespace csm;
 
 #ifndef NHIP_C16_WG_WAVES
-#define NHIP_C16_WG_WAVES 1
+#define NHIP_C16_WG_WAVES 4
 #endif
 #ifndef NHIP_C16_SDWA
 #define NHIP_C16_SDWA 0  // 1: let hipcc fold the high-half shift into SDWA adds (measurement)
@@ -54,7 +58,7 @@ constexpr int PB_NY = WG_WAVES * WAVE_ROWS;
 constexpr int LP_QW = 53;                  // LDS tile pitch in qwords (conflict-free: 53 = 21 mod 32)
 constexpr int LP = 8 * LP_QW;              // 424 bytes
 #ifndef NHIP_C16_TILE_ROWS
-#define NHIP_C16_TILE_ROWS (48 * NHIP_C16_WG_WAVES)
+#define NHIP_C16_TILE_ROWS (24 * NHIP_C16_WG_WAVES)
 #endif
 #ifndef NHIP_C16_FILL_INFLIGHT
 #define NHIP_C16_FILL_INFLIGHT 4
@@ -193,7 +197,7 @@ __device__ __forceinline__ void acc_finish(const Acc16 &A, uint32_t (&acc)[SEG_C
 }
 
 #ifndef NHIP_C16_WAVES_PER_SIMD
-#define NHIP_C16_WAVES_PER_SIMD 2
+#define NHIP_C16_WAVES_PER_SIMD 4
 #endif
 // DENSE: the grids carry no skip map (16-bit grids are built without one unless the spec asks: the matcher's product
 // path never reads it), or NHIP_CSM_DENSE=1: every strip is added, zero or not

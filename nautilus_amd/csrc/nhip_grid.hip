@@ -94,7 +94,8 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
                                                         uint8_t *__restrict__ grids, int32_t S,
                                                         int32_t pad, int32_t pitch, int64_t slot_bytes,
                                                         int32_t R, double res, double inv_res, GridKernelTables tab,
-                                                        const uint32_t *__restrict__ thr16) {
+                                                        const uint32_t *__restrict__ thr16, int64_t hi_offset,
+                                                        int32_t hi_pitch) {
   __shared__ uint32_t sA[TILE][TILE + 1];
   __shared__ uint16_t sHits[MAX_TILE_HITS];
   __shared__ uint32_t sSeen[(TH_MAX * TH_MAX + 31) / 32];  // one bit per neighbourhood cell: a cell is a hit once
@@ -200,6 +201,12 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
             if (CB == 1) dst[b] = (uint8_t)qv[b];
             else reinterpret_cast<uint16_t *>(dst)[b] = (uint16_t)qv[b];
           }
+      }
+      if (CB == 2) {  // the plane of high bytes (columns past the raster stay zero, like the image's border)
+        uint32_t h = 0u;
+        for (int b = 0; b < 4; b++)
+          if (c0 + c4 + b < S) h |= (qv[b] >> 8) << (8 * b);
+        if (h) *reinterpret_cast<uint32_t *>(g + hi_offset + (size_t)(r0 + r + pad) * hi_pitch + (size_t)(c0 + c4 + pad)) = h;
       }
     }
   }
@@ -463,11 +470,12 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     if (L.cb == 1)
       hipLaunchKernelGGL(grid_blur_kernel<1>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
-                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16);
+                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16, (int64_t)0, 0);
     else
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
-                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16);
+                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_pitch);
     // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernels that
     // perform every add; the branch-and-bound matcher never reads it, so 16-bit grids -- its product path -- carry
     // one only when the spec asks.)

@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Match) == 16
     assert C.sizeof(_lib.GridSpec) == 48  # + flags, reserved
     assert C.sizeof(_lib.Search) == 24
-    assert C.sizeof(_lib.GridLayout) == 104  # + pool_* and pool4_* (branch-and-bound tables, levels 1 and 2)
+    assert C.sizeof(_lib.GridLayout) == 120  # + pool_*, pool4_* (branch-and-bound tables), hi_* (high bytes of 16-bit cells)
 
 
 def test_grid_layout_follows_cimg_debug():
@@ -50,9 +50,12 @@ def test_grid_layout_follows_cimg_debug():
     # second level: a byte pair per 4 x 4 cells + the reach of 22 sub-blocks + a 16-byte read from an aligned offset
     assert L.pool4_rows == 348 + 24 and L.pool4_pitch == 768 and L.pool4_bytes == 372 * 768
     assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes and L.slot_bytes % 16 == 0
+    assert L.hi_bytes == 0 and L.hi_pitch == 0
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
     L16 = csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=16))
     assert L16.cell_bytes == 2 and L16.pitch == 2 * 1392 and L16.rows == 1392 and L16.grid_bytes == 2 * 1392 * 1392
+    assert L16.hi_pitch == 1392 and L16.hi_bytes == 1392 * 1392  # the plane of high bytes, at the 8-bit pitch
+    assert L16.slot_bytes == L16.grid_bytes + L16.skip_bytes + L16.pool_bytes + L16.pool4_bytes + L16.hi_bytes
     for (r, res, side) in [(30, 0.3, 200), (30, 0.01, 6000), (10, 0.03, 666)]:
         assert csm.grid_layout(csm.grid_spec(r, res, 2.0, 1e-10, 4)).side == side
 

@@ -101,6 +101,11 @@ def test_grid_16bit_cells_bit_exact(gpu, small_bag):
             border = stored[:, :L.rows].copy()
             border[L.pad:L.pad + L.side, L.pad:L.pad + L.side] = 0
             assert not border.any(), "zero border violated"
+            # the plane of high bytes the matcher takes its block sums on: cell >> 8, zero wherever the image is
+            hi = grids.hi_plane(slot)
+            assert hi.shape == (L.rows, L.hi_pitch) and L.hi_pitch % 16 == 0 and L.hi_pitch >= L.rows
+            assert np.array_equal(hi[:, :L.rows], (stored[:, :L.rows] >> 8).astype(np.uint8))
+            assert not hi[:, L.rows:].any()
         grids.close()
         st.close()
 
@@ -658,7 +663,7 @@ def test_full_lattice_16bit_and_8bit_agree_with_oracle_and_each_other(gpu):
     ids = np.unique(tgt)
     slot = np.searchsorted(ids, tgt)
     search = csm.search_spec(61, 81, 81, DEG)
-    os.environ["NHIP_BNB_STATS"] = "1"
+    os.environ["NHIP_BNB_STATS"] = os.environ["NHIP_BNB_INSTRUMENT"] = "1"  # (the instrumented build of the kernels)
     try:
         csm.bnb_stats()
         for bits in (8, 16):
@@ -677,6 +682,7 @@ def test_full_lattice_16bit_and_8bit_agree_with_oracle_and_each_other(gpu):
             assert lv["candidates_refined"] > 0 and lv["sub_blocks"] < 2 * lv["candidates_refined"]
     finally:
         os.environ.pop("NHIP_BNB_STATS", None)
+        os.environ.pop("NHIP_BNB_INSTRUMENT", None)
 
 
 def test_cell_width_against_unquantised_table(gpu):

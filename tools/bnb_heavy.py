@@ -13,14 +13,14 @@ wl = bench.Workload("weak", 1, 1000, 10)
 plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
 shard = plan.shard(0)
 dev = torch.device("cuda", 0)
-os.environ["NHIP_BNB_STATS"] = "1"
+os.environ["NHIP_BNB_STATS"] = os.environ["NHIP_BNB_INSTRUMENT"] = "1"
 m = bench.HipMatcher(wl, shard, dev, 8)
 m.step(); torch.cuda.synchronize(); csm.bnb_stats()
 m.step(); torch.cuda.synchronize()
 per = np.zeros(m.n_pairs, dtype=np.uint64)
 _lib.check(lib.nhip_bnb_stats_per_pair(_lib.ptr(per), m.n_pairs))
 csm.bnb_stats()
-os.environ.pop("NHIP_BNB_STATS")
+os.environ.pop("NHIP_BNB_STATS"); os.environ.pop("NHIP_BNB_INSTRUMENT")
 m.free_grids(); del m
 order = np.argsort(per)[::-1]
 idx, src, tgt, th0, ids, slot = shard

@@ -7,7 +7,7 @@ sys.path.insert(0, ROOT)
 import numpy as np, torch
 import bench
 from nautilus_amd import _lib, csm, sharding
-os.environ["NHIP_BNB_STATS"] = "1"
+os.environ["NHIP_BNB_STATS"] = os.environ["NHIP_BNB_INSTRUMENT"] = "1"  # the instrumented build of the kernels
 lib = _lib.load()
 wl = bench.Workload("weak", 1, int(sys.argv[1]) if len(sys.argv) > 1 else 1000, 10)
 plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)

@@ -2,7 +2,7 @@
 """Timeline of the matcher's workgroups on the bench workload (GPU box): when each pair's workgroup started and
 ended, how many were resident over time, how long the tail is."""
 import json, os, sys
-os.environ["NHIP_BNB_TIMELINE"] = "1"
+os.environ["NHIP_BNB_TIMELINE"] = os.environ["NHIP_BNB_INSTRUMENT"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
@@ -11,7 +11,8 @@ from nautilus_amd import _lib, sharding
 lib = _lib.load()
 wl = bench.Workload("weak", 1, 1000, 10)
 plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
-m = bench.HipMatcher(wl, plan.shard(0), torch.device("cuda", 0), 8)
+BITS = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+m = bench.HipMatcher(wl, plan.shard(0), torch.device("cuda", 0), BITS)
 for _ in range(2):
     m.step()
 torch.cuda.synchronize()
@@ -26,7 +27,7 @@ t0 = t[:, 0].min()
 us = (t - t0) / 100.0
 dur = us[:, 3] - us[:, 0]
 end = us[:, 3].max()
-out = {"kernel_us": float(end), "wg_us_mean": float(dur.mean()), "wg_us_p50_p90_p99_max": [float(x) for x in np.percentile(dur, [50, 90, 99, 100])],
+out = {"cell_bits": BITS, "lib": os.path.basename(_lib.LIB_PATH), "kernel_us": float(end), "wg_us_mean": float(dur.mean()), "wg_us_p50_p90_p99_max": [float(x) for x in np.percentile(dur, [50, 90, 99, 100])],
        "bounds_us_mean": float((us[:, 1] - us[:, 0]).mean()), "seeds_us_mean": float((us[:, 2] - us[:, 1]).mean()),
        "phase3_us_mean": float((us[:, 3] - us[:, 2]).mean()),
        "sum_wg_us_over_512_slots": float(dur.sum() / 512), "env": {k_: v_ for k_, v_ in os.environ.items() if k_.startswith("NHIP_BNB")}}

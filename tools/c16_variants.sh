@@ -10,7 +10,7 @@ FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-result -ffp-
 build() {  # name, defines...
   name=$1; shift
   /opt/rocm/bin/hipcc $FLAGS "$@" -c nhip_csm16.hip -o $OUT/c16_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$name.so nhip_api.o nhip_grid.o nhip_csm.o $OUT/c16_$name.o nhip_bnb.o nhip_lc.o nhip_resid.o nhip_corr.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/lib_$name.so nhip_api.o nhip_grid.o nhip_csm.o $OUT/c16_$name.o nhip_bnb.o nhip_bnb_instr.o nhip_lc.o nhip_resid.o nhip_corr.o -ldl
   rm -f $OUT/c16_$name.o
 }
 rm -f $OUT/lib_*.so

@@ -2,8 +2,9 @@
     gpurun -- python tools/parity_sweep.py 400
 Random grid geometry / blur / lattice / search centre / dense, sparse and clustered clouds; grids,
 indices and integer sums must be bit-exact, for both cell widths, through the branch-and-bound matcher (lattices up
-to 88 x 88) AND the kernel that performs every add (8-bit cells).  Round 1: 400 configurations, all equal;
-round 2: 3000 configurations x {8, 16}-bit, all equal (210 s)."""
+to 88 x 88) AND the kernel that performs every add (csm_correlate_kernel / csm_correlate16_kernel).  Round 1: 400
+configurations, all equal; round 2: 3000 configurations x {8, 16}-bit, all equal (210 s).  `--quick`: 100 configurations
+(tests/test_parity_sweep_gpu.py runs that form under -m gpu)."""
 import math, sys, time
 import numpy as np
 import os
@@ -15,7 +16,8 @@ bag = synth.SynthBag(64, dense=True)
 sparse = synth.SynthBag(64, dense=False, seed=7)
 n_ok = 0
 t0 = time.time()
-for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
+N_CONF = 100 if "--quick" in sys.argv else next((int(a) for a in sys.argv[1:] if a.isdigit()), 60)
+for seed in range(N_CONF):
     rng = np.random.default_rng(1000 + seed)
     B = bag if rng.random() < 0.6 else sparse
     range_m = float(rng.choice([8.0, 12.0, 20.0, 30.0])); res = float(rng.choice([0.05, 0.08, 0.1, 0.025]))
@@ -24,7 +26,7 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     if range_m / res > 900: res = range_m / 600
     n_theta = 2 * int(rng.integers(0, 6)) + 1
     step = float(rng.choice([0.25, 1.0, 3.0])) * DEG
-    bits = 16 if (seed % 2 and max(hx, hy) <= 43) else 8   # 16-bit cells need the branch-and-bound matcher's lattice limit
+    bits = 16 if seed % 2 else 8
     spec = csm.grid_spec(range_m, res, sigma, 1e-10, max(hx, hy) + 12, bits); ospec = O.grid_spec(range_m, res, sigma, 1e-10, bits)
     search = csm.search_spec(n_theta, 2 * hx + 1, 2 * hy + 1, step)
     n_pairs = int(rng.integers(1, 20))
@@ -40,10 +42,9 @@ for seed in range(int(sys.argv[1]) if len(sys.argv) > 1 else 60):
     xy, off = csm.pack_scans(scans)
     st = csm.ScanTable(xy, off); grids = csm.LikelihoodGrids(st, ids, spec)
     got, sums = csm.match_pairs(st, grids, src, slot, th0, search, origin)
-    if bits == 8:
-        ex = csm.search_spec(n_theta, 2 * hx + 1, 2 * hy + 1, step, exhaustive=True)
-        got_x, sums_x = csm.match_pairs(st, grids, src, slot, th0, ex, origin)
-        assert got_x.tobytes() == got.tobytes() and np.array_equal(sums_x, sums), ("bnb vs exhaustive", seed)
+    ex = csm.search_spec(n_theta, 2 * hx + 1, 2 * hy + 1, step, exhaustive=True)
+    got_x, sums_x = csm.match_pairs(st, grids, src, slot, th0, ex, origin)
+    assert got_x.tobytes() == got.tobytes() and np.array_equal(sums_x, sums), ("bnb vs exhaustive", seed)
     ogr = O.grid_build_batch(xy, off, ids, ospec)
     for s_, i_ in enumerate(ids):
         assert np.array_equal(grids.interior(s_), ogr[s_]), ("grid", seed, s_)
