@@ -60,6 +60,8 @@ def parse(argv=None):
                          "path for callers that only gate on a threshold (secondary.csm_u8)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-resid", action="store_true", help="skip the secondary measurements")
+    ap.add_argument("--no-cost-model", action="store_true",
+                    help="shard by pair count and launch in by-target order (no per-pair cost estimate)")
     ap.add_argument("--no-drop-in", action="store_true",
                     help="skip the single-pair latency leg (its small launches of the correlation kernel would "
                          "blur that kernel's average in a rocprofv3 --stats summary)")
@@ -140,12 +142,20 @@ class HipMatcher:
     """This rank's shard on the MI355X: device-resident scans, pair list, grids; step() enqueues the
     host trig + K1 + K2/K3 and returns the (n_local, 4) int32 record tensor."""
 
-    def __init__(self, wl, shard, device, cell_bits=8, exhaustive=False):
+    def __init__(self, wl, shard, device, cell_bits=8, exhaustive=False, weights=None):
+        """weights: cost estimate per pair of the shard (sharding.predicted_pair_cost): the pairs are handed to the
+        matcher heaviest first (one workgroup per pair, started in index order: a pair that takes milliseconds must
+        not start last); step() returns the records in shard order either way."""
         import torch
-        from nautilus_amd import _lib, csm
+        from nautilus_amd import _lib, csm, sharding
         self.torch, self._lib, self.lib = torch, _lib, _lib.load()
         idx, src, tgt, th0, ids, slot = shard
         self.n_pairs, self.n_targets = len(src), len(ids)
+        self.d_unperm = None
+        if weights is not None and self.n_pairs:
+            perm, inv = sharding.pair_launch_order(weights)
+            src, slot, th0 = src[perm], slot[perm], th0[perm]
+            self.d_unperm = torch.from_numpy(inv.astype(np.int64)).to(device)
         self.src, self.slot, self.ids = src, slot, ids
         # (the kernel that performs every add reads the skip maps; the branch-and-bound matcher does not, and 16-bit
         #  grids are built without them unless asked)
@@ -171,6 +181,7 @@ class HipMatcher:
         self.ws_csm = self.lib.nhip_csm_workspace_bytes(self.n_pairs)
         self.d_ws_csm = torch.empty(self.ws_csm, dtype=torch.uint8, device=device)
         self.sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        self.built = False  # after the first build the grids are REbuilt: only the tiles the last build wrote are cleared
 
     def step(self):
         lib, ck = self.lib, self._lib.check
@@ -178,15 +189,25 @@ class HipMatcher:
             return self.d_out[:0]
         ck(lib.nhip_csm_rot0(self._lib.ptr(self.h_th0), None, self.n_pairs, self._lib.ptr(self.rot0_np)))
         self.d_rot0.copy_(self.h_rot0, non_blocking=True)
-        ck(lib.nhip_grid_build_dev(self.d_xy.data_ptr(), self.d_off.data_ptr(), self.d_ids.data_ptr(), self.n_targets,
-                                   C.byref(self.spec), self.d_grids.data_ptr(), self.d_ws.data_ptr(), self.ws_bytes,
-                                   self.sp))
+        build = lib.nhip_grid_rebuild_dev if self.built else lib.nhip_grid_build_dev
+        ck(build(self.d_xy.data_ptr(), self.d_off.data_ptr(), self.d_ids.data_ptr(), self.n_targets,
+                 C.byref(self.spec), self.d_grids.data_ptr(), self.d_ws.data_ptr(), self.ws_bytes, self.sp))
+        self.built = True
         ck(lib.nhip_csm_match_dev(self.d_xy.data_ptr(), self.d_off.data_ptr(), self.d_grids.data_ptr(),
                                   C.byref(self.spec), self.d_src.data_ptr(), self.d_slot.data_ptr(),
                                   self.d_rot0.data_ptr(), self.d_delta.data_ptr(), None, self.n_pairs,
                                   C.byref(self.search), self.d_keys.data_ptr(), self.d_out.data_ptr(),
                                   self.d_sums.data_ptr(), self.d_ws_csm.data_ptr(), self.ws_csm, self.sp))
+        if self.d_unperm is not None:  # back to shard order (records and sums)
+            self.d_out_shard = self.d_out[:self.n_pairs].index_select(0, self.d_unperm)
+            return self.d_out_shard
         return self.d_out[:self.n_pairs]
+
+    def records(self):
+        """(records (n, 4) int32, sums int32) of the last step, in shard order."""
+        if self.d_unperm is not None:
+            return self.d_out[:self.n_pairs].index_select(0, self.d_unperm), self.d_sums[:self.n_pairs].index_select(0, self.d_unperm)
+        return self.d_out[:self.n_pairs], self.d_sums[:self.n_pairs]
 
     def free_grids(self):
         self.d_grids = None
@@ -257,12 +278,47 @@ def _cpu_info():
     return {"cpu_model": model, "hw_threads": threads or os.cpu_count(), "physical_cores": len(phys) or None}
 
 
+def kernel_source_hash():
+    """sha256 over nautilus_amd/csrc (the same recipe as tools/make_traffic_json.py)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    base = os.path.join(ROOT, "nautilus_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(base, "*.hip")) + glob.glob(os.path.join(base, "*.h")) + [os.path.join(base, "Makefile")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+_TRAFFIC = None
+
+
+def _traffic_file():
+    """profiles/traffic.json (counters of the committed PMC passes) + whether it describes THIS build: the file carries
+    the hash of the kernel sources it was taken from; another tree's counters would silently misprice the roofline."""
+    global _TRAFFIC
+    if _TRAFFIC is None:
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+        except Exception:
+            d = {}
+        have, want = d.get("kernel_source_hash"), kernel_source_hash()
+        _TRAFFIC = (d, {"profile_hash": have, "tree_hash": want, "stale": have != want})
+    return _TRAFFIC
+
+
 def _traffic(key):
-    """Numbers taken from the committed PMC profiles (profiles/traffic.json), or None."""
-    try:
-        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
-    except Exception:
-        return None
+    """A number taken from the committed PMC profiles, or None (missing, or taken from other kernel sources)."""
+    d, st = _traffic_file()
+    return None if st["stale"] else d.get(key)
+
+
+def _profile_matches(wl, n_pairs):
+    """The counters are per launch of the profiled workload (BASELINE configs[1]: 10,000 pairs); the matcher's work is
+    data dependent, so they are not scaled to other pair lists."""
+    d, st = _traffic_file()
+    w = d.get("workload") or {}
+    return (not st["stale"]) and wl.mode == w.get("mode") and n_pairs == w.get("pairs") and wl.per_target == w.get("per_target")
 
 
 def _timer(lib, _lib, tid):
@@ -276,9 +332,9 @@ def onchip_roofline(n_pairs, avg_ms, cell_bits, kernel="bnb"):
     per launch come from rocprofv3's SQ counters on this workload (profiles/traffic.json, per 10k-pair launch,
     scaled by the pair count); the kernel time is the one measured live in this run."""
     sq = _traffic("csm_%s_sq_per_launch_10000pairs_u%d" % (kernel, cell_bits))
-    if not sq:
+    if not sq or n_pairs != 10000:
         return None
-    k, secs = n_pairs / 10000.0, avg_ms * 1e-3
+    k, secs = 1.0, avg_ms * 1e-3
     valu, salu = k * sq["SQ_INSTS_VALU"] / secs, k * sq["SQ_INSTS_SALU"] / secs
     out = {"valu_wave_instr_per_s": valu, "valu_peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
            "valu_frac": valu / VALU_PEAK_WAVE_INSTR,
@@ -343,9 +399,12 @@ def worker(a):
         assert dist.get_world_size() == world
 
     wl = Workload(a.mode, world, a.scans, a.per_target)
-    plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, world)
+    # cost estimate per pair from the odometry poses the caller holds (the pair list itself is gated on them): balances
+    # the ranks' shards and orders each rank's launch heaviest first.  Part of the plan: computed once, outside the steps.
+    weights = None if a.no_cost_model else sharding.predicted_pair_cost(wl.bag.odom, wl.src, wl.tgt)
+    plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, world, weights)
     shard = plan.shard(rank)
-    m = HipMatcher(wl, shard, dev, a.cell_bits)
+    m = HipMatcher(wl, shard, dev, a.cell_bits, weights=plan.shard_weights(rank))
 
     def start_timers():
         lib.nhip_timing_reset()
@@ -355,6 +414,7 @@ def worker(a):
     lib.nhip_timing_enable(0)
     k_ms, k_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
     g_ms, g_n = _timer(lib, _lib, _lib.NHIP_TIMER_GRID)
+    c_ms, _ = _timer(lib, _lib, _lib.NHIP_TIMER_GRID_CLEAR)
     avg_ms = k_ms / max(k_n, 1)
 
     # per-rank load balance: pairs, targets, correlate-kernel ms per step
@@ -367,19 +427,21 @@ def worker(a):
         per_rank = mine.cpu().numpy()[None]
     # this rank's block of the gathered table must equal what this rank computed
     got_local = full.index_select(0, torch.from_numpy(shard[0].astype(np.int64)).to(dev))
-    assert torch.equal(got_local, m.d_out[:m.n_pairs]), "all-gather returned a different block for this rank"
+    assert torch.equal(got_local, m.records()[0]), "all-gather returned a different block for this rank"
     if rank != 0:
         dist.destroy_process_group()
         return 0
 
-    got = m.d_out[:m.n_pairs].cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
-    got_sums = m.d_sums[:m.n_pairs].cpu().numpy()
+    got = m.records()[0].cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
+    got_sums = m.records()[1].cpu().numpy()
     cell_bytes = a.cell_bits // 8
     lookups_per_pair = m.search.n_theta * m.search.nx * m.search.ny * synth.N_BEAMS  # 432,638,901
     alg_bytes = float(m.n_pairs) * lookups_per_pair * cell_bytes  # per launch of rank 0's shard
     hbm_equiv = alg_bytes / (avg_ms * 1e-3) / 1e9
-    oc = onchip_roofline(m.n_pairs, avg_ms, a.cell_bits)
-    traffic = _traffic("csm_bnb_bytes_per_launch_%dpairs_u%d" % (m.n_pairs, a.cell_bits))
+    matches = _profile_matches(wl, m.n_pairs)
+    oc = onchip_roofline(m.n_pairs, avg_ms, a.cell_bits) if matches else None
+    traffic = _traffic("csm_bnb_bytes_per_launch_%dpairs_u%d" % (m.n_pairs, a.cell_bits)) if matches else None
+    prof = dict(_traffic_file()[1], workload_matches_profile=matches)
     bnb = None
     if os.environ.get("NHIP_BNB_STATS") == "1" and os.environ.get("NHIP_BNB_INSTRUMENT") == "1":
         lv = csm.bnb_stats_levels()
@@ -422,9 +484,12 @@ def worker(a):
                      "other_ceilings": {"l1_lookups_per_clk_per_cu": oc.get("l1_tag_frac") if oc else None,
                                         "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                                         "waves_waiting_frac": oc.get("wave_wait_frac") if oc else None},
-                     "note": "VALU wave64 instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/) / kernel time "
-                             "measured live with HIP events on the launch stream; peak = 1024 SIMDs x 2.4 GHz / 2 clk; "
-                             "traffic = HBM bytes per launch from the PMC passes"},
+                     "stale": prof["stale"], "profile": prof,
+                     "note": "VALU wave64 instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/traffic.json) / kernel "
+                             "time measured live with HIP events on the launch stream; peak = 1024 SIMDs x 2.4 GHz / 2 clk; "
+                             "traffic = HBM bytes per launch from the PMC passes.  The counters belong to one build and "
+                             "one workload: frac, achieved and traffic are null when traffic.json was taken from other "
+                             "kernel sources (stale) or this run's pair list is not the profiled one"},
         # SURVEY 8(d)'s gather-equivalent figure: every lookup of the exhaustive definition priced at one cell.
         # It exceeds the HBM peak because the lookups are served from LDS: NOT a fraction of a physical ceiling.
         "roofline_hbm_equiv": {"bound": "hbm", "achieved": hbm_equiv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -432,7 +497,10 @@ def worker(a):
                                "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                                "note": "gather-equivalent: lookups x cell bytes / kernel time; hbm_traffic_frac = measured "
                                        "HBM bytes per launch / kernel time / 8 TB/s"},
-        "kernels_ms_per_step": {"csm_match": k_ms / a.steps, "grid_blur_skipmap_pool": g_ms / a.steps},
+        "kernels_ms_per_step": {"csm_match": k_ms / a.steps, "grid_build": g_ms / a.steps,
+                                "of_which_grid_clear": c_ms / a.steps,
+                                "host_trig_h2d_finalize_gather": 1e3 * elapsed / a.steps - (k_ms + g_ms) / a.steps,
+                                "kernels_share_of_step": (k_ms + g_ms) / (1e3 * elapsed)},
         "onchip_roofline": oc,
         "algorithm": {"name": "branch and bound, exact: bounds of 8x8 blocks of translations from a max-pooled table "
                               "(run-length compressed points), 4x4 sub-block bounds from a second table, exact sums for "
@@ -455,7 +523,7 @@ def worker(a):
         recs = {a.cell_bits: (got, got_sums)}  # the branch-and-bound records by cell width
 
         def other_cells():
-            r = leg_other_cells(wl, shard, dev, a)
+            r = leg_other_cells(wl, shard, dev, a, weights=plan.shard_weights(rank))
             recs[24 - a.cell_bits] = r.pop("_records")
             return r
 
@@ -465,7 +533,8 @@ def worker(a):
         for name, fn in (("csm_u16" if a.cell_bits == 8 else "csm_u8", other_cells),
                          ("exhaustive_u16", lambda: exhaustive(16)),
                          ("exhaustive_u8", lambda: exhaustive(8)),
-                         ("resid_lidar", lambda: bench_residuals(torch, lib, dev, m.sp, a.cpu_seconds > 0)),):
+                         ("resid_lidar", lambda: bench_residuals(torch, lib, dev, m.sp, a.cpu_seconds > 0)),
+                         ("resid_feature_mode", lambda: bench_residuals_feature(torch, lib, dev, a.cpu_seconds > 0)),):
             try:
                 sec[name] = fn()
             except Exception as e:  # secondary measurements must not lose the headline line
@@ -519,8 +588,8 @@ def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3, bits=8):
                  "lookups_per_s": lookups / (avg * 1e-3)}
             if got is not None:
                 r["same_result_as_branch_and_bound_u%d" % bits] = bool(
-                    np.array_equal(m.d_sums[:m.n_pairs].cpu().numpy(), got_sums) and
-                    m.d_out[:m.n_pairs].cpu().numpy().tobytes() == got.tobytes())
+                    np.array_equal(m.records()[1].cpu().numpy(), got_sums) and
+                    m.records()[0].cpu().numpy().tobytes() == got.tobytes())
             if not env:
                 oc = onchip_roofline(m.n_pairs, avg, bits, "correlate")
                 r["roofline"] = {"bound": "valu", "avg_launch_ms": avg,
@@ -536,14 +605,14 @@ def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3, bits=8):
     return out
 
 
-def leg_other_cells(wl, shard, dev, a, steps=3):
+def leg_other_cells(wl, shard, dev, a, steps=3, weights=None):
     """The same workload on the other cell width (16-bit cells meet the 1e-5 score tolerance against an
     unquantised table, 8-bit cells do not: DESIGN.md section 3)."""
     import torch
     from nautilus_amd import _lib, csm
     bits = 16 if a.cell_bits == 8 else 8
     lib = _lib.load()
-    m2 = HipMatcher(wl, shard, dev, bits)
+    m2 = HipMatcher(wl, shard, dev, bits, weights=weights)
     m2.step()
     torch.cuda.synchronize()
     lib.nhip_timing_reset()
@@ -557,7 +626,7 @@ def leg_other_cells(wl, shard, dev, a, steps=3):
     ms, n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
     avg = ms / max(n, 1)
     oc = onchip_roofline(m2.n_pairs, avg, bits)
-    rec = (m2.d_out[:m2.n_pairs].cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1).copy(), m2.d_sums[:m2.n_pairs].cpu().numpy().copy())
+    rec = (m2.records()[0].cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1).copy(), m2.records()[1].cpu().numpy().copy())
     res = {"_records": rec, "dtype": "u%d" % bits, "value": m2.n_pairs / dt, "unit": "pairs/s", "ms_per_step": 1e3 * dt,
            "correlate_kernel_ms": avg, "steps": steps,
            "roofline": {"bound": "valu", "frac": oc["valu_frac"] if oc else None, "peak": VALU_PEAK_WAVE_INSTR / 1e12,
@@ -804,6 +873,130 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
     return out
 
 
+def feature_blocks(n_poses=1000, window=10, seed=3):
+    """The blocks Solver::SolveSLAM actually builds (OptimizationType::FEATURE, solver.cc:363, 297-318): per (i, j)
+    pair of a window-10 graph one LIDARNormalResidual block on the planar features and one LIDARPointResidual block
+    on the edge features of scan i -- at most 20 and 10 points (FeatureExtractor(pc, 0.008, 2.0, 10, 10, 20, 10),
+    slam_types.h:66-67), fewer where the 0.25 m outlier gate drops a match (solver.cc:156-170).  Synthetic
+    correspondences of that shape: returns {kind: (corr (n, 8) float32, offsets, block_src, block_tgt)}, poses."""
+    rng = np.random.default_rng(seed)
+    bs, bt = [], []
+    for i in range(1, n_poses):
+        for j in range(max(0, i - window), i):
+            bs.append(i)
+            bt.append(j)
+    bs, bt = np.asarray(bs, np.int32), np.asarray(bt, np.int32)
+    out = {}
+    for kind, cap in ((0, 20), (1, 10)):
+        cnt = rng.integers(cap // 2, cap + 1, len(bs))
+        off = np.zeros(len(bs) + 1, np.int32)
+        np.cumsum(cnt, out=off[1:])
+        n = int(off[-1])
+        a = rng.uniform(-math.pi, math.pi, n)
+        r = rng.uniform(1.0, 12.0, n)
+        sp = np.stack([r * np.cos(a), r * np.sin(a)], 1)
+        tp = sp + rng.normal(0, 0.05, (n, 2))
+        na = a + rng.normal(0, 0.1, n)
+        nrm = np.stack([np.cos(na), np.sin(na)], 1)
+        out[kind] = (np.concatenate([sp, tp, nrm, nrm + rng.normal(0, 0.02, (n, 2))], 1).astype(np.float32), off, bs, bt)
+    poses = np.cumsum(rng.normal(0, 0.1, (n_poses, 3)), axis=0)
+    return out, poses
+
+
+def bench_residuals_feature(torch, lib, dev, with_cpu, evals=20):
+    """The production block shape (FEATURE mode: <= 20 planar + <= 10 edge rows per block, 9,945 + 9,945 blocks) through
+    the host-buffer API a Ceres EvaluationCallback uses (nhip_resid_batch_eval_compact: poses up, residuals + J_src +
+    the theta column of J_tgt down, every evaluation) and through the per-block normal equations, with the Jet<6>
+    CPU restatement on all host threads beside it.  At ~300k correspondences the evaluation is launch- and
+    PCIe-latency-bound on the GPU and cache-resident on the CPU: whichever wins is reported as it is."""
+    from nautilus_amd import _lib
+    blocks, poses = feature_blocks()
+    out = {"workload": "FEATURE mode (solver.cc:363): 1000 poses, window 10 -> 9,945 LIDARNormal blocks of <= 20 rows + "
+                       "9,945 LIDARPoint blocks of <= 10 rows", "evaluations": evals}
+    n_poses = len(poses)
+    hnd, pins, total = {}, {}, 0
+    pin = lambda n: torch.empty(max(n, 1), dtype=torch.float64).pin_memory().numpy()
+    for kind, (corr, off, bs, bt) in blocks.items():
+        h = C.c_void_p()
+        _lib.check(lib.nhip_resid_batch_create(kind, _lib.ptr(corr), _lib.ptr(off), _lib.ptr(bs), _lib.ptr(bt), len(bs),
+                                               n_poses, C.byref(h)))
+        hnd[kind] = h
+        n = len(corr)
+        total += n
+        pins[kind] = (pin(2 * n), pin(6 * n), pin(2 * n))
+    out["correspondences"] = total
+
+    def gpu_eval(jac):
+        for kind in hnd:
+            r, js, jtt = pins[kind]
+            if jac:
+                _lib.check(lib.nhip_resid_batch_eval_compact(hnd[kind], _lib.ptr(poses), _lib.ptr(r), _lib.ptr(js), _lib.ptr(jtt)))
+            else:
+                _lib.check(lib.nhip_resid_batch_eval(hnd[kind], _lib.ptr(poses), _lib.ptr(r), None, None))
+    for jac, name in ((True, "with_jacobians"), (False, "residuals_only")):
+        gpu_eval(jac)
+        t0 = time.perf_counter()
+        for _ in range(evals):
+            gpu_eval(jac)
+        dt = (time.perf_counter() - t0) / evals
+        out["gpu_host_buffer_api_%s" % name] = {"seconds_per_evaluation": dt, "correspondences_per_s": total / dt}
+    # device-resident path: the same blocks reduced to 28 doubles per block on the GPU (what the build's own solver eats)
+    d = {}
+    for kind, (corr, off, bs, bt) in blocks.items():
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        d[kind] = (t(corr), t(off), t(bs), t(bt), torch.empty(8 * len(bs), dtype=torch.float64, device=dev),
+                   torch.empty(28 * len(bs), dtype=torch.float64, device=dev))
+    d_poses = torch.from_numpy(poses).to(dev)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def neq():
+        for kind, (c, o, bs_, bt_, consts, outb) in d.items():
+            _lib.check(lib.nhip_resid_lidar_normal_eq_dev(kind, c.data_ptr(), o.data_ptr(), bs_.data_ptr(), bt_.data_ptr(),
+                                                          len(bs_), d_poses.data_ptr(), n_poses, consts.data_ptr(),
+                                                          outb.data_ptr(), sp))
+    neq()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(evals):
+        neq()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / evals
+    out["gpu_normal_equations_device_resident"] = {"seconds_per_evaluation": dt, "correspondences_per_s": total / dt,
+                                                   "bytes_out_per_evaluation": 2 * 9945 * 224}
+    if with_cpu:
+        from oracle import oracle as O
+        thr = O.num_threads()
+        cpu = {}
+        for jac, name in ((True, "with_jacobians"), (False, "residuals_only")):
+            def run():
+                res = []
+                for kind, (corr, off, bs, bt) in blocks.items():
+                    res.append(O.lidar_batch(kind, corr, off, bs, bt, poses, jac, thr))
+                return res
+            med, ts, res = _median_runs(run, 5)
+            cpu[name] = {"seconds_per_evaluation": med, "correspondences_per_s": total / med}
+            if jac:
+                ok = True
+                for (kind, _), (wr, w0, w1) in zip(blocks.items(), res):
+                    r, js, jtt = pins[kind]
+                    n = len(blocks[kind][0])
+                    ok = ok and np.allclose(r[:2 * n], wr, rtol=1e-9, atol=1e-9) and \
+                        np.allclose(js[:6 * n].reshape(-1, 3), w0, rtol=1e-9, atol=1e-9) and \
+                        np.allclose(jtt[:2 * n], w1[:, 2], rtol=1e-9, atol=1e-9)
+                cpu["gpu_matches_oracle"] = bool(ok)
+        # one thread too: at this size the all-thread run is dominated by the fork/join of an OpenMP region
+        med1, _, _ = _median_runs(lambda: [O.lidar_batch(k_, c_, o_, s_, t_, poses, True, 1) for k_, (c_, o_, s_, t_) in blocks.items()], 3)
+        cpu["with_jacobians_one_thread"] = {"seconds_per_evaluation": med1, "correspondences_per_s": total / med1}
+        cpu.update({"kind": "port", "cores": thr, "sample": "all 19,890 blocks, Jet<6> autodiff restatement, OpenMP over blocks; median of 5"})
+        out["cpu_baseline"] = cpu
+        g, c = out["gpu_host_buffer_api_with_jacobians"]["seconds_per_evaluation"], cpu["with_jacobians"]["seconds_per_evaluation"]
+        out["faster_through_the_ceres_shaped_api"] = "gpu" if g < c else "cpu"
+        out["gpu_over_cpu_time_ratio_with_jacobians"] = g / c
+    for h in hnd.values():
+        lib.nhip_resid_batch_free(h)
+    return out
+
+
 def bench_icp(bag, xy, off, with_cpu, window=10, iters=5):
     """SURVEY 8f rows 1-2 at BASELINE configs[2] scale: 1000 poses, window 10 -> 9,945 (i, j) blocks of
     1081-point scans: correspondence search (K5) + per-block normal equations, all resident in HBM."""
@@ -861,19 +1054,25 @@ def bench_config1(with_cpu):
     examples/slam_loop.py drives both through the same host code (scipy sparse solves included in both)."""
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import slam_loop
-    # 0.4 m between scans: the 200 scans cover 1.3 laps of the room, so the bag closes its loop
-    kw = dict(n_scans=200, window=10, min_scatter_score=0.3, cell_bits=16, spacing=0.4)
+    # 0.55 m between scans: the 200 scans cover 2.4 laps of the 45 m loop and LCCandidateFilter's 5 m spacing puts the
+    # candidate nodes of successive laps within the matcher's +-2 m window of each other (tools/lc_leg_probe.py: 10-11 of
+    # 11 candidate pairs accepted; at 0.4 m the candidates interleave 2.6 m apart and none is)
+    kw = dict(n_scans=200, window=10, min_scatter_score=0.3, cell_bits=16, spacing=0.55)
     out = {"workload": "configs[0]: 200 dense 1081-beam scans; growing-window ICP solve 1..10 (LIDARNormalResidual on all "
                        "points), scatter-score candidates + geometric pair gate, 61x81x81 scan matching on 16-bit tables, "
                        "constraints + re-solve, one HITL message + re-solve"}
     slam_loop.run(n_scans=40, window=2, hitl=False, min_scatter_score=0.3)  # warm up the GPU path
     out["gpu"] = slam_loop.run(**kw)
+    assert out["gpu"]["lc_accepted"] > 0, "configs[0] leg: the bag does not close its loop (no loop closure accepted)"
     if with_cpu:
         from oracle import oracle as O
         from oracle.cpu_backend import OracleBackend
         out["cpu"] = slam_loop.run(backend=OracleBackend(), **kw)
         out["cpu"].update({"kind": "port", "cores": O.num_threads()})
         out["wall_clock_ratio_cpu_over_gpu"] = out["cpu"]["t_total_s"] / max(out["gpu"]["t_total_s"], 1e-9)
+        out["loop_closure_ratio_cpu_over_gpu"] = (out["cpu"]["t_csm_s"] + out["cpu"]["t_lc_solve_s"]) / \
+            max(out["gpu"]["t_csm_s"] + out["gpu"]["t_lc_solve_s"], 1e-9)
+        out["same_loop_closures"] = bool(out["cpu"]["lc_accepted"] == out["gpu"]["lc_accepted"])
         out["same_trajectory"] = bool(abs(out["cpu"]["err_hitl_m"] - out["gpu"]["err_hitl_m"]) < 1e-6)
     return out
 

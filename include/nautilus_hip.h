@@ -175,6 +175,16 @@ int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32
                         int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
                         void *d_workspace, int64_t workspace_bytes, void *stream);
 
+/* The same build INTO A BUFFER THE PREVIOUS BUILD FILLED: instead of zero-filling n_targets * slot_bytes (gigabytes at
+ * 1000 targets) it clears the ~20 % of 64 x 64 tiles the previous build wrote -- their list is still in the workspace
+ * -- and the small derived tables.  Contract: same d_workspace as the build that last wrote d_grids, and d_grids
+ * untouched since.  The workspace header carries a tag of (d_grids, n_targets, geometry) that the clearing kernel checks
+ * on the device: a header that does not vouch for this buffer (fresh or recycled workspace memory, another buffer,
+ * another spec) makes the call clear everything, i.e. behave as nhip_grid_build_dev.  Same results, bit for bit. */
+int nhip_grid_rebuild_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+                          int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
+                          void *d_workspace, int64_t workspace_bytes, void *stream);
+
 /* K2+K3: exhaustive (theta, x, y) correlation + argmax for n_pairs candidate pairs.
  * Pair i matches scan d_pair_src[i] against grid slot d_pair_slot[i].
  * d_rot0_cs: 2 doubles (cos, sin theta0) per pair; d_delta_cs: 2 doubles per lattice rotation.
@@ -426,14 +436,15 @@ int nhip_allgather_matches(void *comm, const nhip_match_t *d_local, int32_t n_lo
 
 /* ------------------------------------------------------------------ in-stream kernel timing
  * When enabled, the dominant kernels are bracketed by hipEvents on their own stream.
- * ids: 0 = csm_correlate, 1 = grid_build (blur), 2 = resid_lidar, 3 = corr_search,
- *      4 = resid_normal_eq. */
+ * ids: 0 = csm match (bounds, candidates, exact sums), 1 = grid build (everything nhip_grid_build_dev enqueues),
+ *      2 = resid_lidar, 3 = corr_search, 4 = resid_normal_eq, 5 = the clearing part of a grid build (inside 1). */
 #define NHIP_TIMER_CSM 0
 #define NHIP_TIMER_GRID 1
 #define NHIP_TIMER_RESID 2
 #define NHIP_TIMER_CORR 3
 #define NHIP_TIMER_NORMEQ 4
-#define NHIP_TIMER_COUNT 5
+#define NHIP_TIMER_GRID_CLEAR 5
+#define NHIP_TIMER_COUNT 6
 int nhip_timing_enable(int on);
 int nhip_timing_reset(void);
 /* synchronises the recorded events; total_ms / launches since the last reset */

@@ -15,7 +15,7 @@ NHIP_OK, NHIP_ERR_ARG, NHIP_ERR_NODEV, NHIP_ERR_HIP, NHIP_ERR_ALLOC, NHIP_ERR_ST
 NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1
 NHIP_SEARCH_EXHAUSTIVE = 1
 NHIP_GRID_SKIP_MAP = 1
-NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ = 0, 1, 2, 3, 4
+NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ, NHIP_TIMER_GRID_CLEAR = 0, 1, 2, 3, 4, 5
 
 
 class NhipError(RuntimeError):
@@ -74,6 +74,7 @@ PROTOTYPES = {
                                           _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "nhip_score_from_sum": (_f64, [_P(GridSpec), _i64, _i32]),
     "nhip_grid_build_dev": (C.c_int, [_vp, _vp, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
+    "nhip_grid_rebuild_dev": (C.c_int, [_vp, _vp, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
     "nhip_csm_match_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _vp, _vp, _vp, _vp, _vp, _i32,
                                      _P(Search), _vp, _vp, _vp, _vp, _i64, _vp]),
     "nhip_csm_workspace_bytes": (_i64, [_i32]),

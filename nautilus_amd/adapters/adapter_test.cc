@@ -4,6 +4,8 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <array>
 #include <atomic>
 #include <cstring>
 #include <string>
@@ -91,7 +93,6 @@ int main(int argc, char **argv) {
 
   // ---- residual blocks, used as solver.cc:277-295 + Ceres' evaluation loop would
   auto &B = nautilus_hip::ResidualBatcher::Instance();
-  B.Reset();
   std::vector<Vec2f> sp, tp, sn, tn;
   for (int i = 0; i < 300; i++) {
     const float a = 0.01f * i;
@@ -110,6 +111,7 @@ int main(int argc, char **argv) {
   double const *params[2] = {poses[0], poses[1]};
   // No Bind, no PrepareForEvaluation: the block learns its parameter blocks from this call and is evaluated alone on
   // the GPU at the parameters passed in (what ceres::Problem::Evaluate or Covariance::Compute would trigger).
+  REQUIRE(B.slow_path_calls() == 0 && B.live_blocks(nautilus_hip::kLidarNormal) == 2 && B.live_blocks(nautilus_hip::kLidarPoint) == 1);
   REQUIRE(c0->Evaluate(params, r.data(), jac));
   REQUIRE(B.slow_path_calls() == 1);
   const std::vector<double> r_one = r, j0_one = j0, j1_one = j1;
@@ -187,8 +189,125 @@ int main(int argc, char **argv) {
     REQUIRE(B.slow_path_calls() == before);  // all 3200 calls took the lock-free path
     std::printf("resid: 16 threads x 200 Evaluate() calls on the prepared batch: identical, lock-free\n");
   }
-  delete c0; delete c1; delete c2;
-  B.Reset();
+  if (dump) {
+    // the three LIDAR blocks' inputs and what Evaluate() returned at the prepared point, for the oracle comparison
+    // (tests/test_adapters_gpu.py: orc_lidar_block, the Jet<6> restatement of slam_residuals.h:65-89, 124-145)
+    nautilus_hip::BatchedCost *blocks[3] = {c0, c1, c2};
+    double const *bp[3][2] = {{poses[0], poses[1]}, {poses[0], poses[1]}, {poses[2], poses[0]}};
+    const std::vector<Vec2f> *in[3][4] = {{&sp, &tp, &sn, &tn}, {&sp, &tp, &sn, &tn}, {&tp, &sp, &tn, &sn}};
+    for (int q = 0; q < 3; q++) {
+      std::vector<double> rr(600), ja(1800), jb(1800);
+      double *jq[2] = {ja.data(), jb.data()};
+      REQUIRE(blocks[q]->Evaluate(bp[q], rr.data(), jq));
+      FILE *f = std::fopen((std::string(dump) + "/lidar_block_" + std::to_string(q) + ".bin").c_str(), "wb");
+      REQUIRE(f != nullptr);
+      const int32_t head[2] = {blocks[q]->family(), 300};
+      std::fwrite(head, sizeof(head), 1, f);
+      for (int v = 0; v < 4; v++) std::fwrite(in[q][v]->data(), sizeof(Vec2f), 300, f);
+      std::fwrite(bp[q][0], sizeof(double), 3, f);
+      std::fwrite(bp[q][1], sizeof(double), 3, f);
+      std::fwrite(rr.data(), sizeof(double), 600, f);
+      std::fwrite(ja.data(), sizeof(double), 1800, f);
+      std::fwrite(jb.data(), sizeof(double), 1800, f);
+      std::fclose(f);
+    }
+  }
+  {
+    // Two problems at once: a second "problem" (its own cost functions, its own parameter blocks) is built while the
+    // first one lives, evaluated in the same pass, and survives the first one's destruction.
+    double q0[3] = {0.3, 0.1, -0.2}, q1[3] = {-0.1, 0.0, 0.1};
+    auto *d0 = nautilus::LIDARNormalResidual::create(sp, tp, sn, tn);
+    B.Bind(d0, q0, q1);
+    REQUIRE(B.live_blocks(nautilus_hip::kLidarNormal) == 3);
+    const long before = B.slow_path_calls();
+    B.PrepareForEvaluation(true, true);
+    double const *qp[2] = {q0, q1};
+    std::vector<double> rd(600), jd0(1800), jd1(1800), ra(600);
+    double *jd[2] = {jd0.data(), jd1.data()};
+    REQUIRE(d0->Evaluate(qp, rd.data(), jd) && c0->Evaluate(params, ra.data(), nullptr));
+    REQUIRE(B.slow_path_calls() == before && ra == r_one && rd != r_one);
+    delete c0; delete c1; delete c2;  // "problem A" is destroyed (ceres::Problem deletes its cost functions)
+    REQUIRE(B.live_blocks(nautilus_hip::kLidarNormal) == 1 && B.live_blocks(nautilus_hip::kLidarPoint) == 0);
+    B.PrepareForEvaluation(true, true);
+    std::vector<double> rd2(600), jd20(1800), jd21(1800);
+    double *jd2[2] = {jd20.data(), jd21.data()};
+    REQUIRE(d0->Evaluate(qp, rd2.data(), jd2));
+    REQUIRE(B.slow_path_calls() == before && rd2 == rd && jd20 == jd0 && jd21 == jd1);
+    REQUIRE(B.compiled_rows(nautilus_hip::kLidarNormal) == 600);  // the batch holds the live block only
+    delete d0;
+    REQUIRE(B.live_blocks(nautilus_hip::kLidarNormal) == 0);
+    std::printf("resid: two problems coexist; a destroyed problem leaves nothing behind\n");
+  }
+  {
+    // Solver::OptimizeOverGrowingWindow (solver.cc:335-356): ten times ResetProblem() + AddOdomFactors +
+    // BuildOptimizationOverWindow + Solve, with FEATURE-sized blocks (<= 20 planar LIDARNormal rows + <= 10 edge
+    // LIDARPoint rows per (i, j), slam_types.h:66-67).  NO Reset() call, as in the reference's sources: the cost
+    // functions' destructors (ceres::Problem owns them) take their blocks out.  Every window's batch holds exactly
+    // that window's rows, no block is ever evaluated alone, and a rebuilt window reproduces its values bit for bit.
+    const int n_nodes = 40;
+    std::vector<std::array<double, 3>> P(n_nodes);
+    for (int i = 0; i < n_nodes; i++) P[i] = {0.25 * i, 0.02 * i, 0.01 * i};
+    auto feature = [&](int i, int j, int n, std::vector<Vec2f> *v) {
+      for (int q = 0; q < 4; q++) v[q].clear();
+      for (int t = 0; t < n; t++) {
+        const float a = 0.1f * t + 0.01f * i - 0.02f * j;
+        v[0].emplace_back(3.f * std::cos(a), 3.f * std::sin(a));
+        v[1].emplace_back(3.02f * std::cos(a + 0.01f), 2.97f * std::sin(a + 0.01f));
+        v[2].emplace_back(std::cos(a), std::sin(a));
+        v[3].emplace_back(std::cos(a + 0.01f), std::sin(a + 0.01f));
+      }
+    };
+    struct FakeProblem {
+      std::vector<nautilus_hip::CostFunctionBase *> owned;
+      int AddResidualBlock(nautilus_hip::CostFunctionBase *c, void *, double *, double *) { owned.push_back(c); return (int)owned.size(); }
+      ~FakeProblem() { for (auto *c : owned) delete c; }  // ceres::Problem::~Problem with default ownership
+    };
+    struct Factor { Vec2f translation; float rotation; };
+    const long slow0 = B.slow_path_calls(), built0 = B.batches_built();
+    std::vector<double> first_w10;
+    for (int pass = 0; pass < 2; pass++)
+      for (int window = 1; window <= 10; window++) {
+        FakeProblem problem;  // ceres_information.ResetProblem()
+        for (int i = 1; i < n_nodes; i++) {  // AddOdomFactors (solver.cc:370-387)
+          const Factor f{Vec2f(0.25f, 0.02f), 0.01f};
+          nautilus_hip::AddResidualBlock(problem, nautilus::OdometryResidual::create(f, 1.0, 1.0), (void *)nullptr, P[i - 1].data(), P[i].data());
+        }
+        int64_t rows_n = 0, rows_p = 0;
+        std::vector<Vec2f> v[4];
+        for (int i = 1; i < n_nodes; i++)  // BuildOptimizationOverWindow (solver.cc:321-333) -> AddLidarResiduals (:297-318)
+          for (int j = std::max(0, i - window); j < i; j++) {
+            feature(i, j, 20 - (i % 3), v);
+            nautilus_hip::AddResidualBlock(problem, nautilus::LIDARNormalResidual::create(v[0], v[1], v[2], v[3]), (void *)nullptr, P[i].data(), P[j].data());
+            rows_n += 2 * (int64_t)v[0].size();
+            feature(i, j, 10 - (j % 2), v);
+            nautilus_hip::AddResidualBlock(problem, nautilus::LIDARPointResidual::create(v[0], v[1], v[2], v[3]), (void *)nullptr, P[i].data(), P[j].data());
+            rows_p += 2 * (int64_t)v[0].size();
+          }
+        for (int it = 0; it < 3; it++) {  // ceres::Solve: evaluation points
+          for (int i = 1; i < n_nodes; i++) P[i][0] = 0.25 * i + 1e-3 * it;
+          B.PrepareForEvaluation(true, true);
+          std::vector<double> all;
+          for (auto *c : problem.owned) {
+            const auto *bc = static_cast<const nautilus_hip::BatchedCost *>(c);
+            std::vector<double> rr(c->num_residuals()), ja(3 * rr.size()), jb(3 * rr.size());
+            double *jq[2] = {ja.data(), jb.data()};
+            double const *pp[2] = {bc->block()->pa, bc->block()->pb};
+            REQUIRE(c->Evaluate(pp, rr.data(), jq));
+            if (window == 10 && it == 2) { all.insert(all.end(), rr.begin(), rr.end()); all.insert(all.end(), jb.begin(), jb.end()); }
+          }
+          if (window == 10 && it == 2) {
+            if (pass == 0) first_w10 = all;
+            else REQUIRE(all == first_w10);
+          }
+        }
+        REQUIRE(B.compiled_rows(nautilus_hip::kLidarNormal) == rows_n && B.compiled_rows(nautilus_hip::kLidarPoint) == rows_p);
+        REQUIRE(B.compiled_rows(nautilus_hip::kOdometry) == 3 * (n_nodes - 1));
+      }
+    REQUIRE(B.slow_path_calls() == slow0);              // no block was ever evaluated alone
+    REQUIRE(B.batches_built() == built0 + 2 * 20);      // one device batch per family and problem build
+    for (int f = 0; f < 4; f++) REQUIRE(B.live_blocks(f) == 0);
+    std::printf("resid: 20 problem builds (windows 1..10 twice, FEATURE-sized blocks): constant batch size, no slow path\n");
+  }
 
   // ---- odometry factors (solver.cc:378) and HITL line constraints (solver.cc:521,528) in the same problem
   struct Factor { Vec2f translation; float rotation; };   // slam_types::OdometryFactor2D's members used by create()
@@ -234,7 +353,7 @@ int main(int argc, char **argv) {
   REQUIRE(std::fabs(jl0[1] - 1.0) < 1e-12 && std::fabs(jl1[1] + 1.0) < 1e-12);  // d r0 / d pose.y = +1, / d line.y = -1
   std::printf("odometry + point-to-line blocks: ok (r_line = %.4f %.4f %.4f)\n", rl[0], rl[1], rl[2]);
   delete o0; delete o1; delete l0;
-  B.Reset();
+  for (int f = 0; f < 4; f++) REQUIRE(B.live_blocks(f) == 0);
   // ---- the path's one collective through the C ABI: a C++ host owns the RCCL communicator
   // (one rank per GPU; this box has one, so world size 1) and hands it over as void*
   {

@@ -10,8 +10,15 @@
 // installed, a structurally identical local base class otherwise).  Instead of
 // AutoDiffCostFunction running a templated functor on Jets per block per thread, every block
 // registers its immutable data (the functors copy their vectors too, slam_residuals.h:117-120) with
-// a process-wide nautilus_hip::ResidualBatcher, which evaluates ALL blocks of a family in one pass
+// a process-wide nautilus_hip::ResidualBatcher, which evaluates ALL live blocks of a family in one pass
 // on the MI355X (nhip_resid_*) and from which each block's Evaluate() copies its slice.
+//
+// Lifetime follows Ceres' ownership (data_structures.h:111-116): ceres::Problem owns the cost functions it was
+// given and deletes them when it is destroyed -- CeresInformation::ResetProblem() does that ten times per SolveSLAM
+// (solver.cc:335-356).  A BatchedCost registers its block when it is created and UNREGISTERS it in its destructor,
+// so a rebuilt problem leaves nothing behind (no Reset() call in the reference's sources), and the blocks of two
+// problems that exist at the same time simply coexist: an evaluation pass covers every live block, each at the
+// current values of its own parameter blocks.
 //
 // Ceres 1.14 hook: the ONE line the batched evaluation needs is
 //   options.evaluation_callback = &nautilus_hip::ResidualBatcher::Instance();   // BuildOptions(), solver.cc:266-275
@@ -20,8 +27,6 @@
 // its slice without taking a lock.  Parameter blocks are learned from each block's first Evaluate() (Ceres
 // evaluates at the user's own blocks when the callback is set) or, without that first single-block pass, from
 //   nautilus_hip::AddResidualBlock(problem, cost, NULL, pose_a, pose_b);        // instead of problem.AddResidualBlock
-// Blocks of a problem that is rebuilt (CeresInformation::ResetProblem) are dropped with
-//   nautilus_hip::ResidualBatcher::Instance().Reset();
 // Evaluate() at parameter values other than the prepared ones -- ceres::Problem::Evaluate, Covariance::Compute
 // (LCMatcher::GetCovarianceMatrix, lc_matcher.cc:28-46), GradientChecker, or no callback at all -- is detected by
 // comparing the values and served by a single-block evaluation on the GPU at the parameters passed in.
@@ -114,17 +119,31 @@ struct PinnedDoubles {
   const double *data() const { return p; }
 };
 
-class BatchedCost;
+class ResidualBatcher;
 
-// Collects the residual blocks of one ceres::Problem build and evaluates each family in one pass.
+// One residual block: what its create() call copied, the parameter blocks it was bound to, and where its rows sit in
+// the arrays of the last evaluation pass.  Owned by the BatchedCost that create() returned.
+struct Block {
+  int family = 0;
+  int32_t live_index = -1;  // position in the batcher's list of live blocks of the family
+  int32_t slot = -1;        // position in the family's compiled arrays; -1: registered after they were compiled
+  int32_t rows = 0;         // residual rows: 2 N, 3, N
+  int64_t row0 = 0;         // first row in the family's result arrays (valid while slot >= 0)
+  const double *pa = nullptr, *pb = nullptr;
+  std::vector<float> data;  // LIDAR: 8 floats per correspondence; odometry: tx ty rot; point-to-line: x0 y0 x1 y1, points
+  double tw = 1.0, rw = 1.0;  // odometry weights
+};
+
+// Collects the live residual blocks and evaluates each family in one pass.
 //
-// Threading: blocks are registered and bound while the problem is built (one thread).  PrepareForEvaluation runs
-// on one thread with no Evaluate() in flight (the ceres::EvaluationCallback contract); afterwards Evaluate() may be
-// called from any number of threads at once: the fast path only READS the prepared arrays and takes no lock.
-// An Evaluate() that arrives at parameter values other than the prepared ones (Problem::Evaluate,
-// Covariance::Compute, GradientChecker, a solver without the callback) or for a block whose parameter blocks are
-// not known yet is served by a single-block evaluation on the GPU at exactly the parameters passed in (slow path,
-// serialised by a mutex) -- never by stale values, never by the CPU.
+// Threading: blocks are created, bound and destroyed while a problem is built or torn down (one thread; never while
+// Evaluate() calls are in flight -- Ceres does not).  PrepareForEvaluation runs on one thread with no Evaluate() in
+// flight (the ceres::EvaluationCallback contract); afterwards Evaluate() may be called from any number of threads at
+// once: the fast path only READS the prepared arrays and takes no lock.  An Evaluate() that arrives at parameter
+// values other than the prepared ones (Problem::Evaluate, Covariance::Compute, GradientChecker, a solver without the
+// callback), for a block whose parameter blocks are not known yet, or for a block created after the last pass is
+// served by a single-block evaluation on the GPU at exactly the parameters passed in (slow path, serialised by a
+// mutex) -- never by stale values, never by the CPU.
 class ResidualBatcher : public EvaluationCallbackBase {
  public:
   static ResidualBatcher &Instance() {
@@ -132,54 +151,65 @@ class ResidualBatcher : public EvaluationCallbackBase {
     return *b;
   }
 
-  // CeresInformation::ResetProblem() (data_structures.h:111-116) starts a new problem: drop everything.
+  // Releases the device batches and pinned result buffers (they are rebuilt by the next pass).  Live blocks stay:
+  // they belong to their cost functions.  Never needed for correctness -- kept for hosts that want the memory back.
   void Reset() {
     std::lock_guard<std::mutex> lk(mu_);
     prepared_.store(false, std::memory_order_release);
     for (int k = 0; k < 2; k++) {
       if (batch_[k]) nhip_resid_batch_free(batch_[k]);
       batch_[k] = nullptr;
-      corr_[k].clear();
-      offsets_[k].assign(1, 0);
-      bsrc_[k].clear();
-      btgt_[k].clear();
       jtt_[k].release();
     }
     for (int f = 0; f < 4; f++) {
-      pa_[f].clear(); pb_[f].clear(); ia_[f].clear(); ib_[f].clear(); poses_a_[f].clear(); poses_b_[f].clear();
+      dirty_[f] = true;
+      for (Block *b : live_[f]) b->slot = -1;
       res_[f].release(); j0_[f].release(); j1_[f].release();
     }
-    t_odom_.clear(); r_odom_.clear(); tw_.clear(); rw_.clear();
-    seg_.clear(); p2l_pts_.clear(); p2l_block_.clear(); p2l_off_.assign(1, 0);
-    slow_calls_ = 0;
   }
 
-  int RegisterLidar(int kind, const std::vector<Vec2f> &sp, const std::vector<Vec2f> &tp,
-                    const std::vector<Vec2f> &sn, const std::vector<Vec2f> &tn) {
-    std::lock_guard<std::mutex> lk(mu_);
+  Block *RegisterLidar(int kind, const std::vector<Vec2f> &sp, const std::vector<Vec2f> &tp,
+                       const std::vector<Vec2f> &sn, const std::vector<Vec2f> &tn) {
+    Block *b = new Block();
+    b->family = kind;
+    b->rows = 2 * (int32_t)sp.size();
+    b->data.reserve(8 * sp.size());
     for (size_t i = 0; i < sp.size(); i++) {
       const float row[8] = {sp[i](0), sp[i](1), tp[i](0), tp[i](1), sn[i](0), sn[i](1), tn[i](0), tn[i](1)};
-      corr_[kind].insert(corr_[kind].end(), row, row + 8);
+      b->data.insert(b->data.end(), row, row + 8);
     }
-    offsets_[kind].push_back(offsets_[kind].back() + (int32_t)sp.size());
-    if (batch_[kind]) { nhip_resid_batch_free(batch_[kind]); batch_[kind] = nullptr; }
-    return NewBlock(kind);
+    return Add(b);
   }
 
-  int RegisterOdometry(float tx, float ty, float rot, double tw, double rw) {
-    std::lock_guard<std::mutex> lk(mu_);
-    t_odom_.push_back(tx); t_odom_.push_back(ty); r_odom_.push_back(rot);
-    tw_.push_back(tw); rw_.push_back(rw);
-    return NewBlock(kOdometry);
+  Block *RegisterOdometry(float tx, float ty, float rot, double tw, double rw) {
+    Block *b = new Block();
+    b->family = kOdometry;
+    b->rows = 3;
+    b->data = {tx, ty, rot};
+    b->tw = tw;
+    b->rw = rw;
+    return Add(b);
   }
 
-  int RegisterPointToLine(float x0, float y0, float x1, float y1, const std::vector<Vec2f> &points) {
+  Block *RegisterPointToLine(float x0, float y0, float x1, float y1, const std::vector<Vec2f> &points) {
+    Block *b = new Block();
+    b->family = kPointToLine;
+    b->rows = (int32_t)points.size();
+    b->data = {x0, y0, x1, y1};
+    for (const Vec2f &p : points) { b->data.push_back(p(0)); b->data.push_back(p(1)); }
+    return Add(b);
+  }
+
+  // ~BatchedCost: the block leaves the live set (O(1): the last live block takes its place) and is freed.
+  void Unregister(Block *b) {
     std::lock_guard<std::mutex> lk(mu_);
-    const int b = (int)pa_[kPointToLine].size();
-    seg_.insert(seg_.end(), {x0, y0, x1, y1});
-    for (const Vec2f &p : points) { p2l_pts_.push_back(p(0)); p2l_pts_.push_back(p(1)); p2l_block_.push_back(b); }
-    p2l_off_.push_back(p2l_off_.back() + (int32_t)points.size());
-    return NewBlock(kPointToLine);
+    std::vector<Block *> &L = live_[b->family];
+    L[b->live_index] = L.back();
+    L[b->live_index]->live_index = b->live_index;
+    L.pop_back();
+    dirty_[b->family] = true;
+    prepared_.store(false, std::memory_order_release);
+    delete b;
   }
 
   // The parameter blocks handed to AddResidualBlock(cost, NULL, pose_a, pose_b) (solver.cc:280-283).  Optional:
@@ -188,20 +218,18 @@ class ResidualBatcher : public EvaluationCallbackBase {
   // nautilus_hip::AddResidualBlock() below binds and adds in one line.
   void Bind(const CostFunctionBase *cost, double *pose_a, double *pose_b);
 
-  // ceres::EvaluationCallback: one GPU pass per family per evaluation point.
+  // ceres::EvaluationCallback: one GPU pass per family per evaluation point, over every live block.
   void PrepareForEvaluation(bool evaluate_jacobians, bool /*new_evaluation_point*/) override {
     std::lock_guard<std::mutex> lk(mu_);
     prepared_.store(false, std::memory_order_release);
     const bool J = evaluate_jacobians;
     for (int k = 0; k < 2; k++) {  // LIDARNormal / LIDARPoint
-      const int32_t nb = (int32_t)pa_[k].size();
-      if (nb == 0) continue;
+      if (live_[k].empty()) continue;
       PoseTable T;
-      BuildIndices(k, &T);
-      EnsureLidarBatch(k, (int32_t)T.ptrs.size());
+      CompileLidar(k, &T);
       const std::vector<double> poses = T.Gather();
-      SnapshotPoses(k, poses);
-      const size_t n = (size_t)offsets_[k].back();
+      poses_a_[k] = poses;
+      const size_t n = (size_t)rows_total_[k] / 2;
       res_[k].reserve(2 * n);
       if (J) {
         j0_[k].reserve(6 * n);
@@ -212,12 +240,16 @@ class ResidualBatcher : public EvaluationCallbackBase {
         Check(nhip_resid_batch_eval(batch_[k], poses.data(), res_[k].data(), nullptr, nullptr), "nhip_resid_batch_eval");
       }
     }
-    if (!pa_[kOdometry].empty()) {
-      const int32_t n = (int32_t)pa_[kOdometry].size();
+    if (!live_[kOdometry].empty()) {
+      const std::vector<Block *> &L = live_[kOdometry];
+      const int32_t n = (int32_t)L.size();
       PoseTable T;
-      BuildIndices(kOdometry, &T);
+      AssignSlots(kOdometry);
+      BuildIndices(kOdometry, &T, nullptr);
+      t_odom_.resize(2 * (size_t)n); r_odom_.resize(n);
+      for (int32_t f = 0; f < n; f++) { t_odom_[2 * f] = L[f]->data[0]; t_odom_[2 * f + 1] = L[f]->data[1]; r_odom_[f] = L[f]->data[2]; }
       const std::vector<double> poses = T.Gather();
-      SnapshotPoses(kOdometry, poses);
+      poses_a_[kOdometry] = poses;
       res_[kOdometry].reserve(3 * (size_t)n);
       if (J) { j0_[kOdometry].reserve(9 * (size_t)n); j1_[kOdometry].reserve(9 * (size_t)n); }
       double *r = res_[kOdometry].data(), *ji = j0_[kOdometry].data(), *jj = j1_[kOdometry].data();
@@ -225,70 +257,109 @@ class ResidualBatcher : public EvaluationCallbackBase {
       Check(nhip_resid_odometry(t_odom_.data(), r_odom_.data(), ia_[kOdometry].data(), ib_[kOdometry].data(), n, 1.0, 1.0,
                                 poses.data(), (int32_t)T.ptrs.size(), r, J ? ji : nullptr, J ? jj : nullptr),
             "nhip_resid_odometry");
-      for (int32_t f = 0; f < n; f++) ApplyOdometryWeights(f, r + 3 * f, J ? ji + 9 * f : nullptr, J ? jj + 9 * f : nullptr);
+      for (int32_t f = 0; f < n; f++) ApplyOdometryWeights(*L[f], r + 3 * f, J ? ji + 9 * f : nullptr, J ? jj + 9 * f : nullptr);
     }
-    if (!pa_[kPointToLine].empty()) {
-      const int32_t nb = (int32_t)pa_[kPointToLine].size();
+    if (!live_[kPointToLine].empty()) {
+      const std::vector<Block *> &L = live_[kPointToLine];
+      const int32_t nb = (int32_t)L.size();
       PoseTable TP, TL;
-      std::vector<int32_t> &bp = ia_[kPointToLine], &bl = ib_[kPointToLine];
-      bp.resize(nb); bl.resize(nb);
-      for (int32_t b = 0; b < nb; b++) { bp[b] = TP.Id(Bound(pa_[kPointToLine][b])); bl[b] = TL.Id(Bound(pb_[kPointToLine][b])); }
+      AssignSlots(kPointToLine);
+      BuildIndices(kPointToLine, &TP, &TL);
+      seg_.clear(); p2l_pts_.clear(); p2l_block_.clear();
+      for (int32_t b = 0; b < nb; b++) {
+        seg_.insert(seg_.end(), L[b]->data.begin(), L[b]->data.begin() + 4);
+        p2l_pts_.insert(p2l_pts_.end(), L[b]->data.begin() + 4, L[b]->data.end());
+        p2l_block_.insert(p2l_block_.end(), (size_t)L[b]->rows, b);
+      }
       const std::vector<double> poses = TP.Gather(), lines = TL.Gather();
       poses_a_[kPointToLine] = poses;
       poses_b_[kPointToLine] = lines;
       const size_t n = p2l_block_.size();
       res_[kPointToLine].reserve(n);
       if (J) { j0_[kPointToLine].reserve(3 * n); j1_[kPointToLine].reserve(3 * n); }
-      Check(nhip_resid_point_to_line(seg_.data(), p2l_pts_.data(), p2l_block_.data(), (int64_t)n, bp.data(), bl.data(),
-                                     nb, poses.data(), (int32_t)TP.ptrs.size(), lines.data(), (int32_t)TL.ptrs.size(),
-                                     res_[kPointToLine].data(), J ? j0_[kPointToLine].data() : nullptr,
-                                     J ? j1_[kPointToLine].data() : nullptr), "nhip_resid_point_to_line");
+      Check(nhip_resid_point_to_line(seg_.data(), p2l_pts_.data(), p2l_block_.data(), (int64_t)n, ia_[kPointToLine].data(),
+                                     ib_[kPointToLine].data(), nb, poses.data(), (int32_t)TP.ptrs.size(), lines.data(),
+                                     (int32_t)TL.ptrs.size(), res_[kPointToLine].data(),
+                                     J ? j0_[kPointToLine].data() : nullptr, J ? j1_[kPointToLine].data() : nullptr),
+            "nhip_resid_point_to_line");
     }
     have_jac_ = evaluate_jacobians;
     prepared_.store(true, std::memory_order_release);
   }
 
-  // Block `b`'s residuals (and Jacobians) at `parameters`.  Fast path: the prepared arrays, no lock.
-  bool Fetch(int family, int b, double const *const *parameters, double *residuals, double **jacobians) {
+  // The block's residuals (and Jacobians) at `parameters`.  Fast path: the prepared arrays, no lock.
+  bool Fetch(Block *b, double const *const *parameters, double *residuals, double **jacobians) {
     const bool want_j = jacobians && (jacobians[0] || jacobians[1]);
-    if (prepared_.load(std::memory_order_acquire) && pa_[family][b] && (!want_j || have_jac_) &&
-        SameParameters(family, b, parameters)) {
-      CopyPrepared(family, b, residuals, jacobians);
+    if (prepared_.load(std::memory_order_acquire) && b->slot >= 0 && b->pa && (!want_j || have_jac_) &&
+        SameParameters(*b, parameters)) {
+      CopyPrepared(*b, residuals, jacobians);
       return true;
     }
-    return EvaluateOne(family, b, parameters, residuals, jacobians);
+    return EvaluateOne(b, parameters, residuals, jacobians);
   }
 
   long slow_path_calls() const { return slow_calls_; }
+  // (tests) live blocks of a family, rows of its last compiled batch, device batches built so far
+  size_t live_blocks(int family) const { return live_[family].size(); }
+  int64_t compiled_rows(int family) const { return rows_total_[family]; }
+  long batches_built() const { return batches_built_; }
 
  private:
-  ResidualBatcher() { offsets_[0].assign(1, 0); offsets_[1].assign(1, 0); p2l_off_.assign(1, 0); }
-  int NewBlock(int family) {
-    pa_[family].push_back(nullptr);
-    pb_[family].push_back(nullptr);
-    prepared_.store(false, std::memory_order_release);
-    return (int)pa_[family].size() - 1;
+  ResidualBatcher() {}
+  Block *Add(Block *b) {
+    std::lock_guard<std::mutex> lk(mu_);
+    b->live_index = (int32_t)live_[b->family].size();
+    live_[b->family].push_back(b);
+    dirty_[b->family] = true;
+    return b;  // (the prepared arrays of the OTHER blocks stay valid: this one has slot -1 until the next pass)
   }
   // unbound blocks read a dummy pose until their first Evaluate() binds them (their prepared values are never used)
-  const double *Bound(const double *p) const { static const double zero[3] = {0, 0, 0}; return p ? p : zero; }
-  void BuildIndices(int f, PoseTable *T) {
-    const size_t nb = pa_[f].size();
-    ia_[f].resize(nb); ib_[f].resize(nb);
-    for (size_t b = 0; b < nb; b++) { ia_[f][b] = T->Id(Bound(pa_[f][b])); ib_[f][b] = T->Id(Bound(pb_[f][b])); }
+  static const double *Bound(const double *p) { static const double zero[3] = {0, 0, 0}; return p ? p : zero; }
+  // slot = position in the live list; rows laid out in that order
+  void AssignSlots(int f) {
+    int64_t row = 0;
+    for (size_t i = 0; i < live_[f].size(); i++) {
+      live_[f][i]->slot = (int32_t)i;
+      live_[f][i]->row0 = row;
+      row += live_[f][i]->rows;
+    }
+    rows_total_[f] = row;
+    dirty_[f] = false;
   }
-  void SnapshotPoses(int f, const std::vector<double> &poses) { poses_a_[f] = poses; }
-  void EnsureLidarBatch(int k, int32_t n_poses) {
-    if (!batch_[k] || ia_[k] != bsrc_[k] || ib_[k] != btgt_[k]) {
-      if (batch_[k]) nhip_resid_batch_free(batch_[k]);
-      batch_[k] = nullptr;
-      Check(nhip_resid_batch_create(k, corr_[k].data(), offsets_[k].data(), ia_[k].data(), ib_[k].data(),
-                                    (int32_t)ia_[k].size(), n_poses, &batch_[k]), "nhip_resid_batch_create");
-      bsrc_[k] = ia_[k];
-      btgt_[k] = ib_[k];
+  // indices of the blocks' parameter blocks into dense pose tables (TB null: both blocks in TA)
+  void BuildIndices(int f, PoseTable *TA, PoseTable *TB) {
+    const size_t nb = live_[f].size();
+    ia_[f].resize(nb); ib_[f].resize(nb);
+    for (size_t b = 0; b < nb; b++) {
+      ia_[f][b] = TA->Id(Bound(live_[f][b]->pa));
+      ib_[f][b] = (TB ? TB : TA)->Id(Bound(live_[f][b]->pb));
     }
   }
-  void ApplyOdometryWeights(int32_t f, double *r, double *ji, double *jj) const {
-    const double w[3] = {tw_[f], tw_[f], rw_[f]};
+  // The LIDAR family's device batch: rebuilt when the set of live blocks or their parameter-block pattern changed.
+  void CompileLidar(int k, PoseTable *T) {
+    const bool was_dirty = dirty_[k];
+    if (was_dirty) AssignSlots(k);
+    BuildIndices(k, T, nullptr);
+    if (!batch_[k] || was_dirty || ia_[k] != bsrc_[k] || ib_[k] != btgt_[k]) {
+      if (batch_[k]) nhip_resid_batch_free(batch_[k]);
+      batch_[k] = nullptr;
+      const std::vector<Block *> &L = live_[k];
+      std::vector<float> corr;
+      corr.reserve(4 * (size_t)rows_total_[k]);
+      std::vector<int32_t> offsets(1, 0);
+      for (const Block *b : L) {
+        corr.insert(corr.end(), b->data.begin(), b->data.end());
+        offsets.push_back(offsets.back() + b->rows / 2);
+      }
+      Check(nhip_resid_batch_create(k, corr.data(), offsets.data(), ia_[k].data(), ib_[k].data(), (int32_t)L.size(),
+                                    (int32_t)T->ptrs.size(), &batch_[k]), "nhip_resid_batch_create");
+      bsrc_[k] = ia_[k];
+      btgt_[k] = ib_[k];
+      batches_built_++;
+    }
+  }
+  static void ApplyOdometryWeights(const Block &b, double *r, double *ji, double *jj) {
+    const double w[3] = {b.tw, b.tw, b.rw};
     for (int row = 0; row < 3; row++) {
       r[row] *= w[row];
       if (ji) for (int c = 0; c < 3; c++) ji[3 * row + c] *= w[row];
@@ -296,19 +367,15 @@ class ResidualBatcher : public EvaluationCallbackBase {
     }
   }
   // Were the prepared values computed at exactly these parameter values?
-  bool SameParameters(int f, int b, double const *const *parameters) const {
-    const double *a = &poses_a_[f][3 * (size_t)ia_[f][b]];
-    const double *c = (f == kPointToLine) ? &poses_b_[f][3 * (size_t)ib_[f][b]] : &poses_a_[f][3 * (size_t)ib_[f][b]];
+  bool SameParameters(const Block &b, double const *const *parameters) const {
+    const int f = b.family;
+    const double *a = &poses_a_[f][3 * (size_t)ia_[f][b.slot]];
+    const double *c = (f == kPointToLine) ? &poses_b_[f][3 * (size_t)ib_[f][b.slot]] : &poses_a_[f][3 * (size_t)ib_[f][b.slot]];
     return std::memcmp(a, parameters[0], 3 * sizeof(double)) == 0 && std::memcmp(c, parameters[1], 3 * sizeof(double)) == 0;
   }
-  void Rows(int family, int b, size_t *r_off, size_t *r_n) const {
-    if (family <= kLidarPoint) { *r_off = 2 * (size_t)offsets_[family][b]; *r_n = 2 * (size_t)(offsets_[family][b + 1] - offsets_[family][b]); }
-    else if (family == kOdometry) { *r_off = 3 * (size_t)b; *r_n = 3; }
-    else { *r_off = (size_t)p2l_off_[b]; *r_n = (size_t)(p2l_off_[b + 1] - p2l_off_[b]); }
-  }
-  void CopyPrepared(int family, int b, double *residuals, double **jacobians) const {
-    size_t r_off, r_n;
-    Rows(family, b, &r_off, &r_n);
+  void CopyPrepared(const Block &b, double *residuals, double **jacobians) const {
+    const int family = b.family;
+    const size_t r_off = (size_t)b.row0, r_n = (size_t)b.rows;
     std::memcpy(residuals, res_[family].data() + r_off, sizeof(double) * r_n);
     if (!jacobians) return;
     const double *js = j0_[family].data() + 3 * r_off;
@@ -325,55 +392,54 @@ class ResidualBatcher : public EvaluationCallbackBase {
     }
   }
   // Slow path: this block alone, on the GPU, at the parameters passed in.
-  bool EvaluateOne(int family, int b, double const *const *parameters, double *residuals, double **jacobians) {
+  bool EvaluateOne(Block *b, double const *const *parameters, double *residuals, double **jacobians) {
     std::lock_guard<std::mutex> lk(mu_);
     slow_calls_++;
-    if (!pa_[family][b]) {  // first sight of this block's parameter blocks
-      pa_[family][b] = parameters[0];
-      pb_[family][b] = parameters[1];
+    if (!b->pa) {  // first sight of this block's parameter blocks
+      b->pa = parameters[0];
+      b->pb = parameters[1];
       prepared_.store(false, std::memory_order_release);  // the next PrepareForEvaluation batches it
     }
     double *j0 = jacobians ? jacobians[0] : nullptr, *j1 = jacobians ? jacobians[1] : nullptr;
+    const int family = b->family;
     if (family <= kLidarPoint) {
-      if (!batch_[family]) {
+      if (!batch_[family] || dirty_[family] || b->slot < 0) {  // (a block newer than the device batch: rebuild it)
         PoseTable T;
-        BuildIndices(family, &T);
-        EnsureLidarBatch(family, (int32_t)T.ptrs.size());
+        dirty_[family] = true;
+        CompileLidar(family, &T);
+        prepared_.store(false, std::memory_order_release);  // rows moved
       }
-      return nhip_resid_batch_eval_block(batch_[family], b, parameters[0], parameters[1], residuals, j0, j1) == NHIP_OK;
+      return nhip_resid_batch_eval_block(batch_[family], b->slot, parameters[0], parameters[1], residuals, j0, j1) == NHIP_OK;
     }
     if (family == kOdometry) {
       double two[6];
       std::memcpy(two, parameters[0], 24); std::memcpy(two + 3, parameters[1], 24);
       const int32_t i0 = 0, i1 = 1;
-      if (nhip_resid_odometry(&t_odom_[2 * b], &r_odom_[b], &i0, &i1, 1, 1.0, 1.0, two, 2, residuals, j0, j1) != NHIP_OK) return false;
-      ApplyOdometryWeights(b, residuals, j0, j1);
+      if (nhip_resid_odometry(&b->data[0], &b->data[2], &i0, &i1, 1, 1.0, 1.0, two, 2, residuals, j0, j1) != NHIP_OK) return false;
+      ApplyOdometryWeights(*b, residuals, j0, j1);
       return true;
     }
     const int32_t zero = 0;
-    const int32_t n = p2l_off_[b + 1] - p2l_off_[b];
-    std::vector<int32_t> blk((size_t)n, 0);
-    return nhip_resid_point_to_line(&seg_[4 * b], &p2l_pts_[2 * (size_t)p2l_off_[b]], blk.data(), n, &zero, &zero, 1,
+    std::vector<int32_t> blk((size_t)b->rows, 0);
+    return nhip_resid_point_to_line(&b->data[0], b->data.data() + 4, blk.data(), b->rows, &zero, &zero, 1,
                                     parameters[0], 1, parameters[1], 1, residuals, j0, j1) == NHIP_OK;
   }
 
   std::mutex mu_;
   std::atomic<bool> prepared_{false};
   bool have_jac_ = false;
-  long slow_calls_ = 0;
-  // LIDAR families
-  std::vector<float> corr_[2];
-  std::vector<int32_t> offsets_[2], bsrc_[2], btgt_[2];
+  long slow_calls_ = 0, batches_built_ = 0;
+  std::vector<Block *> live_[4];
+  bool dirty_[4] = {false, false, false, false};
+  int64_t rows_total_[4] = {0, 0, 0, 0};
+  // LIDAR families: the device batch and the parameter-block pattern it was built for
+  std::vector<int32_t> bsrc_[2], btgt_[2];
   nhip_resid_batch_t *batch_[2] = {nullptr, nullptr};
   PinnedDoubles jtt_[2];  // theta column of J_tgt, 2 per correspondence
-  // odometry
-  std::vector<float> t_odom_, r_odom_;
-  std::vector<double> tw_, rw_;
-  // point-to-line
-  std::vector<float> seg_, p2l_pts_;
-  std::vector<int32_t> p2l_block_, p2l_off_;
-  // per family: bound parameter blocks, their indices into the last gathered pose table(s), the last evaluation
-  std::vector<const double *> pa_[4], pb_[4];
+  // staging of the two small families (rebuilt per pass: a few KB)
+  std::vector<float> t_odom_, r_odom_, seg_, p2l_pts_;
+  std::vector<int32_t> p2l_block_;
+  // per family: indices of the blocks' parameter blocks into the last gathered pose table(s), the last evaluation
   std::vector<int32_t> ia_[4], ib_[4];
   std::vector<double> poses_a_[4], poses_b_[4];
   PinnedDoubles res_[4], j0_[4], j1_[4];
@@ -381,22 +447,26 @@ class ResidualBatcher : public EvaluationCallbackBase {
 };
 
 // What create() returns: two 3-vectors as parameter blocks and `num_residuals` residuals, exactly
-// the shape of AutoDiffCostFunction<F, DYNAMIC | 3, 3, 3>.
+// the shape of AutoDiffCostFunction<F, DYNAMIC | 3, 3, 3>.  Owns its block: ceres::Problem deletes the cost
+// function (CeresInformation::ResetProblem, data_structures.h:111-116) and the block goes with it.
 class BatchedCost : public CostFunctionBase {
  public:
-  BatchedCost(int family, int block, int num_residuals) : family_(family), block_(block) {
+  explicit BatchedCost(Block *block) : block_(block) {
     mutable_parameter_block_sizes()->push_back(3);
     mutable_parameter_block_sizes()->push_back(3);
-    set_num_residuals(num_residuals);
+    set_num_residuals(block->rows);
   }
+  ~BatchedCost() override { ResidualBatcher::Instance().Unregister(block_); }
+  BatchedCost(const BatchedCost &) = delete;
+  BatchedCost &operator=(const BatchedCost &) = delete;
   bool Evaluate(double const *const *parameters, double *residuals, double **jacobians) const override {
-    return ResidualBatcher::Instance().Fetch(family_, block_, parameters, residuals, jacobians);
+    return ResidualBatcher::Instance().Fetch(block_, parameters, residuals, jacobians);
   }
-  int family() const { return family_; }
-  int block() const { return block_; }
+  int family() const { return block_->family; }
+  Block *block() const { return block_; }
 
  private:
-  int family_, block_;
+  Block *block_;
 };
 using LidarCost = BatchedCost;
 
@@ -404,8 +474,8 @@ inline void ResidualBatcher::Bind(const CostFunctionBase *cost, double *pose_a, 
   const BatchedCost *c = dynamic_cast<const BatchedCost *>(cost);
   if (!c) return;  // not one of ours
   std::lock_guard<std::mutex> lk(mu_);
-  pa_[c->family()][c->block()] = pose_a;
-  pb_[c->family()][c->block()] = pose_b;
+  c->block()->pa = pose_a;
+  c->block()->pb = pose_b;
   prepared_.store(false, std::memory_order_release);
 }
 
@@ -434,10 +504,9 @@ struct OdometryResidual {
   // Factor: slam_types::OdometryFactor2D (slam_types.h:102-120) or anything with .translation(i), .rotation
   template <class Factor>
   static nautilus_hip::BatchedCost *create(const Factor &factor, double translation_weight, double rotation_weight) {
-    const int b = nautilus_hip::ResidualBatcher::Instance().RegisterOdometry(
+    return new nautilus_hip::BatchedCost(nautilus_hip::ResidualBatcher::Instance().RegisterOdometry(
         (float)factor.translation(0), (float)factor.translation(1), (float)factor.rotation, translation_weight,
-        rotation_weight);
-    return new nautilus_hip::BatchedCost(nautilus_hip::kOdometry, b, 3);
+        rotation_weight));
   }
 };
 
@@ -447,9 +516,8 @@ struct LIDARNormalResidual {
                                            const std::vector<nautilus_hip::Vec2f> &source_normals,
                                            const std::vector<nautilus_hip::Vec2f> &target_normals) {
     nautilus_hip::CheckSizes(source_points, target_points, source_normals, target_normals);
-    const int b = nautilus_hip::ResidualBatcher::Instance().RegisterLidar(NHIP_LIDAR_NORMAL, source_points, target_points,
-                                                                           source_normals, target_normals);
-    return new nautilus_hip::BatchedCost(nautilus_hip::kLidarNormal, b, 2 * (int)source_points.size());
+    return new nautilus_hip::BatchedCost(nautilus_hip::ResidualBatcher::Instance().RegisterLidar(
+        NHIP_LIDAR_NORMAL, source_points, target_points, source_normals, target_normals));
   }
 };
 
@@ -459,9 +527,8 @@ struct LIDARPointResidual {
                                            const std::vector<nautilus_hip::Vec2f> &source_normals,
                                            const std::vector<nautilus_hip::Vec2f> &target_normals) {
     nautilus_hip::CheckSizes(source_points, target_points, source_normals, target_normals);
-    const int b = nautilus_hip::ResidualBatcher::Instance().RegisterLidar(NHIP_LIDAR_POINT, source_points, target_points,
-                                                                           source_normals, target_normals);
-    return new nautilus_hip::BatchedCost(nautilus_hip::kLidarPoint, b, 2 * (int)source_points.size());
+    return new nautilus_hip::BatchedCost(nautilus_hip::ResidualBatcher::Instance().RegisterLidar(
+        NHIP_LIDAR_POINT, source_points, target_points, source_normals, target_normals));
   }
 };
 
@@ -469,10 +536,9 @@ struct PointToLineResidual {
   // Segment: LineSegment<float> (data_structures.h:13-32) or anything with .start(i), .end(i)
   template <class Segment>
   static nautilus_hip::BatchedCost *create(const Segment &line_segment, const std::vector<nautilus_hip::Vec2f> points) {
-    const int b = nautilus_hip::ResidualBatcher::Instance().RegisterPointToLine(
+    return new nautilus_hip::BatchedCost(nautilus_hip::ResidualBatcher::Instance().RegisterPointToLine(
         (float)line_segment.start(0), (float)line_segment.start(1), (float)line_segment.end(0),
-        (float)line_segment.end(1), points);
-    return new nautilus_hip::BatchedCost(nautilus_hip::kPointToLine, b, (int)points.size());
+        (float)line_segment.end(1), points));
   }
 };
 

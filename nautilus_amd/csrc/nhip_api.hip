@@ -379,6 +379,21 @@ int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32
                            workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
+int nhip_grid_rebuild_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+                          int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
+                          void *d_workspace, int64_t workspace_bytes, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(d_xy && d_offsets && d_target_ids && d_grids && d_workspace, "grid_rebuild_dev: null pointer");
+  NHIP_REQUIRE(n_targets >= 0, "grid_rebuild_dev: n_targets < 0");
+  GridLayout L;
+  rc = make_layout(spec, &L);
+  if (rc) return rc;
+  if (n_targets == 0) return NHIP_OK;
+  return launch_grid_build(d_xy, d_offsets, d_target_ids, n_targets, spec, L, d_grids, d_workspace,
+                           workspace_bytes, static_cast<hipStream_t>(stream), true);
+}
+
 int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                        const nhip_grid_spec_t *spec, const int32_t *d_pair_src,
                        const int32_t *d_pair_slot, const double *d_rot0_cs,

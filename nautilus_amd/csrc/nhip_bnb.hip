@@ -1510,8 +1510,9 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
       uint32_t xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-      BNB_TIMELINE(P)[4 * pair + 3] = (wall_clock64() & 0xffffffffffffull) | ((unsigned long long)(hw & 0xffffu) << 48);
-      (void)xcc;
+      // 44 bits of time (100 MHz: two days), then the CU the workgroup ran on: HW_ID[15:8] = cu, sh, se; XCC id
+      BNB_TIMELINE(P)[4 * pair + 3] = (wall_clock64() & 0xfffffffffffull) | ((unsigned long long)((hw >> 8) & 0xffu) << 44) |
+                                      ((unsigned long long)(xcc & 0xfu) << 52);
     }
     if (BNB_STATS(P) && BY_ROT) atomicAdd(&BNB_STATS(P)[8], *s_slow);  // sum over pairs of the slowest wave's phase 3
     if (stats_g) {
@@ -1778,8 +1779,47 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
   const bool second_kernel = P.rot_list && (P.debug == 0 || (P.debug >= 3 && P.debug < 26));
   timer_begin(NHIP_TIMER_CSM, s);
-  const int rc = instr ? bnb::launch_bnb_kernels_instr(P, L.cb, pool_lds, lds, blocks, second_kernel, s)
-                       : bnb::launch_bnb_kernels(P, L.cb, pool_lds, lds, blocks, second_kernel, s);
+  // NHIP_BNB_QUEUES=K (experiment): the batch as K launches on K streams of the library (fork / join around the
+  // caller's stream with events).  One hardware queue dispatches workgroups in order; with several, a queue whose next
+  // workgroup has no slot does not keep the others' from filling the slots that are free.
+  const char *qenv = getenv("NHIP_BNB_QUEUES");
+  const int n_queues = (qenv && !instr && !second_kernel) ? std::max(1, std::min(8, atoi(qenv))) : 1;
+  int rc = NHIP_OK;
+  if (n_queues > 1 && n_pairs >= 64 * n_queues) {
+    static hipStream_t q_stream[8];
+    static hipEvent_t q_done[8], q_start;
+    static std::once_flag q_once;
+    static bool q_ok = false;
+    std::call_once(q_once, [] {
+      q_ok = hipEventCreateWithFlags(&q_start, hipEventDisableTiming) == hipSuccess;
+      for (int i = 0; i < 8 && q_ok; i++)
+        q_ok = hipStreamCreateWithFlags(&q_stream[i], hipStreamNonBlocking) == hipSuccess &&
+               hipEventCreateWithFlags(&q_done[i], hipEventDisableTiming) == hipSuccess;
+    });
+    NHIP_REQUIRE(q_ok, "csm_bnb: could not create the library's streams");
+    NHIP_TRY_HIP(hipEventRecord(q_start, s));
+    for (int q = 0; q < n_queues && rc == NHIP_OK; q++) {
+      // pairs are dealt to the queues in turn by blocks of 8 (the launch order of the whole batch is kept inside a queue)
+      const int32_t per = ((n_pairs + n_queues - 1) / n_queues + 7) / 8 * 8;
+      const int32_t base = q * per, count = std::min(per, n_pairs - base);
+      if (count <= 0) break;
+      BnbParams Q = P;
+      Q.pair_src += base;
+      Q.pair_slot += base;
+      Q.rot0_cs += 2 * (size_t)base;
+      if (Q.pair_origin) Q.pair_origin += 2 * (size_t)base;
+      Q.keys += base;
+      Q.n_pairs = count;
+      Q.pairs_per_xcd = (count + 7) / 8;
+      NHIP_TRY_HIP(hipStreamWaitEvent(q_stream[q], q_start, 0));
+      rc = bnb::launch_bnb_kernels(Q, L.cb, pool_lds, lds, (int64_t)Q.pairs_per_xcd * 8, false, q_stream[q]);
+      NHIP_TRY_HIP(hipEventRecord(q_done[q], q_stream[q]));
+      NHIP_TRY_HIP(hipStreamWaitEvent(s, q_done[q], 0));
+    }
+  } else {
+    rc = instr ? bnb::launch_bnb_kernels_instr(P, L.cb, pool_lds, lds, blocks, second_kernel, s)
+               : bnb::launch_bnb_kernels(P, L.cb, pool_lds, lds, blocks, second_kernel, s);
+  }
   if (rc) return rc;
   timer_end(NHIP_TIMER_CSM, s);
   NHIP_TRY_HIP(hipGetLastError());

@@ -104,7 +104,7 @@ void timer_end(int id, hipStream_t s);
 // ---- kernel launchers (defined in the .hip files) ----
 int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
                       int32_t n_targets, const nhip_grid_spec_t *spec, const GridLayout &L,
-                      uint8_t *d_grids, void *d_ws, int64_t ws_bytes, hipStream_t s);
+                      uint8_t *d_grids, void *d_ws, int64_t ws_bytes, hipStream_t s, bool incremental = false);
 
 int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,

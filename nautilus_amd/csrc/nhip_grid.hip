@@ -394,6 +394,61 @@ __global__ __launch_bounds__(256) void grid_pool_kernel(const uint8_t *__restric
   }
 }
 
+// ---- incremental rebuild ---------------------------------------------------------------------------------
+// A build leaves in the workspace the list of (target slot, 64 x 64 tile) entries it wrote and, in the header, a tag
+// of the buffer it wrote them to.  nhip_grid_rebuild_dev clears exactly those tiles (image, and the plane of high
+// bytes of 16-bit grids) instead of zero-filling gigabytes: ~20 % of a dense scan's tiles hold anything.  The tag is
+// checked ON THE DEVICE (no host round trip): a header that does not describe this very buffer -- fresh or recycled
+// workspace memory, another buffer, another geometry -- makes the same kernel clear everything instead.
+constexpr uint64_t GRID_TAG_SEED = 0x9e3779b97f4a7c15ull;
+inline uint64_t grid_tag(const void *d_grids, int64_t n_targets, const GridLayout &L, int32_t flags) {
+  uint64_t h = GRID_TAG_SEED;
+  const uint64_t v[6] = {(uint64_t)(uintptr_t)d_grids, (uint64_t)n_targets, (uint64_t)L.slot_bytes, (uint64_t)L.S,
+                         (uint64_t)L.cb, (uint64_t)flags};
+  for (uint64_t x : v) {
+    h ^= x + GRID_TAG_SEED + (h << 6) + (h >> 2);
+    h *= 0xff51afd7ed558ccdull;
+  }
+  return h | 1ull;  // (never 0: a zeroed header is never valid)
+}
+
+__global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restrict__ header, uint64_t expect,
+                                                         const int32_t *__restrict__ list, uint8_t *__restrict__ grids,
+                                                         int32_t n_targets, int32_t S, int32_t tiles, int32_t pad,
+                                                         int32_t pitch, int32_t cb, int64_t slot_bytes, int64_t hi_offset,
+                                                         int32_t hi_pitch) {
+  const uint64_t tag = *reinterpret_cast<const uint64_t *>(header + 2);
+  if (tag != expect) {  // unknown contents: everything goes (16-byte stores, grid-stride)
+    uint4 *p = reinterpret_cast<uint4 *>(grids);
+    const int64_t n16 = (int64_t)n_targets * slot_bytes / 16;  // (slot_bytes is a multiple of 16)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
+    return;
+  }
+  const int32_t n_entries = header[0];
+  for (int32_t e = blockIdx.x; e < n_entries; e += gridDim.x) {
+    const int32_t entry = list[e];
+    const int32_t t = entry / (tiles * tiles), tile = entry % (tiles * tiles);
+    const int32_t r0 = (tile / tiles) * TILE, c0 = (tile % tiles) * TILE;
+    uint8_t *g = grids + (size_t)t * slot_bytes;
+    // 64 rows x 64 cells as 4-byte stores (pad, c0 are multiples of 4): 16 (8-bit) or 32 (16-bit) per row, + 16 of the
+    // plane of high bytes; cells past the raster were never written
+    const int per_row = 16 * cb;
+    for (int i = threadIdx.x; i < TILE * per_row; i += 256) {
+      const int r = i / per_row, d = i % per_row;
+      if (r0 + r < S && c0 + (4 / cb) * d < S)
+        *reinterpret_cast<uint32_t *>(g + (size_t)(r0 + r + pad) * pitch + (size_t)(c0 + pad) * cb + 4 * d) = 0u;
+    }
+    if (cb == 2)
+      for (int i = threadIdx.x; i < TILE * 16; i += 256) {
+        const int r = i / 16, d = i % 16;
+        if (r0 + r < S && c0 + 4 * d < S)
+          *reinterpret_cast<uint32_t *>(g + hi_offset + (size_t)(r0 + r + pad) * hi_pitch + (size_t)(c0 + pad) + 4 * d) = 0u;
+      }
+  }
+}
+
+__global__ void grid_tag_kernel(int32_t *header, uint64_t tag) { *reinterpret_cast<uint64_t *>(header + 2) = tag; }
+
 template <int CB, int ST>
 void launch_pool(const uint8_t *occ, uint8_t *g, const GridLayout &L, int32_t tiles, int32_t n, hipStream_t s) {
   const int32_t rows = L.S + 2 * L.pad, mpitch = L.pitch / 4;
@@ -412,7 +467,7 @@ void launch_pool(const uint8_t *occ, uint8_t *g, const GridLayout &L, int32_t ti
 
 int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
                       int32_t n_targets, const nhip_grid_spec_t *spec, const GridLayout &L,
-                      uint8_t *d_grids, void *d_ws, int64_t ws_bytes, hipStream_t s) {
+                      uint8_t *d_grids, void *d_ws, int64_t ws_bytes, hipStream_t s, bool incremental) {
   NHIP_REQUIRE(L.R <= MAX_R, "grid_build: blur radius %d > %d (sigma too large)", L.R, MAX_R);
   NHIP_REQUIRE(L.K * L.K < (1ll << 32), "grid_build: tap sum overflows 32-bit accumulation");
   NHIP_REQUIRE(L.pitch % 4 == 0, "grid_build: pitch must be a multiple of 4");
@@ -445,6 +500,10 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     d_thr16 = reinterpret_cast<uint32_t *>(static_cast<uint8_t *>(d_ws) + GRID_WS_HEADER);
     NHIP_TRY_HIP(hipMemcpyAsync(d_thr16, T.thr16, GRID_WS_THR16, hipMemcpyHostToDevice, s));
   }
+  // one pass over all targets leaves a complete tile list behind: only then can the next build be incremental
+  const bool one_pass = chunk >= n_targets;
+  const uint64_t tag = grid_tag(d_grids, n_targets, L, spec->flags);
+  timer_begin(NHIP_TIMER_GRID, s);
   for (int64_t t0 = 0; t0 < n_targets; t0 += chunk) {
     const int32_t n = (int32_t)((n_targets - t0 < chunk) ? (n_targets - t0) : chunk);
     uint8_t *base = static_cast<uint8_t *>(d_ws);
@@ -453,10 +512,21 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     const size_t occ_bytes = (size_t)n * tiles * tiles;
     int32_t *list = reinterpret_cast<int32_t *>(occ + ((occ_bytes + 3) & ~(size_t)3));
     uint8_t *g = d_grids + (size_t)t0 * L.slot_bytes;
-    // counter and occupancy in one fill; images and skip maps in another
+    timer_begin(NHIP_TIMER_GRID_CLEAR, s);
+    if (incremental && one_pass) {
+      // the tiles the previous build wrote (or everything, if the header does not vouch for this buffer), then the
+      // derived tables between the image and the plane of high bytes: skip map and the two pooled tables, every slot
+      hipLaunchKernelGGL(grid_clear_kernel, dim3(4096), dim3(256), 0, s, count, tag, list, g, n, L.S, tiles, L.pad, L.pitch,
+                         L.cb, L.slot_bytes, L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_pitch);
+      NHIP_TRY_HIP(hipMemset2DAsync(g + L.grid_bytes, (size_t)L.slot_bytes, 0,
+                                    (size_t)(L.skip_bytes + L.pool_bytes + L.pool4_bytes), (size_t)n, s));
+    } else {
+      NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.slot_bytes, s));
+    }
+    // counter (and tag: the buffer is in flux until this build is through) and occupancy
     NHIP_TRY_HIP(hipMemsetAsync(base, 0, GRID_WS_HEADER, s));
     NHIP_TRY_HIP(hipMemsetAsync(occ, 0, occ_bytes, s));
-    NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.slot_bytes, s));
+    timer_end(NHIP_TIMER_GRID_CLEAR, s);
     const double inv_res = 1.0 / spec->res;
     hipLaunchKernelGGL(grid_occupancy_kernel, dim3(n), dim3(256), 0, s,
                        reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
@@ -464,7 +534,6 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     const int32_t n_tiles_total = n * tiles * tiles;
     hipLaunchKernelGGL(grid_tile_list_kernel, dim3((n_tiles_total + 255) / 256), dim3(256), 0, s, occ,
                        n_tiles_total, count, list);
-    timer_begin(NHIP_TIMER_GRID, s);
     const int32_t blur_blocks = n_tiles_total < 8192 ? n_tiles_total : 8192;  // persistent over the list
     const int32_t rows = L.S + 2 * L.pad, mpitch = L.pitch / 4;
     if (L.cb == 1)
@@ -497,8 +566,9 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
       launch_pool<2, BNB_B>(occ, g, L, tiles, n, s);
       launch_pool<2, BNB_B4>(occ, g, L, tiles, n, s);
     }
-    timer_end(NHIP_TIMER_GRID, s);
+    if (one_pass) hipLaunchKernelGGL(grid_tag_kernel, dim3(1), dim3(1), 0, s, count, tag);
   }
+  timer_end(NHIP_TIMER_GRID, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }

@@ -64,3 +64,27 @@ def test_adapter_binary_on_gpu(gpu, tmp_path):
             assert np.float32(th) == np.float32(theta0 + (m.itheta - 30) * (math.pi / 180.0))
             seen.add("batch%d" % i)
     assert seen == {"get_transformation", "get_transformation_swapped", "batch0", "batch1"}
+    # the residual half: what the C++ cost functions' Evaluate() returned for the three LIDAR blocks (batched pass,
+    # compact target Jacobian rebuilt on the host) against the oracle's Jet<6> restatement of slam_residuals.h:65-89
+    # (LIDARNormal) and :124-145 (LIDARPoint) on the same correspondences and parameter blocks
+    for q in range(3):
+        raw = open(os.path.join(tmp_path, "lidar_block_%d.bin" % q), "rb").read()
+        kind, n = np.frombuffer(raw, dtype=np.int32, count=2)
+        assert n == 300 and kind == (1 if q == 1 else 0)
+        off = 8
+        vecs = []
+        for _ in range(4):
+            vecs.append(np.frombuffer(raw, dtype=np.float32, count=2 * n, offset=off).reshape(n, 2))
+            off += 8 * n
+        pa = np.frombuffer(raw, dtype=np.float64, count=3, offset=off)
+        pb = np.frombuffer(raw, dtype=np.float64, count=3, offset=off + 24)
+        off += 48
+        r = np.frombuffer(raw, dtype=np.float64, count=2 * n, offset=off)
+        js = np.frombuffer(raw, dtype=np.float64, count=6 * n, offset=off + 16 * n).reshape(2 * n, 3)
+        jt = np.frombuffer(raw, dtype=np.float64, count=6 * n, offset=off + 64 * n).reshape(2 * n, 3)
+        assert len(raw) == off + 112 * n
+        wr, w0, w1 = O.lidar_block(int(kind), vecs[0], vecs[1], vecs[2], vecs[3], pa, pb)
+        assert np.abs(wr).max() > 0.01 and np.abs(w0).max() > 0.5
+        assert np.allclose(r, wr, rtol=1e-9, atol=1e-12)      # bar of tests/test_resid_gpu.py
+        assert np.allclose(js, w0, rtol=1e-9, atol=1e-9) and np.allclose(jt, w1, rtol=1e-9, atol=1e-9)
+    assert "20 problem builds" in p.stdout and "two problems coexist" in p.stdout

@@ -745,7 +745,7 @@ def test_config4_per_gpu_share(gpu, cell_bits):
     elapsed, full = bench.run_sharded(plan, 0, 1, dev, m, steps=1, warmup=0)
     rec = full.cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
     sums = np.empty(wl.n_pairs, np.int32)
-    sums[plan.order] = m.d_sums[:m.n_pairs].cpu().numpy()
+    sums[plan.order] = m.records()[1].cpu().numpy()
     m.free_grids()
     mx = bench.HipMatcher(wl, plan.shard(0), dev, cell_bits, exhaustive=True)
     _, full_x = bench.run_sharded(plan, 0, 1, dev, mx, steps=1, warmup=0)
@@ -789,16 +789,20 @@ def test_config2_full_size_16bit_branch_and_bound_equals_every_add(gpu):
     from nautilus_amd import sharding
     wl = bench.Workload("weak", 1)
     assert wl.n_pairs == 10000 and wl.n_scans == 1000
-    plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
+    # (as bench.py runs it: the pairs launched heaviest first by the cost estimate from the odometry poses; the kernel
+    #  that performs every add takes them in by-target order -- the records must agree in shard order)
+    w = sharding.predicted_pair_cost(wl.bag.odom, wl.src, wl.tgt)
+    plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1, w)
     dev = torch.device("cuda", 0)
-    m = bench.HipMatcher(wl, plan.shard(0), dev, 16)
+    m = bench.HipMatcher(wl, plan.shard(0), dev, 16, weights=plan.shard_weights(0))
+    assert m.d_unperm is not None and not np.array_equal(m.src, plan.shard(0)[1])
     _, full = bench.run_sharded(plan, 0, 1, dev, m, steps=1, warmup=0)
-    sums = m.d_sums[:m.n_pairs].clone()
+    sums = m.records()[1].clone()
     m.free_grids()
     mx = bench.HipMatcher(wl, plan.shard(0), dev, 16, exhaustive=True)
     _, full_x = bench.run_sharded(plan, 0, 1, dev, mx, steps=1, warmup=0)
     assert torch.equal(full, full_x), "branch and bound differs from the kernel that performs every add (16-bit cells)"
-    assert torch.equal(sums, mx.d_sums[:mx.n_pairs])
+    assert torch.equal(sums, mx.records()[1])
     mx.free_grids()
     rec = full.cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
     hsums = np.empty(wl.n_pairs, np.int32)
@@ -829,3 +833,44 @@ def test_drop_in_call_with_rotation_restriction_pi(gpu, small_bag):
     got = m2.GetTransformation(a, b, rot_a, rot_b, math.radians(30))
     want = O.two_level_match(a, b, rot_a, rot_b, math.radians(30), 30.0, 4.8, 0.1, 0.05, cell_bits=16)
     assert got[0] == want[0] and got[1][0][0] == want[1][0][0] and got[1][0][1] == want[1][0][1] and got[1][1] == want[1][1]
+
+
+@pytest.mark.parametrize("cell_bits", [16, 8])
+def test_grid_rebuild_clears_what_the_last_build_wrote(gpu, small_bag, cell_bits):
+    """nhip_grid_rebuild_dev clears only the tiles the previous build listed in the workspace -- and must leave the
+    buffer exactly as a build into zeroed memory would: other targets than before (their tiles lie elsewhere), a
+    workspace whose header holds garbage, and a buffer the workspace has never seen (full of 0xFF) all give the
+    slots of a fresh build, byte for byte (image, skip map, pooled tables, plane of high bytes)."""
+    import torch
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits, skip_map=True)
+    L = csm.grid_layout(spec)
+    xy, off = csm.pack_scans(small_bag.scans)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_xy, d_off = t(xy), t(off)
+    n = 3
+    nbytes = lib.nhip_grids_bytes(C.byref(spec), n)
+    ws_bytes = lib.nhip_grid_workspace_bytes(C.byref(spec), n)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call(fn, ids, d_grids, d_ws):
+        d_ids = t(np.asarray(ids, dtype=np.int32))
+        _lib.check(fn(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), n, C.byref(spec), d_grids.data_ptr(),
+                      d_ws.data_ptr(), ws_bytes, sp))
+        torch.cuda.synchronize()
+        return d_grids[:n * L.slot_bytes].cpu().numpy().copy()
+
+    ids_a, ids_b = [3, 17, 40], [25, 8, 3]
+    fresh_b = call(lib.nhip_grid_build_dev, ids_b, torch.zeros(nbytes, dtype=torch.uint8, device=dev),
+                   torch.zeros(ws_bytes, dtype=torch.uint8, device=dev))
+    assert fresh_b.any()
+    G, W = torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    a = call(lib.nhip_grid_build_dev, ids_a, G, W)
+    assert not np.array_equal(a, fresh_b)
+    assert np.array_equal(call(lib.nhip_grid_rebuild_dev, ids_b, G, W), fresh_b), "rebuild over another set of targets"
+    assert np.array_equal(call(lib.nhip_grid_rebuild_dev, ids_b, G, W), fresh_b), "rebuild over the same targets"
+    W2 = torch.randint(0, 256, (ws_bytes,), dtype=torch.uint8, device=dev)
+    assert np.array_equal(call(lib.nhip_grid_rebuild_dev, ids_b, G, W2), fresh_b), "garbage workspace header"
+    G3 = torch.full((nbytes,), 255, dtype=torch.uint8, device=dev)
+    assert np.array_equal(call(lib.nhip_grid_rebuild_dev, ids_b, G3, W), fresh_b), "a buffer the workspace never saw"

@@ -248,3 +248,48 @@ def test_full_size_block_properties(gpu):
         fd = (rp - rm) / (2 * eps)       # every pose moved: d r / d src[col] + d r / d tgt[col]
         assert np.max(np.abs(fd - (js[:, col] + jt[:, col]))) < 1e-5
     batch.close()
+
+
+def test_feature_mode_blocks_match_oracle(gpu):
+    """The production block shape: Solver::SolveSLAM only ever builds OptimizationType::FEATURE blocks (solver.cc:363):
+    <= 20 planar rows (LIDARNormalResidual) and <= 10 edge rows (LIDARPointResidual) per (i, j) of a window-10 graph,
+    9,945 blocks of each at 1000 poses (slam_types.h:66-67).  Through the host-buffer API (compact target Jacobian) and
+    through the per-block normal equations, against the Jet<6> oracle on every block."""
+    import ctypes as C
+    import os
+    import sys
+    import torch
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from nautilus_amd import _lib
+    lib = _lib.load()
+    blocks, poses = bench.feature_blocks()
+    dev = torch.device("cuda:0")
+    for kind, (corr, off, bs, bt) in blocks.items():
+        assert len(bs) == 9945 and np.diff(off).max() <= (20, 10)[kind] and np.diff(off).min() >= 1
+        n = len(corr)
+        h = C.c_void_p()
+        _lib.check(lib.nhip_resid_batch_create(kind, _lib.ptr(corr), _lib.ptr(off), _lib.ptr(bs), _lib.ptr(bt), len(bs),
+                                               len(poses), C.byref(h)))
+        r, js, jtt = np.empty(2 * n), np.empty((2 * n, 3)), np.empty(2 * n)
+        _lib.check(lib.nhip_resid_batch_eval_compact(h, _lib.ptr(poses), _lib.ptr(r), _lib.ptr(js), _lib.ptr(jtt)))
+        lib.nhip_resid_batch_free(h)
+        wr, w0, w1 = O.lidar_batch(kind, corr, off, bs, bt, poses)
+        assert np.allclose(r, wr, rtol=1e-9, atol=1e-12) and np.allclose(js, w0, rtol=1e-9, atol=1e-9)
+        assert np.allclose(jtt, w1[:, 2], rtol=1e-9, atol=1e-9) and np.allclose(-js[:, :2], w1[:, :2], rtol=1e-9, atol=1e-9)
+        # normal equations of every block: J^T J (upper triangle), J^T r, r^T r
+        t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+        d_corr, d_off, d_bs, d_bt, d_poses = t(corr), t(off), t(bs), t(bt), t(poses)
+        consts = torch.empty(8 * len(bs), dtype=torch.float64, device=dev)
+        outb = torch.empty(28 * len(bs), dtype=torch.float64, device=dev)
+        _lib.check(lib.nhip_resid_lidar_normal_eq_dev(kind, d_corr.data_ptr(), d_off.data_ptr(), d_bs.data_ptr(), d_bt.data_ptr(),
+                                                      len(bs), d_poses.data_ptr(), len(poses), consts.data_ptr(), outb.data_ptr(), None))
+        torch.cuda.synchronize()
+        got = outb.cpu().numpy().reshape(-1, 28)
+        J = np.concatenate([w0, w1], axis=1)  # (2n, 6)
+        iu = np.triu_indices(6)
+        for b in np.r_[0:5, np.random.default_rng(0).choice(len(bs), 60, replace=False)]:
+            rows = slice(2 * off[b], 2 * off[b + 1])
+            Jb, rb = J[rows], wr[rows]
+            assert np.allclose(got[b, :21], (Jb.T @ Jb)[iu], rtol=1e-9, atol=1e-9)
+            assert np.allclose(got[b, 21:27], Jb.T @ rb, rtol=1e-9, atol=1e-9) and np.isclose(got[b, 27], rb @ rb, rtol=1e-9)

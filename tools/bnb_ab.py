@@ -8,9 +8,10 @@ libs = sorted(glob.glob(os.path.join(ROOT, "build", "variants", "libbnb_*.so")))
 res = {}
 for r in range(rounds):
     for lp in libs:
-        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bnb_quick.py")], env=dict(os.environ, NHIP_LIB=lp),
-                           stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
-        name = os.path.basename(lp)[6:-3]
+      for order in ("0", "1"):  # by-target launch order / heaviest first
+        p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bnb_quick.py")],
+                           env=dict(os.environ, NHIP_LIB=lp, NHIP_QUICK_ORDER=order), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+        name = os.path.basename(lp)[6:-3] + ("+lpt" if order == "1" else "")
         for line in p.stdout.decode().splitlines():
             if "kernel_ms" in line:
                 res.setdefault(name, {}).setdefault(line.split()[0], []).append(float(line.split()[2]))

@@ -10,9 +10,11 @@ if os.environ.get("NHIP_LIB_ALT"):  # (A/B experiments: a second build of the li
     _lib.LIB_PATH = os.path.join(ROOT, "nautilus_amd", "lib", "alt_" + os.environ["NHIP_LIB_ALT"], "libnautilus_hip.so")
 lib = _lib.load()
 wl = bench.Workload("weak", 1, int(sys.argv[1]) if len(sys.argv) > 1 else 1000, int(sys.argv[2]) if len(sys.argv) > 2 else 10)
-plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
+# NHIP_QUICK_ORDER=1: the pairs are launched heaviest first (sharding.predicted_pair_cost from the odometry poses)
+w = sharding.predicted_pair_cost(wl.bag.odom, wl.src, wl.tgt) if os.environ.get("NHIP_QUICK_ORDER") == "1" else None
+plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1, w)
 for bits in (8, 16):
-    m = bench.HipMatcher(wl, plan.shard(0), torch.device("cuda", 0), bits)
+    m = bench.HipMatcher(wl, plan.shard(0), torch.device("cuda", 0), bits, weights=plan.shard_weights(0))
     m.step(); torch.cuda.synchronize()
     lib.nhip_timing_reset(); lib.nhip_timing_enable(1)
     for _ in range(5):

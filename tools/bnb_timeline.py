@@ -20,8 +20,8 @@ raw = np.zeros(4 * m.n_pairs + 2, dtype=np.uint64)
 _lib.check(lib.nhip_bnb_timeline(_lib.ptr(raw), m.n_pairs))
 t = raw[:-2].reshape(m.n_pairs, 4).copy()
 k2 = raw[-2:].astype(np.int64)
-hw = (t[:, 3] >> np.uint64(48)).astype(np.int64)
-t[:, 3] &= np.uint64(0xffffffffffff)
+hw = (t[:, 3] >> np.uint64(44)).astype(np.int64)   # cu | sh | se (8 bits), xcc (4 bits)
+t[:, 3] &= np.uint64(0xfffffffffff)
 t = t.astype(np.int64)
 t0 = t[:, 0].min()
 us = (t - t0) / 100.0
@@ -39,5 +39,30 @@ order = np.argsort(us[:, 3])[-3:]
 out["last_3_to_finish"] = [{"pair": int(i), "start_us": float(us[i, 0]), "end_us": float(us[i, 3]), "phase3_us": float(us[i, 3] - us[i, 2])} for i in order]
 out["last_start_us"] = float(us[:, 0].max())
 out["second_kernel_us"] = [float((k2[0] - t0) / 100.0), float((k2[1] - t0) / 100.0)] if k2[1] else None
-out["distinct_hw_ids"] = int(len(np.unique(hw)))
+out["distinct_cus"] = int(len(np.unique(hw)))
+# per CU: workgroups resident over time (sampled), and the gap between one workgroup's end and the next one's start
+# in the same "slot" (greedy assignment of a CU's workgroups to two slots in start order)
+res_per_cu, gaps, busy = [], [], []
+mid0, mid1 = 0.15 * end, 0.6 * end   # mid-launch: the chip is supposed to be full
+for cu in np.unique(hw):
+    sel = np.nonzero(hw == cu)[0]
+    o = sel[np.argsort(us[sel, 0])]
+    slots = []
+    for i in o:
+        placed = False
+        for k in range(len(slots)):
+            if slots[k] <= us[i, 0]:
+                if mid0 < us[i, 0] < mid1:
+                    gaps.append(us[i, 0] - slots[k])
+                slots[k] = us[i, 3]
+                placed = True
+                break
+        if not placed:
+            slots.append(us[i, 3])
+    res_per_cu.append(len(slots))
+    g = np.linspace(mid0, mid1, 50)
+    busy.append(np.mean([((us[sel, 0] <= x) & (us[sel, 3] > x)).sum() for x in g]))
+out["max_concurrent_wgs_per_cu_hist"] = {int(k_): int(v_) for k_, v_ in zip(*np.unique(res_per_cu, return_counts=True))}
+out["mean_resident_wgs_per_cu_mid_launch"] = float(np.mean(busy))
+out["slot_gap_us_p10_p50_p90_mean"] = [float(x) for x in np.percentile(gaps, [10, 50, 90])] + [float(np.mean(gaps))] if gaps else None
 print(json.dumps(out, indent=1))
