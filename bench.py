@@ -61,7 +61,11 @@ def parse(argv=None):
     ap.add_argument("--cpu-seconds", type=float, default=20.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--no-resid", action="store_true", help="skip the secondary measurements")
     ap.add_argument("--no-cost-model", action="store_true",
-                    help="shard by pair count and launch in by-target order (no per-pair cost estimate)")
+                    help="shard by pair count (no per-pair cost estimate in the plan)")
+    ap.add_argument("--launch-order", choices=["target", "weight"], default="target",
+                    help="order in which a rank hands its pairs to the matcher: by target (a target's pairs share an "
+                         "XCD's L2), or heaviest first by the cost estimate (measured: no gain at 10,000 pairs -- the pairs "
+                         "that take milliseconds are not the ones the odometry offset predicts)")
     ap.add_argument("--no-drop-in", action="store_true",
                     help="skip the single-pair latency leg (its small launches of the correlation kernel would "
                          "blur that kernel's average in a rocprofv3 --stats summary)")
@@ -404,7 +408,8 @@ def worker(a):
     weights = None if a.no_cost_model else sharding.predicted_pair_cost(wl.bag.odom, wl.src, wl.tgt)
     plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, world, weights)
     shard = plan.shard(rank)
-    m = HipMatcher(wl, shard, dev, a.cell_bits, weights=plan.shard_weights(rank))
+    launch_w = plan.shard_weights(rank) if a.launch_order == "weight" else None
+    m = HipMatcher(wl, shard, dev, a.cell_bits, weights=launch_w)
 
     def start_timers():
         lib.nhip_timing_reset()
@@ -523,7 +528,7 @@ def worker(a):
         recs = {a.cell_bits: (got, got_sums)}  # the branch-and-bound records by cell width
 
         def other_cells():
-            r = leg_other_cells(wl, shard, dev, a, weights=plan.shard_weights(rank))
+            r = leg_other_cells(wl, shard, dev, a, weights=launch_w)
             recs[24 - a.cell_bits] = r.pop("_records")
             return r
 

@@ -211,7 +211,8 @@ int nhip_bnb_stats(uint64_t *evaluated, uint64_t *total);
 /* ... by level: out[0..3] = {blocks evaluated whole, blocks in all, candidate blocks refined through their four
  * sub-block bounds, 4 x 4 sub-blocks evaluated exactly}; out[4..10] = shader-clock sums of the matcher's kernel:
  * wave time in the candidate phase, of which window origins / sub-block bounds / exact sums, the slowest wave of
- * each pair, seed phase and bound phase (per workgroup); out[11..15] reserved (synchronises; resets) */
+ * each pair, seed phase and bound phase (per workgroup); out[11..13] further clocks, out[14] = poses of 16-bit grids whose exact
+ * sums were read from the 16-bit image (the rest was settled on the plane of high bytes); (synchronises; resets) */
 int nhip_bnb_stats_levels(uint64_t out[16]);
 /* ... and per pair of the last launch (4 x 4 sub-blocks evaluated exactly, a whole block counting four), before
  * nhip_bnb_stats resets the totals */

@@ -183,7 +183,7 @@ def bnb_stats_levels():
     return {"blocks_whole": v[0], "blocks_total": v[1], "candidates_refined": v[2], "sub_blocks": v[3],
             "clk_wave_phase3": v[4], "clk_origins": v[5], "clk_sub_bounds": v[6], "clk_exact": v[7],
             "clk_slowest_wave": v[8], "clk_seeds": v[9], "clk_bounds": v[10], "clk_wave_phase3_100MHz": v[11],
-            "pairs_handed_over": v[12], "clk_wave_second_kernel": v[13]}
+            "pairs_handed_over": v[12], "clk_wave_second_kernel": v[13], "pose_evals16": v[14]}
 
 
 def score_volume(scans, grids, src, slot, theta0, search, origin=(0, 0)):

@@ -832,9 +832,12 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
                                               int32_t Y, int32_t X, int32_t sy, int32_t sx, int lane, int *dy, int *dx) {
   const uint32_t off = (uint32_t)(BNB_B * Y + BNB_B4 * sy) * pitch + (uint32_t)(BNB_B * X + BNB_B4 * sx);
 #ifndef NHIP_BNB_SUB_U8
-#define NHIP_BNB_SUB_U8 6
+#define NHIP_BNB_SUB_U8 2
 #endif
-  constexpr int U = NHIP_BNB_SUB_U8;  // chunks per round: 4 U row loads in flight
+  // chunks per round: 4 U row loads in flight.  (6 -> 2 together with NHIP_BNB_BLOCK_ROWS 8 -> 4: the same speed within
+  // the run-to-run spread -- gpurun_out r3_bnb_ab6.log -- and the by-rotation kernels fit their 128 registers: no
+  // scratch memory at all, where each launch used to write 225-370 MB of spills for 160 KB of records.)
+  constexpr int U = NHIP_BNB_SUB_U8;
   static_assert(OC % U == 0, "whole rounds");
   // (18 chunks * 255 * 8 lanes < 65536: the packed fields hold a whole scan)
   uint32_t E[4] = {0u, 0u, 0u, 0u}, O[4] = {0u, 0u, 0u, 0u};
@@ -893,25 +896,37 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
 #pragma unroll
   for (int r = 0; r < OC / U; r++) {
     if (U * r >= nch) continue;
-    u32x3 w[U][8];
-    uint32_t sh[U];
+    // rows in groups of ROWS per chunk: 8 -> all eight 12-byte loads of a chunk in flight (24 registers), 4 -> two
+    // groups of four (12 registers: with the 32 accumulators the kernel then stays inside its 128 registers)
+#ifndef NHIP_BNB_BLOCK_ROWS
+#define NHIP_BNB_BLOCK_ROWS 4
+#endif
+    constexpr int ROWS = NHIP_BNB_BLOCK_ROWS;
+    uint32_t gg[U], sh[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
       const uint32_t o = origin_of(org, U * r + j);
       const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
       sh[j] = (g & 3u) * 8u;
-#pragma unroll
-      for (int y = 0; y < 8; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
+      gg[j] = g & ~3u;
     }
 #pragma unroll
-    for (int j = 0; j < U; j++)
+    for (int y0 = 0; y0 < 8; y0 += ROWS) {
+      u32x3 w[U][ROWS];
 #pragma unroll
-      for (int y = 0; y < 8; y++) {
-        const uint32_t n0 = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
-        const uint32_t n1 = __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
-        E[y][0] += n0 & M8; O[y][0] += n0 >> 8;
-        E[y][1] += n1 & M8; O[y][1] += n1 >> 8;
-      }
+      for (int j = 0; j < U; j++)
+#pragma unroll
+        for (int y = 0; y < ROWS; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gg[j] + (uint32_t)(y0 + y) * pitch), 0, 0);
+#pragma unroll
+      for (int j = 0; j < U; j++)
+#pragma unroll
+        for (int y = 0; y < ROWS; y++) {
+          const uint32_t n0 = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+          const uint32_t n1 = __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
+          E[y0 + y][0] += n0 & M8; O[y0 + y][0] += n0 >> 8;
+          E[y0 + y][1] += n1 & M8; O[y0 + y][1] += n1 >> 8;
+        }
+    }
   }
   uint32_t R[32];  // R[4 y + d]: d = 0: dx 0, 2; 1: dx 1, 3; 2: dx 4, 6; 3: dx 5, 7
 #pragma unroll
@@ -1040,7 +1055,7 @@ struct PairCtx {
 
 template <int CB>
 __device__ __forceinline__ void process_candidate(const BnbParams &P, const PairCtx &C, int32_t k, int32_t v, int lane,
-                                                  unsigned long long *best, uint32_t (&n)[3]) {
+                                                  unsigned long long *best, uint32_t (&n)[4]) {
   const int Y = v / NB, X = v - NB * Y;  // v: block index NB * Y + X
   float cf, sf;
   rotation_k(P, C.pair, k, &cf, &sf);
@@ -1080,7 +1095,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
                                                     __amdgpu_buffer_rsrc_t rsrc16, const uint32_t *org, int32_t nch,
                                                     int32_t n_pts, int32_t k, int32_t Y, int32_t X,
                                                     uint32_t sb0, uint32_t sb1, uint32_t sb2, uint32_t sb3, int lane,
-                                                    unsigned long long *best, uint32_t &bcopy, uint32_t (&n)[3]) {
+                                                    unsigned long long *best, uint32_t &bcopy, uint32_t (&n)[4]) {
   const uint32_t bsum = best_sum_cached<GLOBAL>(best, bcopy);
   const int alive = (sb0 != 0u && sb0 >= bsum) + (sb1 != 0u && sb1 >= bsum) + (sb2 != 0u && sb2 >= bsum) +
                     (sb3 != 0u && sb3 >= bsum);
@@ -1094,7 +1109,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
       if (lane == 0) atomicMax(best, key);  // (generic address: LDS or global)
       if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
     } else {
-      refine16<GLOBAL>(P, rsrc16, org, nch, n_pts, k, ix, iy, total, true, lane, best, bcopy);
+      n[3] += refine16<GLOBAL>(P, rsrc16, org, nch, n_pts, k, ix, iy, total, true, lane, best, bcopy);
     }
     n[0]++;
     return;
@@ -1111,7 +1126,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
       if (lane == 0) atomicMax(best, key);
       if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
     } else {
-      refine16<GLOBAL>(P, rsrc16, org, nch, n_pts, k, ix, iy, total, lane < 16, lane, best, bcopy);
+      n[3] += refine16<GLOBAL>(P, rsrc16, org, nch, n_pts, k, ix, iy, total, lane < 16, lane, best, bcopy);
     }
     n[2]++;
   }
@@ -1128,7 +1143,7 @@ template <int CB, bool GLOBAL>
 __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx &C, int32_t k, uint32_t u0, uint32_t u1,
                                               unsigned long long m0, unsigned long long m1, int lane,
                                               unsigned long long *best, uint32_t *done, uint32_t *org,
-                                              uint32_t (&n_work)[3], PhaseClocks &clk) {
+                                              uint32_t (&n_work)[4], PhaseClocks &clk) {
   const int32_t nch = (C.n_pts + 63) >> 6;
   long long t_mark = 0;
   float cf, sf;
@@ -1257,7 +1272,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     *s_slow = 0ull;
     // (NHIP_BNB_DEBUG=3, experiments only: start from the keys a previous launch left = the ideal threshold)
     *s_best = BNB_DEBUG(P) == 3 ? (P.keys[pair] & 0xffffffff00000000ull) : key0;
-    s_cnt[0] = s_cnt[3] = s_cnt[4] = 0u;
+    s_cnt[0] = s_cnt[3] = s_cnt[4] = s_cnt[5] = 0u;
     *s_qn = 0u;
     *s_qhead = 0u;
   }
@@ -1310,7 +1325,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     wbest = o > wbest ? o : wbest;
   }
   // (2) seed: the wave's highest-bound block, evaluated exactly
-  uint32_t n_work[3] = {0u, 0u, 0u};
+  uint32_t n_work[4] = {0u, 0u, 0u, 0u};
   PairCtx C;
   C.grid = grid;
   C.pts = pts;
@@ -1501,6 +1516,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     atomicAdd(&s_cnt[0], n_work[0]);
     atomicAdd(&s_cnt[3], n_work[1]);
     atomicAdd(&s_cnt[4], n_work[2]);
+    atomicAdd(&s_cnt[5], n_work[3]);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -1520,6 +1536,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
       atomicAdd(&stats_g[1], (unsigned long long)(P.n_theta * P.nbx * P.nby));
       atomicAdd(&stats_g[2], (unsigned long long)s_cnt[3]);
       atomicAdd(&stats_g[3], (unsigned long long)s_cnt[4]);
+      atomicAdd(&stats_g[14], (unsigned long long)s_cnt[5]);  // poses of 16-bit grids evaluated exactly (refine16)
       if (pair < BNB_STATS_PAIRS) atomicAdd(&stats_g[BNB_STATS_HEAD + pair], 4ull * s_cnt[0] + s_cnt[4]);
     }
   }
@@ -1536,7 +1553,7 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
   const uint32_t filled = P.rot_count[8 * xcd];
   const uint32_t count = filled < P.rot_cap ? filled : P.rot_cap;
   const RotEntry *list = P.rot_list + (size_t)xcd * P.rot_cap;
-  uint32_t n_work[3] = {0u, 0u, 0u};
+  uint32_t n_work[4] = {0u, 0u, 0u, 0u};
   __shared__ uint32_t s_org2[4 * ORG_WAVE];
   uint32_t *org = s_org2 + (threadIdx.x >> 6) * ORG_WAVE + lane;
   PhaseClocks clk = {0, 0, 0};
@@ -1551,7 +1568,7 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
     read_entry(list + i, &pair, &k, &m0, &m1);
     PairCtx C;
     pair_context(P, pair, &C);
-    uint32_t n[3] = {0u, 0u, 0u};
+    uint32_t n[4] = {0u, 0u, 0u, 0u};
     // (no block bounds here: 0xffffffff lets every candidate through to its sub-block bounds, which are checked
     //  against the best as it stands in keys[pair])
     rotation_pass<CB, true>(P, C, k, 0xffffffffu, 0xffffffffu, m0, m1, lane, &P.keys[pair], nullptr, org, n, clk);
@@ -1559,11 +1576,13 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
     n_work[0] += n[0];
     n_work[1] += n[1];
     n_work[2] += n[2];
+    n_work[3] += n[3];
   }
   if (BNB_STATS(P) && lane == 0) {
     if (n_work[0]) atomicAdd(&BNB_STATS(P)[0], (unsigned long long)n_work[0]);
     if (n_work[1]) atomicAdd(&BNB_STATS(P)[2], (unsigned long long)n_work[1]);
     if (n_work[2]) atomicAdd(&BNB_STATS(P)[3], (unsigned long long)n_work[2]);
+    if (n_work[3]) atomicAdd(&BNB_STATS(P)[14], (unsigned long long)n_work[3]);
     atomicAdd(&BNB_STATS(P)[13], (unsigned long long)(clock64() - t0));  // wave time in the second kernel
     atomicAdd(&BNB_STATS(P)[5], (unsigned long long)clk.org);
     atomicAdd(&BNB_STATS(P)[6], (unsigned long long)clk.strip);
@@ -1779,47 +1798,10 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
   const bool second_kernel = P.rot_list && (P.debug == 0 || (P.debug >= 3 && P.debug < 26));
   timer_begin(NHIP_TIMER_CSM, s);
-  // NHIP_BNB_QUEUES=K (experiment): the batch as K launches on K streams of the library (fork / join around the
-  // caller's stream with events).  One hardware queue dispatches workgroups in order; with several, a queue whose next
-  // workgroup has no slot does not keep the others' from filling the slots that are free.
-  const char *qenv = getenv("NHIP_BNB_QUEUES");
-  const int n_queues = (qenv && !instr && !second_kernel) ? std::max(1, std::min(8, atoi(qenv))) : 1;
-  int rc = NHIP_OK;
-  if (n_queues > 1 && n_pairs >= 64 * n_queues) {
-    static hipStream_t q_stream[8];
-    static hipEvent_t q_done[8], q_start;
-    static std::once_flag q_once;
-    static bool q_ok = false;
-    std::call_once(q_once, [] {
-      q_ok = hipEventCreateWithFlags(&q_start, hipEventDisableTiming) == hipSuccess;
-      for (int i = 0; i < 8 && q_ok; i++)
-        q_ok = hipStreamCreateWithFlags(&q_stream[i], hipStreamNonBlocking) == hipSuccess &&
-               hipEventCreateWithFlags(&q_done[i], hipEventDisableTiming) == hipSuccess;
-    });
-    NHIP_REQUIRE(q_ok, "csm_bnb: could not create the library's streams");
-    NHIP_TRY_HIP(hipEventRecord(q_start, s));
-    for (int q = 0; q < n_queues && rc == NHIP_OK; q++) {
-      // pairs are dealt to the queues in turn by blocks of 8 (the launch order of the whole batch is kept inside a queue)
-      const int32_t per = ((n_pairs + n_queues - 1) / n_queues + 7) / 8 * 8;
-      const int32_t base = q * per, count = std::min(per, n_pairs - base);
-      if (count <= 0) break;
-      BnbParams Q = P;
-      Q.pair_src += base;
-      Q.pair_slot += base;
-      Q.rot0_cs += 2 * (size_t)base;
-      if (Q.pair_origin) Q.pair_origin += 2 * (size_t)base;
-      Q.keys += base;
-      Q.n_pairs = count;
-      Q.pairs_per_xcd = (count + 7) / 8;
-      NHIP_TRY_HIP(hipStreamWaitEvent(q_stream[q], q_start, 0));
-      rc = bnb::launch_bnb_kernels(Q, L.cb, pool_lds, lds, (int64_t)Q.pairs_per_xcd * 8, false, q_stream[q]);
-      NHIP_TRY_HIP(hipEventRecord(q_done[q], q_stream[q]));
-      NHIP_TRY_HIP(hipStreamWaitEvent(s, q_done[q], 0));
-    }
-  } else {
-    rc = instr ? bnb::launch_bnb_kernels_instr(P, L.cb, pool_lds, lds, blocks, second_kernel, s)
-               : bnb::launch_bnb_kernels(P, L.cb, pool_lds, lds, blocks, second_kernel, s);
-  }
+  // (Tried and removed: the batch as K launches on K streams, so that one hardware queue's in-order dispatch does not
+  //  keep free slots empty -- 2 / 4 / 8 queues took 10 / 30 / 45 % longer, gpurun_out r3_queues_ab.log.)
+  const int rc = instr ? bnb::launch_bnb_kernels_instr(P, L.cb, pool_lds, lds, blocks, second_kernel, s)
+                       : bnb::launch_bnb_kernels(P, L.cb, pool_lds, lds, blocks, second_kernel, s);
   if (rc) return rc;
   timer_end(NHIP_TIMER_CSM, s);
   NHIP_TRY_HIP(hipGetLastError());

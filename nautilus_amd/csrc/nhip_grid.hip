@@ -412,11 +412,31 @@ inline uint64_t grid_tag(const void *d_grids, int64_t n_targets, const GridLayou
   return h | 1ull;  // (never 0: a zeroed header is never valid)
 }
 
+// W = bytes per store the tiles' row starts allow ((pad * cell bytes) mod 16; tile columns are multiples of 64 cells)
+template <int W>
+__device__ __forceinline__ void zero_store(uint8_t *p) {
+  if (W == 16) *reinterpret_cast<uint4 *>(p) = make_uint4(0, 0, 0, 0);
+  else if (W == 8) *reinterpret_cast<uint2 *>(p) = make_uint2(0, 0);
+  else *reinterpret_cast<uint32_t *>(p) = 0u;
+}
+
+// rows [r0, r0 + 64) x bytes [col_byte, col_byte + row_bytes) of a plane of pitch `pitch`, clipped to the raster's rows
+template <int W>
+__device__ __forceinline__ void zero_tile(uint8_t *plane, int32_t pitch, int32_t r0, int32_t pad, int32_t S, int32_t col_byte,
+                                          int32_t row_bytes) {
+  const int per_row = row_bytes / W;
+  for (int i = threadIdx.x; i < TILE * per_row; i += 256) {
+    const int r = i / per_row, d = i % per_row;
+    if (r0 + r < S) zero_store<W>(plane + (size_t)(r0 + r + pad) * pitch + col_byte + W * d);
+  }
+}
+
+template <int W, int WH>
 __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restrict__ header, uint64_t expect,
                                                          const int32_t *__restrict__ list, uint8_t *__restrict__ grids,
                                                          int32_t n_targets, int32_t S, int32_t tiles, int32_t pad,
-                                                         int32_t pitch, int32_t cb, int64_t slot_bytes, int64_t hi_offset,
-                                                         int32_t hi_pitch) {
+                                                         int32_t pitch, int32_t cb, int64_t slot_bytes, int64_t table_offset,
+                                                         int64_t table_bytes, int64_t hi_offset, int32_t hi_pitch) {
   const uint64_t tag = *reinterpret_cast<const uint64_t *>(header + 2);
   if (tag != expect) {  // unknown contents: everything goes (16-byte stores, grid-stride)
     uint4 *p = reinterpret_cast<uint4 *>(grids);
@@ -424,27 +444,21 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (int64_t)gridDim.x * 256) p[i] = make_uint4(0, 0, 0, 0);
     return;
   }
+  // (1) the tiles the previous build wrote: 64 rows x 64 cells of the image and, for 16-bit cells, of the plane of high
+  // bytes (a tile's last columns may lie in the raster's zero border: clearing them again is harmless)
   const int32_t n_entries = header[0];
   for (int32_t e = blockIdx.x; e < n_entries; e += gridDim.x) {
     const int32_t entry = list[e];
     const int32_t t = entry / (tiles * tiles), tile = entry % (tiles * tiles);
     const int32_t r0 = (tile / tiles) * TILE, c0 = (tile % tiles) * TILE;
     uint8_t *g = grids + (size_t)t * slot_bytes;
-    // 64 rows x 64 cells as 4-byte stores (pad, c0 are multiples of 4): 16 (8-bit) or 32 (16-bit) per row, + 16 of the
-    // plane of high bytes; cells past the raster were never written
-    const int per_row = 16 * cb;
-    for (int i = threadIdx.x; i < TILE * per_row; i += 256) {
-      const int r = i / per_row, d = i % per_row;
-      if (r0 + r < S && c0 + (4 / cb) * d < S)
-        *reinterpret_cast<uint32_t *>(g + (size_t)(r0 + r + pad) * pitch + (size_t)(c0 + pad) * cb + 4 * d) = 0u;
-    }
-    if (cb == 2)
-      for (int i = threadIdx.x; i < TILE * 16; i += 256) {
-        const int r = i / 16, d = i % 16;
-        if (r0 + r < S && c0 + 4 * d < S)
-          *reinterpret_cast<uint32_t *>(g + hi_offset + (size_t)(r0 + r + pad) * hi_pitch + (size_t)(c0 + pad) + 4 * d) = 0u;
-      }
+    zero_tile<W>(g, pitch, r0, pad, S, (c0 + pad) * cb, TILE * cb);
+    if (cb == 2) zero_tile<WH>(g + hi_offset, hi_pitch, r0, pad, S, c0 + pad, TILE);
   }
+  // (2) the derived tables of every slot (skip map, both pooled tables: between the image and the plane of high bytes)
+  const int64_t per_slot = table_bytes / 16;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < per_slot * n_targets; i += (int64_t)gridDim.x * 256)
+    *reinterpret_cast<uint4 *>(grids + (i / per_slot) * slot_bytes + table_offset + 16 * (i % per_slot)) = make_uint4(0, 0, 0, 0);
 }
 
 __global__ void grid_tag_kernel(int32_t *header, uint64_t tag) { *reinterpret_cast<uint64_t *>(header + 2) = tag; }
@@ -516,10 +530,16 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     if (incremental && one_pass) {
       // the tiles the previous build wrote (or everything, if the header does not vouch for this buffer), then the
       // derived tables between the image and the plane of high bytes: skip map and the two pooled tables, every slot
-      hipLaunchKernelGGL(grid_clear_kernel, dim3(4096), dim3(256), 0, s, count, tag, list, g, n, L.S, tiles, L.pad, L.pitch,
-                         L.cb, L.slot_bytes, L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_pitch);
-      NHIP_TRY_HIP(hipMemset2DAsync(g + L.grid_bytes, (size_t)L.slot_bytes, 0,
-                                    (size_t)(L.skip_bytes + L.pool_bytes + L.pool4_bytes), (size_t)n, s));
+      const int64_t tb = L.skip_bytes + L.pool_bytes + L.pool4_bytes, hio = L.grid_bytes + tb;
+      const int w = (L.pad * L.cb) % 16 == 0 ? 16 : ((L.pad * L.cb) % 8 == 0 ? 8 : 4), wh = L.pad % 16 == 0 ? 16 : (L.pad % 8 == 0 ? 8 : 4);
+#define NHIP_CLEAR(W, WH)                                                                                             \
+  hipLaunchKernelGGL((grid_clear_kernel<W, WH>), dim3(4096), dim3(256), 0, s, count, tag, list, g, n, L.S, tiles, L.pad, \
+                     L.pitch, L.cb, L.slot_bytes, L.grid_bytes, tb, hio, L.hi_pitch)
+      if (w == 16 && wh == 16) NHIP_CLEAR(16, 16);
+      else if (w == 16) NHIP_CLEAR(16, 4);
+      else if (w == 8) NHIP_CLEAR(8, 4);
+      else NHIP_CLEAR(4, 4);
+#undef NHIP_CLEAR
     } else {
       NHIP_TRY_HIP(hipMemsetAsync(g, 0, (size_t)n * L.slot_bytes, s));
     }

@@ -74,14 +74,20 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _weights(src, tgt):
+    """A cost estimate that makes the pairs of the first two targets heavy (as sharding.predicted_pair_cost would for
+    distant pairs)."""
+    return np.where(tgt <= 4, 6.0, 1.0)
+
+
+def _worker(rank, world, port, q, weighted=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         xy, off, src, tgt, th0 = _workload()
         gs, ss = O.grid_spec(30.0, 0.05, 2.0, 1e-10), O.search_spec(5, 11, 11, math.radians(2))
-        plan = sharding.ShardPlan(src, tgt, th0, world)
+        plan = sharding.ShardPlan(src, tgt, th0, world, _weights(src, tgt) if weighted else None)
         m = _OracleMatcher(xy, off, plan.shard(rank), gs, ss)
         elapsed, full = bench.run_sharded(plan, rank, world, "cpu", m, steps=2, warmup=1, dist=dist)
         q.put((rank, full.numpy().tobytes(), m.calls, elapsed, len(plan.shard(rank)[1])))
@@ -115,3 +121,33 @@ def test_bench_sharded_step_over_gloo_world_2():
     ids = np.unique(tgt)
     direct = O.csm_match_batch(xy, off, O.grid_build_batch(xy, off, ids, gs), gs, src, np.searchsorted(ids, tgt), th0, ss)
     assert np.array_equal(got["ix"], direct["ix"]) and np.array_equal(got["itheta"], direct["itheta"])
+
+
+def test_cost_aware_split_over_gloo_world_2():
+    """The same sharded step with a per-pair cost estimate in the plan (bench.py --mode config4 builds it from the
+    odometry poses): the ranks' blocks balance the weight (3 heavy pairs | 3 heavy + 9 light = 18 | 27, where the split
+    by count would give 39 | 6), every rank still ends with the same table, equal to the unsharded result in the
+    original pair order."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    xy, off, src, tgt, th0 = _workload()
+    w = _weights(src, tgt)
+    plan = sharding.ShardPlan(src, tgt, th0, world, w)
+    assert [res[0][4], res[1][4]] == [int(c) for c in plan.counts] == [3, 12]
+    assert list(plan.rank_weight) == [18.0, 27.0]   # within one target's weight (18) of each other
+    plain = sharding.ShardPlan(src, tgt, th0, world)
+    assert [w[plain.shard(r)[0]].sum() for r in range(world)] == [39.0, 6.0]
+    assert len({r[1] for r in res}) == 1, "ranks hold different tables"
+    gs, ss = O.grid_spec(30.0, 0.05, 2.0, 1e-10), O.search_spec(5, 11, 11, math.radians(2))
+    one = sharding.ShardPlan(src, tgt, th0, 1)
+    want = one.all_gather(_OracleMatcher(xy, off, one.shard(0), gs, ss).step(), 0)
+    assert res[0][1] == want.numpy().tobytes()

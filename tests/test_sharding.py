@@ -103,3 +103,49 @@ def test_all_gather_single_rank_is_identity():
     order, bounds = sharding.partition_by_target(tgt, 1)
     out = sharding.all_gather_matches(rec[torch.from_numpy(order)], tgt, 0, 1)
     assert torch.equal(out, rec)
+
+
+def test_cost_aware_partition_balances_weight_not_count():
+    """BASELINE configs[3] is strong scaling: the run ends when the slowest rank does, and the matcher's time per pair
+    spans two orders of magnitude.  With a cost estimate per pair the contiguous by-target blocks balance its SUM;
+    targets still never straddle ranks, every pair is owned once, and weights=None keeps the count-balanced split."""
+    rng = np.random.default_rng(11)
+    n_t, per = 400, 10
+    tgt = np.repeat(np.arange(n_t), per).astype(np.int32)
+    perm = rng.permutation(len(tgt))
+    tgt = tgt[perm]
+    src = rng.integers(0, n_t, len(tgt)).astype(np.int32)
+    th0 = rng.uniform(-1, 1, len(tgt))
+    w = np.where(tgt < 80, 9.0, 1.0) * rng.uniform(0.8, 1.2, len(tgt))   # the first fifth of the targets is 9x as heavy
+    world = 8
+    plain = sharding.ShardPlan(src, tgt, th0, world)
+    plan = sharding.ShardPlan(src, tgt, th0, world, w)
+    assert list(plain.counts) == [500] * 8
+    tot = w.sum()
+    assert np.allclose(plan.rank_weight.sum(), tot)
+    assert plan.rank_weight.max() < 1.12 * tot / world, plan.rank_weight          # within a target's weight of the ideal
+    plain_w = np.array([w[plain.order[plain.bounds[r]:plain.bounds[r + 1]]].sum() for r in range(world)])
+    assert plain_w.max() > 2.5 * tot / world                                        # what the count split would have cost
+    owned = np.concatenate([plan.shard(r)[0] for r in range(world)])
+    assert np.array_equal(np.sort(owned), np.arange(len(tgt)))
+    tsets = [set(plan.shard(r)[2].tolist()) for r in range(world)]
+    assert all(not (tsets[a] & tsets[b]) for a in range(world) for b in range(a + 1, world)), "a target straddles ranks"
+    for r in range(world):
+        assert np.array_equal(plan.shard_weights(r), w[plan.shard(r)[0]])
+    # heavy-first launch order inside a shard: XCD run x holds weight ranks x, x + 8, ...: every run starts with its heaviest
+    sw = plan.shard_weights(0)
+    order, inv = sharding.pair_launch_order(sw)
+    assert np.array_equal(order[inv], np.arange(len(sw))) and np.array_equal(np.sort(order), np.arange(len(sw)))
+    runs = np.array_split(order, 8) if len(sw) % 8 == 0 else None
+    if runs is not None:
+        for run in runs:
+            assert np.all(np.diff(sw[run]) <= 1e-12), "a run must be in descending weight"
+        assert max(sw[run].sum() for run in runs) < 1.05 * min(sw[run].sum() for run in runs)
+
+
+def test_predicted_pair_cost_grows_with_the_predicted_offset():
+    poses = np.zeros((6, 3))
+    poses[:, 0] = [0.0, 0.5, 1.5, 2.5, 3.5, 3.5]
+    poses[5, 2] = 1.0   # heading does not enter
+    c = sharding.predicted_pair_cost(poses, [1, 2, 3, 4, 5], [0, 0, 0, 0, 0])
+    assert np.all(np.diff(c[:4]) > 0) and c[3] == c[4] and 1.0 <= c[0] < 1.1 and 3.5 < c[3] < 6.0

@@ -8,7 +8,7 @@ libs = sorted(glob.glob(os.path.join(ROOT, "build", "variants", "libbnb_*.so")))
 res = {}
 for r in range(rounds):
     for lp in libs:
-      for order in ("0", "1"):  # by-target launch order / heaviest first
+      for order in ("0",):  # ("0", "1"): by-target launch order / heaviest first
         p = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bnb_quick.py")],
                            env=dict(os.environ, NHIP_LIB=lp, NHIP_QUICK_ORDER=order), stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
         name = os.path.basename(lp)[6:-3] + ("+lpt" if order == "1" else "")

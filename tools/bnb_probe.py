@@ -38,6 +38,7 @@ for bits in (8, 16):
                                            "frac": ev / max(tot, 1), "whole_per_pair": lv["blocks_whole"] / 3 / m.n_pairs,
                                            "refined_per_pair": lv["candidates_refined"] / 3 / m.n_pairs,
                                            "sub_blocks_per_pair": lv["sub_blocks"] / 3 / m.n_pairs,
+                                           "pose_evals16_per_pair": lv["pose_evals16"] / 3 / m.n_pairs,
                                            "clk_per_pair": {k_: v_ / 3 / m.n_pairs for k_, v_ in lv.items() if k_.startswith("clk_")},
                                            "pairs_handed_over": lv["pairs_handed_over"] / 3}
     m.free_grids()
