@@ -374,7 +374,7 @@ typedef struct nhip_csm_params {
   double high_res;      /* ctor arg 4 (0.01) */
   double sigma;         /* blur sigma in cells (2.0) */
   double floor_p;       /* likelihood floor (1e-10) */
-  int32_t cell_bits;    /* 8 or 16 (0 = 16: scores within 1e-5 of an unquantised table) */
+  int32_t cell_bits;    /* 16 or 8 (0 = 16, as in nhip_grid_spec_t: scores within 1e-5 of an unquantised table) */
   int32_t reserved;
 } nhip_csm_params_t;
 int nhip_csm_get_transformation(const nhip_csm_params_t *params, const float *pc_a, int32_t n_a, const float *pc_b,

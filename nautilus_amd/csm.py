@@ -19,9 +19,10 @@ MATCH_DTYPE = np.dtype([("itheta", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("score
 assert MATCH_DTYPE.itemsize == C.sizeof(Match) == 16
 
 
-def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, cell_bits=8, skip_map=False):
-    """cell_bits: 8 (255 quantisation steps over [ln floor_p, 0]) or 16 (65535 steps: scores within 1e-5 of an
-    unquantised table).  skip_map: 16-bit grids carry a skip map too (only the kernel that performs
+def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, cell_bits=16, skip_map=False):
+    """cell_bits: 16 (the default everywhere: 65535 quantisation steps over [ln floor_p, 0], scores within 1e-5 of an
+    unquantised table) or 8 (255 steps, scores within 1e-3: the explicit opt-in for callers that
+    only gate on a threshold).  skip_map: 16-bit grids carry a skip map too (only the kernel that performs
     every add reads it; LikelihoodGrids builds a missing one the first time such a search needs it)."""
     return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(max_shift), int(cell_bits),
                     _lib.NHIP_GRID_SKIP_MAP if skip_map else 0, 0)

@@ -47,14 +47,14 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   NHIP_REQUIRE(spec->floor_p > 0 && spec->floor_p < 1, "grid spec: floor_p must be in (0, 1)");
   NHIP_REQUIRE(spec->max_shift >= 0 && spec->max_shift <= 4096, "grid spec: max_shift out of range");
   NHIP_REQUIRE(spec->cell_bits == 0 || spec->cell_bits == 8 || spec->cell_bits == 16,
-               "grid spec: cell_bits must be 8 or 16 (0 = 8), got %d", spec->cell_bits);
+               "grid spec: cell_bits must be 8 or 16 (0 = 16), got %d", spec->cell_bits);
   NHIP_REQUIRE((spec->flags & ~NHIP_GRID_SKIP_MAP) == 0 && spec->reserved == 0, "grid spec: unknown flags %d / reserved %d",
                spec->flags, spec->reserved);
   const double side = floor((spec->range * 2.0) / spec->res);  // cimg_debug.h:21-22
   NHIP_REQUIRE(side >= 1 && side <= 16384, "grid spec: side %g out of range [1, 16384]", side);
   L->S = (int32_t)side;
-  L->cb = spec->cell_bits == 16 ? 2 : 1;
-  L->levels = spec->cell_bits == 16 ? 65535 : 255;
+  L->cb = spec->cell_bits == 8 ? 1 : 2;  // (0 = the default: 16-bit cells, in every struct of the ABI)
+  L->levels = L->cb == 2 ? 65535 : 255;
   L->pad = ((2 * spec->max_shift + 16) + 3) & ~3;
   L->pitch = ((L->S + 2 * L->pad) * L->cb + 15) & ~15;
   L->R = (int32_t)ceil(3.0 * spec->sigma);
@@ -356,7 +356,7 @@ int nhip_match_to_transform(const nhip_match_t *m, const nhip_grid_spec_t *spec,
 }
 
 double nhip_score_from_sum(const nhip_grid_spec_t *spec, int64_t sum, int32_t n_points) {
-  const double Lf = log(spec->floor_p), step = -Lf / (spec->cell_bits == 16 ? 65535.0 : 255.0);
+  const double Lf = log(spec->floor_p), step = -Lf / (spec->cell_bits == 8 ? 255.0 : 65535.0);
   if (n_points <= 0) return Lf;
   const double t = step * (double)sum;
   const double u = t / (double)n_points;

@@ -81,7 +81,7 @@ class HipBackend:
                                          int(min_separation), _lib.ptr(flags)))
         return flags
 
-    def match(self, xy, offsets, pair_src, pair_tgt, theta0, cell_bits=8):
+    def match(self, xy, offsets, pair_src, pair_tgt, theta0, cell_bits=16):
         """Batched loop-closure scan matching (BASELINE config #2 lattice): (records, spec, search)."""
         from . import csm
         spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits)

@@ -44,7 +44,7 @@ class OracleBackend:
     def pair_gate(self, poses, candidates, max_range, min_separation):
         return O.pair_gate(poses, candidates, max_range, min_separation)
 
-    def match(self, xy, offsets, pair_src, pair_tgt, theta0, cell_bits=8):
+    def match(self, xy, offsets, pair_src, pair_tgt, theta0, cell_bits=16):
         from nautilus_amd import csm
         gs = O.grid_spec(30.0, 0.05, 2.0, 1e-10, cell_bits)
         ss = O.search_spec(61, 81, 81, math.radians(1.0))

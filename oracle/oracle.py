@@ -164,7 +164,7 @@ def _chk(rc, what):
         raise RuntimeError("oracle %s failed: %d" % (what, rc))
 
 
-def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, cell_bits=8):
+def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, cell_bits=16):
     return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(cell_bits), 0)
 
 
@@ -223,7 +223,7 @@ def csm_match_f64_batch(xy, offsets, pair_src, pair_tgt, theta0, gs, ss, probe=N
 
 
 def two_level_match(pc_a, pc_b, rot_a, rot_b, rot_restriction, scanner_range=30.0, trans_range=2.0, low_res=0.3,
-                    high_res=0.01, sigma=2.0, floor_p=1e-10, cell_bits=8):
+                    high_res=0.01, sigma=2.0, floor_p=1e-10, cell_bits=16):
     """(score, ((tx, ty), theta)) of the reference-shaped single-pair call (solver.cc:633-644)."""
     a = np.ascontiguousarray(pc_a, dtype=np.float32).reshape(-1, 2)
     b = np.ascontiguousarray(pc_b, dtype=np.float32).reshape(-1, 2)

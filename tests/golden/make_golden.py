@@ -63,7 +63,7 @@ def main():
     keep = sorted(set(src.tolist()) | set(ids))
     for i in keep:
         arrays["scan%d" % i] = bag.scans[i]
-    gs = O.grid_spec(30.0, 0.05, 2.0, 1e-10)
+    gs = O.grid_spec(30.0, 0.05, 2.0, 1e-10, 8)
     pairs = []
     for cfg in ({"n_theta": 61, "nx": 81, "ny": 81, "step_deg": 1.0}, {"n_theta": 9, "nx": 21, "ny": 13, "step_deg": 2.0}):
         ss = O.search_spec(cfg["n_theta"], cfg["nx"], cfg["ny"], math.radians(cfg["step_deg"]))
@@ -75,7 +75,7 @@ def main():
                           "iy": m.iy, "sum": m.sum, "score": m.score, "truth": [gx, gy, gth]})
     out["csm_pairs"] = pairs
     out["grid_sha256"] = {str(t): hashlib.sha256(O.grid_build(bag.scans[t], gs).tobytes()).hexdigest() for t in ids}
-    out["grid_spec"] = {"range": 30.0, "res": 0.05, "sigma": 2.0, "floor_p": 1e-10}
+    out["grid_spec"] = {"range": 30.0, "res": 0.05, "sigma": 2.0, "floor_p": 1e-10, "cell_bits": 8}
     np.savez_compressed(os.path.join(HERE, "golden_arrays.npz"), **arrays)
     json.dump(out, open(os.path.join(HERE, "golden.json"), "w"), indent=1)
     print("wrote golden.json (%d csm pairs) and golden_arrays.npz (%d arrays)" % (len(pairs), len(arrays)))

@@ -38,7 +38,7 @@ def test_struct_sizes_match_header():
 
 
 def test_grid_layout_follows_cimg_debug():
-    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40)
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=8)
     L = csm.grid_layout(spec)
     assert L.side == 1200 == O.grid_side(O.grid_spec(30.0, 0.05))  # floor(2*30/0.05), cimg_debug.h:21
     assert L.pad == 96 and L.pitch == 1392 and L.rows == 1392
@@ -52,7 +52,9 @@ def test_grid_layout_follows_cimg_debug():
     assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes and L.slot_bytes % 16 == 0
     assert L.hi_bytes == 0 and L.hi_pitch == 0
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
-    L16 = csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=16))
+    L16 = csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40))  # the default width: 16-bit cells (0 means 16 too)
+    zero = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=0)
+    assert csm.grid_layout(zero).cell_bytes == 2
     assert L16.cell_bytes == 2 and L16.pitch == 2 * 1392 and L16.rows == 1392 and L16.grid_bytes == 2 * 1392 * 1392
     assert L16.hi_pitch == 1392 and L16.hi_bytes == 1392 * 1392  # the plane of high bytes, at the 8-bit pitch
     assert L16.slot_bytes == L16.grid_bytes + L16.skip_bytes + L16.pool_bytes + L16.pool4_bytes + L16.hi_bytes
@@ -71,7 +73,7 @@ def test_bad_specs_are_rejected_with_message():
 
 def test_threshold_table_reproduces_direct_quantiser():
     """thr[k] <= V  <=>  q(V) >= k, against the oracle's direct libm quantiser on a 1-point grid."""
-    spec = csm.grid_spec(1.0, 0.05, 2.0, 1e-10, 2)
+    spec = csm.grid_spec(1.0, 0.05, 2.0, 1e-10, 2, cell_bits=8)
     L = csm.grid_layout(spec)
     taps = np.zeros(2 * L.blur_radius + 1, dtype=np.int32)
     thr = np.zeros(256, dtype=np.uint32)
@@ -79,7 +81,7 @@ def test_threshold_table_reproduces_direct_quantiser():
     assert taps.sum() == L.tap_sum and np.all(taps == taps[::-1]) and taps.argmax() == L.blur_radius
     assert np.all(np.diff(thr.astype(np.int64)) >= 0)
     # one hit in the middle of a 40x40 grid: V[r][c] = taps[i]*taps[j] exactly
-    g = O.grid_build(np.array([[0.01, 0.01]], dtype=np.float32), O.grid_spec(1.0, 0.05, 2.0, 1e-10))
+    g = O.grid_build(np.array([[0.01, 0.01]], dtype=np.float32), O.grid_spec(1.0, 0.05, 2.0, 1e-10, 8))
     R = L.blur_radius
     for i in range(-R, R + 1):
         for j in range(-R, R + 1):
@@ -132,7 +134,7 @@ def test_rot0_and_delta_tables():
 
 
 def test_score_from_sum_matches_oracle_formula():
-    spec = csm.grid_spec()
+    spec = csm.grid_spec(cell_bits=8)
     lib = _lib.load()
     Lf = math.log(1e-10)
     step = -Lf / 255.0

@@ -567,23 +567,28 @@ def skip_map_definition(stored, width=21):
     return (cnt > 0).astype(np.uint8)
 
 
-def test_zero_strip_skipping_changes_nothing(gpu, small_bag, monkeypatch):
-    """NHIP_CSM_DENSE=1 adds every strip, zero or not; the default leaves the all-zero ones out.
-    Records and integer sums must be identical (and equal the oracle's)."""
+@pytest.mark.parametrize("cell_bits", [16, 8])
+def test_zero_strip_skipping_changes_nothing(gpu, small_bag, monkeypatch, cell_bits):
+    """The kernels that perform every add (NHIP_SEARCH_EXHAUSTIVE): NHIP_CSM_DENSE=1 adds every strip, zero or not;
+    the default leaves the all-zero ones out through the skip map (16-bit grids: built late by the handle).  Records
+    and integer sums must be identical (and equal the oracle's)."""
     xy, off = csm.pack_scans(small_bag.scans)
     ids = np.array([3, 11], dtype=np.int32)
     src = np.array([5, 9, 14, 2, 30, 31], dtype=np.int32)
     slot = np.array([0, 1, 1, 0, 1, 0], dtype=np.int32)
     th0 = np.array([0.1, -0.3, 0.0, 2.0, 0.7, -1.2])
-    spec, search = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40), csm.search_spec(7, 81, 81, DEG)
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits)
+    search = csm.search_spec(7, 81, 81, DEG, exhaustive=True)
     st = csm.ScanTable(xy, off)
     grids = csm.LikelihoodGrids(st, ids, spec)
     m1, s1 = csm.match_pairs(st, grids, src, slot, th0, search)
+    if cell_bits == 16:
+        assert grids.skip_map(0).any(), "the first exhaustive search on 16-bit grids builds their skip maps"
     monkeypatch.setenv("NHIP_CSM_DENSE", "1")
     m2, s2 = csm.match_pairs(st, grids, src, slot, th0, search)
     monkeypatch.delenv("NHIP_CSM_DENSE")
     assert np.array_equal(s1, s2) and m1.tobytes() == m2.tobytes()
-    ospec = O.grid_spec(30.0, 0.05, 2.0, 1e-10)
+    ospec = O.grid_spec(30.0, 0.05, 2.0, 1e-10, cell_bits)
     ogr = O.grid_build_batch(xy, off, ids, ospec)
     want = O.csm_match_batch(xy, off, ogr, ospec, src, slot, th0, O.search_spec(7, 81, 81, DEG))
     assert np.array_equal(s1, want["sum"])

@@ -15,7 +15,8 @@ HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 G = json.load(open(os.path.join(HERE, "golden.json")))
 A = np.load(os.path.join(HERE, "golden_arrays.npz"))
 GS = O.grid_spec(**{"range_m": G["grid_spec"]["range"], "res": G["grid_spec"]["res"],
-                    "sigma": G["grid_spec"]["sigma"], "floor_p": G["grid_spec"]["floor_p"]})
+                    "sigma": G["grid_spec"]["sigma"], "floor_p": G["grid_spec"]["floor_p"],
+                    "cell_bits": G["grid_spec"].get("cell_bits", 8)})  # (the frozen vectors are 8-bit grids)
 
 
 def test_oracle_reproduces_dist_kats():
@@ -74,7 +75,7 @@ def test_hip_path_reproduces_csm_goldens(gpu):
     srcs = sorted({p["src"] for p in G["csm_pairs"]} | set(ids))
     index = {s: i for i, s in enumerate(srcs)}
     st = csm.ScanTable.from_list([A["scan%d" % s] for s in srcs])
-    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40)
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=8)
     grids = csm.LikelihoodGrids(st, [index[t] for t in ids], spec)
     for slot, t in enumerate(ids):
         assert hashlib.sha256(np.ascontiguousarray(grids.interior(slot)).tobytes()).hexdigest() == G["grid_sha256"][str(t)]

@@ -183,7 +183,7 @@ def test_jacobians_against_sympy():
 
 # ---------------------------------------------------------------- CSM oracle consistency
 def test_csm_argmax_is_first_maximum_of_volume(small_bag):
-    gs = O.grid_spec(30.0, 0.05, 2.0, 1e-10)
+    gs = O.grid_spec(30.0, 0.05, 2.0, 1e-10, 8)
     ss = O.search_spec(5, 9, 11, math.radians(2))
     g = O.grid_build(small_bag.scans[10], gs)
     vol = O.csm_scores(small_bag.scans[12], g, gs, 0.05, ss)
@@ -225,7 +225,7 @@ def test_csm_empty_and_outside():
 
 def test_csm_recovers_known_offset(small_bag):
     """Goldens (iii) of SURVEY 8c: synthetic pair with a known offset, answer within one cell / step."""
-    gs = O.grid_spec(30.0, 0.05, 2.0, 1e-10)
+    gs = O.grid_spec(30.0, 0.05, 2.0, 1e-10, 8)
     base = small_bag.scans[20]
     for (dx, dy, dth) in [(0.35, -0.20, math.radians(7)), (-0.6, 0.45, math.radians(-12))]:
         c, s = math.cos(-dth), math.sin(-dth)

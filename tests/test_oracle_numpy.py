@@ -14,9 +14,9 @@ import pytest
 from oracle import oracle as O
 
 
-def np_grid(points, range_m, res, sigma, floor_p):
+def np_grid(points, range_m, res, sigma, floor_p, levels=255):
     """hit raster -> exact integer separable blur (taps round(16384 g / sum g), R = ceil(3 sigma))
-    -> floor, ln, q = round((L - Lf) / step) in 8 bits."""
+    -> floor, ln, q = round((L - Lf) / step) in `levels` steps (255: 8-bit cells, 65535: 16-bit cells)."""
     S = int(math.floor((range_m * 2.0) / res))
     H = np.zeros((S, S), dtype=np.int64)
     for x, y in np.asarray(points, dtype=np.float32):
@@ -34,9 +34,9 @@ def np_grid(points, range_m, res, sigma, floor_p):
     V = np.apply_along_axis(lambda col: np.convolve(col, taps, mode="same"), 0, V)
     v = np.maximum(V.astype(np.float64) / (float(K) * float(K)), floor_p)
     Lf = math.log(floor_p)
-    step = -Lf / 255.0
+    step = -Lf / float(levels)
     q = np.floor((np.log(v) - Lf) / step + 0.5)
-    return np.clip(q, 0, 255).astype(np.uint8), K
+    return np.clip(q, 0, levels).astype(np.uint8 if levels == 255 else np.uint16), K
 
 
 def np_volume(points, grid, res, theta0, n_theta, nx, ny, theta_step, origin=(0, 0)):
@@ -78,9 +78,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("cell_bits", [16, 8])
 @pytest.mark.parametrize("case", CASES)
-def test_c_oracle_equals_numpy_restatement(case):
+def test_c_oracle_equals_numpy_restatement(case, cell_bits):
     range_m, res, sigma, floor_p, n_theta, nx, ny, step_deg, theta0, origin = case
+    levels = 65535 if cell_bits == 16 else 255
     rng = np.random.default_rng(int(range_m * 100 + nx))
     # an L-shaped wall + clutter + a few points outside the grid and one non-finite
     t = rng.uniform(0, 1, 60)
@@ -93,12 +95,12 @@ def test_c_oracle_equals_numpy_restatement(case):
     src = ((wall - shift) @ np.array([[c, -s], [s, c]]).T).astype(np.float32)
     src = np.concatenate([src, np.array([[np.nan, 0.0], [1e12, 1.0]], np.float32)])
 
-    gs = O.grid_spec(range_m, res, sigma, floor_p)
+    gs = O.grid_spec(range_m, res, sigma, floor_p, cell_bits)
     ss = O.search_spec(n_theta, nx, ny, math.radians(step_deg))
-    want_grid, K = np_grid(tgt, range_m, res, sigma, floor_p)
+    want_grid, K = np_grid(tgt, range_m, res, sigma, floor_p, levels)
     got_grid = np.asarray(O.grid_build(tgt, gs)).reshape(want_grid.shape)
-    assert np.array_equal(got_grid, want_grid)
-    assert want_grid.max() > 200 and (want_grid == 0).mean() > 0.5   # walls near 255, mostly floor
+    assert got_grid.dtype == want_grid.dtype and np.array_equal(got_grid, want_grid)
+    assert want_grid.max() > 0.78 * levels and (want_grid == 0).mean() > 0.5   # walls near the top level, mostly floor
 
     want_vol = np_volume(src, want_grid, res, theta0, n_theta, nx, ny, math.radians(step_deg), origin)
     got_vol = np.asarray(O.csm_scores(src, got_grid, gs, theta0, ss, origin)).reshape(n_theta, nx, ny)
@@ -110,4 +112,4 @@ def test_c_oracle_equals_numpy_restatement(case):
     assert (int(m.itheta), int(m.ix), int(m.iy)) == (k, ix, iy)
     assert int(m.sum) == int(want_vol.max())
     Lf = math.log(floor_p)
-    assert float(m.score) == Lf + (-Lf / 255.0 * float(want_vol.max())) / float(len(src))
+    assert float(m.score) == Lf + (-Lf / float(levels) * float(want_vol.max())) / float(len(src))
