@@ -315,11 +315,20 @@ int nhip_corr_compact_dev(const float *d_corr_padded, const int64_t *d_cap_offse
  * eigenvalue (closed form in double); one double per scan, NaN for an empty scan.
  * nhip_lc_pair_gate*: for n candidate nodes (indices into poses[n_poses][3]), flags[i*n + j] = 1 iff candidates i and
  * j are different nodes more than min_separation apart in index whose translations (as Vector2f) are closer than
- * max_range -- a geometric stand-in for LCMatcher's per-pair ceres::Covariance test (lc_matcher.cc:28-74). */
+ * max_range -- a geometric stand-in for LCMatcher's per-pair ceres::Covariance test (lc_matcher.cc:28-74).
+ * nhip_lc_chi_square_gate*: LCMatcher's own test given the covariance blocks -- for pair i, d = Vector2f(pose of
+ * pair_tgt[i]) - Vector2f(pose of pair_src[i]), scores[i] = d^T cov_i^-1 d evaluated in float as ChiSquareScore does
+ * (lc_matcher.cc:50-57; cov[i] = the Matrix2f of GetCovarianceMatrix, :28-46, row major m00 m01 m10 m11), widened to
+ * double; flags[i] = 1 iff pair_src[i] != pair_tgt[i] and scores[i] < max_score (GetPossibleMatches, :59-74, which
+ * passes 5000.0).  A singular block gives inf / NaN scores as the reference's inverse() does, and flag 0 for NaN.
+ * d_cov must be 16-byte aligned.  The covariance solve itself (ceres::Covariance) stays with the host's solver. */
 int nhip_lc_scatter_scores_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, double *d_scores,
                                void *stream);
 int nhip_lc_pair_gate_dev(const double *d_poses, const int32_t *d_candidates, int32_t n_candidates, double max_range,
                           int32_t min_separation, uint8_t *d_flags, void *stream);
+int nhip_lc_chi_square_gate_dev(const double *d_poses, const int32_t *d_pair_src, const int32_t *d_pair_tgt,
+                                const float *d_cov, int32_t n_pairs, double max_score, double *d_scores,
+                                uint8_t *d_flags, void *stream);
 
 /* ------------------------------------------------------------------ handle API (host pointers) */
 typedef struct nhip_scans nhip_scans_t;
@@ -358,6 +367,9 @@ int nhip_csm_scores(const nhip_scans_t *scans, const nhip_grids_t *grids, int32_
 int nhip_lc_scatter_scores(const nhip_scans_t *scans, double *scores /* n_scans */);
 int nhip_lc_pair_gate(const double *poses, int32_t n_poses, const int32_t *candidates, int32_t n_candidates,
                       double max_range, int32_t min_separation, uint8_t *flags /* n_candidates^2 */);
+int nhip_lc_chi_square_gate(const double *poses, int32_t n_poses, const int32_t *pair_src, const int32_t *pair_tgt,
+                            const float *cov /* n_pairs x 4 */, int32_t n_pairs, double max_score,
+                            double *scores /* n_pairs */, uint8_t *flags /* n_pairs */);
 
 /* The reference-shaped single-pair call: CorrelativeScanMatcher(scanner_range, trans_range, low_res, high_res)
  * .GetTransformation(pc_a, pc_b, rot_a, rot_b, rot_restriction) -> (score, ((tx, ty), theta))

@@ -109,6 +109,8 @@ PROTOTYPES = {
     "nhip_csm_scores": (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, _i32, _P(Search), _vp]),
     "nhip_lc_scatter_scores_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
     "nhip_lc_pair_gate_dev": (C.c_int, [_vp, _vp, _i32, _f64, _i32, _vp, _vp]),
+    "nhip_lc_chi_square_gate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
+    "nhip_lc_chi_square_gate": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _f64, _vp, _vp]),
     "nhip_lc_scatter_scores": (C.c_int, [_vp, _vp]),
     "nhip_lc_pair_gate": (C.c_int, [_vp, _i32, _vp, _i32, _f64, _i32, _vp]),
     "nhip_csm_get_transformation": (C.c_int, [_P(CsmParams), _vp, _i32, _vp, _i32, _f64, _f64, _f64, _P(_f64),

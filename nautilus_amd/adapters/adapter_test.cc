@@ -378,6 +378,19 @@ int main(int argc, char **argv) {
     ncclCommDestroy(comm);
     std::printf("allgather of 1000 match records over RCCL (1 rank): ok\n");
   }
+  // ---- LCMatcher::GetPossibleMatches (lc_matcher.cc:59-74) from a C++ host: one call for a source node's candidates
+  {
+    const double poses[4][3] = {{0.0, 0.0, 0.0}, {1.0, 0.0, 0.1}, {0.0, 30.0, 0.2}, {0.5, 0.5, 0.3}};
+    const int32_t src[4] = {0, 0, 0, 0}, tgt[4] = {0, 1, 2, 3};
+    const float cov[4][4] = {{1e-3f, 0, 0, 1e-3f}, {1e-3f, 0, 0, 1e-3f}, {1e-3f, 0, 0, 1e-3f}, {2e-3f, 1e-3f, 1e-3f, 2e-3f}};
+    double scores[4];
+    uint8_t flags[4];
+    REQUIRE(nhip_lc_chi_square_gate(&poses[0][0], 4, src, tgt, &cov[0][0], 4, 5000.0, scores, flags) == NHIP_OK);
+    REQUIRE(flags[0] == 0 && flags[1] == 1 && flags[2] == 0 && flags[3] == 1);      // self; 1000; 900000; 166.7
+    REQUIRE(std::fabs(scores[1] - 1000.0) < 0.5 && std::fabs(scores[2] - 900000.0) < 500.0 && std::fabs(scores[3] - 166.667) < 0.1);
+    REQUIRE(nhip_lc_chi_square_gate(&poses[0][0], 4, src, tgt, nullptr, 4, 5000.0, scores, flags) == NHIP_ERR_ARG);
+    std::printf("chi-square gate of 4 candidates: ok\n");
+  }
   if (results) std::fclose(results);
   std::printf("ADAPTER_OK\n");
   return 0;

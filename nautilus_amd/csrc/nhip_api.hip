@@ -801,6 +801,46 @@ int nhip_lc_pair_gate_dev(const double *d_poses, const int32_t *d_candidates, in
                              static_cast<hipStream_t>(stream));
 }
 
+int nhip_lc_chi_square_gate_dev(const double *d_poses, const int32_t *d_pair_src, const int32_t *d_pair_tgt,
+                                const float *d_cov, int32_t n_pairs, double max_score, double *d_scores,
+                                uint8_t *d_flags, void *stream) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || (d_poses && d_pair_src && d_pair_tgt && d_cov && d_scores && d_flags)),
+               "lc_chi_square_gate_dev: bad arguments");
+  NHIP_REQUIRE((reinterpret_cast<uintptr_t>(d_cov) & 15) == 0, "lc_chi_square_gate_dev: d_cov must be 16-byte aligned");
+  return launch_lc_chi_square(d_poses, d_pair_src, d_pair_tgt, d_cov, n_pairs, max_score, d_scores, d_flags,
+                              static_cast<hipStream_t>(stream));
+}
+
+int nhip_lc_chi_square_gate(const double *poses, int32_t n_poses, const int32_t *pair_src, const int32_t *pair_tgt,
+                            const float *cov, int32_t n, double max_score, double *scores, uint8_t *flags) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(n >= 0 && n_poses >= 0 && (n == 0 || (poses && pair_src && pair_tgt && cov && scores && flags)),
+               "lc_chi_square_gate: bad arguments");
+  for (int32_t i = 0; i < n; i++)
+    NHIP_REQUIRE(pair_src[i] >= 0 && pair_src[i] < n_poses && pair_tgt[i] >= 0 && pair_tgt[i] < n_poses,
+                 "lc_chi_square_gate: pair %d (%d, %d) out of range", i, pair_src[i], pair_tgt[i]);
+  if (n == 0) return NHIP_OK;
+  const size_t N = (size_t)n;
+  DevBuf dp, ds, dt, dc, dsc, df;
+  if ((rc = dp.alloc(sizeof(double) * 3 * (size_t)n_poses)) || (rc = ds.alloc(4 * N)) || (rc = dt.alloc(4 * N)) ||
+      (rc = dc.alloc(16 * N)) || (rc = dsc.alloc(8 * N)) || (rc = df.alloc(N)))
+    return rc;
+  NHIP_TRY_HIP(hipMemcpy(dp.p, poses, sizeof(double) * 3 * (size_t)n_poses, hipMemcpyHostToDevice));
+  NHIP_TRY_HIP(hipMemcpy(ds.p, pair_src, 4 * N, hipMemcpyHostToDevice));
+  NHIP_TRY_HIP(hipMemcpy(dt.p, pair_tgt, 4 * N, hipMemcpyHostToDevice));
+  NHIP_TRY_HIP(hipMemcpy(dc.p, cov, 16 * N, hipMemcpyHostToDevice));
+  rc = launch_lc_chi_square(static_cast<const double *>(dp.p), static_cast<const int32_t *>(ds.p),
+                            static_cast<const int32_t *>(dt.p), static_cast<const float *>(dc.p), n, max_score,
+                            static_cast<double *>(dsc.p), static_cast<uint8_t *>(df.p), nullptr);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(scores, dsc.p, 8 * N, hipMemcpyDeviceToHost));
+  NHIP_TRY_HIP(hipMemcpy(flags, df.p, N, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
 int nhip_lc_scatter_scores(const nhip_scans_t *scans, double *scores) {
   int rc = require_device();
   if (rc) return rc;

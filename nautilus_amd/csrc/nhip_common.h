@@ -170,6 +170,8 @@ int launch_corr_compact(const float *d_corr_padded, const int64_t *d_cap_offsets
                         float *d_corr, int32_t *d_corr_block, hipStream_t s);
 
 int launch_lc_scatter_scores(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, double *d_scores, hipStream_t s);
+int launch_lc_chi_square(const double *d_poses, const int32_t *d_src, const int32_t *d_tgt, const float *d_cov, int32_t n,
+                         double max_score, double *d_scores, uint8_t *d_flags, hipStream_t s);
 int launch_lc_pair_gate(const double *d_poses, const int32_t *d_cand, int32_t n, double max_range, int32_t min_sep,
                         uint8_t *d_flags, hipStream_t s);
 

@@ -7,6 +7,10 @@
 //   lc_pair_gate_kernel       a geometric gate over all ordered candidate pairs, in place of the per-pair
 //                             ceres::Covariance + chi-square test of LCMatcher (src/loop_closure/lc_matcher.cc:28-74),
 //                             whose cost is a sparse factorisation per pair.
+//   lc_chi_square_kernel      LCMatcher's own test given the cross-covariance blocks: ChiSquareScore and the
+//                             `score < 5000` acceptance of GetPossibleMatches (lc_matcher.cc:50-74) for every
+//                             (source, candidate) pair at once.  The covariance blocks themselves come from the
+//                             host's sparse solve (ceres::Covariance in the reference, :28-46).
 //
 // The reference sums in float, in point order (Eigen::Vector2f / Matrix2f accumulators).  One lane per scan walks
 // its points in that order with individually rounded float operations, so the sums are the reference's bit for bit
@@ -70,7 +74,38 @@ __global__ __launch_bounds__(256) void lc_pair_gate_kernel(const double *__restr
   flags[t] = (a != b && sep > min_sep && dist < max_range) ? 1 : 0;
 }
 
+// ChiSquareScore (lc_matcher.cc:50-57): d = Vector2f(target) - Vector2f(source), score = d^T * cov.inverse() * d in
+// float, widened to double.  Eigen's fixed-size 2 x 2 inverse is the closed form (adjugate times 1 / determinant,
+// determinant m00 m11 - m10 m01); the product is (d^T inv) first, then the dot with d -- each float operation rounded
+// on its own, as the expression templates evaluate them on baseline x86-64.
+__global__ __launch_bounds__(256) void lc_chi_square_kernel(const double *__restrict__ poses, const int32_t *__restrict__ src,
+                                                            const int32_t *__restrict__ tgt, const float *__restrict__ cov,
+                                                            int32_t n, double max_score, double *__restrict__ scores,
+                                                            uint8_t *__restrict__ flags) {
+  const int32_t t = blockIdx.x * 256 + threadIdx.x;
+  if (t >= n) return;
+  const int32_t a = src[t], b = tgt[t];
+  const float4 m = reinterpret_cast<const float4 *>(cov)[t];  // row major: m00 m01 m10 m11
+  const float d0 = __fsub_rn((float)poses[3 * b], (float)poses[3 * a]), d1 = __fsub_rn((float)poses[3 * b + 1], (float)poses[3 * a + 1]);
+  const float det = __fsub_rn(__fmul_rn(m.x, m.w), __fmul_rn(m.z, m.y));
+  const float invdet = __fdiv_rn(1.0f, det);
+  const float i00 = __fmul_rn(m.w, invdet), i10 = __fmul_rn(-m.z, invdet), i01 = __fmul_rn(-m.y, invdet), i11 = __fmul_rn(m.x, invdet);
+  const float r0 = __fadd_rn(__fmul_rn(d0, i00), __fmul_rn(d1, i10)), r1 = __fadd_rn(__fmul_rn(d0, i01), __fmul_rn(d1, i11));
+  const double score = (double)__fadd_rn(__fmul_rn(r0, d0), __fmul_rn(r1, d1));
+  scores[t] = score;
+  flags[t] = (a != b && score < max_score) ? 1 : 0;  // `match.node_idx == source.node_idx` is skipped (:64-66); NaN fails
+}
+
 }  // namespace
+
+int launch_lc_chi_square(const double *d_poses, const int32_t *d_src, const int32_t *d_tgt, const float *d_cov, int32_t n,
+                         double max_score, double *d_scores, uint8_t *d_flags, hipStream_t s) {
+  if (n == 0) return NHIP_OK;
+  hipLaunchKernelGGL(lc_chi_square_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_poses, d_src, d_tgt, d_cov, n, max_score,
+                     d_scores, d_flags);
+  NHIP_TRY_HIP(hipGetLastError());
+  return NHIP_OK;
+}
 
 int launch_lc_scatter_scores(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, double *d_scores, hipStream_t s) {
   if (n_scans == 0) return NHIP_OK;

@@ -84,13 +84,19 @@ def chi_square_score(cov2x2, source_xy, target_xy):
     return float(d @ np.linalg.inv(cov) @ d)
 
 
-def lc_possible_matches(source, candidates, poses, covariance_fn, max_score=5000.0):
+def lc_possible_matches(source, candidates, poses, covariance_fn, max_score=5000.0, backend=None):
     """GetPossibleMatches (lc_matcher.cc:59-74): every other candidate whose chi-square score against
-    `source` is below 5000.  covariance_fn(pairs) -> (n, 2, 2) float32 (PoseGraph.cross_covariances)."""
+    `source` is below 5000.  covariance_fn(pairs) -> (n, 2, 2) float32 (PoseGraph.cross_covariances).
+    With a backend the scores and flags of all pairs come from one call of its chi_square_gate (product:
+    nhip_lc_chi_square_gate); without one they are taken pair by pair with chi_square_score, the numpy statement
+    of the same test that the backend is checked against in tests/."""
     others = [c for c in candidates if c != source]
     if not others:
         return []
     cov = covariance_fn([(source, c) for c in others])
+    if backend is not None:
+        _, flags = backend.chi_square_gate(poses, [source] * len(others), others, cov, max_score)
+        return [c for c, f in zip(others, flags) if f]
     out = []
     for c, m in zip(others, cov):
         if chi_square_score(m, poses[source][:2], poses[c][:2]) < max_score:

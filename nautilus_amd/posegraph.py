@@ -81,6 +81,20 @@ class HipBackend:
                                          int(min_separation), _lib.ptr(flags)))
         return flags
 
+    def chi_square_gate(self, poses, pair_src, pair_tgt, cov, max_score=5000.0):
+        """LCMatcher's chi-square test of n (source, candidate) pairs given their cross-covariance blocks
+        (nhip_lc_chi_square_gate; lc_matcher.cc:50-74): (scores float64, flags uint8)."""
+        P = np.ascontiguousarray(poses, dtype=np.float64)
+        src = np.ascontiguousarray(pair_src, dtype=np.int32)
+        tgt = np.ascontiguousarray(pair_tgt, dtype=np.int32)
+        cov = np.ascontiguousarray(cov, dtype=np.float32).reshape(-1, 4)
+        if not len(cov) == len(src) == len(tgt):
+            raise ValueError("chi_square_gate: one covariance block per pair")
+        scores, flags = np.zeros(len(src)), np.zeros(len(src), dtype=np.uint8)
+        check(self.lib.nhip_lc_chi_square_gate(_lib.ptr(P), len(P), _lib.ptr(src), _lib.ptr(tgt), _lib.ptr(cov), len(src),
+                                               float(max_score), _lib.ptr(scores), _lib.ptr(flags)))
+        return scores, flags
+
     def match(self, xy, offsets, pair_src, pair_tgt, theta0, cell_bits=16):
         """Batched loop-closure scan matching (BASELINE config #2 lattice): (records, spec, search)."""
         from . import csm

@@ -44,6 +44,9 @@ class OracleBackend:
     def pair_gate(self, poses, candidates, max_range, min_separation):
         return O.pair_gate(poses, candidates, max_range, min_separation)
 
+    def chi_square_gate(self, poses, pair_src, pair_tgt, cov, max_score=5000.0):
+        return O.chi_square_gate(poses, pair_src, pair_tgt, cov, max_score)
+
     def match(self, xy, offsets, pair_src, pair_tgt, theta0, cell_bits=16):
         from nautilus_amd import csm
         gs = O.grid_spec(30.0, 0.05, 2.0, 1e-10, cell_bits)

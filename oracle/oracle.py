@@ -155,6 +155,21 @@ def pair_gate(poses, candidates, max_range, min_separation):
     return flags
 
 
+def chi_square_gate(poses, pair_src, pair_tgt, cov, max_score=5000.0):
+    """(scores float64, flags uint8) of LCMatcher's chi-square test for n (source, candidate) pairs
+    (lc_matcher.cc:50-74); cov: (n, 2, 2) float32 cross-covariance blocks."""
+    poses = np.ascontiguousarray(poses, dtype=np.float64)
+    src = np.ascontiguousarray(pair_src, dtype=np.int32)
+    tgt = np.ascontiguousarray(pair_tgt, dtype=np.int32)
+    cov = np.ascontiguousarray(cov, dtype=np.float32).reshape(-1, 4)
+    assert len(cov) == len(src) == len(tgt)
+    scores, flags = np.zeros(len(src)), np.zeros(len(src), dtype=np.uint8)
+    fn = load().orc_chi_square_gate
+    fn.argtypes, fn.restype = [_vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp], None
+    fn(_p(poses), _p(src), _p(tgt), _p(cov), len(src), float(max_score), _p(scores), _p(flags))
+    return scores, flags
+
+
 def _p(a):
     return None if a is None else a.ctypes.data_as(_vp)
 

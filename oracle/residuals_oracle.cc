@@ -639,4 +639,29 @@ void orc_pair_gate(const double *poses, const int32_t *cand, int32_t n, double m
     }
 }
 
+// LCMatcher::ChiSquareScore + the acceptance of GetPossibleMatches (src/loop_closure/lc_matcher.cc:50-74) for n
+// (source, candidate) pairs: cov[i] is the Matrix2f GetCovarianceMatrix returned (row major), the translations are
+// Vector2f (slam_util.h:48-53).  Eigen is not in the image: Matrix2f::inverse() is restated as its published
+// fixed-size closed form (Eigen/src/LU/InverseImpl.h, compute_inverse<_, _, 2>: adjugate times 1 / (m00 m11 - m10 m01)),
+// and d^T * inv * d as the row vector (d^T inv) dotted with d -- float operations rounded one by one
+// (-ffp-contract=off).
+void orc_chi_square_gate(const double *poses, const int32_t *src, const int32_t *tgt, const float *cov, int32_t n,
+                         double max_score, double *scores, uint8_t *flags) {
+  for (int32_t t = 0; t < n; t++) {
+    const int32_t a = src[t], b = tgt[t];
+    const float *m = cov + 4 * (size_t)t;
+    const float d0 = (float)poses[3 * b] - (float)poses[3 * a], d1 = (float)poses[3 * b + 1] - (float)poses[3 * a + 1];
+    const float p0 = m[0] * m[3], p1 = m[2] * m[1];
+    const float det = p0 - p1;
+    const float invdet = 1.0f / det;
+    const float i00 = m[3] * invdet, i10 = -m[2] * invdet, i01 = -m[1] * invdet, i11 = m[0] * invdet;
+    const float a0 = d0 * i00, a1 = d1 * i10, b0 = d0 * i01, b1 = d1 * i11;
+    const float r0 = a0 + a1, r1 = b0 + b1;
+    const float c0 = r0 * d0, c1 = r1 * d1;
+    const double score = (double)(c0 + c1);
+    scores[t] = score;
+    flags[t] = (a != b && score < max_score) ? 1 : 0;
+  }
+}
+
 }  // extern "C"

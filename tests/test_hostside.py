@@ -54,6 +54,38 @@ def test_chi_square_gate_mirrors_lc_matcher():
     assert hostside.lc_possible_matches(2, [2], poses, provider) == []
 
 
+def test_chi_square_gate_oracle_against_the_numpy_statement(chi_square_cases):
+    """oracle.chi_square_gate (ChiSquareScore + the acceptance of GetPossibleMatches, lc_matcher.cc:50-74, with
+    Matrix2f::inverse() restated in closed form) against hostside.chi_square_score, which inverts with LAPACK: the same
+    scores to float rounding of a 2 x 2 inverse, the same accept decisions away from the threshold."""
+    import numpy as np
+    from nautilus_amd import hostside
+    from oracle import oracle as O
+    poses, src, tgt, cov = chi_square_cases
+    scores, flags = O.chi_square_gate(poses, src, tgt, cov, 5000.0)
+    assert not flags[:8].any()
+    assert not np.isfinite(scores[40:48]).all()
+    assert not flags[48:56].any()                                  # 0 * inf = NaN never passes `score < 5000`
+    ok = 0
+    for i in range(56, len(src), 7):
+        want = hostside.chi_square_score(cov[i], poses[src[i], :2], poses[tgt[i], :2])
+        cond = np.linalg.cond(cov[i].astype(np.float64))
+        assert abs(scores[i] - want) <= 4e-6 * cond * abs(want) + 1e-6, (i, scores[i], want, cond)
+        if abs(want - 5000.0) > 1e-3 * cond * 5000.0:
+            assert bool(flags[i]) == (want < 5000.0 and src[i] != tgt[i])
+            ok += 1
+    assert ok > 300 and 0 < flags.sum() < len(flags)
+    # hand-checked values: identity-like covariance, d = (1, 2): (1 + 4) / 0.01
+    s, f = O.chi_square_gate([[0, 0, 0], [1, 2, 0]], [0, 0], [1, 0], np.stack([np.eye(2) * 0.01] * 2), 5000.0)
+    assert abs(s[0] - 500.0) < 1e-3 and f.tolist() == [1, 0]
+    # lc_possible_matches through a backend gives what the pair-by-pair numpy walk gives
+    from oracle.cpu_backend import OracleBackend
+    P = np.array([[0.0, 0.0, 0.0], [1.0, 0.0, 0.1], [0.0, 30.0, 0.2], [0.5, 0.5, 0.3]])
+    table = {(0, 1): np.eye(2) * 1e-3, (0, 2): np.eye(2) * 1e-3, (0, 3): np.array([[2e-3, 1e-3], [1e-3, 2e-3]])}
+    provider = lambda pairs: np.stack([table[p] for p in pairs]).astype(np.float32)
+    assert hostside.lc_possible_matches(0, [0, 1, 2, 3], P, provider, backend=OracleBackend()) == [1, 3]
+
+
 def test_hitl_relevant_poses_mirror_get_relevant_poses_for_hitl():
     """GetRelevantPosesForHITL (solver.cc:479-513): float world points, DistanceToLineSegment<float> <= 0.05, a point
     on line a is not tested against line b, a pose needs 10 points and joins a before b."""

@@ -55,3 +55,29 @@ def test_pair_gate_and_candidate_walk(gpu):
     # the reference's own threshold (0.70) keeps fewer scans: most scans of this 24 m x 16 m room score ~0.4
     strict = hostside.lc_candidates_from_scores(bag.odom, scores)
     assert len(strict) < len(cand) and all(scores[i] >= 0.70 for i in strict)
+
+
+def test_chi_square_gate_bit_exact(gpu, chi_square_cases):
+    """nhip_lc_chi_square_gate (host-pointer and device-pointer forms) against the oracle's restatement of
+    ChiSquareScore / GetPossibleMatches (lc_matcher.cc:50-74) on 4,000 pairs with covariance blocks of every
+    conditioning, singular and zero blocks included: scores equal as bit patterns (NaN and inf too), flags equal."""
+    import ctypes as C
+    import torch
+    poses, src, tgt, cov = chi_square_cases
+    be = posegraph.HipBackend()
+    want_s, want_f = O.chi_square_gate(poses, src, tgt, cov, 5000.0)
+    got_s, got_f = be.chi_square_gate(poses, src, tgt, cov, 5000.0)
+    assert got_s.tobytes() == want_s.tobytes() and got_f.tobytes() == want_f.tobytes()
+    assert 0 < got_f.sum() < len(got_f) and np.isnan(got_s).any()
+    dev = torch.device("cuda:0")
+    d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (poses, src, tgt, cov.reshape(-1, 4))]
+    d_s, d_f = torch.empty(len(src), dtype=torch.float64, device=dev), torch.empty(len(src), dtype=torch.uint8, device=dev)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(_lib.load().nhip_lc_chi_square_gate_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+                                                      len(src), 100.0, d_s.data_ptr(), d_f.data_ptr(), sp))
+    w_s, w_f = O.chi_square_gate(poses, src, tgt, cov, 100.0)
+    assert d_s.cpu().numpy().tobytes() == w_s.tobytes() and d_f.cpu().numpy().tobytes() == w_f.tobytes()
+    # argument checks: a pair outside the pose table is refused before anything is launched
+    with pytest.raises(_lib.NhipError):
+        be.chi_square_gate(poses, [0], [300], cov[:1])
+    assert be.chi_square_gate(poses, [], [], np.zeros((0, 2, 2), np.float32))[0].size == 0

@@ -76,5 +76,7 @@ def test_cross_covariance_blocks_match_dense_inverse(gpu):
         assert np.allclose(g, want, rtol=1e-4, atol=1e-9)
     matches = hostside.lc_possible_matches(30, [5, 12, 30, 39], pg.poses, pg.cross_covariances)
     assert 30 not in matches and set(matches) <= {5, 12, 39}
+    # the same walk with the scores taken on the GPU (nhip_lc_chi_square_gate) keeps the same scans
+    assert hostside.lc_possible_matches(30, [5, 12, 30, 39], pg.poses, pg.cross_covariances, backend=pg.backend) == matches
     s = hostside.chi_square_score(np.eye(2) * 0.01, [0.0, 0.0], [1.0, 2.0])
     assert abs(s - 500.0) < 1e-2
