@@ -282,6 +282,38 @@ def _cpu_info():
     return {"cpu_model": model, "hw_threads": threads or os.cpu_count(), "physical_cores": len(phys) or None}
 
 
+def _effective_cpus():
+    """CPUs this process may actually use: the affinity mask, capped by the cgroup's CPU quota when one is set (a GPU
+    box hands a one-GPU job a share of the host's cores; threads beyond the share only time-slice)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except Exception:
+        n = os.cpu_count() or 1
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:
+            continue
+    if quota is not None:
+        n = max(1, min(n, int(math.ceil(quota))))
+    return n, quota
+
+
+def _omp_threads():
+    """Threads for the CPU legs: the oracle's OpenMP default, capped by the CPUs this process may use."""
+    from oracle import oracle as O
+    return max(1, min(O.num_threads(), _effective_cpus()[0]))
+
+
 def kernel_source_hash():
     """sha256 over nautilus_amd/csrc (the same recipe as tools/make_traffic_json.py)."""
     import glob
@@ -680,7 +712,8 @@ def cpu_baseline(wl, shard, got, got_sums, budget_s, cell_bits):
     idx, src, tgt, th0, ids, slot = shard
     ospec = O.grid_spec(cell_bits=cell_bits)
     oss = O.search_spec(61, 81, 81, math.radians(1.0))
-    threads = O.num_threads()
+    quota = _effective_cpus()[1]
+    threads = _omp_threads()
     t0 = time.perf_counter()
     g0 = O.grid_build_batch(wl.xy, wl.off, ids[:1], ospec, 1)
     O.csm_match_batch(wl.xy, wl.off, g0, ospec, src[:1], np.zeros(1, np.int32), th0[:1], oss, None, 1)
@@ -696,6 +729,7 @@ def cpu_baseline(wl, shard, got, got_sums, budget_s, cell_bits):
     del gp
     per_run = budget_s / 7.0
     n_targets = int(max(n_probe, n_probe * per_run / max(t_probe, 1e-3)))
+    n_targets = max(n_targets, -(-20 * threads // per_target))  # at least 20 pairs per thread: load balance, warm caches
     n_targets = min(n_targets, len(ids), 400)  # oracle grids are 1.44 / 2.88 MB each, keep host memory small
     sel = np.nonzero(slot < n_targets)[0]
     state = {}
@@ -718,7 +752,8 @@ def cpu_baseline(wl, shard, got, got_sums, budget_s, cell_bits):
                     "oracle C restatement, OpenMP over pairs; median of 5 timed runs after 1 warm-up"
                     % (len(sel), n_targets, state["t_grid"], state["t_match"]),
           "runs_s": ts, "single_thread_pairs_per_s": 1.0 / max(t_one, 1e-9),
-          "omp_threads": threads, "physical_cores": info["physical_cores"], "hw_threads": info["hw_threads"],
+          "omp_threads": threads, "pairs_per_thread": len(sel) / threads, "cgroup_cpu_quota": quota,
+          "physical_cores": info["physical_cores"], "hw_threads": info["hw_threads"],
           "build_flags": "-O3 -fopenmp -DNDEBUG (the reference's CMakeLists.txt:16), -ffp-contract=off",
           "cpu_model": info["cpu_model"]}
     return cb, bool(ok)
@@ -746,7 +781,7 @@ def bench_drop_in(bag, with_cpu, calls=8):
            "seconds_per_call": dt, "calls_per_s": 1.0 / dt, "each_call_s": each}
     if with_cpu:
         from oracle import oracle as O
-        threads = O.num_threads()
+        threads = _omp_threads()
         t0 = time.perf_counter()
         want = O.two_level_match(*args(*pairs[0]), 30.0, 2.0, 0.3, 0.01, cell_bits=16)
         dc = time.perf_counter() - t0
@@ -859,19 +894,19 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
         # ceres::AutoDiffCostFunction does per block) and the closed-form Jacobians, blocks across OpenMP
         # threads like Ceres' num_threads.
         from oracle import oracle as O
-        k = min(n_blocks, 8 * O.num_threads())
+        k = min(n_blocks, 8 * _omp_threads())
         h_corr = corr[:k * n_per].cpu().numpy()
         h_off = np.arange(k + 1, dtype=np.int32) * n_per
         h_bs, h_bt, h_poses = bs[:k].cpu().numpy(), bt[:k].cpu().numpy(), poses.cpu().numpy()
-        med, ts, (wr, w0, w1) = _median_runs(lambda: O.lidar_batch(0, h_corr, h_off, h_bs, h_bt, h_poses, True, O.num_threads()))
+        med, ts, (wr, w0, w1) = _median_runs(lambda: O.lidar_batch(0, h_corr, h_off, h_bs, h_bt, h_poses, True, _omp_threads()))
         ok = bool(np.allclose(res[:2 * k * n_per].cpu().numpy(), wr, rtol=1e-9, atol=1e-9) and
                   np.allclose(js[:6 * k * n_per].cpu().numpy().reshape(-1, 3), w0, rtol=1e-9, atol=1e-8))
-        out["cpu_baseline"] = {"value": k * n_per / med, "unit": "correspondences/s", "cores": O.num_threads(), "kind": "port",
+        out["cpu_baseline"] = {"value": k * n_per / med, "unit": "correspondences/s", "cores": _omp_threads(), "kind": "port",
                                "sample": "%d blocks x %d, Jet<6> autodiff restatement, OpenMP over blocks; median of 5" % (k, n_per),
                                "gpu_matches_oracle_on_sample": ok}
-        med_a, _, (ar, a0, a1) = _median_runs(lambda: O.lidar_batch(0, h_corr, h_off, h_bs, h_bt, h_poses, True, O.num_threads(), analytic=True))
+        med_a, _, (ar, a0, a1) = _median_runs(lambda: O.lidar_batch(0, h_corr, h_off, h_bs, h_bt, h_poses, True, _omp_threads(), analytic=True))
         med_1, _, _ = _median_runs(lambda: O.lidar_batch(0, h_corr[:8 * n_per], h_off[:9], h_bs[:8], h_bt[:8], h_poses, True, 1, analytic=True), 3)
-        out["cpu_baseline_analytic"] = {"value": k * n_per / med_a, "unit": "correspondences/s", "cores": O.num_threads(),
+        out["cpu_baseline_analytic"] = {"value": k * n_per / med_a, "unit": "correspondences/s", "cores": _omp_threads(),
                                         "kind": "port", "single_thread_value": 8 * n_per / med_1,
                                         "sample": "same blocks, closed-form Jacobians (SURVEY 8a), OpenMP over blocks; median of 5",
                                         "matches_autodiff": bool(np.allclose(a0, w0, rtol=1e-9, atol=1e-9) and np.allclose(a1, w1, rtol=1e-9, atol=1e-9))}
@@ -970,7 +1005,7 @@ def bench_residuals_feature(torch, lib, dev, with_cpu, evals=20):
                                                    "bytes_out_per_evaluation": 2 * 9945 * 224}
     if with_cpu:
         from oracle import oracle as O
-        thr = O.num_threads()
+        thr = _omp_threads()
         cpu = {}
         for jac, name in ((True, "with_jacobians"), (False, "residuals_only")):
             def run():
@@ -1042,10 +1077,10 @@ def bench_icp(bag, xy, off, with_cpu, window=10, iters=5):
                                   "note": "32 B read per correspondence, 224 B written per block"}}
     if with_cpu:
         from oracle import oracle as O
-        k = min(len(bs), 4 * O.num_threads())
+        k = min(len(bs), 4 * _omp_threads())
         aff = O.pose_affines(bag.odom)
-        med, _, _ = _median_runs(lambda: O.corr_search_batch(xy, nrm, off, bs[:k], bt[:k], aff, 0.25, O.num_threads()))
-        out["cpu_baseline"] = {"value": k / med, "unit": "blocks/s", "cores": O.num_threads(), "kind": "port",
+        med, _, _ = _median_runs(lambda: O.corr_search_batch(xy, nrm, off, bs[:k], bt[:k], aff, 0.25, _omp_threads()))
+        out["cpu_baseline"] = {"value": k / med, "unit": "blocks/s", "cores": _omp_threads(), "kind": "port",
                                "sample": "%d blocks, oracle linear-scan restatement, OpenMP; median of 5" % k,
                                "gpu_blocks_per_s": len(bs) / (t_search * 1e-3)}
     return out
@@ -1073,7 +1108,7 @@ def bench_config1(with_cpu):
         from oracle import oracle as O
         from oracle.cpu_backend import OracleBackend
         out["cpu"] = slam_loop.run(backend=OracleBackend(), **kw)
-        out["cpu"].update({"kind": "port", "cores": O.num_threads()})
+        out["cpu"].update({"kind": "port", "cores": _omp_threads()})
         out["wall_clock_ratio_cpu_over_gpu"] = out["cpu"]["t_total_s"] / max(out["gpu"]["t_total_s"], 1e-9)
         out["loop_closure_ratio_cpu_over_gpu"] = (out["cpu"]["t_csm_s"] + out["cpu"]["t_lc_solve_s"]) / \
             max(out["gpu"]["t_csm_s"] + out["gpu"]["t_lc_solve_s"], 1e-9)

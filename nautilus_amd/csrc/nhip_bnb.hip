@@ -41,6 +41,12 @@
 #ifndef NHIP_BNB_RS_DPP
 #define NHIP_BNB_RS_DPP 1   // 0: every step beyond the quad through ds_bpermute (measurement)
 #endif
+#ifndef NHIP_BNB_RUN_MAX
+#define NHIP_BNB_RUN_MAX 64  // lanes per run group in the bounds phase (8 / 16: measurement)
+#endif
+#ifndef NHIP_BNB_P1_PREFETCH
+#define NHIP_BNB_P1_PREFETCH 2  // chunks of points in flight in the bounds phase
+#endif
 #ifndef NHIP_BNB_F32_ORIGINS
 #define NHIP_BNB_F32_ORIGINS 1  // 0: window origins through two double-precision quotients (measurement)
 #endif
@@ -53,7 +59,12 @@
 #else
 #define BNB_STATS(P) (static_cast<unsigned long long *>(nullptr))
 #define BNB_TIMELINE(P) (static_cast<unsigned long long *>(nullptr))
-#define BNB_DEBUG(P) 0
+// (tools/bnb_variants.sh builds product kernels with a timing experiment compiled in -- WRONG results, no counters whose
+//  atomics would distort the time: -DNHIP_BNB_EXPERIMENT=<a NHIP_BNB_DEBUG value>)
+#ifndef NHIP_BNB_EXPERIMENT
+#define NHIP_BNB_EXPERIMENT 0
+#endif
+#define BNB_DEBUG(P) NHIP_BNB_EXPERIMENT
 #endif
 
 namespace nhip {
@@ -218,13 +229,18 @@ __device__ __forceinline__ uint32_t add_xor(uint32_t v) {
 //
 // Consecutive beams hit the same wall: on a 1081-beam scan 5 to 10 consecutive points share a pooled entry
 // (8 x 8 cells = 40 cm), and every one of them would gather the same 11 x 11 bytes.  So the points are first
-// run-length compressed: a lane whose pooled offset differs from its predecessor's (or that starts a group of 8
-// lanes) is the head of a run and writes (offset, run length <= 8) to the wave's list in LDS; the gather then
-// works on list entries, 64 at a time, and adds every byte `length` times (one multiply-add in place of the add).
-// Field widths: a lane gathers at most 4 entries = 32 points between reductions, as 32 points did before.
-constexpr int RUN_MAX = 8;        // longest run: 4 entries * 8 points * 255 * 8 lanes < 65536 (16-bit fields)
-constexpr int SEG_PASSES = 4;     // gather passes between reductions
+// run-length compressed: a lane whose pooled offset differs from its predecessor's (or that starts a 64-point chunk)
+// is the head of a run and writes (offset, run length <= 64) to the wave's list in LDS; the gather then works on
+// list entries, 64 at a time, and adds every byte `length` times (one multiply-add in place of the add): ~165
+// entries for 1081 points, three passes.  (Runs cut at every 8th lane, the first form: 265 entries, five passes.)
+// Field widths: the accumulators and the first two reduction steps (over 4 lanes) hold 16-bit fields, so a lane may
+// gather a total run length of at most LANE_WEIGHT = 64 between two reductions (4 lanes * 64 * 255 = 65,280); the
+// wave reduces early when a pass would take some lane past that, otherwise once per rotation.
+constexpr int RUN_MAX = NHIP_BNB_RUN_MAX;  // longest run = lanes per group whose first lane always starts a run: 8, 16 or 64
+constexpr uint32_t LANE_WEIGHT = 64u;
+constexpr int RUN_SHIFT = 25;     // entry = pooled offset | (run length - 1) << RUN_SHIFT
 constexpr int LIST_ENTRIES = 128; // ring of pending entries per wave (a chunk appends <= 64, 64 are consumed at a time)
+static_assert(RUN_MAX == 8 || RUN_MAX == 16 || RUN_MAX == 64, "runs are cut at DPP row or chunk boundaries");
 
 template <bool POOL_LDS>
 __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_t *pool, __amdgpu_buffer_rsrc_t prs,
@@ -239,11 +255,11 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
 #pragma unroll
     for (int d = 0; d < 3; d++) E[y][d] = O[y][d] = 0u;
   uint32_t head = 0u, tail = 0u;  // ring positions (wave-uniform)
-  int passes = 0;
+  bool pending = false;           // passes gathered since the last reduction
+  uint32_t weight = 0u;           // this lane's run lengths gathered since the last reduction
 
   // 64 list entries: every lane gathers the 11 x 12 bytes of its entry, weighted by the run length
-  auto gather = [&](uint32_t entry) {
-    const uint32_t a = entry & 0x07ffffffu, cnt = entry >> 27;
+  auto gather = [&](uint32_t a, uint32_t cnt) {
     const uint32_t sh = (a & 3u) * 8u;
     const uint32_t *q = reinterpret_cast<const uint32_t *>(pool + (a & ~3u));
 #pragma unroll
@@ -308,52 +324,83 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
       for (int d = 0; d < 3; d++) E[y][d] = O[y][d] = 0u;
   };
 
-  float2 qn = lane < n_pts ? pts[lane] : make_float2(0.f, 0.f);
+  // (the points of the next PD chunks are in flight while one chunk is worked: with two workgroups per CU gathering
+  //  from their grids, a point load takes ~1,300 clocks, more than a chunk's work)
+  constexpr int PD = NHIP_BNB_P1_PREFETCH;
+  float2 qn[PD];
+#pragma unroll
+  for (int d = 0; d < PD; d++) qn[d] = 64 * d + lane < n_pts ? pts[64 * d + lane] : make_float2(0.f, 0.f);
   for (int32_t c = 0;; c += 64) {
+    if (BNB_DEBUG(P) == 30) break;  // (timing experiment: no chunk loop at all)
     const bool more = c < n_pts;  // (one more turn after the last chunk drains the list)
     if (more) {
-      const float2 pt = qn;
-      if (c + 64 + lane < n_pts) qn = pts[c + 64 + lane];  // next chunk's point
+      const float2 pt = qn[0];
+#pragma unroll
+      for (int d = 0; d < PD - 1; d++) qn[d] = qn[d + 1];
+      if (c + 64 * PD + lane < n_pts) qn[PD - 1] = pts[c + 64 * PD + lane];
       const bool live = c + lane < n_pts;
       uint32_t a = zero_a;
-      if (live) {
+      if (live && BNB_DEBUG(P) != 29) {  // (timing experiments 28 / 29: without the run lists / without the origins too)
         int32_t prow, pcol;
         window_origin(pt, cf, sf, P, cx, cy, &prow, &pcol);
         a = (uint32_t)((prow >> 3) * DP + (pcol >> 3));
       }
-      // runs of equal offsets inside groups of RUN_MAX lanes
-      // (the predecessor inside the row of 16 lanes: a DPP shift, no LDS round trip; a row's first lane is a head anyway)
-#if NHIP_BNB_RS_DPP
-      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
-#else
+      if (BNB_DEBUG(P) >= 28 && BNB_DEBUG(P) <= 29) {
+        tot[0] += a;
+        continue;
+      }
+      // runs of equal offsets inside groups of RUN_MAX lanes: the predecessor's offset by a DPP shift (inside the row
+      // of 16 lanes, or -- RUN_MAX 64 -- across the wave), no LDS round trip; a group's first lane is a head anyway
+#if !NHIP_BNB_RS_DPP
       const uint32_t prev = (uint32_t)__shfl_up((int)a, 1, 64);
+#elif NHIP_BNB_RUN_MAX == 64
+      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+#else
+      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
 #endif
       const bool is_head = (lane & (RUN_MAX - 1)) == 0 || a != prev;
       const unsigned long long H = __ballot(is_head);
-      const uint32_t Hh = (lane & 32) ? (uint32_t)(H >> 32) : (uint32_t)H;  // the half of H that holds the lane's group
-      const uint32_t g = (Hh >> (lane & 31 & ~(RUN_MAX - 1))) & ((1u << RUN_MAX) - 1u);
-      const uint32_t rest = g >> ((lane & (RUN_MAX - 1)) + 1);
-      const uint32_t cnt = rest ? (uint32_t)__builtin_ctz(rest) + 1u : (uint32_t)(RUN_MAX - (lane & (RUN_MAX - 1)));
+      // run length = distance to the next head of the lane's group (or to the group's end)
+      uint32_t cnt;
+      if (RUN_MAX == 64) {
+        const unsigned long long rest = (H >> lane) >> 1;
+        cnt = rest ? (uint32_t)__builtin_ctzll(rest) + 1u : (uint32_t)(64 - lane);
+      } else {
+        const uint32_t Hh = (lane & 32) ? (uint32_t)(H >> 32) : (uint32_t)H;  // the half of H that holds the lane's group
+        const uint32_t g = (Hh >> (lane & 31 & ~(RUN_MAX - 1))) & ((1u << (RUN_MAX & 31)) - 1u);
+        const uint32_t rest = g >> ((lane & (RUN_MAX - 1)) + 1);
+        cnt = rest ? (uint32_t)__builtin_ctz(rest) + 1u : (uint32_t)(RUN_MAX - (lane & (RUN_MAX - 1)));
+      }
       const unsigned long long He = __ballot(is_head && live);  // (lanes past the scan's end emit nothing)
       if (is_head && live) {
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(He >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)He, 0u));
-        list[(tail + before) & (LIST_ENTRIES - 1)] = a | (cnt << 27);
+        list[(tail + before) & (LIST_ENTRIES - 1)] = a | ((cnt - 1u) << RUN_SHIFT);
       }
       tail += (uint32_t)__builtin_popcountll(He);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    // (last turn: also when nothing is pending but unreduced passes are -- an all-zero pass brings the reduction)
-    while (tail - head >= 64u || (!more && (tail != head || passes != 0))) {
+    // gather passes: whenever 64 entries are pending, and to the last entry once the scan is through; then one more
+    // turn for the rotation's (only, as a rule) reduction -- one copy of that code
+    for (;;) {
       const uint32_t avail = tail - head;
+      if (avail < 64u && more) break;
+      const bool last = avail == 0u;  // (!more)
       // (lanes past the list gather the zero rows with length 0)
-      if (BNB_DEBUG(P) != 27) gather((uint32_t)lane < avail ? list[(head + (uint32_t)lane) & (LIST_ENTRIES - 1)] : zero_a);
-      head += avail < 64u ? avail : 64u;
-      passes++;
-      if ((passes == SEG_PASSES || (!more && tail == head)) && BNB_DEBUG(P) != 26) {
+      const bool mine = (uint32_t)lane < avail;
+      const uint32_t entry = mine ? list[(head + (uint32_t)lane) & (LIST_ENTRIES - 1)] : zero_a;
+      const uint32_t a = entry & ((1u << RUN_SHIFT) - 1u), cnt = mine ? (entry >> RUN_SHIFT) + 1u : 0u;
+      // (also before a pass that could overflow some lane's fields)
+      if (pending && (last || __ballot(weight + cnt > LANE_WEIGHT) != 0ull) && BNB_DEBUG(P) != 26) {
         reduce();
-        passes = 0;
+        pending = false;
+        weight = 0u;
       }
+      if (last) break;
+      if (BNB_DEBUG(P) != 27) gather(a, cnt);
+      weight += cnt;
+      pending = true;
+      head += avail < 64u ? avail : 64u;
       __builtin_amdgcn_wave_barrier();
     }
     if (!more) break;
@@ -1283,19 +1330,34 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   if (POOL_LDS) {  // the target's pooled table -> LDS
     const uint4 *gp = reinterpret_cast<const uint4 *>(grid + P.grid_bytes + P.skip_bytes);
     uint4 *sp = reinterpret_cast<uint4 *>(s_pool);
-    for (int32_t i = threadIdx.x; i < (int32_t)(P.pool_bytes / 16); i += BNB_THREADS) sp[i] = gp[i];
+    // (four loads in flight per thread: 35 KB are 4.4 rounds of 512 threads, and a round trip each was 10 % of the pair)
+    const int32_t n16 = (int32_t)(P.pool_bytes / 16);
+    for (int32_t i = threadIdx.x; i < n16; i += 4 * BNB_THREADS) {
+      uint4 v[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = gp[min(i + j * BNB_THREADS, n16 - 1)];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+        if (i + j * BNB_THREADS < n16) sp[i + j * BNB_THREADS] = v[j];
+    }
   }
   const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(grid + P.grid_bytes + P.skip_bytes, P.pool_bytes);
+  const long long x_loaded = BNB_STATS(P) && BNB_DEBUG(P) >= 26 ? clock64() : 0;  // (this wave's share is in LDS)
   __syncthreads();
+  // (timing experiments NHIP_BNB_DEBUG >= 26: wave 0's clocks of the staging, the rotations and the rest of phase 1)
+  long long x_rot = 0, x_post = 0;
+  const long long x_staged = BNB_STATS(P) && BNB_DEBUG(P) >= 26 ? clock64() : 0;
 
   // (1) bounds of every block of every rotation this wave owns; the wave's own best bound
   const uint32_t scale = CB == 1 ? 1u : 257u;
   unsigned long long wbest = 0ull;  // (U << 32) | (k << 8 | slot)
-  for (int32_t k = wave; k < P.n_theta; k += BNB_WAVES) {
+  for (int32_t k = wave; k < P.n_theta && BNB_DEBUG(P) != 31; k += BNB_WAVES) {
     float cf, sf;
     rotation_k(P, pair, k, &cf, &sf);
     uint32_t tot[2];
+    const long long x0 = BNB_STATS(P) && BNB_DEBUG(P) >= 26 ? clock64() : 0;
     coarse_rotation<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, s_list + wave * LIST_ENTRIES, tot);
+    if (BNB_STATS(P) && BNB_DEBUG(P) >= 26) x_rot += clock64() - x0;
     if (lane < 128 - NB * NB) s_U[k * 128 + NB * NB + lane] = 0u;  // (the row's unused tail)
     uint32_t umax = 0u;
 #pragma unroll
@@ -1324,6 +1386,13 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     const unsigned long long o = shfl_xor_u64b(wbest, m);
     wbest = o > wbest ? o : wbest;
   }
+  if (BNB_STATS(P) && BNB_DEBUG(P) >= 26 && threadIdx.x == 0) {
+    atomicAdd(&BNB_STATS(P)[5], (unsigned long long)(x_staged - t_start));
+    atomicAdd(&BNB_STATS(P)[6], (unsigned long long)x_rot);
+    // (experiments >= 30: wave 0's wait at the barrier behind the staging, i.e. for the last wave of the workgroup)
+    atomicAdd(&BNB_STATS(P)[7], (unsigned long long)(BNB_DEBUG(P) >= 30 ? x_staged - x_loaded : clock64() - x_staged - x_rot));
+  }
+  (void)x_post;
   // (2) seed: the wave's highest-bound block, evaluated exactly
   uint32_t n_work[4] = {0u, 0u, 0u, 0u};
   PairCtx C;
@@ -1669,7 +1738,7 @@ bool bnb_fits(const GridLayout &L, const nhip_search_t *search) {
   const int nbx = (search->nx + BNB_B - 1) / BNB_B, nby = (search->ny + BNB_B - 1) / BNB_B;
   // (the pooled table goes to LDS when it fits beside the bounds; else it is read from global memory)
   return nbx <= NB && nby <= NB && bnb_lds_bytes(L, search, false) <= LDS_MAX && L.pool_bytes % 16 == 0 &&
-         L.pool_bytes < 0x7fffffffll && L.S + 2 * L.pad < 65536 && search->n_theta <= MAX_ROT;
+         L.pool_bytes < (1ll << RUN_SHIFT) && L.S + 2 * L.pad < 65536 && search->n_theta <= MAX_ROT;
 }
 
 // Instrumentation buffers (NHIP_BNB_INSTRUMENT=1 only): process-wide, allocated on first use, guarded by g_instr_mu

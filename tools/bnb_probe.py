@@ -12,9 +12,10 @@ lib = _lib.load()
 wl = bench.Workload("weak", 1, int(sys.argv[1]) if len(sys.argv) > 1 else 1000, 10)
 plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
 out = {}
-for bits in (8, 16):
+MODES = os.environ.get("NHIP_PROBE_MODES", "0,L1,3,4,5,1,2").split(",")   # NHIP_BNB_DEBUG values; 26 / 27: bounds without reduction / gather
+for bits in [int(b) for b in os.environ.get("NHIP_PROBE_BITS", "8,16").split(",")]:
     m = bench.HipMatcher(wl, plan.shard(0), torch.device("cuda", 0), bits)
-    for dbg in ("0", "L1", "3", "4", "5", "1", "2"):
+    for dbg in MODES:
         os.environ["NHIP_BNB_LEVELS"] = "1" if dbg == "L1" else "2"   # L1: full run without the sub-block bounds
         os.environ["NHIP_BNB_DEBUG"] = "0" if dbg == "L1" else dbg
         m.step(); torch.cuda.synchronize(); csm.bnb_stats()
