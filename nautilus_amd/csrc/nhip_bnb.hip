@@ -896,7 +896,11 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
 #pragma unroll
     for (int j = 0; j < U; j++) {
       const uint32_t o = origin_of(org, U * r + j);
+#ifdef NHIP_BNB_ROWBAND_EXPERIMENT  // (timing, WRONG results: every 8-row band reads one row -- what a tiled plane could save in L1 lookups)
+      const uint32_t g = ((o >> 16) & ~7u) * pitch + (o & 0xffffu) + off;
+#else
       const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
+#endif
       sh[j] = (g & 3u) * 8u;
 #pragma unroll
       for (int y = 0; y < 4; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
@@ -953,7 +957,11 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
 #pragma unroll
     for (int j = 0; j < U; j++) {
       const uint32_t o = origin_of(org, U * r + j);
+#ifdef NHIP_BNB_ROWBAND_EXPERIMENT  // (timing, WRONG results: every 8-row band reads one row -- what a tiled plane could save in L1 lookups)
+      const uint32_t g = ((o >> 16) & ~7u) * pitch + (o & 0xffffu) + off;
+#else
       const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
+#endif
       sh[j] = (g & 3u) * 8u;
       gg[j] = g & ~3u;
     }
@@ -1270,7 +1278,9 @@ __device__ __forceinline__ void pair_context(const BnbParams &P, int32_t pair, P
 // BY_ROT: the pairs whose scan fits the register-held origins (n_pts <= 64 * OC), rotation by rotation; the other
 // instantiation takes the longer scans -- or, with P.general_all (NHIP_BNB_QUEUE=1), every pair.
 // Both are launched; a workgroup whose pair belongs to the other one returns at once.
-template <int CB, bool POOL_LDS, bool BY_ROT>
+// SPLIT (by-rotation form only): the workgroup ends after the seeds and leaves its state in P.ps_* for
+// csm_bnb_cand_kernel.
+template <int CB, bool POOL_LDS, bool BY_ROT, bool SPLIT = false>
 __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   extern __shared__ __align__(16) uint8_t smem[];
   // first region: the pooled table (POOL_LDS) while the bounds are computed, then the waves' window origins
@@ -1342,11 +1352,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     }
   }
   const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(grid + P.grid_bytes + P.skip_bytes, P.pool_bytes);
-  const long long x_loaded = BNB_STATS(P) && BNB_DEBUG(P) >= 26 ? clock64() : 0;  // (this wave's share is in LDS)
   __syncthreads();
-  // (timing experiments NHIP_BNB_DEBUG >= 26: wave 0's clocks of the staging, the rotations and the rest of phase 1)
-  long long x_rot = 0, x_post = 0;
-  const long long x_staged = BNB_STATS(P) && BNB_DEBUG(P) >= 26 ? clock64() : 0;
 
   // (1) bounds of every block of every rotation this wave owns; the wave's own best bound
   const uint32_t scale = CB == 1 ? 1u : 257u;
@@ -1355,9 +1361,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     float cf, sf;
     rotation_k(P, pair, k, &cf, &sf);
     uint32_t tot[2];
-    const long long x0 = BNB_STATS(P) && BNB_DEBUG(P) >= 26 ? clock64() : 0;
     coarse_rotation<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, s_list + wave * LIST_ENTRIES, tot);
-    if (BNB_STATS(P) && BNB_DEBUG(P) >= 26) x_rot += clock64() - x0;
     if (lane < 128 - NB * NB) s_U[k * 128 + NB * NB + lane] = 0u;  // (the row's unused tail)
     uint32_t umax = 0u;
 #pragma unroll
@@ -1386,13 +1390,6 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     const unsigned long long o = shfl_xor_u64b(wbest, m);
     wbest = o > wbest ? o : wbest;
   }
-  if (BNB_STATS(P) && BNB_DEBUG(P) >= 26 && threadIdx.x == 0) {
-    atomicAdd(&BNB_STATS(P)[5], (unsigned long long)(x_staged - t_start));
-    atomicAdd(&BNB_STATS(P)[6], (unsigned long long)x_rot);
-    // (experiments >= 30: wave 0's wait at the barrier behind the staging, i.e. for the last wave of the workgroup)
-    atomicAdd(&BNB_STATS(P)[7], (unsigned long long)(BNB_DEBUG(P) >= 30 ? x_staged - x_loaded : clock64() - x_staged - x_rot));
-  }
-  (void)x_post;
   // (2) seed: the wave's highest-bound block, evaluated exactly
   uint32_t n_work[4] = {0u, 0u, 0u, 0u};
   PairCtx C;
@@ -1497,7 +1494,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
           s_order[rank] = (uint32_t)kk;
         }
         // ... and how many candidates the seeds have left: a flat landscape leaves thousands (the median pair: ~30)
-        if (P.rot_list) {
+        if (P.rot_list || SPLIT) {
           const uint32_t bsum = best_sum<false>(s_best);
           uint32_t mine = 0u;
           for (int32_t kk = wave; kk < P.n_theta; kk += BNB_WAVES) {
@@ -1508,6 +1505,29 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
           if (lane == 0) atomicAdd(s_qn, mine);
         }
         __syncthreads();
+        if (SPLIT) {
+          // the state for csm_bnb_cand_kernel: the rows of the rotations that still hold a candidate, best first
+          const uint32_t bsum = best_sum<false>(s_best);
+          uint32_t *rows = P.ps_rows + (size_t)pair * (size_t)P.n_theta * 128u;
+          uint32_t live = 0u;
+          for (int32_t r = wave; r < P.n_theta; r += BNB_WAVES) {
+            const uint32_t kk = s_order[r];
+            const uint32_t kmax = (uint32_t)(s_kmax[kk] >> 32);
+            if (kmax == 0u || kmax < bsum) break;  // (descending: no later rank holds one either)
+            live = (uint32_t)r + 1u;
+            const uint32_t w1 = lane == 62 ? kmax : (lane == 63 ? kk : s_U[kk * 128 + 64 + lane]);
+            rows[(size_t)r * 128u + lane] = s_U[kk * 128 + lane];
+            rows[(size_t)r * 128u + 64 + lane] = w1;
+          }
+          if (lane == 0 && live) atomicMax(s_qhead, live);  // (the hand-out counter is not used in this form)
+          __syncthreads();
+          if (threadIdx.x == 0) {
+            P.ps_count[pair] = *s_qn;
+            P.ps_live[pair] = *s_qhead;
+            P.ps_next[pair] = 0u;
+          }
+          break;
+        }
         heavy = P.rot_list && *s_qn >= P.heavy_min;
         state = OWN;
       }
@@ -1659,6 +1679,131 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
   }
 }
 
+// ---- the split form's second and third launch ----------------------------------------------------------------
+// Order of the second launch: per XCD (the pairs of a target stay where its grid is L2-resident) the pairs by the
+// candidates the seeds have left, most first -- with exact knowledge of what is heavy, the hardware's in-order dispatch
+// becomes longest-first list scheduling; the pairs at the head get one more workgroup per P.split_min candidates (they
+// share the pair's rotations through ps_next and its best through keys[pair]), as long as the XCD's list has room.
+// One workgroup per XCD segment; buckets of ~19 % width in the count (16 per octave up to 2^20).
+constexpr int SORT_THREADS = 1024;
+constexpr int SORT_BUCKETS = 16 * 21;
+__device__ __forceinline__ int cand_bucket(uint32_t c) {  // heaviest = bucket 0
+  if (c == 0u) return SORT_BUCKETS - 1;
+  const int e = 31 - __builtin_clz(c);                  // floor(log2 c)
+  const int f = e >= 4 ? (int)((c >> (e - 4)) & 15u) : (int)((c << (4 - e)) & 15u);
+  const int b = 16 * e + f;                              // ascending in c
+  return b >= SORT_BUCKETS - 1 ? 0 : SORT_BUCKETS - 2 - b;
+}
+__device__ __forceinline__ uint32_t cand_shares(const BnbParams &P, uint32_t c) {
+  const uint32_t w = 1u + c / P.split_min;
+  return w < P.split_max ? w : P.split_max;
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void csm_bnb_order_kernel(BnbParams P) {
+  __shared__ uint32_t s_pairs[SORT_BUCKETS], s_extra[SORT_BUCKETS], s_off[SORT_BUCKETS], s_cur[SORT_BUCKETS];
+  __shared__ int s_grant;
+  const int32_t xcd = blockIdx.x;
+  const int32_t lo = xcd * P.pairs_per_xcd, hi = min(lo + P.pairs_per_xcd, P.n_pairs);
+  int32_t *work = P.ps_work + (size_t)xcd * P.ps_work_stride;
+  for (int i = threadIdx.x; i < SORT_BUCKETS; i += SORT_THREADS) s_pairs[i] = s_extra[i] = s_cur[i] = 0u;
+  for (int i = threadIdx.x; i < P.ps_work_stride; i += SORT_THREADS) work[i] = -1;
+  __syncthreads();
+  for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
+    const uint32_t c = P.ps_count[p];
+    const int b = cand_bucket(c);
+    atomicAdd(&s_pairs[b], 1u);
+    atomicAdd(&s_extra[b], cand_shares(P, c) - 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // additional workgroups are granted bucket by bucket from the heaviest while the list has room for them
+    uint32_t room = (uint32_t)P.ps_work_stride - (uint32_t)(hi > lo ? hi - lo : 0);
+    int grant = 0;
+    while (grant < SORT_BUCKETS && s_extra[grant] <= room) room -= s_extra[grant++];
+    s_grant = grant;
+    uint32_t off = 0u;
+    for (int b = 0; b < SORT_BUCKETS; b++) {
+      s_off[b] = off;
+      off += s_pairs[b] + (b < grant ? s_extra[b] : 0u);
+    }
+  }
+  __syncthreads();
+  for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
+    const uint32_t c = P.ps_count[p];
+    const int b = cand_bucket(c);
+    const uint32_t w = b < s_grant ? cand_shares(P, c) : 1u;
+    const uint32_t at = s_off[b] + atomicAdd(&s_cur[b], w);
+    for (uint32_t j = 0; j < w; j++) work[at + j] = p;
+    P.ps_nw[p] = w;
+  }
+}
+
+// The candidates: the OWN loop of csm_bnb_kernel on the state its split form left.  Four waves per workgroup, each takes
+// the pair's live rotations one at a time, best first.  A pair with one workgroup keeps its hand-out counter and its
+// best in LDS; a shared pair uses ps_next[pair] and keys[pair] -- the code is the same, through generic pointers, with
+// the look-once-per-strip discipline of a best that may live in global memory.
+#ifndef NHIP_BNB_CAND_OCC
+#define NHIP_BNB_CAND_OCC 4  // waves per SIMD the candidates' kernel is compiled for (register budget 512 / that)
+#endif
+template <int CB>
+__global__ __launch_bounds__(256, NHIP_BNB_CAND_OCC) void csm_bnb_cand_kernel(BnbParams P) {
+  __shared__ uint32_t s_org2[4 * ORG_WAVE];
+  __shared__ unsigned long long s_best2;
+  __shared__ uint32_t s_next2;
+  const int lane = threadIdx.x & 63;
+  const uint32_t xcd = blockIdx.x & 7u, slot = blockIdx.x >> 3;
+  if ((int32_t)slot >= P.ps_work_stride) return;
+  const int32_t pair = P.ps_work[(size_t)xcd * P.ps_work_stride + slot];
+  if (pair < 0) return;
+  const uint32_t live = P.ps_live[pair];
+  if (live == 0u) return;  // (nothing left after the seeds, or a pair of the general kernel)
+  const bool shared = P.ps_nw[pair] > 1u;
+  if (threadIdx.x == 0) {
+    s_best2 = P.keys[pair];
+    s_next2 = 0u;
+  }
+  __syncthreads();
+  unsigned long long *best = shared ? &P.keys[pair] : &s_best2;
+  uint32_t *next = shared ? &P.ps_next[pair] : &s_next2;
+  const uint32_t *rows = P.ps_rows + (size_t)pair * (size_t)P.n_theta * 128u;
+  uint32_t *org = s_org2 + (threadIdx.x >> 6) * ORG_WAVE + lane;
+  PairCtx C;
+  pair_context(P, pair, &C);
+  uint32_t n_work[4] = {0u, 0u, 0u, 0u};
+  PhaseClocks clk = {0, 0, 0};
+  const long long t0 = BNB_STATS(P) ? clock64() : 0;
+  for (;;) {
+    uint32_t rank = 0u;
+    if (lane == 0) rank = atomicAdd(next, 1u);
+    rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
+    if (rank >= live) break;
+    const uint32_t u0 = rows[(size_t)rank * 128u + lane], u1 = rows[(size_t)rank * 128u + 64 + lane];
+    const uint32_t kmax = (uint32_t)__builtin_amdgcn_readlane((int)u1, 62);
+    const int32_t k = __builtin_amdgcn_readlane((int)u1, 63);
+    const uint32_t bsum = best_sum<true>(best);
+    if (kmax < bsum) break;  // (best first: the later ranks hold nothing either)
+    const unsigned long long m0 = __ballot(u0 != 0u && u0 >= bsum);
+    const unsigned long long m1 = __ballot(u1 != 0u && u1 >= bsum && lane + 64 < NB * NB);
+    if ((m0 | m1) == 0ull) continue;
+    rotation_pass<CB, true>(P, C, k, u0, u1, m0, m1, lane, best, nullptr, org, n_work, clk);
+  }
+  if (BNB_STATS(P) && lane == 0) {
+    if (n_work[0]) atomicAdd(&BNB_STATS(P)[0], (unsigned long long)n_work[0]);
+    if (n_work[1]) atomicAdd(&BNB_STATS(P)[2], (unsigned long long)n_work[1]);
+    if (n_work[2]) atomicAdd(&BNB_STATS(P)[3], (unsigned long long)n_work[2]);
+    if (n_work[3]) atomicAdd(&BNB_STATS(P)[14], (unsigned long long)n_work[3]);
+    atomicAdd(&BNB_STATS(P)[13], (unsigned long long)(clock64() - t0));
+    atomicAdd(&BNB_STATS(P)[5], (unsigned long long)clk.org);
+    atomicAdd(&BNB_STATS(P)[6], (unsigned long long)clk.strip);
+    atomicAdd(&BNB_STATS(P)[7], (unsigned long long)clk.eval);
+    if (pair < BNB_STATS_PAIRS) atomicAdd(&BNB_STATS(P)[BNB_STATS_HEAD + pair], 4ull * n_work[0] + n_work[2]);
+  }
+  if (!shared) {
+    __syncthreads();
+    if (threadIdx.x == 0) P.keys[pair] = s_best2;
+  }
+}
+
 }  // namespace
 
 // ---- the kernel launches of one batch (compiled in both builds)
@@ -1666,22 +1811,33 @@ namespace bnb {
 
 namespace {
 // hipFuncSetAttribute once per instantiation and LDS size reached (not per launch)
-template <int CB, bool PL, bool BR>
+template <int CB, bool PL, bool BR, bool SP = false>
 int launch_main(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
   static std::atomic<size_t> lds_set{0};
   if (lds > lds_set.load(std::memory_order_relaxed)) {
-    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL, BR>),
+    NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL, BR, SP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     lds_set.store(lds, std::memory_order_relaxed);
   }
 #if NHIP_BNB_INSTR
   if (P.stats && getenv("NHIP_BNB_OCCUPANCY")) {
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, csm_bnb_kernel<CB, PL, BR>, BNB_THREADS, lds);
-    fprintf(stderr, "csm_bnb_kernel<%d,%d,%d>: lds %zu B, %d workgroups per CU\n", CB, (int)PL, (int)BR, lds, nb);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, csm_bnb_kernel<CB, PL, BR, SP>, BNB_THREADS, lds);
+    fprintf(stderr, "csm_bnb_kernel<%d,%d,%d,%d>: lds %zu B, %d workgroups per CU\n", CB, (int)PL, (int)BR, (int)SP, lds, nb);
   }
 #endif
-  hipLaunchKernelGGL((csm_bnb_kernel<CB, PL, BR>), dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);
+  hipLaunchKernelGGL((csm_bnb_kernel<CB, PL, BR, SP>), dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);
+  return NHIP_OK;
+}
+
+// The split form's first part on one batch: bounds + seeds of the by-rotation pairs, the general kernel for the scans
+// that form does not take, the order of the candidates' launch ...
+template <int CB, bool PL>
+int launch_split_a(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
+  int rc = launch_main<CB, PL, true, true>(P, lds, blocks, s);
+  if (rc) return rc;
+  if ((rc = launch_main<CB, PL, false>(P, lds, blocks, s))) return rc;
+  hipLaunchKernelGGL(csm_bnb_order_kernel, dim3(8), dim3(SORT_THREADS), 0, s, P);
   return NHIP_OK;
 }
 
@@ -1717,6 +1873,28 @@ int launch_bnb_kernels(const BnbParams &P, int cb, bool pool_lds, size_t lds, in
   return NHIP_OK;
 }
 
+#if NHIP_BNB_INSTR
+int launch_bnb_split_a_instr(const BnbParams &P, int cb, bool pool_lds, size_t lds, int64_t blocks, hipStream_t s) {
+#else
+int launch_bnb_split_a(const BnbParams &P, int cb, bool pool_lds, size_t lds, int64_t blocks, hipStream_t s) {
+#endif
+  if (cb == 1 && pool_lds) return launch_split_a<1, true>(P, lds, blocks, s);
+  if (cb == 1) return launch_split_a<1, false>(P, lds, blocks, s);
+  if (pool_lds) return launch_split_a<2, true>(P, lds, blocks, s);
+  return launch_split_a<2, false>(P, lds, blocks, s);
+}
+
+// ... and its second: the candidates (on any stream ordered behind the first part of the same batch)
+#if NHIP_BNB_INSTR
+int launch_bnb_split_b_instr(const BnbParams &P, int cb, hipStream_t s) {
+#else
+int launch_bnb_split_b(const BnbParams &P, int cb, hipStream_t s) {
+#endif
+  if (cb == 1) hipLaunchKernelGGL(csm_bnb_cand_kernel<1>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(256), 0, s, P);
+  else hipLaunchKernelGGL(csm_bnb_cand_kernel<2>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(256), 0, s, P);
+  return NHIP_OK;
+}
+
 }  // namespace bnb
 
 #if !NHIP_BNB_INSTR
@@ -1747,10 +1925,28 @@ static unsigned long long *g_bnb_timeline = nullptr;
 static unsigned long long *g_bnb_stats = nullptr;
 
 constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, next entry to work}
-// room for 16 rotations per pair on average (what does not fit is worked by the pair's own workgroup)
+// Small batches: room for 16 handed-over rotations per pair on average (what does not fit is worked by the pair's own
+// workgroup).  Large batches (the split form): per pair its four counters, 1.5 entries of the candidates' work list and
+// the rows of bounds of up to 64 rotations, for up to SPLIT_PAIRS pairs at a time (a longer list of pairs, or a search
+// with more rotations, goes through the same workspace in more rounds).
+constexpr int64_t SPLIT_PAIRS = 16384, SPLIT_MIN_PAIRS = 1024, SPLIT_BATCH = SPLIT_PAIRS, SPLIT_RING = 16;
+int64_t split_bytes_per_pair(int32_t n_theta) { return 16 + 6 + (int64_t)n_theta * 512; }
+constexpr int64_t SPLIT_SLOT_FIXED = 8 * 64 * 4 + 1024;  // per batch: the work lists' floor of 64 extra entries, alignment
 int64_t bnb_workspace_bytes(int32_t n_pairs) {
-  return BNB_WS_HEADER + 8 * ((((int64_t)(n_pairs > 0 ? n_pairs : 0) + 7) / 8) * 16 + 64) * (int64_t)sizeof(RotEntry);
+  const int64_t n = n_pairs > 0 ? n_pairs : 0;
+  const int64_t lists = BNB_WS_HEADER + 8 * (((n + 7) / 8) * 16 + 64) * (int64_t)sizeof(RotEntry);
+  const char *sp = getenv("NHIP_BNB_SPLIT");  // (=1: the split form for small batches too -- tests)
+  const int64_t m = n < SPLIT_PAIRS ? n : SPLIT_PAIRS;
+  const int64_t split = n >= SPLIT_MIN_PAIRS || (n > 0 && sp && sp[0] == '1')
+                            ? BNB_WS_HEADER + (m / 512 + 2) * SPLIT_SLOT_FIXED + m * split_bytes_per_pair(64) : 0;
+  return lists > split ? lists : split;
 }
+
+// The helper stream of the split form (the candidates of batch i run beside the bounds of batch i + 1) and the events
+// that order the two; process-wide, created on first use, used under g_split_mu.
+static std::mutex g_split_mu;
+static hipStream_t g_split_stream = nullptr;
+static hipEvent_t g_split_ea[SPLIT_RING], g_split_eb[SPLIT_RING];
 
 // NHIP_BNB_INSTRUMENT=1 selects the instrumented build of the kernels; only then are NHIP_BNB_STATS, NHIP_BNB_TIMELINE
 // and NHIP_BNB_DEBUG (timing experiments: WRONG results) read at all.
@@ -1866,7 +2062,94 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.lds_first = (int32_t)bnb_lds_first(L, pool_lds);
   const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
   const bool second_kernel = P.rot_list && (P.debug == 0 || (P.debug >= 3 && P.debug < 26));
+  // Large batches: the split form, in rounds of as many pairs as the workspace holds state for.
+  // NHIP_BNB_SPLIT=0: never, =1: whenever the workspace allows; NHIP_BNB_SPLIT_MIN=<candidates per additional
+  // workgroup of a pair>, NHIP_BNB_SPLIT_MAX=<workgroups per pair>.
+  const char *sp = getenv("NHIP_BNB_SPLIT");
+  const char *smin = getenv("NHIP_BNB_SPLIT_MIN");
+  const char *smax = getenv("NHIP_BNB_SPLIT_MAX");
+  const char *sbat = getenv("NHIP_BNB_SPLIT_BATCH");
+  const char *sov = getenv("NHIP_BNB_SPLIT_OVERLAP");
+  int64_t split_batch = 0, split_slots = 0, slot_bytes = 0;
+  if (d_workspace && !P.general_all && !P.rot_list && P.debug == 0 && !(sp && sp[0] == '0') &&
+      (n_pairs >= SPLIT_MIN_PAIRS || (sp && sp[0] == '1'))) {
+    split_batch = sbat && atoi(sbat) > 0 ? atoi(sbat) : SPLIT_BATCH;
+    if (split_batch > n_pairs) split_batch = n_pairs;
+    for (;;) {  // (a workspace too small for two batches in flight: smaller batches, down to 512 pairs)
+      slot_bytes = (SPLIT_SLOT_FIXED + split_batch * split_bytes_per_pair(P.n_theta) + 511) & ~(int64_t)511;
+      split_slots = (workspace_bytes - BNB_WS_HEADER - 512) / slot_bytes;
+      const int64_t rounds = (n_pairs + split_batch - 1) / split_batch;
+      if (split_slots >= (rounds < 2 ? rounds : 2) || split_batch <= 512) break;
+      split_batch = split_batch / 2 > 512 ? split_batch / 2 : 512;
+    }
+    if (split_slots > SPLIT_RING) split_slots = SPLIT_RING;
+    if (split_slots < 1) split_batch = 0;  // (no room: the fused form)
+  }
   timer_begin(NHIP_TIMER_CSM, s);
+  if (split_batch > 0) {
+    // Candidates (bound by the L1's lookups) beside the next batch's bounds (bound by the vector ALUs): the first part
+    // of every batch on the caller's stream, the second on the helper stream, each batch's state in its own slot of the
+    // workspace.  NHIP_BNB_SPLIT_OVERLAP=0: everything on the caller's stream.
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    const bool overlap = !(sov && sov[0] == '0') && split_slots >= 2 && n_pairs > split_batch;
+    if (overlap && !g_split_stream) {
+      NHIP_TRY_HIP(hipStreamCreateWithFlags(&g_split_stream, hipStreamNonBlocking));
+      for (int i = 0; i < SPLIT_RING; i++) {
+        NHIP_TRY_HIP(hipEventCreateWithFlags(&g_split_ea[i], hipEventDisableTiming));
+        NHIP_TRY_HIP(hipEventCreateWithFlags(&g_split_eb[i], hipEventDisableTiming));
+      }
+    }
+    hipStream_t s2 = overlap ? g_split_stream : s;
+    uint8_t *base = static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER;
+    base += (512 - (reinterpret_cast<uintptr_t>(base) & 511)) & 511;
+    int64_t round = 0;
+    for (int64_t b0 = 0; b0 < n_pairs; b0 += split_batch, round++) {
+      const int32_t nb = (int32_t)(n_pairs - b0 < split_batch ? n_pairs - b0 : split_batch);
+      BnbParams Q = P;
+      Q.pair_src += b0;
+      Q.pair_slot += b0;
+      Q.rot0_cs += 2 * b0;
+      if (Q.pair_origin) Q.pair_origin += 2 * b0;
+      Q.keys += b0;
+      Q.n_pairs = nb;
+      Q.pairs_per_xcd = (nb + 7) / 8;
+      Q.ps_work_stride = Q.pairs_per_xcd + (Q.pairs_per_xcd / 2 > 64 ? Q.pairs_per_xcd / 2 : 64);
+      Q.split_min = smin ? (uint32_t)(atoi(smin) > 0 ? atoi(smin) : 1) : 400u;
+      Q.split_max = smax ? (uint32_t)(atoi(smax) > 0 ? atoi(smax) : 1) : 8u;
+      uint8_t *w = base + (round % split_slots) * slot_bytes;
+      Q.ps_count = reinterpret_cast<uint32_t *>(w);
+      Q.ps_live = Q.ps_count + nb;
+      Q.ps_next = Q.ps_live + nb;
+      Q.ps_nw = Q.ps_next + nb;
+      Q.ps_work = reinterpret_cast<int32_t *>(Q.ps_nw + nb);
+      const uintptr_t rows = (reinterpret_cast<uintptr_t>(Q.ps_work + 8 * (size_t)Q.ps_work_stride) + 511) & ~(uintptr_t)511;
+      Q.ps_rows = reinterpret_cast<uint32_t *>(rows);
+      NHIP_REQUIRE((int64_t)(rows - reinterpret_cast<uintptr_t>(w)) + (int64_t)nb * P.n_theta * 512 <= slot_bytes &&
+                       w + slot_bytes <= static_cast<uint8_t *>(d_workspace) + workspace_bytes,
+                   "csm_bnb: workspace accounting");
+      // (the slot's previous batch must be through its candidates)
+      if (overlap && round >= split_slots) NHIP_TRY_HIP(hipStreamWaitEvent(s, g_split_eb[(round - split_slots) % SPLIT_RING], 0));
+      NHIP_TRY_HIP(hipMemsetAsync(w, 0, 16 * (size_t)nb, s));
+      const int64_t blocks_b = (int64_t)Q.pairs_per_xcd * 8;
+      int rc = instr ? bnb::launch_bnb_split_a_instr(Q, L.cb, pool_lds, lds, blocks_b, s)
+                     : bnb::launch_bnb_split_a(Q, L.cb, pool_lds, lds, blocks_b, s);
+      if (rc) return rc;
+      if (overlap) {
+        NHIP_TRY_HIP(hipEventRecord(g_split_ea[round % SPLIT_RING], s));
+        NHIP_TRY_HIP(hipStreamWaitEvent(s2, g_split_ea[round % SPLIT_RING], 0));
+      }
+      rc = instr ? bnb::launch_bnb_split_b_instr(Q, L.cb, s2) : bnb::launch_bnb_split_b(Q, L.cb, s2);
+      if (rc) return rc;
+      if (overlap) NHIP_TRY_HIP(hipEventRecord(g_split_eb[round % SPLIT_RING], s2));
+    }
+    // (the helper stream works in order: its last batch done, all are)
+    if (overlap) NHIP_TRY_HIP(hipStreamWaitEvent(s, g_split_eb[(round - 1) % SPLIT_RING], 0));
+    timer_end(NHIP_TIMER_CSM, s);
+    NHIP_TRY_HIP(hipGetLastError());
+    launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
+    NHIP_TRY_HIP(hipGetLastError());
+    return NHIP_OK;
+  }
   // (Tried and removed: the batch as K launches on K streams, so that one hardware queue's in-order dispatch does not
   //  keep free slots empty -- 2 / 4 / 8 queues took 10 / 30 / 45 % longer, gpurun_out r3_queues_ab.log.)
   const int rc = instr ? bnb::launch_bnb_kernels_instr(P, L.cb, pool_lds, lds, blocks, second_kernel, s)

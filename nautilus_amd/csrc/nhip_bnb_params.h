@@ -30,6 +30,18 @@ struct BnbParams {
   uint32_t rot_cap;           //   counters {filled, next}; entries per list
   uint32_t heavy_min;         // candidates (after the seeds) from which a PAIR hands its rotations over ...
   uint32_t keep_ranks;        // ... except its first keep_ranks rotations in best-first order (one per wave)
+  // Split form (large batches): the workgroup of a pair ends after bounds and seeds and leaves its state -- per live
+  // rotation, best first, the 128-word row of block bounds (word 126: the rotation's highest bound, word 127: the
+  // rotation) -- in the caller's workspace; the candidates are worked by a second launch, heaviest pairs first.
+  uint32_t *ps_rows;    // [pair][rank][128]; null = the fused form
+  uint32_t *ps_count;   // [pair] candidate blocks the seeds have left
+  uint32_t *ps_live;    // [pair] rotations with at least one of them
+  uint32_t *ps_next;    // [pair] next rank to hand out (pairs worked by several workgroups)
+  uint32_t *ps_nw;      // [pair] workgroups of the second launch that share the pair
+  int32_t *ps_work;     // [8][ps_work_stride] pair of each workgroup of the second launch (-1: none), per XCD
+  int32_t ps_work_stride;
+  uint32_t split_min;   // candidates per additional workgroup of a pair
+  uint32_t split_max;   // workgroups per pair at most
   int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
   int32_t S, pad, pitch, rows, max_shift;
   int32_t pool_pitch, pool_rows, pairs_per_xcd;
@@ -40,7 +52,10 @@ struct BnbParams {
   int32_t levels;  // 2: candidates are refined through the 4 x 4 sub-block bounds; 1: evaluated whole (NHIP_BNB_LEVELS)
   int32_t debug;   // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only,
                    // 4 = phase 3 without exact sums, 5 = phase 3 without sub-block bounds and exact sums,
-                   // 26 / 27 = bounds only, without their reductions / gathers
+                   // 26 / 27 = bounds only, without their reductions / gathers; 28 = without the run lists too,
+                   // 29 = without the window origins too, 30 = no chunk loop, 31 = no rotations (staging + launch).
+                   // With NHIP_BNB_STATS=1 the counters' atomics dominate the short forms: time those as product
+                   // builds with -DNHIP_BNB_EXPERIMENT=<value> (tools/bnb_variants.sh)
   int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes, pool4_bytes;
   int64_t hi_offset, hi_bytes;  // 16-bit grids: the plane of high bytes inside a slot
   int32_t hi_pitch;
@@ -54,6 +69,12 @@ int launch_bnb_kernels(const BnbParams &P, int cb, bool pool_lds, size_t lds, in
                        hipStream_t s);
 int launch_bnb_kernels_instr(const BnbParams &P, int cb, bool pool_lds, size_t lds, int64_t blocks, bool second_kernel,
                              hipStream_t s);
+// The split form (P.ps_rows set) on one batch: bounds + seeds + the ordering of the pairs by candidates left (a),
+// then the candidates (b; on any stream ordered behind a).
+int launch_bnb_split_a(const BnbParams &P, int cb, bool pool_lds, size_t lds, int64_t blocks, hipStream_t s);
+int launch_bnb_split_a_instr(const BnbParams &P, int cb, bool pool_lds, size_t lds, int64_t blocks, hipStream_t s);
+int launch_bnb_split_b(const BnbParams &P, int cb, hipStream_t s);
+int launch_bnb_split_b_instr(const BnbParams &P, int cb, hipStream_t s);
 
 }  // namespace bnb
 }  // namespace nhip

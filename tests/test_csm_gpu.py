@@ -29,11 +29,19 @@ def _check_pairs(scans_list, target_ids, pair_src, pair_slot, theta0, spec, ospe
     # rotations to a second kernel (<= 64 pairs: every pair does); NHIP_BNB_KERNELS=1 keeps everything in the pair's
     # workgroup, =2 hands over in any batch; the single kernel works rotation by rotation with register-held origins
     # for scans of <= 1088 points and through the workgroup queue otherwise (NHIP_BNB_QUEUE=1: always);
-    # NHIP_BNB_LEVELS=1 leaves out the sub-block bounds
+    # NHIP_BNB_LEVELS=1 leaves out the sub-block bounds.  Batches of >= 1024 pairs take the split form (bounds + seeds,
+    # then the candidates of the pairs ordered by how many are left, the heaviest shared by several workgroups);
+    # NHIP_BNB_SPLIT=1 brings it to small batches: in one round, or in rounds of three pairs whose candidates run on the
+    # helper stream beside the next round's bounds, every pair shared by up to five workgroups
     import os
     for env in ({"NHIP_BNB_KERNELS": "1"}, {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_LEVELS": "1"},
                 {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_QUEUE": "1"}, {"NHIP_BNB_KERNELS": "2", "NHIP_BNB_LEVELS": "1"},
-                {"NHIP_BNB_KERNELS": "2", "NHIP_BNB_HEAVY_MIN": "1", "NHIP_BNB_KEEP_RANKS": "0"}):
+                {"NHIP_BNB_KERNELS": "2", "NHIP_BNB_HEAVY_MIN": "1", "NHIP_BNB_KEEP_RANKS": "0"},
+                {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_SPLIT": "1"},
+                {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_SPLIT": "1", "NHIP_BNB_SPLIT_BATCH": "3", "NHIP_BNB_SPLIT_MIN": "1",
+                 "NHIP_BNB_SPLIT_MAX": "5"},
+                {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_SPLIT": "1", "NHIP_BNB_SPLIT_BATCH": "2", "NHIP_BNB_SPLIT_OVERLAP": "0",
+                 "NHIP_BNB_LEVELS": "1"}):
         os.environ.update(env)
         try:
             got_v, sums_v = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, search, origin)
@@ -809,6 +817,19 @@ def test_config2_full_size_16bit_branch_and_bound_equals_every_add(gpu):
     assert torch.equal(full, full_x), "branch and bound differs from the kernel that performs every add (16-bit cells)"
     assert torch.equal(sums, mx.records()[1])
     mx.free_grids()
+    # 10,000 pairs take the split form (bounds + seeds; the pairs ordered by candidates left; the candidates); the fused
+    # form (one workgroup per pair from start to end), and the split form in rounds of 3,000 pairs with the candidates on
+    # the helper stream, return the same records
+    for env in ({"NHIP_BNB_SPLIT": "0"}, {"NHIP_BNB_SPLIT_BATCH": "3000", "NHIP_BNB_SPLIT_MIN": "100"}):
+        os.environ.update(env)
+        try:
+            mf = bench.HipMatcher(wl, plan.shard(0), dev, 16, weights=plan.shard_weights(0))
+            _, full_f = bench.run_sharded(plan, 0, 1, dev, mf, steps=1, warmup=0)
+            assert torch.equal(full, full_f) and torch.equal(sums, mf.records()[1]), env
+            mf.free_grids()
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
     rec = full.cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1)
     hsums = np.empty(wl.n_pairs, np.int32)
     hsums[plan.order] = sums.cpu().numpy()
