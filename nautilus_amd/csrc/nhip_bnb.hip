@@ -47,6 +47,9 @@
 #ifndef NHIP_BNB_P1_PREFETCH
 #define NHIP_BNB_P1_PREFETCH 2  // chunks of points in flight in the bounds phase
 #endif
+#ifndef NHIP_BNB_UNALIGNED
+#define NHIP_BNB_UNALIGNED 0  // 1: exact block sums read their rows at byte addresses (4 / 8 bytes instead of 8 / 12)
+#endif
 #ifndef NHIP_BNB_F32_ORIGINS
 #define NHIP_BNB_F32_ORIGINS 1  // 0: window origins through two double-precision quotients (measurement)
 #endif
@@ -901,15 +904,26 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
 #else
       const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
 #endif
+#if NHIP_BNB_UNALIGNED
+      // (the four bytes of a row from their own address: vector memory takes byte addresses on this target, and the
+      //  address unit's time goes with the dwords a lane loads -- one here, two with the aligned read)
+      sh[j] = 0u;
+#pragma unroll
+      for (int y = 0; y < 4; y++) {
+        w[j][y].x = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(g + (uint32_t)y * pitch), 0, 0);
+        w[j][y].y = 0u;
+      }
+#else
       sh[j] = (g & 3u) * 8u;
 #pragma unroll
       for (int y = 0; y < 4; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
+#endif
     }
 #pragma unroll
     for (int j = 0; j < U; j++)
 #pragma unroll
       for (int y = 0; y < 4; y++) {
-        const uint32_t n = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+        const uint32_t n = NHIP_BNB_UNALIGNED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
         E[y] += n & M8;
         O[y] += n >> 8;
       }
@@ -962,8 +976,8 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
 #else
       const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
 #endif
-      sh[j] = (g & 3u) * 8u;
-      gg[j] = g & ~3u;
+      sh[j] = NHIP_BNB_UNALIGNED ? 0u : (g & 3u) * 8u;
+      gg[j] = NHIP_BNB_UNALIGNED ? g : g & ~3u;
     }
 #pragma unroll
     for (int y0 = 0; y0 < 8; y0 += ROWS) {
@@ -971,13 +985,22 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
 #pragma unroll
       for (int j = 0; j < U; j++)
 #pragma unroll
-        for (int y = 0; y < ROWS; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gg[j] + (uint32_t)(y0 + y) * pitch), 0, 0);
+        for (int y = 0; y < ROWS; y++) {
+#if NHIP_BNB_UNALIGNED
+          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gg[j] + (uint32_t)(y0 + y) * pitch), 0, 0);
+          w[j][y].x = v.x;
+          w[j][y].y = v.y;
+          w[j][y].z = 0u;
+#else
+          w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gg[j] + (uint32_t)(y0 + y) * pitch), 0, 0);
+#endif
+        }
 #pragma unroll
       for (int j = 0; j < U; j++)
 #pragma unroll
         for (int y = 0; y < ROWS; y++) {
-          const uint32_t n0 = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
-          const uint32_t n1 = __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
+          const uint32_t n0 = NHIP_BNB_UNALIGNED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+          const uint32_t n1 = NHIP_BNB_UNALIGNED ? w[j][y].y : __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
           E[y0 + y][0] += n0 & M8; O[y0 + y][0] += n0 >> 8;
           E[y0 + y][1] += n1 & M8; O[y0 + y][1] += n1 >> 8;
         }
@@ -1403,7 +1426,18 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   // Longer scans take the general path below.
   if (BY_ROT) {
     // (the pooled table's space becomes the origins' once every wave is done with its bounds)
+    // Seeds: only the P.seeds waves with the highest bounds evaluate theirs (a whole block costs the memory pipeline
+    // what ~50 sub-block bounds do, and the eight blocks are mostly neighbours in rotation: the lower ones rarely raise
+    // the best).  Each wave leaves its bound in its own, now idle, run list.
+    unsigned long long *s_wbest = reinterpret_cast<unsigned long long *>(s_list + wave * LIST_ENTRIES);
+    if (lane == 0) *s_wbest = wbest;
     __syncthreads();
+    if (P.seeds < BNB_WAVES) {
+      uint32_t above = 0u;
+      for (int w = 0; w < BNB_WAVES; w++)
+        above += *reinterpret_cast<unsigned long long *>(s_list + w * LIST_ENTRIES) > wbest ? 1u : 0u;
+      if (above >= P.seeds) wbest = 0ull;  // (this wave sits the seeds out)
+    }
     uint32_t *org = s_org + wave * ORG_WAVE + lane;
     // (NHIP_BNB_STATS=1: shader-clock sums -- wave time in phase 3 by part, and the workgroup's wall time)
     PhaseClocks clk = {0, 0, 0};
@@ -1680,18 +1714,22 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
 }
 
 // ---- the split form's second and third launch ----------------------------------------------------------------
-// Order of the second launch: per XCD (the pairs of a target stay where its grid is L2-resident) the pairs by the
-// candidates the seeds have left, most first -- with exact knowledge of what is heavy, the hardware's in-order dispatch
-// becomes longest-first list scheduling; the pairs at the head get one more workgroup per P.split_min candidates (they
+// The candidates' launch: per XCD (the pairs of a target stay where its grid is L2-resident) the list of its workgroups'
+// pairs.  The pairs with the most candidates left get one more workgroup per P.split_min of them, up to P.split_max (they
 // share the pair's rotations through ps_next and its best through keys[pair]), as long as the XCD's list has room.
-// One workgroup per XCD segment; buckets of ~19 % width in the count (16 per octave up to 2^20).
+// The list can be ordered by that count, most first (longest-first list scheduling; buckets of 2^sort_coarse
+// sixteenths of an octave) -- measured on the 10,000-pair workload it is not worth it: the candidates' kernel is bound
+// by the vector-memory address unit (TA busy 82 %), the shared heavy pairs leave no tail to hide, and an order by count
+// scatters the pairs of a target in time (L2 misses 4 % -> 30 %): 8.02 ms ordered, 7.78 ms in target order.  So one
+// bucket is the default (sort_coarse = 9).  (sort_coarse = 10, the shared pairs first and the rest in target order:
+// 7.9 ms -- the heavy pairs are better spread over the launch.)  One workgroup per XCD segment.
 constexpr int SORT_THREADS = 1024;
 constexpr int SORT_BUCKETS = 16 * 21;
-__device__ __forceinline__ int cand_bucket(uint32_t c) {  // heaviest = bucket 0
+__device__ __forceinline__ int cand_bucket(uint32_t c, uint32_t coarse) {  // heaviest = bucket 0
   if (c == 0u) return SORT_BUCKETS - 1;
   const int e = 31 - __builtin_clz(c);                  // floor(log2 c)
   const int f = e >= 4 ? (int)((c >> (e - 4)) & 15u) : (int)((c << (4 - e)) & 15u);
-  const int b = 16 * e + f;                              // ascending in c
+  const int b = ((16 * e + f) >> coarse) << coarse;      // ascending in c
   return b >= SORT_BUCKETS - 1 ? 0 : SORT_BUCKETS - 2 - b;
 }
 __device__ __forceinline__ uint32_t cand_shares(const BnbParams &P, uint32_t c) {
@@ -1700,41 +1738,49 @@ __device__ __forceinline__ uint32_t cand_shares(const BnbParams &P, uint32_t c) 
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void csm_bnb_order_kernel(BnbParams P) {
-  __shared__ uint32_t s_pairs[SORT_BUCKETS], s_extra[SORT_BUCKETS], s_off[SORT_BUCKETS], s_cur[SORT_BUCKETS];
+  __shared__ uint32_t s_size[SORT_BUCKETS], s_extra[SORT_BUCKETS], s_off[SORT_BUCKETS], s_cur[SORT_BUCKETS];
   __shared__ int s_grant;
   const int32_t xcd = blockIdx.x;
   const int32_t lo = xcd * P.pairs_per_xcd, hi = min(lo + P.pairs_per_xcd, P.n_pairs);
   int32_t *work = P.ps_work + (size_t)xcd * P.ps_work_stride;
-  for (int i = threadIdx.x; i < SORT_BUCKETS; i += SORT_THREADS) s_pairs[i] = s_extra[i] = s_cur[i] = 0u;
+  for (int i = threadIdx.x; i < SORT_BUCKETS; i += SORT_THREADS) s_size[i] = s_extra[i] = s_cur[i] = 0u;
   for (int i = threadIdx.x; i < P.ps_work_stride; i += SORT_THREADS) work[i] = -1;
   __syncthreads();
+  // additional workgroups are granted by candidate count (fine buckets), from the heaviest pairs down, while the list
+  // has room for a whole bucket's
   for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
     const uint32_t c = P.ps_count[p];
-    const int b = cand_bucket(c);
-    atomicAdd(&s_pairs[b], 1u);
-    atomicAdd(&s_extra[b], cand_shares(P, c) - 1u);
+    atomicAdd(&s_extra[cand_bucket(c, 0u)], cand_shares(P, c) - 1u);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    // additional workgroups are granted bucket by bucket from the heaviest while the list has room for them
     uint32_t room = (uint32_t)P.ps_work_stride - (uint32_t)(hi > lo ? hi - lo : 0);
     int grant = 0;
     while (grant < SORT_BUCKETS && s_extra[grant] <= room) room -= s_extra[grant++];
     s_grant = grant;
+  }
+  __syncthreads();
+  // the list's order: buckets of 2^sort_coarse sixteenths of an octave (9: one bucket, the pairs stay in target order)
+  for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
+    const uint32_t c = P.ps_count[p];
+    const uint32_t w = cand_bucket(c, 0u) < s_grant ? cand_shares(P, c) : 1u;
+    atomicAdd(&s_size[P.sort_coarse == 10u ? (w > 1u ? 0 : 1) : cand_bucket(c, P.sort_coarse)], w);
+    P.ps_nw[p] = w;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
     uint32_t off = 0u;
     for (int b = 0; b < SORT_BUCKETS; b++) {
       s_off[b] = off;
-      off += s_pairs[b] + (b < grant ? s_extra[b] : 0u);
+      off += s_size[b];
     }
   }
   __syncthreads();
   for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
-    const uint32_t c = P.ps_count[p];
-    const int b = cand_bucket(c);
-    const uint32_t w = b < s_grant ? cand_shares(P, c) : 1u;
+    const uint32_t w = P.ps_nw[p];
+    const int b = P.sort_coarse == 10u ? (w > 1u ? 0 : 1) : cand_bucket(P.ps_count[p], P.sort_coarse);  // (10: the shared pairs first)
     const uint32_t at = s_off[b] + atomicAdd(&s_cur[b], w);
     for (uint32_t j = 0; j < w; j++) work[at + j] = p;
-    P.ps_nw[p] = w;
   }
 }
 
@@ -2004,6 +2050,8 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   // Policies that never change the records (tests run the matcher in every form and compare): read per launch.
   const char *lv = getenv("NHIP_BNB_LEVELS");  // (1: without the sub-block bounds)
   P.levels = lv && lv[0] == '1' ? 1 : 2;
+  const char *sd = getenv("NHIP_BNB_SEEDS");  // (waves that evaluate a seed block)
+  P.seeds = sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : 8u;
   const char *wm = getenv("NHIP_BNB_WHOLE_MIN");
   P.whole_min = wm ? atoi(wm) : 3;
   const char *qe = getenv("NHIP_BNB_QUEUE");  // (the general path for every scan)
@@ -2114,8 +2162,10 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
       Q.n_pairs = nb;
       Q.pairs_per_xcd = (nb + 7) / 8;
       Q.ps_work_stride = Q.pairs_per_xcd + (Q.pairs_per_xcd / 2 > 64 ? Q.pairs_per_xcd / 2 : 64);
-      Q.split_min = smin ? (uint32_t)(atoi(smin) > 0 ? atoi(smin) : 1) : 400u;
+      Q.split_min = smin ? (uint32_t)(atoi(smin) > 0 ? atoi(smin) : 1) : 300u;
       Q.split_max = smax ? (uint32_t)(atoi(smax) > 0 ? atoi(smax) : 1) : 8u;
+      const char *sco = getenv("NHIP_BNB_SORT_COARSE");  // (buckets of 2^n sixteenths of an octave: 4 = one per octave)
+      Q.sort_coarse = sco ? (uint32_t)atoi(sco) : 9u;  // (one bucket: see csm_bnb_order_kernel)
       uint8_t *w = base + (round % split_slots) * slot_bytes;
       Q.ps_count = reinterpret_cast<uint32_t *>(w);
       Q.ps_live = Q.ps_count + nb;

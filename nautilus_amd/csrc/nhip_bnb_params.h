@@ -42,6 +42,8 @@ struct BnbParams {
   int32_t ps_work_stride;
   uint32_t split_min;   // candidates per additional workgroup of a pair
   uint32_t split_max;   // workgroups per pair at most
+  uint32_t sort_coarse; // log2 of the width of the ordering's buckets in sixteenths of an octave of the candidate count
+  uint32_t seeds;       // waves of a pair's workgroup that evaluate a seed block (those with the highest bounds)
   int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
   int32_t S, pad, pitch, rows, max_shift;
   int32_t pool_pitch, pool_rows, pairs_per_xcd;
