@@ -363,6 +363,28 @@ def _timer(lib, _lib, tid):
     return ms.value, n.value
 
 
+def kernel_rates(sq, avg_ms):
+    """Rates of one kernel against the units that can bound it: counters per launch (profiles/traffic.json) over the
+    launch time measured live in this run.  VALU: wave64 instructions against 1024 SIMDs x 2.4 GHz / 2 clk; vector L1:
+    tag lookups against one per clock and CU; vector-memory address unit: TA busy cycles (summed over the 256 units)
+    against 256 x 2.4 GHz."""
+    if not sq or not avg_ms:
+        return None
+    secs = avg_ms * 1e-3
+    out = {"avg_launch_ms": avg_ms, "source": sq.get("source")}
+    if "SQ_INSTS_VALU" in sq:
+        out["valu_frac"] = sq["SQ_INSTS_VALU"] / secs / VALU_PEAK_WAVE_INSTR
+    if "TCP_TOTAL_CACHE_ACCESSES_sum" in sq:
+        out["l1_tag_frac"] = sq["TCP_TOTAL_CACHE_ACCESSES_sum"] / secs / (256 * 2.4e9)
+    if "TA_TA_BUSY_sum" in sq:
+        out["ta_busy_frac"] = sq["TA_TA_BUSY_sum"] / secs / (256 * 2.4e9)
+    if "TCC_HIT_sum" in sq and "TCC_MISS_sum" in sq:
+        out["l2_miss_frac"] = sq["TCC_MISS_sum"] / max(sq["TCC_HIT_sum"] + sq["TCC_MISS_sum"], 1.0)
+    if "SQ_WAIT_ANY" in sq and "SQ_WAVE_CYCLES" in sq:
+        out["wave_wait_frac"] = sq["SQ_WAIT_ANY"] / sq["SQ_WAVE_CYCLES"]
+    return out
+
+
 def onchip_roofline(n_pairs, avg_ms, cell_bits, kernel="bnb"):
     """What bounds the match kernel (both are cache / LDS resident: HBM traffic is ~1 % of peak): instruction counts
     per launch come from rocprofv3's SQ counters on this workload (profiles/traffic.json, per 10k-pair launch,
@@ -452,6 +474,8 @@ def worker(a):
     k_ms, k_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
     g_ms, g_n = _timer(lib, _lib, _lib.NHIP_TIMER_GRID)
     c_ms, _ = _timer(lib, _lib, _lib.NHIP_TIMER_GRID_CLEAR)
+    kb_ms, kb_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM_BOUNDS)   # split form of the matcher: its two kernels
+    kc_ms, kc_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM_CAND)
     avg_ms = k_ms / max(k_n, 1)
 
     # per-rank load balance: pairs, targets, correlate-kernel ms per step
@@ -476,8 +500,35 @@ def worker(a):
     alg_bytes = float(m.n_pairs) * lookups_per_pair * cell_bytes  # per launch of rank 0's shard
     hbm_equiv = alg_bytes / (avg_ms * 1e-3) / 1e9
     matches = _profile_matches(wl, m.n_pairs)
-    oc = onchip_roofline(m.n_pairs, avg_ms, a.cell_bits) if matches else None
-    traffic = _traffic("csm_bnb_bytes_per_launch_%dpairs_u%d" % (m.n_pairs, a.cell_bits)) if matches else None
+    split = kb_n > 0 and kc_n > 0
+    cb_tag = a.cell_bits // 8
+    if split:
+        # the matcher is two kernels: bounds + seeds (vector-ALU work on the LDS-resident pooled table) and the
+        # candidates (gathers through the vector L1); the second is the longer one and carries the roofline
+        bounds_avg, cand_avg = kb_ms / kb_n, kc_ms / kc_n
+        sq_b = _traffic("csm_bnb_bounds_sq_per_launch_10000pairs_u%d" % a.cell_bits) if matches else None
+        sq_c = _traffic("csm_bnb_cand_sq_per_launch_10000pairs_u%d" % a.cell_bits) if matches else None
+        rates_b, rates_c = kernel_rates(sq_b, bounds_avg), kernel_rates(sq_c, cand_avg)
+        tb = _traffic("csm_bnb_bounds_bytes_per_launch_10000pairs_u%d" % a.cell_bits) if matches else None
+        tc = _traffic("csm_bnb_cand_bytes_per_launch_10000pairs_u%d" % a.cell_bits) if matches else None
+        traffic = tc
+        oc = None
+        if sq_b and sq_c and "SQ_INSTS_VALU" in sq_b and "SQ_INSTS_VALU" in sq_c:
+            valu = (sq_b["SQ_INSTS_VALU"] + sq_c["SQ_INSTS_VALU"]) / ((bounds_avg + cand_avg) * 1e-3)
+            oc = {"valu_wave_instr_per_s": valu, "valu_peak_wave_instr_per_s": VALU_PEAK_WAVE_INSTR,
+                  "valu_frac": valu / VALU_PEAK_WAVE_INSTR,
+                  "valu_instr_per_launch": sq_b["SQ_INSTS_VALU"] + sq_c["SQ_INSTS_VALU"],
+                  "note": "both kernels of the matcher together (the figure of the rounds that ran it as one kernel)"}
+        matcher = {"form": "split", "ms_per_launch": avg_ms,
+                   "bounds_and_seeds": dict(rates_b or {"avg_launch_ms": bounds_avg}, kernel="csm_bnb_kernel<%d, true, true, true>" % cb_tag,
+                                            launches=kb_n, hbm_bytes_per_launch=tb, bound="valu"),
+                   "candidates": dict(rates_c or {"avg_launch_ms": cand_avg}, kernel="csm_bnb_cand_kernel<%d>" % cb_tag,
+                                      launches=kc_n, hbm_bytes_per_launch=tc, bound="vmem"),
+                   "valu_frac_both_kernels": oc["valu_frac"] if oc else None}
+    else:
+        oc = onchip_roofline(m.n_pairs, avg_ms, a.cell_bits) if matches else None
+        traffic = _traffic("csm_bnb_bytes_per_launch_%dpairs_u%d" % (m.n_pairs, a.cell_bits)) if matches else None
+        matcher = {"form": "fused", "ms_per_launch": avg_ms}
     prof = dict(_traffic_file()[1], workload_matches_profile=matches)
     bnb = None
     if os.environ.get("NHIP_BNB_STATS") == "1" and os.environ.get("NHIP_BNB_INSTRUMENT") == "1":
@@ -511,22 +562,33 @@ def worker(a):
                    "collective": "all_gather 16 B/pair" if world > 1 else "none",
                    "per_rank": [{"pairs": int(r[0]), "targets": int(r[1]), "correlate_ms_per_step": r[2],
                                  "grid_ms_per_step": r[3]} for r in per_rank]},
-        # The dominant kernel (csm_bnb_kernel) has a VALU-bound phase (bounds from the LDS-resident pooled table) and a
-        # phase bound by the vector L1's lookup rate (sub-block bounds and exact sums gathered through L1/L2); the two
-        # overlap between the workgroups of a CU.  It is priced against the vector-instruction peak; the L1 lookup rate
-        # and the HBM traffic (register spills, mostly) are beside it in other_ceilings and onchip_roofline.
-        "roofline": {"bound": "valu", "kernel": "csm_bnb_kernel<%d, true, true>" % cell_bytes, "avg_launch_ms": avg_ms, "launches": k_n,
-                     "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None, "peak": VALU_PEAK_WAVE_INSTR / 1e12,
-                     "unit": "T wave-instr/s", "frac": oc["valu_frac"] if oc else None, "traffic": traffic,
-                     "other_ceilings": {"l1_lookups_per_clk_per_cu": oc.get("l1_tag_frac") if oc else None,
-                                        "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                                        "waves_waiting_frac": oc.get("wave_wait_frac") if oc else None},
-                     "stale": prof["stale"], "profile": prof,
-                     "note": "VALU wave64 instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/traffic.json) / kernel "
-                             "time measured live with HIP events on the launch stream; peak = 1024 SIMDs x 2.4 GHz / 2 clk; "
-                             "traffic = HBM bytes per launch from the PMC passes.  The counters belong to one build and "
-                             "one workload: frac, achieved and traffic are null when traffic.json was taken from other "
-                             "kernel sources (stale) or this run's pair list is not the profiled one"},
+        # The matcher in its split form: the candidates' kernel is the longer of the two and is bound by the vector-memory
+        # pipeline -- its address unit (TA) is busy ~80 % of the launch, the L1 does ~0.7 tag lookups per clock and CU,
+        # the vector ALUs idle; the bounds-and-seeds kernel is priced against the vector-instruction peak beside it.
+        # (Fused form, NHIP_BNB_SPLIT=0 or a workspace without room: one kernel, priced against the VALU peak.)
+        "roofline": ({"bound": "vmem", "kernel": "csm_bnb_cand_kernel<%d>" % cb_tag, "avg_launch_ms": cand_avg, "launches": kc_n,
+                      "achieved": (rates_c["ta_busy_frac"] * 256 * 2.4 if rates_c and "ta_busy_frac" in rates_c else None),
+                      "peak": 256 * 2.4, "unit": "G busy cycles/s of the 256 vector-memory address units (TA_TA_BUSY)",
+                      "frac": rates_c.get("ta_busy_frac") if rates_c else None, "traffic": traffic,
+                      "other_ceilings": {"l1_lookups_per_clk_per_cu": rates_c.get("l1_tag_frac") if rates_c else None,
+                                         "valu_frac": rates_c.get("valu_frac") if rates_c else None,
+                                         "hbm_traffic_frac": (traffic / (cand_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                                         "l2_miss_frac": rates_c.get("l2_miss_frac") if rates_c else None},
+                      "matcher": matcher, "stale": prof["stale"], "profile": prof,
+                      "note": "counters per launch from the rocprofv3 passes in profiles/traffic.json / the kernel's launch "
+                              "time measured live with HIP events on its stream; the counters belong to one build and one "
+                              "workload: the fractions are null when traffic.json was taken from other kernel sources "
+                              "(stale) or this run's pair list is not the profiled one"}
+                     if split else
+                     {"bound": "valu", "kernel": "csm_bnb_kernel<%d, true, true, false>" % cb_tag, "avg_launch_ms": avg_ms, "launches": k_n,
+                      "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None, "peak": VALU_PEAK_WAVE_INSTR / 1e12,
+                      "unit": "T wave-instr/s", "frac": oc["valu_frac"] if oc else None, "traffic": traffic,
+                      "other_ceilings": {"l1_lookups_per_clk_per_cu": oc.get("l1_tag_frac") if oc else None,
+                                         "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                                         "waves_waiting_frac": oc.get("wave_wait_frac") if oc else None},
+                      "matcher": matcher, "stale": prof["stale"], "profile": prof,
+                      "note": "VALU wave64 instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/traffic.json) / kernel "
+                              "time measured live with HIP events on the launch stream; peak = 1024 SIMDs x 2.4 GHz / 2 clk"}),
         # SURVEY 8(d)'s gather-equivalent figure: every lookup of the exhaustive definition priced at one cell.
         # It exceeds the HBM peak because the lookups are served from LDS: NOT a fraction of a physical ceiling.
         "roofline_hbm_equiv": {"bound": "hbm", "achieved": hbm_equiv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -534,7 +596,8 @@ def worker(a):
                                "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
                                "note": "gather-equivalent: lookups x cell bytes / kernel time; hbm_traffic_frac = measured "
                                        "HBM bytes per launch / kernel time / 8 TB/s"},
-        "kernels_ms_per_step": {"csm_match": k_ms / a.steps, "grid_build": g_ms / a.steps,
+        "kernels_ms_per_step": {"csm_match": k_ms / a.steps, "of_which_bounds_and_seeds": kb_ms / a.steps if split else None,
+                                "of_which_candidates": kc_ms / a.steps if split else None, "grid_build": g_ms / a.steps,
                                 "of_which_grid_clear": c_ms / a.steps,
                                 "host_trig_h2d_finalize_gather": 1e3 * elapsed / a.steps - (k_ms + g_ms) / a.steps,
                                 "kernels_share_of_step": (k_ms + g_ms) / (1e3 * elapsed)},
@@ -542,7 +605,7 @@ def worker(a):
         "algorithm": {"name": "branch and bound, exact: bounds of 8x8 blocks of translations from a max-pooled table "
                               "(run-length compressed points), 4x4 sub-block bounds from a second table, exact sums for "
                               "the sub-blocks that remain; indices, sums and scores identical to the exhaustive kernel's "
-                              "(secondary.exhaustive_u8)",
+                              "(secondary.exhaustive_u16 / exhaustive_u8)",
                       "stats": bnb},
     }
     legs = world == 1 and a.mode == "weak"

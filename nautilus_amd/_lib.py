@@ -16,6 +16,7 @@ NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1
 NHIP_SEARCH_EXHAUSTIVE = 1
 NHIP_GRID_SKIP_MAP = 1
 NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ, NHIP_TIMER_GRID_CLEAR = 0, 1, 2, 3, 4, 5
+NHIP_TIMER_CSM_BOUNDS, NHIP_TIMER_CSM_CAND = 6, 7
 
 
 class NhipError(RuntimeError):

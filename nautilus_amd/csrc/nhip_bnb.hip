@@ -800,8 +800,11 @@ __device__ __forceinline__ void cache_origins(const BnbParams &P, const float2 *
 
 // Sub-block bounds of a strip of up to three blocks (Y, X0), (Y, X0 + 1), (Y, X0 + 2): their twelve table bytes are
 // consecutive, ONE 16-byte load per point.  out[4 t + q]: block X0 + t, sub-block q = 2 sy + sx.
+// `len` blocks are wanted (wave-uniform): their 4 len bytes start at a 2-byte-aligned offset, so 8 / 12 / 16 bytes are
+// loaded -- the vector-memory address unit's time goes with the dwords a lane loads, and the candidates are bound by it.
 __device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buffer_rsrc_t p4, const uint32_t *org,
-                                               int32_t nch, int32_t Y, int32_t X0, uint32_t scale, uint32_t (&out)[12]) {
+                                               int32_t nch, int32_t Y, int32_t X0, int len, uint32_t scale,
+                                               uint32_t (&out)[12]) {
   const uint32_t DP = (uint32_t)P.pool4_pitch;
   const uint32_t off = (uint32_t)(2 * Y) * DP + (uint32_t)(4 * X0);
   uint32_t E[3] = {0u, 0u, 0u}, O[3] = {0u, 0u, 0u};  // 16-bit fields: 18 chunks * 255 * 8 lanes < 65536
@@ -814,13 +817,30 @@ __device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buff
     if (H * h >= nch) continue;
     u32x4 w[H];
     uint32_t sh[H];
+    uint32_t aa[H];
 #pragma unroll
     for (int j = 0; j < H; j++) {
       const uint32_t o = origin_of(org, H * h + j);
       // (lanes without a point: origin (0, 0), whose entries lie in the zero border)
       const uint32_t a = (o >> 18) * DP + 2u * ((o >> 2) & 0x3fffu) + off;
       sh[j] = (a & 2u) * 8u;
-      w[j] = __builtin_amdgcn_raw_buffer_load_b128(p4, (int)(a & ~3u), 0, 0);
+      aa[j] = a & ~3u;
+    }
+    if (len == 1) {
+#pragma unroll
+      for (int j = 0; j < H; j++) {
+        const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(p4, (int)aa[j], 0, 0);
+        w[j].x = v.x; w[j].y = v.y; w[j].z = 0u; w[j].w = 0u;
+      }
+    } else if (len == 2) {
+#pragma unroll
+      for (int j = 0; j < H; j++) {
+        const u32x3 v = __builtin_amdgcn_raw_buffer_load_b96(p4, (int)aa[j], 0, 0);
+        w[j].x = v.x; w[j].y = v.y; w[j].z = v.z; w[j].w = 0u;
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < H; j++) w[j] = __builtin_amdgcn_raw_buffer_load_b128(p4, (int)aa[j], 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < H; j++) {
@@ -1251,7 +1271,7 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
     if (BNB_DEBUG(P) == 5) break;  // (timing: origins only)
     if (P.levels >= 2) {
       if (BNB_STATS(P)) t_mark = clock64();
-      strip_bounds_c(P, p4, org, nch, Y, X0, CB == 1 ? 1u : 257u, sb);
+      strip_bounds_c(P, p4, org, nch, Y, X0, len, CB == 1 ? 1u : 257u, sb);
       if (BNB_STATS(P)) clk.strip += clock64() - t_mark;
       n_work[1] += (uint32_t)len;
     } else {
@@ -2181,15 +2201,19 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
       if (overlap && round >= split_slots) NHIP_TRY_HIP(hipStreamWaitEvent(s, g_split_eb[(round - split_slots) % SPLIT_RING], 0));
       NHIP_TRY_HIP(hipMemsetAsync(w, 0, 16 * (size_t)nb, s));
       const int64_t blocks_b = (int64_t)Q.pairs_per_xcd * 8;
+      timer_begin(NHIP_TIMER_CSM_BOUNDS, s);
       int rc = instr ? bnb::launch_bnb_split_a_instr(Q, L.cb, pool_lds, lds, blocks_b, s)
                      : bnb::launch_bnb_split_a(Q, L.cb, pool_lds, lds, blocks_b, s);
       if (rc) return rc;
+      timer_end(NHIP_TIMER_CSM_BOUNDS, s);
       if (overlap) {
         NHIP_TRY_HIP(hipEventRecord(g_split_ea[round % SPLIT_RING], s));
         NHIP_TRY_HIP(hipStreamWaitEvent(s2, g_split_ea[round % SPLIT_RING], 0));
       }
+      timer_begin(NHIP_TIMER_CSM_CAND, s2);
       rc = instr ? bnb::launch_bnb_split_b_instr(Q, L.cb, s2) : bnb::launch_bnb_split_b(Q, L.cb, s2);
       if (rc) return rc;
+      timer_end(NHIP_TIMER_CSM_CAND, s2);
       if (overlap) NHIP_TRY_HIP(hipEventRecord(g_split_eb[round % SPLIT_RING], s2));
     }
     // (the helper stream works in order: its last batch done, all are)

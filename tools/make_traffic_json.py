@@ -44,7 +44,11 @@ out = {"source": "tools/profile_round.sh: rocprofv3 --pmc passes of `bench.py --
                  "bytes = (FETCH_SIZE*2 + WRITE_SIZE)*1024 per dispatch",
        "kernel_source_hash": kernel_source_hash(),
        "workload": {"mode": "weak", "pairs": 10000, "scans": 1000, "per_target": 10}}
-names = {"csm_bnb_kernel<1, true, true>": ("bnb", 8), "csm_bnb_kernel<2, true, true>": ("bnb", 16),
+# the branch-and-bound matcher: fused form (one kernel per 10,000-pair launch; NHIP_BNB_SPLIT=0) or split form (bounds +
+# seeds, then the candidates): whichever the profiled run launched
+names = {"csm_bnb_kernel<1, true, true, false>": ("bnb", 8), "csm_bnb_kernel<2, true, true, false>": ("bnb", 16),
+         "csm_bnb_kernel<1, true, true, true>": ("bnb_bounds", 8), "csm_bnb_kernel<2, true, true, true>": ("bnb_bounds", 16),
+         "csm_bnb_cand_kernel<1>": ("bnb_cand", 8), "csm_bnb_cand_kernel<2>": ("bnb_cand", 16),
          "csm_correlate_kernel<false, false>": ("correlate", 8), "csm_correlate16_kernel<false, false>": ("correlate", 16)}
 for k, (tag, bits) in names.items():
     f, w = med(k, "FETCH_SIZE"), med(k, "WRITE_SIZE")
