@@ -50,6 +50,12 @@
 #ifndef NHIP_BNB_UNALIGNED
 #define NHIP_BNB_UNALIGNED 0  // 1: exact block sums read their rows at byte addresses (4 / 8 bytes instead of 8 / 12)
 #endif
+#ifndef NHIP_BNB_MAX_FIRST
+#define NHIP_BNB_MAX_FIRST 0  // 1: a rotation's candidates highest bound first instead of in block order (measurement)
+#endif
+#ifndef NHIP_BNB_MERGE_ORIGINS
+#define NHIP_BNB_MERGE_ORIGINS 1  // 0: one list entry per point in the candidates' phase (measurement)
+#endif
 #ifndef NHIP_BNB_F32_ORIGINS
 #define NHIP_BNB_F32_ORIGINS 1  // 0: window origins through two double-precision quotients (measurement)
 #endif
@@ -758,44 +764,96 @@ constexpr int OCL = 17;                     // chunks held: 1088 points (a 1081-
 constexpr int ORG_WAVE = OCL * 64;          // words of LDS per wave
 constexpr int ORG_LDS = BNB_WAVES * ORG_WAVE * 4;  // bytes per workgroup (34,816: the 1200 x 1200 grid's pooled table is 35,712)
 
-// (origin of chunk c for this lane; `org` points at the lane's word of chunk 0)
+// Entry format: row << 19 | column << 6 | (points - 1): consecutive beams that fall into the SAME stored cell (a third
+// of a 1081-beam scan's) have the same window origin and read the same bytes in every bound and every exact sum of
+// the rotation; they are kept as one entry with their number, and every sum adds the entry's bytes that many times.
+// 749 entries instead of 1081 points on the bench workload: 12 chunks of loads instead of 17 in everything that
+// follows.  Rows and columns < 8192 (grids up to 8000 cells + border; larger ones take the general kernel).
+constexpr int ORG_COL_SHIFT = 6, ORG_ROW_SHIFT = 19;
+constexpr uint32_t ORG_LIMIT = 1u << 13;
+__device__ __forceinline__ uint32_t org_row(uint32_t o) { return o >> ORG_ROW_SHIFT; }
+__device__ __forceinline__ uint32_t org_col(uint32_t o) { return (o >> ORG_COL_SHIFT) & (ORG_LIMIT - 1u); }
+__device__ __forceinline__ uint32_t org_cnt(uint32_t o) { return (o & 63u) + 1u; }
+
+// (entry of chunk c for this lane; `org` points at the lane's word of chunk 0.  Past the list: row 0, column 0, whose
+//  cells lie in the zero border)
 __device__ __forceinline__ uint32_t origin_of(const uint32_t *org, int c) { return c < OCL ? org[64 * c] : 0u; }
 
-__device__ __forceinline__ void cache_origins(const BnbParams &P, const float2 *pts, int32_t n_pts, float cf, float sf,
-                                              int32_t cx, int32_t cy, int lane, uint32_t *org) {
-  // (rolled: the origin arithmetic holds a division on its rare path.  The points of the next D chunks are in flight
-  //  while one chunk's origins are computed; that array rotates so that its indices stay static.)
-  constexpr int D = 6;
-  float px[D], py[D];
+// Returns the number of 64-entry chunks of the list (wave-uniform).  The packed sums of the bounds and exact sums hold
+// 16-bit fields that are added over 8 lanes before they are unpacked: the points of every aligned group of 8 lanes,
+// over all chunks, must not exceed 257 (257 * 255 = 65,535).  One point per entry keeps that by construction (<= 18
+// chunks); with merged entries the wave checks it and, if a group would pass the limit (hundreds of beams in a few
+// cells), builds the list again with one point per entry.
+// `merged`: 16-bit grids (measured on 10,000 pairs: 7.45 -> 7.38 ms; with 8-bit cells the multiply-adds that replace
+// the adds cost more than the loads save: 6.81 -> 6.93 ms, so those keep one point per entry).
+__device__ __forceinline__ int32_t cache_origins(const BnbParams &P, const float2 *pts, int32_t n_pts, float cf, float sf,
+                                                 int32_t cx, int32_t cy, int lane, uint32_t *org, bool merged) {
+  uint32_t *base = org - lane;  // the wave's list
+  for (int merge = merged && NHIP_BNB_MERGE_ORIGINS ? 1 : 0; merge >= 0; merge--) {
+    // (rolled: the origin arithmetic holds a division on its rare path.  The points of the next D chunks are in flight
+    //  while one chunk's origins are computed; that array rotates so that its indices stay static.)
+    constexpr int D = 6;
+    float px[D], py[D];
 #pragma unroll
-  for (int d = 0; d < D; d++) {
-    const float2 q = 64 * d + lane < n_pts ? pts[64 * d + lane] : make_float2(0.f, 0.f);
-    px[d] = q.x;
-    py[d] = q.y;
-  }
+    for (int d = 0; d < D; d++) {
+      const float2 q = 64 * d + lane < n_pts ? pts[64 * d + lane] : make_float2(0.f, 0.f);
+      px[d] = q.x;
+      py[d] = q.y;
+    }
+    uint32_t tail = 0u;  // entries written (wave-uniform)
 #pragma unroll 1
-  for (int c = 0; c < OCL; c++) {
-    const int32_t idx = 64 * c + lane;
-    const float2 pt = make_float2(px[0], py[0]);
-    const float2 qn = idx + 64 * D < n_pts ? pts[idx + 64 * D] : make_float2(0.f, 0.f);
+    for (int c = 0; c < OCL; c++) {
+      const int32_t idx = 64 * c + lane;
+      if (64 * c >= n_pts) break;
+      const float2 pt = make_float2(px[0], py[0]);
+      const float2 qn = idx + 64 * D < n_pts ? pts[idx + 64 * D] : make_float2(0.f, 0.f);
 #pragma unroll
-    for (int d = 0; d < D - 1; d++) {
-      px[d] = px[d + 1];
-      py[d] = py[d + 1];
+      for (int d = 0; d < D - 1; d++) {
+        px[d] = px[d + 1];
+        py[d] = py[d + 1];
+      }
+      px[D - 1] = qn.x;
+      py[D - 1] = qn.y;
+      const bool live = idx < n_pts;
+      uint32_t o = 0u;
+      if (live) {
+        int32_t prow, pcol;
+        window_origin(pt, cf, sf, P, cx, cy, &prow, &pcol);
+        o = ((uint32_t)prow << ORG_ROW_SHIFT) | ((uint32_t)pcol << ORG_COL_SHIFT);
+      }
+      // runs of equal origins inside the chunk: the predecessor's by a DPP shift across the wave
+      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)o, (int)o, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
+      const bool head = live && (lane == 0 || o != prev || merge == 0);
+      const unsigned long long H = __ballot(head), L = __ballot(live);
+      // run length = distance to the next head, or to the end of the chunk's live lanes
+      const unsigned long long rest = ((H | ~L) >> lane) >> 1;  // (a dead lane ends the run as a head would)
+      const uint32_t cnt = rest ? (uint32_t)__builtin_ctzll(rest) + 1u : (uint32_t)(64 - lane);
+      if (head) {
+        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(H >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)H, 0u));
+        base[tail + before] = o | (cnt - 1u);
+      }
+      tail += (uint32_t)__builtin_popcountll(H);
     }
-    px[D - 1] = qn.x;
-    py[D - 1] = qn.y;
-    uint32_t o = 0u;
-    if (idx < n_pts) {
-      int32_t prow, pcol;
-      window_origin(pt, cf, sf, P, cx, cy, &prow, &pcol);
-      o = ((uint32_t)prow << 16) | (uint32_t)pcol;
+    const int32_t nch = (int32_t)((tail + 63u) >> 6);
+    // (the rest of the list reads as row 0, column 0: the sums below unroll over groups of chunks and may read past nch)
+    for (uint32_t e = tail + (uint32_t)lane; e < (uint32_t)ORG_WAVE; e += 64u) base[e] = 0u;
+    // (the wave reads only its own words back: LDS operations of one wave are performed in order)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (merge == 0) return nch;
+    // the points of this lane's entries, summed over the aligned group of 8 lanes
+    uint32_t w = 0u;
+    for (int c = 0; c < nch; c++) {
+      const uint32_t e = org[64 * c];
+      w += 64u * (uint32_t)c + (uint32_t)lane < tail ? org_cnt(e) : 0u;
     }
-    org[64 * c] = o;
+    w += shfl_xor_u32(w, 1);
+    w += shfl_xor_u32(w, 2);
+    w += shfl_xor_u32(w, 4);
+    if (__ballot(w > 257u) == 0ull) return nch;
+    __builtin_amdgcn_wave_barrier();
   }
-  // (the wave reads only its own words back: LDS operations of one wave are performed in order)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
+  return 0;  // (not reached)
 }
 
 // Sub-block bounds of a strip of up to three blocks (Y, X0), (Y, X0 + 1), (Y, X0 + 2): their twelve table bytes are
@@ -816,15 +874,16 @@ __device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buff
   for (int h = 0; h < NHIP_BNB_STRIP_ROUNDS; h++) {
     if (H * h >= nch) continue;
     u32x4 w[H];
-    uint32_t sh[H];
+    uint32_t sh[H], cn[H];
     uint32_t aa[H];
 #pragma unroll
     for (int j = 0; j < H; j++) {
       const uint32_t o = origin_of(org, H * h + j);
       // (lanes without a point: origin (0, 0), whose entries lie in the zero border)
-      const uint32_t a = (o >> 18) * DP + 2u * ((o >> 2) & 0x3fffu) + off;
+      const uint32_t a = (org_row(o) >> 2) * DP + 2u * (org_col(o) >> 2) + off;
       sh[j] = (a & 2u) * 8u;
       aa[j] = a & ~3u;
+      cn[j] = org_cnt(o);
     }
     if (len == 1) {
 #pragma unroll
@@ -848,9 +907,9 @@ __device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buff
       const uint32_t n1 = __builtin_amdgcn_alignbit(w[j].z, w[j].y, sh[j]);
       const uint32_t n2 = __builtin_amdgcn_alignbit(w[j].w, w[j].z, sh[j]);
       // bytes of n_t: (sy 0, sx 0), (sy 1, sx 0), (sy 0, sx 1), (sy 1, sx 1) of block X0 + t
-      E[0] += n0 & M8; O[0] += (n0 >> 8) & M8;
-      E[1] += n1 & M8; O[1] += (n1 >> 8) & M8;
-      E[2] += n2 & M8; O[2] += (n2 >> 8) & M8;
+      E[0] += __umul24(n0 & M8, cn[j]); O[0] += __umul24((n0 >> 8) & M8, cn[j]);
+      E[1] += __umul24(n1 & M8, cn[j]); O[1] += __umul24((n1 >> 8) & M8, cn[j]);
+      E[2] += __umul24(n2 & M8, cn[j]); O[2] += __umul24((n2 >> 8) & M8, cn[j]);
     }
   }
 #pragma unroll
@@ -915,15 +974,16 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
   for (int r = 0; r < OC / U; r++) {
     if (U * r >= nch) continue;
     u32x2 w[U][4];
-    uint32_t sh[U];
+    uint32_t sh[U], cn[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
       const uint32_t o = origin_of(org, U * r + j);
 #ifdef NHIP_BNB_ROWBAND_EXPERIMENT  // (timing, WRONG results: every 8-row band reads one row -- what a tiled plane could save in L1 lookups)
-      const uint32_t g = ((o >> 16) & ~7u) * pitch + (o & 0xffffu) + off;
+      const uint32_t g = (org_row(o) & ~7u) * pitch + org_col(o) + off;
 #else
-      const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
+      const uint32_t g = org_row(o) * pitch + org_col(o) + off;
 #endif
+      cn[j] = org_cnt(o);
 #if NHIP_BNB_UNALIGNED
       // (the four bytes of a row from their own address: vector memory takes byte addresses on this target, and the
       //  address unit's time goes with the dwords a lane loads -- one here, two with the aligned read)
@@ -944,8 +1004,8 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
 #pragma unroll
       for (int y = 0; y < 4; y++) {
         const uint32_t n = NHIP_BNB_UNALIGNED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
-        E[y] += n & M8;
-        O[y] += n >> 8;
+        E[y] += __umul24(n & M8, cn[j]);
+        O[y] += __umul24(n >> 8, cn[j]);
       }
   }
   uint32_t R[8];  // R[2 y + d]: d = 0: dx 0, 2; d = 1: dx 1, 3
@@ -987,15 +1047,16 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
 #define NHIP_BNB_BLOCK_ROWS 4
 #endif
     constexpr int ROWS = NHIP_BNB_BLOCK_ROWS;
-    uint32_t gg[U], sh[U];
+    uint32_t gg[U], sh[U], cn[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
       const uint32_t o = origin_of(org, U * r + j);
 #ifdef NHIP_BNB_ROWBAND_EXPERIMENT  // (timing, WRONG results: every 8-row band reads one row -- what a tiled plane could save in L1 lookups)
-      const uint32_t g = ((o >> 16) & ~7u) * pitch + (o & 0xffffu) + off;
+      const uint32_t g = (org_row(o) & ~7u) * pitch + org_col(o) + off;
 #else
-      const uint32_t g = (o >> 16) * pitch + (o & 0xffffu) + off;
+      const uint32_t g = org_row(o) * pitch + org_col(o) + off;
 #endif
+      cn[j] = org_cnt(o);
       sh[j] = NHIP_BNB_UNALIGNED ? 0u : (g & 3u) * 8u;
       gg[j] = NHIP_BNB_UNALIGNED ? g : g & ~3u;
     }
@@ -1021,8 +1082,8 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
         for (int y = 0; y < ROWS; y++) {
           const uint32_t n0 = NHIP_BNB_UNALIGNED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
           const uint32_t n1 = NHIP_BNB_UNALIGNED ? w[j][y].y : __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
-          E[y0 + y][0] += n0 & M8; O[y0 + y][0] += n0 >> 8;
-          E[y0 + y][1] += n1 & M8; O[y0 + y][1] += n1 >> 8;
+          E[y0 + y][0] += __umul24(n0 & M8, cn[j]); O[y0 + y][0] += __umul24(n0 >> 8, cn[j]);
+          E[y0 + y][1] += __umul24(n1 & M8, cn[j]); O[y0 + y][1] += __umul24(n1 >> 8, cn[j]);
         }
     }
   }
@@ -1099,7 +1160,7 @@ __device__ __forceinline__ uint32_t pose_sum16(const BnbParams &P, __amdgpu_buff
   for (int c = 0; c < OCL; c++) {
     if (c >= nch) continue;
     const uint32_t o = origin_of(org, c);
-    acc += (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc16, (int)((o >> 16) * pitch + 2u * (o & 0xffffu) + off), 0, 0);
+    acc += org_cnt(o) * (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc16, (int)(org_row(o) * pitch + 2u * org_col(o) + off), 0, 0);
   }
   return wave_sum(acc);
 }
@@ -1242,12 +1303,11 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
                                               unsigned long long m0, unsigned long long m1, int lane,
                                               unsigned long long *best, uint32_t *done, uint32_t *org,
                                               uint32_t (&n_work)[4], PhaseClocks &clk) {
-  const int32_t nch = (C.n_pts + 63) >> 6;
   long long t_mark = 0;
   float cf, sf;
   rotation_k(P, C.pair, k, &cf, &sf);
   if (BNB_STATS(P)) t_mark = clock64();
-  cache_origins(P, C.pts, C.n_pts, cf, sf, C.cx, C.cy, lane, org);
+  const int32_t nch = cache_origins(P, C.pts, C.n_pts, cf, sf, C.cx, C.cy, lane, org, CB == 2);
   if (BNB_STATS(P)) clk.org += clock64() - t_mark;
   // (stored image + skip map: every offset an evaluation can form lies inside; see nhip_api.hip make_layout)
   const __amdgpu_buffer_rsrc_t rsrc16 = uniform_rsrc(C.grid, P.grid_bytes + P.skip_bytes);
@@ -1258,7 +1318,17 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
   const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(C.grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
   // candidates in block order b = NB * Y + X; neighbours in X (up to three) share one pass over the table
   while ((m0 | m1) != 0ull) {
+#if NHIP_BNB_MAX_FIRST
+    // the remaining candidate with the highest bound first (lowest block index among equals): its exact sums are the
+    // likeliest to raise the best, which the others are then checked against
+    const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const uint32_t v0 = ((m0 >> lane_) & 1ull) ? u0 : 0u, v1 = ((m1 >> lane_) & 1ull) ? u1 : 0u;
+    const uint32_t vmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max(v0 > v1 ? v0 : v1));
+    const unsigned long long e0 = __ballot(v0 == vmax && ((m0 >> lane_) & 1ull)), e1 = __ballot(v1 == vmax && ((m1 >> lane_) & 1ull));
+    const int b0 = e0 ? (int)__builtin_ctzll(e0) : 64 + (int)__builtin_ctzll(e1);
+#else
     const int b0 = m0 ? (int)__builtin_ctzll(m0) : 64 + (int)__builtin_ctzll(m1);
+#endif
     const int Y = b0 / NB, X0 = b0 - NB * Y;
     int len = 1;
     while (len < 3 && X0 + len < NB) {
@@ -1356,7 +1426,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   const int32_t cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
   const int32_t cy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
   const bool centre_ok = (abs(cx) + P.hx <= P.max_shift) && (abs(cy) + P.hy <= P.max_shift);
-  if (BY_ROT != (n_pts <= 64 * OCL && !P.general_all)) return;  // the other instantiation's pair
+  if (BY_ROT != (n_pts <= 64 * OCL && (uint32_t)P.rows < ORG_LIMIT && !P.general_all)) return;  // the other instantiation's pair
 
   // pose 0 with sum 0 is a lower bound of the optimum (sums are >= 0; if all are 0, pose 0 is the answer)
   const unsigned long long key0 = 0xffffffffull;
@@ -1811,9 +1881,13 @@ __global__ __launch_bounds__(SORT_THREADS) void csm_bnb_order_kernel(BnbParams P
 #ifndef NHIP_BNB_CAND_OCC
 #define NHIP_BNB_CAND_OCC 4  // waves per SIMD the candidates' kernel is compiled for (register budget 512 / that)
 #endif
+#ifndef NHIP_BNB_CAND_WAVES
+#define NHIP_BNB_CAND_WAVES 4  // waves per workgroup of the candidates' kernel
+#endif
+constexpr int CAND_THREADS = 64 * NHIP_BNB_CAND_WAVES;
 template <int CB>
-__global__ __launch_bounds__(256, NHIP_BNB_CAND_OCC) void csm_bnb_cand_kernel(BnbParams P) {
-  __shared__ uint32_t s_org2[4 * ORG_WAVE];
+__global__ __launch_bounds__(CAND_THREADS, NHIP_BNB_CAND_OCC) void csm_bnb_cand_kernel(BnbParams P) {
+  __shared__ uint32_t s_org2[NHIP_BNB_CAND_WAVES * ORG_WAVE];
   __shared__ unsigned long long s_best2;
   __shared__ uint32_t s_next2;
   const int lane = threadIdx.x & 63;
@@ -1956,8 +2030,15 @@ int launch_bnb_split_b_instr(const BnbParams &P, int cb, hipStream_t s) {
 #else
 int launch_bnb_split_b(const BnbParams &P, int cb, hipStream_t s) {
 #endif
-  if (cb == 1) hipLaunchKernelGGL(csm_bnb_cand_kernel<1>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(256), 0, s, P);
-  else hipLaunchKernelGGL(csm_bnb_cand_kernel<2>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(256), 0, s, P);
+  // (NHIP_BNB_CAND_LDS_PAD=<bytes>, measurement: unused dynamic LDS that lowers the workgroups a CU holds)
+  const char *padv = getenv("NHIP_BNB_CAND_LDS_PAD");
+  const size_t lds_pad = padv ? (size_t)atoi(padv) : 0;
+  if (lds_pad > 0) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_cand_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_cand_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad);
+  }
+  if (cb == 1) hipLaunchKernelGGL(csm_bnb_cand_kernel<1>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(CAND_THREADS), lds_pad, s, P);
+  else hipLaunchKernelGGL(csm_bnb_cand_kernel<2>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(CAND_THREADS), lds_pad, s, P);
   return NHIP_OK;
 }
 
@@ -2073,7 +2154,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const char *sd = getenv("NHIP_BNB_SEEDS");  // (waves that evaluate a seed block)
   P.seeds = sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : 8u;
   const char *wm = getenv("NHIP_BNB_WHOLE_MIN");
-  P.whole_min = wm ? atoi(wm) : 3;
+  P.whole_min = wm ? atoi(wm) : 2;  // (3 -> 2: 7.70 -> 7.45 ms per 10,000 pairs; 1: 7.8, 4: 7.9)
   const char *qe = getenv("NHIP_BNB_QUEUE");  // (the general path for every scan)
   P.general_all = qe && qe[0] == '1';
   P.res = spec->res;
