@@ -327,6 +327,34 @@ def test_swar_fields_do_not_overflow_in_one_alignment_class(gpu):
         assert want["sum"].max() > 255 * 2000
 
 
+@pytest.mark.parametrize("cell_bits", [16, 8])
+def test_beams_piled_into_few_cells(gpu, cell_bits):
+    """The candidates' phase keeps consecutive beams that fall into one stored cell as ONE list entry with a count
+    (16-bit grids) and its packed sums hold 16-bit fields over groups of 8 lanes: at most 257 points per group.  Scans
+    whose beams pile up -- all 1081 in one cell; runs of 60-64 beams per cell (entries of count 60+ in neighbouring
+    lanes: the wave must fall back to one point per entry); alternating long and short runs; the same with the walls
+    of a real scan behind them -- give the oracle's records in every form of the matcher."""
+    rng = np.random.default_rng(5)
+    res = 0.05
+    one_cell = np.tile(np.array([[3.0 + 0.01, -2.0 + 0.01]], np.float32), (1081, 1))
+    runs = np.repeat(np.stack([(np.arange(18) * 3 + 0.5) * res + 1.0, np.full(18, 2.0125)], 1), 60, axis=0)[:1081].astype(np.float32)
+    mixed = []
+    for i in range(40):
+        k = 64 if i % 2 == 0 else 3
+        mixed.append(np.tile(np.array([[(i * 2 + 0.5) * res - 2.0, (i % 7 + 0.5) * res + 1.0]]), (k, 1)))
+    mixed = np.concatenate(mixed).astype(np.float32)[:1081]
+    bag = synth.SynthBag(3, dense=True)
+    piled = np.concatenate([np.tile(bag.scans[0][:1], (500, 1)), bag.scans[0][500:]]).astype(np.float32)
+    jitter = (one_cell + rng.uniform(0, 0.002, one_cell.shape)).astype(np.float32)   # same cell, different floats
+    scans = [one_cell, runs, mixed, piled, jitter, bag.scans[1], bag.scans[0]]
+    spec, ospec = _specs(cell_bits=cell_bits)
+    src = [0, 1, 2, 3, 4, 0, 1, 2, 3, 4, 6, 5]
+    slot = [0, 1, 2, 3, 0, 5, 5, 6, 6, 3, 3, 6]
+    th = [0.0, 0.01, -0.02, 0.03, 0.0, 0.3, -0.3, 0.1, 0.02, -0.01, 0.0, 0.05]
+    got, want = _check_pairs(scans, list(range(7)), src, slot, th, spec, ospec, csm.search_spec(61, 81, 81, DEG))
+    assert want["sum"][0] > 1000 * (200 if cell_bits == 8 else 50000)   # 1081 points on the peak of their own blur
+
+
 def test_non_finite_points_are_off_grid(gpu, small_bag):
     """NaN / inf / absurd coordinates (a broken range reading) never fault and never score: dropped
     from a target raster, floor-only as source points -- same answer as the oracle."""
