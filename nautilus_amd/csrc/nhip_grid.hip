@@ -398,23 +398,28 @@ __global__ __launch_bounds__(256) void grid_pool_kernel(const uint8_t *__restric
 // level-2 windows [4a, 4a + 7) x [4b, 4b + 7), a = 2i .. 2i + 2, b = 2j .. 2j + 2, and a maximum of maxima is the
 // maximum (ceil(. / 257) is monotone, so the scaled bytes of 16-bit cells commute with it too): the 36 KB table is
 // derived from the 286 KB one instead of from a second pass over the image (0.37 -> 0.03 ms per 1000 targets).
-__global__ __launch_bounds__(256) void grid_pool8_from_pool4_kernel(uint8_t *__restrict__ grids, int32_t rows, int64_t pool_offset,
-                                                                    int64_t pool4_offset, int64_t slot_bytes, int32_t pool_pitch,
-                                                                    int32_t pool4_pitch, int32_t t_base) {
-  const int32_t t = t_base + blockIdx.z, i = blockIdx.y, j = blockIdx.x * 256 + threadIdx.x;
+__global__ __launch_bounds__(64) void grid_pool8_from_pool4_kernel(uint8_t *__restrict__ grids, int32_t rows, int64_t pool_offset,
+                                                                   int64_t pool4_offset, int64_t slot_bytes, int32_t pool_pitch,
+                                                                   int32_t pool4_pitch, int32_t t_base) {
+  // one thread per four entries (i, 4q .. 4q + 3): five dwords of each of three level-2 rows in, one dword out
+  const int32_t t = t_base + blockIdx.z, i = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
   const int32_t n8 = (rows + BNB_B - 1) / BNB_B;  // pooled rows = pooled columns (square image)
-  if (i >= n8 || j >= n8) return;
+  if (i >= n8 || 4 * q >= n8) return;
   uint8_t *g = grids + (size_t)t * slot_bytes;
   const uint8_t *p4 = g + pool4_offset;
-  uint32_t m = 0u;
+  uint32_t m[4] = {0u, 0u, 0u, 0u};
 #pragma unroll
   for (int da = 0; da < 3; da++) {
-    // byte (a, 2 b) = P4[a][b]: b = 2j, 2j + 1, 2j + 2 are bytes 4j, 4j + 2, 4j + 4 of row a
-    const uint32_t *row = reinterpret_cast<const uint32_t *>(p4 + (size_t)(2 * i + da) * pool4_pitch) + j;
-    const uint32_t w0 = row[0], w1 = row[1];
-    m = max(m, max(max(w0 & 0xffu, (w0 >> 16) & 0xffu), w1 & 0xffu));
+    // byte (a, 2 b) = P4[a][b]: for entry j, b = 2j, 2j + 1, 2j + 2 are bytes 4j, 4j + 2, 4j + 4 of row a
+    const uint32_t *row = reinterpret_cast<const uint32_t *>(p4 + (size_t)(2 * i + da) * pool4_pitch) + 4 * q;
+    uint32_t w[5];
+#pragma unroll
+    for (int d = 0; d < 5; d++) w[d] = row[d];
+#pragma unroll
+    for (int e = 0; e < 4; e++) m[e] = max(m[e], max(max(w[e] & 0xffu, (w[e] >> 16) & 0xffu), w[e + 1] & 0xffu));
   }
-  g[pool_offset + (size_t)i * pool_pitch + j] = (uint8_t)m;
+  // (entries past the table's n8 columns come out 0: their level-2 bytes are)
+  *reinterpret_cast<uint32_t *>(g + pool_offset + (size_t)i * pool_pitch + 4 * q) = m[0] | (m[1] << 8) | (m[2] << 16) | (m[3] << 24);
 }
 
 // ---- incremental rebuild ---------------------------------------------------------------------------------
@@ -505,7 +510,7 @@ void launch_pool8_from_pool4(uint8_t *g, const GridLayout &L, int32_t n, hipStre
   const int64_t off8 = L.grid_bytes + L.skip_bytes, off4 = off8 + L.pool_bytes;
   for (int32_t z0 = 0; z0 < n; z0 += 65535) {  // gridDim.z is limited to 65,535
     const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
-    hipLaunchKernelGGL(grid_pool8_from_pool4_kernel, dim3((n8 + 255) / 256, n8, nz), dim3(256), 0, s, g, rows, off8, off4,
+    hipLaunchKernelGGL(grid_pool8_from_pool4_kernel, dim3((n8 + 255) / 256, n8, nz), dim3(64), 0, s, g, rows, off8, off4,
                        L.slot_bytes, L.pool_pitch, L.pool4_pitch, z0);
   }
 }
