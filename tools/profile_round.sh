@@ -24,7 +24,7 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_
 rocprofv3 --pmc SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH SQ_INSTS_VMEM_RD SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY --output-format csv -d $OUT/sq2 -- $BENCH > /dev/null 2> $OUT/sq2.log
 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/l1 -- $BENCH > /dev/null 2> $OUT/l1.log
 rocprofv3 --pmc TA_TA_BUSY_sum TA_BUFFER_WAVEFRONTS_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum --output-format csv -d $OUT/ta -- $BENCH > /dev/null 2> $OUT/ta.log
-for p in sq1 sq2 l1 ta; do python3 $R/tools/rocprof_summary.py $OUT/$p --pmc | grep -A9 "csm_\|resid_lidar_kernel<0, true>" >> $OUT/pmc_sq.txt || true; done
+for p in sq1 sq2 l1 ta; do python3 $R/tools/rocprof_summary.py $OUT/$p --pmc | grep -A9 "csm_\|resid_lidar_kernel<0, true>\|corr_search_kernel\|resid_normal_eq_kernel\|grid_blur_kernel\|grid_pool_kernel" >> $OUT/pmc_sq.txt || true; done
 python3 $R/tools/make_traffic_json.py $OUT > $OUT/traffic.json
 rm -rf $OUT/kt $OUT/pmc_FETCH_SIZE $OUT/pmc_WRITE_SIZE $OUT/sq1 $OUT/sq2 $OUT/l1 $OUT/ta
 ls -la $OUT
