@@ -1866,6 +1866,42 @@ __global__ __launch_bounds__(SORT_THREADS) void csm_bnb_order_kernel(BnbParams P
     }
   }
   __syncthreads();
+  if (P.sort_coarse == 9u) {
+    // one bucket: the list in pair order EXACTLY (a prefix sum, not atomics whose order scrambles windows of 1024 pairs):
+    // the workgroups of a target's pairs then run together and share its lines in the XCD's L2
+    __shared__ uint32_t s_wave[SORT_THREADS / 64];
+    __shared__ uint32_t s_base;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (threadIdx.x == 0) s_base = s_off[cand_bucket(1u, 9u)];  // (pairs without candidates sit in the last bucket, after these)
+    __syncthreads();
+    for (int32_t p0 = lo; p0 < hi; p0 += SORT_THREADS) {
+      const int32_t p = p0 + (int32_t)threadIdx.x;
+      const bool in = p < hi && P.ps_count[p] != 0u;
+      const uint32_t w = in ? P.ps_nw[p] : 0u;
+      uint32_t v = w;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t u = (uint32_t)__shfl_up((int)v, off, 64);
+        if (lane >= off) v += u;
+      }
+      if (lane == 63) s_wave[wv] = v;
+      __syncthreads();
+      uint32_t before = s_base;
+      for (int q = 0; q < wv; q++) before += s_wave[q];
+      const uint32_t at = before + v - w;
+      for (uint32_t j = 0; j < w; j++) work[at + j] = p;
+      __syncthreads();
+      if (threadIdx.x == SORT_THREADS - 1) s_base = before + v;
+      __syncthreads();
+    }
+    // (pairs with no candidate left: their workgroups return at once; any order)
+    for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
+      if (P.ps_count[p] != 0u) continue;
+      const int b = cand_bucket(0u, 9u);
+      work[s_off[b] + atomicAdd(&s_cur[b], 1u)] = p;
+    }
+    return;
+  }
   for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
     const uint32_t w = P.ps_nw[p];
     const int b = P.sort_coarse == 10u ? (w > 1u ? 0 : 1) : cand_bucket(P.ps_count[p], P.sort_coarse);  // (10: the shared pairs first)
@@ -2073,18 +2109,24 @@ static unsigned long long *g_bnb_stats = nullptr;
 
 constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, next entry to work}
 // Small batches: room for 16 handed-over rotations per pair on average (what does not fit is worked by the pair's own
-// workgroup).  Large batches (the split form): per pair its four counters, 1.5 entries of the candidates' work list and
-// the rows of bounds of up to 64 rotations, for up to SPLIT_PAIRS pairs at a time (a longer list of pairs, or a search
-// with more rotations, goes through the same workspace in more rounds).
-constexpr int64_t SPLIT_PAIRS = 16384, SPLIT_MIN_PAIRS = 1024, SPLIT_BATCH = SPLIT_PAIRS, SPLIT_RING = 16;
+// workgroup).  The split form: per pair its four counters, 1.5 entries of the candidates' work list and the rows of
+// bounds of up to 64 rotations.  It is used for lists of SPLIT_MIN_PAIRS .. SPLIT_PAIRS pairs, in ONE round: measured
+// (tools/bnb_size_ab.sh, gpurun_out r4i_size.log) 3,000 pairs fused 4.8 / split 5.3 ms, 10,000 pairs 8.2 / 7.3,
+// 40,000 pairs 29.1 / 26.7 in one round but 29.9 in rounds of 16,384 (every round pays its own tail), 1,000,000 pairs
+// with 100 per target 612 fused / 868 in rounds -- so longer lists, which also profit most from the fused form's L2
+// locality, stay fused.  (Rounds exist for tests and measurements: NHIP_BNB_SPLIT_BATCH.)
+constexpr int64_t SPLIT_PAIRS = 65536, SPLIT_MIN_PAIRS = 6144, SPLIT_RING = 16;
 int64_t split_bytes_per_pair(int32_t n_theta) { return 16 + 6 + (int64_t)n_theta * 512; }
 constexpr int64_t SPLIT_SLOT_FIXED = 8 * 64 * 4 + 1024;  // per batch: the work lists' floor of 64 extra entries, alignment
 int64_t bnb_workspace_bytes(int32_t n_pairs) {
   const int64_t n = n_pairs > 0 ? n_pairs : 0;
   const int64_t lists = BNB_WS_HEADER + 8 * (((n + 7) / 8) * 16 + 64) * (int64_t)sizeof(RotEntry);
   const char *sp = getenv("NHIP_BNB_SPLIT");  // (=1: the split form for small batches too -- tests)
-  const int64_t m = n < SPLIT_PAIRS ? n : SPLIT_PAIRS;
-  const int64_t split = n >= SPLIT_MIN_PAIRS || (n > 0 && sp && sp[0] == '1')
+  const char *spp = getenv("NHIP_BNB_SPLIT_PAIRS");  // (measurement: pairs the workspace holds state for)
+  const int64_t cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
+  const int64_t m = n < cap ? n : cap;
+  const bool forced = n > 0 && ((sp && sp[0] == '1') || getenv("NHIP_BNB_SPLIT_BATCH"));
+  const int64_t split = (n >= SPLIT_MIN_PAIRS && n <= cap) || forced
                             ? BNB_WS_HEADER + (m / 512 + 2) * SPLIT_SLOT_FIXED + m * split_bytes_per_pair(64) : 0;
   return lists > split ? lists : split;
 }
@@ -2220,9 +2262,11 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const char *sbat = getenv("NHIP_BNB_SPLIT_BATCH");
   const char *sov = getenv("NHIP_BNB_SPLIT_OVERLAP");
   int64_t split_batch = 0, split_slots = 0, slot_bytes = 0;
+  const char *spp = getenv("NHIP_BNB_SPLIT_PAIRS");
+  const int64_t split_cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
   if (d_workspace && !P.general_all && !P.rot_list && P.debug == 0 && !(sp && sp[0] == '0') &&
-      (n_pairs >= SPLIT_MIN_PAIRS || (sp && sp[0] == '1'))) {
-    split_batch = sbat && atoi(sbat) > 0 ? atoi(sbat) : SPLIT_BATCH;
+      ((n_pairs >= SPLIT_MIN_PAIRS && (n_pairs <= split_cap || sbat)) || (sp && sp[0] == '1'))) {
+    split_batch = sbat && atoi(sbat) > 0 ? atoi(sbat) : split_cap;
     if (split_batch > n_pairs) split_batch = n_pairs;
     for (;;) {  // (a workspace too small for two batches in flight: smaller batches, down to 512 pairs)
       slot_bytes = (SPLIT_SLOT_FIXED + split_batch * split_bytes_per_pair(P.n_theta) + 511) & ~(int64_t)511;
