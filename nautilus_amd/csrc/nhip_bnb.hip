@@ -56,6 +56,9 @@
 #ifndef NHIP_BNB_MERGE_ORIGINS
 #define NHIP_BNB_MERGE_ORIGINS 1  // 0: one list entry per point in the candidates' phase (measurement)
 #endif
+#ifndef NHIP_BNB_WAVE_SLOW_PATH
+#define NHIP_BNB_WAVE_SLOW_PATH 1  // window origins: one wave-level test for the double-precision path (0: per-lane nesting)
+#endif
 #ifndef NHIP_BNB_F32_ORIGINS
 #define NHIP_BNB_F32_ORIGINS 1  // 0: window origins through two double-precision quotients (measurement)
 #endif
@@ -103,7 +106,7 @@ constexpr int BNB_STATS_HEAD = 16;       // totals: 4 counts, then shader-clock 
 // (twice the bound; about one coordinate in 2,000 on the 1200-cell grid) take the double-precision path, so the result
 // is the spec's, always.  From |m| >= 2^22 on (no fraction bits left to test) the cell is far outside any grid
 // (sides <= 16384) on either path and the clamp decides; v_cvt_i32_f32 saturates.
-__device__ __forceinline__ int32_t cell_floor(float v, const BnbParams &P, int32_t lo, int32_t hi) {
+__device__ __forceinline__ __attribute__((unused)) int32_t cell_floor(float v, const BnbParams &P, int32_t lo, int32_t hi) {
   const float m = __fmul_rn(v, P.inv_res_f);
   const float f = floorf(m);
   const float frac = __fsub_rn(m, f);  // exact
@@ -122,14 +125,39 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
                                               int32_t *prow, int32_t *pcol) {
   const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
   const float yr = __fadd_rn(__fmul_rn(sf, q.x), __fmul_rn(cf, q.y));
-  int32_t col = -P.hx - 1, row = -P.hy - 1;  // non-finite points score nothing
-  if ((fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f)) {
-    // col = clamp(S / 2 + floor(xr / res) + cx, -hx - 1, S + hx), as window_cell of nhip_csm.hip -- with the clamp
-    // applied to the quotient's floor, so that everything stays in 32-bit arithmetic
-    const int32_t half = P.S / 2;
-    col = half + cell_floor(xr, P, -P.hx - 1 - half - cx, P.S + P.hx - half - cx) + cx;
-    row = half + cell_floor(yr, P, -P.hy - 1 - half - cy, P.S + P.hy - half - cy) + cy;
+  const int32_t half = P.S / 2;
+  const bool finite = (fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f);
+  int32_t ix, iy;
+#if NHIP_BNB_F32_ORIGINS && NHIP_BNB_WAVE_SLOW_PATH
+  // cell_floor of both coordinates with ONE test for the rare path, taken by the wave only if some lane needs it
+  // (about one chunk in 16): the straight-line code has no nested exec masks.  A lane is "near" when either quotient
+  // lies within |m| * 2^-22 of an integer -- which includes every |m| >= 2^22 (no fraction bits left), whose floors
+  // the double-precision path then takes like any other.
+  const float mx = __fmul_rn(xr, P.inv_res_f), my = __fmul_rn(yr, P.inv_res_f);
+  const float fx = floorf(mx), fy = floorf(my);
+  const float rx = __fsub_rn(mx, fx), ry = __fsub_rn(my, fy);  // exact
+  const bool near = fminf(rx, __fsub_rn(1.0f, rx)) <= __fmul_rn(fabsf(mx), 0x1p-22f) ||
+                    fminf(ry, __fsub_rn(1.0f, ry)) <= __fmul_rn(fabsf(my), 0x1p-22f);
+  ix = (int32_t)fx;
+  iy = (int32_t)fy;
+  if (__builtin_amdgcn_ballot_w64(near && finite) != 0ull) {
+    if (near && finite) {
+      ix = (int32_t)fmin(fmax(floor_quotient((double)xr, P.res, P.inv_res), -2147483000.0), 2147483000.0);
+      iy = (int32_t)fmin(fmax(floor_quotient((double)yr, P.res, P.inv_res), -2147483000.0), 2147483000.0);
+    }
   }
+  ix = min(max(ix, -P.hx - 1 - half - cx), P.S + P.hx - half - cx);
+  iy = min(max(iy, -P.hy - 1 - half - cy), P.S + P.hy - half - cy);
+#else
+  ix = iy = 0;
+  if (finite) {
+    ix = cell_floor(xr, P, -P.hx - 1 - half - cx, P.S + P.hx - half - cx);
+    iy = cell_floor(yr, P, -P.hy - 1 - half - cy, P.S + P.hy - half - cy);
+  }
+#endif
+  // col = clamp(S / 2 + floor(xr / res) + cx, -hx - 1, S + hx), as window_cell of nhip_csm.hip -- with the clamp
+  // applied to the quotient's floor, so that everything stays in 32-bit arithmetic; non-finite points score nothing
+  const int32_t col = finite ? half + ix + cx : -P.hx - 1, row = finite ? half + iy + cy : -P.hy - 1;
   *pcol = col - P.hx + P.pad;
   *prow = row - P.hy + P.pad;
 }
@@ -368,7 +396,9 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
       const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
 #endif
       const bool is_head = (lane & (RUN_MAX - 1)) == 0 || a != prev;
-      const unsigned long long H = __ballot(is_head);
+      // (the lane masks straight from the compares: a ballot of the bools goes through a 0 / 1 register and back)
+      constexpr unsigned long long GROUP_HEADS = RUN_MAX == 64 ? 1ull : (RUN_MAX == 16 ? 0x0001000100010001ull : 0x0101010101010101ull);
+      const unsigned long long H = __builtin_amdgcn_uicmp(a, prev, 33 /* ne */) | GROUP_HEADS;
       // run length = distance to the next head of the lane's group (or to the group's end)
       uint32_t cnt;
       if (RUN_MAX == 64) {
@@ -380,7 +410,8 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
         const uint32_t rest = g >> ((lane & (RUN_MAX - 1)) + 1);
         cnt = rest ? (uint32_t)__builtin_ctz(rest) + 1u : (uint32_t)(RUN_MAX - (lane & (RUN_MAX - 1)));
       }
-      const unsigned long long He = __ballot(is_head && live);  // (lanes past the scan's end emit nothing)
+      const int32_t n_live = n_pts - c;  // (lanes past the scan's end emit nothing)
+      const unsigned long long He = H & (n_live >= 64 ? ~0ull : (1ull << n_live) - 1ull);
       if (is_head && live) {
         const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(He >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)He, 0u));
         list[(tail + before) & (LIST_ENTRIES - 1)] = a | ((cnt - 1u) << RUN_SHIFT);
