@@ -104,8 +104,9 @@ typedef struct nhip_grid_layout {
                           byte (i, 2j+1) holds P4[i+1][j]: one read returns both sub-block rows */
   int32_t pool4_pitch;
   int32_t pool4_rows;
-  int64_t hi_bytes;    /* 16-bit cells only (else 0): after the second table, the plane of the cells' HIGH BYTES, rows x
-                          hi_pitch bytes, byte (r+pad)*hi_pitch + (c+pad) = cell (r, c) >> 8.  The branch-and-bound matcher
+  int64_t hi_bytes;    /* 16-bit cells only (else 0): after the second table, the plane of the cells' HIGH BYTES (cell >> 8),
+                          hi_bytes bytes: two copies tiled 8 rows x 16 bytes, the second shifted by 8 columns (nhip_common.h
+                          hi_tiled(); nhip_grids_download_hi_plane returns it as rows x hi_pitch).  The branch-and-bound matcher
                           takes its exact block sums on this plane at the cost of 8-bit cells -- 256*sum(high bytes) +
                           255*points bounds a pose's 16-bit sum from above -- and reads 16-bit cells for the few poses
                           whose bound still reaches the best sum: same records, bit for bit */
@@ -349,8 +350,11 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
 int nhip_grids_free(nhip_grids_t *grids);
 /* copy stored (padded) grid `slot` to host: layout.grid_bytes bytes (uint8 or uint16 cells) */
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
-/* copy the plane of high bytes of grid `slot` (16-bit cells) to host: layout.hi_bytes bytes (rows x hi_pitch) */
+/* copy the plane of high bytes of grid `slot` (16-bit cells) to host in plain row-major form: rows x hi_pitch bytes.
+ * On the device the plane is stored as two copies tiled 8 rows x 16 bytes (layout.hi_bytes bytes in all; the second
+ * copy's tiles are shifted by 8 columns); `_copy` selects the copy that is read back (0 / 1: both hold the same bytes). */
 int nhip_grids_download_hi_plane(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
+int nhip_grids_download_hi_plane_copy(const nhip_grids_t *grids, int32_t slot, int32_t copy, uint8_t *out);
 /* copy the skip map of grid `slot` to host: layout.skip_bytes bytes (rows x 8*ceil(pitch/256) bytes, then padding) */
 int nhip_grids_download_skip_map(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* copy the max-pooled table of grid `slot` to host: layout.pool_bytes bytes (pool_rows x pool_pitch) */

@@ -111,11 +111,12 @@ class LikelihoodGrids:
         check(_lib.load().nhip_grids_download(self._h, int(slot), ptr(out)))
         return out.view(np.uint16) if L.cell_bytes == 2 else out
 
-    def hi_plane(self, slot):
-        """16-bit grids: the stored plane of the cells' high bytes, (rows, hi_pitch) uint8."""
+    def hi_plane(self, slot, copy=0):
+        """16-bit grids: the plane of the cells' high bytes in plain form, (rows, hi_pitch) uint8 (on the device: two
+        tiled copies; `copy` selects which one is read back)."""
         L = self.layout
         out = np.empty((L.rows, L.hi_pitch), dtype=np.uint8)
-        check(_lib.load().nhip_grids_download_hi_plane(self._h, int(slot), ptr(out)))
+        check(_lib.load().nhip_grids_download_hi_plane_copy(self._h, int(slot), int(copy), ptr(out)))
         return out
 
     def skip_map(self, slot):

@@ -75,7 +75,9 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   // and 4 x 4 blocks on this plane at the cost of 8-bit cells (256 * sum(hi) + 255 * points bounds a pose's sum from
   // above) and reads 16-bit cells only for the poses that bound still admits (nhip_bnb.hip)
   L->hi_pitch = L->cb == 2 ? (((L->S + 2 * L->pad) + 15) & ~15) : 0;
-  L->hi_bytes = (int64_t)L->hi_pitch * (int64_t)(L->S + 2 * L->pad);
+  L->hi_tpr = L->cb == 2 ? L->hi_pitch / 16 + 1 : 0;  // (+ 1: the shifted copy's last tile)
+  L->hi_copy_bytes = (int64_t)((L->S + 2 * L->pad + 7) / 8) * L->hi_tpr * (int64_t)HI_TILE_BYTES;
+  L->hi_bytes = 2 * L->hi_copy_bytes;
   L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes + L->hi_bytes;
   L->Lf = log(spec->floor_p);
   L->step = -L->Lf / (double)L->levels;
@@ -644,14 +646,23 @@ int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   return NHIP_OK;
 }
 
-int nhip_grids_download_hi_plane(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
-  NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_hi_plane: bad arguments");
+int nhip_grids_download_hi_plane_copy(const nhip_grids_t *grids, int32_t slot, int32_t copy, uint8_t *out) {
+  NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n && (copy == 0 || copy == 1), "grids_download_hi_plane: bad arguments");
   const GridLayout &L = grids->L;
   NHIP_REQUIRE(L.hi_bytes > 0, "grids_download_hi_plane: 8-bit grids have no plane of high bytes");
-  NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes +
-                                  L.skip_bytes + L.pool_bytes + L.pool4_bytes,
+  std::vector<uint8_t> raw((size_t)L.hi_bytes);
+  NHIP_TRY_HIP(hipMemcpy(raw.data(), static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes +
+                                         L.skip_bytes + L.pool_bytes + L.pool4_bytes,
                          (size_t)L.hi_bytes, hipMemcpyDeviceToHost));
+  const int32_t rows = L.S + 2 * L.pad;
+  for (int32_t r = 0; r < rows; r++)
+    for (int32_t c = 0; c < L.hi_pitch; c++)
+      out[(size_t)r * L.hi_pitch + c] = raw[hi_tiled((uint32_t)r, (uint32_t)c, (uint32_t)copy, (uint32_t)L.hi_tpr, (uint32_t)L.hi_copy_bytes)];
   return NHIP_OK;
+}
+
+int nhip_grids_download_hi_plane(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
+  return nhip_grids_download_hi_plane_copy(grids, slot, 0, out);
 }
 
 int nhip_grids_download_skip_map(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {

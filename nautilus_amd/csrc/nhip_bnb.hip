@@ -988,9 +988,15 @@ __device__ __forceinline__ uint32_t best_sum_cached(unsigned long long *best, ui
 // `pitch`, for the rotation whose origins the wave holds.
 // 4 x 4 sub-block (sy, sx) of block (Y, X): four 8-byte row loads per point.  Returns the sum of this lane's pose
 // (*dy, *dx inside the sub-block; lanes 16.. hold copies of lanes 0..15).
-__device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint32_t pitch, const uint32_t *org, int32_t nch,
-                                              int32_t Y, int32_t X, int32_t sy, int32_t sx, int lane, int *dy, int *dx) {
+// TILED: the plane is the tiled plane of high bytes (two copies; `pitch` = tiles per tile row, `copy_bytes` = bytes of a
+// copy): a row's 8 bytes come from the copy in which they start in a tile's first half, so no read crosses a tile, and
+// the rows of a point's window are 16 bytes apart inside a tile and (tiles per row - 1) * 128 + 16 further at its end.
+template <bool TILED>
+__device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint32_t pitch, uint32_t copy_bytes, const uint32_t *org,
+                                              int32_t nch, int32_t Y, int32_t X, int32_t sy, int32_t sx, int lane, int *dy, int *dx) {
   const uint32_t off = (uint32_t)(BNB_B * Y + BNB_B4 * sy) * pitch + (uint32_t)(BNB_B * X + BNB_B4 * sx);
+  const uint32_t roff = (uint32_t)(BNB_B * Y + BNB_B4 * sy), coff = (uint32_t)(BNB_B * X + BNB_B4 * sx);
+  const uint32_t wrap = pitch * HI_TILE_BYTES - HI_TILE_BYTES;  // (TILED) from a tile's last row to the next tile's first
 #ifndef NHIP_BNB_SUB_U8
 #define NHIP_BNB_SUB_U8 2
 #endif
@@ -1015,6 +1021,16 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
       const uint32_t g = org_row(o) * pitch + org_col(o) + off;
 #endif
       cn[j] = org_cnt(o);
+      if (TILED) {
+        const uint32_t row0 = org_row(o) + roff, col0 = org_col(o) + coff, col4 = col0 & ~3u;
+        const uint32_t cp = (col4 >> 3) & 1u, q = row0 & 7u;
+        const uint32_t v0 = hi_tiled(row0, col4, cp, pitch, copy_bytes);
+        sh[j] = (col0 & 3u) * 8u;
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+          w[j][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(v0 + (q + (uint32_t)y >= 8u ? wrap : 0u) + 16u * (uint32_t)y), 0, 0);
+        continue;
+      }
 #if NHIP_BNB_UNALIGNED
       // (the four bytes of a row from their own address: vector memory takes byte addresses on this target, and the
       //  address unit's time goes with the dwords a lane loads -- one here, two with the aligned read)
@@ -1034,7 +1050,7 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
     for (int j = 0; j < U; j++)
 #pragma unroll
       for (int y = 0; y < 4; y++) {
-        const uint32_t n = NHIP_BNB_UNALIGNED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+        const uint32_t n = NHIP_BNB_UNALIGNED && !TILED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
         E[y] += __umul24(n & M8, cn[j]);
         O[y] += __umul24(n >> 8, cn[j]);
       }
@@ -1058,9 +1074,12 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
 }
 
 // whole 8 x 8 block (Y, X): eight 12-byte row loads per point; lane l holds the sum of pose (*dy, *dx) of the block
-__device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uint32_t pitch, const uint32_t *org, int32_t nch,
-                                                int32_t Y, int32_t X, int lane, int *dy, int *dx) {
+template <bool TILED>
+__device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uint32_t pitch, uint32_t copy_bytes, const uint32_t *org,
+                                                int32_t nch, int32_t Y, int32_t X, int lane, int *dy, int *dx) {
   const uint32_t off = (uint32_t)(BNB_B * Y) * pitch + (uint32_t)(BNB_B * X);
+  const uint32_t roff = (uint32_t)(BNB_B * Y), coff = (uint32_t)(BNB_B * X);
+  const uint32_t wrap = pitch * HI_TILE_BYTES - HI_TILE_BYTES;  // (TILED) from a tile's last row to the next tile's first
 // (one chunk's eight row loads in flight: with two the 32 accumulators + 48 row registers spill, measured 5 % slower)
 #ifndef NHIP_BNB_BLOCK_U
 #define NHIP_BNB_BLOCK_U 1
@@ -1078,7 +1097,7 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
 #define NHIP_BNB_BLOCK_ROWS 4
 #endif
     constexpr int ROWS = NHIP_BNB_BLOCK_ROWS;
-    uint32_t gg[U], sh[U], cn[U];
+    uint32_t gg[U], sh[U], cn[U], qq[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
       const uint32_t o = origin_of(org, U * r + j);
@@ -1090,6 +1109,13 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
       cn[j] = org_cnt(o);
       sh[j] = NHIP_BNB_UNALIGNED ? 0u : (g & 3u) * 8u;
       gg[j] = NHIP_BNB_UNALIGNED ? g : g & ~3u;
+      qq[j] = 0u;
+      if (TILED) {  // (12 bytes from a 4-aligned column: the copy in which they start in a tile's first half)
+        const uint32_t row0 = org_row(o) + roff, col0 = org_col(o) + coff, col4 = col0 & ~3u;
+        qq[j] = row0 & 7u;
+        gg[j] = hi_tiled(row0, col4, (col4 >> 3) & 1u, pitch, copy_bytes);
+        sh[j] = (col0 & 3u) * 8u;
+      }
     }
 #pragma unroll
     for (int y0 = 0; y0 < 8; y0 += ROWS) {
@@ -1098,6 +1124,10 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
       for (int j = 0; j < U; j++)
 #pragma unroll
         for (int y = 0; y < ROWS; y++) {
+          if (TILED) {
+            w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gg[j] + (qq[j] + (uint32_t)(y0 + y) >= 8u ? wrap : 0u) + 16u * (uint32_t)(y0 + y)), 0, 0);
+            continue;
+          }
 #if NHIP_BNB_UNALIGNED
           const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gg[j] + (uint32_t)(y0 + y) * pitch), 0, 0);
           w[j][y].x = v.x;
@@ -1111,8 +1141,8 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
       for (int j = 0; j < U; j++)
 #pragma unroll
         for (int y = 0; y < ROWS; y++) {
-          const uint32_t n0 = NHIP_BNB_UNALIGNED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
-          const uint32_t n1 = NHIP_BNB_UNALIGNED ? w[j][y].y : __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
+          const uint32_t n0 = NHIP_BNB_UNALIGNED && !TILED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+          const uint32_t n1 = NHIP_BNB_UNALIGNED && !TILED ? w[j][y].y : __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
           E[y0 + y][0] += __umul24(n0 & M8, cn[j]); O[y0 + y][0] += __umul24(n0 >> 8, cn[j]);
           E[y0 + y][1] += __umul24(n1 & M8, cn[j]); O[y0 + y][1] += __umul24(n1 >> 8, cn[j]);
         }
@@ -1281,7 +1311,7 @@ __device__ __forceinline__ void process_candidate(const BnbParams &P, const Pair
 // 8-bit plane the exact block sums are taken on (8-bit grids: the image; 16-bit grids: the plane of high bytes) and
 // `pitch8` its pitch; `rsrc16` the 16-bit image (CB == 2).
 template <int CB, bool GLOBAL>
-__device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc, uint32_t pitch8,
+__device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc, uint32_t pitch8,  // (CB 2: tiles per row)
                                                     __amdgpu_buffer_rsrc_t rsrc16, const uint32_t *org, int32_t nch,
                                                     int32_t n_pts, int32_t k, int32_t Y, int32_t X,
                                                     uint32_t sb0, uint32_t sb1, uint32_t sb2, uint32_t sb3, int lane,
@@ -1292,7 +1322,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
   if (alive == 0) return;
   if (alive >= P.whole_min) {
     int dy, dx;
-    const uint32_t total = block_sums8(rsrc, pitch8, org, nch, Y, X, lane, &dy, &dx);
+    const uint32_t total = block_sums8<CB == 2>(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, lane, &dy, &dx);
     const int32_t ix = BNB_B * X + dx, iy = BNB_B * Y + dy;
     if (CB == 1) {
       const unsigned long long key = best_key(P, k, ix, iy, total, 32);
@@ -1309,7 +1339,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
     const uint32_t b = q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3));
     if (b == 0u || b < best_sum_cached<GLOBAL>(best, bcopy)) continue;
     int dy, dx;
-    const uint32_t total = sub_sums8(rsrc, pitch8, org, nch, Y, X, q >> 1, q & 1, lane, &dy, &dx);
+    const uint32_t total = sub_sums8<CB == 2>(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, q >> 1, q & 1, lane, &dy, &dx);
     const int32_t ix = BNB_B * X + BNB_B4 * (q & 1) + dx, iy = BNB_B * Y + BNB_B4 * (q >> 1) + dy;
     if (CB == 1) {
       const unsigned long long key = best_key(P, k, ix, iy, total, 8);  // (lanes 16.. hold copies)
@@ -1344,8 +1374,8 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
   const __amdgpu_buffer_rsrc_t rsrc16 = uniform_rsrc(C.grid, P.grid_bytes + P.skip_bytes);
   // the 8-bit plane of the exact block sums: the image itself, or the high bytes of 16-bit cells (+ the 16 bytes a row
   // load may reach past the plane's last cell: the next slot, or the buffer's read slack)
-  const __amdgpu_buffer_rsrc_t rsrc = CB == 1 ? rsrc16 : uniform_rsrc(C.grid + P.hi_offset, P.hi_bytes + 16);
-  const uint32_t pitch8 = CB == 1 ? (uint32_t)P.pitch : (uint32_t)P.hi_pitch;
+  const __amdgpu_buffer_rsrc_t rsrc = CB == 1 ? rsrc16 : uniform_rsrc(C.grid + P.hi_offset, P.hi_bytes);
+  const uint32_t pitch8 = CB == 1 ? (uint32_t)P.pitch : (uint32_t)P.hi_tpr;
   const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(C.grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
   // candidates in block order b = NB * Y + X; neighbours in X (up to three) share one pass over the table
   while ((m0 | m1) != 0ull) {
@@ -2221,6 +2251,8 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.hi_offset = L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes;
   P.hi_bytes = L.hi_bytes;
   P.hi_pitch = L.hi_pitch;
+  P.hi_tpr = L.hi_tpr;
+  P.hi_copy_bytes = L.hi_copy_bytes;
   // Policies that never change the records (tests run the matcher in every form and compare): read per launch.
   const char *lv = getenv("NHIP_BNB_LEVELS");  // (1: without the sub-block bounds)
   P.levels = lv && lv[0] == '1' ? 1 : 2;

@@ -61,6 +61,8 @@ struct BnbParams {
   int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes, pool4_bytes;
   int64_t hi_offset, hi_bytes;  // 16-bit grids: the plane of high bytes inside a slot
   int32_t hi_pitch;
+  int32_t hi_tpr;          // tiles per tile row and bytes of one copy of the tiled plane (nhip_common.h hi_tiled)
+  int64_t hi_copy_bytes;
   double res, inv_res;
   float inv_res_f;  // RN_f32(1 / res): the single-precision path of the window origins
 };

@@ -43,13 +43,28 @@ struct GridLayout {
   int64_t skip_bytes;  // skip_pitch(pitch) * rows rounded up to 16: the skip map that follows the image
   int64_t pool_bytes;  // pool_rows * pool_pitch: the max-pooled table (branch-and-bound bounds) after the skip map
   int64_t pool4_bytes; // pool4_rows * pool4_pitch: the stride-4 pooled table (second bound level) after the first
-  int64_t hi_bytes;    // 16-bit cells: hi_pitch * rows, the plane of high bytes after the second pooled table; else 0
-  int32_t hi_pitch;    // bytes per row of that plane (the 8-bit pitch of the same grid)
+  int64_t hi_bytes;    // 16-bit cells: stored bytes of the plane of high bytes after the second pooled table (two tiled
+                       // copies: hi_tiled() below); else 0
+  int32_t hi_pitch;    // bytes per row of the plane in its plain (downloaded) form: the 8-bit pitch of the same grid
+  int32_t hi_tpr;      // tiles per tile row of a copy
+  int64_t hi_copy_bytes;  // bytes of one copy
   int64_t slot_bytes;  // grid_bytes + skip_bytes + pool_bytes + pool4_bytes + hi_bytes: stride between consecutive grids
   int32_t pool_pitch, pool_rows;
   int32_t pool4_pitch, pool4_rows;
   double Lf, step;
 };
+// The plane of high bytes is stored in tiles of 8 rows x 16 bytes = one 128-byte cache line, so that the points of a
+// chunk -- neighbours along a wall whatever its direction -- read their rows from a dozen lines instead of forty
+// (in a row-major plane every row of every point is a line of its own).  A row read of the matcher is 8 or 12 bytes
+// from a 4-byte-aligned column and must not cross a tile: there are TWO copies, the second with its tiles shifted by
+// 8 columns, and a read takes the copy in which it starts in a tile's first half.
+// Byte offset of (row, col) in copy cp (0 / 1):
+constexpr uint32_t HI_TILE_BYTES = 128u;
+__host__ __device__ __forceinline__ uint32_t hi_tiled(uint32_t row, uint32_t col, uint32_t cp, uint32_t tpr, uint32_t copy_bytes) {
+  const uint32_t c = col + 8u * cp;
+  return cp * copy_bytes + ((row >> 3) * tpr + (c >> 4)) * HI_TILE_BYTES + (row & 7u) * 16u + (c & 15u);
+}
+
 // Branch and bound works on 8 x 8 blocks of translations; a pooled entry covers the 15 x 15 stored cells an 8 x 8
 // block can reach from any window origin with the same (row >> 3, col >> 3).
 constexpr int BNB_B = 8;

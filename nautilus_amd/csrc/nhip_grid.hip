@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
                                                         int32_t pad, int32_t pitch, int64_t slot_bytes,
                                                         int32_t R, double res, double inv_res, GridKernelTables tab,
                                                         const uint32_t *__restrict__ thr16, int64_t hi_offset,
-                                                        int32_t hi_pitch) {
+                                                        int32_t hi_tpr, int64_t hi_copy_bytes) {
   __shared__ uint32_t sA[TILE][TILE + 1];
   __shared__ uint16_t sHits[MAX_TILE_HITS];
   __shared__ uint32_t sSeen[(TH_MAX * TH_MAX + 31) / 32];  // one bit per neighbourhood cell: a cell is a hit once
@@ -206,7 +206,11 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
         uint32_t h = 0u;
         for (int b = 0; b < 4; b++)
           if (c0 + c4 + b < S) h |= (qv[b] >> 8) << (8 * b);
-        if (h) *reinterpret_cast<uint32_t *>(g + hi_offset + (size_t)(r0 + r + pad) * hi_pitch + (size_t)(c0 + c4 + pad)) = h;
+        if (h) {  // (both tiled copies: a 4-aligned group of four cells never straddles a tile of either)
+          const uint32_t hr = (uint32_t)(r0 + r + pad), hc = (uint32_t)(c0 + c4 + pad);
+          *reinterpret_cast<uint32_t *>(g + hi_offset + hi_tiled(hr, hc, 0u, (uint32_t)hi_tpr, (uint32_t)hi_copy_bytes)) = h;
+          *reinterpret_cast<uint32_t *>(g + hi_offset + hi_tiled(hr, hc, 1u, (uint32_t)hi_tpr, (uint32_t)hi_copy_bytes)) = h;
+        }
       }
     }
   }
@@ -464,7 +468,8 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
                                                          const int32_t *__restrict__ list, uint8_t *__restrict__ grids,
                                                          int32_t n_targets, int32_t S, int32_t tiles, int32_t pad,
                                                          int32_t pitch, int32_t cb, int64_t slot_bytes, int64_t table_offset,
-                                                         int64_t table_bytes, int64_t hi_offset, int32_t hi_pitch) {
+                                                         int64_t table_bytes, int64_t hi_offset, int32_t hi_tpr,
+                                                         int64_t hi_copy_bytes) {
   const uint64_t tag = *reinterpret_cast<const uint64_t *>(header + 2);
   if (tag != expect) {  // unknown contents: everything goes (16-byte stores, grid-stride)
     uint4 *p = reinterpret_cast<uint4 *>(grids);
@@ -481,7 +486,14 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
     const int32_t r0 = (tile / tiles) * TILE, c0 = (tile % tiles) * TILE;
     uint8_t *g = grids + (size_t)t * slot_bytes;
     zero_tile<W>(g, pitch, r0, pad, S, (c0 + pad) * cb, TILE * cb);
-    if (cb == 2) zero_tile<WH>(g + hi_offset, hi_pitch, r0, pad, S, c0 + pad, TILE);
+    if (cb == 2) {  // the tile's 64 x 64 bytes in both tiled copies of the plane of high bytes, a dword at a time
+      for (int i = threadIdx.x; i < TILE * (TILE / 4) * 2; i += 256) {
+        const int cp = i & 1, d = (i >> 1) % (TILE / 4), r = (i >> 1) / (TILE / 4);
+        if (r0 + r < S)
+          *reinterpret_cast<uint32_t *>(g + hi_offset + hi_tiled((uint32_t)(r0 + r + pad), (uint32_t)(c0 + pad + 4 * d), (uint32_t)cp,
+                                                                 (uint32_t)hi_tpr, (uint32_t)hi_copy_bytes)) = 0u;
+      }
+    }
   }
   // (2) the derived tables of every slot (skip map, both pooled tables: between the image and the plane of high bytes)
   const int64_t per_slot = table_bytes / 16;
@@ -572,7 +584,7 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
       const int w = (L.pad * L.cb) % 16 == 0 ? 16 : ((L.pad * L.cb) % 8 == 0 ? 8 : 4), wh = L.pad % 16 == 0 ? 16 : (L.pad % 8 == 0 ? 8 : 4);
 #define NHIP_CLEAR(W, WH)                                                                                             \
   hipLaunchKernelGGL((grid_clear_kernel<W, WH>), dim3(4096), dim3(256), 0, s, count, tag, list, g, n, L.S, tiles, L.pad, \
-                     L.pitch, L.cb, L.slot_bytes, L.grid_bytes, tb, hio, L.hi_pitch)
+                     L.pitch, L.cb, L.slot_bytes, L.grid_bytes, tb, hio, L.hi_tpr, L.hi_copy_bytes)
       if (w == 16 && wh == 16) NHIP_CLEAR(16, 16);
       else if (w == 16) NHIP_CLEAR(16, 4);
       else if (w == 8) NHIP_CLEAR(8, 4);
@@ -597,12 +609,12 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     if (L.cb == 1)
       hipLaunchKernelGGL(grid_blur_kernel<1>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
-                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16, (int64_t)0, 0);
+                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16, (int64_t)0, 0, (int64_t)0);
     else
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_pitch);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes);
     // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernels that
     // perform every add; the branch-and-bound matcher never reads it, so 16-bit grids -- its product path -- carry
     // one only when the spec asks.)

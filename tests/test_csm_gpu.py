@@ -114,6 +114,8 @@ def test_grid_16bit_cells_bit_exact(gpu, small_bag):
             assert hi.shape == (L.rows, L.hi_pitch) and L.hi_pitch % 16 == 0 and L.hi_pitch >= L.rows
             assert np.array_equal(hi[:, :L.rows], (stored[:, :L.rows] >> 8).astype(np.uint8))
             assert not hi[:, L.rows:].any()
+            # (on the device: two tiled copies, the second shifted by 8 columns; both hold the same plane)
+            assert np.array_equal(grids.hi_plane(slot, copy=1), hi) and L.hi_bytes > 2 * L.rows * L.hi_pitch
         grids.close()
         st.close()
 
