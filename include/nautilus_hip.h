@@ -106,7 +106,8 @@ typedef struct nhip_grid_layout {
   int32_t pool4_rows;
   int64_t hi_bytes;    /* 16-bit cells only (else 0): after the second table, the plane of the cells' HIGH BYTES (cell >> 8),
                           hi_bytes bytes: two copies tiled 8 rows x 16 bytes, the second shifted by 8 columns (nhip_common.h
-                          hi_tiled(); nhip_grids_download_hi_plane returns it as rows x hi_pitch).  The branch-and-bound matcher
+                          hi_tiled(); nhip_grids_download_hi_plane returns it as rows x hi_pitch), then the 16-bit image once
+                          more, tiled 8 rows x 8 cells (nhip_grids_download_tiled16).  The branch-and-bound matcher
                           takes its exact block sums on this plane at the cost of 8-bit cells -- 256*sum(high bytes) +
                           255*points bounds a pose's 16-bit sum from above -- and reads 16-bit cells for the few poses
                           whose bound still reaches the best sum: same records, bit for bit */
@@ -355,6 +356,9 @@ int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
  * copy's tiles are shifted by 8 columns); `_copy` selects the copy that is read back (0 / 1: both hold the same bytes). */
 int nhip_grids_download_hi_plane(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 int nhip_grids_download_hi_plane_copy(const nhip_grids_t *grids, int32_t slot, int32_t copy, uint8_t *out);
+/* 16-bit cells: the matcher's copy of the 16-bit image (tiled 8 rows x 8 cells on the device; it follows the two copies
+ * of the plane of high bytes inside layout.hi_bytes) in the plain form of nhip_grids_download: layout.grid_bytes bytes */
+int nhip_grids_download_tiled16(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* copy the skip map of grid `slot` to host: layout.skip_bytes bytes (rows x 8*ceil(pitch/256) bytes, then padding) */
 int nhip_grids_download_skip_map(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* copy the max-pooled table of grid `slot` to host: layout.pool_bytes bytes (pool_rows x pool_pitch) */

@@ -105,6 +105,7 @@ PROTOTYPES = {
     "nhip_grids_download_skip_map": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_hi_plane": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_hi_plane_copy": (C.c_int, [_vp, _i32, _i32, _vp]),
+    "nhip_grids_download_tiled16": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_pool": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_pool4": (C.c_int, [_vp, _i32, _vp]),
     "nhip_csm_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _P(Search), _vp, _vp]),

@@ -119,6 +119,13 @@ class LikelihoodGrids:
         check(_lib.load().nhip_grids_download_hi_plane_copy(self._h, int(slot), int(copy), ptr(out)))
         return out
 
+    def tiled16(self, slot):
+        """16-bit grids: the matcher's tiled copy of the image, read back in the plain form of download()."""
+        L = self.layout
+        out = np.empty((L.rows, L.pitch), dtype=np.uint8)
+        check(_lib.load().nhip_grids_download_tiled16(self._h, int(slot), ptr(out)))
+        return out.view(np.uint16)
+
     def skip_map(self, slot):
         """The slot's skip map as (rows, bytes per map row) uint8: bit c & 7 of byte c >> 3 of row r = "stored rows
         [r, r + 21) x aligned dwords [c, c + 21 * cell_bytes) hold a non-zero cell"."""

@@ -77,7 +77,9 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   L->hi_pitch = L->cb == 2 ? (((L->S + 2 * L->pad) + 15) & ~15) : 0;
   L->hi_tpr = L->cb == 2 ? L->hi_pitch / 16 + 1 : 0;  // (+ 1: the shifted copy's last tile)
   L->hi_copy_bytes = (int64_t)((L->S + 2 * L->pad + 7) / 8) * L->hi_tpr * (int64_t)HI_TILE_BYTES;
-  L->hi_bytes = 2 * L->hi_copy_bytes;
+  L->t16_tpr = L->cb == 2 ? L->hi_pitch / 8 : 0;
+  L->t16_bytes = (int64_t)((L->S + 2 * L->pad + 7) / 8) * L->t16_tpr * (int64_t)HI_TILE_BYTES;
+  L->hi_bytes = 2 * L->hi_copy_bytes + L->t16_bytes;  // (the matcher's private planes, all three)
   L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes + L->hi_bytes;
   L->Lf = log(spec->floor_p);
   L->step = -L->Lf / (double)L->levels;
@@ -658,6 +660,22 @@ int nhip_grids_download_hi_plane_copy(const nhip_grids_t *grids, int32_t slot, i
   for (int32_t r = 0; r < rows; r++)
     for (int32_t c = 0; c < L.hi_pitch; c++)
       out[(size_t)r * L.hi_pitch + c] = raw[hi_tiled((uint32_t)r, (uint32_t)c, (uint32_t)copy, (uint32_t)L.hi_tpr, (uint32_t)L.hi_copy_bytes)];
+  return NHIP_OK;
+}
+
+int nhip_grids_download_tiled16(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
+  NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_tiled16: bad arguments");
+  const GridLayout &L = grids->L;
+  NHIP_REQUIRE(L.t16_bytes > 0, "grids_download_tiled16: 8-bit grids have no tiled 16-bit copy");
+  std::vector<uint8_t> raw((size_t)L.t16_bytes);
+  NHIP_TRY_HIP(hipMemcpy(raw.data(), static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes +
+                                         L.skip_bytes + L.pool_bytes + L.pool4_bytes + 2 * L.hi_copy_bytes,
+                         (size_t)L.t16_bytes, hipMemcpyDeviceToHost));
+  const int32_t rows = L.S + 2 * L.pad;
+  memset(out, 0, (size_t)L.grid_bytes);
+  for (int32_t r = 0; r < rows; r++)
+    for (int32_t c = 0; c < rows; c++)  // (square image: `rows` cells per row; the plain pitch may end before hi_pitch cells)
+      memcpy(out + (size_t)r * L.pitch + 2 * (size_t)c, raw.data() + t16_tiled((uint32_t)r, (uint32_t)c, (uint32_t)L.t16_tpr), 2);
   return NHIP_OK;
 }
 

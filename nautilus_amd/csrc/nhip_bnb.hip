@@ -1214,14 +1214,14 @@ __device__ __forceinline__ uint32_t wave_max(uint32_t v) {
 // sum over the scan's points of the 16-bit cell that pose (ix, iy) of the rotation reads: one 2-byte load per point
 __device__ __forceinline__ uint32_t pose_sum16(const BnbParams &P, __amdgpu_buffer_rsrc_t rsrc16, const uint32_t *org,
                                                int32_t nch, int32_t ix, int32_t iy) {
-  const uint32_t pitch = (uint32_t)P.pitch;
-  const uint32_t off = (uint32_t)iy * pitch + 2u * (uint32_t)ix;
+  // (rsrc16: the tiled copy of the 16-bit image -- one cell per point, neighbours along a wall in the same lines)
   uint32_t acc = 0u;  // (17 chunks * 65535 fits)
 #pragma unroll
   for (int c = 0; c < OCL; c++) {
     if (c >= nch) continue;
     const uint32_t o = origin_of(org, c);
-    acc += org_cnt(o) * (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(rsrc16, (int)(org_row(o) * pitch + 2u * org_col(o) + off), 0, 0);
+    acc += org_cnt(o) * (uint32_t)__builtin_amdgcn_raw_buffer_load_b16(
+                            rsrc16, (int)t16_tiled(org_row(o) + (uint32_t)iy, org_col(o) + (uint32_t)ix, (uint32_t)P.t16_tpr), 0, 0);
   }
   return wave_sum(acc);
 }
@@ -1371,10 +1371,12 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
   const int32_t nch = cache_origins(P, C.pts, C.n_pts, cf, sf, C.cx, C.cy, lane, org, CB == 2);
   if (BNB_STATS(P)) clk.org += clock64() - t_mark;
   // (stored image + skip map: every offset an evaluation can form lies inside; see nhip_api.hip make_layout)
-  const __amdgpu_buffer_rsrc_t rsrc16 = uniform_rsrc(C.grid, P.grid_bytes + P.skip_bytes);
+  // (8-bit grids: the image, on which the exact sums run; 16-bit grids: the tiled copy of the image, for pose_sum16)
+  const __amdgpu_buffer_rsrc_t rsrc16 = CB == 1 ? uniform_rsrc(C.grid, P.grid_bytes + P.skip_bytes)
+                                                : uniform_rsrc(C.grid + P.hi_offset + 2 * P.hi_copy_bytes, P.t16_bytes);
   // the 8-bit plane of the exact block sums: the image itself, or the high bytes of 16-bit cells (+ the 16 bytes a row
   // load may reach past the plane's last cell: the next slot, or the buffer's read slack)
-  const __amdgpu_buffer_rsrc_t rsrc = CB == 1 ? rsrc16 : uniform_rsrc(C.grid + P.hi_offset, P.hi_bytes);
+  const __amdgpu_buffer_rsrc_t rsrc = CB == 1 ? rsrc16 : uniform_rsrc(C.grid + P.hi_offset, 2 * P.hi_copy_bytes);
   const uint32_t pitch8 = CB == 1 ? (uint32_t)P.pitch : (uint32_t)P.hi_tpr;
   const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(C.grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
   // candidates in block order b = NB * Y + X; neighbours in X (up to three) share one pass over the table
@@ -2253,6 +2255,8 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.hi_pitch = L.hi_pitch;
   P.hi_tpr = L.hi_tpr;
   P.hi_copy_bytes = L.hi_copy_bytes;
+  P.t16_bytes = L.t16_bytes;
+  P.t16_tpr = L.t16_tpr;
   // Policies that never change the records (tests run the matcher in every form and compare): read per launch.
   const char *lv = getenv("NHIP_BNB_LEVELS");  // (1: without the sub-block bounds)
   P.levels = lv && lv[0] == '1' ? 1 : 2;

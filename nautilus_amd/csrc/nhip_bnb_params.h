@@ -63,6 +63,8 @@ struct BnbParams {
   int32_t hi_pitch;
   int32_t hi_tpr;          // tiles per tile row and bytes of one copy of the tiled plane (nhip_common.h hi_tiled)
   int64_t hi_copy_bytes;
+  int64_t t16_bytes;       // the tiled copy of the 16-bit image behind the two copies (nhip_common.h t16_tiled)
+  int32_t t16_tpr;
   double res, inv_res;
   float inv_res_f;  // RN_f32(1 / res): the single-precision path of the window origins
 };

@@ -48,6 +48,8 @@ struct GridLayout {
   int32_t hi_pitch;    // bytes per row of the plane in its plain (downloaded) form: the 8-bit pitch of the same grid
   int32_t hi_tpr;      // tiles per tile row of a copy
   int64_t hi_copy_bytes;  // bytes of one copy
+  int64_t t16_bytes;   // 16-bit cells: after the two copies, the 16-bit image once more, tiled 8 rows x 8 cells (t16_tiled())
+  int32_t t16_tpr;     // its tiles per tile row
   int64_t slot_bytes;  // grid_bytes + skip_bytes + pool_bytes + pool4_bytes + hi_bytes: stride between consecutive grids
   int32_t pool_pitch, pool_rows;
   int32_t pool4_pitch, pool4_rows;
@@ -63,6 +65,12 @@ constexpr uint32_t HI_TILE_BYTES = 128u;
 __host__ __device__ __forceinline__ uint32_t hi_tiled(uint32_t row, uint32_t col, uint32_t cp, uint32_t tpr, uint32_t copy_bytes) {
   const uint32_t c = col + 8u * cp;
   return cp * copy_bytes + ((row >> 3) * tpr + (c >> 4)) * HI_TILE_BYTES + (row & 7u) * 16u + (c & 15u);
+}
+
+// The matcher's exact 16-bit pose sums read ONE cell per point: from a copy of the 16-bit image tiled 8 rows x 8 cells
+// (128 bytes), for the same reason.  Byte offset of cell (row, col):
+__host__ __device__ __forceinline__ uint32_t t16_tiled(uint32_t row, uint32_t col, uint32_t tpr) {
+  return ((row >> 3) * tpr + (col >> 3)) * HI_TILE_BYTES + (row & 7u) * 16u + (col & 7u) * 2u;
 }
 
 // Branch and bound works on 8 x 8 blocks of translations; a pooled entry covers the 15 x 15 stored cells an 8 x 8

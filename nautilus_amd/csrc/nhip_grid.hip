@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
                                                         int32_t pad, int32_t pitch, int64_t slot_bytes,
                                                         int32_t R, double res, double inv_res, GridKernelTables tab,
                                                         const uint32_t *__restrict__ thr16, int64_t hi_offset,
-                                                        int32_t hi_tpr, int64_t hi_copy_bytes) {
+                                                        int32_t hi_tpr, int64_t hi_copy_bytes, int32_t t16_tpr) {
   __shared__ uint32_t sA[TILE][TILE + 1];
   __shared__ uint16_t sHits[MAX_TILE_HITS];
   __shared__ uint32_t sSeen[(TH_MAX * TH_MAX + 31) / 32];  // one bit per neighbourhood cell: a cell is a hit once
@@ -201,6 +201,15 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
             if (CB == 1) dst[b] = (uint8_t)qv[b];
             else reinterpret_cast<uint16_t *>(dst)[b] = (uint16_t)qv[b];
           }
+      }
+      if (CB == 2) {  // the matcher's tiled copy of the 16-bit cells (a 4-aligned group of four lies in one tile row)
+        uint8_t *td = g + hi_offset + 2 * hi_copy_bytes + t16_tiled((uint32_t)(r0 + r + pad), (uint32_t)(c0 + c4 + pad), (uint32_t)t16_tpr);
+        if (c0 + c4 + 3 < S) {
+          *reinterpret_cast<uint2 *>(td) = make_uint2(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16));
+        } else {
+          for (int b = 0; b < 4; b++)
+            if (c0 + c4 + b < S) reinterpret_cast<uint16_t *>(td)[b] = (uint16_t)qv[b];
+        }
       }
       if (CB == 2) {  // the plane of high bytes (columns past the raster stay zero, like the image's border)
         uint32_t h = 0u;
@@ -469,7 +478,7 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
                                                          int32_t n_targets, int32_t S, int32_t tiles, int32_t pad,
                                                          int32_t pitch, int32_t cb, int64_t slot_bytes, int64_t table_offset,
                                                          int64_t table_bytes, int64_t hi_offset, int32_t hi_tpr,
-                                                         int64_t hi_copy_bytes) {
+                                                         int64_t hi_copy_bytes, int32_t t16_tpr) {
   const uint64_t tag = *reinterpret_cast<const uint64_t *>(header + 2);
   if (tag != expect) {  // unknown contents: everything goes (16-byte stores, grid-stride)
     uint4 *p = reinterpret_cast<uint4 *>(grids);
@@ -486,12 +495,37 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
     const int32_t r0 = (tile / tiles) * TILE, c0 = (tile % tiles) * TILE;
     uint8_t *g = grids + (size_t)t * slot_bytes;
     zero_tile<W>(g, pitch, r0, pad, S, (c0 + pad) * cb, TILE * cb);
-    if (cb == 2) {  // the tile's 64 x 64 bytes in both tiled copies of the plane of high bytes, a dword at a time
-      for (int i = threadIdx.x; i < TILE * (TILE / 4) * 2; i += 256) {
-        const int cp = i & 1, d = (i >> 1) % (TILE / 4), r = (i >> 1) / (TILE / 4);
-        if (r0 + r < S)
-          *reinterpret_cast<uint32_t *>(g + hi_offset + hi_tiled((uint32_t)(r0 + r + pad), (uint32_t)(c0 + pad + 4 * d), (uint32_t)cp,
-                                                                 (uint32_t)hi_tpr, (uint32_t)hi_copy_bytes)) = 0u;
+    if (cb == 2) {
+      // the tile's 64 x 64 cells in the matcher's tiled planes, 16 bytes (one tile row) a store where the tiles allow:
+      // pad and c0 are multiples of 16 columns here (W == 16), so per row the first copy of the high bytes takes four
+      // whole tile rows, the shifted copy half a tile row + three whole + half, the 16-bit copy eight whole ones
+      uint8_t *hp = g + hi_offset;
+      const uint32_t tpr = (uint32_t)hi_tpr, cpb = (uint32_t)hi_copy_bytes, cc = (uint32_t)(c0 + pad);
+      if (((c0 + pad) & 15) == 0) {
+        for (int i = threadIdx.x; i < TILE * 17; i += 256) {
+          const int r = i / 17, d = i % 17;
+          if (r0 + r >= S) continue;
+          const uint32_t row = (uint32_t)(r0 + r + pad);
+          if (d < 4) {
+            *reinterpret_cast<uint4 *>(hp + hi_tiled(row, cc + 16u * (uint32_t)d, 0u, tpr, cpb)) = make_uint4(0, 0, 0, 0);
+          } else if (d < 9) {
+            const int e = d - 4;  // columns cc + 16 e - 8 ... of the plain plane = a tile row of the shifted copy
+            uint8_t *q = hp + hi_tiled(row, cc + 16u * (uint32_t)e, 1u, tpr, cpb) - 8;
+            if (e == 0) *reinterpret_cast<uint2 *>(q + 8) = make_uint2(0, 0);
+            else if (e == 4) *reinterpret_cast<uint2 *>(q) = make_uint2(0, 0);
+            else *reinterpret_cast<uint4 *>(q) = make_uint4(0, 0, 0, 0);
+          } else {
+            *reinterpret_cast<uint4 *>(hp + 2 * hi_copy_bytes + t16_tiled(row, cc + 8u * (uint32_t)(d - 9), (uint32_t)t16_tpr)) = make_uint4(0, 0, 0, 0);
+          }
+        }
+      } else {  // (odd geometries: a dword / four cells at a time)
+        for (int i = threadIdx.x; i < TILE * (TILE / 4) * 3; i += 256) {
+          const int k = i % 3, d = (i / 3) % (TILE / 4), r = (i / 3) / (TILE / 4);
+          if (r0 + r >= S) continue;
+          const uint32_t row = (uint32_t)(r0 + r + pad), col = cc + 4u * (uint32_t)d;
+          if (k < 2) *reinterpret_cast<uint32_t *>(hp + hi_tiled(row, col, (uint32_t)k, tpr, cpb)) = 0u;
+          else *reinterpret_cast<uint2 *>(hp + 2 * hi_copy_bytes + t16_tiled(row, col, (uint32_t)t16_tpr)) = make_uint2(0u, 0u);
+        }
       }
     }
   }
@@ -584,7 +618,7 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
       const int w = (L.pad * L.cb) % 16 == 0 ? 16 : ((L.pad * L.cb) % 8 == 0 ? 8 : 4), wh = L.pad % 16 == 0 ? 16 : (L.pad % 8 == 0 ? 8 : 4);
 #define NHIP_CLEAR(W, WH)                                                                                             \
   hipLaunchKernelGGL((grid_clear_kernel<W, WH>), dim3(4096), dim3(256), 0, s, count, tag, list, g, n, L.S, tiles, L.pad, \
-                     L.pitch, L.cb, L.slot_bytes, L.grid_bytes, tb, hio, L.hi_tpr, L.hi_copy_bytes)
+                     L.pitch, L.cb, L.slot_bytes, L.grid_bytes, tb, hio, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr)
       if (w == 16 && wh == 16) NHIP_CLEAR(16, 16);
       else if (w == 16) NHIP_CLEAR(16, 4);
       else if (w == 8) NHIP_CLEAR(8, 4);
@@ -609,12 +643,12 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     if (L.cb == 1)
       hipLaunchKernelGGL(grid_blur_kernel<1>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
-                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16, (int64_t)0, 0, (int64_t)0);
+                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16, (int64_t)0, 0, (int64_t)0, 0);
     else
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr);
     // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernels that
     // perform every add; the branch-and-bound matcher never reads it, so 16-bit grids -- its product path -- carry
     // one only when the spec asks.)

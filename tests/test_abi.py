@@ -57,7 +57,8 @@ def test_grid_layout_follows_cimg_debug():
     assert csm.grid_layout(zero).cell_bytes == 2
     assert L16.cell_bytes == 2 and L16.pitch == 2 * 1392 and L16.rows == 1392 and L16.grid_bytes == 2 * 1392 * 1392
     # the plane of high bytes: plain form at the 8-bit pitch; stored as two copies of 174 x 88 tiles of 8 rows x 16 bytes
-    assert L16.hi_pitch == 1392 and L16.hi_bytes == 2 * 174 * 88 * 128
+    # ... and the 16-bit image once more in 174 x 174 tiles of 8 rows x 8 cells
+    assert L16.hi_pitch == 1392 and L16.hi_bytes == 2 * 174 * 88 * 128 + 174 * 174 * 128
     assert L16.slot_bytes == L16.grid_bytes + L16.skip_bytes + L16.pool_bytes + L16.pool4_bytes + L16.hi_bytes
     for (r, res, side) in [(30, 0.3, 200), (30, 0.01, 6000), (10, 0.03, 666)]:
         assert csm.grid_layout(csm.grid_spec(r, res, 2.0, 1e-10, 4)).side == side

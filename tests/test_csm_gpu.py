@@ -116,6 +116,8 @@ def test_grid_16bit_cells_bit_exact(gpu, small_bag):
             assert not hi[:, L.rows:].any()
             # (on the device: two tiled copies, the second shifted by 8 columns; both hold the same plane)
             assert np.array_equal(grids.hi_plane(slot, copy=1), hi) and L.hi_bytes > 2 * L.rows * L.hi_pitch
+            # ... and the tiled copy of the 16-bit cells that the exact pose sums read
+            assert np.array_equal(grids.tiled16(slot)[:, :L.rows], stored[:, :L.rows])
         grids.close()
         st.close()
 
