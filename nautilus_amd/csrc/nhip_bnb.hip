@@ -1984,8 +1984,11 @@ __global__ __launch_bounds__(SORT_THREADS) void csm_bnb_order_kernel(BnbParams P
 #define NHIP_BNB_CAND_WAVES 4  // waves per workgroup of the candidates' kernel
 #endif
 constexpr int CAND_THREADS = 64 * NHIP_BNB_CAND_WAVES;
+#ifndef NHIP_BNB_CAND_OCC16
+#define NHIP_BNB_CAND_OCC16 5  // the same for 16-bit grids: with their planes tiled the working set fits five waves per SIMD
+#endif                         // (6.78 -> 6.43 ms; the row-major 8-bit image thrashes with more than four: 6.7 -> 7.0)
 template <int CB>
-__global__ __launch_bounds__(CAND_THREADS, NHIP_BNB_CAND_OCC) void csm_bnb_cand_kernel(BnbParams P) {
+__global__ __launch_bounds__(CAND_THREADS, CB == 2 ? NHIP_BNB_CAND_OCC16 : NHIP_BNB_CAND_OCC) void csm_bnb_cand_kernel(BnbParams P) {
   __shared__ uint32_t s_org2[NHIP_BNB_CAND_WAVES * ORG_WAVE];
   __shared__ unsigned long long s_best2;
   __shared__ uint32_t s_next2;
@@ -2263,7 +2266,9 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const char *sd = getenv("NHIP_BNB_SEEDS");  // (waves that evaluate a seed block)
   P.seeds = sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : 8u;
   const char *wm = getenv("NHIP_BNB_WHOLE_MIN");
-  P.whole_min = wm ? atoi(wm) : 2;  // (3 -> 2: 7.70 -> 7.45 ms per 10,000 pairs; 1: 7.8, 4: 7.9)
+  // (row-major planes -- 8-bit grids, and 16-bit grids before their planes were tiled: 2 beats 3, 7.70 -> 7.45 ms per
+  //  10,000 pairs, 1: 7.8, 4: 7.9; tiled planes: loads are cheaper and 3 beats 2, 6.37 -> 6.22 ms)
+  P.whole_min = wm ? atoi(wm) : (L.cb == 2 ? 3 : 2);
   const char *qe = getenv("NHIP_BNB_QUEUE");  // (the general path for every scan)
   P.general_all = qe && qe[0] == '1';
   P.res = spec->res;
