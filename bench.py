@@ -562,19 +562,30 @@ def worker(a):
                    "collective": "all_gather 16 B/pair" if world > 1 else "none",
                    "per_rank": [{"pairs": int(r[0]), "targets": int(r[1]), "correlate_ms_per_step": r[2],
                                  "grid_ms_per_step": r[3]} for r in per_rank]},
-        # The matcher in its split form: the candidates' kernel is the longer of the two and is bound by the vector-memory
-        # pipeline -- its address unit (TA) is busy ~80 % of the launch, the L1 does ~0.7 tag lookups per clock and CU,
-        # the vector ALUs idle; the bounds-and-seeds kernel is priced against the vector-instruction peak beside it.
+        # The matcher in its split form is two kernels; the LONGER one of this run carries the roofline, the other sits in
+        # roofline.matcher.  Bounds + seeds: vector-ALU work on the LDS-resident pooled table, priced against the
+        # vector-instruction peak.  Candidates: gathers through the vector L1, priced against the busy time of the
+        # vector-memory address units (TA), with the L1's lookup rate, the VALU rate and the HBM traffic beside it.
         # (Fused form, NHIP_BNB_SPLIT=0 or a workspace without room: one kernel, priced against the VALU peak.)
-        "roofline": ({"bound": "vmem", "kernel": "csm_bnb_cand_kernel<%d>" % cb_tag, "avg_launch_ms": cand_avg, "launches": kc_n,
-                      "achieved": (rates_c["ta_busy_frac"] * 256 * 2.4 if rates_c and "ta_busy_frac" in rates_c else None),
-                      "peak": 256 * 2.4, "unit": "G busy cycles/s of the 256 vector-memory address units (TA_TA_BUSY)",
-                      "frac": rates_c.get("ta_busy_frac") if rates_c else None, "traffic": traffic,
-                      "other_ceilings": {"l1_lookups_per_clk_per_cu": rates_c.get("l1_tag_frac") if rates_c else None,
-                                         "valu_frac": rates_c.get("valu_frac") if rates_c else None,
-                                         "hbm_traffic_frac": (traffic / (cand_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                                         "l2_miss_frac": rates_c.get("l2_miss_frac") if rates_c else None},
-                      "matcher": matcher, "stale": prof["stale"], "profile": prof,
+        "roofline": (({"bound": "valu", "kernel": "csm_bnb_kernel<%d, true, true, true>" % cb_tag, "avg_launch_ms": bounds_avg,
+                       "launches": kb_n,
+                       "achieved": (rates_b["valu_frac"] * VALU_PEAK_WAVE_INSTR / 1e12 if rates_b and "valu_frac" in rates_b else None),
+                       "peak": VALU_PEAK_WAVE_INSTR / 1e12, "unit": "T wave-instr/s (1024 SIMDs x 2.4 GHz / 2 clk)",
+                       "frac": rates_b.get("valu_frac") if rates_b else None, "traffic": tb,
+                       "other_ceilings": {"l1_lookups_per_clk_per_cu": rates_b.get("l1_tag_frac") if rates_b else None,
+                                          "ta_busy_frac": rates_b.get("ta_busy_frac") if rates_b else None,
+                                          "hbm_traffic_frac": (tb / (bounds_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None,
+                                          "waves_waiting_frac": rates_b.get("wave_wait_frac") if rates_b else None}}
+                      if bounds_avg >= cand_avg else
+                      {"bound": "vmem", "kernel": "csm_bnb_cand_kernel<%d>" % cb_tag, "avg_launch_ms": cand_avg, "launches": kc_n,
+                       "achieved": (rates_c["ta_busy_frac"] * 256 * 2.4 if rates_c and "ta_busy_frac" in rates_c else None),
+                       "peak": 256 * 2.4, "unit": "G busy cycles/s of the 256 vector-memory address units (TA_TA_BUSY)",
+                       "frac": rates_c.get("ta_busy_frac") if rates_c else None, "traffic": traffic,
+                       "other_ceilings": {"l1_lookups_per_clk_per_cu": rates_c.get("l1_tag_frac") if rates_c else None,
+                                          "valu_frac": rates_c.get("valu_frac") if rates_c else None,
+                                          "hbm_traffic_frac": (traffic / (cand_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                                          "l2_miss_frac": rates_c.get("l2_miss_frac") if rates_c else None}}) |
+                     {"matcher": matcher, "stale": prof["stale"], "profile": prof,
                       "note": "counters per launch from the rocprofv3 passes in profiles/traffic.json / the kernel's launch "
                               "time measured live with HIP events on its stream; the counters belong to one build and one "
                               "workload: the fractions are null when traffic.json was taken from other kernel sources "
