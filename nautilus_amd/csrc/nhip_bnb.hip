@@ -26,6 +26,15 @@
 //
 // One 512-thread workgroup per pair; waves take rotations k = wave, wave + 8, ...; LDS holds the target's
 // pooled table (36 KB at 1200 x 1200) and the bounds (n_theta x 128 dwords).
+//
+// Kernels.  csm_bnb_kernel<CB, POOL_LDS, BY_ROT, SPLIT>: steps (1)-(3) for one pair (the fused form), or with SPLIT
+// steps (1)-(2) only, leaving the pair's rows of bounds in the caller's workspace; csm_bnb_order_kernel +
+// csm_bnb_cand_kernel<CB>: step (3) of all pairs of a list as a launch of its own (the split form: lists of 6,144 to
+// 65,536 pairs -- the first part's workgroups all take the same time, the candidates' vary 100-fold and the heaviest
+// pairs are shared by several workgroups); csm_bnb_rot_kernel<CB>: rotations handed over by pairs with flat landscapes
+// in small batches.  Exact sums of 16-bit grids run on the plane of high bytes (256 sum(hi) + 255 n bounds a pose's sum;
+// only the poses that bound admits read 16-bit cells), which -- like the copy of the cells those reads use -- is stored
+// in tiles of one cache line, because what a gather costs here is the number of distinct lines per load.
 #include <atomic>
 #include <mutex>
 
@@ -1001,7 +1010,7 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
 #define NHIP_BNB_SUB_U8 2
 #endif
   // chunks per round: 4 U row loads in flight.  (6 -> 2 together with NHIP_BNB_BLOCK_ROWS 8 -> 4: the same speed within
-  // the run-to-run spread -- gpurun_out r3_bnb_ab6.log -- and the by-rotation kernels fit their 128 registers: no
+  // the run-to-run spread -- profiles/r03_bnb_ab_scratch_free.log -- and the by-rotation kernels fit their 128 registers: no
   // scratch memory at all, where each launch used to write 225-370 MB of spills for 160 KB of records.)
   constexpr int U = NHIP_BNB_SUB_U8;
   static_assert(OC % U == 0, "whole rounds");
@@ -2177,7 +2186,7 @@ constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, ne
 // Small batches: room for 16 handed-over rotations per pair on average (what does not fit is worked by the pair's own
 // workgroup).  The split form: per pair its four counters, 1.5 entries of the candidates' work list and the rows of
 // bounds of up to 64 rotations.  It is used for lists of SPLIT_MIN_PAIRS .. SPLIT_PAIRS pairs, in ONE round: measured
-// (tools/bnb_size_ab.sh, gpurun_out r4i_size.log) 3,000 pairs fused 4.8 / split 5.3 ms, 10,000 pairs 8.2 / 7.3,
+// (tools/bnb_size_ab.sh, profiles/r03_matcher_experiments.txt) 3,000 pairs fused 4.8 / split 5.3 ms, 10,000 pairs 8.2 / 7.3,
 // 40,000 pairs 29.1 / 26.7 in one round but 29.9 in rounds of 16,384 (every round pays its own tail), 1,000,000 pairs
 // with 100 per target 612 fused / 868 in rounds -- so longer lists, which also profit most from the fused form's L2
 // locality, stay fused.  (Rounds exist for tests and measurements: NHIP_BNB_SPLIT_BATCH.)
@@ -2422,7 +2431,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     return NHIP_OK;
   }
   // (Tried and removed: the batch as K launches on K streams, so that one hardware queue's in-order dispatch does not
-  //  keep free slots empty -- 2 / 4 / 8 queues took 10 / 30 / 45 % longer, gpurun_out r3_queues_ab.log.)
+  //  keep free slots empty -- 2 / 4 / 8 queues took 10 / 30 / 45 % longer, profiles/r03_matcher_experiments.txt.)
   const int rc = instr ? bnb::launch_bnb_kernels_instr(P, L.cb, pool_lds, lds, blocks, second_kernel, s)
                        : bnb::launch_bnb_kernels(P, L.cb, pool_lds, lds, blocks, second_kernel, s);
   if (rc) return rc;

@@ -27,7 +27,7 @@
 // LDS is what limits the waves here: a tile of 48 rows x 424 bytes per one-wave workgroup (the 8-bit kernel's shape)
 // is 20 KB -- 8 waves per CU.  Four waves (84 plane rows: one 81 x 81 plane) sharing ONE 96-row tile (40.7 KB) put
 // 16 waves on a CU, and the shared fills more than pay for the barriers: measured on 3,000 config #2 pairs
-// (gpurun_out r3_c16_variants*.jsonl, tools/c16_variants.sh) 49.6 ms with one wave per 48-row tile, 45.0 / 43.5 with two
+// (profiles/r03_csm16_variants.jsonl, tools/c16_variants.sh) 49.6 ms with one wave per 48-row tile, 45.0 / 43.5 with two
 // per 64 / 72 rows, 41.1 / 43.0 / 46.4 with four per 120 / 112 / 104 rows (12 waves per CU), 37.9 with four per 96 rows;
 // letting hipcc fold the high-half shift into SDWA adds: 40.6.
 #include "nhip_csm_shared.h"
