@@ -104,9 +104,9 @@ typedef struct nhip_grid_layout {
                           byte (i, 2j+1) holds P4[i+1][j]: one read returns both sub-block rows */
   int32_t pool4_pitch;
   int32_t pool4_rows;
-  int64_t hi_bytes;    /* 16-bit cells only (else 0): after the second table, the plane of the cells' HIGH BYTES (cell >> 8),
+  int64_t hi_bytes;    /* after the second table, the matcher's 8-BIT PLANE: the cells' HIGH BYTES (cell >> 8; 8-bit cells: the cells),
                           hi_bytes bytes: two copies tiled 8 rows x 16 bytes, the second shifted by 8 columns (nhip_common.h
-                          hi_tiled(); nhip_grids_download_hi_plane returns it as rows x hi_pitch), then the 16-bit image once
+                          hi_tiled(); nhip_grids_download_hi_plane returns it as rows x hi_pitch), then (16-bit cells) the image once
                           more, tiled 8 rows x 8 cells (nhip_grids_download_tiled16).  The branch-and-bound matcher
                           takes its exact block sums on this plane at the cost of 8-bit cells -- 256*sum(high bytes) +
                           255*points bounds a pose's 16-bit sum from above -- and reads 16-bit cells for the few poses

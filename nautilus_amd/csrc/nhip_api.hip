@@ -74,8 +74,9 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   // 16-bit cells: the plane of their high bytes, one byte per cell at the 8-bit pitch.  The matcher sums exact 8 x 8
   // and 4 x 4 blocks on this plane at the cost of 8-bit cells (256 * sum(hi) + 255 * points bounds a pose's sum from
   // above) and reads 16-bit cells only for the poses that bound still admits (nhip_bnb.hip)
-  L->hi_pitch = L->cb == 2 ? (((L->S + 2 * L->pad) + 15) & ~15) : 0;
-  L->hi_tpr = L->cb == 2 ? L->hi_pitch / 16 + 1 : 0;  // (+ 1: the shifted copy's last tile)
+  // (8-bit cells: the same two tiled copies hold the cells themselves -- the image's bytes)
+  L->hi_pitch = ((L->S + 2 * L->pad) + 15) & ~15;
+  L->hi_tpr = L->hi_pitch / 16 + 1;  // (+ 1: the shifted copy's last tile)
   L->hi_copy_bytes = (int64_t)((L->S + 2 * L->pad + 7) / 8) * L->hi_tpr * (int64_t)HI_TILE_BYTES;
   L->t16_tpr = L->cb == 2 ? L->hi_pitch / 8 : 0;
   L->t16_bytes = (int64_t)((L->S + 2 * L->pad + 7) / 8) * L->t16_tpr * (int64_t)HI_TILE_BYTES;
@@ -651,7 +652,6 @@ int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
 int nhip_grids_download_hi_plane_copy(const nhip_grids_t *grids, int32_t slot, int32_t copy, uint8_t *out) {
   NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n && (copy == 0 || copy == 1), "grids_download_hi_plane: bad arguments");
   const GridLayout &L = grids->L;
-  NHIP_REQUIRE(L.hi_bytes > 0, "grids_download_hi_plane: 8-bit grids have no plane of high bytes");
   std::vector<uint8_t> raw((size_t)L.hi_bytes);
   NHIP_TRY_HIP(hipMemcpy(raw.data(), static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes +
                                          L.skip_bytes + L.pool_bytes + L.pool4_bytes,

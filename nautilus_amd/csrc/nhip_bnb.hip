@@ -68,6 +68,12 @@
 #ifndef NHIP_BNB_WAVE_SLOW_PATH
 #define NHIP_BNB_WAVE_SLOW_PATH 1  // window origins: one wave-level test for the double-precision path (0: per-lane nesting)
 #endif
+#ifndef NHIP_BNB_TILED
+#define NHIP_BNB_TILED 1  // exact block sums on the tiled 8-bit plane (0: 8-bit grids read their row-major image)
+#endif
+#ifndef NHIP_BNB_MERGE_U8
+#define NHIP_BNB_MERGE_U8 1  // merged list entries for 8-bit grids too (0: measurement)
+#endif
 #ifndef NHIP_BNB_F32_ORIGINS
 #define NHIP_BNB_F32_ORIGINS 1  // 0: window origins through two double-precision quotients (measurement)
 #endif
@@ -824,8 +830,9 @@ __device__ __forceinline__ uint32_t origin_of(const uint32_t *org, int c) { retu
 // over all chunks, must not exceed 257 (257 * 255 = 65,535).  One point per entry keeps that by construction (<= 18
 // chunks); with merged entries the wave checks it and, if a group would pass the limit (hundreds of beams in a few
 // cells), builds the list again with one point per entry.
-// `merged`: 16-bit grids (measured on 10,000 pairs: 7.45 -> 7.38 ms; with 8-bit cells the multiply-adds that replace
-// the adds cost more than the loads save: 6.81 -> 6.93 ms, so those keep one point per entry).
+// `merged`: measured on 10,000 pairs with row-major planes 7.45 -> 7.38 ms for 16-bit grids and 6.81 -> 6.93 ms for
+// 8-bit ones (the multiply-adds that replace the adds cost what the loads saved); with the tiled planes both widths
+// merge (8-bit: 6.31 -> 6.25 ms).
 __device__ __forceinline__ int32_t cache_origins(const BnbParams &P, const float2 *pts, int32_t n_pts, float cf, float sf,
                                                  int32_t cx, int32_t cy, int lane, uint32_t *org, bool merged) {
   uint32_t *base = org - lane;  // the wave's list
@@ -1331,7 +1338,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
   if (alive == 0) return;
   if (alive >= P.whole_min) {
     int dy, dx;
-    const uint32_t total = block_sums8<CB == 2>(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, lane, &dy, &dx);
+    const uint32_t total = block_sums8<NHIP_BNB_TILED != 0>(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, lane, &dy, &dx);
     const int32_t ix = BNB_B * X + dx, iy = BNB_B * Y + dy;
     if (CB == 1) {
       const unsigned long long key = best_key(P, k, ix, iy, total, 32);
@@ -1348,7 +1355,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
     const uint32_t b = q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3));
     if (b == 0u || b < best_sum_cached<GLOBAL>(best, bcopy)) continue;
     int dy, dx;
-    const uint32_t total = sub_sums8<CB == 2>(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, q >> 1, q & 1, lane, &dy, &dx);
+    const uint32_t total = sub_sums8<NHIP_BNB_TILED != 0>(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, q >> 1, q & 1, lane, &dy, &dx);
     const int32_t ix = BNB_B * X + BNB_B4 * (q & 1) + dx, iy = BNB_B * Y + BNB_B4 * (q >> 1) + dy;
     if (CB == 1) {
       const unsigned long long key = best_key(P, k, ix, iy, total, 8);  // (lanes 16.. hold copies)
@@ -1377,7 +1384,7 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
   float cf, sf;
   rotation_k(P, C.pair, k, &cf, &sf);
   if (BNB_STATS(P)) t_mark = clock64();
-  const int32_t nch = cache_origins(P, C.pts, C.n_pts, cf, sf, C.cx, C.cy, lane, org, CB == 2);
+  const int32_t nch = cache_origins(P, C.pts, C.n_pts, cf, sf, C.cx, C.cy, lane, org, CB == 2 || NHIP_BNB_MERGE_U8);
   if (BNB_STATS(P)) clk.org += clock64() - t_mark;
   // (stored image + skip map: every offset an evaluation can form lies inside; see nhip_api.hip make_layout)
   // (8-bit grids: the image, on which the exact sums run; 16-bit grids: the tiled copy of the image, for pose_sum16)
@@ -1385,8 +1392,10 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
                                                 : uniform_rsrc(C.grid + P.hi_offset + 2 * P.hi_copy_bytes, P.t16_bytes);
   // the 8-bit plane of the exact block sums: the image itself, or the high bytes of 16-bit cells (+ the 16 bytes a row
   // load may reach past the plane's last cell: the next slot, or the buffer's read slack)
-  const __amdgpu_buffer_rsrc_t rsrc = CB == 1 ? rsrc16 : uniform_rsrc(C.grid + P.hi_offset, 2 * P.hi_copy_bytes);
-  const uint32_t pitch8 = CB == 1 ? (uint32_t)P.pitch : (uint32_t)P.hi_tpr;
+  // (the matcher's 8-bit plane, tiled, two copies: the cells of 8-bit grids, the high bytes of 16-bit ones;
+  //  NHIP_BNB_TILED=0, measurement on 8-bit grids only: the row-major image instead)
+  const __amdgpu_buffer_rsrc_t rsrc = (CB == 1 && !NHIP_BNB_TILED) ? rsrc16 : uniform_rsrc(C.grid + P.hi_offset, 2 * P.hi_copy_bytes);
+  const uint32_t pitch8 = (CB == 1 && !NHIP_BNB_TILED) ? (uint32_t)P.pitch : (uint32_t)P.hi_tpr;
   const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(C.grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
   // candidates in block order b = NB * Y + X; neighbours in X (up to three) share one pass over the table
   while ((m0 | m1) != 0ull) {
@@ -2276,8 +2285,8 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.seeds = sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : 8u;
   const char *wm = getenv("NHIP_BNB_WHOLE_MIN");
   // (row-major planes -- 8-bit grids, and 16-bit grids before their planes were tiled: 2 beats 3, 7.70 -> 7.45 ms per
-  //  10,000 pairs, 1: 7.8, 4: 7.9; tiled planes: loads are cheaper and 3 beats 2, 6.37 -> 6.22 ms)
-  P.whole_min = wm ? atoi(wm) : (L.cb == 2 ? 3 : 2);
+  //  10,000 pairs, 1: 7.8, 4: 7.9; tiled planes, both widths now: loads are cheaper and 3 beats 2, 6.37 -> 6.22 ms)
+  P.whole_min = wm ? atoi(wm) : 3;
   const char *qe = getenv("NHIP_BNB_QUEUE");  // (the general path for every scan)
   P.general_all = qe && qe[0] == '1';
   P.res = spec->res;

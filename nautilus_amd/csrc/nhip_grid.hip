@@ -211,10 +211,11 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
             if (c0 + c4 + b < S) reinterpret_cast<uint16_t *>(td)[b] = (uint16_t)qv[b];
         }
       }
-      if (CB == 2) {  // the plane of high bytes (columns past the raster stay zero, like the image's border)
+      {  // the matcher's 8-bit plane: the high bytes of 16-bit cells, the cells themselves of 8-bit ones (columns past
+         // the raster stay zero, like the image's border)
         uint32_t h = 0u;
         for (int b = 0; b < 4; b++)
-          if (c0 + c4 + b < S) h |= (qv[b] >> 8) << (8 * b);
+          if (c0 + c4 + b < S) h |= (CB == 2 ? qv[b] >> 8 : qv[b]) << (8 * b);
         if (h) {  // (both tiled copies: a 4-aligned group of four cells never straddles a tile of either)
           const uint32_t hr = (uint32_t)(r0 + r + pad), hc = (uint32_t)(c0 + c4 + pad);
           *reinterpret_cast<uint32_t *>(g + hi_offset + hi_tiled(hr, hc, 0u, (uint32_t)hi_tpr, (uint32_t)hi_copy_bytes)) = h;
@@ -495,15 +496,16 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
     const int32_t r0 = (tile / tiles) * TILE, c0 = (tile % tiles) * TILE;
     uint8_t *g = grids + (size_t)t * slot_bytes;
     zero_tile<W>(g, pitch, r0, pad, S, (c0 + pad) * cb, TILE * cb);
-    if (cb == 2) {
+    {
       // the tile's 64 x 64 cells in the matcher's tiled planes, 16 bytes (one tile row) a store where the tiles allow:
       // pad and c0 are multiples of 16 columns here (W == 16), so per row the first copy of the high bytes takes four
       // whole tile rows, the shifted copy half a tile row + three whole + half, the 16-bit copy eight whole ones
       uint8_t *hp = g + hi_offset;
       const uint32_t tpr = (uint32_t)hi_tpr, cpb = (uint32_t)hi_copy_bytes, cc = (uint32_t)(c0 + pad);
       if (((c0 + pad) & 15) == 0) {
-        for (int i = threadIdx.x; i < TILE * 17; i += 256) {
-          const int r = i / 17, d = i % 17;
+        const int per = cb == 2 ? 17 : 9;  // (8-bit cells: no tiled 16-bit copy)
+        for (int i = threadIdx.x; i < TILE * per; i += 256) {
+          const int r = i / per, d = i % per;
           if (r0 + r >= S) continue;
           const uint32_t row = (uint32_t)(r0 + r + pad);
           if (d < 4) {
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
           if (r0 + r >= S) continue;
           const uint32_t row = (uint32_t)(r0 + r + pad), col = cc + 4u * (uint32_t)d;
           if (k < 2) *reinterpret_cast<uint32_t *>(hp + hi_tiled(row, col, (uint32_t)k, tpr, cpb)) = 0u;
-          else *reinterpret_cast<uint2 *>(hp + 2 * hi_copy_bytes + t16_tiled(row, col, (uint32_t)t16_tpr)) = make_uint2(0u, 0u);
+          else if (cb == 2) *reinterpret_cast<uint2 *>(hp + 2 * hi_copy_bytes + t16_tiled(row, col, (uint32_t)t16_tpr)) = make_uint2(0u, 0u);
         }
       }
     }
@@ -643,7 +645,8 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     if (L.cb == 1)
       hipLaunchKernelGGL(grid_blur_kernel<1>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
-                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16, (int64_t)0, 0, (int64_t)0, 0);
+                         tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, 0);
     else
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,

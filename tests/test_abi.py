@@ -49,8 +49,9 @@ def test_grid_layout_follows_cimg_debug():
     assert L.pool_rows == 174 + 12 and L.pool_pitch == 192 and L.pool_bytes == 186 * 192
     # second level: a byte pair per 4 x 4 cells + the reach of 22 sub-blocks + a 16-byte read from an aligned offset
     assert L.pool4_rows == 348 + 24 and L.pool4_pitch == 768 and L.pool4_bytes == 372 * 768
-    assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes and L.slot_bytes % 16 == 0
-    assert L.hi_bytes == 0 and L.hi_pitch == 0
+    # the matcher's tiled 8-bit plane (8-bit grids: the cells themselves): two copies of 174 x 88 tiles of 8 rows x 16 bytes
+    assert L.hi_pitch == 1392 and L.hi_bytes == 2 * 174 * 88 * 128
+    assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes and L.slot_bytes % 16 == 0
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
     L16 = csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40))  # the default width: 16-bit cells (0 means 16 too)
     zero = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=0)

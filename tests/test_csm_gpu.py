@@ -84,6 +84,9 @@ def test_grid_bit_exact_and_border_zero(gpu, small_bag):
         inner = stored[L.pad:L.pad + L.side, L.pad:L.pad + L.side]
         assert np.array_equal(inner, want)
         assert want.max() > 200 and (want > 0).sum() > 1000
+        # the matcher's tiled copies of the cells (two, the second shifted by 8 columns) hold the same bytes
+        for cp in (0, 1):
+            assert np.array_equal(grids.hi_plane(slot, copy=cp)[:, :L.rows], stored[:, :L.rows])
         border = stored.copy()
         border[L.pad:L.pad + L.side, L.pad:L.pad + L.side] = 0
         assert not border.any(), "zero border violated"
