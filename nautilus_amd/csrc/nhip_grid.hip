@@ -412,11 +412,11 @@ __global__ __launch_bounds__(256) void grid_pool_kernel(const uint8_t *__restric
 // level-2 windows [4a, 4a + 7) x [4b, 4b + 7), a = 2i .. 2i + 2, b = 2j .. 2j + 2, and a maximum of maxima is the
 // maximum (ceil(. / 257) is monotone, so the scaled bytes of 16-bit cells commute with it too): the 36 KB table is
 // derived from the 286 KB one instead of from a second pass over the image (0.37 -> 0.03 ms per 1000 targets).
-__global__ __launch_bounds__(64) void grid_pool8_from_pool4_kernel(uint8_t *__restrict__ grids, int32_t rows, int64_t pool_offset,
+__global__ __launch_bounds__(256) void grid_pool8_from_pool4_kernel(uint8_t *__restrict__ grids, int32_t rows, int64_t pool_offset,
                                                                    int64_t pool4_offset, int64_t slot_bytes, int32_t pool_pitch,
                                                                    int32_t pool4_pitch, int32_t t_base) {
   // one thread per four entries (i, 4q .. 4q + 3): five dwords of each of three level-2 rows in, one dword out
-  const int32_t t = t_base + blockIdx.z, i = blockIdx.y, q = blockIdx.x * 64 + threadIdx.x;
+  const int32_t t = t_base + blockIdx.z, i = 4 * blockIdx.y + (threadIdx.x >> 6), q = blockIdx.x * 64 + (threadIdx.x & 63);
   const int32_t n8 = (rows + BNB_B - 1) / BNB_B;  // pooled rows = pooled columns (square image)
   if (i >= n8 || 4 * q >= n8) return;
   uint8_t *g = grids + (size_t)t * slot_bytes;
@@ -558,7 +558,7 @@ void launch_pool8_from_pool4(uint8_t *g, const GridLayout &L, int32_t n, hipStre
   const int64_t off8 = L.grid_bytes + L.skip_bytes, off4 = off8 + L.pool_bytes;
   for (int32_t z0 = 0; z0 < n; z0 += 65535) {  // gridDim.z is limited to 65,535
     const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
-    hipLaunchKernelGGL(grid_pool8_from_pool4_kernel, dim3((n8 + 255) / 256, n8, nz), dim3(64), 0, s, g, rows, off8, off4,
+    hipLaunchKernelGGL(grid_pool8_from_pool4_kernel, dim3((n8 + 255) / 256, (n8 + 3) / 4, nz), dim3(256), 0, s, g, rows, off8, off4,
                        L.slot_bytes, L.pool_pitch, L.pool4_pitch, z0);
   }
 }
@@ -616,11 +616,16 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     if (incremental && one_pass) {
       // the tiles the previous build wrote (or everything, if the header does not vouch for this buffer), then the
       // derived tables between the image and the plane of high bytes: skip map and the two pooled tables, every slot
-      const int64_t tb = L.skip_bytes + L.pool_bytes + L.pool4_bytes, hio = L.grid_bytes + tb;
+      // (without a skip map -- 16-bit grids unless the spec asks for one -- only the second-level table: nothing reads
+      //  the map's space, and the first-level table is rewritten entry by entry from the second)
+      const bool with_map = L.cb == 1 || (spec->flags & NHIP_GRID_SKIP_MAP);
+      const int64_t hio = L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes;
+      const int64_t tb = with_map ? L.skip_bytes + L.pool_bytes + L.pool4_bytes : L.pool4_bytes;
+      const int64_t to = with_map ? L.grid_bytes : L.grid_bytes + L.skip_bytes + L.pool_bytes;
       const int w = (L.pad * L.cb) % 16 == 0 ? 16 : ((L.pad * L.cb) % 8 == 0 ? 8 : 4), wh = L.pad % 16 == 0 ? 16 : (L.pad % 8 == 0 ? 8 : 4);
 #define NHIP_CLEAR(W, WH)                                                                                             \
   hipLaunchKernelGGL((grid_clear_kernel<W, WH>), dim3(4096), dim3(256), 0, s, count, tag, list, g, n, L.S, tiles, L.pad, \
-                     L.pitch, L.cb, L.slot_bytes, L.grid_bytes, tb, hio, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr)
+                     L.pitch, L.cb, L.slot_bytes, to, tb, hio, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr)
       if (w == 16 && wh == 16) NHIP_CLEAR(16, 16);
       else if (w == 16) NHIP_CLEAR(16, 4);
       else if (w == 8) NHIP_CLEAR(8, 4);

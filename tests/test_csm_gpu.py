@@ -896,9 +896,10 @@ def test_drop_in_call_with_rotation_restriction_pi(gpu, small_bag):
     assert got[0] == want[0] and got[1][0][0] == want[1][0][0] and got[1][0][1] == want[1][0][1] and got[1][1] == want[1][1]
 
 
-@pytest.mark.parametrize("cell_bits,geometry", [(16, (30.0, 0.05, 2.0, 40)), (8, (30.0, 0.05, 2.0, 40)),
-                                                (16, (10.0, 0.03, 1.0, 10)), (16, (12.0, 0.05, 2.0, 6))])
-def test_grid_rebuild_clears_what_the_last_build_wrote(gpu, small_bag, cell_bits, geometry):
+@pytest.mark.parametrize("cell_bits,geometry,skip_map", [(16, (30.0, 0.05, 2.0, 40), True), (8, (30.0, 0.05, 2.0, 40), True),
+                                                         (16, (10.0, 0.03, 1.0, 10), True), (16, (12.0, 0.05, 2.0, 6), True),
+                                                         (16, (30.0, 0.05, 2.0, 40), False), (16, (10.0, 0.03, 1.0, 10), False)])
+def test_grid_rebuild_clears_what_the_last_build_wrote(gpu, small_bag, cell_bits, geometry, skip_map):
     """nhip_grid_rebuild_dev clears only the tiles the previous build listed in the workspace -- and must leave the
     buffer exactly as a build into zeroed memory would: other targets than before (their tiles lie elsewhere), a
     workspace whose header holds garbage, and a buffer the workspace has never seen (full of 0xFF) all give the
@@ -909,7 +910,8 @@ def test_grid_rebuild_clears_what_the_last_build_wrote(gpu, small_bag, cell_bits
     # (the second and third geometry have borders of 36 and 28 cells: their tiles do not start on the 16-byte
     #  boundaries of the tiled planes, and the clearing kernel takes its dword path)
     range_m, res, sigma, max_shift = geometry
-    spec = csm.grid_spec(range_m, res, sigma, 1e-10, max_shift, cell_bits, skip_map=True)
+    # (without a skip map the rebuild leaves the map's space and the first-level table's out of its clearing)
+    spec = csm.grid_spec(range_m, res, sigma, 1e-10, max_shift, cell_bits, skip_map=skip_map)
     L = csm.grid_layout(spec)
     xy, off = csm.pack_scans(small_bag.scans)
     t = lambda a: torch.from_numpy(a).to(dev)
