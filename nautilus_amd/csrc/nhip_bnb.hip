@@ -2194,12 +2194,14 @@ static unsigned long long *g_bnb_stats = nullptr;
 constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, next entry to work}
 // Small batches: room for 16 handed-over rotations per pair on average (what does not fit is worked by the pair's own
 // workgroup).  The split form: per pair its four counters, 1.5 entries of the candidates' work list and the rows of
-// bounds of up to 64 rotations.  It is used for lists of SPLIT_MIN_PAIRS .. SPLIT_PAIRS pairs, in ONE round: measured
-// (tools/bnb_size_ab.sh, profiles/r03_matcher_experiments.txt) 3,000 pairs fused 4.8 / split 5.3 ms, 10,000 pairs 8.2 / 7.3,
-// 40,000 pairs 29.1 / 26.7 in one round but 29.9 in rounds of 16,384 (every round pays its own tail), 1,000,000 pairs
-// with 100 per target 612 fused / 868 in rounds -- so longer lists, which also profit most from the fused form's L2
-// locality, stay fused.  (Rounds exist for tests and measurements: NHIP_BNB_SPLIT_BATCH.)
-constexpr int64_t SPLIT_PAIRS = 65536, SPLIT_MIN_PAIRS = 6144, SPLIT_RING = 16;
+// bounds of up to 64 rotations.  Lists of SPLIT_MIN_PAIRS .. SPLIT_PAIRS pairs take it in ONE round; longer lists in
+// rounds of SPLIT_PAIRS with the candidates of a round on the helper stream beside the next round's bounds, which needs
+// two rounds' state (8.6 GB at 61 rotations); with less workspace they stay fused.  Measured on the final build
+// (tools/bnb_size_ab.sh, profiles/r03_matcher_experiments.txt; match ms fused / split): 3,000 pairs 4.2 / 4.7, 4,500
+// pairs 4.3 / 3.4, 10,000 pairs 8.1 / 6.5, 40,000 pairs 27.1 / 22.8, 60,000 pairs at 60 per target 39.3 / 34.1,
+// 1,000,000 pairs at 100 per target 606 fused, 663 in rounds of 65,536 without the helper stream (every round pays its
+// own tail), 600 with it, 543 in rounds of 131,072 with it.
+constexpr int64_t SPLIT_PAIRS = 131072, SPLIT_MIN_PAIRS = 4096, SPLIT_RING = 16;
 int64_t split_bytes_per_pair(int32_t n_theta) { return 16 + 6 + (int64_t)n_theta * 512; }
 constexpr int64_t SPLIT_SLOT_FIXED = 8 * 64 * 4 + 1024;  // per batch: the work lists' floor of 64 extra entries, alignment
 int64_t bnb_workspace_bytes(int32_t n_pairs) {
@@ -2208,10 +2210,10 @@ int64_t bnb_workspace_bytes(int32_t n_pairs) {
   const char *sp = getenv("NHIP_BNB_SPLIT");  // (=1: the split form for small batches too -- tests)
   const char *spp = getenv("NHIP_BNB_SPLIT_PAIRS");  // (measurement: pairs the workspace holds state for)
   const int64_t cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
-  const int64_t m = n < cap ? n : cap;
+  const int64_t m = n <= cap ? n : 2 * cap;  // (a longer list: two rounds' state, so that the helper stream can be used)
   const bool forced = n > 0 && ((sp && sp[0] == '1') || getenv("NHIP_BNB_SPLIT_BATCH"));
-  const int64_t split = (n >= SPLIT_MIN_PAIRS && n <= cap) || forced
-                            ? BNB_WS_HEADER + (m / 512 + 2) * SPLIT_SLOT_FIXED + m * split_bytes_per_pair(64) : 0;
+  const int64_t split = n >= SPLIT_MIN_PAIRS || forced
+                            ? BNB_WS_HEADER + (m / 512 + 4) * SPLIT_SLOT_FIXED + m * split_bytes_per_pair(64) : 0;
   return lists > split ? lists : split;
 }
 
@@ -2355,7 +2357,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const char *spp = getenv("NHIP_BNB_SPLIT_PAIRS");
   const int64_t split_cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
   if (d_workspace && !P.general_all && !P.rot_list && P.debug == 0 && !(sp && sp[0] == '0') &&
-      ((n_pairs >= SPLIT_MIN_PAIRS && (n_pairs <= split_cap || sbat)) || (sp && sp[0] == '1'))) {
+      (n_pairs >= SPLIT_MIN_PAIRS || (sp && sp[0] == '1'))) {
     split_batch = sbat && atoi(sbat) > 0 ? atoi(sbat) : split_cap;
     if (split_batch > n_pairs) split_batch = n_pairs;
     for (;;) {  // (a workspace too small for two batches in flight: smaller batches, down to 512 pairs)
@@ -2367,6 +2369,8 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     }
     if (split_slots > SPLIT_RING) split_slots = SPLIT_RING;
     if (split_slots < 1) split_batch = 0;  // (no room: the fused form)
+    // (several rounds pay off only with the helper stream, i.e. with two rounds' state, and in rounds that are long)
+    if (!sbat && split_batch > 0 && n_pairs > split_batch && (split_slots < 2 || split_batch < split_cap)) split_batch = 0;
   }
   timer_begin(NHIP_TIMER_CSM, s);
   if (split_batch > 0) {
