@@ -864,7 +864,7 @@ def bench_drop_in(bag, with_cpu, calls=8):
         each.append(time.perf_counter() - t0)
     dt = float(np.median(each))  # (a call allocates and frees 72 MB of device memory: the odd one waits for the driver)
     out = {"workload": "%d single-pair calls on dense 1081-beam scans: 181x13x13 lattice on a 200x200 grid, then "
-                       "21x61x61 on a 6000x6000 grid of 16-bit cells (72 MB built per call)" % calls,
+                       "21x61x61 on a 6000x6000 grid of 16-bit cells (77 MB of cells + 161 MB of bound tables and tiled planes, zeroed and built per call)" % calls,
            "seconds_per_call": dt, "calls_per_s": 1.0 / dt, "each_call_s": each}
     if with_cpu:
         from oracle import oracle as O
