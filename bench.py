@@ -765,7 +765,7 @@ def leg_host_api(wl, shard, m, got, got_sums):
     from nautilus_amd import csm
     idx, src, tgt, th0, ids, slot = shard
     runs = []
-    for _ in range(3):  # (the first run also pays for fresh device allocations of 2.3 GB)
+    for _ in range(3):  # (the first run also pays for fresh device allocations: 12 GB of tables at 16-bit cells)
         t0 = time.perf_counter()
         st = csm.ScanTable(wl.xy, wl.off)
         gr = csm.LikelihoodGrids(st, ids, m.spec)
