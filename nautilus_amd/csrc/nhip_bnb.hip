@@ -206,6 +206,31 @@ __device__ __forceinline__ unsigned long long shfl_xor_u64b(unsigned long long v
   return ((unsigned long long)hi << 32) | lo;
 }
 
+// ---- one lane acts for the wave ------------------------------------------------------------------------------
+// `if (lane == 0) x = atomicAdd(...); x = readfirstlane(x);` at the head of a loop whose body ends in
+// `if (lane == 0) atomicMax(...)` is two tests of ONE value, and hipcc threads the second into the first: lanes 1..63,
+// for which both are false, get a loop of their own that bypasses both blocks, and lane 0 is parked until they leave
+// it.  readfirstlane is a convergent operation: without lane 0 it returns lane 1's x = 0, the sub-wave takes entry 0
+// again and again (lane 0's atomicMax, which would prune it, never runs) and the kernel does not return.  That was the
+// hang of the general instantiation under NHIP_BNB_LEVELS=1 once its counters were compiled out (round 3; the
+// counters' increments kept the two blocks apart): profiles/r04_general_kernel_hang_isa.txt shows the threaded loop.
+// So the lane id of every such test passes through an empty asm: each test is then of a value the compiler knows
+// nothing about, and no two of them can be related.
+__device__ __forceinline__ bool wave_leader(int lane) {
+  asm volatile("" : "+v"(lane));
+  return lane == 0;
+}
+// atomicAdd by one lane, the old value in every lane (wave-uniform, in a scalar register)
+__device__ __forceinline__ uint32_t wave_fetch_add(uint32_t *p, uint32_t v, int lane) {
+  uint32_t r = 0u;
+  if (wave_leader(lane)) r = atomicAdd(p, v);
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)r);
+}
+// atomicMax of a wave-uniform key by one lane (generic address: LDS or global)
+__device__ __forceinline__ void wave_atomic_max(unsigned long long *p, unsigned long long key, int lane) {
+  if (wave_leader(lane)) atomicMax(p, key);
+}
+
 // One step of a transposing reduction over the lanes: lanes pair up across MASK; of every two registers the
 // lane keeps the one its own bit selects, adds the partner's copy of the same register, and gives the other away.
 // N registers in, N / 2 out.  No step goes through LDS:
@@ -1263,7 +1288,7 @@ __device__ __forceinline__ uint32_t refine16(const BnbParams &P, __amdgpu_buffer
     const uint32_t sum = pose_sum16(P, rsrc16, org, nch, jx, jy);
     const uint32_t lin = (uint32_t)((k * P.nx + jx) * P.ny + jy);
     const unsigned long long key = ((unsigned long long)sum << 32) | (0xffffffffu - lin);
-    if (lane == 0) atomicMax(best, key);  // (generic address: LDS or global)
+    wave_atomic_max(best, key, lane);  // (generic address: LDS or global)
     if (GLOBAL) bcopy = max(bcopy, sum);
     if (lane == j) ub = 0u;
     n_eval++;
@@ -1312,14 +1337,14 @@ __device__ __forceinline__ void process_candidate(const BnbParams &P, const Pair
         const uint32_t b = q == 0 ? sb[0] : (q == 1 ? sb[1] : (q == 2 ? sb[2] : sb[3]));  // (no indexed array: scratch)
         if (b == 0u || b < best_sum<false>(best)) continue;
         const unsigned long long key = eval_sub<CB>(P, rsrc, C.pts, C.n_pts, cf, sf, C.cx, C.cy, k, Y, X, q >> 1, q & 1, lane);
-        if (lane == 0) atomicMax(best, key);
+        wave_atomic_max(best, key, lane);
         n[2]++;
       }
       return;
     }
   }
   const unsigned long long key = eval_block<CB>(P, C.grid, C.pts, C.n_pts, cf, sf, C.cx, C.cy, k, Y, X, lane);
-  if (lane == 0) atomicMax(best, key);
+  wave_atomic_max(best, key, lane);
   n[0]++;
 }
 
@@ -1342,7 +1367,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
     const int32_t ix = BNB_B * X + dx, iy = BNB_B * Y + dy;
     if (CB == 1) {
       const unsigned long long key = best_key(P, k, ix, iy, total, 32);
-      if (lane == 0) atomicMax(best, key);  // (generic address: LDS or global)
+      wave_atomic_max(best, key, lane);  // (generic address: LDS or global)
       if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
     } else {
       n[3] += refine16<GLOBAL>(P, rsrc16, org, nch, n_pts, k, ix, iy, total, true, lane, best, bcopy);
@@ -1359,7 +1384,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
     const int32_t ix = BNB_B * X + BNB_B4 * (q & 1) + dx, iy = BNB_B * Y + BNB_B4 * (q >> 1) + dy;
     if (CB == 1) {
       const unsigned long long key = best_key(P, k, ix, iy, total, 8);  // (lanes 16.. hold copies)
-      if (lane == 0) atomicMax(best, key);
+      wave_atomic_max(best, key, lane);
       if (GLOBAL) bcopy = max(bcopy, (uint32_t)(key >> 32));
     } else {
       n[3] += refine16<GLOBAL>(P, rsrc16, org, nch, n_pts, k, ix, iy, total, lane < 16, lane, best, bcopy);
@@ -1443,7 +1468,7 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
       process_candidate_c<CB, GLOBAL>(P, rsrc, pitch8, rsrc16, org, nch, C.n_pts, k, Y, X0 + t, s0, s1, s2, s3, lane, best,
                                       bcopy, n_work);
       if (BNB_STATS(P)) clk.eval += clock64() - t_mark;
-      if (done && lane == 0) done[b] = 0u;
+      if (done && wave_leader(lane)) done[b] = 0u;
     }
   }
 }
@@ -1511,12 +1536,9 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
 
   // pose 0 with sum 0 is a lower bound of the optimum (sums are >= 0; if all are 0, pose 0 is the answer)
   const unsigned long long key0 = 0xffffffffull;
-  // The general instantiation (scans too long for the by-rotation form) keeps its work counters in the product build
-  // too, behind this pointer, which the product host code leaves null.  With them compiled out, hipcc 7.2 -O3 produced
-  // a kernel that never returned on scans of more than 1088 points under NHIP_BNB_LEVELS=1 (every candidate block
-  // evaluated whole; tools/bnb_hang_probe2.py reproduces it; with the counters compiled in and switched off, as in
-  // every earlier build, the same source runs through 3,000 sweep configurations).  Cause not found: the counters stay.
-  unsigned long long *const stats_g = (NHIP_BNB_INSTR || !BY_ROT) ? P.stats : nullptr;
+  // (work counters: the instrumented build only.  Round 3 kept them in the general instantiation of the product build
+  //  because it hung without them -- see wave_leader() for the cause, which was in the source, not in the counters.)
+  unsigned long long *const stats_g = NHIP_BNB_INSTR ? P.stats : nullptr;
   const long long t_start = BNB_STATS(P) ? clock64() : 0;
   if (BNB_TIMELINE(P) && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) BNB_TIMELINE(P)[4 * pair] = wall_clock64();
   if (threadIdx.x == 0) {
@@ -1576,7 +1598,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         const uint32_t o = shfl_xor_u32(umax, m);
         umax = o > umax ? o : umax;
       }
-      if (lane == 0) s_kmax[k] = ((unsigned long long)umax << 32) | (uint32_t)k;
+      if (wave_leader(lane)) s_kmax[k] = ((unsigned long long)umax << 32) | (uint32_t)k;
     }
   }
 #pragma unroll
@@ -1601,7 +1623,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     // what ~50 sub-block bounds do, and the eight blocks are mostly neighbours in rotation: the lower ones rarely raise
     // the best).  Each wave leaves its bound in its own, now idle, run list.
     unsigned long long *s_wbest = reinterpret_cast<unsigned long long *>(s_list + wave * LIST_ENTRIES);
-    if (lane == 0) *s_wbest = wbest;
+    if (wave_leader(lane)) *s_wbest = wbest;
     __syncthreads();
     if (P.seeds < BNB_WAVES) {
       uint32_t above = 0u;
@@ -1651,8 +1673,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
       } else if (state == OWN) {
         int32_t rank = P.n_theta;
         if (BNB_DEBUG(P) == 0 || (BNB_DEBUG(P) >= 3 && BNB_DEBUG(P) < 26)) {
-          if (lane == 0) rank = (int32_t)atomicAdd(s_qhead, 1u);
-          rank = __builtin_amdgcn_readfirstlane(rank);
+          rank = (int32_t)wave_fetch_add(s_qhead, 1u, lane);
         }
         if (rank >= P.n_theta) break;
         k = (int32_t)s_order[rank];
@@ -1663,11 +1684,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         m1 = __ballot(u1 != 0u && u1 >= bsum && lane + 64 < NB * NB);
         if ((m0 | m1) == 0ull) continue;
         if (heavy && (uint32_t)rank >= P.keep_ranks) {
-          uint32_t e = 0u;
-          if (lane == 0) {
-            e = atomicAdd(P.rot_count + 8 * xcd, 1u);
-          }
-          e = (uint32_t)__builtin_amdgcn_readfirstlane((int)e);
+          const uint32_t e = wave_fetch_add(P.rot_count + 8 * xcd, 1u, lane);
           if (e < P.rot_cap) {
             if (lane < 4) {
               const unsigned long long M41 = (1ull << 41) - 1ull;
@@ -1707,7 +1724,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
             mine += (uint32_t)__builtin_popcountll(__ballot(c0 != 0u && c0 >= bsum)) +
                     (uint32_t)__builtin_popcountll(__ballot(c1 != 0u && c1 >= bsum && lane + 64 < NB * NB));
           }
-          if (lane == 0) atomicAdd(s_qn, mine);
+          if (wave_leader(lane)) atomicAdd(s_qn, mine);
         }
         __syncthreads();
         if (SPLIT) {
@@ -1724,7 +1741,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
             rows[(size_t)r * 128u + lane] = s_U[kk * 128 + lane];
             rows[(size_t)r * 128u + 64 + lane] = w1;
           }
-          if (lane == 0 && live) atomicMax(s_qhead, live);  // (the hand-out counter is not used in this form)
+          if (live && wave_leader(lane)) atomicMax(s_qhead, live);  // (the hand-out counter is not used in this form)
           __syncthreads();
           if (threadIdx.x == 0) {
             P.ps_count[pair] = *s_qn;
@@ -1758,7 +1775,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
       float cf, sf;
       rotation_k(P, pair, k, &cf, &sf);
       const unsigned long long key = eval_block<CB>(P, grid, pts, n_pts, cf, sf, cx, cy, k, Y, X, lane);
-      if (lane == 0) {
+      if (wave_leader(lane)) {
         atomicMax(s_best, key);
         s_U[k * 128 + v] = 0u;  // done
       }
@@ -1775,9 +1792,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         bool cand = u != 0u && u >= bsum;
         const unsigned long long m = __ballot(cand);
         if (m == 0ull) continue;
-        uint32_t base = 0u;
-        if (lane == 0) base = atomicAdd(s_qn, (uint32_t)__builtin_popcountll(m));
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint32_t base = wave_fetch_add(s_qn, (uint32_t)__builtin_popcountll(m), lane);
         const uint32_t pos = base + (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
         const unsigned long long entry = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | (lane + 64 * i));
         if (cand && pos < (uint32_t)QCAP) s_queue[pos] = entry;
@@ -1796,9 +1811,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     {
       const uint32_t qn = min(*s_qn, (uint32_t)QCAP);
       while (BNB_DEBUG(P) == 0 || BNB_DEBUG(P) == 3) {
-        uint32_t i = 0u;
-        if (lane == 0) i = atomicAdd(s_qhead, 1u);
-        i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+        const uint32_t i = wave_fetch_add(s_qhead, 1u, lane);
         if (i >= qn) break;
         const unsigned long long entry = s_queue[i];
         if ((uint32_t)(entry >> 32) >= best_sum<false>(s_best))
@@ -1853,9 +1866,7 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
   PhaseClocks clk = {0, 0, 0};
   const long long t0 = BNB_STATS(P) ? clock64() : 0;
   for (;;) {
-    uint32_t i = 0u;
-    if (lane == 0) i = atomicAdd(P.rot_count + 8 * xcd + 1, 1u);
-    i = (uint32_t)__builtin_amdgcn_readfirstlane((int)i);
+    const uint32_t i = wave_fetch_add(P.rot_count + 8 * xcd + 1, 1u, lane);
     if (i >= count) break;
     int32_t pair, k;
     unsigned long long m0, m1;
@@ -2033,9 +2044,7 @@ __global__ __launch_bounds__(CAND_THREADS, CB == 2 ? NHIP_BNB_CAND_OCC16 : NHIP_
   PhaseClocks clk = {0, 0, 0};
   const long long t0 = BNB_STATS(P) ? clock64() : 0;
   for (;;) {
-    uint32_t rank = 0u;
-    if (lane == 0) rank = atomicAdd(next, 1u);
-    rank = (uint32_t)__builtin_amdgcn_readfirstlane((int)rank);
+    const uint32_t rank = wave_fetch_add(next, 1u, lane);
     if (rank >= live) break;
     const uint32_t u0 = rows[(size_t)rank * 128u + lane], u1 = rows[(size_t)rank * 128u + 64 + lane];
     const uint32_t kmax = (uint32_t)__builtin_amdgcn_readlane((int)u1, 62);
