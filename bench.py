@@ -51,7 +51,10 @@ def parse(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--mode", choices=["weak", "config4"], default="weak")
+    ap.add_argument("--mode", choices=["weak", "config4"], default=None,
+                    help="default: one GPU runs BASELINE configs[1] (`weak` with one rank IS that config); --gpus N > 1 runs "
+                         "BASELINE configs[3], ONE list of 10,000 scans / 1,000,000 pairs sharded over the N ranks (config4, "
+                         "strong scaling: what north_star quotes); `--mode weak` with N > 1 = N x configs[1] from one list")
     ap.add_argument("--scans", type=int, default=None, help="scans per GPU (weak, default 1000) / in all (config4, default 10000)")
     ap.add_argument("--per-target", type=int, default=None, help="pairs per target scan (default 10 weak / 100 config4)")
     ap.add_argument("--cell-bits", type=int, choices=[8, 16], default=16,
@@ -69,7 +72,10 @@ def parse(argv=None):
     ap.add_argument("--no-drop-in", action="store_true",
                     help="skip the single-pair latency leg (its small launches of the correlation kernel would "
                          "blur that kernel's average in a rocprofv3 --stats summary)")
-    return ap.parse_args(argv)
+    a = ap.parse_args(argv)
+    if a.mode is None:
+        a.mode = "weak" if a.gpus <= 1 else "config4"
+    return a
 
 
 # ------------------------------------------------------------------------------------------ launcher
@@ -164,7 +170,11 @@ class HipMatcher:
         # (the kernel that performs every add reads the skip maps; the branch-and-bound matcher does not, and 16-bit
         #  grids are built without them unless asked)
         self.spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=cell_bits, skip_map=exhaustive)
-        self.search = csm.search_spec(61, 81, 81, math.radians(1.0), exhaustive=exhaustive)
+        # (the host knows its scan lengths: 1081-beam scans all fit the matcher's by-rotation form, and saying so saves
+        #  the launch of the other instantiation's n_pairs workgroups, which would all return at once)
+        lens = np.diff(np.asarray(wl.off))
+        self.search = csm.search_spec(61, 81, 81, math.radians(1.0), exhaustive=exhaustive,
+                                      short_scans=bool(len(lens) == 0 or lens.max() <= _lib.NHIP_SHORT_SCAN_POINTS))
         self.layout = csm.grid_layout(self.spec)
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
         self.d_xy, self.d_off = t(wl.xy), t(wl.off)
@@ -479,7 +489,8 @@ def worker(a):
     avg_ms = k_ms / max(k_n, 1)
 
     # per-rank load balance: pairs, targets, correlate-kernel ms per step
-    mine = torch.tensor([m.n_pairs, m.n_targets, k_ms / a.steps, g_ms / a.steps], dtype=torch.float64, device=dev)
+    cost_mine = float(plan.rank_weight[rank]) if plan.rank_weight is not None else float(m.n_pairs)
+    mine = torch.tensor([m.n_pairs, m.n_targets, k_ms / a.steps, g_ms / a.steps, cost_mine], dtype=torch.float64, device=dev)
     if use_dist and world > 1:
         allr = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(allr, mine)
@@ -560,8 +571,14 @@ def worker(a):
                    "rccl_world_size": dist.get_world_size() if use_dist else 1,
                    "collective_backend": ("gloo (REHEARSAL on a shared GPU: not a measurement)" if rehearsal else "nccl (RCCL)") if use_dist else None,
                    "collective": "all_gather 16 B/pair" if world > 1 else "none",
+                   # (predicted_cost: the plan's estimate for the rank's shard, in units of one nearby pair -- what the
+                   #  contiguous by-target split balances; beside it the time the rank's matcher actually took)
                    "per_rank": [{"pairs": int(r[0]), "targets": int(r[1]), "correlate_ms_per_step": r[2],
-                                 "grid_ms_per_step": r[3]} for r in per_rank]},
+                                 "grid_ms_per_step": r[3], "predicted_cost": r[4],
+                                 "predicted_cost_over_mean": r[4] / max(float(np.mean(per_rank[:, 4])), 1e-30)} for r in per_rank],
+                   "shard_balance": {"by": "pair count" if a.no_cost_model else "predicted cost (sharding.predicted_pair_cost)",
+                                     "max_over_mean_predicted_cost": float(np.max(per_rank[:, 4]) / max(np.mean(per_rank[:, 4]), 1e-30)),
+                                     "max_over_mean_correlate_ms": float(np.max(per_rank[:, 2]) / max(np.mean(per_rank[:, 2]), 1e-30))}},
         # The matcher in its split form is two kernels; the LONGER one of this run carries the roofline, the other sits in
         # roofline.matcher.  Bounds + seeds: vector-ALU work on the LDS-resident pooled table, priced against the
         # vector-instruction peak.  Candidates: gathers through the vector L1, priced against the busy time of the
@@ -651,7 +668,8 @@ def worker(a):
             except Exception as e:  # secondary measurements must not lose the headline line
                 sec[name + "_error"] = repr(e)
         m.free_grids()
-        more = [("icp_front_half", lambda: bench_icp(wl.bag, wl.xy, wl.off, a.cpu_seconds > 0)),
+        more = [("config4_one_gpu", lambda: leg_config4_one_gpu(dev, a, lib, _lib)),
+                ("icp_front_half", lambda: bench_icp(wl.bag, wl.xy, wl.off, a.cpu_seconds > 0)),
                 ("host_buffer_api", lambda: leg_host_api(wl, shard, m, got, got_sums))]
         if not a.no_drop_in:
             more.append(("drop_in_two_level", lambda: bench_drop_in(wl.bag, a.cpu_seconds > 0)))
@@ -668,6 +686,44 @@ def worker(a):
 
 
 # ------------------------------------------------------------------------------------------ legs
+def leg_config4_one_gpu(dev, a, lib, _lib, steps=2):
+    """BASELINE configs[3] -- 10,000 scans, 1,000,000 candidate pairs (100 per target) -- on ONE GPU through the same
+    sharded code at world size 1: grid rebuild + match of the whole list per step.  Lists of more than 131,072 pairs go
+    through the matcher in rounds of that many, the candidates of a round on the library's helper stream beside the
+    next round's bounds (nhip_bnb.hip launch_csm_bnb); 10,000 grids of 16-bit cells are 121 GB of the 288 GB."""
+    import torch
+    from nautilus_amd import sharding
+    t0 = time.perf_counter()
+    wl = Workload("config4", 1)
+    t_gen = time.perf_counter() - t0
+    weights = None if a.no_cost_model else sharding.predicted_pair_cost(wl.bag.odom, wl.src, wl.tgt)
+    plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1, weights)
+    m = HipMatcher(wl, plan.shard(0), dev, a.cell_bits)
+
+    def start():
+        lib.nhip_timing_reset()
+        lib.nhip_timing_enable(1)
+    elapsed, full = run_sharded(plan, 0, 1, dev, m, steps, 1, None, start)
+    lib.nhip_timing_enable(0)
+    k_ms, k_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM)
+    g_ms, _ = _timer(lib, _lib, _lib.NHIP_TIMER_GRID)
+    kb_ms, kb_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM_BOUNDS)
+    kc_ms, kc_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM_CAND)
+    rec = full.cpu().numpy()
+    out = {"value": wl.n_pairs * steps / elapsed, "unit": "pairs/s", "n_gpus": 1, "steps": steps, "warmup": 1,
+           "ms_per_step": 1e3 * elapsed / steps, "scaling": "strong", "dtype": "u%d" % a.cell_bits,
+           "config": {"workload": wl.describe(1), "pairs_total": wl.n_pairs, "scans_total": wl.n_scans},
+           "matcher_ms_per_step": k_ms / steps, "grid_build_ms_per_step": g_ms / steps,
+           "rounds_per_step": kb_n // max(steps, 1), "bounds_ms_per_step": kb_ms / steps, "candidates_ms_per_step": kc_ms / steps,
+           "grids_GB": m.d_grids.numel() / 1e9, "matcher_workspace_GB": m.ws_csm / 1e9, "host_seconds_to_generate_the_bag": t_gen,
+           "records_crc": int(np.bitwise_xor.reduce(rec.astype(np.uint32).reshape(-1) * np.arange(1, rec.size + 1, dtype=np.uint32))),
+           "inside_the_lattice": bool((rec[:, 0] >= 0).all() and (rec[:, 0] < 61).all() and (rec[:, 1:3] >= 0).all() and (rec[:, 1:3] < 81).all())}
+    m.free_grids()
+    del m, full
+    torch.cuda.empty_cache()
+    return out
+
+
 def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3, bits=8):
     """The kernel that performs every add of the exhaustive definition -- SURVEY 8(d)'s work -- (csm_correlate_kernel
     for 8-bit, csm_correlate16_kernel for 16-bit cells: accumulator-stationary, LDS-tiled; all-zero window strips left
@@ -680,8 +736,8 @@ def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3, bits=8):
     out = {}
     for name, env in (("skip_map", None), ("every_add", "1")):
         try:
-            if env:
-                os.environ["NHIP_CSM_DENSE"] = env
+            if env:  # (NHIP_SEARCH_DENSE: the all-zero strips too -- a flag of the ABI, no environment switch)
+                m.search.flags |= _lib.NHIP_SEARCH_DENSE
             m.step()
             torch.cuda.synchronize()
             lib.nhip_timing_reset()
@@ -711,7 +767,7 @@ def leg_exhaustive(wl, shard, dev, lib, _lib, got, got_sums, steps=3, bits=8):
                 r["onchip_roofline"] = oc
             out[name] = r
         finally:
-            os.environ.pop("NHIP_CSM_DENSE", None)
+            m.search.flags &= ~_lib.NHIP_SEARCH_DENSE
     m.free_grids()
     return out
 

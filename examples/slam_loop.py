@@ -67,6 +67,7 @@ def run(n_scans=320, window=10, seed=20201114, drift_t=0.02, drift_th_deg=0.3, v
     kind = _lib.NHIP_LIDAR_NORMAL if residual == "normal" else _lib.NHIP_LIDAR_POINT
     out = {"backend": backend.name, "n_scans": n_scans, "window": window, "residual": residual,
            "err_odometry_m": posegraph.trajectory_error(odom, bag.truth)}
+    posegraph.clock_reset()
 
     t0 = time.perf_counter()
     pg, poses = posegraph.solve_growing_window(xy, nrm, off, odom, 1, window, iterations=iterations, kind=kind,
@@ -79,11 +80,13 @@ def run(n_scans=320, window=10, seed=20201114, drift_t=0.02, drift_th_deg=0.3, v
     t0 = time.perf_counter()
     if gate == "scatter":
         # LCCandidateFilter::GetLCCandidates: scatter-matrix score of every scan (one GPU pass), nodes >= 5 m apart ...
-        scores = hostside.scatter_scores(backend, xy, off)
+        with posegraph.clocked("path"):
+            scores = hostside.scatter_scores(backend, xy, off)
         cand = hostside.lc_candidates_from_scores(poses, scores, min_score=min_scatter_score)
         # ... then the pair gate: |dt| < lc_base_max_range (3.5 m, default_config.lua:122) on the current estimate and
         # more than 20 nodes apart (geometric stand-in for LCMatcher's per-pair ceres::Covariance, lc_matcher.cc:28-74)
-        src, tgt = hostside.geometric_pair_gate(poses, cand, max_range=3.5, min_separation=20, backend=backend)
+        with posegraph.clocked("path"):
+            src, tgt = hostside.geometric_pair_gate(poses, cand, max_range=3.5, min_separation=20, backend=backend)
         out["lc_candidate_scans"] = len(cand)
     else:
         idx = np.arange(n_scans)
@@ -106,10 +109,12 @@ def run(n_scans=320, window=10, seed=20201114, drift_t=0.02, drift_th_deg=0.3, v
                     return np.zeros(0, dtype=csm.MATCH_DTYPE)
                 m_, spec_search["spec"], spec_search["search"] = backend.match(xy, off, src_s, ids_s[slot_s], th_s, cell_bits)
                 return m_
-            m = sharding.distributed_match(match_shard, src, tgt, theta0, rank, world, device=device)
+            with posegraph.clocked("path"):
+                m = sharding.distributed_match(match_shard, src, tgt, theta0, rank, world, device=device)
             spec, search = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits), csm.search_spec()
         else:
-            m, spec, search = backend.match(xy, off, src, tgt, theta0, cell_bits)
+            with posegraph.clocked("path"):
+                m, spec, search = backend.match(xy, off, src, tgt, theta0, cell_bits)
         out["t_csm_s"] = time.perf_counter() - t0
         rel = np.array([csm.match_to_transform(mi, spec, search, t0i) for mi, t0i in zip(m, theta0)], dtype=np.float64)
         inside = (np.abs(m["ix"] - 40) < 40) & (np.abs(m["iy"] - 40) < 40) & (np.abs(m["itheta"] - 30) < 30)
@@ -146,6 +151,14 @@ def run(n_scans=320, window=10, seed=20201114, drift_t=0.02, drift_th_deg=0.3, v
         out["err_hitl_m"] = posegraph.trajectory_error(poses, bag.truth)
         out["hitl_chosen_line_pose"] = [float(v) for v in con.chosen_line_pose]
     out["t_total_s"] = sum(v for k, v in out.items() if k.startswith("t_") and k.endswith("_s"))
+    # By owner: the hot path of this repo (every call into the backend: correspondence search, normal equations,
+    # gating, scan matching -- "gpu_path_s" with the product's backend, "cpu_path_s" with the oracle's), the sparse
+    # solves (the reference's Ceres: out of scope, identical host code under either backend), and the remaining host
+    # bookkeeping (assembly of the sparse system in numpy, HITL point selection, the synthetic message).
+    key = "gpu_path_s" if backend.name == "hip" else "cpu_path_s"
+    out[key] = posegraph.CLOCK["path"]
+    out["host_solver_s"] = posegraph.CLOCK["host_solver"]
+    out["host_other_s"] = out["t_total_s"] - out[key] - out["host_solver_s"]
     return out
 
 

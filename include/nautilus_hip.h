@@ -135,20 +135,30 @@ typedef struct nhip_search {
   int32_t n_theta;
   int32_t nx;
   int32_t ny;
-  int32_t flags;     /* 0, or NHIP_SEARCH_EXHAUSTIVE */
+  int32_t flags;     /* 0, or an OR of NHIP_SEARCH_* */
   double theta_step; /* radians */
 } nhip_search_t;
 /* The matcher's result is that of the exhaustive (theta, x, y) search, always.  By default it gets there by
  * branch and bound: upper bounds of every 8 x 8 block of translations from a max-pooled copy of the table, bounds
  * of the 4 x 4 sub-blocks of the blocks that reach the best sum found from a second one, then exact sums only for
  * the sub-blocks whose bound still reaches it (indices, sums and scores are identical to the exhaustive kernel's,
- * bit for bit: tests compare the two).  NHIP_SEARCH_EXHAUSTIVE (or the environment variable NHIP_CSM_EXHAUSTIVE=1)
+ * bit for bit: tests compare the two).  NHIP_SEARCH_EXHAUSTIVE (or, in a process started with NHIP_TUNABLES=1, the environment variable NHIP_CSM_EXHAUSTIVE=1)
  * forces the kernel that performs every add (csm_correlate_kernel for 8-bit, csm_correlate16_kernel for 16-bit cells;
  * also taken for lattices of more than 88 x 88 translations, or more rotations than fit the LDS beside the bounds:
  * ~230 -- e.g. GetTransformation with a rotation restriction of pi).
  * Scan length: sums are reported as int32, so with 16-bit cells a scan may hold at most 32,768 points (8-bit:
  * 8,421,504); the handle API checks it, callers of the _dev entry points must. */
 #define NHIP_SEARCH_EXHAUSTIVE 1
+/* NHIP_SEARCH_DENSE (with the kernel that performs every add): add every window strip, the all-zero ones the skip map
+ * would leave out too -- literally every add of the exhaustive definition; same records, ~1.5x the time. */
+#define NHIP_SEARCH_DENSE 2
+/* NHIP_SEARCH_SHORT_SCANS: the caller vouches that every source scan of the list has at most NHIP_SHORT_SCAN_POINTS
+ * points (a 1081-beam scan does).  The branch-and-bound matcher serves longer scans with a second instantiation of its
+ * kernel, launched beside the first over all pairs (its workgroups return at once when their pair is not theirs); with
+ * this flag it is not launched.  A PROMISE: pairs whose scan is longer are then not matched at all (their records are
+ * whatever d_keys held).  The handle API (nhip_csm_match) knows the lengths and sets the flag itself. */
+#define NHIP_SEARCH_SHORT_SCANS 4
+#define NHIP_SHORT_SCAN_POINTS 1088
 
 /* One result per candidate pair: 16 bytes, the record that is all-gathered across GPUs. */
 typedef struct nhip_match {
@@ -211,6 +221,13 @@ int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_
                        const nhip_search_t *search, uint64_t *d_keys, nhip_match_t *d_out,
                        int32_t *d_sums, void *d_workspace, int64_t workspace_bytes, void *stream);
 int64_t nhip_csm_workspace_bytes(int32_t n_pairs);
+/* The form the calling thread's last branch-and-bound match took (diagnostic; every form returns the same records):
+ * out[0] = 0 one kernel per pair from start to end (+ the hand-over kernel when out[5]), 1 split form in one round,
+ * 2 split form in several rounds on the caller's stream, 3 split form in rounds with the candidates on the library's
+ * helper stream of the current device; out[1] pairs per round; out[2] rounds' state the workspace holds; out[3] rounds;
+ * out[4] 1 when NHIP_SEARCH_SHORT_SCANS was honoured; out[5] hand-over kernel launched; out[6] instrumented build;
+ * out[7] n_pairs. */
+int nhip_csm_last_launch(int32_t out[8]);
 
 /* With NHIP_BNB_STATS=1 in the environment the branch-and-bound matcher counts its work: blocks of 8 x 8
  * translations whose sums it evaluated exactly (four 4 x 4 sub-blocks count as one block), and blocks in all, since

@@ -13,7 +13,8 @@ LIB_PATH = os.environ.get("NHIP_LIB") or os.path.join(_HERE, "lib", "libnautilus
 
 NHIP_OK, NHIP_ERR_ARG, NHIP_ERR_NODEV, NHIP_ERR_HIP, NHIP_ERR_ALLOC, NHIP_ERR_STATE = 0, -1, -2, -3, -4, -5
 NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1
-NHIP_SEARCH_EXHAUSTIVE = 1
+NHIP_SEARCH_EXHAUSTIVE, NHIP_SEARCH_DENSE, NHIP_SEARCH_SHORT_SCANS = 1, 2, 4
+NHIP_SHORT_SCAN_POINTS = 1088
 NHIP_GRID_SKIP_MAP = 1
 NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ, NHIP_TIMER_GRID_CLEAR = 0, 1, 2, 3, 4, 5
 NHIP_TIMER_CSM_BOUNDS, NHIP_TIMER_CSM_CAND = 6, 7
@@ -79,6 +80,7 @@ PROTOTYPES = {
     "nhip_csm_match_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _vp, _vp, _vp, _vp, _vp, _i32,
                                      _P(Search), _vp, _vp, _vp, _vp, _i64, _vp]),
     "nhip_csm_workspace_bytes": (_i64, [_i32]),
+    "nhip_csm_last_launch": (C.c_int, [_P(_i32)]),
     "nhip_bnb_stats": (C.c_int, [_P(C.c_uint64), _P(C.c_uint64)]),
     "nhip_bnb_stats_per_pair": (C.c_int, [_vp, _i32]),
     "nhip_bnb_timeline": (C.c_int, [_vp, _i32]),

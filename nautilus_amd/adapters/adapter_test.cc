@@ -51,7 +51,124 @@ static void Dump(const char *dir, const char *name, const std::vector<Vec2f> &pc
 
 // argv[1] (optional): directory that receives the point clouds and every matcher result as hex floats, so that
 // tests/test_adapters_gpu.py can compare them with the oracle's restatement float for float.
+
+// ---- one host thread per stream (what SURVEY section 8e describes for a C++ host: one thread per device, here two
+// threads on the one device this box has): each matches its own pair list on its own stream, forced onto the split
+// form in overlapped rounds (NHIP_BNB_SPLIT_BATCH: rounds of 3 pairs, candidates on a helper stream of the library's
+// per-device pool).  A shared event ring or a stream of the wrong device would show as wrong records or an error.
+struct ThreadList {
+  std::vector<int32_t> src, slot;
+  std::vector<double> rot0;  // (cos, sin) per pair
+};
+
+static bool MatchList(const float *d_xy, const int32_t *d_off, const uint8_t *d_grids, const nhip_grid_spec_t &spec,
+                      const nhip_search_t &search, const double *d_delta, const ThreadList &L, hipStream_t st,
+                      std::vector<nhip_match_t> *out, int32_t info[8]) {
+  const int32_t n = (int32_t)L.src.size();
+  int32_t *d_src = nullptr, *d_slot = nullptr;
+  double *d_rot0 = nullptr;
+  uint64_t *d_keys = nullptr;
+  nhip_match_t *d_out = nullptr;
+  void *d_ws = nullptr;
+  const int64_t ws = nhip_csm_workspace_bytes(n);
+  bool ok = hipMalloc(&d_src, 4 * n) == hipSuccess && hipMalloc(&d_slot, 4 * n) == hipSuccess &&
+            hipMalloc(&d_rot0, 16 * n) == hipSuccess && hipMalloc(&d_keys, 8 * n) == hipSuccess &&
+            hipMalloc(&d_out, sizeof(nhip_match_t) * n) == hipSuccess && hipMalloc(&d_ws, (size_t)ws) == hipSuccess;
+  ok = ok && hipMemcpyAsync(d_src, L.src.data(), 4 * n, hipMemcpyHostToDevice, st) == hipSuccess &&
+       hipMemcpyAsync(d_slot, L.slot.data(), 4 * n, hipMemcpyHostToDevice, st) == hipSuccess &&
+       hipMemcpyAsync(d_rot0, L.rot0.data(), 16 * n, hipMemcpyHostToDevice, st) == hipSuccess;
+  ok = ok && nhip_csm_match_dev(d_xy, d_off, d_grids, &spec, d_src, d_slot, d_rot0, d_delta, nullptr, n, &search, d_keys,
+                                d_out, nullptr, d_ws, ws, st) == NHIP_OK;
+  if (!ok) std::printf("MatchList: %s\n", nhip_last_error());
+  ok = ok && nhip_csm_last_launch(info) == NHIP_OK;
+  out->resize(n);
+  ok = ok && hipMemcpyAsync(out->data(), d_out, sizeof(nhip_match_t) * n, hipMemcpyDeviceToHost, st) == hipSuccess &&
+       hipStreamSynchronize(st) == hipSuccess;
+  (void)hipFree(d_src); (void)hipFree(d_slot); (void)hipFree(d_rot0); (void)hipFree(d_keys); (void)hipFree(d_out); (void)hipFree(d_ws);
+  return ok;
+}
+
+static bool TwoThreadsOnTwoStreams() {
+  // eight clouds of the room from eight poses; every cloud is a target (grid) and a source
+  const int NS = 8;
+  std::vector<float> xy;
+  std::vector<int32_t> off(1, 0), ids;
+  for (int i = 0; i < NS; i++) {
+    const auto pc = Room(0.25 * i - 0.9, 0.12 * (i % 3) - 0.1, 0.05 * i - 0.15);
+    for (const Vec2f &p : pc) { xy.push_back(p(0)); xy.push_back(p(1)); }
+    off.push_back((int32_t)(xy.size() / 2));
+    ids.push_back(i);
+  }
+  const nhip_grid_spec_t spec = {30.0, 0.05, 2.0, 1e-10, 40, 16, 0, 0};
+  const nhip_search_t search = {61, 81, 81, 0, M_PI / 180.0};
+  float *d_xy = nullptr;
+  int32_t *d_off = nullptr, *d_ids = nullptr;
+  uint8_t *d_grids = nullptr;
+  void *d_gws = nullptr;
+  double *d_delta = nullptr;
+  std::vector<double> delta(2 * 61);
+  if (nhip_csm_delta_table(&search, delta.data()) != NHIP_OK) return false;
+  const int64_t gbytes = nhip_grids_bytes(&spec, NS), gws = nhip_grid_workspace_bytes(&spec, NS);
+  bool ok = hipMalloc(&d_xy, 4 * xy.size()) == hipSuccess && hipMalloc(&d_off, 4 * off.size()) == hipSuccess &&
+            hipMalloc(&d_ids, 4 * NS) == hipSuccess && hipMalloc(&d_grids, (size_t)gbytes) == hipSuccess &&
+            hipMalloc(&d_gws, (size_t)gws) == hipSuccess && hipMalloc(&d_delta, 8 * delta.size()) == hipSuccess;
+  ok = ok && hipMemcpy(d_xy, xy.data(), 4 * xy.size(), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(d_off, off.data(), 4 * off.size(), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(d_ids, ids.data(), 4 * NS, hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemcpy(d_delta, delta.data(), 8 * delta.size(), hipMemcpyHostToDevice) == hipSuccess &&
+       hipMemset(d_grids, 0, (size_t)gbytes) == hipSuccess;
+  ok = ok && nhip_grid_build_dev(d_xy, d_off, d_ids, NS, &spec, d_grids, d_gws, gws, nullptr) == NHIP_OK &&
+       hipDeviceSynchronize() == hipSuccess;
+  if (!ok) { std::printf("two threads: setup failed: %s\n", nhip_last_error()); return false; }
+  ThreadList lists[2];
+  for (int t = 0; t < 2; t++)
+    for (int i = 0; i < 28; i++) {
+      const int s_ = (3 * i + t) % NS, g_ = (5 * i + 2 * t + 1) % NS;
+      const double th = 0.05 * (s_ - g_) + 0.01 * t;
+      lists[t].src.push_back(s_);
+      lists[t].slot.push_back(g_);
+      lists[t].rot0.push_back(std::cos(th));
+      lists[t].rot0.push_back(std::sin(th));
+    }
+  // reference: each list on its own, default form (28 pairs: one kernel per pair + the hand-over kernel)
+  std::vector<nhip_match_t> want[2], got[2];
+  int32_t info[2][8];
+  for (int t = 0; t < 2; t++) ok = ok && MatchList(d_xy, d_off, d_grids, spec, search, d_delta, lists[t], nullptr, &want[t], info[t]);
+  ok = ok && info[0][0] == 0;
+  // forced: the split form in rounds of 3 pairs, candidates of a round on a helper stream (tunables are read per launch
+  // in a process started with NHIP_TUNABLES=1: main() set it before the library's first call)
+  setenv("NHIP_BNB_KERNELS", "1", 1);
+  setenv("NHIP_BNB_SPLIT", "1", 1);
+  setenv("NHIP_BNB_SPLIT_BATCH", "3", 1);
+  setenv("NHIP_BNB_SPLIT_MIN", "40", 1);
+  hipStream_t st[2];
+  ok = ok && hipStreamCreateWithFlags(&st[0], hipStreamNonBlocking) == hipSuccess &&
+       hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking) == hipSuccess;
+  bool tok[2] = {false, false};
+  for (int rep = 0; rep < 3 && ok; rep++) {
+    std::thread th0([&] { tok[0] = MatchList(d_xy, d_off, d_grids, spec, search, d_delta, lists[0], st[0], &got[0], info[0]); });
+    std::thread th1([&] { tok[1] = MatchList(d_xy, d_off, d_grids, spec, search, d_delta, lists[1], st[1], &got[1], info[1]); });
+    th0.join();
+    th1.join();
+    ok = tok[0] && tok[1];
+    for (int t = 0; t < 2 && ok; t++) {
+      ok = info[t][0] == 3 && info[t][1] == 3 && info[t][3] == 10 &&
+           std::memcmp(got[t].data(), want[t].data(), sizeof(nhip_match_t) * want[t].size()) == 0;
+      if (!ok) std::printf("two threads: rep %d thread %d: form %d batch %d rounds %d, records %s\n", rep, t, info[t][0], info[t][1],
+                           info[t][3], std::memcmp(got[t].data(), want[t].data(), sizeof(nhip_match_t) * want[t].size()) ? "DIFFER" : "equal");
+    }
+  }
+  unsetenv("NHIP_BNB_KERNELS");
+  unsetenv("NHIP_BNB_SPLIT");
+  unsetenv("NHIP_BNB_SPLIT_BATCH");
+  unsetenv("NHIP_BNB_SPLIT_MIN");
+  (void)hipStreamDestroy(st[0]); (void)hipStreamDestroy(st[1]);
+  (void)hipFree(d_xy); (void)hipFree(d_off); (void)hipFree(d_ids); (void)hipFree(d_grids); (void)hipFree(d_gws); (void)hipFree(d_delta);
+  return ok;
+}
+
 int main(int argc, char **argv) {
+  setenv("NHIP_TUNABLES", "1", 1);  // (a test binary: the section on two host threads forces a form of the matcher)
   const char *dump = argc > 1 ? argv[1] : nullptr;
   FILE *results = nullptr;
   if (dump) results = std::fopen((std::string(dump) + "/results.txt").c_str(), "w");
@@ -391,6 +508,8 @@ int main(int argc, char **argv) {
     REQUIRE(nhip_lc_chi_square_gate(&poses[0][0], 4, src, tgt, nullptr, 4, 5000.0, scores, flags) == NHIP_ERR_ARG);
     std::printf("chi-square gate of 4 candidates: ok\n");
   }
+  REQUIRE(TwoThreadsOnTwoStreams());
+  std::printf("two host threads on two streams, split form forced into overlapped rounds: records equal the one-thread runs\n");
   if (results) std::fclose(results);
   std::printf("ADAPTER_OK\n");
   return 0;

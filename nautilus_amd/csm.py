@@ -28,10 +28,13 @@ def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, ce
                     _lib.NHIP_GRID_SKIP_MAP if skip_map else 0, 0)
 
 
-def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0), exhaustive=False):
-    """exhaustive=True forces the kernel that performs every add; the default (branch and bound) returns the same
-    records bit for bit."""
-    return Search(int(n_theta), int(nx), int(ny), _lib.NHIP_SEARCH_EXHAUSTIVE if exhaustive else 0, float(theta_step))
+def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0), exhaustive=False, dense=False, short_scans=False):
+    """exhaustive=True forces the kernel that performs every add (dense=True: the all-zero strips too); the default
+    (branch and bound) returns the same records bit for bit.  short_scans=True is the caller's promise that no source
+    scan of the list has more than 1088 points (nautilus_hip.h, NHIP_SEARCH_SHORT_SCANS)."""
+    flags = (_lib.NHIP_SEARCH_EXHAUSTIVE if exhaustive else 0) | (_lib.NHIP_SEARCH_DENSE if dense else 0) | \
+            (_lib.NHIP_SEARCH_SHORT_SCANS if short_scans else 0)
+    return Search(int(n_theta), int(nx), int(ny), flags, float(theta_step))
 
 
 def grid_layout(spec):
@@ -229,3 +232,13 @@ class CorrelativeScanMatcher:
                                                       float(rotation_a), float(rotation_b), float(rotation_restriction),
                                                       C.byref(score), C.byref(tx), C.byref(ty), C.byref(th)))
         return score.value, ((np.float32(tx.value), np.float32(ty.value)), np.float32(th.value))
+
+
+def last_launch():
+    """What the calling thread's last branch-and-bound match did (nhip_csm_last_launch): a dict."""
+    out = (C.c_int32 * 8)()
+    check(_lib.load().nhip_csm_last_launch(out))
+    form = {0: "fused", 1: "split, one round", 2: "split, rounds on one stream", 3: "split, rounds overlapped on the helper stream"}
+    return {"form": form.get(out[0], "?"), "form_id": out[0], "pairs_per_round": out[1], "rounds_of_state": out[2],
+            "rounds": out[3], "short_scans": bool(out[4]), "hand_over_kernel": bool(out[5]), "instrumented": bool(out[6]),
+            "n_pairs": out[7]}

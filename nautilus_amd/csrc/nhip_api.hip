@@ -39,6 +39,16 @@ int require_device() {
   return NHIP_OK;
 }
 
+const char *tunable(const char *name) {
+  static std::once_flag once;
+  static bool on = false;
+  std::call_once(once, [] {
+    const char *e = getenv("NHIP_TUNABLES");
+    on = e && e[0] == '1';
+  });
+  return on ? getenv(name) : nullptr;
+}
+
 // ---------------------------------------------------------------- spec tables (host)
 int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   NHIP_REQUIRE(spec != nullptr && L != nullptr, "grid spec: null pointer");
@@ -422,6 +432,12 @@ int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_
 
 int64_t nhip_csm_workspace_bytes(int32_t n_pairs) { return bnb_workspace_bytes(n_pairs); }
 
+int nhip_csm_last_launch(int32_t out[8]) {
+  NHIP_REQUIRE(out != nullptr, "csm_last_launch: null out");
+  bnb_last_launch(out);
+  return NHIP_OK;
+}
+
 int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                         const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
                         const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
@@ -710,8 +726,10 @@ int nhip_grids_download_pool4(const nhip_grids_t *grids, int32_t slot, uint8_t *
 // 16-bit grids are built without skip maps unless their spec asks (the branch-and-bound matcher never reads them).
 // The first search on a handle that takes the kernel that performs every add builds them, once.
 static int ensure_skip_maps(const nhip_grids_t *grids, const nhip_search_t *search) {
+  // (writes to the handle -- the maps, then the flag -- under the handle's mutex, which is taken before the flag is looked
+  //  at: concurrent nhip_csm_match calls on one handle are ordered, the loser finds the maps built.  L and n never change.)
   nhip_grids *g = const_cast<nhip_grids *>(grids);
-  if (g->L.cb != 2 || (g->spec.flags & NHIP_GRID_SKIP_MAP) || g->n == 0) return NHIP_OK;
+  if (g->L.cb != 2 || g->n == 0) return NHIP_OK;
   NHIP_REQUIRE(search->n_theta >= 1 && search->nx >= 1 && search->ny >= 1, "search: empty lattice");
   if (!csm_takes_exhaustive(g->L, search)) return NHIP_OK;
   std::lock_guard<std::mutex> lock(g->mu);
@@ -749,12 +767,32 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
                  "int32 sums", i, pair_src[i], (long long)n_i, 8 * grids->L.cb, (long long)max_pts);
   }
   if ((rc = ensure_skip_maps(grids, search))) return rc;
+  nhip_grid_spec_t spec_now;  // (the flags may be written by a concurrent call's ensure_skip_maps: read them under the same lock)
+  {
+    std::lock_guard<std::mutex> lock(const_cast<nhip_grids *>(grids)->mu);
+    spec_now = grids->spec;
+  }
+  // the host knows the scan lengths: when every source fits the by-rotation form the general kernel is not launched
+  nhip_search_t search_now = *search;
+  {
+    bool all_short = true;
+    for (int32_t i = 0; i < n_pairs && all_short; i++)
+      all_short = scans->h_offsets[pair_src[i] + 1] - scans->h_offsets[pair_src[i]] <= NHIP_SHORT_SCAN_POINTS;
+    if (all_short) search_now.flags |= NHIP_SEARCH_SHORT_SCANS;
+  }
+  search = &search_now;
   std::vector<double> rot0(2 * (size_t)n_pairs), delta(2 * (size_t)search->n_theta);
   if ((rc = nhip_csm_rot0(theta0, nullptr, n_pairs, rot0.data()))) return rc;
   if ((rc = nhip_csm_delta_table(search, delta.data()))) return rc;
   DevBuf d_src, d_slot, d_rot0, d_delta, d_keys, d_out, d_sums, d_org, d_ws;
-  const int64_t ws_bytes = bnb_workspace_bytes(n_pairs);
-  if ((rc = d_ws.alloc((size_t)ws_bytes))) return rc;
+  // The split form's workspace is 32 KB per pair (4.3 GB at 131,072 pairs, 8.6 GB beyond): on a GPU that cannot spare
+  // it the list still matches -- with the hand-over lists alone, in the one-kernel form (same records).
+  int64_t ws_bytes = bnb_workspace_bytes(n_pairs);
+  if (d_ws.alloc((size_t)ws_bytes) != NHIP_OK) {
+    (void)hipGetLastError();
+    ws_bytes = bnb_workspace_bytes_lists(n_pairs);
+    if ((rc = d_ws.alloc((size_t)ws_bytes))) return rc;
+  }
   if (pair_origin) {
     if ((rc = d_org.alloc(sizeof(int32_t) * 2 * (size_t)n_pairs))) return rc;
     NHIP_TRY_HIP(hipMemcpy(d_org.p, pair_origin, sizeof(int32_t) * 2 * (size_t)n_pairs, hipMemcpyHostToDevice));
@@ -769,7 +807,7 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
   NHIP_TRY_HIP(hipMemcpy(d_rot0.p, rot0.data(), sizeof(double) * rot0.size(), hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(d_delta.p, delta.data(), sizeof(double) * delta.size(), hipMemcpyHostToDevice));
   rc = launch_csm_match(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p),
-                        static_cast<const uint8_t *>(grids->grids.p), &grids->spec, grids->L,
+                        static_cast<const uint8_t *>(grids->grids.p), &spec_now, grids->L,
                         static_cast<const int32_t *>(d_src.p), static_cast<const int32_t *>(d_slot.p),
                         static_cast<const double *>(d_rot0.p), static_cast<const double *>(d_delta.p),
                         pair_origin ? static_cast<const int32_t *>(d_org.p) : nullptr, n_pairs, search, static_cast<uint64_t *>(d_keys.p), static_cast<nhip_match_t *>(d_out.p),

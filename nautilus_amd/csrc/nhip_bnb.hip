@@ -37,6 +37,7 @@
 // in tiles of one cache line, because what a gather costs here is the number of distinct lines per load.
 #include <atomic>
 #include <mutex>
+#include <vector>
 
 #include "nhip_bnb_params.h"
 
@@ -2089,7 +2090,7 @@ int launch_main(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
     lds_set.store(lds, std::memory_order_relaxed);
   }
 #if NHIP_BNB_INSTR
-  if (P.stats && getenv("NHIP_BNB_OCCUPANCY")) {
+  if (P.stats && tunable("NHIP_BNB_OCCUPANCY")) {
     int nb = -1;
     (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, csm_bnb_kernel<CB, PL, BR, SP>, BNB_THREADS, lds);
     fprintf(stderr, "csm_bnb_kernel<%d,%d,%d,%d>: lds %zu B, %d workgroups per CU\n", CB, (int)PL, (int)BR, (int)SP, lds, nb);
@@ -2105,7 +2106,9 @@ template <int CB, bool PL>
 int launch_split_a(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
   int rc = launch_main<CB, PL, true, true>(P, lds, blocks, s);
   if (rc) return rc;
-  if ((rc = launch_main<CB, PL, false>(P, lds, blocks, s))) return rc;
+  // (the general instantiation only has work when some scan does not fit the by-rotation form: a caller that knows its
+  //  scan lengths says so -- NHIP_SEARCH_SHORT_SCANS -- and saves the launch of n_pairs workgroups that return at once)
+  if (!P.short_scans && (rc = launch_main<CB, PL, false>(P, lds, blocks, s))) return rc;
   hipLaunchKernelGGL(csm_bnb_order_kernel, dim3(8), dim3(SORT_THREADS), 0, s, P);
   return NHIP_OK;
 }
@@ -2116,6 +2119,7 @@ int launch_both(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
   if (!P.general_all) {
     int rc = launch_main<CB, PL, true>(P, lds, blocks, s);
     if (rc) return rc;
+    if (P.short_scans) return NHIP_OK;
   }
   return launch_main<CB, PL, false>(P, lds, blocks, s);
 }
@@ -2160,7 +2164,7 @@ int launch_bnb_split_b_instr(const BnbParams &P, int cb, hipStream_t s) {
 int launch_bnb_split_b(const BnbParams &P, int cb, hipStream_t s) {
 #endif
   // (NHIP_BNB_CAND_LDS_PAD=<bytes>, measurement: unused dynamic LDS that lowers the workgroups a CU holds)
-  const char *padv = getenv("NHIP_BNB_CAND_LDS_PAD");
+  const char *padv = tunable("NHIP_BNB_CAND_LDS_PAD");
   const size_t lds_pad = padv ? (size_t)atoi(padv) : 0;
   if (lds_pad > 0) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_cand_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad);
@@ -2213,31 +2217,80 @@ constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, ne
 constexpr int64_t SPLIT_PAIRS = 131072, SPLIT_MIN_PAIRS = 4096, SPLIT_RING = 16;
 int64_t split_bytes_per_pair(int32_t n_theta) { return 16 + 6 + (int64_t)n_theta * 512; }
 constexpr int64_t SPLIT_SLOT_FIXED = 8 * 64 * 4 + 1024;  // per batch: the work lists' floor of 64 extra entries, alignment
+int64_t bnb_workspace_bytes_lists(int32_t n_pairs) {  // (the hand-over lists alone: the one-kernel form)
+  const int64_t n = n_pairs > 0 ? n_pairs : 0;
+  return BNB_WS_HEADER + 8 * (((n + 7) / 8) * 16 + 64) * (int64_t)sizeof(RotEntry);
+}
 int64_t bnb_workspace_bytes(int32_t n_pairs) {
   const int64_t n = n_pairs > 0 ? n_pairs : 0;
-  const int64_t lists = BNB_WS_HEADER + 8 * (((n + 7) / 8) * 16 + 64) * (int64_t)sizeof(RotEntry);
-  const char *sp = getenv("NHIP_BNB_SPLIT");  // (=1: the split form for small batches too -- tests)
-  const char *spp = getenv("NHIP_BNB_SPLIT_PAIRS");  // (measurement: pairs the workspace holds state for)
+  const int64_t lists = bnb_workspace_bytes_lists(n_pairs);
+  const char *sp = tunable("NHIP_BNB_SPLIT");  // (=1: the split form for small batches too -- tests)
+  const char *spp = tunable("NHIP_BNB_SPLIT_PAIRS");  // (measurement: pairs the workspace holds state for)
   const int64_t cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
   const int64_t m = n <= cap ? n : 2 * cap;  // (a longer list: two rounds' state, so that the helper stream can be used)
-  const bool forced = n > 0 && ((sp && sp[0] == '1') || getenv("NHIP_BNB_SPLIT_BATCH"));
+  const bool forced = n > 0 && ((sp && sp[0] == '1') || tunable("NHIP_BNB_SPLIT_BATCH"));
   const int64_t split = n >= SPLIT_MIN_PAIRS || forced
                             ? BNB_WS_HEADER + (m / 512 + 4) * SPLIT_SLOT_FIXED + m * split_bytes_per_pair(64) : 0;
   return lists > split ? lists : split;
 }
 
-// The helper stream of the split form (the candidates of batch i run beside the bounds of batch i + 1) and the events
-// that order the two; process-wide, created on first use, used under g_split_mu.
+// The helper stream of the split form (the candidates of round i run beside the bounds of round i + 1) and the events
+// that order the two.  One set per CALL IN FLIGHT, taken from a per-device pool: a host with one thread per device
+// (nhip_set_device) gets a stream and events of ITS device, and two threads on one device never share
+// events -- a wait binds to the event's latest record, so a shared ring would let one caller's candidates start on the
+// other's bounds.  The pool's mutex is held only to take a set and to put it back, never across the enqueue: the set
+// goes back as soon as the call has enqueued its work (the waits already issued stay bound to their records, and the
+// helper stream runs in order, so the next user queues up behind).  Sets live until the process ends.
+struct SplitSet {
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ea[SPLIT_RING], eb[SPLIT_RING];
+};
 static std::mutex g_split_mu;
-static hipStream_t g_split_stream = nullptr;
-static hipEvent_t g_split_ea[SPLIT_RING], g_split_eb[SPLIT_RING];
+static std::vector<SplitSet *> g_split_free;
+
+static int split_set_acquire(SplitSet **out) {
+  int dev = -1;
+  NHIP_TRY_HIP(hipGetDevice(&dev));
+  {
+    std::lock_guard<std::mutex> lock(g_split_mu);
+    for (size_t i = 0; i < g_split_free.size(); i++)
+      if (g_split_free[i]->device == dev) {
+        *out = g_split_free[i];
+        g_split_free.erase(g_split_free.begin() + (long)i);
+        return NHIP_OK;
+      }
+  }
+  SplitSet *n = new SplitSet();
+  n->device = dev;
+  hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
+  for (int i = 0; i < SPLIT_RING && e == hipSuccess; i++) {
+    e = hipEventCreateWithFlags(&n->ea[i], hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&n->eb[i], hipEventDisableTiming);
+  }
+  if (e != hipSuccess) {
+    delete n;  // (what was created stays with the runtime: an allocation failure of streams / events is not a path to tidy)
+    return hip_fail(e, "split form: helper stream / events", __FILE__, __LINE__);
+  }
+  *out = n;
+  return NHIP_OK;
+}
+static void split_set_release(SplitSet *set) {
+  if (!set) return;
+  std::lock_guard<std::mutex> lock(g_split_mu);
+  g_split_free.push_back(set);
+}
 
 // NHIP_BNB_INSTRUMENT=1 selects the instrumented build of the kernels; only then are NHIP_BNB_STATS, NHIP_BNB_TIMELINE
 // and NHIP_BNB_DEBUG (timing experiments: WRONG results) read at all.
 static bool instrumented() {
-  const char *e = getenv("NHIP_BNB_INSTRUMENT");
+  const char *e = tunable("NHIP_BNB_INSTRUMENT");
   return e && e[0] == '1';
 }
+
+// What the calling thread's last launch_csm_bnb did (nhip_csm_last_launch: tests assert the form a list took).
+static thread_local int32_t t_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+void bnb_last_launch(int32_t out[8]) { memcpy(out, t_last_launch, sizeof(t_last_launch)); }
 
 int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
                    const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
@@ -2290,25 +2343,27 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.t16_bytes = L.t16_bytes;
   P.t16_tpr = L.t16_tpr;
   // Policies that never change the records (tests run the matcher in every form and compare): read per launch.
-  const char *lv = getenv("NHIP_BNB_LEVELS");  // (1: without the sub-block bounds)
+  const char *lv = tunable("NHIP_BNB_LEVELS");  // (1: without the sub-block bounds)
   P.levels = lv && lv[0] == '1' ? 1 : 2;
-  const char *sd = getenv("NHIP_BNB_SEEDS");  // (waves that evaluate a seed block)
+  const char *sd = tunable("NHIP_BNB_SEEDS");  // (waves that evaluate a seed block)
   P.seeds = sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : 8u;
-  const char *wm = getenv("NHIP_BNB_WHOLE_MIN");
+  const char *wm = tunable("NHIP_BNB_WHOLE_MIN");
   // (row-major planes -- 8-bit grids, and 16-bit grids before their planes were tiled: 2 beats 3, 7.70 -> 7.45 ms per
   //  10,000 pairs, 1: 7.8, 4: 7.9; tiled planes, both widths now: loads are cheaper and 3 beats 2, 6.37 -> 6.22 ms)
   P.whole_min = wm ? atoi(wm) : 3;
-  const char *qe = getenv("NHIP_BNB_QUEUE");  // (the general path for every scan)
+  const char *qe = tunable("NHIP_BNB_QUEUE");  // (the general path for every scan)
   P.general_all = qe && qe[0] == '1';
+  static_assert(NHIP_SHORT_SCAN_POINTS == 64 * OCL, "the header's promise is the by-rotation form's limit");
+  P.short_scans = (search->flags & NHIP_SEARCH_SHORT_SCANS) != 0 && !P.general_all && (uint32_t)P.rows < ORG_LIMIT;
   P.res = spec->res;
   P.inv_res = 1.0 / spec->res;
   P.inv_res_f = (float)P.inv_res;
   const bool instr = instrumented();
   if (instr) {
     std::lock_guard<std::mutex> lock(g_instr_mu);
-    const char *dbg = getenv("NHIP_BNB_DEBUG");
+    const char *dbg = tunable("NHIP_BNB_DEBUG");
     P.debug = dbg ? atoi(dbg) : 0;
-    const char *st = getenv("NHIP_BNB_STATS");
+    const char *st = tunable("NHIP_BNB_STATS");
     if (st && st[0] == '1') {
       if (!g_bnb_stats) {
         NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_stats), 8 * (BNB_STATS_HEAD + (size_t)BNB_STATS_PAIRS)));
@@ -2316,7 +2371,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
       }
       P.stats = g_bnb_stats;
     }
-    const char *tl = getenv("NHIP_BNB_TIMELINE");
+    const char *tl = tunable("NHIP_BNB_TIMELINE");
     if (tl && tl[0] == '1') {
       if (!g_bnb_timeline) NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_timeline), 32 * (size_t)BNB_STATS_PAIRS + 16));
       P.timeline = g_bnb_timeline;
@@ -2336,9 +2391,9 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   // letting the waves of finished workgroups take entries inside the first kernel, and persistent workgroups -- never
   // a gain.)
   // NHIP_BNB_KERNELS=1: never, =2: always; NHIP_BNB_HEAVY_MIN=<candidates>, NHIP_BNB_KEEP_RANKS=<n>.
-  const char *force = getenv("NHIP_BNB_KERNELS");
-  const char *hm = getenv("NHIP_BNB_HEAVY_MIN");
-  const char *kr = getenv("NHIP_BNB_KEEP_RANKS");
+  const char *force = tunable("NHIP_BNB_KERNELS");
+  const char *hm = tunable("NHIP_BNB_HEAVY_MIN");
+  const char *kr = tunable("NHIP_BNB_KEEP_RANKS");
   const bool second = force ? force[0] == '2' : n_pairs < 1024;
   P.heavy_min = hm ? (uint32_t)atoi(hm) : (n_pairs <= 64 ? 1u : 384u);
   P.keep_ranks = kr ? (uint32_t)atoi(kr) : 8u;
@@ -2357,13 +2412,14 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   // Large batches: the split form, in rounds of as many pairs as the workspace holds state for.
   // NHIP_BNB_SPLIT=0: never, =1: whenever the workspace allows; NHIP_BNB_SPLIT_MIN=<candidates per additional
   // workgroup of a pair>, NHIP_BNB_SPLIT_MAX=<workgroups per pair>.
-  const char *sp = getenv("NHIP_BNB_SPLIT");
-  const char *smin = getenv("NHIP_BNB_SPLIT_MIN");
-  const char *smax = getenv("NHIP_BNB_SPLIT_MAX");
-  const char *sbat = getenv("NHIP_BNB_SPLIT_BATCH");
-  const char *sov = getenv("NHIP_BNB_SPLIT_OVERLAP");
+  const char *sp = tunable("NHIP_BNB_SPLIT");
+  const char *smin = tunable("NHIP_BNB_SPLIT_MIN");
+  const char *smax = tunable("NHIP_BNB_SPLIT_MAX");
+  const char *sbat = tunable("NHIP_BNB_SPLIT_BATCH");
+  const char *sov = tunable("NHIP_BNB_SPLIT_OVERLAP");
+  const char *sco = tunable("NHIP_BNB_SORT_COARSE");  // (buckets of 2^n sixteenths of an octave: 4 = one per octave)
   int64_t split_batch = 0, split_slots = 0, slot_bytes = 0;
-  const char *spp = getenv("NHIP_BNB_SPLIT_PAIRS");
+  const char *spp = tunable("NHIP_BNB_SPLIT_PAIRS");
   const int64_t split_cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
   if (d_workspace && !P.general_all && !P.rot_list && P.debug == 0 && !(sp && sp[0] == '0') &&
       (n_pairs >= SPLIT_MIN_PAIRS || (sp && sp[0] == '1'))) {
@@ -2381,21 +2437,41 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     // (several rounds pay off only with the helper stream, i.e. with two rounds' state, and in rounds that are long)
     if (!sbat && split_batch > 0 && n_pairs > split_batch && (split_slots < 2 || split_batch < split_cap)) split_batch = 0;
   }
-  timer_begin(NHIP_TIMER_CSM, s);
+  // (an error return between timer_begin and timer_end closes the open slot)
+  struct TimerScope {
+    int id;
+    hipStream_t s;
+    bool open = true;
+    TimerScope(int i, hipStream_t st) : id(i), s(st) { timer_begin(id, s); }
+    void end() {
+      if (open) timer_end(id, s);
+      open = false;
+    }
+    ~TimerScope() { end(); }
+  };
+  TimerScope t_all(NHIP_TIMER_CSM, s);
+  {
+    const int64_t rounds = split_batch > 0 ? (n_pairs + split_batch - 1) / split_batch : 1;
+    const bool ov = split_batch > 0 && !(sov && sov[0] == '0') && split_slots >= 2 && n_pairs > split_batch;
+    const int32_t info[8] = {split_batch > 0 ? (ov ? 3 : (rounds > 1 ? 2 : 1)) : 0, (int32_t)split_batch, (int32_t)split_slots,
+                             (int32_t)rounds, P.short_scans, second_kernel ? 1 : 0, instr ? 1 : 0, n_pairs};
+    memcpy(t_last_launch, info, sizeof(info));
+  }
   if (split_batch > 0) {
     // Candidates (bound by the L1's lookups) beside the next batch's bounds (bound by the vector ALUs): the first part
     // of every batch on the caller's stream, the second on the helper stream, each batch's state in its own slot of the
     // workspace.  NHIP_BNB_SPLIT_OVERLAP=0: everything on the caller's stream.
-    std::lock_guard<std::mutex> lock(g_split_mu);
     const bool overlap = !(sov && sov[0] == '0') && split_slots >= 2 && n_pairs > split_batch;
-    if (overlap && !g_split_stream) {
-      NHIP_TRY_HIP(hipStreamCreateWithFlags(&g_split_stream, hipStreamNonBlocking));
-      for (int i = 0; i < SPLIT_RING; i++) {
-        NHIP_TRY_HIP(hipEventCreateWithFlags(&g_split_ea[i], hipEventDisableTiming));
-        NHIP_TRY_HIP(hipEventCreateWithFlags(&g_split_eb[i], hipEventDisableTiming));
-      }
+    SplitSet *set = nullptr;
+    if (overlap) {
+      const int rc = split_set_acquire(&set);
+      if (rc) return rc;
     }
-    hipStream_t s2 = overlap ? g_split_stream : s;
+    struct SetGuard {
+      SplitSet *p;
+      ~SetGuard() { split_set_release(p); }
+    } set_guard{set};
+    hipStream_t s2 = overlap ? set->stream : s;
     uint8_t *base = static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER;
     base += (512 - (reinterpret_cast<uintptr_t>(base) & 511)) & 511;
     int64_t round = 0;
@@ -2412,7 +2488,6 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
       Q.ps_work_stride = Q.pairs_per_xcd + (Q.pairs_per_xcd / 2 > 64 ? Q.pairs_per_xcd / 2 : 64);
       Q.split_min = smin ? (uint32_t)(atoi(smin) > 0 ? atoi(smin) : 1) : 300u;
       Q.split_max = smax ? (uint32_t)(atoi(smax) > 0 ? atoi(smax) : 1) : 8u;
-      const char *sco = getenv("NHIP_BNB_SORT_COARSE");  // (buckets of 2^n sixteenths of an octave: 4 = one per octave)
       Q.sort_coarse = sco ? (uint32_t)atoi(sco) : 9u;  // (one bucket: see csm_bnb_order_kernel)
       uint8_t *w = base + (round % split_slots) * slot_bytes;
       Q.ps_count = reinterpret_cast<uint32_t *>(w);
@@ -2426,27 +2501,29 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
                        w + slot_bytes <= static_cast<uint8_t *>(d_workspace) + workspace_bytes,
                    "csm_bnb: workspace accounting");
       // (the slot's previous batch must be through its candidates)
-      if (overlap && round >= split_slots) NHIP_TRY_HIP(hipStreamWaitEvent(s, g_split_eb[(round - split_slots) % SPLIT_RING], 0));
+      if (overlap && round >= split_slots) NHIP_TRY_HIP(hipStreamWaitEvent(s, set->eb[(round - split_slots) % SPLIT_RING], 0));
       NHIP_TRY_HIP(hipMemsetAsync(w, 0, 16 * (size_t)nb, s));
       const int64_t blocks_b = (int64_t)Q.pairs_per_xcd * 8;
-      timer_begin(NHIP_TIMER_CSM_BOUNDS, s);
-      int rc = instr ? bnb::launch_bnb_split_a_instr(Q, L.cb, pool_lds, lds, blocks_b, s)
-                     : bnb::launch_bnb_split_a(Q, L.cb, pool_lds, lds, blocks_b, s);
-      if (rc) return rc;
-      timer_end(NHIP_TIMER_CSM_BOUNDS, s);
-      if (overlap) {
-        NHIP_TRY_HIP(hipEventRecord(g_split_ea[round % SPLIT_RING], s));
-        NHIP_TRY_HIP(hipStreamWaitEvent(s2, g_split_ea[round % SPLIT_RING], 0));
+      {
+        TimerScope t_a(NHIP_TIMER_CSM_BOUNDS, s);
+        const int rc = instr ? bnb::launch_bnb_split_a_instr(Q, L.cb, pool_lds, lds, blocks_b, s)
+                             : bnb::launch_bnb_split_a(Q, L.cb, pool_lds, lds, blocks_b, s);
+        if (rc) return rc;
       }
-      timer_begin(NHIP_TIMER_CSM_CAND, s2);
-      rc = instr ? bnb::launch_bnb_split_b_instr(Q, L.cb, s2) : bnb::launch_bnb_split_b(Q, L.cb, s2);
-      if (rc) return rc;
-      timer_end(NHIP_TIMER_CSM_CAND, s2);
-      if (overlap) NHIP_TRY_HIP(hipEventRecord(g_split_eb[round % SPLIT_RING], s2));
+      if (overlap) {
+        NHIP_TRY_HIP(hipEventRecord(set->ea[round % SPLIT_RING], s));
+        NHIP_TRY_HIP(hipStreamWaitEvent(s2, set->ea[round % SPLIT_RING], 0));
+      }
+      {
+        TimerScope t_b(NHIP_TIMER_CSM_CAND, s2);
+        const int rc = instr ? bnb::launch_bnb_split_b_instr(Q, L.cb, s2) : bnb::launch_bnb_split_b(Q, L.cb, s2);
+        if (rc) return rc;
+      }
+      if (overlap) NHIP_TRY_HIP(hipEventRecord(set->eb[round % SPLIT_RING], s2));
     }
     // (the helper stream works in order: its last batch done, all are)
-    if (overlap) NHIP_TRY_HIP(hipStreamWaitEvent(s, g_split_eb[(round - 1) % SPLIT_RING], 0));
-    timer_end(NHIP_TIMER_CSM, s);
+    if (overlap) NHIP_TRY_HIP(hipStreamWaitEvent(s, set->eb[(round - 1) % SPLIT_RING], 0));
+    t_all.end();
     NHIP_TRY_HIP(hipGetLastError());
     launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
     NHIP_TRY_HIP(hipGetLastError());
@@ -2457,7 +2534,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const int rc = instr ? bnb::launch_bnb_kernels_instr(P, L.cb, pool_lds, lds, blocks, second_kernel, s)
                        : bnb::launch_bnb_kernels(P, L.cb, pool_lds, lds, blocks, second_kernel, s);
   if (rc) return rc;
-  timer_end(NHIP_TIMER_CSM, s);
+  t_all.end();
   NHIP_TRY_HIP(hipGetLastError());
   launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
   NHIP_TRY_HIP(hipGetLastError());

@@ -51,6 +51,7 @@ struct BnbParams {
   int32_t lds_first;    // bytes of the kernel's first LDS region: max(pooled table if staged, origins)
   int32_t whole_min;    // sub-blocks alive from which an 8-bit block is evaluated whole (3; NHIP_BNB_WHOLE_MIN)
   int32_t general_all;  // the general instantiation takes every pair (NHIP_BNB_QUEUE=1)
+  int32_t short_scans;  // the caller vouches that every scan fits the by-rotation form (NHIP_SEARCH_SHORT_SCANS)
   int32_t levels;  // 2: candidates are refined through the 4 x 4 sub-block bounds; 1: evaluated whole (NHIP_BNB_LEVELS)
   int32_t debug;   // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only,
                    // 4 = phase 3 without exact sums, 5 = phase 3 without sub-block bounds and exact sums,

@@ -33,6 +33,12 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 
 int require_device();
 
+// Environment switches that select a form of the matcher (tests and measurements: every form returns the same records)
+// are honoured only by a process that had NHIP_TUNABLES=1 in its environment when the library first asked (looked up
+// once, std::call_once).  Such a process reads them at every launch, so a test can change form between calls; any other
+// process -- a shipped host -- never reads any of them: tunable() is a null pointer there and every policy is its default.
+const char *tunable(const char *name);
+
 // ---- grid layout (host) ----
 struct GridLayout {
   int32_t S, pad, pitch, R;
@@ -144,6 +150,8 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
                    uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled,
                    void *d_workspace = nullptr, int64_t workspace_bytes = 0);
 int64_t bnb_workspace_bytes(int32_t n_pairs);
+int64_t bnb_workspace_bytes_lists(int32_t n_pairs);
+void bnb_last_launch(int32_t out[8]);
 bool bnb_fits(const GridLayout &L, const nhip_search_t *search);
 int bnb_stats_read(unsigned long long out[16]);
 int bnb_timeline_read(unsigned long long *out, int32_t n);

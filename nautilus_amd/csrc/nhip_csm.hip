@@ -442,8 +442,8 @@ void fill_params(CsmParams &P, const nhip_grid_spec_t *spec, const GridLayout &L
   P.grid_bytes = L.grid_bytes;
   P.slot_bytes = L.slot_bytes;
   // NHIP_CSM_DENSE=1 switches the zero-strip skipping off (measurement: the same kernel, every add done)
-  const char *dense = getenv("NHIP_CSM_DENSE");
-  P.dense = (dense && dense[0] == '1') ? 1 : 0;
+  const char *dense = tunable("NHIP_CSM_DENSE");
+  P.dense = ((dense && dense[0] == '1') || (search->flags & NHIP_SEARCH_DENSE)) ? 1 : 0;
   P.res = spec->res;
   P.inv_res = 1.0 / spec->res;
 }
@@ -451,7 +451,7 @@ void fill_params(CsmParams &P, const nhip_grid_spec_t *spec, const GridLayout &L
 }  // namespace
 
 bool csm_takes_exhaustive(const GridLayout &L, const nhip_search_t *search) {
-  const char *ex = getenv("NHIP_CSM_EXHAUSTIVE");
+  const char *ex = tunable("NHIP_CSM_EXHAUSTIVE");
   return (search->flags & NHIP_SEARCH_EXHAUSTIVE) || (ex && ex[0] == '1') || !bnb_fits(L, search);
 }
 

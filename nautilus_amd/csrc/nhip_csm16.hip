@@ -395,8 +395,8 @@ void fill_params16(CsmParams &P, const nhip_grid_spec_t *spec, const GridLayout 
   P.grid_bytes = L.grid_bytes;
   P.slot_bytes = L.slot_bytes;
   // without a skip map in the slots (spec->flags) every strip is added; NHIP_CSM_DENSE=1 asks for that too
-  const char *dense = getenv("NHIP_CSM_DENSE");
-  P.dense = ((dense && dense[0] == '1') || !(spec->flags & NHIP_GRID_SKIP_MAP)) ? 1 : 0;
+  const char *dense = tunable("NHIP_CSM_DENSE");
+  P.dense = ((dense && dense[0] == '1') || (search->flags & NHIP_SEARCH_DENSE) || !(spec->flags & NHIP_GRID_SKIP_MAP)) ? 1 : 0;
   P.res = spec->res;
   P.inv_res = 1.0 / spec->res;
 }

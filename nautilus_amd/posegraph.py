@@ -18,14 +18,37 @@ neighbour comes from the backend -- HipBackend (the product: libnautilus_hip) un
 bench's cpu_baseline leg injects another one (oracle/cpu_backend.py times the same loop on the CPU
 restatement; the product never imports it).
 """
+import contextlib
 import ctypes as C
 import math
+import time
 
 import numpy as np
 
 from . import _lib
 from ._lib import check
 from .correspondence import IcpBatch, window_pairs
+
+
+# Where the loop's wall-clock goes, by owner (seconds since the last reset): "path" = calls into the backend -- the hot
+# path of this repo: correspondence search, residuals / normal equations, gating, scan matching (every one returns
+# host data, so the device is drained when the clock stops); "host_solver" = the sparse linear solves (Ceres' job in
+# the reference: out of scope, the same code whatever the backend); the rest of a run is host bookkeeping.
+CLOCK = {"path": 0.0, "host_solver": 0.0}
+
+
+def clock_reset():
+    for k in CLOCK:
+        CLOCK[k] = 0.0
+
+
+@contextlib.contextmanager
+def clocked(key):
+    t0 = time.perf_counter()
+    try:
+        yield
+    finally:
+        CLOCK[key] += time.perf_counter() - t0
 
 
 def compose(pose, rel):
@@ -195,7 +218,8 @@ class PoseGraph:
         self.kind = kind
         self.backend = backend if backend is not None else HipBackend(device)
         bs, bt = window_pairs(self.n, window)
-        self.icp = self.backend.icp(xy, normals, offsets, bs, bt, outlier_threshold)
+        with clocked("path"):  # (uploads of the clouds, block lists)
+            self.icp = self.backend.icp(xy, normals, offsets, bs, bt, outlier_threshold)
         self.odo = odometry_factors_from_poses(odom, tw=odom_weights[0], rw=odom_weights[1])
         self.lc = None
         self.hitl = []
@@ -215,10 +239,11 @@ class PoseGraph:
     def _assemble(self, poses, lines, research):
         import scipy.sparse as sp
         N, NU = self.n, self.n_unknowns
-        self.icp.set_poses(poses)
-        if research:
-            self.icp.search()  # correspondences are rebuilt per solve, like each window pass of the reference
-        neq = self.icp.normal_equations(self.kind)
+        with clocked("path"):
+            self.icp.set_poses(poses)
+            if research:
+                self.icp.search()  # correspondences are rebuilt per solve, like each window pass of the reference
+            neq = self.icp.normal_equations(self.kind)
         rows, cols, vals = [], [], []
         g = np.zeros(NU)
         cost = 0.5 * float(neq[:, 27].sum()) if len(neq) else 0.0
@@ -235,7 +260,8 @@ class PoseGraph:
         for fac in (self.odo, self.lc):
             if fac is None or fac.n == 0:
                 continue
-            r, ji, jj = fac.evaluate(self.backend, poses)
+            with clocked("path"):
+                r, ji, jj = fac.evaluate(self.backend, poses)
             J = np.concatenate([ji, jj], axis=2)  # (F, 3, 6)
             Hf = np.einsum("fki,fkj->fij", J, J)
             gf = np.einsum("fki,fk->fi", J, r)
@@ -249,7 +275,8 @@ class PoseGraph:
             seg, pts, pb, bp, bl = con.arrays(c)
             if len(pts) == 0:
                 continue
-            r, j0, j1 = self.backend.point_to_line(seg, pts, pb, bp, bl, poses, lines)
+            with clocked("path"):
+                r, j0, j1 = self.backend.point_to_line(seg, pts, pb, bp, bl, poses, lines)
             J = np.concatenate([j0, j1], axis=1)  # (n, 6): d/d pose of the point's node, d/d chosen_line_pose
             ids = np.concatenate([3 * bp[pb][:, None] + np.arange(3), np.full((len(pts), 1), 3 * N + 3 * c) + np.arange(3)], axis=1)
             Hp = np.einsum("ni,nj->nij", J, J)
@@ -307,7 +334,8 @@ class PoseGraph:
         for it in range(iterations):
             Hf = H[free][:, free]
             step = np.zeros(NU)
-            step[free] = spsolve(Hf + lam * sp.diags(Hf.diagonal() + 1e-9), -g[free])
+            with clocked("host_solver"):
+                step[free] = spsolve(Hf + lam * sp.diags(Hf.diagonal() + 1e-9), -g[free])
             trial = poses + step[:3 * self.n].reshape(-1, 3)
             trial_lines = lines + step[3 * self.n:].reshape(-1, 3)
             H2, g2, cost2 = self._assemble(trial, trial_lines, research=False)

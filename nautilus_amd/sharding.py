@@ -78,8 +78,12 @@ class ShardPlan:
         self.weights = None if weights is None else np.ascontiguousarray(weights, dtype=np.float64)
         self.order, self.bounds = partition_by_target(self.pair_tgt, self.world, self.weights)
         self.counts = np.diff(self.bounds)
-        self.rank_weight = (np.add.reduceat(self.weights[self.order], self.bounds[:-1].clip(max=max(self.n_pairs - 1, 0)))
-                            * (self.counts > 0) if self.weights is not None and self.n_pairs else None)
+        # (from the cumulative sum: np.add.reduceat with clipped bounds handed the last pair of the last non-empty rank
+        #  to an empty trailing rank, where it was then multiplied by 0)
+        self.rank_weight = None
+        if self.weights is not None and self.n_pairs:
+            cum = np.concatenate([[0.0], np.cumsum(self.weights[self.order])])
+            self.rank_weight = cum[self.bounds[1:]] - cum[self.bounds[:-1]]
         self.width = int(self.counts.max()) if self.n_pairs else 0  # padded block length of the all-gather
         # row of the gathered (world * width) table that holds the pair at position i of `order`
         self.gathered_rows = np.concatenate(

@@ -115,15 +115,20 @@ def ranges_to_cloud(r_row):
 class SynthBag:
     """n_scans scans + truth/odometry poses + per-point wall normals (scan frame)."""
 
-    def __init__(self, n_scans, dense=False, seed=SEED, n_walls=12, spacing=0.25):
+    def __init__(self, n_scans, dense=False, seed=SEED, n_walls=12, spacing=0.25, poses_only=False):
+        """poses_only: trajectory, odometry and pair sampling without the ray casting (the scans stay empty) -- what a
+        shard plan needs; the 10,000-scan bag's poses take milliseconds, its scans 12 s."""
         # dense: 24 m x 16 m room (diagonal 28.8 m < 30 m) so every one of the 1081 beams returns
         self.width, self.height = (24.0, 16.0) if dense else (40.0, 25.0)
         self.margin = 3.0 if dense else 4.0
         self.segs = make_world(self.width, self.height, n_walls, self.margin, seed)
         self.truth = loop_trajectory(n_scans, self.width, self.height, self.margin, spacing=spacing, seed=seed)
         self.odom = odometry_from_truth(self.truth, seed=seed)
-        ranges, hit = raycast(self.truth, self.segs, seed=seed)
         self.scans, self.normals = [], []
+        self.n_scans = n_scans
+        if poses_only:
+            return
+        ranges, hit = raycast(self.truth, self.segs, seed=seed)
         d = self.segs[:, 2:4] - self.segs[:, 0:2]
         nrm = np.stack([-d[:, 1], d[:, 0]], axis=1)
         nrm /= np.maximum(np.linalg.norm(nrm, axis=1, keepdims=True), 1e-12)

@@ -3,6 +3,10 @@ import sys
 
 import pytest
 
+# The tests run the matcher in every form (environment switches read at each launch): the library honours those only in
+# a process that asked for it before its first call (nhip_common.h, tunable()).
+os.environ.setdefault("NHIP_TUNABLES", "1")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

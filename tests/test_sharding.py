@@ -149,3 +149,86 @@ def test_predicted_pair_cost_grows_with_the_predicted_offset():
     poses[5, 2] = 1.0   # heading does not enter
     c = sharding.predicted_pair_cost(poses, [1, 2, 3, 4, 5], [0, 0, 0, 0, 0])
     assert np.all(np.diff(c[:4]) > 0) and c[3] == c[4] and 1.0 <= c[0] < 1.1 and 3.5 < c[3] < 6.0
+
+
+def test_rank_weight_with_more_ranks_than_targets():
+    """three targets over six ranks, weights [1, ..., 1, 5] -- the last pair's weight must stay with the
+    last non-empty rank (np.add.reduceat with clipped bounds gave it to an empty trailing rank, times 0)."""
+    tgt = np.array([0, 0, 0, 1, 1, 1, 1, 2, 2, 2], dtype=np.int32)
+    w = np.ones(len(tgt))
+    w[-1] = 5.0
+    plan = sharding.ShardPlan(np.zeros(len(tgt), np.int32), tgt, np.zeros(len(tgt)), 6, w)
+    assert np.isclose(plan.rank_weight.sum(), w.sum())
+    for r in range(6):
+        assert np.isclose(plan.rank_weight[r], plan.shard_weights(r).sum()), (r, plan.rank_weight)
+    assert (plan.rank_weight[plan.counts == 0] == 0).all()
+
+
+def _config4_plan(world):
+    """BASELINE configs[3]'s pair list (10,000 scans, 1,000,000 pairs, 100 per target; bench.Workload("config4")) from the
+    bag's poses alone, and its cost-balanced plan."""
+    bag = synth.SynthBag(10000, dense=True, poses_only=True)
+    ids = np.arange(10000, dtype=np.int32)
+    src, tgt, th0 = bag.sample_pairs(per_target=100, targets=ids, max_dist=3.5, min_sep=20)
+    w = sharding.predicted_pair_cost(bag.odom, src, tgt)
+    return src, tgt, th0, w, sharding.ShardPlan(src, tgt, th0, world, w)
+
+
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_config4_plan_balances_predicted_cost(world):
+    """The 1,000,000-pair list of configs[3] over 2 / 4 / 8 ranks: the plan balances PREDICTED COST (max / mean <= 1.03)
+    and that -- not drift -- is why the ranks' pair counts differ (8 ranks: 118,400 .. 127,600 pairs)."""
+    src, tgt, th0, w, plan = _config4_plan(world)
+    assert plan.n_pairs == 1000000
+    rw = plan.rank_weight
+    assert np.isclose(rw.sum(), w.sum()) and rw.max() / rw.mean() <= 1.03, rw / rw.mean()
+    plain = sharding.ShardPlan(src, tgt, th0, world)                      # the split by pair count, for comparison
+    assert plain.counts.max() - plain.counts.min() <= 100                  # (one target's pairs)
+    plain_w = np.array([w[plain.order[plain.bounds[r]:plain.bounds[r + 1]]].sum() for r in range(world)])
+    assert rw.max() / rw.mean() <= plain_w.max() / plain_w.mean() + 1e-12  # never worse than the count split, by its own measure
+    # the count spread IS the cost model's doing: ranks with more pairs hold cheaper pairs
+    mean_cost = rw / plan.counts
+    if world > 2:
+        assert np.corrcoef(plan.counts, mean_cost)[0, 1] < -0.9
+    owned = np.concatenate([plan.shard(r)[0] for r in range(world)])
+    assert len(owned) == 1000000 and np.array_equal(np.sort(owned), np.arange(1000000))
+
+
+def _config4_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        src, tgt, th0, w, plan = _config4_plan(world)
+        idx = plan.shard(rank)[0]
+        # stand-in records that name their pair: (global index, src, tgt, rank)
+        rec = np.stack([idx.astype(np.int32), src[idx], tgt[idx], np.full(len(idx), rank, np.int32)], axis=1)
+        full = plan.all_gather(torch.from_numpy(np.ascontiguousarray(rec)), rank).numpy()
+        ok = (np.array_equal(full[:, 0], np.arange(plan.n_pairs)) and np.array_equal(full[:, 1], src)
+              and np.array_equal(full[:, 2], tgt))
+        owner = np.empty(plan.n_pairs, np.int32)
+        for r in range(world):
+            owner[plan.shard(r)[0]] = r
+        ok = ok and np.array_equal(full[:, 3], owner)
+        q.put((rank, bool(ok), int(plan.counts[rank]), float(plan.rank_weight[rank]), float(plan.rank_weight.mean())))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_config4_all_gather_over_gloo_world_4():
+    """configs[3] at full size through the ONE collective of the multi-GPU path, four ranks over gloo: every rank ends
+    with the 1,000,000 records in the original pair order, each contributed by the rank the plan gave it to."""
+    world = 4
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_config4_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(r[1] for r in res), res
+    assert sum(r[2] for r in res) == 1000000
+    assert max(r[3] for r in res) / res[0][4] <= 1.03

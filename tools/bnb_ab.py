@@ -2,6 +2,7 @@
 every build/variants/libbnb_*.so (tools/bnb_variants.sh), one subprocess each, interleaved over the rounds.
   python tools/bnb_ab.py [rounds]"""
 import glob, json, os, subprocess, sys
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 libs = sorted(glob.glob(os.path.join(ROOT, "build", "variants", "libbnb_*.so")))

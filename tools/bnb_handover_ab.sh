@@ -1,4 +1,5 @@
 #!/bin/bash
+export NHIP_TUNABLES=1  # (the library reads its environment switches only then)
 # hand-over policy of the branch-and-bound matcher on the 10,000-pair bench workload: kernel ms (u8, u16) by
 # NHIP_BNB_KERNELS / NHIP_BNB_HEAVY_MIN / NHIP_BNB_KEEP_RANKS
 echo "default: $(timeout -k 5 100 python tools/bnb_quick.py 2>/dev/null | tr '\n' ' ')"

@@ -2,6 +2,7 @@
 """The pairs with the most candidates of the bench workload, each matched alone (GPU box): how long does one such
 pair take, with and without handing rotations over?  usage: bnb_heavy.py [top_n]"""
 import json, os, sys
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch

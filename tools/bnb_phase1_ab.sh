@@ -1,4 +1,5 @@
 #!/bin/bash
+export NHIP_TUNABLES=1  # (the library reads its environment switches only then)
 # Bounds phase of the branch-and-bound matcher by part (instrumented build; NHIP_BNB_DEBUG timing experiments), for the
 # product library and every build in build/variants (tools/bnb_variants.sh): kernel ms of the full run (0), bounds only
 # (2), bounds without the reductions (26), without the gathers (27), without the run lists too (28), without the

@@ -2,6 +2,7 @@
 """Timing probe of the branch-and-bound matcher on the bench workload (GPU box): kernel ms with and without
 its phases (NHIP_BNB_DEBUG), fraction of blocks evaluated exactly (NHIP_BNB_STATS)."""
 import ctypes as C, json, math, os, sys, time
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch

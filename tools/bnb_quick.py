@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of the branch-and-bound matcher on the bench workload under the environment given (GPU box)."""
 import os, sys
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -1,4 +1,5 @@
 #!/bin/bash
+export NHIP_TUNABLES=1  # (the library reads its environment switches only then)
 # The split form of the branch-and-bound matcher on the 10,000-pair bench workload: kernel ms (u8, u16) by how the
 # heaviest pairs are shared out (NHIP_BNB_SPLIT_MIN candidates per additional workgroup, NHIP_BNB_SPLIT_MAX workgroups
 # per pair), by batch size, with and without the candidates of one batch running beside the bounds of the next.

@@ -2,6 +2,7 @@
 """Timeline of the matcher's workgroups on the bench workload (GPU box): when each pair's workgroup started and
 ended, how many were resident over time, how long the tail is."""
 import json, os, sys
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 os.environ["NHIP_BNB_TIMELINE"] = os.environ["NHIP_BNB_INSTRUMENT"] = "1"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)

@@ -1,4 +1,5 @@
 #!/bin/bash
+export NHIP_TUNABLES=1  # (the library reads its environment switches only then)
 # Variants of libnautilus_hip.so that differ in the branch-and-bound matcher's compile-time switches, into
 # build/variants/ (run on the GPU box through NHIP_LIB: tools/bnb_quick.py, tools/bnb_ab.py).
 #   tools/bnb_variants.sh name1 "-Dflags1" name2 "-Dflags2" ...

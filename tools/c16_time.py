@@ -5,6 +5,7 @@ import argparse
 import glob
 import json
 import os
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 import subprocess
 import sys
 

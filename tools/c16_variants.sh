@@ -1,4 +1,5 @@
 #!/bin/bash
+export NHIP_TUNABLES=1  # (the library reads its environment switches only then)
 # Builds variants of libnautilus_hip.so that differ in csm_correlate16_kernel's compile-time shape (tile rows, waves
 # per workgroup, SDWA adds) into build/variants/, for tools/c16_time.py (run on the GPU box through NHIP_LIB).
 set -e

@@ -1,5 +1,6 @@
 """Which 200-scan bag makes bench.py's configs[0] leg close its loop?  (GPU box; prints one line per spacing)"""
 import json, os, sys
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "examples"))
 import slam_loop

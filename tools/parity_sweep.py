@@ -8,6 +8,7 @@ configurations, all equal; round 2: 3000 configurations x {8, 16}-bit, all equal
 import math, sys, time
 import numpy as np
 import os
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nautilus_amd import csm, synth
 from oracle import oracle as O

@@ -3,6 +3,7 @@
 predicted cost and by pair count, and times every shard's matcher on this one GPU, one after the other: max / mean of
 the per-shard match times is what the slowest rank costs the job.   tools/shard_balance.py [world]"""
 import os, sys
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np, torch
