@@ -246,6 +246,9 @@ int nhip_bnb_stats_per_pair(uint64_t *evaluated, int32_t n_pairs);
  * done, seeds done, end (the top 16 bits of the last one hold the hardware id of the CU it ran on); after the
  * n_pairs records two more values: first start and last end of the second kernel.  ticks: 4*n_pairs + 2 values */
 int nhip_bnb_timeline(uint64_t *ticks, int32_t n_pairs);
+/* ... and of the candidates' launch of the split form: ticks[i] = first start, ticks[n_pairs + i] = last end over the
+ * workgroups that worked pair i of the last round (~0 / 0: none did).  ticks: 2*n_pairs values */
+int nhip_bnb_timeline_candidates(uint64_t *ticks, int32_t n_pairs);
 
 /* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy]. */
 int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
@@ -408,8 +411,11 @@ int nhip_lc_chi_square_gate(const double *poses, int32_t n_poses, const int32_t 
  * exhaustive on the low_res grid over +-trans_range and +-rot_restriction in 1 degree steps, then exhaustive on the
  * high_res grid over +-low_res around the coarse optimum in 0.1 degree steps.  This is the ONE implementation of that
  * search: the C++ drop-in (adapters/CorrelativeScanMatcher.h) and the Python mirror (nautilus_amd/csm.py) both call it;
- * oracle/csm_oracle.c restates it independently for the tests.  Host pointers; uploads, builds both grids, matches,
- * frees.  pc_a / pc_b: n x 2 floats (std::vector<Eigen::Vector2f>). */
+ * oracle/csm_oracle.c restates it independently for the tests.  Host pointers.  pc_a / pc_b: n x 2 floats
+ * (std::vector<Eigen::Vector2f>).  The two tables built from pc_b stay in a cache of the last targets (keyed by the cloud's
+ * bytes and the parameters, per device; least recently used out first under a byte cap, 3 GB by default -- one target of
+ * the (30, 2, 0.3, 0.01) matcher is ~0.3 GB): SolveAutoLC -> GetRelativeTransform (solver.cc:630-649, 676-700) matches many
+ * sources against one target in a row, and only the first of those calls pays the build.  Thread-safe. */
 typedef struct nhip_csm_params {
   double scanner_range; /* ctor arg 1 (30) */
   double trans_range;   /* ctor arg 2 (2) */
@@ -420,6 +426,11 @@ typedef struct nhip_csm_params {
   int32_t cell_bits;    /* 16 or 8 (0 = 16, as in nhip_grid_spec_t: scores within 1e-5 of an unquantised table) */
   int32_t reserved;
 } nhip_csm_params_t;
+/* The cache of nhip_csm_get_transformation: its byte cap (0 = keep nothing; entries beyond the new cap are freed), all
+ * entries freed, and counters {entries, bytes held, hits, misses since the process started} (any pointer may be NULL). */
+int nhip_csm_cache_configure(int64_t max_bytes);
+int nhip_csm_cache_clear(void);
+int nhip_csm_cache_stats(int64_t *entries, int64_t *bytes, int64_t *hits, int64_t *misses);
 int nhip_csm_get_transformation(const nhip_csm_params_t *params, const float *pc_a, int32_t n_a, const float *pc_b,
                                 int32_t n_b, double rot_a, double rot_b, double rot_restriction, double *score,
                                 float *tx, float *ty, float *theta);

@@ -84,6 +84,7 @@ PROTOTYPES = {
     "nhip_bnb_stats": (C.c_int, [_P(C.c_uint64), _P(C.c_uint64)]),
     "nhip_bnb_stats_per_pair": (C.c_int, [_vp, _i32]),
     "nhip_bnb_timeline": (C.c_int, [_vp, _i32]),
+    "nhip_bnb_timeline_candidates": (C.c_int, [_vp, _i32]),
     "nhip_bnb_stats_levels": (C.c_int, [_P(C.c_uint64)]),
     "nhip_csm_scores_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _i32, _i32, _vp, _vp, _i32, _i32,
                                       _P(Search), _vp, _vp]),
@@ -118,6 +119,9 @@ PROTOTYPES = {
     "nhip_lc_chi_square_gate": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _f64, _vp, _vp]),
     "nhip_lc_scatter_scores": (C.c_int, [_vp, _vp]),
     "nhip_lc_pair_gate": (C.c_int, [_vp, _i32, _vp, _i32, _f64, _i32, _vp]),
+    "nhip_csm_cache_configure": (C.c_int, [_i64]),
+    "nhip_csm_cache_clear": (C.c_int, []),
+    "nhip_csm_cache_stats": (C.c_int, [_P(_i64), _P(_i64), _P(_i64), _P(_i64)]),
     "nhip_csm_get_transformation": (C.c_int, [_P(CsmParams), _vp, _i32, _vp, _i32, _f64, _f64, _f64, _P(_f64),
                                               _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "nhip_resid_batch_create": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _P(_vp)]),

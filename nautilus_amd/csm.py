@@ -242,3 +242,18 @@ def last_launch():
     return {"form": form.get(out[0], "?"), "form_id": out[0], "pairs_per_round": out[1], "rounds_of_state": out[2],
             "rounds": out[3], "short_scans": bool(out[4]), "hand_over_kernel": bool(out[5]), "instrumented": bool(out[6]),
             "n_pairs": out[7]}
+
+
+def drop_in_cache_stats():
+    """{entries, bytes, hits, misses} of nhip_csm_get_transformation's cache of target tables."""
+    v = [C.c_int64(0) for _ in range(4)]
+    check(_lib.load().nhip_csm_cache_stats(*[C.byref(x) for x in v]))
+    return dict(zip(("entries", "bytes", "hits", "misses"), (x.value for x in v)))
+
+
+def drop_in_cache_clear():
+    check(_lib.load().nhip_csm_cache_clear())
+
+
+def drop_in_cache_configure(max_bytes):
+    check(_lib.load().nhip_csm_cache_configure(int(max_bytes)))

@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <map>
+#include <memory>
 #include <mutex>
 
 #include "nhip_common.h"
@@ -943,6 +944,163 @@ int nhip_lc_pair_gate(const double *poses, int32_t n_poses, const int32_t *candi
   return NHIP_OK;
 }
 
+// ---- the reference-shaped single-pair call, with the tables of the last targets kept
+// Solver::SolveAutoLC -> GetRelativeTransform (solver.cc:630-649, 676-700) calls GetTransformation once per candidate pair,
+// and a target scan is matched against many sources in a row.  A call used to zero and build 77 MB + 161 MB of tables
+// for a target it had seen a call ago (1.4 ms, 708 calls/s); now the two grid handles of the last targets stay, keyed by
+// the target cloud ITSELF (length + 64-bit hash to find it, the bytes compared to be sure) and the constructor's
+// parameters, least recently used out first under a byte cap (nhip_csm_cache_configure / nhip_csm_cache_clear).
+// The fine grid of a cached target is built for the largest reach any coarse optimum can ask for (its layout no longer
+// depends on the source), which changes no result: the border is zeros either way.
+namespace {
+
+struct CachedTarget {
+  std::vector<float> cloud;   // the target's points, for the exact comparison
+  uint64_t hash = 0;
+  nhip_csm_params_t params;
+  int device = -1;
+  nhip_grids_t *g1 = nullptr, *g2 = nullptr;
+  nhip_grid_spec_t spec1, spec2;
+  int64_t bytes = 0;
+  ~CachedTarget() {
+    if (g1) nhip_grids_free(g1);
+    if (g2) nhip_grids_free(g2);
+  }
+};
+
+std::mutex g_cache_mu;
+// most recently used first.  (Heap-allocated and never destroyed: at process exit the HIP runtime may be gone before
+// static destructors run, and freeing device memory then is not safe; nhip_csm_cache_clear() frees it while it is.)
+std::vector<std::shared_ptr<CachedTarget>> &g_cache = *new std::vector<std::shared_ptr<CachedTarget>>();
+int64_t g_cache_cap = 3ll << 30;
+int64_t g_cache_hits = 0, g_cache_misses = 0;
+
+uint64_t hash_bytes(const void *p, size_t n) {  // FNV-1a over 8-byte words (+ tail): finds the entry, never decides equality
+  const uint8_t *b = static_cast<const uint8_t *>(p);
+  uint64_t h = 1469598103934665603ull;
+  size_t i = 0;
+  for (; i + 8 <= n; i += 8) {
+    uint64_t w;
+    memcpy(&w, b + i, 8);
+    h = (h ^ w) * 1099511628211ull;
+  }
+  for (; i < n; i++) h = (h ^ b[i]) * 1099511628211ull;
+  return h;
+}
+
+bool same_params(const nhip_csm_params_t &a, const nhip_csm_params_t &b) {
+  return a.scanner_range == b.scanner_range && a.trans_range == b.trans_range && a.low_res == b.low_res &&
+         a.high_res == b.high_res && a.sigma == b.sigma && a.floor_p == b.floor_p &&
+         (a.cell_bits == 0 ? 16 : a.cell_bits) == (b.cell_bits == 0 ? 16 : b.cell_bits);
+}
+
+// The calling thread's scratch for one pair (device buffers that live as long as the thread's library use: a call is
+// two launches and four small copies, no allocation).
+struct DropInScratch {
+  int device = -1;
+  DevBuf xy, off, idx, rot0, origin, keys, out, delta1, delta2, ws;
+  size_t xy_cap = 0;
+  int32_t n_theta1 = -1, n_theta2 = -1;
+  double step1 = 0, step2 = 0;
+};
+thread_local DropInScratch *t_scratch = nullptr;  // (a few KB of device memory per calling thread, left to the process's end)
+
+int scratch_for(int device, int32_t n_a, const nhip_search_t &s1, const nhip_search_t &s2, DropInScratch **out) {
+  if (!t_scratch) t_scratch = new DropInScratch();
+  DropInScratch &S = *t_scratch;
+  int rc;
+  if (S.device != device) {
+    S.~DropInScratch();
+    new (&S) DropInScratch();
+    S.device = device;
+    const int32_t zero2[2] = {0, 0};
+    if ((rc = S.off.alloc(8)) || (rc = S.idx.alloc(8)) || (rc = S.rot0.alloc(16)) || (rc = S.origin.alloc(8)) ||
+        (rc = S.keys.alloc(8)) || (rc = S.out.alloc(sizeof(nhip_match_t))) || (rc = S.ws.alloc((size_t)bnb_workspace_bytes_lists(1))))
+      return rc;
+    NHIP_TRY_HIP(hipMemcpy(S.idx.p, zero2, 8, hipMemcpyHostToDevice));  // {source scan 0, grid slot 0}
+  }
+  if ((size_t)n_a > S.xy_cap) {
+    const size_t cap = std::max<size_t>((size_t)n_a, 2048);
+    if ((rc = S.xy.alloc(sizeof(float) * 2 * cap))) return rc;
+    S.xy_cap = cap;
+  }
+  auto table = [&](DevBuf &d, int32_t &n_have, double &step_have, const nhip_search_t &s) -> int {
+    if (n_have == s.n_theta && step_have == s.theta_step) return NHIP_OK;
+    std::vector<double> t(2 * (size_t)s.n_theta);
+    int r = nhip_csm_delta_table(&s, t.data());
+    if (r) return r;
+    if ((r = d.alloc(sizeof(double) * t.size()))) return r;
+    NHIP_TRY_HIP(hipMemcpy(d.p, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
+    n_have = s.n_theta;
+    step_have = s.theta_step;
+    return NHIP_OK;
+  };
+  if ((rc = table(S.delta1, S.n_theta1, S.step1, s1)) || (rc = table(S.delta2, S.n_theta2, S.step2, s2))) return rc;
+  *out = &S;
+  return NHIP_OK;
+}
+
+// one pair (scan 0 of the scratch against slot 0 of `g`) on the null stream; the record comes back to the host
+int match_one(DropInScratch &S, nhip_grids_t *g, const nhip_search_t *search, const void *d_delta, double theta0,
+              const int32_t *origin, nhip_match_t *m) {
+  int rc = ensure_skip_maps(g, search);
+  if (rc) return rc;
+  nhip_grid_spec_t spec_now;
+  {
+    std::lock_guard<std::mutex> lock(g->mu);
+    spec_now = g->spec;
+  }
+  double cs[2];
+  if ((rc = nhip_csm_rot0(&theta0, nullptr, 1, cs))) return rc;
+  NHIP_TRY_HIP(hipMemcpyAsync(S.rot0.p, cs, 16, hipMemcpyHostToDevice, nullptr));
+  if (origin) NHIP_TRY_HIP(hipMemcpyAsync(S.origin.p, origin, 8, hipMemcpyHostToDevice, nullptr));
+  rc = launch_csm_match(static_cast<const float *>(S.xy.p), static_cast<const int32_t *>(S.off.p),
+                        static_cast<const uint8_t *>(g->grids.p), &spec_now, g->L, static_cast<const int32_t *>(S.idx.p),
+                        static_cast<const int32_t *>(S.idx.p) + 1, static_cast<const double *>(S.rot0.p),
+                        static_cast<const double *>(d_delta), origin ? static_cast<const int32_t *>(S.origin.p) : nullptr, 1,
+                        search, static_cast<uint64_t *>(S.keys.p), static_cast<nhip_match_t *>(S.out.p), nullptr, nullptr,
+                        S.ws.p, (int64_t)S.ws.bytes);
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpy(m, S.out.p, sizeof(nhip_match_t), hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+}  // namespace
+
+int nhip_csm_cache_configure(int64_t max_bytes) {
+  NHIP_REQUIRE(max_bytes >= 0, "csm_cache_configure: negative size");
+  std::vector<std::shared_ptr<CachedTarget>> drop;  // (freed outside the lock)
+  std::lock_guard<std::mutex> lock(g_cache_mu);
+  g_cache_cap = max_bytes;
+  int64_t tot = 0;
+  size_t keep = 0;
+  for (; keep < g_cache.size(); keep++) {
+    if (tot + g_cache[keep]->bytes > g_cache_cap) break;
+    tot += g_cache[keep]->bytes;
+  }
+  drop.assign(g_cache.begin() + (long)keep, g_cache.end());
+  g_cache.resize(keep);
+  return NHIP_OK;
+}
+
+int nhip_csm_cache_clear(void) {
+  std::vector<std::shared_ptr<CachedTarget>> drop;
+  std::lock_guard<std::mutex> lock(g_cache_mu);
+  drop.swap(g_cache);
+  return NHIP_OK;
+}
+
+int nhip_csm_cache_stats(int64_t *entries, int64_t *bytes, int64_t *hits, int64_t *misses) {
+  std::lock_guard<std::mutex> lock(g_cache_mu);
+  int64_t tot = 0;
+  for (auto &e : g_cache) tot += e->bytes;
+  if (entries) *entries = (int64_t)g_cache.size();
+  if (bytes) *bytes = tot;
+  if (hits) *hits = g_cache_hits;
+  if (misses) *misses = g_cache_misses;
+  return NHIP_OK;
+}
+
 int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, int32_t n_a, const float *pc_b,
                                 int32_t n_b, double rot_a, double rot_b, double rot_restriction, double *score,
                                 float *tx, float *ty, float *theta) {
@@ -953,47 +1111,120 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   NHIP_REQUIRE(p->low_res > 0 && p->high_res > 0 && p->low_res >= p->high_res && p->trans_range >= 0 && rot_restriction >= 0,
                "csm_get_transformation: bad search parameters");
   const int32_t bits = p->cell_bits == 0 ? 16 : p->cell_bits;
-  // scan 0 = A (source), scan 1 = B (target: the lookup table is built from it)
-  std::vector<float> xy(2 * ((size_t)n_a + (size_t)n_b));
-  if (n_a) memcpy(xy.data(), pc_a, sizeof(float) * 2 * (size_t)n_a);
-  if (n_b) memcpy(xy.data() + 2 * (size_t)n_a, pc_b, sizeof(float) * 2 * (size_t)n_b);
-  const int32_t off[3] = {0, n_a, n_a + n_b};
-  nhip_scans_t *scans = nullptr;
-  if ((rc = nhip_scans_upload(xy.data(), off, 2, &scans))) return rc;
-  struct Guard {
-    nhip_scans_t *s;
-    nhip_grids_t *g = nullptr;
-    ~Guard() {
-      if (g) nhip_grids_free(g);
-      nhip_scans_free(s);
-    }
-  } guard{scans};
+  int device = 0;
+  NHIP_TRY_HIP(hipGetDevice(&device));
   double theta0 = rot_a - rot_b;  // math_util.h:81-89 AngleDiff
   theta0 -= (2.0 * M_PI) * rint(theta0 / (2.0 * M_PI));
   const double coarse_step = M_PI / 180.0;
-  const int32_t src = 0, slot = 0, target = 1;
   // level 1: low_res grid, whole translation range, +-rot_restriction
   const int32_t h1 = (int32_t)floor(p->trans_range / p->low_res);
   const nhip_grid_spec_t spec1 = {p->scanner_range, p->low_res, p->sigma, p->floor_p, h1, bits, 0, 0};
   const nhip_search_t s1 = {2 * (int32_t)floor(rot_restriction / coarse_step) + 1, 2 * h1 + 1, 2 * h1 + 1, 0, coarse_step};
-  nhip_match_t m1;
-  if ((rc = nhip_grids_build(scans, &target, 1, &spec1, &guard.g))) return rc;
-  if ((rc = nhip_csm_match(scans, guard.g, &src, &slot, &theta0, nullptr, 1, &s1, &m1, nullptr))) return rc;
-  nhip_grids_free(guard.g);
-  guard.g = nullptr;
-  float tx1, ty1, th1;
-  if ((rc = nhip_match_to_transform(&m1, &spec1, &s1, theta0, 0, 0, &tx1, &ty1, &th1))) return rc;
-  // level 2: high_res grid, +-low_res around the coarse optimum, +-1 coarse step in 0.1 steps
+  // level 2: high_res grid, +-low_res around the coarse optimum, +-1 coarse step in 0.1 steps.  Its tables are built for
+  // the largest search centre a coarse optimum can produce (+ the fine half-width), so that they serve every source.
   const int32_t ratio = (int32_t)lround(p->low_res / p->high_res);
-  const int32_t origin[2] = {(int32_t)lround((double)tx1 / p->high_res), (int32_t)lround((double)ty1 / p->high_res)};
-  const int32_t reach = std::max(abs(origin[0]), abs(origin[1])) + ratio;
-  const nhip_grid_spec_t spec2 = {p->scanner_range, p->high_res, p->sigma, p->floor_p, reach, bits, 0, 0};
+  const int32_t reach_max = (int32_t)lround((double)h1 * p->low_res / p->high_res) + ratio + 2;
   const nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1, 0, coarse_step / 10.0};
+  const bool cacheable = reach_max <= 4096 && n_b > 0;
+
+  // ---- the target's tables: from the cache, or built now
+  std::shared_ptr<CachedTarget> T;
+  const size_t b_bytes = sizeof(float) * 2 * (size_t)n_b;
+  const uint64_t h = cacheable ? hash_bytes(pc_b, b_bytes) ^ (uint64_t)n_b : 0;
+  if (cacheable) {
+    std::lock_guard<std::mutex> lock(g_cache_mu);
+    for (size_t i = 0; i < g_cache.size(); i++) {
+      CachedTarget &c = *g_cache[i];
+      if (c.hash == h && c.device == device && c.cloud.size() == 2 * (size_t)n_b && same_params(c.params, *p) &&
+          memcmp(c.cloud.data(), pc_b, b_bytes) == 0) {
+        T = g_cache[i];
+        g_cache.erase(g_cache.begin() + (long)i);
+        g_cache.insert(g_cache.begin(), T);
+        g_cache_hits++;
+        break;
+      }
+    }
+    if (!T) g_cache_misses++;
+  }
+  nhip_match_t m1;
+  float tx1, ty1, th1;
+  if (!T) {
+    T = std::make_shared<CachedTarget>();
+    T->hash = h;
+    T->params = *p;
+    T->device = device;
+    if (n_b) T->cloud.assign(pc_b, pc_b + 2 * (size_t)n_b);
+    const int32_t off[2] = {0, n_b}, target = 0;
+    nhip_scans_t *bs = nullptr;
+    if ((rc = nhip_scans_upload(pc_b, off, 1, &bs))) return rc;
+    T->spec1 = spec1;
+    rc = nhip_grids_build(bs, &target, 1, &spec1, &T->g1);
+    if (rc == NHIP_OK && cacheable) {
+      T->spec2 = {p->scanner_range, p->high_res, p->sigma, p->floor_p, reach_max, bits, 0, 0};
+      rc = nhip_grids_build(bs, &target, 1, &T->spec2, &T->g2);
+    }
+    if (rc) {
+      nhip_scans_free(bs);
+      return rc;
+    }
+    if (!cacheable) {
+      // (no common reach, or an empty target: the fine grid is sized by this call's coarse optimum, below; nothing is kept.
+      //  The target's scan table must outlive the coarse match: matched here.)
+      DropInScratch *S0 = nullptr;
+      if ((rc = scratch_for(device, n_a, s1, s2, &S0))) { nhip_scans_free(bs); return rc; }
+      const int32_t offa[2] = {0, n_a};
+      hipError_t e = hipMemcpy(S0->off.p, offa, 8, hipMemcpyHostToDevice);
+      if (e == hipSuccess && n_a) e = hipMemcpy(S0->xy.p, pc_a, sizeof(float) * 2 * (size_t)n_a, hipMemcpyHostToDevice);
+      if (e != hipSuccess) { nhip_scans_free(bs); return hip_fail(e, "csm_get_transformation upload", __FILE__, __LINE__); }
+      rc = match_one(*S0, T->g1, &s1, S0->delta1.p, theta0, nullptr, &m1);
+      if (rc == NHIP_OK) rc = nhip_match_to_transform(&m1, &spec1, &s1, theta0, 0, 0, &tx1, &ty1, &th1);
+      if (rc) { nhip_scans_free(bs); return rc; }
+      const int32_t origin[2] = {(int32_t)lround((double)tx1 / p->high_res), (int32_t)lround((double)ty1 / p->high_res)};
+      const int32_t reach = std::max(abs(origin[0]), abs(origin[1])) + ratio;
+      T->spec2 = {p->scanner_range, p->high_res, p->sigma, p->floor_p, reach, bits, 0, 0};
+      rc = nhip_grids_build(bs, &target, 1, &T->spec2, &T->g2);
+      nhip_scans_free(bs);
+      if (rc) return rc;
+      nhip_match_t m2;
+      const double theta1 = th1;
+      if ((rc = match_one(*S0, T->g2, &s2, S0->delta2.p, theta1, origin, &m2))) return rc;
+      if ((rc = nhip_match_to_transform(&m2, &T->spec2, &s2, theta1, origin[0], origin[1], tx, ty, theta))) return rc;
+      *score = (double)m2.score;
+      return NHIP_OK;
+    }
+    nhip_scans_free(bs);
+    T->bytes = (int64_t)T->g1->grids.bytes + (int64_t)T->g2->grids.bytes;
+    std::vector<std::shared_ptr<CachedTarget>> drop;  // (evicted entries are freed outside the lock; a thread still matching
+    {                                                  //  against one keeps it alive through its own shared_ptr)
+      std::lock_guard<std::mutex> lock(g_cache_mu);
+      if (T->bytes <= g_cache_cap) {
+        g_cache.insert(g_cache.begin(), T);
+        int64_t tot = 0;
+        size_t keep = 0;
+        for (; keep < g_cache.size(); keep++) {
+          if (tot + g_cache[keep]->bytes > g_cache_cap) break;
+          tot += g_cache[keep]->bytes;
+        }
+        drop.assign(g_cache.begin() + (long)keep, g_cache.end());
+        g_cache.resize(keep);
+      }
+    }
+  }
+  // ---- the two searches of this source against the target's tables
+  DropInScratch *S = nullptr;
+  if ((rc = scratch_for(device, n_a, s1, s2, &S))) return rc;
+  const int32_t offa[2] = {0, n_a};
+  NHIP_TRY_HIP(hipMemcpyAsync(S->off.p, offa, 8, hipMemcpyHostToDevice, nullptr));
+  if (n_a) NHIP_TRY_HIP(hipMemcpyAsync(S->xy.p, pc_a, sizeof(float) * 2 * (size_t)n_a, hipMemcpyHostToDevice, nullptr));
+  if ((rc = match_one(*S, T->g1, &s1, S->delta1.p, theta0, nullptr, &m1))) return rc;
+  if ((rc = nhip_match_to_transform(&m1, &spec1, &s1, theta0, 0, 0, &tx1, &ty1, &th1))) return rc;
+  const int32_t origin[2] = {(int32_t)lround((double)tx1 / p->high_res), (int32_t)lround((double)ty1 / p->high_res)};
+  NHIP_REQUIRE(std::max(abs(origin[0]), abs(origin[1])) + ratio <= reach_max, "csm_get_transformation: coarse optimum (%d, %d) beyond "
+               "the fine tables' reach %d", origin[0], origin[1], reach_max);
   const double theta1 = th1;
   nhip_match_t m2;
-  if ((rc = nhip_grids_build(scans, &target, 1, &spec2, &guard.g))) return rc;
-  if ((rc = nhip_csm_match(scans, guard.g, &src, &slot, &theta1, origin, 1, &s2, &m2, nullptr))) return rc;
-  if ((rc = nhip_match_to_transform(&m2, &spec2, &s2, theta1, origin[0], origin[1], tx, ty, theta))) return rc;
+  if ((rc = match_one(*S, T->g2, &s2, S->delta2.p, theta1, origin, &m2))) return rc;
+  if ((rc = nhip_match_to_transform(&m2, &T->spec2, &s2, theta1, origin[0], origin[1], tx, ty, theta))) return rc;
   *score = (double)m2.score;
   return NHIP_OK;
 }
@@ -1287,6 +1518,11 @@ int nhip_bnb_stats_per_pair(uint64_t *evaluated, int32_t n_pairs) {
 int nhip_bnb_timeline(uint64_t *ticks, int32_t n_pairs) {
   NHIP_REQUIRE(ticks && n_pairs >= 0, "bnb_timeline: bad arguments");
   return bnb_timeline_read(reinterpret_cast<unsigned long long *>(ticks), n_pairs);
+}
+
+int nhip_bnb_timeline_candidates(uint64_t *ticks, int32_t n_pairs) {
+  NHIP_REQUIRE(ticks && n_pairs >= 0, "bnb_timeline_candidates: bad arguments");
+  return bnb_timeline_cand_read(reinterpret_cast<unsigned long long *>(ticks), n_pairs);
 }
 
 int nhip_bnb_stats(uint64_t *evaluated, uint64_t *total) {

@@ -2030,6 +2030,10 @@ __global__ __launch_bounds__(CAND_THREADS, CB == 2 ? NHIP_BNB_CAND_OCC16 : NHIP_
   const uint32_t live = P.ps_live[pair];
   if (live == 0u) return;  // (nothing left after the seeds, or a pair of the general kernel)
   const bool shared = P.ps_nw[pair] > 1u;
+  // (NHIP_BNB_TIMELINE=1, instrumented build: first start and last end over the pair's workgroups, 100 MHz ticks; the
+  //  pair's index here is its index in the ROUND -- tools look at lists of one round)
+  if (BNB_TIMELINE(P) && threadIdx.x == 0 && pair < BNB_STATS_PAIRS)
+    atomicMin(&BNB_TIMELINE(P)[4 * (size_t)BNB_STATS_PAIRS + 2 + pair], wall_clock64());
   if (threadIdx.x == 0) {
     s_best2 = P.keys[pair];
     s_next2 = 0u;
@@ -2068,6 +2072,8 @@ __global__ __launch_bounds__(CAND_THREADS, CB == 2 ? NHIP_BNB_CAND_OCC16 : NHIP_
     atomicAdd(&BNB_STATS(P)[7], (unsigned long long)clk.eval);
     if (pair < BNB_STATS_PAIRS) atomicAdd(&BNB_STATS(P)[BNB_STATS_HEAD + pair], 4ull * n_work[0] + n_work[2]);
   }
+  if (BNB_TIMELINE(P) && lane == 0 && pair < BNB_STATS_PAIRS)
+    atomicMax(&BNB_TIMELINE(P)[5 * (size_t)BNB_STATS_PAIRS + 2 + pair], wall_clock64());
   if (!shared) {
     __syncthreads();
     if (threadIdx.x == 0) P.keys[pair] = s_best2;
@@ -2373,8 +2379,11 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     }
     const char *tl = tunable("NHIP_BNB_TIMELINE");
     if (tl && tl[0] == '1') {
-      if (!g_bnb_timeline) NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_timeline), 32 * (size_t)BNB_STATS_PAIRS + 16));
+      if (!g_bnb_timeline) NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_timeline), 48 * (size_t)BNB_STATS_PAIRS + 16));
       P.timeline = g_bnb_timeline;
+      // (the candidates' launch of the split form: first start / last end per pair)
+      NHIP_TRY_HIP(hipMemsetAsync(g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS + 2, 0xff, 8 * (size_t)BNB_STATS_PAIRS, s));
+      NHIP_TRY_HIP(hipMemsetAsync(g_bnb_timeline + 5 * (size_t)BNB_STATS_PAIRS + 2, 0, 8 * (size_t)BNB_STATS_PAIRS, s));
       const unsigned long long init[2] = {~0ull, 0ull};  // the second kernel's first start and last end
       NHIP_TRY_HIP(hipMemcpyAsync(g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS, init, 16, hipMemcpyHostToDevice, s));
     }
@@ -2554,6 +2563,14 @@ int bnb_timeline_read(unsigned long long *out, int32_t n) {
   NHIP_TRY_HIP(hipMemcpy(out, g_bnb_timeline, 32 * (size_t)n, hipMemcpyDeviceToHost));
   // (the last pair's slot is followed by the second kernel's first start / last end)
   NHIP_TRY_HIP(hipMemcpy(out + 4 * (size_t)n, g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS, 16, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int bnb_timeline_cand_read(unsigned long long *out, int32_t n) {  // out[0..n): first start, out[n..2n): last end
+  if (!g_bnb_timeline || n <= 0) return NHIP_OK;
+  if (n > BNB_STATS_PAIRS) n = BNB_STATS_PAIRS;
+  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS + 2, 8 * (size_t)n, hipMemcpyDeviceToHost));
+  NHIP_TRY_HIP(hipMemcpy(out + n, g_bnb_timeline + 5 * (size_t)BNB_STATS_PAIRS + 2, 8 * (size_t)n, hipMemcpyDeviceToHost));
   return NHIP_OK;
 }
 

@@ -155,6 +155,7 @@ void bnb_last_launch(int32_t out[8]);
 bool bnb_fits(const GridLayout &L, const nhip_search_t *search);
 int bnb_stats_read(unsigned long long out[16]);
 int bnb_timeline_read(unsigned long long *out, int32_t n);
+int bnb_timeline_cand_read(unsigned long long *out, int32_t n);
 int bnb_stats_per_pair(unsigned long long *out, int32_t n);
 void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, const int32_t *d_offsets, int32_t n_pairs,
                          int32_t nx, int32_t ny, const GridLayout &L, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s);

@@ -101,12 +101,12 @@ def test_config4_loop_on_a_10000_scan_bag(gpu):
     wall-clock by owner -- this repo's path on the GPU beside the host's sparse solves (the reference's Ceres)."""
     sys.path.insert(0, os.path.join(ROOT, "examples"))
     import slam_loop
-    out = slam_loop.run(n_scans=10000, window=10, min_scatter_score=0.3)
+    out = slam_loop.run(n_scans=10000, window=10)  # (LCCandidateFilter's own threshold, 0.70: `python examples/slam_loop.py --scans 10000`)
     print({k: (round(v, 4) if isinstance(v, float) else v) for k, v in out.items()})
     print("GPU path %.2f s | host sparse solves %.2f s | other host work %.2f s | total %.2f s"
           % (out["gpu_path_s"], out["host_solver_s"], out["host_other_s"], out["t_total_s"]))
     assert out["icp_correspondences"] > 90e6
-    assert out["lc_candidates"] == 3275 and out["lc_accepted"] == 3239
+    assert out["lc_candidate_scans"] == 153 and out["lc_candidates"] == 3275 and out["lc_accepted"] == 3239
     assert out["lc_rel_err_m"] < 0.04
     assert out["err_lc_m"] < 0.04 and out["err_hitl_m"] < 0.04 and out["err_odometry_m"] > 0.5
     assert out["hitl_points"] > 1000000

@@ -532,6 +532,57 @@ def test_drop_in_class_matches_oracle_two_level_search(gpu, small_bag, cell_bits
     assert got[0] == want[0] and got[1][0][0] == want[1][0][0] and got[1][0][1] == want[1][0][1] and got[1][1] == want[1][1]
 
 
+def test_drop_in_cache_serves_repeated_targets(gpu, small_bag):
+    """SolveAutoLC -> GetRelativeTransform (solver.cc:630-649, 676-700) matches many sources against one target in a row:
+    the target's two tables are built by the first of those calls and kept (least recently used out first under a byte
+    cap).  Results do not depend on whether a call hit the cache, on the order of the calls, or on the cap; the floats
+    are the oracle's."""
+    thin = lambda i: small_bag.scans[i][::3]
+    m = csm.CorrelativeScanMatcher(30, 2, 0.3, 0.01)
+    call = lambda s_, t_: m.GetTransformation(thin(s_), thin(t_), small_bag.odom[s_, 2], small_bag.odom[t_, 2], math.radians(90))
+    csm.drop_in_cache_clear()
+    csm.drop_in_cache_configure(3 << 30)
+    base = csm.drop_in_cache_stats()
+    assert base["entries"] == 0 and base["bytes"] == 0
+    targets, sources = [15, 22, 30], [17, 19, 24, 27]
+    first = {(s_, t_): call(s_, t_) for t_ in targets for s_ in sources}           # per target: 1 miss, 3 hits
+    st = csm.drop_in_cache_stats()
+    assert st["entries"] == 3 and st["misses"] - base["misses"] == 3 and st["hits"] - base["hits"] == 9
+    assert 3 * 200e6 < st["bytes"] < 3 * 400e6                                      # ~0.3 GB per target at (30, 2, 0.3, 0.01)
+    again = {(s_, t_): call(s_, t_) for s_ in sources for t_ in targets}           # other order: all hits
+    assert again == first and csm.drop_in_cache_stats()["hits"] - st["hits"] == 12
+    # a target whose cloud differs in ONE float is another target
+    other = thin(15).copy()
+    other[5, 0] = np.nextafter(other[5, 0], np.float32(10))
+    m.GetTransformation(thin(17), other, small_bag.odom[17, 2], small_bag.odom[15, 2], math.radians(90))
+    assert csm.drop_in_cache_stats()["entries"] == 4
+    # other constructor arguments: other tables
+    m2 = csm.CorrelativeScanMatcher(20, 1.5, 0.25, 0.05)
+    g2 = m2.GetTransformation(thin(17), thin(15), small_bag.odom[17, 2], small_bag.odom[15, 2], math.radians(20))
+    assert csm.drop_in_cache_stats()["entries"] == 5
+    # a cap below one target: nothing is kept, every call builds; same floats
+    csm.drop_in_cache_configure(1 << 20)
+    assert csm.drop_in_cache_stats()["entries"] == 0
+    nocache = {k: call(*k) for k in list(first)[:3]}
+    assert all(nocache[k] == first[k] for k in nocache) and csm.drop_in_cache_stats()["entries"] == 0
+    assert m2.GetTransformation(thin(17), thin(15), small_bag.odom[17, 2], small_bag.odom[15, 2], math.radians(20)) == g2
+    csm.drop_in_cache_configure(3 << 30)
+    # the oracle's independent restatement, float for float (one pair per target)
+    for t_ in targets:
+        want = O.two_level_match(thin(17), thin(t_), small_bag.odom[17, 2], small_bag.odom[t_, 2], math.radians(90), 30.0, 2.0,
+                                 0.3, 0.01, cell_bits=16)
+        got = first[(17, t_)]
+        assert got[0] == want[0] and got[1][0][0] == want[1][0][0] and got[1][0][1] == want[1][0][1] and got[1][1] == want[1][1]
+    # several host threads on one target (ctypes releases the GIL): one of them builds, or two do and one entry stays
+    csm.drop_in_cache_clear()
+    import concurrent.futures as cf
+    with cf.ThreadPoolExecutor(4) as ex:
+        par = list(ex.map(lambda s_: call(s_, 22), sources * 2))
+    assert par == [first[(s_, 22)] for s_ in sources * 2]
+    csm.drop_in_cache_clear()
+    assert csm.drop_in_cache_stats()["entries"] == 0
+
+
 def test_device_pointer_api_on_torch_stream(gpu, small_bag):
     """The *_dev entry points: caller-owned HBM (torch tensors), launched on torch's stream."""
     import torch
