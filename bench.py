@@ -69,6 +69,11 @@ def parse(argv=None):
                     help="order in which a rank hands its pairs to the matcher: by target (a target's pairs share an "
                          "XCD's L2), or heaviest first by the cost estimate (measured: no gain at 10,000 pairs -- the pairs "
                          "that take milliseconds are not the ones the odometry offset predicts)")
+    ap.add_argument("--config4-loop", type=int, default=0, metavar="SCANS",
+                    help="instead of the bench: BASELINE configs[4]'s end-to-end loop on a bag of SCANS scans (10000) through the "
+                         "GPU path and -- its cpu_baseline leg, unless --cpu-seconds 0 -- through the CPU restatement, wall-clock "
+                         "by owner: this repo's path (gpu_path_s / cpu_path_s), the host's sparse solves, other host work; "
+                         "minutes of CPU time at 10,000 scans: not part of the default run")
     ap.add_argument("--no-drop-in", action="store_true",
                     help="skip the single-pair latency leg (its small launches of the correlation kernel would "
                          "blur that kernel's average in a rocprofv3 --stats summary)")
@@ -1293,9 +1298,39 @@ def bench_config1(with_cpu):
     return out
 
 
+def bench_config4_loop(n_scans, with_cpu):
+    """BASELINE configs[4] -- "end-to-end HITL-SLAM loop on a 10k-scan synthetic bag, wall-clock vs CPU reference" -- on one
+    GPU: examples/slam_loop.py at LCCandidateFilter's own threshold through the product's backend and through the oracle's
+    (Jet<6> autodiff residuals, linear-scan correspondences, the exhaustive scan matcher under OpenMP).  The comparison
+    that says something about THIS path is gpu_path_s vs cpu_path_s: the sparse solves (the reference's Ceres, out of scope)
+    are the same host code under either backend and dominate both totals."""
+    sys.path.insert(0, os.path.join(ROOT, "examples"))
+    import slam_loop
+    out = {"workload": "configs[4] on one GPU: %d dense 1081-beam scans; growing-window ICP solve 1..10, scatter-score candidates "
+                       "(threshold 0.70) + geometric pair gate, 61x81x81 scan matching on 16-bit tables, constraints + re-solve, "
+                       "one HITL message + re-solve" % n_scans}
+    slam_loop.run(n_scans=40, window=2, hitl=False, min_scatter_score=0.3)  # warm up the GPU path
+    g = out["gpu"] = slam_loop.run(n_scans=n_scans, window=10)
+    if with_cpu:
+        from oracle.cpu_backend import OracleBackend
+        c = out["cpu"] = slam_loop.run(n_scans=n_scans, window=10, backend=OracleBackend())
+        c.update({"kind": "port", "cores": _omp_threads()})
+        out["path_ratio_cpu_over_gpu"] = c["cpu_path_s"] / max(g["gpu_path_s"], 1e-9)
+        out["wall_clock_ratio_cpu_over_gpu"] = c["t_total_s"] / max(g["t_total_s"], 1e-9)
+        out["scan_matching_ratio_cpu_over_gpu"] = c["t_csm_s"] / max(g["t_csm_s"], 1e-9)
+        out["same_loop_closures"] = bool(c["lc_accepted"] == g["lc_accepted"] and c["lc_candidates"] == g["lc_candidates"])
+        out["same_trajectory"] = bool(abs(c["err_hitl_m"] - g["err_hitl_m"]) < 1e-6 and abs(c["err_lc_m"] - g["err_lc_m"]) < 1e-6)
+    return out
+
+
 def main(argv=None):
     argv = sys.argv[1:] if argv is None else argv
     a = parse(argv)
+    if a.config4_loop > 0:
+        from nautilus_amd import _lib
+        _lib.load()
+        print(json.dumps(bench_config4_loop(a.config4_loop, a.cpu_seconds > 0)))
+        return 0
     if "RANK" not in os.environ and a.gpus > 1:
         return launch_ranks(a, argv)
     return worker(a)

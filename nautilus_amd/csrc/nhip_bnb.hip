@@ -1685,7 +1685,10 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         m1 = __ballot(u1 != 0u && u1 >= bsum && lane + 64 < NB * NB);
         if ((m0 | m1) == 0ull) continue;
         if (heavy && (uint32_t)rank >= P.keep_ranks) {
-          const uint32_t e = wave_fetch_add(P.rot_count + 8 * xcd, 1u, lane);
+          // (a pair's rotations go round the eight lists, starting at its home XCD's: pairs with flat landscapes are
+          //  consecutive pairs -- one XCD's list held them all and the other seven XCDs' waves found theirs empty)
+          const uint32_t lx = (xcd + (uint32_t)rank) & 7u;
+          const uint32_t e = wave_fetch_add(P.rot_count + 8 * lx, 1u, lane);
           if (e < P.rot_cap) {
             if (lane < 4) {
               const unsigned long long M41 = (1ull << 41) - 1ull;
@@ -1693,7 +1696,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
                                               : lane == 1 ? (m0 & M41)
                                               : lane == 2 ? ((m0 >> 41) | (m1 << 23)) & M41
                                                           : (m1 >> 18);
-              P.rot_list[(size_t)xcd * P.rot_cap + e].w[lane] = word;
+              P.rot_list[(size_t)lx * P.rot_cap + e].w[lane] = word;
             }
             handed_over = true;
             continue;
@@ -2003,6 +2006,36 @@ __global__ __launch_bounds__(SORT_THREADS) void csm_bnb_order_kernel(BnbParams P
   }
 }
 
+// The work lists, spread form (the default): every pair ONCE in its home XCD's list, in pair order (the pairs of a target
+// run together where its tables are L2-resident), and IN FRONT of those the additional workgroups of the pairs with many
+// candidates left -- one more per P.split_min of them, up to P.split_max per pair -- dealt round-robin over ALL EIGHT
+// lists.  Round 3 kept a pair's additional workgroups in its home XCD's list, behind a budget per XCD: the pairs with
+// flat landscapes are consecutive pairs (the sources far from one target), so one XCD held them all, granted the
+// heaviest bucket its shares and left the next bucket with ONE workgroup per pair -- on 3,000 pairs the candidates'
+// launch ran 3.6 ms of which the last 2 ms were ten such pairs on one eighth of the chip (profiles/r04_small_lists.txt).
+// The additional workgroups come first in the launch so that a heavy pair's work starts with the launch, not after it.
+constexpr int ORDER_THREADS = 256;
+__global__ __launch_bounds__(ORDER_THREADS) void csm_bnb_order_spread_kernel(BnbParams P) {
+  const int32_t p = (int32_t)(blockIdx.x * ORDER_THREADS + threadIdx.x);
+  if (p >= P.n_pairs) return;
+  const int32_t extra_slots = P.ps_work_stride - P.pairs_per_xcd;  // per list
+  const int32_t home = p / P.pairs_per_xcd;
+  P.ps_work[(size_t)home * P.ps_work_stride + extra_slots + (p - home * P.pairs_per_xcd)] = p;
+  const uint32_t want = cand_shares(P, P.ps_count[p]) - 1u;
+  uint32_t got = 0u;
+  if (want) {
+    const uint32_t t0 = atomicAdd(P.ps_ticket, want);
+    for (uint32_t j = 0; j < want; j++) {
+      const uint32_t e = t0 + j;
+      if ((int32_t)(e >> 3) >= extra_slots) break;  // (the lists are full: the pair works with what it got)
+      // (a pair's additional workgroups start on the XCD after its home's and go round from there)
+      P.ps_work[(size_t)((e + (uint32_t)home + 1u) & 7u) * P.ps_work_stride + (e >> 3)] = p;
+      got++;
+    }
+  }
+  P.ps_nw[p] = 1u + got;
+}
+
 // The candidates: the OWN loop of csm_bnb_kernel on the state its split form left.  Four waves per workgroup, each takes
 // the pair's live rotations one at a time, best first.  A pair with one workgroup keeps its hand-out counter and its
 // best in LDS; a shared pair uses ps_next[pair] and keys[pair] -- the code is the same, through generic pointers, with
@@ -2115,7 +2148,10 @@ int launch_split_a(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s
   // (the general instantiation only has work when some scan does not fit the by-rotation form: a caller that knows its
   //  scan lengths says so -- NHIP_SEARCH_SHORT_SCANS -- and saves the launch of n_pairs workgroups that return at once)
   if (!P.short_scans && (rc = launch_main<CB, PL, false>(P, lds, blocks, s))) return rc;
-  hipLaunchKernelGGL(csm_bnb_order_kernel, dim3(8), dim3(SORT_THREADS), 0, s, P);
+  if (P.ps_ticket)
+    hipLaunchKernelGGL(csm_bnb_order_spread_kernel, dim3((uint32_t)((P.n_pairs + ORDER_THREADS - 1) / ORDER_THREADS)), dim3(ORDER_THREADS), 0, s, P);
+  else
+    hipLaunchKernelGGL(csm_bnb_order_kernel, dim3(8), dim3(SORT_THREADS), 0, s, P);
   return NHIP_OK;
 }
 
@@ -2220,7 +2256,12 @@ constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, ne
 // pairs 4.3 / 3.4, 10,000 pairs 8.1 / 6.5, 40,000 pairs 27.1 / 22.8, 60,000 pairs at 60 per target 39.3 / 34.1,
 // 1,000,000 pairs at 100 per target 606 fused, 663 in rounds of 65,536 without the helper stream (every round pays its
 // own tail), 600 with it, 543 in rounds of 131,072 with it.
-constexpr int64_t SPLIT_PAIRS = 131072, SPLIT_MIN_PAIRS = 4096, SPLIT_RING = 16;
+constexpr int64_t SPLIT_PAIRS = 131072, SPLIT_MIN_PAIRS = 1000, SPLIT_RING = 16;
+// Rounds of fewer pairs than this deal the additional workgroups of their heavy pairs over all eight XCDs' lists
+// (csm_bnb_order_spread_kernel); longer ones keep them in the pair's home list (csm_bnb_order_kernel), where every XCD
+// has heavy pairs of its own and the tables stay L2-resident.  Measured, match ms home / spread: 3,000 pairs 4.70 / 2.63,
+// 4,500 pairs 3.39 / 3.46, 10,000 pairs 6.38 / 6.54 (profiles/r04_small_lists.txt).
+constexpr int64_t SPREAD_BELOW_PAIRS = 4096;
 int64_t split_bytes_per_pair(int32_t n_theta) { return 16 + 6 + (int64_t)n_theta * 512; }
 constexpr int64_t SPLIT_SLOT_FIXED = 8 * 64 * 4 + 1024;  // per batch: the work lists' floor of 64 extra entries, alignment
 int64_t bnb_workspace_bytes_lists(int32_t n_pairs) {  // (the hand-over lists alone: the one-kernel form)
@@ -2403,7 +2444,12 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const char *force = tunable("NHIP_BNB_KERNELS");
   const char *hm = tunable("NHIP_BNB_HEAVY_MIN");
   const char *kr = tunable("NHIP_BNB_KEEP_RANKS");
-  const bool second = force ? force[0] == '2' : n_pairs < 1024;
+  // (lists that take the split form -- SPLIT_MIN_PAIRS pairs and more -- do not hand rotations over: their candidates'
+  //  launch shares the heavy pairs among several workgroups)
+  const char *sp0 = tunable("NHIP_BNB_SPLIT");
+  const bool split_wanted = d_workspace && !(sp0 && sp0[0] == '0') && (n_pairs >= SPLIT_MIN_PAIRS || (sp0 && sp0[0] == '1')) &&
+                            workspace_bytes >= BNB_WS_HEADER + 512 + SPLIT_SLOT_FIXED + 512 * split_bytes_per_pair(P.n_theta);
+  const bool second = force ? force[0] == '2' : (n_pairs < 1024 && !split_wanted);
   P.heavy_min = hm ? (uint32_t)atoi(hm) : (n_pairs <= 64 ? 1u : 384u);
   P.keep_ranks = kr ? (uint32_t)atoi(kr) : 8u;
   if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * (int64_t)sizeof(RotEntry) && second && !P.general_all) {
@@ -2427,6 +2473,8 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const char *sbat = tunable("NHIP_BNB_SPLIT_BATCH");
   const char *sov = tunable("NHIP_BNB_SPLIT_OVERLAP");
   const char *sco = tunable("NHIP_BNB_SORT_COARSE");  // (buckets of 2^n sixteenths of an octave: 4 = one per octave)
+  const char *spr = tunable("NHIP_BNB_SPREAD");       // (0: round 3's work lists, a pair's workgroups all in its home XCD's)
+  const bool spread_forced = spr && spr[0] == '1';
   int64_t split_batch = 0, split_slots = 0, slot_bytes = 0;
   const char *spp = tunable("NHIP_BNB_SPLIT_PAIRS");
   const int64_t split_cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
@@ -2496,14 +2544,17 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
       Q.pairs_per_xcd = (nb + 7) / 8;
       Q.ps_work_stride = Q.pairs_per_xcd + (Q.pairs_per_xcd / 2 > 64 ? Q.pairs_per_xcd / 2 : 64);
       Q.split_min = smin ? (uint32_t)(atoi(smin) > 0 ? atoi(smin) : 1) : 300u;
-      Q.split_max = smax ? (uint32_t)(atoi(smax) > 0 ? atoi(smax) : 1) : 8u;
+      Q.split_max = smax ? (uint32_t)(atoi(smax) > 0 ? atoi(smax) : 1) : (nb < SPREAD_BELOW_PAIRS ? 16u : 8u);
       Q.sort_coarse = sco ? (uint32_t)atoi(sco) : 9u;  // (one bucket: see csm_bnb_order_kernel)
       uint8_t *w = base + (round % split_slots) * slot_bytes;
       Q.ps_count = reinterpret_cast<uint32_t *>(w);
       Q.ps_live = Q.ps_count + nb;
       Q.ps_next = Q.ps_live + nb;
       Q.ps_nw = Q.ps_next + nb;
-      Q.ps_work = reinterpret_cast<int32_t *>(Q.ps_nw + nb);
+      // (spread form: the ticket counter of the additional workgroups, zeroed with the four arrays before it)
+      const bool spread = !sco && (spread_forced || (!(spr && spr[0] == '0') && nb < SPREAD_BELOW_PAIRS));
+      Q.ps_ticket = spread ? Q.ps_nw + nb : nullptr;
+      Q.ps_work = reinterpret_cast<int32_t *>(Q.ps_nw + nb + 4);
       const uintptr_t rows = (reinterpret_cast<uintptr_t>(Q.ps_work + 8 * (size_t)Q.ps_work_stride) + 511) & ~(uintptr_t)511;
       Q.ps_rows = reinterpret_cast<uint32_t *>(rows);
       NHIP_REQUIRE((int64_t)(rows - reinterpret_cast<uintptr_t>(w)) + (int64_t)nb * P.n_theta * 512 <= slot_bytes &&
@@ -2511,7 +2562,8 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
                    "csm_bnb: workspace accounting");
       // (the slot's previous batch must be through its candidates)
       if (overlap && round >= split_slots) NHIP_TRY_HIP(hipStreamWaitEvent(s, set->eb[(round - split_slots) % SPLIT_RING], 0));
-      NHIP_TRY_HIP(hipMemsetAsync(w, 0, 16 * (size_t)nb, s));
+      NHIP_TRY_HIP(hipMemsetAsync(w, 0, 16 * (size_t)nb + 16, s));
+      if (spread) NHIP_TRY_HIP(hipMemsetAsync(Q.ps_work, 0xff, 32 * (size_t)Q.ps_work_stride, s));  // (-1: no pair)
       const int64_t blocks_b = (int64_t)Q.pairs_per_xcd * 8;
       {
         TimerScope t_a(NHIP_TIMER_CSM_BOUNDS, s);

@@ -39,6 +39,7 @@ struct BnbParams {
   uint32_t *ps_next;    // [pair] next rank to hand out (pairs worked by several workgroups)
   uint32_t *ps_nw;      // [pair] workgroups of the second launch that share the pair
   int32_t *ps_work;     // [8][ps_work_stride] pair of each workgroup of the second launch (-1: none), per XCD
+  uint32_t *ps_ticket;  // spread form: counter of additional workgroups dealt over the eight lists (null: round 3's lists)
   int32_t ps_work_stride;
   uint32_t split_min;   // candidates per additional workgroup of a pair
   uint32_t split_max;   // workgroups per pair at most
