@@ -929,31 +929,41 @@ def bench_drop_in(bag, with_cpu, calls=8):
         res.append(m.GetTransformation(*args(i, j)))
         each.append(time.perf_counter() - t0)
     dt_new = float(np.median(each))
-    # 10 sources x 8 targets, target by target
+    # 10 sources x 8 targets, target by target: once with the cache (a target's first call builds, the other nine are
+    # served), once with a cap below one target (every call builds: what every call of round 3 did)
     n_src, tgts = 10, [37 + 7 * i for i in range(8)]
+
+    def loop():
+        each_, res_ = [], {}
+        t_all_ = time.perf_counter()
+        for j in tgts:
+            for k in range(n_src):
+                i = j + 2 + k        # 0.5 .. 2.75 m from the target: inside lc_base_max_range (3.5 m)
+                t0 = time.perf_counter()
+                res_[(i, j)] = m.GetTransformation(*args(i, j))
+                each_.append(time.perf_counter() - t0)
+        return time.perf_counter() - t_all_, each_, res_
+    csm.drop_in_cache_configure(1 << 20)
+    t_nocache, each_nocache, res_nocache = loop()
+    csm.drop_in_cache_configure(3 << 30)
     csm.drop_in_cache_clear()
     st0 = csm.drop_in_cache_stats()
-    loop_each, loop_res = [], {}
-    t_all = time.perf_counter()
-    for j in tgts:
-        for k in range(n_src):
-            i = j + 3 + 2 * k
-            t0 = time.perf_counter()
-            loop_res[(i, j)] = m.GetTransformation(*args(i, j))
-            loop_each.append(time.perf_counter() - t0)
-    t_all = time.perf_counter() - t_all
+    t_all, loop_each, loop_res = loop()
     st1 = csm.drop_in_cache_stats()
     hit_calls = [t for q, t in enumerate(loop_each) if q % n_src != 0]
-    same_as_uncached = all(loop_res[(i, j)] == r for (i, j), r in zip(pairs, res) if (i, j) in loop_res)
+    same_as_uncached = loop_res == res_nocache
     csm.drop_in_cache_clear()
     dt = t_all / len(loop_each)
-    out = {"workload": "%d sources x %d targets through GetTransformation, target by target (dense 1081-beam scans): per call "
-                       "181x13x13 lattice on a 200x200 grid, then 21x61x61 on a 6000x6000 grid of 16-bit cells; the target's "
-                       "tables (0.3 GB) are built by its first call and served from the library's cache to the other %d"
+    out = {"workload": "%d sources x %d targets through GetTransformation, target by target (dense 1081-beam scans, sources 0.5-2.75 m "
+                       "from their target): per call 181x13x13 lattice on a 200x200 grid, then 21x61x61 on a 6000x6000 grid of 16-bit "
+                       "cells; the target's tables (0.3 GB) are built by its first call and served from the library's cache to the other %d"
                        % (n_src, len(tgts), n_src - 1),
            "seconds_per_call": dt, "calls_per_s": 1.0 / dt,
            "calls_per_s_on_a_cached_target": 1.0 / float(np.median(hit_calls)),
            "seconds_per_call_on_a_cached_target": float(np.median(hit_calls)),
+           "same_loop_with_the_cache_off": {"seconds_per_call": t_nocache / len(each_nocache), "calls_per_s": len(each_nocache) / t_nocache,
+                                            "median_seconds_per_call": float(np.median(each_nocache))},
+           "speedup_of_the_loop_from_the_cache": t_nocache / t_all,
            "seconds_per_call_on_a_new_target": dt_new, "calls_per_s_on_a_new_target": 1.0 / dt_new,
            "cache": {"hits": st1["hits"] - st0["hits"], "misses": st1["misses"] - st0["misses"], "bytes_held_at_the_end": st1["bytes"]},
            "round3_calls_per_s_every_call_building": 708.0,

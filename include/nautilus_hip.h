@@ -204,10 +204,10 @@ int nhip_grid_rebuild_dev(const float *d_xy, const int32_t *d_offsets, const int
  * the fine level of a coarse-to-fine search); |origin| + half-width must be <= max_shift.
  * d_keys: n_pairs uint64 scratch; d_out: n_pairs records; d_sums: n_pairs int32 or NULL.
  * d_workspace: NULL, or nhip_csm_workspace_bytes(n_pairs) bytes of scratch for the branch-and-bound matcher.  Lists of
- * fewer than 1,000 pairs use it for hand-over lists: a pair whose landscape is flat (hundreds of candidate blocks after
+ * fewer than 192 pairs use it for hand-over lists: a pair whose landscape is flat (hundreds of candidate blocks after
  * bounds and seeds; in lists of <= 64 pairs, e.g. a single GetTransformation call, every pair) hands all but its first
  * 8 rotations to a second kernel that works them with every wave of the chip instead of keeping its one workgroup busy
- * for milliseconds.  Lists of 1,000 pairs and more run as two kernels -- bounds + seeds, whose workgroups all take the
+ * for milliseconds.  Lists of 192 pairs and more run as two kernels -- bounds + seeds, whose workgroups all take the
  * same time, then the candidates of all pairs, the heaviest pairs shared by several workgroups -- with each pair's rows
  * of bounds parked in the workspace in between (nhip_csm_workspace_bytes asks for 32 KB per pair there, for at most
  * 262,144 pairs: 328 MB at 10,000 pairs; 10,000 pairs: 8.2 -> 6.3 ms, 3,000 pairs: 4.1 -> 2.6 ms).  Lists of more than

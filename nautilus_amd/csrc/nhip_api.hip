@@ -1119,7 +1119,13 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   // level 1: low_res grid, whole translation range, +-rot_restriction
   const int32_t h1 = (int32_t)floor(p->trans_range / p->low_res);
   const nhip_grid_spec_t spec1 = {p->scanner_range, p->low_res, p->sigma, p->floor_p, h1, bits, 0, 0};
-  const nhip_search_t s1 = {2 * (int32_t)floor(rot_restriction / coarse_step) + 1, 2 * h1 + 1, 2 * h1 + 1, 0, coarse_step};
+  // (The coarse lattice is many rotations of few translations -- 181 x 13 x 13 at the reference's constants: the kernel that
+  //  performs every add spreads its rotations over the whole chip, where the branch-and-bound matcher would compute the
+  //  bounds of all of them in the pair's ONE workgroup, 23 rounds of its eight waves.  Same records either way.)
+  const char *l1 = tunable("NHIP_DROPIN_COARSE");  // (measurement: "bnb" keeps the branch-and-bound matcher)
+  const bool coarse_every_add = !(l1 && l1[0] == 'b') && (2 * h1 + 1) <= 21;
+  const nhip_search_t s1 = {2 * (int32_t)floor(rot_restriction / coarse_step) + 1, 2 * h1 + 1, 2 * h1 + 1,
+                            coarse_every_add ? NHIP_SEARCH_EXHAUSTIVE : 0, coarse_step};
   // level 2: high_res grid, +-low_res around the coarse optimum, +-1 coarse step in 0.1 steps.  Its tables are built for
   // the largest search centre a coarse optimum can produce (+ the fine half-width), so that they serve every source.
   const int32_t ratio = (int32_t)lround(p->low_res / p->high_res);

@@ -2247,16 +2247,17 @@ static unsigned long long *g_bnb_timeline = nullptr;
 static unsigned long long *g_bnb_stats = nullptr;
 
 constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, next entry to work}
-// Small batches: room for 16 handed-over rotations per pair on average (what does not fit is worked by the pair's own
-// workgroup).  The split form: per pair its four counters, 1.5 entries of the candidates' work list and the rows of
-// bounds of up to 64 rotations.  Lists of SPLIT_MIN_PAIRS .. SPLIT_PAIRS pairs take it in ONE round; longer lists in
-// rounds of SPLIT_PAIRS with the candidates of a round on the helper stream beside the next round's bounds, which needs
-// two rounds' state (8.6 GB at 61 rotations); with less workspace they stay fused.  Measured on the final build
-// (tools/bnb_size_ab.sh, profiles/r03_matcher_experiments.txt; match ms fused / split): 3,000 pairs 4.2 / 4.7, 4,500
-// pairs 4.3 / 3.4, 10,000 pairs 8.1 / 6.5, 40,000 pairs 27.1 / 22.8, 60,000 pairs at 60 per target 39.3 / 34.1,
-// 1,000,000 pairs at 100 per target 606 fused, 663 in rounds of 65,536 without the helper stream (every round pays its
-// own tail), 600 with it, 543 in rounds of 131,072 with it.
-constexpr int64_t SPLIT_PAIRS = 131072, SPLIT_MIN_PAIRS = 1000, SPLIT_RING = 16;
+// Lists of fewer than SPLIT_MIN_PAIRS pairs: room for 16 handed-over rotations per pair on average (what does not fit is
+// worked by the pair's own workgroup).  The split form: per pair its four counters, 1.5 entries of the candidates' work
+// list and the rows of bounds of up to 64 rotations.  Lists of SPLIT_MIN_PAIRS .. SPLIT_PAIRS pairs take it in ONE round;
+// longer lists in rounds of SPLIT_PAIRS with the candidates of a round on a helper stream beside the next round's bounds,
+// which needs two rounds' state (8.6 GB at 61 rotations); with less workspace they stay fused.  Measured (match ms,
+// one kernel per pair + hand-over / split; tools/r04_small_lists.sh, profiles/r04_small_lists.txt): 30 pairs 0.21 / 0.21,
+// 100 pairs 0.23 / 0.28, 200 pairs 0.71 / 0.60, 300 pairs 1.09 / 0.79, 500 pairs 1.12 / 0.86, 1,000 pairs 1.60 / 1.21,
+// 2,000 pairs 4.02 / 1.95, 3,000 pairs 4.08 / 2.63 (round 3's per-XCD work lists: 4.70), 10,000 pairs 8.1 / 6.4; round 3,
+// 40,000 pairs 27.1 / 22.8, 1,000,000 pairs at 100 per target 606 fused, 663 in rounds of 65,536 without the helper
+// stream (every round pays its own tail), 600 with it, 543 in rounds of 131,072 with it.
+constexpr int64_t SPLIT_PAIRS = 131072, SPLIT_MIN_PAIRS = 192, SPLIT_RING = 16;
 // Rounds of fewer pairs than this deal the additional workgroups of their heavy pairs over all eight XCDs' lists
 // (csm_bnb_order_spread_kernel); longer ones keep them in the pair's home list (csm_bnb_order_kernel), where every XCD
 // has heavy pairs of its own and the tables stay L2-resident.  Measured, match ms home / spread: 3,000 pairs 4.70 / 2.63,

@@ -175,14 +175,15 @@ def test_product_never_imports_oracle():
 
 
 def test_matcher_workspace_follows_the_size_rule():
-    """nhip_csm_workspace_bytes (no GPU needed): lists of fewer than 1,000 pairs only need the hand-over lists (64 B
-    per pair); from 1,000 pairs the split form parks 61+ rows of 128 bounds per pair (32 KB) in the workspace, for at
+    """nhip_csm_workspace_bytes (no GPU needed): lists of fewer than 192 pairs only need the hand-over lists (64 B
+    per pair); from 192 pairs the split form parks 61+ rows of 128 bounds per pair (32 KB) in the workspace, for at
     most 131,072 pairs in a round, and twice that for longer lists (two rounds in flight)."""
     from nautilus_amd import _lib
     lib = _lib.load()
     w = lib.nhip_csm_workspace_bytes
-    assert w(0) > 0 and w(999) < 1 << 20 and w(-5) == w(0)
+    assert w(0) > 0 and w(191) < 1 << 20 and w(-5) == w(0)
     per_pair = 16 + 6 + 64 * 512
+    assert 192 * per_pair <= w(192) < 192 * per_pair + (1 << 20)
     assert 1000 * per_pair <= w(1000) < 1000 * per_pair + (1 << 20)
     assert 4096 * per_pair <= w(4096) < 4096 * per_pair + (1 << 20)
     assert 10000 * per_pair <= w(10000) < 10000 * per_pair + (1 << 20)
