@@ -78,6 +78,12 @@
 #ifndef NHIP_BNB_F32_ORIGINS
 #define NHIP_BNB_F32_ORIGINS 1  // 0: window origins through two double-precision quotients (measurement)
 #endif
+#ifndef NHIP_BNB_LDS_UNALIGNED
+#define NHIP_BNB_LDS_UNALIGNED 0  // 1: the bounds' gather reads its 12 bytes per row at their byte address (ds_read_b96, no funnel shifts)
+#endif
+#ifndef NHIP_BNB_FRACT_NEAR
+#define NHIP_BNB_FRACT_NEAR 0  // 1: the origins' near-an-integer test on v_fract_f32 (fewer instructions per coordinate)
+#endif
 #if NHIP_BNB_INSTR
 #define csm_bnb_kernel csm_bnb_kernel_instr          // (their own names in profiles)
 #define csm_bnb_rot_kernel csm_bnb_rot_kernel_instr
@@ -151,9 +157,18 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
   // the double-precision path then takes like any other.
   const float mx = __fmul_rn(xr, P.inv_res_f), my = __fmul_rn(yr, P.inv_res_f);
   const float fx = floorf(mx), fy = floorf(my);
+#if NHIP_BNB_FRACT_NEAR
+  // near an integer <=> |fract(m) - 1/2| >= 1/2 - tol.  v_fract_f32 is m - floor(m) exactly for the finite |m| < 2^22 that
+  // matter (larger ones take the double-precision path through the second term: their tolerance exceeds 1/2)
+  const float gx = __builtin_amdgcn_fractf(mx), gy = __builtin_amdgcn_fractf(my);
+  // (+ 2^-22 absolute: g - 1/2 is rounded for g < 1/4, and v_fract_f32 clamps just below 1 -- both errors are < 2^-24)
+  const bool near = fabsf(__fsub_rn(gx, 0.5f)) >= __fsub_rn(0.5f, __fmaf_rn(fabsf(mx), 0x1p-22f, 0x1p-22f)) ||
+                    fabsf(__fsub_rn(gy, 0.5f)) >= __fsub_rn(0.5f, __fmaf_rn(fabsf(my), 0x1p-22f, 0x1p-22f));
+#else
   const float rx = __fsub_rn(mx, fx), ry = __fsub_rn(my, fy);  // exact
   const bool near = fminf(rx, __fsub_rn(1.0f, rx)) <= __fmul_rn(fabsf(mx), 0x1p-22f) ||
                     fminf(ry, __fsub_rn(1.0f, ry)) <= __fmul_rn(fabsf(my), 0x1p-22f);
+#endif
   ix = (int32_t)fx;
   iy = (int32_t)fy;
   if (__builtin_amdgcn_ballot_w64(near && finite) != 0ull) {
@@ -340,9 +355,16 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
   auto gather = [&](uint32_t a, uint32_t cnt) {
     const uint32_t sh = (a & 3u) * 8u;
     const uint32_t *q = reinterpret_cast<const uint32_t *>(pool + (a & ~3u));
+    struct __attribute__((packed)) Bytes12 { uint32_t a, b, c; };
 #pragma unroll
     for (int y = 0; y < NB; y++) {
       uint32_t w0, w1, w2, w3;
+      uint32_t n0, n1, n2;
+      if (POOL_LDS && NHIP_BNB_LDS_UNALIGNED) {
+        // (LDS reads need no alignment on this target: the row's 12 bytes in one ds_read_b96 at their own address)
+        const Bytes12 v = *reinterpret_cast<const Bytes12 *>(pool + a + (uint32_t)(y * DP));
+        n0 = v.a; n1 = v.b; n2 = v.c;
+      } else {
       if (POOL_LDS) {
         const uint32_t *row = q + (y * DP) / 4;  // DP is a multiple of 16
         w0 = row[0]; w1 = row[1]; w2 = row[2]; w3 = row[3];
@@ -350,8 +372,9 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
         const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((a & ~3u) + (uint32_t)(y * DP)), 0, 0);
         w0 = r4.x; w1 = r4.y; w2 = r4.z; w3 = r4.w;
       }
-      const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
-      const uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+      n0 = __builtin_amdgcn_alignbit(w1, w0, sh); n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+      n2 = __builtin_amdgcn_alignbit(w3, w2, sh);
+      }
       // even: b0 | b2 << 16; odd (raw): w >> 8 = b1 + 256 b2 + 65536 b3, repaired at the reduction
       E[y][0] += __umul24(n0 & M8, cnt); O[y][0] += __umul24(n0 >> 8, cnt);
       E[y][1] += __umul24(n1 & M8, cnt); O[y][1] += __umul24(n1 >> 8, cnt);

@@ -129,10 +129,26 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
     int big = 0;
     for (int32_t i = tid; i < NB; i += CT) s_start[i] = 0u;
     __syncthreads();
-    for (int32_t i = tid; i < nt; i += CT) {
-      const float2 g = xy[tb + i];
+    // (all of a thread's target points -- up to TGT_CHUNK / CT = 8 -- are requested before the first is used: rolled,
+    //  the loop paid one global-memory latency per iteration behind its LDS atomic, five in a row for a 1081-point
+    //  cloud)
+    constexpr int TPL = TGT_CHUNK / CT;
+    float2 tg[TPL], tn[GATE ? TPL : 1];
+#pragma unroll
+    for (int k = 0; k < TPL; k++) {
+      const int32_t i = tid + k * CT;
+      if (i < nt) {
+        tg[k] = xy[tb + i];
+        if (GATE) tn[GATE ? k : 0] = normals[tb + i];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < TPL; k++) {
+      const int32_t i = tid + k * CT;
+      if (i >= nt) continue;
+      const float2 g = tg[k];
       s_tgt[i] = g;
-      if (GATE) s_tgn[i] = normals[tb + i];
+      if (GATE) s_tgn[i] = tn[GATE ? k : 0];
       const float fx = __fmul_rn(g.x, inv_cell), fy = __fmul_rn(g.y, inv_cell);
       if (!(fabsf(fx) < CELL_LIMIT) || !(fabsf(fy) < CELL_LIMIT)) big = 1;
       else atomicAdd(&s_start[cell_hash((int32_t)floorf(fx), (int32_t)floorf(fy))], 1u);

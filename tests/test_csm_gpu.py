@@ -992,3 +992,35 @@ def test_grid_rebuild_clears_what_the_last_build_wrote(gpu, small_bag, cell_bits
     assert np.array_equal(call(lib.nhip_grid_rebuild_dev, ids_b, G, W2), fresh_b), "garbage workspace header"
     G3 = torch.full((nbytes,), 255, dtype=torch.uint8, device=dev)
     assert np.array_equal(call(lib.nhip_grid_rebuild_dev, ids_b, G3, W), fresh_b), "a buffer the workspace never saw"
+
+
+def test_environment_switches_need_nhip_tunables(gpu):
+    """A shipped process reads no behaviour switch: NHIP_BNB_SPLIT=0 changes the form of a 300-pair list only in a
+    process started with NHIP_TUNABLES=1 (the library looks once, at its first call)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import numpy as np\n"
+            "from nautilus_amd import csm, synth\n"
+            "bag = synth.SynthBag(40, dense=True)\n"
+            "st = csm.ScanTable.from_list(bag.scans)\n"
+            "ids = np.arange(30, dtype=np.int32)\n"
+            "grids = csm.LikelihoodGrids(st, ids, csm.grid_spec(max_shift=10))\n"
+            "src, tgt, th0 = bag.sample_pairs(per_target=10, targets=ids, max_dist=3.5, min_sep=2)\n"
+            "got, sums = csm.match_pairs(st, grids, src, np.searchsorted(ids, tgt), th0, csm.search_spec(9, 21, 21))\n"
+            "import zlib; print('FORM', csm.last_launch()['form_id'], len(src), zlib.crc32(got.tobytes()))\n" % root)
+    out = {}
+    for tun in ("0", "1"):
+        env = dict(os.environ, NHIP_BNB_SPLIT="0")
+        env.pop("NHIP_TUNABLES", None)
+        if tun == "1":
+            env["NHIP_TUNABLES"] = "1"
+        p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stdout + p.stderr
+        out[tun] = [l for l in p.stdout.splitlines() if l.startswith("FORM")][0].split()
+    assert out["0"][2] == out["1"][2] == "300"
+    assert out["0"][1] == "1", "without NHIP_TUNABLES the switch must be ignored: 300 pairs take the split form"
+    assert out["1"][1] == "0", "with NHIP_TUNABLES=1 NHIP_BNB_SPLIT=0 selects the one-kernel form"
+    assert out["0"][3] == out["1"][3], "both forms return the same records"

@@ -15,6 +15,11 @@ for r in range(rounds):
         name = os.path.basename(lp)[6:-3] + ("+lpt" if order == "1" else "")
         for line in p.stdout.decode().splitlines():
             if "kernel_ms" in line:
-                res.setdefault(name, {}).setdefault(line.split()[0], []).append(float(line.split()[2]))
+                f = line.split()
+                res.setdefault(name, {}).setdefault(f[0], []).append(float(f[2]))
+                if len(f) >= 9:  # bounds / candidates kernels of the split form, checksum of the records
+                    res[name].setdefault(f[0] + "_bounds", []).append(float(f[4]))
+                    res[name].setdefault(f[0] + "_cand", []).append(float(f[6]))
+                    res[name].setdefault(f[0] + "_crc", set()).add(f[8])
         print(name, r, res.get(name), flush=True)
-print(json.dumps(res))
+print(json.dumps({k: {kk: (sorted(vv) if isinstance(vv, set) else vv) for kk, vv in v.items()} for k, v in res.items()}))

@@ -22,5 +22,9 @@ for bits in (8, 16):
         m.step()
     torch.cuda.synchronize(); lib.nhip_timing_enable(0)
     ms, n = bench._timer(lib, _lib, _lib.NHIP_TIMER_CSM)
-    print("u%d kernel_ms %.3f" % (bits, ms / n), flush=True)
+    mb, nb = bench._timer(lib, _lib, _lib.NHIP_TIMER_CSM_BOUNDS)
+    mc, nc = bench._timer(lib, _lib, _lib.NHIP_TIMER_CSM_CAND)
+    import zlib
+    crc = zlib.crc32(m.records()[0].cpu().numpy().tobytes()) ^ zlib.crc32(m.records()[1].cpu().numpy().tobytes())
+    print("u%d kernel_ms %.3f bounds %.3f cand %.3f records_crc %08x" % (bits, ms / n, mb / max(nb, 1), mc / max(nc, 1), crc), flush=True)
     m.free_grids()
