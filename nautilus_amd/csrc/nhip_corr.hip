@@ -7,9 +7,10 @@
 // which the reference runs from scratch for every (i, j) block and every window size
 // (solver.cc:321-356): three tree descents per matched point.
 //
-// Per block one workgroup: the target cloud is staged in LDS (8 B per point) and bucketed by a
-// uniform grid with cells a shade wider than the outlier threshold (counting sort on a 1024-entry
-// hash of the cell coordinates, all in LDS).  Every lane owns a contiguous range of source
+// Per block one workgroup: the target cloud is staged in LDS (8 B per point) IN THE ORDER OF ITS BUCKETS: a uniform
+// grid with cells a shade wider than the outlier threshold, counting sort on 1024 buckets in LDS; the four cells
+// (4g .. 4g + 3, cy) share a hashed group of four consecutive buckets, so a query's three cells of a row are one or
+// two runs of consecutive points.  Every lane owns a contiguous range of source
 // points, transforms them into the target frame with the float affine inverse(T_target) * T_source
 // (Eigen Affine2f semantics, individually rounded products) and visits the 3 x 3 cells around
 // each: a target that passes sqrt(d2) < outlier_threshold lies in one of them, and so does the
@@ -18,7 +19,12 @@
 // Target clouds larger than the LDS stage, or coordinates so large that float cell indices are
 // no longer exact, take the exhaustive scan (LDS broadcast reads).  Kept rows are written in
 // source order (block-wide exclusive scan of the per-lane counts) as the 8-float rows K4 consumes.
-// ~25 candidates per source point instead of 1081.
+// ~25 candidates per source point instead of 1081.  Where the time goes (tools/corr_phase_probe.py, 9,945 blocks of
+// 1081-point scans, 0.58 ms): staging, sort and the rows' output 0.06 ms; the walk 0.52 ms, and it is its per-candidate
+// iterations under divergent trip counts (a wave runs a bucket run as long as its fullest lane needs: ~40 % of the lanes
+// work) -- not the point reads (0.02 ms), not the index indirection (points in bucket order: -3 %), not the per-run
+// setup (runs of three cells instead of nine single cells: -1.5 %); one loop per lane over all nine cells, which would
+// iterate max-over-lanes of the totals, was measured slower (0.68 ms: its cell-advance test runs every iteration).
 #include "nhip_common.h"
 
 namespace nhip {
@@ -70,8 +76,16 @@ __device__ __forceinline__ Aff2f mul_f(const Aff2f &A, const Aff2f &B) {
 #endif
 constexpr int NB = NHIP_CORR_NB;  // hash buckets of the target grid
 
+// Buckets come in groups of four: the cells (4g .. 4g + 3, cy) of a row occupy four CONSECUTIVE buckets (the group is
+// hashed, the cell's place in it is cx & 3), so the three cells cx - 1 .. cx + 1 a query visits in a row are one run of
+// consecutive buckets -- or two, when they straddle a group -- instead of three separate ones: 4.5 bucket ranges per
+// point instead of 9, each with its hash, its two dependent LDS reads and its short loop (the walk is bound by that
+// per-range overhead: tools/corr_phase_probe.py).  Cells that share a bucket only add candidates the distance test drops.
+__device__ __forceinline__ uint32_t group_hash(int32_t gx, int32_t cy) {
+  return ((((uint32_t)gx * 73856093u) ^ ((uint32_t)cy * 19349663u)) & (uint32_t)(NB / 4 - 1)) << 2;
+}
 __device__ __forceinline__ uint32_t cell_hash(int32_t cx, int32_t cy) {
-  return (((uint32_t)cx * 73856093u) ^ ((uint32_t)cy * 19349663u)) & (uint32_t)(NB - 1);
+  return group_hash(cx >> 2, cy) | ((uint32_t)cx & 3u);
 }
 
 // block-wide inclusive scan of one int per thread: wave scans by shuffles, wave totals through LDS
@@ -129,29 +143,23 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
     int big = 0;
     for (int32_t i = tid; i < NB; i += CT) s_start[i] = 0u;
     __syncthreads();
-    // (all of a thread's target points -- up to TGT_CHUNK / CT = 8 -- are requested before the first is used: rolled,
-    //  the loop paid one global-memory latency per iteration behind its LDS atomic, five in a row for a 1081-point
-    //  cloud)
+    // (all of a thread's target points -- up to TGT_CHUNK / CT = 8 -- are requested before the first is used)
     constexpr int TPL = TGT_CHUNK / CT;
-    float2 tg[TPL], tn[GATE ? TPL : 1];
+    {
+      float2 tg[TPL];
 #pragma unroll
-    for (int k = 0; k < TPL; k++) {
-      const int32_t i = tid + k * CT;
-      if (i < nt) {
-        tg[k] = xy[tb + i];
-        if (GATE) tn[GATE ? k : 0] = normals[tb + i];
+      for (int k = 0; k < TPL; k++) {
+        const int32_t i = tid + k * CT;
+        if (i < nt) tg[k] = xy[tb + i];
       }
-    }
 #pragma unroll
-    for (int k = 0; k < TPL; k++) {
-      const int32_t i = tid + k * CT;
-      if (i >= nt) continue;
-      const float2 g = tg[k];
-      s_tgt[i] = g;
-      if (GATE) s_tgn[i] = tn[GATE ? k : 0];
-      const float fx = __fmul_rn(g.x, inv_cell), fy = __fmul_rn(g.y, inv_cell);
-      if (!(fabsf(fx) < CELL_LIMIT) || !(fabsf(fy) < CELL_LIMIT)) big = 1;
-      else atomicAdd(&s_start[cell_hash((int32_t)floorf(fx), (int32_t)floorf(fy))], 1u);
+      for (int k = 0; k < TPL; k++) {
+        const int32_t i = tid + k * CT;
+        if (i >= nt) continue;
+        const float fx = __fmul_rn(tg[k].x, inv_cell), fy = __fmul_rn(tg[k].y, inv_cell);
+        if (!(fabsf(fx) < CELL_LIMIT) || !(fabsf(fy) < CELL_LIMIT)) big = 1;
+        else atomicAdd(&s_start[cell_hash((int32_t)floorf(fx), (int32_t)floorf(fy))], 1u);
+      }
     }
     hashed = !__syncthreads_or(big);
   }
@@ -172,10 +180,30 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
     }
     if (tid == CT - 1) s_start[NB] = run;
     __syncthreads();
-    for (int32_t i = tid; i < nt; i += CT) {
-      const float2 g = s_tgt[i];
+    // The points themselves go to LDS IN BUCKET ORDER (s_tgt[slot], s_tgn[slot]; s_sorted[slot] = the point's index):
+    // the walk then reads a bucket's points at consecutive addresses, with no index to fetch and follow first.  (Read
+    // again from global memory -- the L2 has them -- rather than held in registers across the scan: 16 more registers
+    // would cost the kernel its fifth wave per SIMD.)
+    constexpr int TPL = TGT_CHUNK / CT;
+    float2 tg[TPL], tn[GATE ? TPL : 1];
+#pragma unroll
+    for (int k = 0; k < TPL; k++) {
+      const int32_t i = tid + k * CT;
+      if (i < nt) {
+        tg[k] = xy[tb + i];
+        if (GATE) tn[GATE ? k : 0] = normals[tb + i];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < TPL; k++) {
+      const int32_t i = tid + k * CT;
+      if (i >= nt) continue;
+      const float2 g = tg[k];
       const uint32_t h = cell_hash((int32_t)floorf(__fmul_rn(g.x, inv_cell)), (int32_t)floorf(__fmul_rn(g.y, inv_cell)));
-      s_sorted[atomicAdd(&s_cur[h], 1u)] = (uint16_t)i;
+      const uint32_t slot = atomicAdd(&s_cur[h], 1u);
+      s_tgt[slot] = g;
+      if (GATE) s_tgn[slot] = tn[GATE ? k : 0];
+      s_sorted[slot] = (uint16_t)i;
     }
     __syncthreads();
   }
@@ -216,26 +244,33 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
         const float fx = __fmul_rn(qx[k], inv_cell), fy = __fmul_rn(qy[k], inv_cell);
         if (!(fabsf(fx) < CELL_LIMIT) || !(fabsf(fy) < CELL_LIMIT)) continue;  // NaN / inf: no match
         const int32_t icx = (int32_t)floorf(fx), icy = (int32_t)floorf(fy);
+        const int32_t lo = icx - 1, hi2 = icx + 1;
+        const bool two = (lo >> 2) != (hi2 >> 2);  // the three cells straddle a group of four
         for (int32_t oy = -1; oy <= 1; oy++)
-          for (int32_t ox = -1; ox <= 1; ox++) {
-            const uint32_t h = cell_hash(icx + ox, icy + oy);
-            const uint32_t e = s_start[h + 1];
-            for (uint32_t i = s_start[h]; i < e; i++) {
-              const int32_t idx = (int32_t)s_sorted[i];
-              const float2 g = s_tgt[idx];
+          for (int32_t r = 0; r < 2; r++) {
+            if (r == 1 && !two) break;
+            // first run: from cell lo to cell hi2 or the end of lo's group; second run: the cells of hi2's group
+            const uint32_t b0 = r == 0 ? cell_hash(lo, icy + oy) : group_hash(hi2 >> 2, icy + oy);
+            const uint32_t b1 = r == 0 ? (two ? (b0 | 3u) : b0 + 2u) : b0 + ((uint32_t)hi2 & 3u);
+            const uint32_t e = s_start[b1 + 1];
+            for (uint32_t i = s_start[b0]; i < e; i++) {
+              const float2 g = s_tgt[i];  // (bucket order: consecutive addresses)
               const float dx = __fsub_rn(g.x, qx[k]), dy = __fsub_rn(g.y, qy[k]);
               const float d2 = __fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy));
               bool ok = true;
               if (GATE) {
-                const float2 gn = s_tgn[idx];
+                const float2 gn = s_tgn[i];
                 ok = __fsqrt_rn(d2) < thr && fabsf(dot2(gn.x, snx[k], gn.y, sny[k])) > min_cos;
               }
-              // the order of visits is arbitrary: (d2, index) lexicographic = "lowest index wins ties"
-              const bool better = ok && (d2 < best[k] || (d2 == best[k] && (uint32_t)idx < (uint32_t)bi[k]));
+              // the order of visits is arbitrary: (d2, index) lexicographic = "lowest index wins ties".  bi[k] holds the
+              // SLOT of the best so far; the indices are fetched only on an exact tie of the squared distances
+              bool better = ok && d2 < best[k];
+              if (ok && d2 == best[k] && bi[k] >= 0) better = s_sorted[i] < s_sorted[bi[k]];
               best[k] = better ? d2 : best[k];
-              bi[k] = better ? idx : bi[k];
+              bi[k] = better ? (int32_t)i : bi[k];
             }
           }
+        if (bi[k] >= 0) bi[k] = (int32_t)s_sorted[bi[k]];  // slot -> index of the target point
       }
     } else {
       for (int32_t t0 = 0; t0 < nt; t0 += TGT_CHUNK) {
@@ -250,6 +285,8 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
         }
         for (int32_t i = 0; i < nc; i++) {
           const float2 g = s_tgt[i];  // same address in every lane: LDS broadcast
+          // (a hashed block holds its cloud in bucket order: position i is point s_sorted[i], and ties go by index)
+          const int32_t idx = hashed ? (int32_t)s_sorted[i] : t0 + i;
 #pragma unroll
           for (int k = 0; k < MAX_PER_LANE; k++) {
             const float dx = __fsub_rn(g.x, qx[k]), dy = __fsub_rn(g.y, qy[k]);
@@ -259,9 +296,9 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
               const float2 gn = s_tgn[i];
               ok = __fsqrt_rn(d2) < thr && fabsf(dot2(gn.x, snx[GATE ? k : 0], gn.y, sny[GATE ? k : 0])) > min_cos;
             }
-            const bool better = ok && d2 < best[k];  // strict: the lowest index wins ties
+            const bool better = ok && (d2 < best[k] || (d2 == best[k] && (uint32_t)idx < (uint32_t)bi[k]));  // the lowest index wins ties
             best[k] = better ? d2 : best[k];
-            bi[k] = better ? (t0 + i) : bi[k];
+            bi[k] = better ? idx : bi[k];
           }
         }
       }

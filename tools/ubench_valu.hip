@@ -63,6 +63,22 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, uint32_t seed) {
     } else if (MODE == 11) {  // v_lshl_add_u32
 #pragma unroll
       for (int i = 0; i < 16; i++) asm volatile("v_lshl_add_u32 %0, %1, 1, %0" : "+v"(a[i]) : "v"(w0));
+    } else if (MODE == 13) {  // v_pk_mad_u16 (VOP3P): 16 per iter
+#pragma unroll
+      for (int i = 0; i < 16; i++) asm volatile("v_pk_mad_u16 %0, %1, %2, %0" : "+v"(a[i]) : "v"(w0), "v"(w1));
+    } else if (MODE == 14) {  // v_mul_u32_u24 (VOP2) + v_add_u32: 8 multiply-adds per iter
+#pragma unroll
+      for (int i = 0; i < 8; i++) {
+        uint32_t t;
+        asm volatile("v_mul_u32_u24 %0, %1, %2" : "=v"(t) : "v"(w0), "v"(w1));
+        asm volatile("v_add_u32 %0, %1, %0" : "+v"(a[i]) : "v"(t));
+      }
+    } else if (MODE == 15) {  // v_alignbit_b32: 16 per iter
+#pragma unroll
+      for (int i = 0; i < 16; i++) asm volatile("v_alignbit_b32 %0, %1, %0, %2" : "+v"(a[i]) : "v"(w0), "v"(w1));
+    } else if (MODE == 16) {  // v_pk_mul_lo_u16: 16 per iter
+#pragma unroll
+      for (int i = 0; i < 16; i++) asm volatile("v_pk_mul_lo_u16 %0, %1, %0" : "+v"(a[i]) : "v"(w0));
     } else if (MODE == 12) {  // v_add_u32_sdwa with WORD sel
 #pragma unroll
       for (int i = 0; i < 8; i++) {
@@ -110,6 +126,10 @@ int main() {
     run<8>("v_add3_u32", d, blocks);
     run<10>("v_mad_u32_u24", d, blocks);
     run<11>("v_lshl_add_u32", d, blocks);
+    run<13>("v_pk_mad_u16", d, blocks);
+    run<16>("v_pk_mul_lo_u16", d, blocks);
+    run<14>("v_mul_u32_u24 + v_add_u32 (x8)", d, blocks);
+    run<15>("v_alignbit_b32", d, blocks);
   }
   return 0;
 }
