@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cstddef>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -996,9 +997,13 @@ bool same_params(const nhip_csm_params_t &a, const nhip_csm_params_t &b) {
 
 // The calling thread's scratch for one pair (device buffers that live as long as the thread's library use: a call is
 // two launches and four small copies, no allocation).
+constexpr int DROPIN_PARTS_MAX = 8;  // "pairs" (workgroups) one search's rotations may be dealt over
 struct DropInScratch {
   int device = -1;
-  DevBuf xy, off, idx, rot0, origin, keys, out, delta1, delta2, ws;
+  // par: one block of per-call parameters, uploaded in ONE copy {scan offsets int32[2] @0, (cos, sin) theta0 per part
+  // double[16] @16, search centre per part int32[16] @144, rotation base per part int32[8] @208}; res: the records
+  // nhip_match_t[8] @0 and their sums int32[8] @128, downloaded in one copy
+  DevBuf xy, par, idx, keys, res, delta1, delta2, ws;
   size_t xy_cap = 0;
   int32_t n_theta1 = -1, n_theta2 = -1;
   double step1 = 0, step2 = 0;
@@ -1013,11 +1018,12 @@ int scratch_for(int device, int32_t n_a, const nhip_search_t &s1, const nhip_sea
     S.~DropInScratch();
     new (&S) DropInScratch();
     S.device = device;
-    const int32_t zero2[2] = {0, 0};
-    if ((rc = S.off.alloc(8)) || (rc = S.idx.alloc(8)) || (rc = S.rot0.alloc(16)) || (rc = S.origin.alloc(8)) ||
-        (rc = S.keys.alloc(8)) || (rc = S.out.alloc(sizeof(nhip_match_t))) || (rc = S.ws.alloc((size_t)bnb_workspace_bytes_lists(1))))
+    const int32_t zeros[2 * DROPIN_PARTS_MAX] = {0};
+    constexpr size_t G = DROPIN_PARTS_MAX;
+    if ((rc = S.par.alloc(256)) || (rc = S.idx.alloc(8 * G)) || (rc = S.keys.alloc(8 * G)) || (rc = S.res.alloc(256)) ||
+        (rc = S.ws.alloc((size_t)bnb_workspace_bytes_lists((int32_t)G))))
       return rc;
-    NHIP_TRY_HIP(hipMemcpy(S.idx.p, zero2, 8, hipMemcpyHostToDevice));  // {source scan 0, grid slot 0}
+    NHIP_TRY_HIP(hipMemcpy(S.idx.p, zeros, 8 * G, hipMemcpyHostToDevice));  // source scan 0, grid slot 0 for every part
   }
   if ((size_t)n_a > S.xy_cap) {
     const size_t cap = std::max<size_t>((size_t)n_a, 2048);
@@ -1026,9 +1032,15 @@ int scratch_for(int device, int32_t n_a, const nhip_search_t &s1, const nhip_sea
   }
   auto table = [&](DevBuf &d, int32_t &n_have, double &step_have, const nhip_search_t &s) -> int {
     if (n_have == s.n_theta && step_have == s.theta_step) return NHIP_OK;
-    std::vector<double> t(2 * (size_t)s.n_theta);
+    // (+ DROPIN_PARTS_MAX copies of the last rotation: a search dealt over several workgroups in equal parts reads past
+    //  the table's end; a copy's poses tie with the original's and lose the tie by their larger index)
+    std::vector<double> t(2 * (size_t)(s.n_theta + DROPIN_PARTS_MAX));
     int r = nhip_csm_delta_table(&s, t.data());
     if (r) return r;
+    for (int e = 0; e < DROPIN_PARTS_MAX; e++) {
+      t[2 * (size_t)(s.n_theta + e)] = t[2 * (size_t)(s.n_theta - 1)];
+      t[2 * (size_t)(s.n_theta + e) + 1] = t[2 * (size_t)(s.n_theta - 1) + 1];
+    }
     if ((r = d.alloc(sizeof(double) * t.size()))) return r;
     NHIP_TRY_HIP(hipMemcpy(d.p, t.data(), sizeof(double) * t.size(), hipMemcpyHostToDevice));
     n_have = s.n_theta;
@@ -1040,8 +1052,13 @@ int scratch_for(int device, int32_t n_a, const nhip_search_t &s1, const nhip_sea
   return NHIP_OK;
 }
 
-// one pair (scan 0 of the scratch against slot 0 of `g`) on the null stream; the record comes back to the host
-int match_one(DropInScratch &S, nhip_grids_t *g, const nhip_search_t *search, const void *d_delta, double theta0,
+// One pair (scan 0 of the scratch against slot 0 of `g`) on the null stream; the record comes back to the host.
+// The branch-and-bound matcher computes a pair's bounds in the pair's ONE workgroup, eight rotations at a time: a search
+// of 21 rotations is three rounds on one CU while 255 idle.  So the rotations are dealt over `parts` workgroups -- to the
+// kernels they are `parts` pairs of the same scan and table whose rotation 0 is entry kbase of the rotation table
+// (BnbParams::pair_kbase) -- and the host takes the best of their records: the larger sum, on a tie the smaller index
+// ((k * nx + ix) * ny + iy with the part's rotations counted from the search's first), which is the one-workgroup result.
+int match_one(DropInScratch &S, int32_t n_a, nhip_grids_t *g, const nhip_search_t *search, const void *d_delta, double theta0,
               const int32_t *origin, nhip_match_t *m) {
   int rc = ensure_skip_maps(g, search);
   if (rc) return rc;
@@ -1050,18 +1067,68 @@ int match_one(DropInScratch &S, nhip_grids_t *g, const nhip_search_t *search, co
     std::lock_guard<std::mutex> lock(g->mu);
     spec_now = g->spec;
   }
-  double cs[2];
-  if ((rc = nhip_csm_rot0(&theta0, nullptr, 1, cs))) return rc;
-  NHIP_TRY_HIP(hipMemcpyAsync(S.rot0.p, cs, 16, hipMemcpyHostToDevice, nullptr));
-  if (origin) NHIP_TRY_HIP(hipMemcpyAsync(S.origin.p, origin, 8, hipMemcpyHostToDevice, nullptr));
-  rc = launch_csm_match(static_cast<const float *>(S.xy.p), static_cast<const int32_t *>(S.off.p),
+  // parts: the fewest (2 .. 8) that give every workgroup an odd number (the lattice's rule) of at most 8 rotations
+  int parts = 1, per = search->n_theta;
+  const char *one = tunable("NHIP_DROPIN_PARTS");  // (measurement: "1" keeps the search in one workgroup)
+  const int q0 = one && atoi(one) >= 2 ? atoi(one) : 2;  // (measurement: at least that many parts)
+  if (!csm_takes_exhaustive(g->L, search) && search->n_theta > 8 && !(one && one[0] == '1'))
+    for (int q = q0; q <= DROPIN_PARTS_MAX; q++) {
+      const int r = (search->n_theta + q - 1) / q;
+      if ((r & 1) && r <= 8) {
+        parts = q;
+        per = r;
+        break;
+      }
+    }
+  struct Par {
+    int32_t off[4];
+    double cs[2 * DROPIN_PARTS_MAX];
+    int32_t org[2 * DROPIN_PARTS_MAX], kb[DROPIN_PARTS_MAX];
+  } par;
+  static_assert(sizeof(Par) == 240 && offsetof(Par, cs) == 16 && offsetof(Par, org) == 144 && offsetof(Par, kb) == 208, "Par layout");
+  memset(&par, 0, sizeof(par));
+  par.off[1] = n_a;
+  if ((rc = nhip_csm_rot0(&theta0, nullptr, 1, par.cs))) return rc;
+  int32_t *kb = par.kb;
+  for (int q = 0; q < parts; q++) {
+    par.cs[2 * q] = par.cs[0];
+    par.cs[2 * q + 1] = par.cs[1];
+    par.org[2 * q] = origin ? origin[0] : 0;
+    par.org[2 * q + 1] = origin ? origin[1] : 0;
+    kb[q] = q * per;
+  }
+  NHIP_TRY_HIP(hipMemcpyAsync(S.par.p, &par, sizeof(par), hipMemcpyHostToDevice, nullptr));
+  uint8_t *dp = static_cast<uint8_t *>(S.par.p), *dr = static_cast<uint8_t *>(S.res.p);
+  nhip_search_t part = *search;
+  part.n_theta = per;
+  rc = launch_csm_match(static_cast<const float *>(S.xy.p), reinterpret_cast<const int32_t *>(dp),
                         static_cast<const uint8_t *>(g->grids.p), &spec_now, g->L, static_cast<const int32_t *>(S.idx.p),
-                        static_cast<const int32_t *>(S.idx.p) + 1, static_cast<const double *>(S.rot0.p),
-                        static_cast<const double *>(d_delta), origin ? static_cast<const int32_t *>(S.origin.p) : nullptr, 1,
-                        search, static_cast<uint64_t *>(S.keys.p), static_cast<nhip_match_t *>(S.out.p), nullptr, nullptr,
-                        S.ws.p, (int64_t)S.ws.bytes);
+                        static_cast<const int32_t *>(S.idx.p) + DROPIN_PARTS_MAX, reinterpret_cast<const double *>(dp + 16),
+                        static_cast<const double *>(d_delta), origin ? reinterpret_cast<const int32_t *>(dp + 144) : nullptr, parts,
+                        &part, static_cast<uint64_t *>(S.keys.p), reinterpret_cast<nhip_match_t *>(dr),
+                        reinterpret_cast<int32_t *>(dr + 128), nullptr, S.ws.p, (int64_t)S.ws.bytes,
+                        parts > 1 ? reinterpret_cast<const int32_t *>(dp + 208) : nullptr);
   if (rc) return rc;
-  NHIP_TRY_HIP(hipMemcpy(m, S.out.p, sizeof(nhip_match_t), hipMemcpyDeviceToHost));
+  struct Res {
+    nhip_match_t rec[DROPIN_PARTS_MAX];
+    int32_t sums[DROPIN_PARTS_MAX];
+  } res;
+  static_assert(sizeof(Res) == 160 && offsetof(Res, sums) == 128, "Res layout");
+  NHIP_TRY_HIP(hipMemcpy(&res, S.res.p, sizeof(res), hipMemcpyDeviceToHost));
+  nhip_match_t *rec = res.rec;
+  const int32_t *sums = res.sums;
+  int best = -1;
+  int64_t best_lin = 0;
+  for (int q = 0; q < parts; q++) {
+    // (a copy of the last rotation past the table's end IS the last rotation)
+    rec[q].itheta = std::min(rec[q].itheta + kb[q], search->n_theta - 1);
+    const int64_t lin = ((int64_t)rec[q].itheta * search->nx + rec[q].ix) * search->ny + rec[q].iy;
+    if (best < 0 || sums[q] > sums[best] || (sums[q] == sums[best] && lin < best_lin)) {
+      best = q;
+      best_lin = lin;
+    }
+  }
+  *m = rec[best];
   return NHIP_OK;
 }
 
@@ -1178,11 +1245,10 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
       //  The target's scan table must outlive the coarse match: matched here.)
       DropInScratch *S0 = nullptr;
       if ((rc = scratch_for(device, n_a, s1, s2, &S0))) { nhip_scans_free(bs); return rc; }
-      const int32_t offa[2] = {0, n_a};
-      hipError_t e = hipMemcpy(S0->off.p, offa, 8, hipMemcpyHostToDevice);
-      if (e == hipSuccess && n_a) e = hipMemcpy(S0->xy.p, pc_a, sizeof(float) * 2 * (size_t)n_a, hipMemcpyHostToDevice);
+      hipError_t e = hipSuccess;
+      if (n_a) e = hipMemcpy(S0->xy.p, pc_a, sizeof(float) * 2 * (size_t)n_a, hipMemcpyHostToDevice);
       if (e != hipSuccess) { nhip_scans_free(bs); return hip_fail(e, "csm_get_transformation upload", __FILE__, __LINE__); }
-      rc = match_one(*S0, T->g1, &s1, S0->delta1.p, theta0, nullptr, &m1);
+      rc = match_one(*S0, n_a, T->g1, &s1, S0->delta1.p, theta0, nullptr, &m1);
       if (rc == NHIP_OK) rc = nhip_match_to_transform(&m1, &spec1, &s1, theta0, 0, 0, &tx1, &ty1, &th1);
       if (rc) { nhip_scans_free(bs); return rc; }
       const int32_t origin[2] = {(int32_t)lround((double)tx1 / p->high_res), (int32_t)lround((double)ty1 / p->high_res)};
@@ -1193,7 +1259,7 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
       if (rc) return rc;
       nhip_match_t m2;
       const double theta1 = th1;
-      if ((rc = match_one(*S0, T->g2, &s2, S0->delta2.p, theta1, origin, &m2))) return rc;
+      if ((rc = match_one(*S0, n_a, T->g2, &s2, S0->delta2.p, theta1, origin, &m2))) return rc;
       if ((rc = nhip_match_to_transform(&m2, &T->spec2, &s2, theta1, origin[0], origin[1], tx, ty, theta))) return rc;
       *score = (double)m2.score;
       return NHIP_OK;
@@ -1219,17 +1285,15 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   // ---- the two searches of this source against the target's tables
   DropInScratch *S = nullptr;
   if ((rc = scratch_for(device, n_a, s1, s2, &S))) return rc;
-  const int32_t offa[2] = {0, n_a};
-  NHIP_TRY_HIP(hipMemcpyAsync(S->off.p, offa, 8, hipMemcpyHostToDevice, nullptr));
   if (n_a) NHIP_TRY_HIP(hipMemcpyAsync(S->xy.p, pc_a, sizeof(float) * 2 * (size_t)n_a, hipMemcpyHostToDevice, nullptr));
-  if ((rc = match_one(*S, T->g1, &s1, S->delta1.p, theta0, nullptr, &m1))) return rc;
+  if ((rc = match_one(*S, n_a, T->g1, &s1, S->delta1.p, theta0, nullptr, &m1))) return rc;
   if ((rc = nhip_match_to_transform(&m1, &spec1, &s1, theta0, 0, 0, &tx1, &ty1, &th1))) return rc;
   const int32_t origin[2] = {(int32_t)lround((double)tx1 / p->high_res), (int32_t)lround((double)ty1 / p->high_res)};
   NHIP_REQUIRE(std::max(abs(origin[0]), abs(origin[1])) + ratio <= reach_max, "csm_get_transformation: coarse optimum (%d, %d) beyond "
                "the fine tables' reach %d", origin[0], origin[1], reach_max);
   const double theta1 = th1;
   nhip_match_t m2;
-  if ((rc = match_one(*S, T->g2, &s2, S->delta2.p, theta1, origin, &m2))) return rc;
+  if ((rc = match_one(*S, n_a, T->g2, &s2, S->delta2.p, theta1, origin, &m2))) return rc;
   if ((rc = nhip_match_to_transform(&m2, &T->spec2, &s2, theta1, origin[0], origin[1], tx, ty, theta))) return rc;
   *score = (double)m2.score;
   return NHIP_OK;

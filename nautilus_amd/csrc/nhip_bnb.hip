@@ -1323,7 +1323,8 @@ __device__ __forceinline__ uint32_t refine16(const BnbParams &P, __amdgpu_buffer
 __device__ __forceinline__ void rotation_k(const BnbParams &P, int32_t pair, int32_t k, float *cf, float *sf) {
   // R(theta0) * R(delta_k), composed in double with individually rounded ops (as csm_correlate_kernel)
   const double c0 = P.rot0_cs[2 * pair], s0 = P.rot0_cs[2 * pair + 1];
-  const double cd = P.delta_cs[2 * k], sd = P.delta_cs[2 * k + 1];
+  const int32_t kd = k + (P.pair_kbase ? P.pair_kbase[pair] : 0);  // (the pair's rotation k is entry kbase + k of the table)
+  const double cd = P.delta_cs[2 * kd], sd = P.delta_cs[2 * kd + 1];
   *cf = __double2float_rn(__dsub_rn(__dmul_rn(c0, cd), __dmul_rn(s0, sd)));
   *sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
 }
@@ -2368,7 +2369,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
                    const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                    const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
                    uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled,
-                   void *d_workspace, int64_t workspace_bytes) {
+                   void *d_workspace, int64_t workspace_bytes, const int32_t *d_pair_kbase) {
   *handled = 0;
   if (!bnb_fits(L, search)) return NHIP_OK;
   *handled = 1;
@@ -2383,6 +2384,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.rot0_cs = d_rot0_cs;
   P.delta_cs = d_delta_cs;
   P.pair_origin = d_pair_origin;
+  P.pair_kbase = d_pair_kbase;
   P.keys = reinterpret_cast<unsigned long long *>(d_keys);
   P.n_pairs = n_pairs;
   P.n_theta = search->n_theta;

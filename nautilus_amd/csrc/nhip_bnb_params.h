@@ -21,6 +21,8 @@ struct BnbParams {
   const double *rot0_cs;
   const double *delta_cs;
   const int32_t *pair_origin;
+  const int32_t *pair_kbase;  // optional: entry of delta_cs that is pair i's rotation 0 (a search's rotations dealt over
+                              // several "pairs" = workgroups: nhip_csm_get_transformation's fine level); null = 0
   unsigned long long *keys;
   unsigned long long *timeline;  // optional (NHIP_BNB_TIMELINE=1): per pair 4 x 100 MHz ticks: start, bounds, seeds, end
   unsigned long long *stats;  // optional: [0] blocks evaluated whole, [1] blocks in all, [2] candidates refined,

@@ -140,7 +140,7 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
                      uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s,
-                     void *d_workspace = nullptr, int64_t workspace_bytes = 0);
+                     void *d_workspace = nullptr, int64_t workspace_bytes = 0, const int32_t *d_pair_kbase = nullptr);
 
 // branch-and-bound matcher (nhip_bnb.hip); returns NHIP_ERR_STATE-free: `*handled` = 0 when the lattice does not fit it
 int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
@@ -148,7 +148,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
                    const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                    const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
                    uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled,
-                   void *d_workspace = nullptr, int64_t workspace_bytes = 0);
+                   void *d_workspace = nullptr, int64_t workspace_bytes = 0, const int32_t *d_pair_kbase = nullptr);
 int64_t bnb_workspace_bytes(int32_t n_pairs);
 int64_t bnb_workspace_bytes_lists(int32_t n_pairs);
 void bnb_last_launch(int32_t out[8]);
@@ -176,6 +176,13 @@ int launch_csm16_scores(const float *d_xy, const int32_t *d_offsets, const uint8
                         const nhip_grid_spec_t *spec, const GridLayout &L, int32_t src, int32_t slot,
                         const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x, int32_t origin_y,
                         const nhip_search_t *search, int32_t *d_sums, hipStream_t s);
+// every add for lattices of few translations (nx * ny <= 256), both cell widths (nhip_csm_small.hip)
+bool csm_small_plane_fits(const nhip_search_t *search);
+int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+                           const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
+                           const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
+                           const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
+                           uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s);
 // skip maps of n finished 16-bit grids (the handle API's late build; occupancy unknown: every map tile is computed)
 int launch_skipmap_build(uint8_t *d_grids, int32_t n_grids, const GridLayout &L, hipStream_t s);
 // true when a search on these grids takes the kernel that performs every add

@@ -467,17 +467,27 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
                      uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s,
-                     void *d_workspace, int64_t workspace_bytes) {
+                     void *d_workspace, int64_t workspace_bytes, const int32_t *d_pair_kbase) {
   const bool exhaustive = csm_takes_exhaustive(L, search);
+  // (per-pair offsets into the rotation table are the branch-and-bound matcher's: an internal caller that passes them has
+  //  made sure the lattice is one it takes)
+  NHIP_REQUIRE(!d_pair_kbase || !exhaustive, "csm_match: rotation offsets per pair with a lattice the matcher does not take");
   int rc = check_search(spec, L, search, exhaustive);
   if (rc) return rc;
   if (n_pairs == 0) return NHIP_OK;
   if (!exhaustive) {  // branch and bound: the same records, most adds never performed (nhip_bnb.hip)
     int handled = 0;
     rc = launch_csm_bnb(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
-                        d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s, &handled, d_workspace, workspace_bytes);
+                        d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s, &handled, d_workspace, workspace_bytes,
+                        d_pair_kbase);
     if (rc || handled) return rc;
   }
+  // planes of few translations (the coarse level of GetTransformation: 13 x 13): the kernel whose lanes are poses
+  // (NHIP_CSM_SMALL=0, measurement / tests: the strip kernels below for these lattices too)
+  const char *sm = tunable("NHIP_CSM_SMALL");
+  if (csm_small_plane_fits(search) && !(sm && sm[0] == '0'))
+    return launch_csm_small_match(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
+                                  d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s);
   if (L.cb == 2)
     return launch_csm16_match(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
                               d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s);

@@ -60,6 +60,15 @@ def _check_pairs(scans_list, target_ids, pair_src, pair_slot, theta0, spec, ospe
     finally:
         os.environ.pop("NHIP_CSM_DENSE", None)
     assert got_d.tobytes() == got.tobytes() and np.array_equal(sums_d, sums)
+    if search.nx * search.ny <= 256:
+        # lattices of few translations take the kernel whose lanes are poses (nhip_csm_small.hip) when every add is asked
+        # for; NHIP_CSM_SMALL=0 sends them through the strip kernels like any other lattice
+        os.environ["NHIP_CSM_SMALL"] = "0"
+        try:
+            got_s, sums_s = csm.match_pairs(st, grids, pair_src, pair_slot, theta0, ex, origin)
+        finally:
+            os.environ.pop("NHIP_CSM_SMALL", None)
+        assert got_s.tobytes() == got.tobytes() and np.array_equal(sums_s, sums)
     ogr = O.grid_build_batch(xy, off, target_ids, ospec)
     oss = O.search_spec(search.n_theta, search.nx, search.ny, search.theta_step)
     want = O.csm_match_batch(xy, off, ogr, ospec, pair_src, pair_slot, theta0, oss, origin)
@@ -265,6 +274,27 @@ def test_long_clouds_cross_staging_batches(gpu, small_bag):
     got, want = _check_pairs([long_a, long_b, small_bag.scans[3]], [0, 1, 2], [0, 1, 0, 1, 2], [2, 2, 1, 0, 1],
                              [0.0, 0.05, -0.04, 0.1, 0.0], spec, ospec, csm.search_spec(7, 25, 25, DEG))
     assert want["sum"].max() > 255 * 1152  # sums beyond what a single unpack interval could hold
+
+
+@pytest.mark.parametrize("cell_bits", [16, 8])
+def test_small_plane_kernel(gpu, small_bag, cell_bits):
+    """Every add on lattices of few translations (csm_small_plane_kernel: lanes are poses, up to 256 of them): the coarse
+    lattice of the drop-in call (181 x 13 x 13), one pose, 255 poses, planes wider than tall and taller than wide; scans of
+    1 to 3,243 points incl. an empty one and a non-finite point, search centres off the middle -- against the oracle, the
+    branch-and-bound matcher and the strip kernels (_check_pairs runs all of them)."""
+    long_a = np.concatenate([small_bag.scans[3], small_bag.scans[4] + np.float32(0.02), small_bag.scans[5]])
+    odd = small_bag.scans[9].copy()
+    odd[7] = (np.float32(np.nan), np.float32(1.0))
+    odd[11] = (np.float32(np.inf), np.float32(-2.0))
+    scans = [small_bag.scans[6], long_a, small_bag.scans[7][:1], np.zeros((0, 2), np.float32), odd, small_bag.scans[8]]
+    src, slot = [0, 1, 2, 3, 4, 5, 0], [1, 0, 1, 0, 0, 0, 0]
+    th0 = [0.02, -0.05, 0.3, 0.0, 0.07, -0.01, 3.1]
+    spec, ospec = _specs(max_shift=14, cell_bits=cell_bits)
+    for lat in ((181, 13, 13), (3, 1, 1), (5, 15, 17), (7, 3, 25), (9, 25, 5), (1, 13, 19)):
+        _check_pairs(scans, [0, 1], src, slot, th0, spec, ospec, csm.search_spec(lat[0], lat[1], lat[2], DEG))
+    # search centres off the middle (the fine level of a two-level search)
+    org = [[3, -2], [0, 0], [-5, 4], [1, 1], [0, -6], [2, 2], [-1, 0]]
+    _check_pairs(scans, [0, 1], src, slot, th0, spec, ospec, csm.search_spec(21, 13, 13, DEG / 10), origin=org)
 
 
 def test_scan_lengths_around_the_held_origins(gpu, small_bag):
