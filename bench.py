@@ -49,8 +49,8 @@ LDS_READ_PEAK_TBS = 75.0       # ds_read_b32: 128 B/clk/CU
 def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--mode", choices=["weak", "config4"], default=None,
                     help="default: one GPU runs BASELINE configs[1] (`weak` with one rank IS that config); --gpus N > 1 runs "
                          "BASELINE configs[3], ONE list of 10,000 scans / 1,000,000 pairs sharded over the N ranks (config4, "
