@@ -13,7 +13,7 @@ build() {
   name=$1; shift
   /opt/rocm/bin/hipcc $FLAGS $@ -c nhip_bnb.hip -o $OUT/bnb_$name.o
   /opt/rocm/bin/hipcc $FLAGS $@ -c nhip_bnb_instr.hip -o $OUT/bnbi_$name.o
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libbnb_$name.so nhip_api.o nhip_grid.o nhip_csm.o nhip_csm16.o $OUT/bnb_$name.o $OUT/bnbi_$name.o nhip_lc.o nhip_resid.o nhip_corr.o -ldl
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $OUT/libbnb_$name.so nhip_api.o nhip_grid.o nhip_csm.o nhip_csm16.o nhip_csm_small.o $OUT/bnb_$name.o $OUT/bnbi_$name.o nhip_lc.o nhip_resid.o nhip_corr.o -ldl
   rm -f $OUT/bnb_$name.o $OUT/bnbi_$name.o
 }
 while [ $# -gt 0 ]; do
