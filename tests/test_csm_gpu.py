@@ -613,6 +613,23 @@ def test_drop_in_cache_serves_repeated_targets(gpu, small_bag):
     assert csm.drop_in_cache_stats()["entries"] == 0
 
 
+def test_drop_in_flat_landscape_first_pose_wins_across_the_parts(gpu, small_bag):
+    """A source that scores nothing anywhere (every point beyond the table): every pose of both levels sums to 0 and the
+    FIRST pose of each lattice is the answer -- also across the three workgroups the fine level's rotations are dealt over
+    (their records tie; the host takes the smaller index), and through the small-plane kernel of the coarse level."""
+    far = (small_bag.scans[17][::3] + np.float32(500.0)).astype(np.float32)
+    b = small_bag.scans[15][::3]
+    m = csm.CorrelativeScanMatcher(30, 2, 0.3, 0.01)
+    got = m.GetTransformation(far, b, 0.3, 0.1, math.radians(90))
+    want = O.two_level_match(far, b, 0.3, 0.1, math.radians(90), 30.0, 2.0, 0.3, 0.01, cell_bits=16)
+    assert got[0] == want[0] and got[1][0][0] == want[1][0][0] and got[1][0][1] == want[1][0][1] and got[1][1] == want[1][1]
+    assert got[0] == pytest.approx(math.log(1e-10))          # the floor: nothing scored
+    # an empty source: the same
+    e = m.GetTransformation(np.zeros((0, 2), np.float32), b, 0.3, 0.1, math.radians(90))
+    we = O.two_level_match(np.zeros((0, 2), np.float32), b, 0.3, 0.1, math.radians(90), 30.0, 2.0, 0.3, 0.01, cell_bits=16)
+    assert e[0] == we[0] and e[1][0][0] == we[1][0][0] and e[1][0][1] == we[1][0][1] and e[1][1] == we[1][1]
+
+
 def test_device_pointer_api_on_torch_stream(gpu, small_bag):
     """The *_dev entry points: caller-owned HBM (torch tensors), launched on torch's stream."""
     import torch
