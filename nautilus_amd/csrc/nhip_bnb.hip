@@ -84,6 +84,12 @@
 #ifndef NHIP_BNB_FRACT_NEAR
 #define NHIP_BNB_FRACT_NEAR 0  // 1: the origins' near-an-integer test on v_fract_f32 (fewer instructions per coordinate)
 #endif
+#ifndef NHIP_BNB_LEAN_ORIGINS
+#define NHIP_BNB_LEAN_ORIGINS 1  // window origins: non-finite points leave through the rare path, one constant per coordinate (0: round 3's form)
+#endif
+#ifndef NHIP_BNB_POS_RUNS
+#define NHIP_BNB_POS_RUNS 1  // bounds' run lists: an entry carries its first point's index, the gather takes the length from the next entry (0: lengths at the heads)
+#endif
 #if NHIP_BNB_INSTR
 #define csm_bnb_kernel csm_bnb_kernel_instr          // (their own names in profiles)
 #define csm_bnb_rot_kernel csm_bnb_rot_kernel_instr
@@ -109,6 +115,17 @@ using namespace bnb;
 
 constexpr int BNB_WAVES = 8;
 constexpr int BNB_THREADS = 64 * BNB_WAVES;
+// Waves per workgroup of the split form's first kernel (bounds + seeds); measurement.  What bounds that kernel is the
+// latency of a wave's own instruction chain more than issue slots: with ONE workgroup per CU (two waves per SIMD;
+// NHIP_BNB_LDS_PAD=12000) it takes 1.63x the time of two.  Five waves per SIMD would need workgroups of ten waves at 96
+// registers; built (=10: same records) and twice as slow -- ten waves spread 3 + 3 + 2 + 2 over the SIMDs, a second
+// workgroup's would make six on two of them, which 96 registers do not allow, so ONE workgroup was resident per CU.
+// Twelve waves need 80 registers, a third workgroup of eight also 53 KB of LDS.  Seeds are evaluated by at most eight waves.
+#ifndef NHIP_BNB_SPLIT_WAVES
+#define NHIP_BNB_SPLIT_WAVES 8
+#endif
+constexpr int SPLIT_WAVES = NHIP_BNB_SPLIT_WAVES;
+static_assert(SPLIT_WAVES >= 8 && SPLIT_WAVES <= 16, "workgroups of 512 to 1024 threads");
 constexpr int NB = BNB_MAX_NB;        // blocks per axis held in registers (11: nx, ny <= 88)
 constexpr int SEG_CHUNKS = 32;        // 64-point chunks between reductions: 32 * 255 * 8 lanes < 65536 (16-bit fields); even
 #ifndef NHIP_BNB_EVAL_CHUNKS
@@ -143,12 +160,15 @@ __device__ __forceinline__ __attribute__((unused)) int32_t cell_floor(float v, c
 
 // Window origin (stored-grid row, column of the top-left lookup cell) of point q under rotation (cf, sf): the
 // same arithmetic as window_cell of nhip_csm.hip (spec: DESIGN.md section 3, items 1 and 3).
+// LEAN (the bounds phase): see below; the candidates' kernels keep round 3's form -- the lean one costs the candidates'
+// kernel of 16-bit grids, at its 96 registers, seven spilled dwords and 0.07 ms.
+template <bool LEAN = false>
 __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, const BnbParams &P, int32_t cx, int32_t cy,
                                               int32_t *prow, int32_t *pcol) {
   const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
   const float yr = __fadd_rn(__fmul_rn(sf, q.x), __fmul_rn(cf, q.y));
   const int32_t half = P.S / 2;
-  const bool finite = (fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f);
+  const bool finite __attribute__((unused)) = (fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f);
   int32_t ix, iy;
 #if NHIP_BNB_F32_ORIGINS && NHIP_BNB_WAVE_SLOW_PATH
   // cell_floor of both coordinates with ONE test for the rare path, taken by the wave only if some lane needs it
@@ -157,6 +177,38 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
   // the double-precision path then takes like any other.
   const float mx = __fmul_rn(xr, P.inv_res_f), my = __fmul_rn(yr, P.inv_res_f);
   const float fx = floorf(mx), fy = floorf(my);
+#if NHIP_BNB_LEAN_ORIGINS
+  if (LEAN) {
+  // The same test written so that it also holds for what is not a number: !(min(r, 1 - r) > tol) is true for NaN (an
+  // infinite quotient: inf - inf), and every |v| >= 1e9 has |m| >= 2^22 at any cell size below 238 m, i.e. r == 0.  So
+  // the points the spec calls non-finite all take the rare path, which gives them the floor that clamps to the window
+  // position of a point that scores nothing (column -hx - 1, row -hy - 1: the lower clamp bounds), and the straight-line
+  // code needs neither the two magnitude compares nor the selects -- one constant per coordinate after the clamp.
+  {
+    const float rx = __fsub_rn(mx, fx), ry = __fsub_rn(my, fy);  // exact
+    const bool slow = !(fminf(rx, __fsub_rn(1.0f, rx)) > __fmul_rn(fabsf(mx), 0x1p-22f)) ||
+                      !(fminf(ry, __fsub_rn(1.0f, ry)) > __fmul_rn(fabsf(my), 0x1p-22f));
+    ix = (int32_t)fx;
+    iy = (int32_t)fy;
+    if (__builtin_amdgcn_ballot_w64(slow) != 0ull) {
+      if (slow) {
+        // (the magnitude test on the promoted values -- 1e9 is a float -- so that it stays on this path)
+        const double xd = (double)xr, yd = (double)yr;
+        const bool fin = (fabs(xd) < 1e9) && (fabs(yd) < 1e9);
+        ix = (int32_t)fmin(fmax(floor_quotient(xd, P.res, P.inv_res), -2147483000.0), 2147483000.0);
+        iy = (int32_t)fmin(fmax(floor_quotient(yd, P.res, P.inv_res), -2147483000.0), 2147483000.0);
+        if (!fin) ix = iy = -2147483000;
+      }
+    }
+    const int32_t lo_x = -P.hx - 1 - half - cx, lo_y = -P.hy - 1 - half - cy;
+    ix = min(max(ix, lo_x), P.S + P.hx - half - cx);
+    iy = min(max(iy, lo_y), P.S + P.hy - half - cy);
+    *pcol = ix + (half + cx - P.hx + P.pad);
+    *prow = iy + (half + cy - P.hy + P.pad);
+    return;
+  }
+  }
+#endif
 #if NHIP_BNB_FRACT_NEAR
   // near an integer <=> |fract(m) - 1/2| >= 1/2 - tol.  v_fract_f32 is m - floor(m) exactly for the finite |m| < 2^22 that
   // matter (larger ones take the double-precision path through the second term: their tolerance exceeds 1/2)
@@ -334,6 +386,7 @@ constexpr uint32_t LANE_WEIGHT = 64u;
 constexpr int RUN_SHIFT = 25;     // entry = pooled offset | (run length - 1) << RUN_SHIFT
 constexpr int LIST_ENTRIES = 128; // ring of pending entries per wave (a chunk appends <= 64, 64 are consumed at a time)
 static_assert(RUN_MAX == 8 || RUN_MAX == 16 || RUN_MAX == 64, "runs are cut at DPP row or chunk boundaries");
+static_assert(!NHIP_BNB_POS_RUNS || RUN_MAX == 64, "the position form of the run lists cuts runs at chunk boundaries only");
 
 template <bool POOL_LDS>
 __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_t *pool, __amdgpu_buffer_rsrc_t prs,
@@ -425,31 +478,11 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
       for (int d = 0; d < 3; d++) E[y][d] = O[y][d] = 0u;
   };
 
-  // (the points of the next PD chunks are in flight while one chunk is worked: with two workgroups per CU gathering
-  //  from their grids, a point load takes ~1,300 clocks, more than a chunk's work)
-  constexpr int PD = NHIP_BNB_P1_PREFETCH;
-  float2 qn[PD];
-#pragma unroll
-  for (int d = 0; d < PD; d++) qn[d] = 64 * d + lane < n_pts ? pts[64 * d + lane] : make_float2(0.f, 0.f);
-  for (int32_t c = 0;; c += 64) {
-    if (BNB_DEBUG(P) == 30) break;  // (timing experiment: no chunk loop at all)
-    const bool more = c < n_pts;  // (one more turn after the last chunk drains the list)
+  // One chunk's pooled offsets `a` (point c + lane; lanes past the scan's end carry the zero rows) into the run list,
+  // then the gather passes that have become due.  more == false: no chunk, the list is drained and reduced.
+  auto feed = [&](uint32_t a, int32_t c, bool more) {
     if (more) {
-      const float2 pt = qn[0];
-#pragma unroll
-      for (int d = 0; d < PD - 1; d++) qn[d] = qn[d + 1];
-      if (c + 64 * PD + lane < n_pts) qn[PD - 1] = pts[c + 64 * PD + lane];
       const bool live = c + lane < n_pts;
-      uint32_t a = zero_a;
-      if (live && BNB_DEBUG(P) != 29) {  // (timing experiments 28 / 29: without the run lists / without the origins too)
-        int32_t prow, pcol;
-        window_origin(pt, cf, sf, P, cx, cy, &prow, &pcol);
-        a = (uint32_t)((prow >> 3) * DP + (pcol >> 3));
-      }
-      if (BNB_DEBUG(P) >= 28 && BNB_DEBUG(P) <= 29) {
-        tot[0] += a;
-        continue;
-      }
       // runs of equal offsets inside groups of RUN_MAX lanes: the predecessor's offset by a DPP shift (inside the row
       // of 16 lanes, or -- RUN_MAX 64 -- across the wave), no LDS round trip; a group's first lane is a head anyway
 #if !NHIP_BNB_RS_DPP
@@ -465,7 +498,13 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
       const unsigned long long H = __builtin_amdgcn_uicmp(a, prev, 33 /* ne */) | GROUP_HEADS;
       // run length = distance to the next head of the lane's group (or to the group's end)
       uint32_t cnt;
-      if (RUN_MAX == 64) {
+      if (NHIP_BNB_POS_RUNS) {
+        // (position form: the entry carries its first point's index modulo 128; the gather subtracts it from the next
+        //  entry's -- one more LDS read per 64 entries instead of two 64-bit shifts, a compare and two bit searches per
+        //  64 points.  The last run ends at the sentinel entry written after the last chunk.)
+        cnt = (uint32_t)(c + lane) & 127u;
+        cnt += 1u;  // (stored as cnt - 1 below)
+      } else if (RUN_MAX == 64) {
         const unsigned long long rest = (H >> lane) >> 1;
         cnt = rest ? (uint32_t)__builtin_ctzll(rest) + 1u : (uint32_t)(64 - lane);
       } else {
@@ -484,16 +523,31 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    // gather passes: whenever 64 entries are pending, and to the last entry once the scan is through; then one more
-    // turn for the rotation's (only, as a rule) reduction -- one copy of that code
+    if (NHIP_BNB_POS_RUNS && !more) {
+      // the sentinel: where the last run ends.  (At most 64 entries are pending here -- the last chunk's turn drained
+      // the list below 65 -- so the slot is free.)
+      if (lane == 0) list[tail & (LIST_ENTRIES - 1)] = ((uint32_t)n_pts & 127u) << RUN_SHIFT;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    }
+    // gather passes: whenever 64 entries are pending (position form: and the one after them, which ends the 64th's run),
+    // and to the last entry once the scan is through; then one more turn for the rotation's (only, as a rule)
+    // reduction -- one copy of that code
     for (;;) {
       const uint32_t avail = tail - head;
-      if (avail < 64u && more) break;
+      if (avail < (NHIP_BNB_POS_RUNS ? 65u : 64u) && more) break;
       const bool last = avail == 0u;  // (!more)
       // (lanes past the list gather the zero rows with length 0)
       const bool mine = (uint32_t)lane < avail;
       const uint32_t entry = mine ? list[(head + (uint32_t)lane) & (LIST_ENTRIES - 1)] : zero_a;
-      const uint32_t a = entry & ((1u << RUN_SHIFT) - 1u), cnt = mine ? (entry >> RUN_SHIFT) + 1u : 0u;
+      const uint32_t ea = entry & ((1u << RUN_SHIFT) - 1u);
+      uint32_t cnt;
+      if (NHIP_BNB_POS_RUNS) {
+        const uint32_t next = mine ? list[(head + (uint32_t)lane + 1u) & (LIST_ENTRIES - 1)] : 0u;
+        cnt = mine ? ((next >> RUN_SHIFT) - (entry >> RUN_SHIFT)) & 127u : 0u;
+      } else {
+        cnt = mine ? (entry >> RUN_SHIFT) + 1u : 0u;
+      }
       // (also before a pass that could overflow some lane's fields)
       if (pending && (last || __ballot(weight + cnt > LANE_WEIGHT) != 0ull) && BNB_DEBUG(P) != 26) {
         reduce();
@@ -501,12 +555,48 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
         weight = 0u;
       }
       if (last) break;
-      if (BNB_DEBUG(P) != 27) gather(a, cnt);
+      if (BNB_DEBUG(P) != 27) gather(ea, cnt);
       weight += cnt;
       pending = true;
       head += avail < 64u ? avail : 64u;
       __builtin_amdgcn_wave_barrier();
     }
+  };
+
+  // (Tried: the window origins of TWO chunks per turn in one basic block, so that the scheduler interleaves the two
+  //  chains -- bounds + seeds 3.18 -> 3.23 ms, profiles/r04_bounds_variants.txt: the chains' latency is hidden already.)
+  // (the points of the next PD chunks are in flight while one chunk is worked: with two workgroups per CU gathering
+  //  from their grids, a point load takes ~1,300 clocks, more than a chunk's work)
+  constexpr int PD = NHIP_BNB_P1_PREFETCH;
+  float2 qn[PD];
+#pragma unroll
+  for (int d = 0; d < PD; d++) qn[d] = 64 * d + lane < n_pts ? pts[64 * d + lane] : make_float2(0.f, 0.f);
+  for (int32_t c = 0;; c += 64) {
+    if (BNB_DEBUG(P) == 30) break;  // (timing experiment: no chunk loop at all)
+    const bool more = c < n_pts;  // (one more turn after the last chunk drains the list)
+    uint32_t a = zero_a;
+    if (more) {
+      const float2 pt = qn[0];
+#pragma unroll
+      for (int d = 0; d < PD - 1; d++) qn[d] = qn[d + 1];
+      if (c + 64 * PD + lane < n_pts) qn[PD - 1] = pts[c + 64 * PD + lane];
+      const bool live = c + lane < n_pts;
+      if (live && BNB_DEBUG(P) != 29) {  // (timing experiments 28 / 29: without the run lists / without the origins too)
+        int32_t prow, pcol;
+        window_origin<true>(pt, cf, sf, P, cx, cy, &prow, &pcol);
+#if NHIP_BNB_LEAN_ORIGINS
+        // (both factors are below 2^12: rows and pitch of the pooled image; the padding keeps prow positive)
+        a = __umul24((uint32_t)prow >> 3, (uint32_t)DP) + ((uint32_t)pcol >> 3);
+#else
+        a = (uint32_t)((prow >> 3) * DP + (pcol >> 3));
+#endif
+      }
+      if (BNB_DEBUG(P) >= 28 && BNB_DEBUG(P) <= 29) {
+        tot[0] += a;
+        continue;
+      }
+    }
+    feed(a, c, more);
     if (!more) break;
   }
 }
@@ -1524,15 +1614,20 @@ __device__ __forceinline__ void pair_context(const BnbParams &P, int32_t pair, P
 // Both are launched; a workgroup whose pair belongs to the other one returns at once.
 // SPLIT (by-rotation form only): the workgroup ends after the seeds and leaves its state in P.ps_* for
 // csm_bnb_cand_kernel.
+// (words of 8 bytes behind the rows of bounds: the candidate queue -- or, in the split form, which has no queue, the
+//  run lists of its ten waves and the rotations' order)
+constexpr int QSPACE_SPLIT = (SPLIT_WAVES * LIST_ENTRIES * 4 + MAX_ROT * 12 + 15) / 16 * 2;
 template <int CB, bool POOL_LDS, bool BY_ROT, bool SPLIT = false>
-__global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
+__global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT && SPLIT_WAVES > 8 ? 5 : 4) void csm_bnb_kernel(BnbParams P) {
+  constexpr int WAVES = SPLIT ? SPLIT_WAVES : BNB_WAVES, THREADS = 64 * WAVES;
+  constexpr int QSPACE = SPLIT ? QSPACE_SPLIT : QCAP;
   extern __shared__ __align__(16) uint8_t smem[];
   // first region: the pooled table (POOL_LDS) while the bounds are computed, then the waves' window origins
   uint8_t *s_pool = smem;
   uint32_t *s_org = reinterpret_cast<uint32_t *>(smem);
   uint32_t *s_U = reinterpret_cast<uint32_t *>(smem + P.lds_first);  // n_theta * 128
-  unsigned long long *s_queue = reinterpret_cast<unsigned long long *>(s_U + (size_t)P.n_theta * 128);  // QCAP
-  unsigned long long *s_best = s_queue + QCAP;
+  unsigned long long *s_queue = reinterpret_cast<unsigned long long *>(s_U + (size_t)P.n_theta * 128);  // QSPACE
+  unsigned long long *s_best = s_queue + QSPACE;
   uint32_t *s_cnt = reinterpret_cast<uint32_t *>(s_best + 1);
   uint32_t *s_qn = s_cnt + 1, *s_qhead = s_cnt + 2;
   unsigned long long *s_slow = s_best + 4;  // (stats: the slowest wave's time in the candidate phase)
@@ -1540,9 +1635,10 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   uint32_t *s_list = reinterpret_cast<uint32_t *>(s_queue);
   static_assert(BNB_WAVES * LIST_ENTRIES * 4 <= QCAP * 4, "the run lists fit the first half of the queue");
   // by-rotation kernel: per rotation its highest bound (<< 32 | k), and the rotations in descending order of it,
-  // in the second half of the queue's space (n_theta <= MAX_ROT)
-  unsigned long long *s_kmax = s_queue + QCAP / 2;
+  // behind the run lists (n_theta <= MAX_ROT): the second half of the queue's space
+  unsigned long long *s_kmax = s_queue + (SPLIT ? WAVES * LIST_ENTRIES / 2 : QCAP / 2);
   uint32_t *s_order = reinterpret_cast<uint32_t *>(s_kmax + MAX_ROT);
+  static_assert(SPLIT_WAVES * LIST_ENTRIES * 4 + MAX_ROT * 12 <= QSPACE_SPLIT * 8 && MAX_ROT * 12 <= QCAP * 4, "lists, maxima and order fit");
 
   // block -> pair: the pairs of one target are consecutive; keep them on one XCD (blocks b and b + 8 share one)
   const uint32_t bid = blockIdx.x;
@@ -1583,13 +1679,13 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     uint4 *sp = reinterpret_cast<uint4 *>(s_pool);
     // (four loads in flight per thread: 35 KB are 4.4 rounds of 512 threads, and a round trip each was 10 % of the pair)
     const int32_t n16 = (int32_t)(P.pool_bytes / 16);
-    for (int32_t i = threadIdx.x; i < n16; i += 4 * BNB_THREADS) {
+    for (int32_t i = threadIdx.x; i < n16; i += 4 * THREADS) {
       uint4 v[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = gp[min(i + j * BNB_THREADS, n16 - 1)];
+      for (int j = 0; j < 4; j++) v[j] = gp[min(i + j * THREADS, n16 - 1)];
 #pragma unroll
       for (int j = 0; j < 4; j++)
-        if (i + j * BNB_THREADS < n16) sp[i + j * BNB_THREADS] = v[j];
+        if (i + j * THREADS < n16) sp[i + j * THREADS] = v[j];
     }
   }
   const __amdgpu_buffer_rsrc_t prs = uniform_rsrc(grid + P.grid_bytes + P.skip_bytes, P.pool_bytes);
@@ -1598,7 +1694,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
   // (1) bounds of every block of every rotation this wave owns; the wave's own best bound
   const uint32_t scale = CB == 1 ? 1u : 257u;
   unsigned long long wbest = 0ull;  // (U << 32) | (k << 8 | slot)
-  for (int32_t k = wave; k < P.n_theta && BNB_DEBUG(P) != 31; k += BNB_WAVES) {
+  for (int32_t k = wave; k < P.n_theta && BNB_DEBUG(P) != 31; k += WAVES) {
     float cf, sf;
     rotation_k(P, pair, k, &cf, &sf);
     uint32_t tot[2];
@@ -1650,13 +1746,17 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
     unsigned long long *s_wbest = reinterpret_cast<unsigned long long *>(s_list + wave * LIST_ENTRIES);
     if (wave_leader(lane)) *s_wbest = wbest;
     __syncthreads();
-    if (P.seeds < BNB_WAVES) {
+    // (the origins' space holds eight waves' lists: of more waves at most eight evaluate a seed, and a seed's wave
+    //  takes the list of its rank among them)
+    uint32_t org_slot = (uint32_t)wave;
+    if (P.seeds < WAVES || WAVES > BNB_WAVES) {
       uint32_t above = 0u;
-      for (int w = 0; w < BNB_WAVES; w++)
+      for (int w = 0; w < WAVES; w++)
         above += *reinterpret_cast<unsigned long long *>(s_list + w * LIST_ENTRIES) > wbest ? 1u : 0u;
-      if (above >= P.seeds) wbest = 0ull;  // (this wave sits the seeds out)
+      if (above >= (P.seeds < (uint32_t)BNB_WAVES ? P.seeds : (uint32_t)BNB_WAVES)) wbest = 0ull;  // (this wave sits the seeds out)
+      if (WAVES > BNB_WAVES) org_slot = above < (uint32_t)BNB_WAVES ? above : 0u;
     }
-    uint32_t *org = s_org + wave * ORG_WAVE + lane;
+    uint32_t *org = s_org + org_slot * ORG_WAVE + lane;
     // (NHIP_BNB_STATS=1: shader-clock sums -- wave time in phase 3 by part, and the workgroup's wall time)
     PhaseClocks clk = {0, 0, 0};
     long long t_busy = 0, t_wall = 0;
@@ -1737,7 +1837,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
           t_wall = wall_clock64();
         }
         // best first: the rotations in descending order of their highest bound (rank by counting: n_theta^2 compares)
-        for (int32_t kk = threadIdx.x; kk < P.n_theta; kk += BNB_THREADS) {
+        for (int32_t kk = threadIdx.x; kk < P.n_theta; kk += THREADS) {
           const unsigned long long mine = s_kmax[kk];
           int32_t rank = 0;
           for (int32_t j = 0; j < P.n_theta; j++) rank += s_kmax[j] > mine ? 1 : 0;
@@ -1747,7 +1847,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
         if (P.rot_list || SPLIT) {
           const uint32_t bsum = best_sum<false>(s_best);
           uint32_t mine = 0u;
-          for (int32_t kk = wave; kk < P.n_theta; kk += BNB_WAVES) {
+          for (int32_t kk = wave; kk < P.n_theta; kk += WAVES) {
             const uint32_t c0 = s_U[kk * 128 + lane], c1 = s_U[kk * 128 + 64 + lane];
             mine += (uint32_t)__builtin_popcountll(__ballot(c0 != 0u && c0 >= bsum)) +
                     (uint32_t)__builtin_popcountll(__ballot(c1 != 0u && c1 >= bsum && lane + 64 < NB * NB));
@@ -1760,7 +1860,7 @@ __global__ __launch_bounds__(BNB_THREADS, 4) void csm_bnb_kernel(BnbParams P) {
           const uint32_t bsum = best_sum<false>(s_best);
           uint32_t *rows = P.ps_rows + (size_t)pair * (size_t)P.n_theta * 128u;
           uint32_t live = 0u;
-          for (int32_t r = wave; r < P.n_theta; r += BNB_WAVES) {
+          for (int32_t r = wave; r < P.n_theta; r += WAVES) {
             const uint32_t kk = s_order[r];
             const uint32_t kmax = (uint32_t)(s_kmax[kk] >> 32);
             if (kmax == 0u || kmax < bsum) break;  // (descending: no later rank holds one either)
@@ -2146,6 +2246,9 @@ namespace {
 // hipFuncSetAttribute once per instantiation and LDS size reached (not per launch)
 template <int CB, bool PL, bool BR, bool SP = false>
 int launch_main(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
+  // (the split form's first kernel: its own workgroup size, and the queue's space replaced by the lists' and the order's)
+  constexpr int THREADS = SP ? 64 * SPLIT_WAVES : BNB_THREADS;
+  if (SP) lds = lds - (size_t)QCAP * 8 + (size_t)QSPACE_SPLIT * 8;
   static std::atomic<size_t> lds_set{0};
   if (lds > lds_set.load(std::memory_order_relaxed)) {
     NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL, BR, SP>),
@@ -2155,11 +2258,11 @@ int launch_main(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
 #if NHIP_BNB_INSTR
   if (P.stats && tunable("NHIP_BNB_OCCUPANCY")) {
     int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, csm_bnb_kernel<CB, PL, BR, SP>, BNB_THREADS, lds);
+    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, csm_bnb_kernel<CB, PL, BR, SP>, THREADS, lds);
     fprintf(stderr, "csm_bnb_kernel<%d,%d,%d,%d>: lds %zu B, %d workgroups per CU\n", CB, (int)PL, (int)BR, (int)SP, lds, nb);
   }
 #endif
-  hipLaunchKernelGGL((csm_bnb_kernel<CB, PL, BR, SP>), dim3((uint32_t)blocks), dim3(BNB_THREADS), lds, s, P);
+  hipLaunchKernelGGL((csm_bnb_kernel<CB, PL, BR, SP>), dim3((uint32_t)blocks), dim3(THREADS), lds, s, P);
   return NHIP_OK;
 }
 
@@ -2486,7 +2589,10 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     NHIP_TRY_HIP(hipMemsetAsync(d_workspace, 0, BNB_WS_HEADER, s));
   }
   const bool pool_lds = bnb_lds_bytes(L, search, true) <= LDS_MAX;
-  const size_t lds = bnb_lds_bytes(L, search, pool_lds);
+  size_t lds = bnb_lds_bytes(L, search, pool_lds);
+  // (NHIP_BNB_LDS_PAD=<bytes>, measurement: unused LDS behind the workgroup's own, which lowers the workgroups a CU holds)
+  if (const char *lp = tunable("NHIP_BNB_LDS_PAD"))
+    if (atoi(lp) > 0 && lds + (size_t)atoi(lp) <= LDS_MAX) lds += (size_t)atoi(lp);
   P.lds_first = (int32_t)bnb_lds_first(L, pool_lds);
   const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
   const bool second_kernel = P.rot_list && (P.debug == 0 || (P.debug >= 3 && P.debug < 26));
