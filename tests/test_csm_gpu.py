@@ -312,6 +312,42 @@ def test_scan_lengths_around_the_held_origins(gpu, small_bag):
         _check_pairs(scans, [tgt], src, [0] * len(src), th0, spec, ospec, csm.search_spec(5, 25, 25, DEG))
 
 
+def test_run_lists_at_their_extremes(gpu, small_bag):
+    """The bounds phase compresses consecutive points that share a pooled entry into runs (an entry carries its first
+    point's index, the gather takes a run's length from the next entry, a sentinel ends the last run).  Its extremes:
+    every point of the scan in ONE cell (runs of 64, the longest a list entry can say, and a lane's 16-bit fields at
+    their limit), every point in a block of its own (64 entries per 64 points: the ring of 128 fills), both mixed, at
+    lengths that end on and off a 64-point chunk -- against the oracle and every other form of the matcher."""
+    rng = np.random.default_rng(11)
+    base = small_bag.scans[8]
+    wall = base[np.argsort(np.hypot(base[:, 0], base[:, 1]))[:40]]          # points that do score against the target
+
+    def one_cell(n):
+        return np.repeat(wall[:1], n, axis=0).astype(np.float32)
+
+    def own_block(n):  # consecutive points 1 m apart, back and forth: no two neighbours share a pooled entry
+        t = np.arange(n)
+        return np.stack([wall[0, 0] + (t % 2) * 1.0 + (t // 2 % 5) * 0.45, wall[0, 1] + (t % 3) * 0.9], 1).astype(np.float32)
+
+    def mixed(n):
+        a = np.concatenate([one_cell(70), own_block(70), np.repeat(wall[5:6], 200, axis=0), wall, one_cell(700)])
+        return np.ascontiguousarray(a[:n]).astype(np.float32)
+
+    scans = [one_cell(64), one_cell(128), one_cell(1088), one_cell(1081), one_cell(65),
+             own_block(64), own_block(128), own_block(1088), own_block(1081), own_block(193),
+             mixed(1081), mixed(1088), mixed(1089), one_cell(1300), own_block(1300),
+             # entry 0 = 64 points, 62 single-point entries, then 64 points of another cell: list entries 0 and 64 fall to the
+             # same lane, whose 16-bit fields would overflow -- the wave reduces between the two gather passes
+             np.concatenate([one_cell(64), own_block(62), np.repeat(wall[5:6], 64, axis=0)]).astype(np.float32), base]
+    tgt = len(scans) - 1
+    src = list(range(len(scans) - 1))
+    th0 = [0.02 * (i - 7) for i in src]
+    for bits in (16, 8):
+        spec, ospec = _specs(max_shift=12, cell_bits=bits)
+        got, want = _check_pairs(scans, [tgt], src, [0] * len(src), th0, spec, ospec, csm.search_spec(5, 25, 25, DEG))
+        assert want["sum"][0] > 0  # (the one-cell scans do score: 64 x one cell's value)
+
+
 def test_hand_over_policies_agree_on_a_large_batch(gpu, small_bag):
     """1,500 pairs (past the 1,024 from which pairs keep their rotations): every hand-over policy -- none, pairs with
     >= 8 candidates from their third rotation on, every pair everything -- returns the records of the kernel that
