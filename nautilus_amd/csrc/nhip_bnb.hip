@@ -87,9 +87,6 @@
 #ifndef NHIP_BNB_LEAN_ORIGINS
 #define NHIP_BNB_LEAN_ORIGINS 1  // window origins: non-finite points leave through the rare path, one constant per coordinate (0: round 3's form)
 #endif
-#ifndef NHIP_BNB_ROW_LANES
-#define NHIP_BNB_ROW_LANES 0  // bounds phase (measurement; slower): a lane gathers one block row of one entry (coarse_rotation_rows; 0: all 11 rows of its entry)
-#endif
 #ifndef NHIP_BNB_POS_RUNS
 #define NHIP_BNB_POS_RUNS 1  // bounds' run lists: an entry carries its first point's index, the gather takes the length from the next entry (0: lengths at the heads)
 #endif
@@ -604,150 +601,10 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
   }
 }
 
-// ---- bounds of one rotation, LANES ARE (ENTRY, BLOCK ROW) ------------------------------------------------------
-// The form above keeps the 11 x 12 byte sums of a lane's entries in 66 registers and needs a transposing reduction of
-// 128 packed sums per rotation; with the chunk loop's own needs that is 114 registers, four waves per SIMD -- and the
-// kernel is bound by the latency of a wave's chain at that occupancy (NHIP_BNB_SPLIT_WAVES above).  Here a lane holds
-// ONE block row of one list entry at a time: five entries x 11 rows fill 55 lanes of a gather pass (one 16-byte read,
-// three funnel shifts, six multiply-adds per lane), a lane's sums are 12 bytes = 6 packed registers (flushed to 11
-// plain ones before a lane's run lengths pass 257: 16-bit fields), and the rotation ends with the five lanes of a
-// block row adding their 11 sums into the row of bounds in LDS (`urow`: one store from the first, LDS atomic adds
-// from the other four).  No reduction network, ~50 registers.  The row holds RAW sums on return (the caller scales).
-constexpr int ROWL_G = 5;  // list entries per sub-pass: 5 x 11 rows = 55 lanes
-#ifndef NHIP_BNB_ROWL_U
-#define NHIP_BNB_ROWL_U 4
-#endif
-constexpr int ROWL_U = NHIP_BNB_ROWL_U;  // sub-passes per gather pass (<= 4: their run lengths must fit one flush)
-static_assert(ROWL_U >= 1 && ROWL_U <= 4, "a pass's run lengths stay below the 16-bit fields' limit");
-template <bool POOL_LDS>
-__device__ __forceinline__ void coarse_rotation_rows(const BnbParams &P, const uint8_t *pool, __amdgpu_buffer_rsrc_t prs,
-                                                     const float2 *pts, int32_t n_pts, float cf, float sf, int32_t cx,
-                                                     int32_t cy, int lane, uint32_t *list, uint32_t *urow) {
-  static_assert(NHIP_BNB_POS_RUNS && RUN_MAX == 64, "entries carry positions");
-  const int32_t DP = P.pool_pitch;
-  const uint32_t zero_a = (uint32_t)(((P.rows + BNB_B - 1) / BNB_B) * DP);  // NB + 1 rows of zeros below the pooled image
-  const uint32_t g = (uint32_t)lane / (uint32_t)NB, row = (uint32_t)lane - g * (uint32_t)NB;  // g == 5: lanes 55..63 idle
-  const uint32_t rowoff = row * (uint32_t)DP;
-  uint32_t E[3] = {0u, 0u, 0u}, O[3] = {0u, 0u, 0u};  // 12 byte sums, even (b0 | b2 << 16) and odd (raw) per dword
-  uint32_t W[12];                                       // the same, flushed: one sum per register
-#pragma unroll
-  for (int x = 0; x < 12; x++) W[x] = 0u;
-  uint32_t weight = 0u;           // this lane's run lengths since the last flush
-  uint32_t head = 0u, tail = 0u;  // ring positions (wave-uniform)
-
-  auto flush = [&]() {
-#pragma unroll
-    for (int d = 0; d < 3; d++) {
-      const uint32_t od = O[d] - ((E[d] >> 16) << 8);  // b1 | b3 << 16
-      W[4 * d] += E[d] & 0xffffu;
-      W[4 * d + 2] += E[d] >> 16;
-      W[4 * d + 1] += od & 0xffffu;
-      W[4 * d + 3] += od >> 16;
-      E[d] = O[d] = 0u;
-    }
-    weight = 0u;
-  };
-  // entries head .. head + n - 1 (n <= ROWL_U * 5; the entry behind them exists: it ends the last one's run), ROWL_U
-  // sub-passes of five entries whose LDS reads are issued together: a sub-pass alone is two dependent LDS round trips
-  // (list entry, then table row) for 15 instructions of arithmetic
-  auto pass = [&](uint32_t n) {
-    uint32_t cnt[ROWL_U], a[ROWL_U];
-#pragma unroll
-    for (int j = 0; j < ROWL_U; j++) {
-      const uint32_t gj = g + (uint32_t)(ROWL_G * j);
-      const bool mine = g < (uint32_t)ROWL_G && gj < n;
-      const uint32_t idx = head + gj;
-      const uint32_t entry = list[idx & (LIST_ENTRIES - 1)], next = list[(idx + 1u) & (LIST_ENTRIES - 1)];
-      cnt[j] = mine ? ((next >> RUN_SHIFT) - (entry >> RUN_SHIFT)) & 127u : 0u;
-      a[j] = (mine ? entry & ((1u << RUN_SHIFT) - 1u) : zero_a) + rowoff;
-    }
-    uint32_t wsum = 0u;
-#pragma unroll
-    for (int j = 0; j < ROWL_U; j++) wsum += cnt[j];
-    if (__ballot(weight + wsum > 257u) != 0ull) flush();  // (wsum <= ROWL_U * 64 <= 256)
-    uint32_t w[ROWL_U][4];
-#pragma unroll
-    for (int j = 0; j < ROWL_U; j++) {
-      if (POOL_LDS) {
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(pool + (a[j] & ~3u));
-        w[j][0] = q[0]; w[j][1] = q[1]; w[j][2] = q[2]; w[j][3] = q[3];
-      } else {
-        const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)(a[j] & ~3u), 0, 0);
-        w[j][0] = r4.x; w[j][1] = r4.y; w[j][2] = r4.z; w[j][3] = r4.w;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < ROWL_U; j++) {
-      const uint32_t sh = (a[j] & 3u) * 8u;
-      const uint32_t n0 = __builtin_amdgcn_alignbit(w[j][1], w[j][0], sh), n1 = __builtin_amdgcn_alignbit(w[j][2], w[j][1], sh);
-      const uint32_t n2 = __builtin_amdgcn_alignbit(w[j][3], w[j][2], sh);
-      E[0] += __umul24(n0 & M8, cnt[j]); O[0] += __umul24(n0 >> 8, cnt[j]);
-      E[1] += __umul24(n1 & M8, cnt[j]); O[1] += __umul24(n1 >> 8, cnt[j]);
-      E[2] += __umul24(n2 & M8, cnt[j]); O[2] += __umul24(n2 >> 8, cnt[j]);
-    }
-    weight += wsum;
-    head += n;
-  };
-
-  constexpr int PD = NHIP_BNB_P1_PREFETCH;
-  float2 qn[PD];
-#pragma unroll
-  for (int d = 0; d < PD; d++) qn[d] = 64 * d + lane < n_pts ? pts[64 * d + lane] : make_float2(0.f, 0.f);
-  for (int32_t c = 0;; c += 64) {
-    const bool more = c < n_pts;  // (one more turn after the last chunk drains the list)
-    if (more) {
-      const float2 pt = qn[0];
-#pragma unroll
-      for (int d = 0; d < PD - 1; d++) qn[d] = qn[d + 1];
-      if (c + 64 * PD + lane < n_pts) qn[PD - 1] = pts[c + 64 * PD + lane];
-      const bool live = c + lane < n_pts;
-      uint32_t a = zero_a;
-      if (live) {
-        int32_t prow, pcol;
-        window_origin<true>(pt, cf, sf, P, cx, cy, &prow, &pcol);
-        // (both factors are below 2^12: rows and pitch of the pooled image; the padding keeps prow positive)
-        a = __umul24((uint32_t)prow >> 3, (uint32_t)DP) + ((uint32_t)pcol >> 3);
-      }
-      // runs of equal offsets: the predecessor's offset by a DPP shift across the wave; lane 0 is a head anyway
-      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-      const unsigned long long H = __builtin_amdgcn_uicmp(a, prev, 33 /* ne */) | 1ull;
-      const int32_t n_live = n_pts - c;  // (lanes past the scan's end emit nothing)
-      const unsigned long long He = H & (n_live >= 64 ? ~0ull : (1ull << n_live) - 1ull);
-      if ((lane == 0 || a != prev) && live) {
-        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(He >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)He, 0u));
-        list[(tail + before) & (LIST_ENTRIES - 1)] = a | (((uint32_t)(c + lane) & 127u) << RUN_SHIFT);
-      }
-      tail += (uint32_t)__builtin_popcountll(He);
-    } else if (lane == 0) {
-      list[tail & (LIST_ENTRIES - 1)] = ((uint32_t)n_pts & 127u) << RUN_SHIFT;  // the sentinel: where the last run ends
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // full passes while one more entry is there to end the last one's run; after the sentinel, to the last entry
-    constexpr uint32_t FULL = (uint32_t)(ROWL_G * ROWL_U);
-    while (tail - head > FULL) pass(FULL);
-    if (!more) {
-      while (tail != head) pass(tail - head < FULL ? tail - head : FULL);
-      break;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  flush();
-  // the five lanes of a block row: one stores, four add (LDS operations of one wave are performed in order)
-  if (g == 0u) {
-#pragma unroll
-    for (int x = 0; x < NB; x++) urow[row * (uint32_t)NB + (uint32_t)x] = W[x];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  if (g >= 1u && g < (uint32_t)ROWL_G) {
-#pragma unroll
-    for (int x = 0; x < NB; x++) atomicAdd(&urow[row * (uint32_t)NB + (uint32_t)x], W[x]);
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
+// (Tried, commit 9e18995: LANES = (list entry, block row) -- a lane holds 12 byte sums instead of 11 x 12, no transposing
+//  reduction, 100 / 80 / 64 registers at 8 / 12 / 16 waves per workgroup.  Same records; bounds + seeds 3.16 -> 4.01 / 3.58 /
+//  3.7 ms: decoding an entry per (entry, row) instead of per entry doubles the vector instructions per row, which eats what
+//  the missing reduction saves, and six waves per SIMD do not make up for it.  profiles/r04_bounds_variants.txt.)
 // (block row Y, block column X) of slot v of the 128-slot layout; false for the unused slots.
 __device__ __forceinline__ bool slot_block(int v, int *Y, int *X) {
   const int lane = v & 63, i = v >> 6;
@@ -1845,20 +1702,6 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
     float cf, sf;
     rotation_k(P, pair, k, &cf, &sf);
     uint32_t umax = 0u;
-#if NHIP_BNB_ROW_LANES
-    coarse_rotation_rows<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, s_list + wave * LIST_ENTRIES, s_U + k * 128);
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      // the row holds raw sums in block order (entry b = NB * Y + X): scaled, the blocks outside the lattice zeroed
-      const int b = lane + 64 * i;
-      const int Y = b / NB, X = b - NB * Y;
-      const uint32_t u = (b < NB * NB && Y < P.nby && X < P.nbx) ? s_U[k * 128 + b] * scale : 0u;
-      s_U[k * 128 + b] = u;
-      umax = u > umax ? u : umax;
-      const unsigned long long cand = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | b);
-      wbest = (u != 0u && cand > wbest) ? cand : wbest;
-    }
-#else
     uint32_t tot[2];
     coarse_rotation<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, s_list + wave * LIST_ENTRIES, tot);
     if (lane < 128 - NB * NB) s_U[k * 128 + NB * NB + lane] = 0u;  // (the row's unused tail)
@@ -1874,7 +1717,6 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
       const unsigned long long cand = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | b);
       wbest = cand > wbest ? cand : wbest;
     }
-#endif
     if (BY_ROT) {
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) {
