@@ -654,7 +654,9 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
       if (((c0 + pad) & 15) == 0) {
         const int per = cb == 2 ? 17 : 9;  // (8-bit cells: no tiled 16-bit copy)
         for (int i = threadIdx.x; i < TILE * per; i += 256) {
-          const int r = i / per, d = i % per;
+          // (eight consecutive threads take the eight rows of one tile = the eight 16-byte pieces of one 128-byte line:
+          //  row-by-row order sent every line to memory as eight partial writes)
+          const int r = 8 * (i / (8 * per)) + (i & 7), d = (i >> 3) % per;
           if (r0 + r >= S) continue;
           const uint32_t row = (uint32_t)(r0 + r + pad);
           if (d < 4) {
