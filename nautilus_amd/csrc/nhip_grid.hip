@@ -58,6 +58,56 @@ __global__ __launch_bounds__(256) void grid_occupancy_kernel(
   }
 }
 
+// The same with the list of occupied tiles in one launch (round 4): the target's tiles are marked in an LDS bitmap, every
+// occupancy byte of the target is written (no memset of the array), and the block appends its occupied tiles to the list
+// with ONE atomic on the counter -- instead of a memset, this kernel and grid_tile_list_kernel over all n x tiles^2 bytes.
+// Entries of one target are consecutive and ascending; targets come in the order their blocks finish.
+constexpr int OCC_WORDS_MAX = 2048;  // tiles^2 <= 65,536 bits (sides of up to 16,384 cells)
+__global__ __launch_bounds__(256) void grid_occupancy_list_kernel(
+    const float2 *__restrict__ xy, const int32_t *__restrict__ offsets,
+    const int32_t *__restrict__ target_ids, int32_t t0, uint8_t *__restrict__ occ, int32_t S, int32_t tiles,
+    int32_t R, double res, double inv_res, int32_t *__restrict__ count, int32_t *__restrict__ list) {
+  __shared__ uint32_t sBits[OCC_WORDS_MAX];
+  __shared__ int32_t sBase, sN;
+  const int32_t t = blockIdx.x, nt = tiles * tiles, nw = (nt + 31) / 32;
+  const int32_t scan = target_ids[t0 + t];
+  const int32_t beg = offsets[scan], end = offsets[scan + 1];
+  for (int i = threadIdx.x; i < nw; i += 256) sBits[i] = 0u;
+  if (threadIdx.x == 0) sN = 0;
+  __syncthreads();
+  for (int32_t p = beg + threadIdx.x; p < end; p += 256) {
+    int32_t c, r;
+    if (!hit_cell(xy[p], S, res, inv_res, &c, &r)) continue;
+    // tiles whose (tile + blur halo) contains this cell: at most 2 x 2 (R <= 16 < TILE)
+    const int tx0 = max(c - R, 0) / TILE, tx1 = min(c + R, S - 1) / TILE;
+    const int ty0 = max(r - R, 0) / TILE, ty1 = min(r + R, S - 1) / TILE;
+    for (int ty = ty0; ty <= ty1; ty++)
+      for (int tx = tx0; tx <= tx1; tx++) {
+        const int k = ty * tiles + tx;
+        atomicOr(&sBits[k >> 5], 1u << (k & 31));
+      }
+  }
+  __syncthreads();
+  // occupancy bytes (the skip map's and the band kernels' input), and this thread's words' share of the list
+  uint8_t *o = occ + (size_t)t * nt;
+  for (int i = threadIdx.x; i < nt; i += 256) o[i] = (uint8_t)((sBits[i >> 5] >> (i & 31)) & 1u);
+  int32_t mine = 0;
+  for (int w = threadIdx.x; w < nw; w += 256) mine += __builtin_popcount(sBits[w]);
+  const int32_t at = mine ? atomicAdd(&sN, mine) : 0;  // (order inside the target's segment: by thread, then ascending)
+  __syncthreads();
+  if (threadIdx.x == 0) sBase = sN ? atomicAdd(count, sN) : 0;
+  __syncthreads();
+  int32_t k = sBase + at;
+  for (int w = threadIdx.x; w < nw; w += 256) {
+    uint32_t m = sBits[w];
+    while (m) {
+      const int b = __builtin_ctz(m);
+      m &= m - 1u;
+      list[k++] = t * nt + 32 * w + b;
+    }
+  }
+}
+
 // ~95 % of the 64x64 tiles of a scan's grid see no hit within their blur halo.  Launching a
 // workgroup per tile just to read its occupancy byte and leave cost more than the blur itself
 // (361k workgroups per 1000 targets), so the occupied (target, tile) pairs are compacted into a
@@ -791,15 +841,22 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
     }
     // counter (and tag: the buffer is in flux until this build is through) and occupancy
     NHIP_TRY_HIP(hipMemsetAsync(base, 0, GRID_WS_HEADER, s));
-    NHIP_TRY_HIP(hipMemsetAsync(occ, 0, occ_bytes, s));
-    timer_end(NHIP_TIMER_GRID_CLEAR, s);
     const double inv_res = 1.0 / spec->res;
-    hipLaunchKernelGGL(grid_occupancy_kernel, dim3(n), dim3(256), 0, s,
-                       reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
-                       (int32_t)t0, occ, L.S, tiles, L.R, spec->res, inv_res);
     const int32_t n_tiles_total = n * tiles * tiles;
-    hipLaunchKernelGGL(grid_tile_list_kernel, dim3((n_tiles_total + 255) / 256), dim3(256), 0, s, occ,
-                       n_tiles_total, count, list);
+    if (tiles * tiles <= 32 * OCC_WORDS_MAX) {
+      timer_end(NHIP_TIMER_GRID_CLEAR, s);
+      hipLaunchKernelGGL(grid_occupancy_list_kernel, dim3(n), dim3(256), 0, s,
+                         reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
+                         (int32_t)t0, occ, L.S, tiles, L.R, spec->res, inv_res, count, list);
+    } else {
+      NHIP_TRY_HIP(hipMemsetAsync(occ, 0, occ_bytes, s));
+      timer_end(NHIP_TIMER_GRID_CLEAR, s);
+      hipLaunchKernelGGL(grid_occupancy_kernel, dim3(n), dim3(256), 0, s,
+                         reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
+                         (int32_t)t0, occ, L.S, tiles, L.R, spec->res, inv_res);
+      hipLaunchKernelGGL(grid_tile_list_kernel, dim3((n_tiles_total + 255) / 256), dim3(256), 0, s, occ,
+                         n_tiles_total, count, list);
+    }
     const int32_t blur_blocks = n_tiles_total < 8192 ? n_tiles_total : 8192;  // persistent over the list
     const int32_t rows = L.S + 2 * L.pad, mpitch = L.pitch / 4;
     if (L.cb == 1)
