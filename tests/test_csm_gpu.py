@@ -1077,6 +1077,49 @@ def test_grid_rebuild_clears_what_the_last_build_wrote(gpu, small_bag, cell_bits
     assert np.array_equal(call(lib.nhip_grid_rebuild_dev, ids_b, G3, W), fresh_b), "a buffer the workspace never saw"
 
 
+@pytest.mark.parametrize("cell_bits", [16, 8])
+def test_pooled_tables_from_the_tile_list_equal_the_band_kernels(gpu, small_bag, cell_bits):
+    """Both pooled tables are built per listed 64 x 64 tile and cleared around the previous build's tiles
+    (grid_pool4_tiles_kernel, grid_pool8_tiles_kernel); NHIP_GRID_POOL=bands keeps the kernels that walk every band of
+    every slot.  Whole slots equal, byte for byte: a first build, a rebuild over other targets, a rebuild over the same."""
+    import os
+    import torch
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits)
+    L = csm.grid_layout(spec)
+    xy, off = csm.pack_scans(small_bag.scans)
+    t = lambda a: torch.from_numpy(a).to(dev)
+    d_xy, d_off = t(xy), t(off)
+    n = 4
+    nbytes = lib.nhip_grids_bytes(C.byref(spec), n)
+    ws_bytes = lib.nhip_grid_workspace_bytes(C.byref(spec), n)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def run(form):
+        if form:
+            os.environ["NHIP_GRID_POOL"] = form
+        try:
+            G = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            W = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+            out = []
+            for fn, ids in ((lib.nhip_grid_build_dev, [3, 17, 40, 5]), (lib.nhip_grid_rebuild_dev, [25, 8, 3, 60]),
+                            (lib.nhip_grid_rebuild_dev, [25, 8, 3, 60])):
+                d_ids = t(np.asarray(ids, dtype=np.int32))
+                _lib.check(fn(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), n, C.byref(spec), G.data_ptr(), W.data_ptr(),
+                              ws_bytes, sp))
+                torch.cuda.synchronize()
+                out.append(G[:n * L.slot_bytes].cpu().numpy().copy())
+            return out
+        finally:
+            os.environ.pop("NHIP_GRID_POOL", None)
+
+    tiles, bands = run(None), run("bands")
+    for a, b, what in zip(tiles, bands, ("first build", "rebuild over other targets", "rebuild over the same targets")):
+        assert a.any() and np.array_equal(a, b), what
+    assert np.array_equal(tiles[1], tiles[2])
+
+
 def test_environment_switches_need_nhip_tunables(gpu):
     """A shipped process reads no behaviour switch: NHIP_BNB_SPLIT=0 changes the form of a 300-pair list only in a
     process started with NHIP_TUNABLES=1 (the library looks once, at its first call)."""
