@@ -1103,8 +1103,8 @@ def test_pooled_tables_from_the_tile_list_equal_the_band_kernels(gpu, small_bag,
             G = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             W = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
             out = []
-            for fn, ids in ((lib.nhip_grid_build_dev, [3, 17, 40, 5]), (lib.nhip_grid_rebuild_dev, [25, 8, 3, 60]),
-                            (lib.nhip_grid_rebuild_dev, [25, 8, 3, 60])):
+            for fn, ids in ((lib.nhip_grid_build_dev, [3, 17, 40, 5]), (lib.nhip_grid_rebuild_dev, [25, 8, 3, 44]),
+                            (lib.nhip_grid_rebuild_dev, [25, 8, 3, 44])):
                 d_ids = t(np.asarray(ids, dtype=np.int32))
                 _lib.check(fn(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), n, C.byref(spec), G.data_ptr(), W.data_ptr(),
                               ws_bytes, sp))
