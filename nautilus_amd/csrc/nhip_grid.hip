@@ -171,9 +171,16 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
     {
       const int32_t scan = target_ids[t0 + t];
       const int32_t beg = offsets[scan], end = offsets[scan + 1];
+      // (the neighbourhood in metres, a cell wider on every side: nineteen points in twenty lie outside it and are
+      //  dropped by four single-precision compares instead of two double-precision quotients; the exact test follows)
+      const float resf = (float)res;
+      const float x_lo = (float)(c0 - R - S / 2 - 1) * resf, x_hi = (float)(c0 + TILE + R - S / 2 + 1) * resf;
+      const float y_lo = (float)(r0 - R - S / 2 - 1) * resf, y_hi = (float)(r0 + TILE + R - S / 2 + 1) * resf;
       for (int32_t p = beg + threadIdx.x; p < end; p += 256) {
         int32_t c, r;
-        if (!hit_cell(xy[p], S, res, inv_res, &c, &r)) continue;
+        const float2 q = xy[p];
+        if (!(q.x >= x_lo && q.x < x_hi && q.y >= y_lo && q.y < y_hi)) continue;
+        if (!hit_cell(q, S, res, inv_res, &c, &r)) continue;
         const int32_t rr = r - (r0 - R), cc = c - (c0 - R);
         if (rr < 0 || rr >= TH || cc < 0 || cc >= TH) continue;
         const uint32_t idx = (uint32_t)(rr * TH + cc), bit = 1u << (idx & 31u);
