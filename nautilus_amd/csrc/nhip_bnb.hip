@@ -87,9 +87,6 @@
 #ifndef NHIP_BNB_LEAN_ORIGINS
 #define NHIP_BNB_LEAN_ORIGINS 1  // window origins: non-finite points leave through the rare path, one constant per coordinate (0: round 3's form)
 #endif
-#ifndef NHIP_BNB_ROW_GROUPS
-#define NHIP_BNB_ROW_GROUPS 1  // bounds phase: a lane gathers three block rows of its entry, 16 entries per pass (coarse_rotation_rg; 0: all 11 rows, 64 entries)
-#endif
 #ifndef NHIP_BNB_POS_RUNS
 #define NHIP_BNB_POS_RUNS 1  // bounds' run lists: an entry carries its first point's index, the gather takes the length from the next entry (0: lengths at the heads)
 #endif
@@ -608,151 +605,6 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
 //  reduction, 100 / 80 / 64 registers at 8 / 12 / 16 waves per workgroup.  Same records; bounds + seeds 3.16 -> 4.01 / 3.58 /
 //  3.7 ms: decoding an entry per (entry, row) instead of per entry doubles the vector instructions per row, which eats what
 //  the missing reduction saves, and six waves per SIMD do not make up for it.  profiles/r04_bounds_variants.txt.)
-// ---- bounds of one rotation, LANES ARE (LIST ENTRY, GROUP OF THREE BLOCK ROWS) ---------------------------------
-// coarse_rotation keeps the 11 x 12 byte sums of a lane's entries in 66 packed registers; with the chunk loop's own
-// needs that is 114 registers, four waves per SIMD, and the kernel is bound by the latency of a wave's chain at that
-// occupancy.  Here the 64 lanes are four groups of 16: lane = 16 g + e gathers block rows 3 g .. 3 g + 2 of list entry
-// e of the pass (16 entries per pass; group 3 has rows 9 and 10 only), so a lane holds 3 x 12 byte sums = 18 packed
-// registers, and the transposing reduction runs INSIDE the rows of 16 lanes (DPP quad permutations, then row
-// rotations): 18 -> 10 -> 5 packed, widened, -> 5 -> 3 totals per lane.  Lane (bits a b c d of e) ends with, in slot i,
-// the total of packed register 8 i + 4 d + 2 b + a, field c -- register 6 y + 3 kind + w = row y of the group, even
-// (kind 0: columns 4 w, 4 w + 2) or odd (columns 4 w + 1, 4 w + 3) bytes of dword w.  The totals go to the row of
-// bounds in LDS (`urow`, block order b = 11 Y + X, RAW sums: the caller scales).  A lane's run lengths between two
-// reductions stay <= 64 (four lanes' packed fields: 4 x 64 x 255 = 65,280).
-template <bool POOL_LDS>
-__device__ __forceinline__ void coarse_rotation_rg(const BnbParams &P, const uint8_t *pool, __amdgpu_buffer_rsrc_t prs,
-                                                   const float2 *pts, int32_t n_pts, float cf, float sf, int32_t cx,
-                                                   int32_t cy, int lane, uint32_t *list, uint32_t *urow) {
-  static_assert(NHIP_BNB_POS_RUNS && RUN_MAX == 64 && NB == 11, "entries carry positions; four groups of three rows");
-  const int32_t DP = P.pool_pitch;
-  const uint32_t zero_a = (uint32_t)(((P.rows + BNB_B - 1) / BNB_B) * DP);  // NB + 1 rows of zeros below the pooled image
-  const uint32_t rg = (uint32_t)lane >> 4, e16 = (uint32_t)lane & 15u;
-  const uint32_t rowoff = 3u * rg * (uint32_t)DP;
-  uint32_t E[3][3], O[3][3];  // [row of the group][dword]: even (b0 | b2 << 16) and odd (raw) byte sums
-#pragma unroll
-  for (int y = 0; y < 3; y++)
-#pragma unroll
-    for (int d = 0; d < 3; d++) E[y][d] = O[y][d] = 0u;
-  uint32_t tot[3] = {0u, 0u, 0u};
-  uint32_t weight = 0u;           // this lane's run lengths since the last reduction
-  bool pending = false;
-  uint32_t head = 0u, tail = 0u;  // ring positions (wave-uniform)
-
-  auto reduce = [&]() {
-    uint32_t R[20];
-#pragma unroll
-    for (int y = 0; y < 3; y++)
-#pragma unroll
-      for (int d = 0; d < 3; d++) {
-        R[6 * y + d] = E[y][d];
-        R[6 * y + 3 + d] = O[y][d] - ((E[y][d] >> 16) << 8);  // b1 | b3 << 16
-        E[y][d] = O[y][d] = 0u;
-      }
-    R[18] = R[19] = 0u;
-    rs_step<20, 1>(R, lane & 1);
-    rs_step<10, 2>(R, lane & 2);
-    uint32_t V[10];
-#pragma unroll
-    for (int i = 0; i < 5; i++) {
-      V[2 * i] = R[i] & 0xffffu;
-      V[2 * i + 1] = R[i] >> 16;
-    }
-    rs_step<10, 4>(V, lane & 4);
-    V[5] = 0u;
-    rs_step<6, 8>(V, lane & 8);
-    tot[0] += V[0];
-    tot[1] += V[1];
-    tot[2] += V[2];
-    weight = 0u;
-    pending = false;
-  };
-  // entries head .. head + n - 1 (n <= 16; the entry behind them exists: it ends the last one's run)
-  auto pass = [&](uint32_t n) {
-    const bool mine = e16 < n;
-    const uint32_t idx = head + e16;
-    const uint32_t entry = list[idx & (LIST_ENTRIES - 1)], next = list[(idx + 1u) & (LIST_ENTRIES - 1)];
-    const uint32_t cnt = mine ? ((next >> RUN_SHIFT) - (entry >> RUN_SHIFT)) & 127u : 0u;
-    const uint32_t a = (mine ? entry & ((1u << RUN_SHIFT) - 1u) : zero_a) + rowoff;
-    if (pending && __ballot(weight + cnt > LANE_WEIGHT) != 0ull) reduce();
-    const uint32_t sh = (a & 3u) * 8u;
-#pragma unroll
-    for (int y = 0; y < 3; y++) {
-      uint32_t w0, w1, w2, w3;
-      if (POOL_LDS) {
-        const uint32_t *q = reinterpret_cast<const uint32_t *>(pool + (a & ~3u)) + (y * DP) / 4;  // DP is a multiple of 16
-        w0 = q[0]; w1 = q[1]; w2 = q[2]; w3 = q[3];
-      } else {
-        const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((a & ~3u) + (uint32_t)(y * DP)), 0, 0);
-        w0 = r4.x; w1 = r4.y; w2 = r4.z; w3 = r4.w;
-      }
-      const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
-      const uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, sh);
-      // (group 3 holds block rows 9 and 10: its third row is past the block grid -- gathered like the others, it reads
-      //  table rows that exist, and dropped when the totals are stored)
-      E[y][0] += __umul24(n0 & M8, cnt); O[y][0] += __umul24(n0 >> 8, cnt);
-      E[y][1] += __umul24(n1 & M8, cnt); O[y][1] += __umul24(n1 >> 8, cnt);
-      E[y][2] += __umul24(n2 & M8, cnt); O[y][2] += __umul24(n2 >> 8, cnt);
-    }
-    weight += cnt;
-    pending = true;
-    head += n;
-  };
-
-  constexpr int PD = NHIP_BNB_P1_PREFETCH;
-  float2 qn[PD];
-#pragma unroll
-  for (int d = 0; d < PD; d++) qn[d] = 64 * d + lane < n_pts ? pts[64 * d + lane] : make_float2(0.f, 0.f);
-  for (int32_t c = 0;; c += 64) {
-    const bool more = c < n_pts;  // (one more turn after the last chunk drains the list)
-    if (more) {
-      const float2 pt = qn[0];
-#pragma unroll
-      for (int d = 0; d < PD - 1; d++) qn[d] = qn[d + 1];
-      if (c + 64 * PD + lane < n_pts) qn[PD - 1] = pts[c + 64 * PD + lane];
-      const bool live = c + lane < n_pts;
-      uint32_t a = zero_a;
-      if (live) {
-        int32_t prow, pcol;
-        window_origin<true>(pt, cf, sf, P, cx, cy, &prow, &pcol);
-        // (both factors are below 2^12: rows and pitch of the pooled image; the padding keeps prow positive)
-        a = __umul24((uint32_t)prow >> 3, (uint32_t)DP) + ((uint32_t)pcol >> 3);
-      }
-      // runs of equal offsets: the predecessor's offset by a DPP shift across the wave; lane 0 is a head anyway
-      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-      const unsigned long long H = __builtin_amdgcn_uicmp(a, prev, 33 /* ne */) | 1ull;
-      const int32_t n_live = n_pts - c;  // (lanes past the scan's end emit nothing)
-      const unsigned long long He = H & (n_live >= 64 ? ~0ull : (1ull << n_live) - 1ull);
-      if ((lane == 0 || a != prev) && live) {
-        const uint32_t before = __builtin_amdgcn_mbcnt_hi((uint32_t)(He >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)He, 0u));
-        list[(tail + before) & (LIST_ENTRIES - 1)] = a | (((uint32_t)(c + lane) & 127u) << RUN_SHIFT);
-      }
-      tail += (uint32_t)__builtin_popcountll(He);
-    } else if (lane == 0) {
-      list[tail & (LIST_ENTRIES - 1)] = ((uint32_t)n_pts & 127u) << RUN_SHIFT;  // the sentinel: where the last run ends
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    // full passes while one more entry is there to end the sixteenth's run; after the sentinel, to the last entry
-    while (tail - head > 16u) pass(16u);
-    if (!more) {
-      while (tail != head) pass(tail - head < 16u ? tail - head : 16u);
-      break;
-    }
-    __builtin_amdgcn_wave_barrier();
-  }
-  if (pending) reduce();
-  // slot i of lane (a b c d) = packed register r = 8 i + 4 d + 2 b + a, field c
-#pragma unroll
-  for (int i = 0; i < 3; i++) {
-    const uint32_t r = 8u * (uint32_t)i + ((e16 >> 3) & 1u) * 4u + (e16 & 2u) + (e16 & 1u), h = (e16 >> 2) & 1u;
-    const uint32_t y = r / 6u, rem = r - 6u * y, kind = rem / 3u, w = rem - 3u * kind;
-    const uint32_t Y = 3u * rg + y, X = 4u * w + kind + 2u * h;
-    if (r < 18u && Y < (uint32_t)NB && X < (uint32_t)NB) urow[Y * (uint32_t)NB + X] = tot[i];
-  }
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-}
-
 // (block row Y, block column X) of slot v of the 128-slot layout; false for the unused slots.
 __device__ __forceinline__ bool slot_block(int v, int *Y, int *X) {
   const int lane = v & 63, i = v >> 6;
@@ -1850,20 +1702,6 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
     float cf, sf;
     rotation_k(P, pair, k, &cf, &sf);
     uint32_t umax = 0u;
-#if NHIP_BNB_ROW_GROUPS
-    coarse_rotation_rg<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, s_list + wave * LIST_ENTRIES, s_U + k * 128);
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      // the row holds raw sums in block order (entry b = NB * Y + X): scaled, the blocks outside the lattice zeroed
-      const int b = lane + 64 * i;
-      const int Y = b / NB, X = b - NB * Y;
-      const uint32_t u = (b < NB * NB && Y < P.nby && X < P.nbx) ? s_U[k * 128 + b] * scale : 0u;
-      s_U[k * 128 + b] = u;
-      umax = u > umax ? u : umax;
-      const unsigned long long cand = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | b);
-      wbest = (u != 0u && cand > wbest) ? cand : wbest;
-    }
-#else
     uint32_t tot[2];
     coarse_rotation<POOL_LDS>(P, s_pool, prs, pts, n_pts, cf, sf, cx, cy, lane, s_list + wave * LIST_ENTRIES, tot);
     if (lane < 128 - NB * NB) s_U[k * 128 + NB * NB + lane] = 0u;  // (the row's unused tail)
@@ -1879,7 +1717,6 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
       const unsigned long long cand = ((unsigned long long)u << 32) | (uint32_t)((k << 8) | b);
       wbest = cand > wbest ? cand : wbest;
     }
-#endif
     if (BY_ROT) {
 #pragma unroll
       for (int m = 32; m >= 1; m >>= 1) {
