@@ -182,7 +182,9 @@ double nhip_score_from_sum(const nhip_grid_spec_t *spec, int64_t sum, int32_t n_
  * d_grids (nhip_grids_bytes(spec, n_targets) bytes): slot t = position in d_target_ids, at byte
  * t * slot_bytes, holds the stored image (grid_bytes) followed by its skip map (skip_bytes) and the two
  * max-pooled tables (pool_bytes, pool4_bytes).
- * d_xy: float2 points of all scans, d_offsets: n_scans+1 prefix offsets (in points). */
+ * d_xy: float2 points of all scans, d_offsets: n_scans+1 prefix offsets (in points).
+ * Ids and offsets live in device memory and are NOT validated (that would cost a round trip): every id must lie in
+ * [0, n_scans) -- the handle API (nhip_grids_build), whose ids are host arrays, checks them. */
 int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
                         int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
                         void *d_workspace, int64_t workspace_bytes, void *stream);
