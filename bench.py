@@ -183,6 +183,7 @@ class HipMatcher:
         self.layout = csm.grid_layout(self.spec)
         t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(device)
         self.d_xy, self.d_off = t(wl.xy), t(wl.off)
+        self.n_scans = len(wl.off) - 1
         self.d_ids, self.d_src, self.d_slot = t(ids), t(src), t(slot)
         self.d_delta = t(csm.delta_table(self.search))
         self.h_th0 = np.ascontiguousarray(th0, dtype=np.float64)
@@ -209,11 +210,11 @@ class HipMatcher:
         ck(lib.nhip_csm_rot0(self._lib.ptr(self.h_th0), None, self.n_pairs, self._lib.ptr(self.rot0_np)))
         self.d_rot0.copy_(self.h_rot0, non_blocking=True)
         build = lib.nhip_grid_rebuild_dev if self.built else lib.nhip_grid_build_dev
-        ck(build(self.d_xy.data_ptr(), self.d_off.data_ptr(), self.d_ids.data_ptr(), self.n_targets,
+        ck(build(self.d_xy.data_ptr(), self.d_off.data_ptr(), self.n_scans, self.d_ids.data_ptr(), self.n_targets,
                  C.byref(self.spec), self.d_grids.data_ptr(), self.d_ws.data_ptr(), self.ws_bytes, self.sp))
         self.built = True
-        ck(lib.nhip_csm_match_dev(self.d_xy.data_ptr(), self.d_off.data_ptr(), self.d_grids.data_ptr(),
-                                  C.byref(self.spec), self.d_src.data_ptr(), self.d_slot.data_ptr(),
+        ck(lib.nhip_csm_match_dev(self.d_xy.data_ptr(), self.d_off.data_ptr(), self.n_scans, self.d_grids.data_ptr(),
+                                  self.n_targets, C.byref(self.spec), self.d_src.data_ptr(), self.d_slot.data_ptr(),
                                   self.d_rot0.data_ptr(), self.d_delta.data_ptr(), None, self.n_pairs,
                                   C.byref(self.search), self.d_keys.data_ptr(), self.d_out.data_ptr(),
                                   self.d_sums.data_ptr(), self.d_ws_csm.data_ptr(), self.ws_csm, self.sp))

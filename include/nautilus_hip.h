@@ -20,6 +20,13 @@
  * thread-local message.  "_dev" entry points take DEVICE pointers owned by the caller and
  * only enqueue work on `stream` (a hipStream_t passed as void*; NULL = default stream):
  * they allocate nothing and do not synchronise, so they can be captured in a hipGraph.
+ * Ids in device memory: the scan ids, grid slots, block ids and pose indices that a "_dev" entry point reads from DEVICE
+ * arrays cannot be validated by the host without a round trip, so the KERNELS check each of them against the count
+ * passed beside its array (n_scans, n_grids, n_blocks, n_poses ...).  An id outside [0, count) is never dereferenced: the
+ * entry is treated as empty (a target without points, a pair that scores nothing, a correspondence that is skipped) and
+ * recorded in the device's status words; nhip_dev_status(stream) -- call it where the host synchronises anyway --
+ * returns NHIP_ERR_ARG with the offending id in nhip_last_error().  (The reference aborts on such input with a glog
+ * CHECK, src/optimization/slam_residuals.h:99-101,109; a stale id here costs an error code, not the process.)
  * Handle entry points take HOST pointers, own their device memory and synchronise.
  * There is no CPU fallback anywhere: without a gfx950 device compute calls fail with
  * NHIP_ERR_NODEV.
@@ -46,6 +53,13 @@ int nhip_init(int *n_devices);
 int nhip_set_device(int device);
 const char *nhip_last_error(void);
 const char *nhip_version(void);
+/* Synchronises `stream` (NULL = the default stream) and reports whether a kernel since the last call met an id in device
+ * memory that was out of range (see "Ids in device memory" above): NHIP_OK, or NHIP_ERR_ARG with the message in
+ * nhip_last_error().  info (may be NULL): {OR of the kinds seen, kind, value, index of the first one reported}; kinds:
+ * 1 target scan id of a grid build, 2 source scan id of a pair, 4 grid slot of a pair, 8 block id of a correspondence,
+ * 16 pose index of a block, 32 scan id of a correspondence-search block.  Clears the record.  One record per device:
+ * a host with several streams on one device learns THAT an id was bad and which, not on which stream. */
+int nhip_dev_status(void *stream, int32_t info[4]);
 
 /* ------------------------------------------------------------------ likelihood grids
  * Replaces the lookup table CorrelativeScanMatcher builds from the target point cloud.
@@ -183,9 +197,10 @@ double nhip_score_from_sum(const nhip_grid_spec_t *spec, int64_t sum, int32_t n_
  * t * slot_bytes, holds the stored image (grid_bytes) followed by its skip map (skip_bytes) and the two
  * max-pooled tables (pool_bytes, pool4_bytes).
  * d_xy: float2 points of all scans, d_offsets: n_scans+1 prefix offsets (in points).
- * Ids and offsets live in device memory and are NOT validated (that would cost a round trip): every id must lie in
- * [0, n_scans) -- the handle API (nhip_grids_build), whose ids are host arrays, checks them. */
-int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+ * d_target_ids live in device memory: the kernels check every id against n_scans; one outside [0, n_scans) gives an
+ * all-floor grid (a target without points) and an error from nhip_dev_status().  The offsets themselves are the
+ * caller's: they must be non-decreasing and end inside d_xy. */
+int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const int32_t *d_target_ids,
                         int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
                         void *d_workspace, int64_t workspace_bytes, void *stream);
 
@@ -195,12 +210,14 @@ int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32
  * untouched since.  The workspace header carries a tag of (d_grids, n_targets, geometry) that the clearing kernel checks
  * on the device: a header that does not vouch for this buffer (fresh or recycled workspace memory, another buffer,
  * another spec) makes the call clear everything, i.e. behave as nhip_grid_build_dev.  Same results, bit for bit. */
-int nhip_grid_rebuild_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+int nhip_grid_rebuild_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const int32_t *d_target_ids,
                           int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
                           void *d_workspace, int64_t workspace_bytes, void *stream);
 
 /* K2+K3: exhaustive (theta, x, y) correlation + argmax for n_pairs candidate pairs.
- * Pair i matches scan d_pair_src[i] against grid slot d_pair_slot[i].
+ * Pair i matches scan d_pair_src[i] (of the n_scans behind d_offsets) against grid slot d_pair_slot[i] (of the n_grids in
+ * d_grids).  Both arrays live in device memory: a pair whose scan or slot is out of range scores nothing (record: pose 0,
+ * sum 0, the floor score) and makes nhip_dev_status() return an error.
  * d_rot0_cs: 2 doubles (cos, sin theta0) per pair; d_delta_cs: 2 doubles per lattice rotation.
  * d_pair_origin: NULL, or 2 int32 per pair = (x, y) cell offset of the search centre (used by
  * the fine level of a coarse-to-fine search); |origin| + half-width must be <= max_shift.
@@ -216,8 +233,8 @@ int nhip_grid_rebuild_dev(const float *d_xy, const int32_t *d_offsets, const int
  * 131,072 pairs go through in rounds of that many, the candidates of a round on an internal stream of the current
  * device (ordered before and after `stream` by events) beside the next round's bounds.  A workspace that is NULL or too
  * small takes the one-kernel form.  Same records in every form. */
-int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
-                       const nhip_grid_spec_t *spec, const int32_t *d_pair_src,
+int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const uint8_t *d_grids,
+                       int32_t n_grids, const nhip_grid_spec_t *spec, const int32_t *d_pair_src,
                        const int32_t *d_pair_slot, const double *d_rot0_cs,
                        const double *d_delta_cs, const int32_t *d_pair_origin, int32_t n_pairs,
                        const nhip_search_t *search, uint64_t *d_keys, nhip_match_t *d_out,
@@ -253,8 +270,8 @@ int nhip_bnb_timeline(uint64_t *ticks, int32_t n_pairs);
 int nhip_bnb_timeline_candidates(uint64_t *ticks, int32_t n_pairs);
 
 /* Full score volume of ONE pair (tests / debugging): sums[(k*nx + ix)*ny + iy]. */
-int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
-                        const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
+int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const uint8_t *d_grids,
+                        int32_t n_grids, const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
                         const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
                         int32_t origin_y, const nhip_search_t *search, int32_t *d_sums,
                         void *stream);

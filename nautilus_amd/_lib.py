@@ -75,9 +75,10 @@ PROTOTYPES = {
     "nhip_match_to_transform": (C.c_int, [_P(Match), _P(GridSpec), _P(Search), _f64, _i32, _i32,
                                           _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "nhip_score_from_sum": (_f64, [_P(GridSpec), _i64, _i32]),
-    "nhip_grid_build_dev": (C.c_int, [_vp, _vp, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
-    "nhip_grid_rebuild_dev": (C.c_int, [_vp, _vp, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
-    "nhip_csm_match_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _vp, _vp, _vp, _vp, _vp, _i32,
+    "nhip_dev_status": (C.c_int, [_vp, _P(_i32)]),
+    "nhip_grid_build_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
+    "nhip_grid_rebuild_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
+    "nhip_csm_match_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _vp, _vp, _vp, _vp, _vp, _i32,
                                      _P(Search), _vp, _vp, _vp, _vp, _i64, _vp]),
     "nhip_csm_workspace_bytes": (_i64, [_i32]),
     "nhip_csm_last_launch": (C.c_int, [_P(_i32)]),
@@ -86,7 +87,7 @@ PROTOTYPES = {
     "nhip_bnb_timeline": (C.c_int, [_vp, _i32]),
     "nhip_bnb_timeline_candidates": (C.c_int, [_vp, _i32]),
     "nhip_bnb_stats_levels": (C.c_int, [_P(C.c_uint64)]),
-    "nhip_csm_scores_dev": (C.c_int, [_vp, _vp, _vp, _P(GridSpec), _i32, _i32, _vp, _vp, _i32, _i32,
+    "nhip_csm_scores_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _i32, _i32, _vp, _vp, _i32, _i32,
                                       _P(Search), _vp, _vp]),
     "nhip_resid_lidar_dev": (C.c_int, [C.c_int, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp,
                                        _vp, _vp, _vp, _vp]),

@@ -61,7 +61,7 @@ struct ThreadList {
   std::vector<double> rot0;  // (cos, sin) per pair
 };
 
-static bool MatchList(const float *d_xy, const int32_t *d_off, const uint8_t *d_grids, const nhip_grid_spec_t &spec,
+static bool MatchList(const float *d_xy, const int32_t *d_off, int32_t n_scans, const uint8_t *d_grids, const nhip_grid_spec_t &spec,
                       const nhip_search_t &search, const double *d_delta, const ThreadList &L, hipStream_t st,
                       std::vector<nhip_match_t> *out, int32_t info[8]) {
   const int32_t n = (int32_t)L.src.size();
@@ -77,7 +77,7 @@ static bool MatchList(const float *d_xy, const int32_t *d_off, const uint8_t *d_
   ok = ok && hipMemcpyAsync(d_src, L.src.data(), 4 * n, hipMemcpyHostToDevice, st) == hipSuccess &&
        hipMemcpyAsync(d_slot, L.slot.data(), 4 * n, hipMemcpyHostToDevice, st) == hipSuccess &&
        hipMemcpyAsync(d_rot0, L.rot0.data(), 16 * n, hipMemcpyHostToDevice, st) == hipSuccess;
-  ok = ok && nhip_csm_match_dev(d_xy, d_off, d_grids, &spec, d_src, d_slot, d_rot0, d_delta, nullptr, n, &search, d_keys,
+  ok = ok && nhip_csm_match_dev(d_xy, d_off, n_scans, d_grids, n_scans /* every scan is a target */, &spec, d_src, d_slot, d_rot0, d_delta, nullptr, n, &search, d_keys,
                                 d_out, nullptr, d_ws, ws, st) == NHIP_OK;
   if (!ok) std::printf("MatchList: %s\n", nhip_last_error());
   ok = ok && nhip_csm_last_launch(info) == NHIP_OK;
@@ -117,7 +117,7 @@ static bool TwoThreadsOnTwoStreams() {
        hipMemcpy(d_ids, ids.data(), 4 * NS, hipMemcpyHostToDevice) == hipSuccess &&
        hipMemcpy(d_delta, delta.data(), 8 * delta.size(), hipMemcpyHostToDevice) == hipSuccess &&
        hipMemset(d_grids, 0, (size_t)gbytes) == hipSuccess;
-  ok = ok && nhip_grid_build_dev(d_xy, d_off, d_ids, NS, &spec, d_grids, d_gws, gws, nullptr) == NHIP_OK &&
+  ok = ok && nhip_grid_build_dev(d_xy, d_off, NS, d_ids, NS, &spec, d_grids, d_gws, gws, nullptr) == NHIP_OK &&
        hipDeviceSynchronize() == hipSuccess;
   if (!ok) { std::printf("two threads: setup failed: %s\n", nhip_last_error()); return false; }
   ThreadList lists[2];
@@ -133,7 +133,7 @@ static bool TwoThreadsOnTwoStreams() {
   // reference: each list on its own, default form (28 pairs: one kernel per pair + the hand-over kernel)
   std::vector<nhip_match_t> want[2], got[2];
   int32_t info[2][8];
-  for (int t = 0; t < 2; t++) ok = ok && MatchList(d_xy, d_off, d_grids, spec, search, d_delta, lists[t], nullptr, &want[t], info[t]);
+  for (int t = 0; t < 2; t++) ok = ok && MatchList(d_xy, d_off, NS, d_grids, spec, search, d_delta, lists[t], nullptr, &want[t], info[t]);
   ok = ok && info[0][0] == 0;
   // forced: the split form in rounds of 3 pairs, candidates of a round on a helper stream (tunables are read per launch
   // in a process started with NHIP_TUNABLES=1: main() set it before the library's first call)
@@ -146,8 +146,8 @@ static bool TwoThreadsOnTwoStreams() {
        hipStreamCreateWithFlags(&st[1], hipStreamNonBlocking) == hipSuccess;
   bool tok[2] = {false, false};
   for (int rep = 0; rep < 3 && ok; rep++) {
-    std::thread th0([&] { tok[0] = MatchList(d_xy, d_off, d_grids, spec, search, d_delta, lists[0], st[0], &got[0], info[0]); });
-    std::thread th1([&] { tok[1] = MatchList(d_xy, d_off, d_grids, spec, search, d_delta, lists[1], st[1], &got[1], info[1]); });
+    std::thread th0([&] { tok[0] = MatchList(d_xy, d_off, NS, d_grids, spec, search, d_delta, lists[0], st[0], &got[0], info[0]); });
+    std::thread th1([&] { tok[1] = MatchList(d_xy, d_off, NS, d_grids, spec, search, d_delta, lists[1], st[1], &got[1], info[1]); });
     th0.join();
     th1.join();
     ok = tok[0] && tok[1];
@@ -162,6 +162,24 @@ static bool TwoThreadsOnTwoStreams() {
   unsetenv("NHIP_BNB_SPLIT");
   unsetenv("NHIP_BNB_SPLIT_BATCH");
   unsetenv("NHIP_BNB_SPLIT_MIN");
+  // A stale id in a device-resident list (include/nautilus_hip.h, "Ids in device memory"): the call enqueues as usual,
+  // the bad pair scores nothing, the others keep their records, and nhip_dev_status() says which id it was -- once.
+  if (ok) {
+    ThreadList bad = lists[0];
+    bad.src[5] = NS + 3;
+    std::vector<nhip_match_t> rec;
+    int32_t inf[8], st4[4] = {0, 0, 0, 0};
+    ok = nhip_dev_status(nullptr, nullptr) == NHIP_OK;  // (nothing pending from the runs above)
+    ok = ok && MatchList(d_xy, d_off, NS, d_grids, spec, search, d_delta, bad, nullptr, &rec, inf);
+    const int rc = nhip_dev_status(nullptr, st4);
+    ok = ok && rc == NHIP_ERR_ARG && st4[1] == 2 && st4[2] == NS + 3 && st4[3] == 5 && std::strstr(nhip_last_error(), "d_pair_src") &&
+         nhip_dev_status(nullptr, nullptr) == NHIP_OK;
+    for (size_t i = 0; i < rec.size() && ok; i++) {
+      if (i == 5) ok = rec[i].itheta == 0 && rec[i].ix == 0 && rec[i].iy == 0;
+      else ok = std::memcmp(&rec[i], &want[0][i], sizeof(nhip_match_t)) == 0;
+    }
+    if (!ok) std::printf("stale id: rc %d status {%d %d %d %d}: %s\n", rc, st4[0], st4[1], st4[2], st4[3], nhip_last_error());
+  }
   (void)hipStreamDestroy(st[0]); (void)hipStreamDestroy(st[1]);
   (void)hipFree(d_xy); (void)hipFree(d_off); (void)hipFree(d_ids); (void)hipFree(d_grids); (void)hipFree(d_gws); (void)hipFree(d_delta);
   return ok;

@@ -41,6 +41,30 @@ int require_device() {
   return NHIP_OK;
 }
 
+// The status words of the current device (nhip_common.h, "ids that live in device memory"): 16 bytes of device memory
+// per device, allocated the first time the device is used and kept to the end of the process.
+uint32_t *dev_status() {
+  constexpr int MAX_DEV = 64;
+  static std::mutex mu;
+  static uint32_t *words[MAX_DEV] = {nullptr};
+  int dev = -1;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  std::lock_guard<std::mutex> lock(mu);
+  if (!words[dev]) {
+    void *p = nullptr;
+    if (hipMalloc(&p, sizeof(uint32_t) * DEV_STATUS_WORDS) != hipSuccess ||
+        hipMemset(p, 0, sizeof(uint32_t) * DEV_STATUS_WORDS) != hipSuccess) {
+      (void)hipGetLastError();
+      return nullptr;
+    }
+    words[dev] = static_cast<uint32_t *>(p);
+  }
+  return words[dev];
+}
+
 const char *tunable(const char *name) {
   static std::once_flag once;
   static bool on = false;
@@ -381,38 +405,38 @@ double nhip_score_from_sum(const nhip_grid_spec_t *spec, int64_t sum, int32_t n_
 }
 
 // ---------------------------------------------------------------- device-pointer API
-int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+int nhip_grid_build_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const int32_t *d_target_ids,
                         int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
                         void *d_workspace, int64_t workspace_bytes, void *stream) {
   int rc = require_device();
   if (rc) return rc;
   NHIP_REQUIRE(d_xy && d_offsets && d_target_ids && d_grids && d_workspace, "grid_build_dev: null pointer");
-  NHIP_REQUIRE(n_targets >= 0, "grid_build_dev: n_targets < 0");
+  NHIP_REQUIRE(n_targets >= 0 && n_scans >= 0, "grid_build_dev: n_targets %d / n_scans %d < 0", n_targets, n_scans);
   GridLayout L;
   rc = make_layout(spec, &L);
   if (rc) return rc;
   if (n_targets == 0) return NHIP_OK;
-  return launch_grid_build(d_xy, d_offsets, d_target_ids, n_targets, spec, L, d_grids, d_workspace,
+  return launch_grid_build(d_xy, d_offsets, n_scans, d_target_ids, n_targets, spec, L, d_grids, d_workspace,
                            workspace_bytes, static_cast<hipStream_t>(stream));
 }
 
-int nhip_grid_rebuild_dev(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+int nhip_grid_rebuild_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const int32_t *d_target_ids,
                           int32_t n_targets, const nhip_grid_spec_t *spec, uint8_t *d_grids,
                           void *d_workspace, int64_t workspace_bytes, void *stream) {
   int rc = require_device();
   if (rc) return rc;
   NHIP_REQUIRE(d_xy && d_offsets && d_target_ids && d_grids && d_workspace, "grid_rebuild_dev: null pointer");
-  NHIP_REQUIRE(n_targets >= 0, "grid_rebuild_dev: n_targets < 0");
+  NHIP_REQUIRE(n_targets >= 0 && n_scans >= 0, "grid_rebuild_dev: n_targets %d / n_scans %d < 0", n_targets, n_scans);
   GridLayout L;
   rc = make_layout(spec, &L);
   if (rc) return rc;
   if (n_targets == 0) return NHIP_OK;
-  return launch_grid_build(d_xy, d_offsets, d_target_ids, n_targets, spec, L, d_grids, d_workspace,
+  return launch_grid_build(d_xy, d_offsets, n_scans, d_target_ids, n_targets, spec, L, d_grids, d_workspace,
                            workspace_bytes, static_cast<hipStream_t>(stream), true);
 }
 
-int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
-                       const nhip_grid_spec_t *spec, const int32_t *d_pair_src,
+int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const uint8_t *d_grids,
+                       int32_t n_grids, const nhip_grid_spec_t *spec, const int32_t *d_pair_src,
                        const int32_t *d_pair_slot, const double *d_rot0_cs,
                        const double *d_delta_cs, const int32_t *d_pair_origin, int32_t n_pairs,
                        const nhip_search_t *search, uint64_t *d_keys, nhip_match_t *d_out,
@@ -423,16 +447,41 @@ int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, const uint8_
                    d_keys && d_out && search,
                "csm_match_dev: null pointer");
   NHIP_REQUIRE(workspace_bytes >= 0 && (d_workspace || workspace_bytes == 0), "csm_match_dev: bad workspace");
-  NHIP_REQUIRE(n_pairs >= 0, "csm_match_dev: n_pairs < 0");
+  NHIP_REQUIRE(n_pairs >= 0 && n_scans >= 0 && n_grids >= 0, "csm_match_dev: negative count (n_pairs %d, n_scans %d, n_grids %d)",
+               n_pairs, n_scans, n_grids);
   GridLayout L;
   rc = make_layout(spec, &L);
   if (rc) return rc;
-  return launch_csm_match(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs,
+  const IdBounds ids = {n_scans, n_grids, dev_status()};
+  return launch_csm_match(d_xy, d_offsets, ids, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs,
                           d_delta_cs, d_pair_origin, n_pairs, search, d_keys, d_out, d_sums,
                           static_cast<hipStream_t>(stream), d_workspace, workspace_bytes);
 }
 
 int64_t nhip_csm_workspace_bytes(int32_t n_pairs) { return bnb_workspace_bytes(n_pairs); }
+
+int nhip_dev_status(void *stream, int32_t info[4]) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+  uint32_t w[DEV_STATUS_WORDS] = {0u, 0u, 0u, 0u};
+  uint32_t *st = dev_status();
+  if (st) NHIP_TRY_HIP(hipMemcpy(w, st, sizeof(w), hipMemcpyDeviceToHost));
+  if (info)
+    for (int i = 0; i < 4; i++) info[i] = (int32_t)w[i];
+  if (w[0] == 0u) return NHIP_OK;
+  NHIP_TRY_HIP(hipMemset(st, 0, sizeof(w)));
+  const char *what = w[1] == BAD_TARGET_ID  ? "target scan id (nhip_grid_build_dev / nhip_grid_rebuild_dev: d_target_ids)"
+                     : w[1] == BAD_PAIR_SRC  ? "source scan id (nhip_csm_match_dev: d_pair_src)"
+                     : w[1] == BAD_PAIR_SLOT ? "grid slot (nhip_csm_match_dev: d_pair_slot)"
+                     : w[1] == BAD_BLOCK_ID  ? "block id (d_corr_block)"
+                     : w[1] == BAD_POSE_ID   ? "pose index (d_block_src / d_block_tgt / pose arrays)"
+                     : w[1] == BAD_SCAN_ID   ? "scan id (d_block_src / d_block_tgt of the correspondence search)"
+                                             : "id";
+  set_error("an id read from device memory was out of range: %s = %d at index %d (kinds seen since the last check: 0x%x); "
+            "the kernels treated every such entry as empty", what, (int32_t)w[2], (int32_t)w[3], w[0]);
+  return NHIP_ERR_ARG;
+}
 
 int nhip_csm_last_launch(int32_t out[8]) {
   NHIP_REQUIRE(out != nullptr, "csm_last_launch: null out");
@@ -440,8 +489,8 @@ int nhip_csm_last_launch(int32_t out[8]) {
   return NHIP_OK;
 }
 
-int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
-                        const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
+int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const uint8_t *d_grids,
+                        int32_t n_grids, const nhip_grid_spec_t *spec, int32_t src, int32_t slot,
                         const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x,
                         int32_t origin_y, const nhip_search_t *search, int32_t *d_sums,
                         void *stream) {
@@ -449,6 +498,8 @@ int nhip_csm_scores_dev(const float *d_xy, const int32_t *d_offsets, const uint8
   if (rc) return rc;
   NHIP_REQUIRE(d_xy && d_offsets && d_grids && d_rot0_cs && d_delta_cs && d_sums && search,
                "csm_scores_dev: null pointer");
+  NHIP_REQUIRE(src >= 0 && src < n_scans && slot >= 0 && slot < n_grids, "csm_scores_dev: scan %d of %d / grid slot %d of %d out of range",
+               src, n_scans, slot, n_grids);
   GridLayout L;
   rc = make_layout(spec, &L);
   if (rc) return rc;
@@ -639,7 +690,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
   }
   if (n_targets) {
     rc = launch_grid_build(static_cast<const float *>(scans->xy.p),
-                           static_cast<const int32_t *>(scans->offsets.p),
+                           static_cast<const int32_t *>(scans->offsets.p), scans->n_scans,
                            static_cast<const int32_t *>(ids.p), n_targets, spec, L,
                            static_cast<uint8_t *>(g->grids.p), ws.p, ws_bytes, nullptr);
     if (rc == NHIP_OK) {
@@ -808,7 +859,8 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
   NHIP_TRY_HIP(hipMemcpy(d_slot.p, pair_slot, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(d_rot0.p, rot0.data(), sizeof(double) * rot0.size(), hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(d_delta.p, delta.data(), sizeof(double) * delta.size(), hipMemcpyHostToDevice));
-  rc = launch_csm_match(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p),
+  const IdBounds idb = {scans->n_scans, grids->n, dev_status()};  // (checked on the host above; the kernels check again)
+  rc = launch_csm_match(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p), idb,
                         static_cast<const uint8_t *>(grids->grids.p), &spec_now, grids->L,
                         static_cast<const int32_t *>(d_src.p), static_cast<const int32_t *>(d_slot.p),
                         static_cast<const double *>(d_rot0.p), static_cast<const double *>(d_delta.p),
@@ -1008,25 +1060,43 @@ struct DropInScratch {
   int32_t n_theta1 = -1, n_theta2 = -1;
   double step1 = 0, step2 = 0;
 };
-thread_local DropInScratch *t_scratch = nullptr;  // (a few KB of device memory per calling thread, left to the process's end)
+// (a few KB of device memory per calling thread, freed when the thread ends: thread-local destructors -- the main thread's
+//  too -- run before the process's static destructors, i.e. while the HIP runtime is still there)
+struct ScratchHolder {
+  DropInScratch *p = nullptr;
+  ~ScratchHolder() { delete p; }
+};
+thread_local ScratchHolder t_scratch;
 
 int scratch_for(int device, int32_t n_a, const nhip_search_t &s1, const nhip_search_t &s2, DropInScratch **out) {
-  if (!t_scratch) t_scratch = new DropInScratch();
-  DropInScratch &S = *t_scratch;
+  if (!t_scratch.p) t_scratch.p = new DropInScratch();
+  DropInScratch &S = *t_scratch.p;
   int rc;
-  if (S.device != device) {
+  // (a failure below leaves the scratch EMPTY -- device -1 -- so that the thread's next call sets it up again instead of
+  //  finding the device it asked for and null buffers behind it)
+  auto reset = [&S]() {
     S.~DropInScratch();
     new (&S) DropInScratch();
-    S.device = device;
+  };
+  if (S.device != device) {
+    reset();
     const int32_t zeros[2 * DROPIN_PARTS_MAX] = {0};
     constexpr size_t G = DROPIN_PARTS_MAX;
     if ((rc = S.par.alloc(256)) || (rc = S.idx.alloc(8 * G)) || (rc = S.keys.alloc(8 * G)) || (rc = S.res.alloc(256)) ||
-        (rc = S.ws.alloc((size_t)bnb_workspace_bytes_lists((int32_t)G))))
+        (rc = S.ws.alloc((size_t)bnb_workspace_bytes_lists((int32_t)G)))) {
+      reset();
       return rc;
-    NHIP_TRY_HIP(hipMemcpy(S.idx.p, zeros, 8 * G, hipMemcpyHostToDevice));  // source scan 0, grid slot 0 for every part
+    }
+    const hipError_t e = hipMemcpy(S.idx.p, zeros, 8 * G, hipMemcpyHostToDevice);  // source scan 0, grid slot 0 for every part
+    if (e != hipSuccess) {
+      reset();
+      return hip_fail(e, "csm_get_transformation scratch", __FILE__, __LINE__);
+    }
+    S.device = device;
   }
   if ((size_t)n_a > S.xy_cap) {
     const size_t cap = std::max<size_t>((size_t)n_a, 2048);
+    S.xy_cap = 0;  // (DevBuf::alloc frees first: a failed allocation leaves no buffer, and no capacity that says otherwise)
     if ((rc = S.xy.alloc(sizeof(float) * 2 * cap))) return rc;
     S.xy_cap = cap;
   }
@@ -1101,7 +1171,8 @@ int match_one(DropInScratch &S, int32_t n_a, nhip_grids_t *g, const nhip_search_
   uint8_t *dp = static_cast<uint8_t *>(S.par.p), *dr = static_cast<uint8_t *>(S.res.p);
   nhip_search_t part = *search;
   part.n_theta = per;
-  rc = launch_csm_match(static_cast<const float *>(S.xy.p), reinterpret_cast<const int32_t *>(dp),
+  const IdBounds idb = {1, g->n, dev_status()};  // (the scratch holds one scan; every part reads scan 0, slot 0)
+  rc = launch_csm_match(static_cast<const float *>(S.xy.p), reinterpret_cast<const int32_t *>(dp), idb,
                         static_cast<const uint8_t *>(g->grids.p), &spec_now, g->L, static_cast<const int32_t *>(S.idx.p),
                         static_cast<const int32_t *>(S.idx.p) + DROPIN_PARTS_MAX, reinterpret_cast<const double *>(dp + 16),
                         static_cast<const double *>(d_delta), origin ? reinterpret_cast<const int32_t *>(dp + 144) : nullptr, parts,
@@ -1178,6 +1249,9 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   NHIP_REQUIRE(p->low_res > 0 && p->high_res > 0 && p->low_res >= p->high_res && p->trans_range >= 0 && rot_restriction >= 0,
                "csm_get_transformation: bad search parameters");
   const int32_t bits = p->cell_bits == 0 ? 16 : p->cell_bits;
+  // (sums are int32, as in nhip_csm_match: the longest source cloud whose largest possible sum fits)
+  NHIP_REQUIRE((int64_t)n_a <= 0x7fffffffll / (bits == 16 ? 65535 : 255), "csm_get_transformation: pc_a has %d points; with %d-bit "
+               "cells at most %lld fit the int32 sums", n_a, bits, (long long)(0x7fffffffll / (bits == 16 ? 65535 : 255)));
   int device = 0;
   NHIP_TRY_HIP(hipGetDevice(&device));
   double theta0 = rot_a - rot_b;  // math_util.h:81-89 AngleDiff
@@ -1269,7 +1343,13 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
     std::vector<std::shared_ptr<CachedTarget>> drop;  // (evicted entries are freed outside the lock; a thread still matching
     {                                                  //  against one keeps it alive through its own shared_ptr)
       std::lock_guard<std::mutex> lock(g_cache_mu);
-      if (T->bytes <= g_cache_cap) {
+      // (two threads that missed on the same target at once both built it: the second finds the first's entry and keeps
+      //  its own tables for this call only, so that no target counts twice against the cap)
+      bool have = false;
+      for (auto &c : g_cache)
+        have = have || (c->hash == h && c->device == device && c->cloud.size() == T->cloud.size() && same_params(c->params, *p) &&
+                        memcmp(c->cloud.data(), T->cloud.data(), b_bytes) == 0);
+      if (!have && T->bytes <= g_cache_cap) {
         g_cache.insert(g_cache.begin(), T);
         int64_t tot = 0;
         size_t keep = 0;

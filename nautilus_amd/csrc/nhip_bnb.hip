@@ -1650,8 +1650,12 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
   if ((int32_t)(bid >> 3) >= P.pairs_per_xcd || pair >= P.n_pairs) return;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  const int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
-  const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
+  int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
+  // (ids from device memory: a pair whose scan or slot lies outside the caller's counts is an empty scan -- it scores
+  //  nothing, like a scan without points -- and is reported through the device's status words; both instantiations see it)
+  const bool ids_ok = pair_ids_ok(P.ids, src, slot, pair, threadIdx.x == 0);
+  if (!ids_ok) src = slot = 0;
+  const int32_t beg = ids_ok ? P.offsets[src] : 0, n_pts = ids_ok ? P.offsets[src + 1] - beg : 0;
   const float2 *pts = P.xy + beg;
   const uint8_t *grid = P.grids + (size_t)slot * P.slot_bytes;
   const int32_t cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
@@ -2253,11 +2257,16 @@ int launch_main(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
   // (the split form's first kernel: its own workgroup size, and the queue's space replaced by the lists' and the order's)
   constexpr int THREADS = SP ? 64 * SPLIT_WAVES : BNB_THREADS;
   if (SP) lds = lds - (size_t)QCAP * 8 + (size_t)QSPACE_SPLIT * 8;
-  static std::atomic<size_t> lds_set{0};
-  if (lds > lds_set.load(std::memory_order_relaxed)) {
+  // (the attribute belongs to the function object of the CURRENT device: one high-water mark per device, so that a host
+  //  with one thread per device raises it on each of them)
+  constexpr int MAX_DEV = 64;
+  static std::atomic<size_t> lds_set[MAX_DEV];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) dev = -1;
+  if (dev < 0 || lds > lds_set[dev].load(std::memory_order_relaxed)) {
     NHIP_TRY_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_kernel<CB, PL, BR, SP>),
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    lds_set.store(lds, std::memory_order_relaxed);
+    if (dev >= 0) lds_set[dev].store(lds, std::memory_order_relaxed);
   }
 #if NHIP_BNB_INSTR
   if (P.stats && tunable("NHIP_BNB_OCCUPANCY")) {
@@ -2471,7 +2480,7 @@ static bool instrumented() {
 static thread_local int32_t t_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 void bnb_last_launch(int32_t out[8]) { memcpy(out, t_last_launch, sizeof(t_last_launch)); }
 
-int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                    const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                    const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                    const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
@@ -2488,6 +2497,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   P.grids = d_grids;
   P.pair_src = d_pair_src;
   P.pair_slot = d_pair_slot;
+  P.ids = ids;
   P.rot0_cs = d_rot0_cs;
   P.delta_cs = d_delta_cs;
   P.pair_origin = d_pair_origin;
@@ -2579,10 +2589,33 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   const char *kr = tunable("NHIP_BNB_KEEP_RANKS");
   // (lists that take the split form -- SPLIT_MIN_PAIRS pairs and more -- do not hand rotations over: their candidates'
   //  launch shares the heavy pairs among several workgroups)
-  const char *sp0 = tunable("NHIP_BNB_SPLIT");
-  const bool split_wanted = d_workspace && !(sp0 && sp0[0] == '0') && (n_pairs >= SPLIT_MIN_PAIRS || (sp0 && sp0[0] == '1')) &&
-                            workspace_bytes >= BNB_WS_HEADER + 512 + SPLIT_SLOT_FIXED + 512 * split_bytes_per_pair(P.n_theta);
-  const bool second = force ? force[0] == '2' : (n_pairs < 1024 && !split_wanted);
+  // The form is decided ONCE, here, from the sizes: the split form's rounds as the workspace allows them, and the
+  // hand-over lists only for lists that do not take the split form.  (Round 4 asked "is there room for 512 pairs' state"
+  // at this point and sized the rounds further down.  nhip_csm_workspace_bytes(n) of a list of 192 .. 487 pairs at 61
+  // rotations is LESS than 512 pairs' state, so for those lists the first test said no, the hand-over lists were set
+  // up, and the split form -- which the header promises from 192 pairs -- was never taken.  Same records; slower.)
+  const char *sp = tunable("NHIP_BNB_SPLIT");
+  const char *sbat = tunable("NHIP_BNB_SPLIT_BATCH");
+  const char *spp = tunable("NHIP_BNB_SPLIT_PAIRS");
+  const int64_t split_cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
+  int64_t split_batch = 0, split_slots = 0, slot_bytes = 0;
+  if (d_workspace && !P.general_all && P.debug == 0 && !(sp && sp[0] == '0') && !(force && force[0] == '2') &&
+      (n_pairs >= SPLIT_MIN_PAIRS || (sp && sp[0] == '1'))) {
+    split_batch = sbat && atoi(sbat) > 0 ? atoi(sbat) : split_cap;
+    if (split_batch > n_pairs) split_batch = n_pairs;
+    for (;;) {  // (a workspace too small for two batches in flight: smaller batches, down to 512 pairs)
+      slot_bytes = (SPLIT_SLOT_FIXED + split_batch * split_bytes_per_pair(P.n_theta) + 511) & ~(int64_t)511;
+      split_slots = (workspace_bytes - BNB_WS_HEADER - 512) / slot_bytes;
+      const int64_t rounds = (n_pairs + split_batch - 1) / split_batch;
+      if (split_slots >= (rounds < 2 ? rounds : 2) || split_batch <= 512) break;
+      split_batch = split_batch / 2 > 512 ? split_batch / 2 : 512;
+    }
+    if (split_slots > SPLIT_RING) split_slots = SPLIT_RING;
+    if (split_slots < 1) split_batch = 0;  // (no room: the fused form)
+    // (several rounds pay off only with the helper stream, i.e. with two rounds' state, and in rounds that are long)
+    if (!sbat && split_batch > 0 && n_pairs > split_batch && (split_slots < 2 || split_batch < split_cap)) split_batch = 0;
+  }
+  const bool second = force ? force[0] == '2' : (n_pairs < 1024 && split_batch == 0);
   P.heavy_min = hm ? (uint32_t)atoi(hm) : (n_pairs <= 64 ? 1u : 384u);
   P.keep_ranks = kr ? (uint32_t)atoi(kr) : 8u;
   if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * (int64_t)sizeof(RotEntry) && second && !P.general_all) {
@@ -2603,33 +2636,13 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   // Large batches: the split form, in rounds of as many pairs as the workspace holds state for.
   // NHIP_BNB_SPLIT=0: never, =1: whenever the workspace allows; NHIP_BNB_SPLIT_MIN=<candidates per additional
   // workgroup of a pair>, NHIP_BNB_SPLIT_MAX=<workgroups per pair>.
-  const char *sp = tunable("NHIP_BNB_SPLIT");
   const char *smin = tunable("NHIP_BNB_SPLIT_MIN");
   const char *smax = tunable("NHIP_BNB_SPLIT_MAX");
-  const char *sbat = tunable("NHIP_BNB_SPLIT_BATCH");
   const char *sov = tunable("NHIP_BNB_SPLIT_OVERLAP");
   const char *sco = tunable("NHIP_BNB_SORT_COARSE");  // (buckets of 2^n sixteenths of an octave: 4 = one per octave)
   const char *spr = tunable("NHIP_BNB_SPREAD");       // (0: round 3's work lists, a pair's workgroups all in its home XCD's)
   const bool spread_forced = spr && spr[0] == '1';
-  int64_t split_batch = 0, split_slots = 0, slot_bytes = 0;
-  const char *spp = tunable("NHIP_BNB_SPLIT_PAIRS");
-  const int64_t split_cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
-  if (d_workspace && !P.general_all && !P.rot_list && P.debug == 0 && !(sp && sp[0] == '0') &&
-      (n_pairs >= SPLIT_MIN_PAIRS || (sp && sp[0] == '1'))) {
-    split_batch = sbat && atoi(sbat) > 0 ? atoi(sbat) : split_cap;
-    if (split_batch > n_pairs) split_batch = n_pairs;
-    for (;;) {  // (a workspace too small for two batches in flight: smaller batches, down to 512 pairs)
-      slot_bytes = (SPLIT_SLOT_FIXED + split_batch * split_bytes_per_pair(P.n_theta) + 511) & ~(int64_t)511;
-      split_slots = (workspace_bytes - BNB_WS_HEADER - 512) / slot_bytes;
-      const int64_t rounds = (n_pairs + split_batch - 1) / split_batch;
-      if (split_slots >= (rounds < 2 ? rounds : 2) || split_batch <= 512) break;
-      split_batch = split_batch / 2 > 512 ? split_batch / 2 : 512;
-    }
-    if (split_slots > SPLIT_RING) split_slots = SPLIT_RING;
-    if (split_slots < 1) split_batch = 0;  // (no room: the fused form)
-    // (several rounds pay off only with the helper stream, i.e. with two rounds' state, and in rounds that are long)
-    if (!sbat && split_batch > 0 && n_pairs > split_batch && (split_slots < 2 || split_batch < split_cap)) split_batch = 0;
-  }
+  if (P.rot_list) split_batch = 0;  // (hand-over lists in the workspace: one kernel per pair)
   // (an error return between timer_begin and timer_end closes the open slot)
   struct TimerScope {
     int id;
@@ -2722,7 +2735,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
     if (overlap) NHIP_TRY_HIP(hipStreamWaitEvent(s, set->eb[(round - 1) % SPLIT_RING], 0));
     t_all.end();
     NHIP_TRY_HIP(hipGetLastError());
-    launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
+    launch_csm_finalize(d_keys, d_pair_src, d_offsets, ids.n_scans, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
     NHIP_TRY_HIP(hipGetLastError());
     return NHIP_OK;
   }
@@ -2733,7 +2746,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d
   if (rc) return rc;
   t_all.end();
   NHIP_TRY_HIP(hipGetLastError());
-  launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
+  launch_csm_finalize(d_keys, d_pair_src, d_offsets, ids.n_scans, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }

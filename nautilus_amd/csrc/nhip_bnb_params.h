@@ -18,6 +18,7 @@ struct BnbParams {
   const uint8_t *grids;
   const int32_t *pair_src;
   const int32_t *pair_slot;
+  IdBounds ids;  // counts the pairs' scan ids and grid slots are checked against (nhip_common.h)
   const double *rot0_cs;
   const double *delta_cs;
   const int32_t *pair_origin;

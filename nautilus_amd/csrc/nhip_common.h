@@ -39,6 +39,40 @@ int require_device();
 // process -- a shipped host -- never reads any of them: tunable() is a null pointer there and every policy is its default.
 const char *tunable(const char *name);
 
+// ---- ids that live in device memory ----
+// The "_dev" entry points read scan ids, grid slots, block and pose indices from DEVICE arrays the host cannot look at
+// without a round trip.  Every kernel checks such an id against the count its caller passed before it forms an address
+// from it: an id outside [0, count) is treated as an empty scan / a pair that scores nothing / a row that is skipped, and
+// is reported through the current device's status words, which nhip_dev_status() turns into NHIP_ERR_ARG after the
+// stream has drained.  A stale id costs the caller an error code, never the process (an out-of-bounds read in a kernel
+// is an HSA abort of the whole process; it happened once, in a test: DESIGN.md section 5, "Ids in device memory").
+struct IdBounds {          // (plain data: it travels inside the kernels' parameter blocks)
+  int32_t n_scans;         // scans behind d_offsets (n_scans + 1 entries)
+  int32_t n_slots;         // grids behind d_grids
+  uint32_t *status;        // the device's status words, or null (ids are still checked, nothing is reported)
+};
+constexpr uint32_t BAD_TARGET_ID = 1u, BAD_PAIR_SRC = 2u, BAD_PAIR_SLOT = 4u, BAD_BLOCK_ID = 8u, BAD_POSE_ID = 16u,
+                   BAD_SCAN_ID = 32u;
+constexpr int DEV_STATUS_WORDS = 4;  // {OR of the kinds seen, kind / value / index of the first report}
+uint32_t *dev_status();              // of the current device (allocated on the device's first use; null if that failed)
+#ifdef __HIPCC__
+__device__ __forceinline__ void flag_bad_id(uint32_t *status, uint32_t kind, int32_t value, int32_t index) {
+  if (!status) return;
+  if (atomicOr(status, kind) != 0u) return;  // (the first report keeps the details)
+  status[1] = kind;
+  status[2] = (uint32_t)value;
+  status[3] = (uint32_t)index;
+}
+__device__ __forceinline__ bool id_in(int32_t id, int32_t n) { return (uint32_t)id < (uint32_t)n; }
+// a pair's source scan and grid slot; false: the pair scores nothing (and is reported)
+__device__ __forceinline__ bool pair_ids_ok(const IdBounds &B, int32_t src, int32_t slot, int32_t pair, bool report) {
+  const bool s_ok = id_in(src, B.n_scans), g_ok = id_in(slot, B.n_slots);
+  if (s_ok && g_ok) return true;
+  if (report) flag_bad_id(B.status, s_ok ? BAD_PAIR_SLOT : BAD_PAIR_SRC, s_ok ? slot : src, pair);
+  return false;
+}
+#endif
+
 // ---- grid layout (host) ----
 struct GridLayout {
   int32_t S, pad, pitch, R;
@@ -131,11 +165,11 @@ void timer_begin(int id, hipStream_t s);
 void timer_end(int id, hipStream_t s);
 
 // ---- kernel launchers (defined in the .hip files) ----
-int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const int32_t *d_target_ids,
                       int32_t n_targets, const nhip_grid_spec_t *spec, const GridLayout &L,
                       uint8_t *d_grids, void *d_ws, int64_t ws_bytes, hipStream_t s, bool incremental = false);
 
-int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
@@ -143,7 +177,7 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
                      void *d_workspace = nullptr, int64_t workspace_bytes = 0, const int32_t *d_pair_kbase = nullptr);
 
 // branch-and-bound matcher (nhip_bnb.hip); returns NHIP_ERR_STATE-free: `*handled` = 0 when the lattice does not fit it
-int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                    const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                    const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                    const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
@@ -157,7 +191,7 @@ int bnb_stats_read(unsigned long long out[16]);
 int bnb_timeline_read(unsigned long long *out, int32_t n);
 int bnb_timeline_cand_read(unsigned long long *out, int32_t n);
 int bnb_stats_per_pair(unsigned long long *out, int32_t n);
-void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, const int32_t *d_offsets, int32_t n_pairs,
+void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, const int32_t *d_offsets, int32_t n_scans, int32_t n_pairs,
                          int32_t nx, int32_t ny, const GridLayout &L, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s);
 
 int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
@@ -167,7 +201,7 @@ int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t
                       hipStream_t s);
 
 // the kernel that performs every add, 16-bit cells (nhip_csm16.hip); called by launch_csm_match / launch_csm_scores
-int launch_csm16_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+int launch_csm16_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                        const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                        const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                        const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
@@ -178,7 +212,7 @@ int launch_csm16_scores(const float *d_xy, const int32_t *d_offsets, const uint8
                         const nhip_search_t *search, int32_t *d_sums, hipStream_t s);
 // every add for lattices of few translations (nx * ny <= 256), both cell widths (nhip_csm_small.hip)
 bool csm_small_plane_fits(const nhip_search_t *search);
-int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                            const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                            const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                            const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,

@@ -204,9 +204,12 @@ __global__ __launch_bounds__(CSM_THREADS, NHIP_WAVES_PER_SIMD) void csm_correlat
   const int32_t nyb = min(P.ny - oy, PB_NY);  // plane rows of this block (1..21)
   const int32_t row_span = TILE_ROWS - nyb;   // max (prow - tile_row0) of a covered point
 
-  const int32_t src = VOLUME ? P.single_src : P.pair_src[pair];
-  const int32_t slot = VOLUME ? P.single_slot : P.pair_slot[pair];
-  const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
+  int32_t src = VOLUME ? P.single_src : P.pair_src[pair];
+  int32_t slot = VOLUME ? P.single_slot : P.pair_slot[pair];
+  // (ids from device memory: a pair whose scan or slot lies outside the caller's counts scores nothing and is reported)
+  const bool ids_ok = VOLUME || pair_ids_ok(P.ids, src, slot, pair, threadIdx.x == 0 && w == 0);
+  if (!ids_ok) src = slot = 0;
+  const int32_t beg = ids_ok ? P.offsets[src] : 0, n_pts = ids_ok ? P.offsets[src + 1] - beg : 0;
   const uint8_t *grid = P.grids + (size_t)slot * P.slot_bytes;
   const uint8_t *skip_map = grid + P.grid_bytes;
   const int32_t mpitch = skip_pitch(P.pitch);
@@ -387,7 +390,7 @@ __global__ __launch_bounds__(CSM_THREADS, NHIP_WAVES_PER_SIMD) void csm_correlat
 
 __global__ void csm_finalize_kernel(const unsigned long long *__restrict__ keys,
                                     const int32_t *__restrict__ pair_src,
-                                    const int32_t *__restrict__ offsets, int32_t n_pairs,
+                                    const int32_t *__restrict__ offsets, int32_t n_scans, int32_t n_pairs,
                                     int32_t nx, int32_t ny, double Lf, double step,
                                     nhip_match_t *__restrict__ out, int32_t *__restrict__ sums) {
   const int32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -396,7 +399,7 @@ __global__ void csm_finalize_kernel(const unsigned long long *__restrict__ keys,
   const uint32_t sum = (uint32_t)(key >> 32);
   const uint32_t lin = 0xffffffffu - (uint32_t)key;
   const int32_t src = pair_src[i];
-  const int32_t n = offsets[src + 1] - offsets[src];
+  const int32_t n = id_in(src, n_scans) ? offsets[src + 1] - offsets[src] : 0;  // (an id out of range: the matcher reported it)
   nhip_match_t m;
   m.iy = (int32_t)(lin % (uint32_t)ny);
   m.ix = (int32_t)((lin / (uint32_t)ny) % (uint32_t)nx);
@@ -455,14 +458,14 @@ bool csm_takes_exhaustive(const GridLayout &L, const nhip_search_t *search) {
   return (search->flags & NHIP_SEARCH_EXHAUSTIVE) || (ex && ex[0] == '1') || !bnb_fits(L, search);
 }
 
-void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, const int32_t *d_offsets, int32_t n_pairs,
+void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, const int32_t *d_offsets, int32_t n_scans, int32_t n_pairs,
                          int32_t nx, int32_t ny, const GridLayout &L, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s) {
   hipLaunchKernelGGL(csm_finalize_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s,
-                     reinterpret_cast<const unsigned long long *>(d_keys), d_pair_src, d_offsets, n_pairs, nx, ny, L.Lf,
+                     reinterpret_cast<const unsigned long long *>(d_keys), d_pair_src, d_offsets, n_scans, n_pairs, nx, ny, L.Lf,
                      L.step, d_out, d_sums);
 }
 
-int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
@@ -477,7 +480,7 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
   if (n_pairs == 0) return NHIP_OK;
   if (!exhaustive) {  // branch and bound: the same records, most adds never performed (nhip_bnb.hip)
     int handled = 0;
-    rc = launch_csm_bnb(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
+    rc = launch_csm_bnb(d_xy, d_offsets, ids, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
                         d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s, &handled, d_workspace, workspace_bytes,
                         d_pair_kbase);
     if (rc || handled) return rc;
@@ -486,10 +489,10 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
   // (NHIP_CSM_SMALL=0, measurement / tests: the strip kernels below for these lattices too)
   const char *sm = tunable("NHIP_CSM_SMALL");
   if (csm_small_plane_fits(search) && !(sm && sm[0] == '0'))
-    return launch_csm_small_match(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
+    return launch_csm_small_match(d_xy, d_offsets, ids, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
                                   d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s);
   if (L.cb == 2)
-    return launch_csm16_match(d_xy, d_offsets, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
+    return launch_csm16_match(d_xy, d_offsets, ids, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
                               d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s);
   CsmParams P;
   fill_params(P, spec, L, search);
@@ -498,6 +501,7 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
   P.grids = d_grids;
   P.pair_src = d_pair_src;
   P.pair_slot = d_pair_slot;
+  P.ids = ids;
   P.rot0_cs = d_rot0_cs;
   P.delta_cs = d_delta_cs;
   P.pair_origin = d_pair_origin;
@@ -515,7 +519,7 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const uint8_t 
     hipLaunchKernelGGL((csm_correlate_kernel<false, false>), dim3((uint32_t)blocks), dim3(CSM_THREADS), 0, s, P);
   timer_end(NHIP_TIMER_CSM, s);
   hipLaunchKernelGGL(csm_finalize_kernel, dim3((n_pairs + 255) / 256), dim3(256), 0, s, P.keys,
-                     d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L.Lf, L.step, d_out, d_sums);
+                     d_pair_src, d_offsets, ids.n_scans, n_pairs, P.nx, P.ny, L.Lf, L.step, d_out, d_sums);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }

@@ -225,9 +225,12 @@ __global__ __launch_bounds__(THREADS, NHIP_C16_WAVES_PER_SIMD) void csm_correlat
   const int32_t nyb = min(P.ny - oy, PB_NY);  // plane rows of this block
   const int32_t row_span = TILE_ROWS - nyb;   // max (prow - tile_row0) of a covered point
 
-  const int32_t src = VOLUME ? P.single_src : P.pair_src[pair];
-  const int32_t slot = VOLUME ? P.single_slot : P.pair_slot[pair];
-  const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
+  int32_t src = VOLUME ? P.single_src : P.pair_src[pair];
+  int32_t slot = VOLUME ? P.single_slot : P.pair_slot[pair];
+  // (ids from device memory: a pair whose scan or slot lies outside the caller's counts scores nothing and is reported)
+  const bool ids_ok = VOLUME || pair_ids_ok(P.ids, src, slot, pair, threadIdx.x == 0 && w == 0);
+  if (!ids_ok) src = slot = 0;
+  const int32_t beg = ids_ok ? P.offsets[src] : 0, n_pts = ids_ok ? P.offsets[src + 1] - beg : 0;
   const uint8_t *grid = P.grids + (size_t)slot * P.slot_bytes;
   const uint8_t *skip_map = grid + P.grid_bytes;
   const int32_t mpitch = skip_pitch(P.pitch);
@@ -403,7 +406,7 @@ void fill_params16(CsmParams &P, const nhip_grid_spec_t *spec, const GridLayout 
 
 }  // namespace
 
-int launch_csm16_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+int launch_csm16_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                        const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                        const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                        const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
@@ -415,6 +418,7 @@ int launch_csm16_match(const float *d_xy, const int32_t *d_offsets, const uint8_
   P.grids = d_grids;
   P.pair_src = d_pair_src;
   P.pair_slot = d_pair_slot;
+  P.ids = ids;
   P.rot0_cs = d_rot0_cs;
   P.delta_cs = d_delta_cs;
   P.pair_origin = d_pair_origin;
@@ -431,7 +435,7 @@ int launch_csm16_match(const float *d_xy, const int32_t *d_offsets, const uint8_
   else
     hipLaunchKernelGGL((csm_correlate16_kernel<false, false>), dim3((uint32_t)blocks), dim3(THREADS), 0, s, P);
   timer_end(NHIP_TIMER_CSM, s);
-  launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
+  launch_csm_finalize(d_keys, d_pair_src, d_offsets, ids.n_scans, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }

@@ -47,8 +47,11 @@ __global__ __launch_bounds__(SMALL_THREADS) void csm_small_plane_kernel(CsmParam
   const int32_t pair = (int32_t)(blockIdx.x / (uint32_t)P.n_theta);
   const int32_t k = (int32_t)(blockIdx.x % (uint32_t)P.n_theta);
   if (pair >= P.n_pairs) return;
-  const int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
-  const int32_t beg = P.offsets[src], n_pts = P.offsets[src + 1] - beg;
+  int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
+  // (ids from device memory: a pair whose scan or slot lies outside the caller's counts scores nothing and is reported)
+  const bool ids_ok = pair_ids_ok(P.ids, src, slot, pair, threadIdx.x == 0 && k == 0);
+  if (!ids_ok) src = slot = 0;
+  const int32_t beg = ids_ok ? P.offsets[src] : 0, n_pts = ids_ok ? P.offsets[src + 1] - beg : 0;
   const float2 *pts = P.xy + beg;
   const uint8_t *grid = P.grids + (size_t)slot * P.slot_bytes;
   const int32_t cx = P.pair_origin ? P.pair_origin[2 * pair] : 0;
@@ -140,7 +143,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void csm_small_plane_kernel(CsmParam
 
 bool csm_small_plane_fits(const nhip_search_t *search) { return (int64_t)search->nx * search->ny <= 64 * SMALL_PASSES; }
 
-int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const uint8_t *d_grids,
+int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                            const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                            const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                            const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
@@ -152,6 +155,7 @@ int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const ui
   P.grids = d_grids;
   P.pair_src = d_pair_src;
   P.pair_slot = d_pair_slot;
+  P.ids = ids;
   P.rot0_cs = d_rot0_cs;
   P.delta_cs = d_delta_cs;
   P.pair_origin = d_pair_origin;
@@ -186,7 +190,7 @@ int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const ui
   }
 #undef NHIP_SMALL_LAUNCH
   timer_end(NHIP_TIMER_CSM, s);
-  launch_csm_finalize(d_keys, d_pair_src, d_offsets, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
+  launch_csm_finalize(d_keys, d_pair_src, d_offsets, ids.n_scans, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }

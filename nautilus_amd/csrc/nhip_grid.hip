@@ -37,15 +37,28 @@ __device__ __forceinline__ bool hit_cell(float2 q, int32_t S, double res, double
   return true;
 }
 
+// The points of target scan `scan` (an id read from device memory): an id outside [0, n_scans) is an EMPTY scan -- its
+// grid comes out all floor -- and is reported through the device's status words (nhip_dev_status), never dereferenced.
+__device__ __forceinline__ void target_points(const int32_t *__restrict__ offsets, int32_t n_scans, int32_t scan, int32_t index,
+                                              uint32_t *status, bool report, int32_t *beg, int32_t *end) {
+  *beg = *end = 0;
+  if (id_in(scan, n_scans)) {
+    *beg = offsets[scan];
+    *end = offsets[scan + 1];
+  } else if (report) {
+    flag_bad_id(status, BAD_TARGET_ID, scan, index);
+  }
+}
+
 // One block per target scan: mark every 64x64 tile whose blur halo contains a hit.  (There is no
 // hit raster: the blur kernel gathers a tile's hits straight from the point list.)
 __global__ __launch_bounds__(256) void grid_occupancy_kernel(
     const float2 *__restrict__ xy, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ target_ids, int32_t t0, uint8_t *__restrict__ occ, int32_t S, int32_t tiles,
-    int32_t R, double res, double inv_res) {
+    int32_t R, double res, double inv_res, int32_t n_scans, uint32_t *__restrict__ status) {
   const int32_t t = blockIdx.x;
-  const int32_t scan = target_ids[t0 + t];
-  const int32_t beg = offsets[scan], end = offsets[scan + 1];
+  int32_t beg, end;
+  target_points(offsets, n_scans, target_ids[t0 + t], t0 + t, status, threadIdx.x == 0, &beg, &end);
   uint8_t *o = occ + (size_t)t * tiles * tiles;
   for (int32_t p = beg + threadIdx.x; p < end; p += blockDim.x) {
     int32_t c, r;
@@ -66,12 +79,13 @@ constexpr int OCC_WORDS_MAX = 2048;  // tiles^2 <= 65,536 bits (sides of up to 1
 __global__ __launch_bounds__(256) void grid_occupancy_list_kernel(
     const float2 *__restrict__ xy, const int32_t *__restrict__ offsets,
     const int32_t *__restrict__ target_ids, int32_t t0, uint8_t *__restrict__ occ, int32_t S, int32_t tiles,
-    int32_t R, double res, double inv_res, int32_t *__restrict__ count, int32_t *__restrict__ list) {
+    int32_t R, double res, double inv_res, int32_t *__restrict__ count, int32_t *__restrict__ list, int32_t n_scans,
+    uint32_t *__restrict__ status) {
   __shared__ uint32_t sBits[OCC_WORDS_MAX];
   __shared__ int32_t sBase, sN;
   const int32_t t = blockIdx.x, nt = tiles * tiles, nw = (nt + 31) / 32;
-  const int32_t scan = target_ids[t0 + t];
-  const int32_t beg = offsets[scan], end = offsets[scan + 1];
+  int32_t beg, end;
+  target_points(offsets, n_scans, target_ids[t0 + t], t0 + t, status, threadIdx.x == 0, &beg, &end);
   for (int i = threadIdx.x; i < nw; i += 256) sBits[i] = 0u;
   if (threadIdx.x == 0) sN = 0;
   __syncthreads();
@@ -145,7 +159,8 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
                                                         int32_t pad, int32_t pitch, int64_t slot_bytes,
                                                         int32_t R, double res, double inv_res, GridKernelTables tab,
                                                         const uint32_t *__restrict__ thr16, int64_t hi_offset,
-                                                        int32_t hi_tpr, int64_t hi_copy_bytes, int32_t t16_tpr) {
+                                                        int32_t hi_tpr, int64_t hi_copy_bytes, int32_t t16_tpr,
+                                                        int32_t n_scans) {
   __shared__ uint32_t sA[TILE][TILE + 1];
   __shared__ uint16_t sHits[MAX_TILE_HITS];
   __shared__ uint32_t sSeen[(TH_MAX * TH_MAX + 31) / 32];  // one bit per neighbourhood cell: a cell is a hit once
@@ -169,8 +184,9 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
     // hits of the neighbourhood -> list (row, column packed; TH <= 96): every point of the target scan
     // whose cell falls inside, each cell once
     {
-      const int32_t scan = target_ids[t0 + t];
-      const int32_t beg = offsets[scan], end = offsets[scan + 1];
+      // (a target whose id is out of range has no tiles on the list: the occupancy kernel reported it)
+      int32_t beg, end;
+      target_points(offsets, n_scans, target_ids[t0 + t], t0 + t, nullptr, false, &beg, &end);
       // (the neighbourhood in metres, a cell wider on every side: nineteen points in twenty lie outside it and are
       //  dropped by four single-precision compares instead of two double-precision quotients; the exact test follows)
       const float resf = (float)res;
@@ -773,9 +789,10 @@ void launch_pool8_from_pool4(uint8_t *g, const GridLayout &L, int32_t n, hipStre
 
 }  // namespace
 
-int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t *d_target_ids,
+int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, const int32_t *d_target_ids,
                       int32_t n_targets, const nhip_grid_spec_t *spec, const GridLayout &L,
                       uint8_t *d_grids, void *d_ws, int64_t ws_bytes, hipStream_t s, bool incremental) {
+  uint32_t *const status = dev_status();
   NHIP_REQUIRE(L.R <= MAX_R, "grid_build: blur radius %d > %d (sigma too large)", L.R, MAX_R);
   NHIP_REQUIRE(L.K * L.K < (1ll << 32), "grid_build: tap sum overflows 32-bit accumulation");
   NHIP_REQUIRE(L.pitch % 4 == 0, "grid_build: pitch must be a multiple of 4");
@@ -854,13 +871,13 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
       timer_end(NHIP_TIMER_GRID_CLEAR, s);
       hipLaunchKernelGGL(grid_occupancy_list_kernel, dim3(n), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
-                         (int32_t)t0, occ, L.S, tiles, L.R, spec->res, inv_res, count, list);
+                         (int32_t)t0, occ, L.S, tiles, L.R, spec->res, inv_res, count, list, n_scans, status);
     } else {
       NHIP_TRY_HIP(hipMemsetAsync(occ, 0, occ_bytes, s));
       timer_end(NHIP_TIMER_GRID_CLEAR, s);
       hipLaunchKernelGGL(grid_occupancy_kernel, dim3(n), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids,
-                         (int32_t)t0, occ, L.S, tiles, L.R, spec->res, inv_res);
+                         (int32_t)t0, occ, L.S, tiles, L.R, spec->res, inv_res, n_scans, status);
       hipLaunchKernelGGL(grid_tile_list_kernel, dim3((n_tiles_total + 255) / 256), dim3(256), 0, s, occ,
                          n_tiles_total, count, list);
     }
@@ -870,12 +887,12 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, const int32_t
       hipLaunchKernelGGL(grid_blur_kernel<1>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, 0);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, 0, n_scans);
     else
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr, n_scans);
     // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernels that
     // perform every add; the branch-and-bound matcher never reads it, so 16-bit grids -- its product path -- carry
     // one only when the spec asks.)

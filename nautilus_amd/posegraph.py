@@ -154,9 +154,10 @@ class HipBackend:
         d_keys = torch.empty(n, dtype=torch.int64, device=dev)
         d_out = torch.empty((n, 4), dtype=torch.int32, device=dev)
         sp = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
-        check(lib.nhip_grid_build_dev(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), len(ids), C.byref(spec),
+        n_sub = len(sub_off) - 1
+        check(lib.nhip_grid_build_dev(d_xy.data_ptr(), d_off.data_ptr(), n_sub, d_ids.data_ptr(), len(ids), C.byref(spec),
                                       d_grids.data_ptr(), d_ws_g.data_ptr(), ws_g, sp))
-        check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), d_grids.data_ptr(), C.byref(spec), d_src.data_ptr(),
+        check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), n_sub, d_grids.data_ptr(), len(ids), C.byref(spec), d_src.data_ptr(),
                                      d_slot.data_ptr(), d_rot0.data_ptr(), d_delta.data_ptr(), None, n, C.byref(search),
                                      d_keys.data_ptr(), d_out.data_ptr(), None, d_ws_m.data_ptr(), ws_m, sp))
         m = d_out.cpu().numpy().view(csm.MATCH_DTYPE).reshape(-1).copy()

@@ -157,7 +157,7 @@ def test_compute_fails_loudly_without_gpu():
     with pytest.raises(_lib.NhipError):
         csm.ScanTable(xy, off)
     spec = csm.grid_spec()
-    rc = _lib.load().nhip_grid_build_dev(None, None, None, 0, C.byref(spec), None, None, 0, None)
+    rc = _lib.load().nhip_grid_build_dev(None, None, 0, None, 0, C.byref(spec), None, None, 0, None)
     assert rc == _lib.NHIP_ERR_NODEV
 
 

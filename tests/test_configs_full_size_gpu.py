@@ -66,7 +66,7 @@ def test_config3_full_list_takes_the_overlapped_rounds_and_equals_every_add(gpu)
     keys = torch.empty(n, dtype=torch.int64, device=dev)
     out = torch.empty((n, 4), dtype=torch.int32, device=dev)
     osum = torch.empty(n, dtype=torch.int32, device=dev)
-    _lib.check(lib.nhip_csm_match_dev(m.d_xy.data_ptr(), m.d_off.data_ptr(), m.d_grids.data_ptr(), C.byref(m.spec),
+    _lib.check(lib.nhip_csm_match_dev(m.d_xy.data_ptr(), m.d_off.data_ptr(), m.n_scans, m.d_grids.data_ptr(), m.n_targets, C.byref(m.spec),
                                       m.d_src.data_ptr() + 4 * a, m.d_slot.data_ptr() + 4 * a, m.d_rot0.data_ptr() + 16 * a,
                                       m.d_delta.data_ptr(), None, n, C.byref(ex), keys.data_ptr(), out.data_ptr(),
                                       osum.data_ptr(), None, 0, m.sp))

@@ -691,10 +691,11 @@ def test_device_pointer_api_on_torch_stream(gpu, small_bag):
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         sp = C.c_void_p(stream.cuda_stream)
-        _lib.check(lib.nhip_grid_build_dev(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), 2, C.byref(spec),
+        n_sc = d_off.numel() - 1
+        _lib.check(lib.nhip_grid_build_dev(d_xy.data_ptr(), d_off.data_ptr(), n_sc, d_ids.data_ptr(), 2, C.byref(spec),
                                            d_grids.data_ptr(), d_ws.data_ptr(), ws_bytes, sp))
         # without a workspace (each pair's workgroup evaluates its own candidates) ...
-        _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), d_grids.data_ptr(), C.byref(spec),
+        _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), n_sc, d_grids.data_ptr(), 2, C.byref(spec),
                                           d_src.data_ptr(), d_slot.data_ptr(), d_rot0.data_ptr(),
                                           d_delta.data_ptr(), None, 4, C.byref(search), d_keys.data_ptr(),
                                           d_out.data_ptr(), d_sums.data_ptr(), None, 0, sp))
@@ -704,7 +705,7 @@ def test_device_pointer_api_on_torch_stream(gpu, small_bag):
         for nbytes in (lib.nhip_csm_workspace_bytes(4), 256 + 8 * 16 * 8):
             d_cws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             d_out.zero_()
-            _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), d_grids.data_ptr(), C.byref(spec),
+            _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), n_sc, d_grids.data_ptr(), 2, C.byref(spec),
                                               d_src.data_ptr(), d_slot.data_ptr(), d_rot0.data_ptr(),
                                               d_delta.data_ptr(), None, 4, C.byref(search), d_keys.data_ptr(),
                                               d_out.data_ptr(), d_sums.data_ptr(), d_cws.data_ptr(), nbytes, sp))
@@ -1057,7 +1058,7 @@ def test_grid_rebuild_clears_what_the_last_build_wrote(gpu, small_bag, cell_bits
 
     def call(fn, ids, d_grids, d_ws):
         d_ids = t(np.asarray(ids, dtype=np.int32))
-        _lib.check(fn(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), n, C.byref(spec), d_grids.data_ptr(),
+        _lib.check(fn(d_xy.data_ptr(), d_off.data_ptr(), d_off.numel() - 1, d_ids.data_ptr(), n, C.byref(spec), d_grids.data_ptr(),
                       d_ws.data_ptr(), ws_bytes, sp))
         torch.cuda.synchronize()
         return d_grids[:n * L.slot_bytes].cpu().numpy().copy()
@@ -1106,8 +1107,8 @@ def test_pooled_tables_from_the_tile_list_equal_the_band_kernels(gpu, small_bag,
             for fn, ids in ((lib.nhip_grid_build_dev, [3, 17, 40, 5]), (lib.nhip_grid_rebuild_dev, [25, 8, 3, 44]),
                             (lib.nhip_grid_rebuild_dev, [25, 8, 3, 44])):
                 d_ids = t(np.asarray(ids, dtype=np.int32))
-                _lib.check(fn(d_xy.data_ptr(), d_off.data_ptr(), d_ids.data_ptr(), n, C.byref(spec), G.data_ptr(), W.data_ptr(),
-                              ws_bytes, sp))
+                _lib.check(fn(d_xy.data_ptr(), d_off.data_ptr(), d_off.numel() - 1, d_ids.data_ptr(), n, C.byref(spec), G.data_ptr(),
+                              W.data_ptr(), ws_bytes, sp))
                 torch.cuda.synchronize()
                 out.append(G[:n * L.slot_bytes].cpu().numpy().copy())
             return out
@@ -1150,3 +1151,148 @@ def test_environment_switches_need_nhip_tunables(gpu):
     assert out["0"][1] == "1", "without NHIP_TUNABLES the switch must be ignored: 300 pairs take the split form"
     assert out["1"][1] == "0", "with NHIP_TUNABLES=1 NHIP_BNB_SPLIT=0 selects the one-kernel form"
     assert out["0"][3] == out["1"][3], "both forms return the same records"
+
+
+@pytest.mark.parametrize("cell_bits", [16, 8])
+def test_ids_in_device_memory_out_of_range_cost_an_error_not_the_process(gpu, small_bag, cell_bits):
+    """The ids a "_dev" entry point reads from device memory are checked by the kernels against the counts passed beside
+    them (include/nautilus_hip.h, "Ids in device memory"; the reference CHECKs such input, slam_residuals.h:99-101,109).
+    Round 4 lost a process to exactly the ids below: scan 60 of a 48-scan bag handed to nhip_grid_rebuild_dev
+    (gpurun_out/diag_csm.log).  Now: the bad target's grid is all floor, the others are what a build of
+    the good ids alone gives, nhip_dev_status() returns NHIP_ERR_ARG naming the id, once; a pair list with one bad source
+    and one bad slot leaves those two records at (0, 0, 0, floor score) and every other record untouched -- in every form
+    of the matcher and in the kernels that perform every add."""
+    import os
+    import torch
+    dev = torch.device("cuda:0")
+    lib = _lib.load()
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits)
+    L = csm.grid_layout(spec)
+    xy, off = csm.pack_scans(small_bag.scans)
+    n_scans = len(off) - 1
+    assert n_scans == 48
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_xy, d_off = t(xy), t(off)
+    n = 4
+    nbytes = lib.nhip_grids_bytes(C.byref(spec), n)
+    ws_bytes = lib.nhip_grid_workspace_bytes(C.byref(spec), n)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    info = (C.c_int32 * 4)()
+    assert lib.nhip_dev_status(sp, info) == _lib.NHIP_OK  # nothing pending
+
+    def build(fn, ids, G, W):
+        d_ids = t(np.asarray(ids, dtype=np.int32))
+        _lib.check(fn(d_xy.data_ptr(), d_off.data_ptr(), n_scans, d_ids.data_ptr(), n, C.byref(spec), G.data_ptr(), W.data_ptr(),
+                      ws_bytes, sp))
+        return lib.nhip_dev_status(sp, info)
+
+    G = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    W = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+    assert build(lib.nhip_grid_build_dev, [3, 17, 40, 5], G, W) == _lib.NHIP_OK
+    # the ids of the failing log, through the rebuild (the call that aborted)
+    rc = build(lib.nhip_grid_rebuild_dev, [25, 8, 3, 60], G, W)
+    assert rc == _lib.NHIP_ERR_ARG and list(info) == [1, 1, 60, 3], (rc, list(info))
+    msg = lib.nhip_last_error().decode()
+    assert "d_target_ids" in msg and "60" in msg, msg
+    assert lib.nhip_dev_status(sp, info) == _lib.NHIP_OK and list(info) == [0, 0, 0, 0]  # reported once
+    got = G[:n * L.slot_bytes].cpu().numpy().reshape(n, L.slot_bytes)
+    G2 = torch.zeros(nbytes, dtype=torch.uint8, device=dev)
+    assert build(lib.nhip_grid_build_dev, [25, 8, 3, 3], G2, torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)) == _lib.NHIP_OK
+    want = G2[:n * L.slot_bytes].cpu().numpy().reshape(n, L.slot_bytes)
+    assert np.array_equal(got[:3], want[:3]) and not got[3].any(), "good targets as built alone, the bad one all floor"
+    # negative and huge ids, first build
+    rc = build(lib.nhip_grid_build_dev, [-1, 8, 2 ** 31 - 1, 3], G, W)
+    assert rc == _lib.NHIP_ERR_ARG and info[0] == 1 and info[2] in (-1, 2 ** 31 - 1)
+    assert build(lib.nhip_grid_build_dev, [25, 8, 3, 44], G, W) == _lib.NHIP_OK
+
+    # ---- pair lists
+    search = csm.search_spec(61, 81, 81, DEG)
+    rng = np.random.default_rng(5)
+    n_pairs = 40
+    src = rng.integers(0, n_scans, n_pairs).astype(np.int32)
+    slot = rng.integers(0, n, n_pairs).astype(np.int32)
+    th0 = rng.uniform(-0.2, 0.2, n_pairs)
+    rot0 = np.empty((n_pairs, 2))
+    _lib.check(lib.nhip_csm_rot0(_lib.ptr(th0), None, n_pairs, _lib.ptr(rot0)))
+    d_rot0 = t(rot0)
+    d_keys = torch.empty(n_pairs, dtype=torch.int64, device=dev)
+    d_out = torch.empty((n_pairs, 4), dtype=torch.int32, device=dev)
+    d_sums = torch.empty(n_pairs, dtype=torch.int32, device=dev)
+    ws = lib.nhip_csm_workspace_bytes(n_pairs)
+    d_ws = torch.empty(ws, dtype=torch.uint8, device=dev)
+
+    def match(src_, slot_, srch):
+        d_src, d_slot = t(src_), t(slot_)
+        d_delta = t(csm.delta_table(srch))
+        d_out.fill_(-7)
+        _lib.check(lib.nhip_csm_match_dev(d_xy.data_ptr(), d_off.data_ptr(), n_scans, G.data_ptr(), n, C.byref(spec),
+                                          d_src.data_ptr(), d_slot.data_ptr(), d_rot0.data_ptr(), d_delta.data_ptr(), None,
+                                          n_pairs, C.byref(srch), d_keys.data_ptr(), d_out.data_ptr(), d_sums.data_ptr(),
+                                          d_ws.data_ptr(), ws, sp))
+        rc_ = lib.nhip_dev_status(sp, info)
+        return rc_, d_out.cpu().numpy().copy(), d_sums.cpu().numpy().copy()
+
+    rc, good, good_sums = match(src, slot, search)
+    assert rc == _lib.NHIP_OK
+    bad_src, bad_slot = src.copy(), slot.copy()
+    bad_src[7], bad_slot[19] = 60, n + 2
+    floor = np.float32(math.log(1e-10))
+    ex = csm.search_spec(61, 81, 81, DEG, exhaustive=True)
+    small = csm.search_spec(9, 13, 13, DEG, exhaustive=True)
+    forms = [({}, search), ({"NHIP_BNB_KERNELS": "1"}, search), ({"NHIP_BNB_KERNELS": "1", "NHIP_BNB_QUEUE": "1"}, search),
+             ({"NHIP_BNB_KERNELS": "1", "NHIP_BNB_SPLIT": "1"}, search),
+             ({"NHIP_BNB_KERNELS": "1", "NHIP_BNB_SPLIT": "1", "NHIP_BNB_SPLIT_BATCH": "3"}, search), ({}, ex), ({}, small)]
+    for env, srch in forms:
+        os.environ.update(env)
+        try:
+            rc0, ref, ref_sums = match(src, slot, srch)
+            rc, rec, sums = match(bad_src, bad_slot, srch)
+        finally:
+            for k_ in env:
+                os.environ.pop(k_, None)
+        assert rc0 == _lib.NHIP_OK
+        if srch is search or srch is ex:
+            assert np.array_equal(ref, good) and np.array_equal(ref_sums, good_sums), env
+        assert rc == _lib.NHIP_ERR_ARG and info[0] == (2 | 4), (env, rc, list(info))
+        assert (info[1], info[2], info[3]) in ((2, 60, 7), (4, n + 2, 19)), list(info)
+        keep = np.ones(n_pairs, bool)
+        keep[[7, 19]] = False
+        assert np.array_equal(rec[keep], ref[keep]) and np.array_equal(sums[keep], ref_sums[keep]), env
+        for i in (7, 19):
+            assert list(rec[i, :3]) == [0, 0, 0] and rec[i, 3:4].view(np.float32)[0] == floor and sums[i] == 0, (env, rec[i])
+    assert lib.nhip_dev_status(sp, info) == _lib.NHIP_OK
+    # the score volume's scan and slot are host arguments: checked on the host
+    d_vol = torch.empty(61 * 81 * 81, dtype=torch.int32, device=dev)
+    d_delta = t(csm.delta_table(search))
+    rc = lib.nhip_csm_scores_dev(d_xy.data_ptr(), d_off.data_ptr(), n_scans, G.data_ptr(), n, C.byref(spec), 60, 0,
+                                 d_rot0.data_ptr(), d_delta.data_ptr(), 0, 0, C.byref(search), d_vol.data_ptr(), sp)
+    assert rc == _lib.NHIP_ERR_ARG
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("n_pairs", [192, 200, 300, 400, 487, 600])
+def test_lists_from_192_pairs_take_the_split_form_at_the_production_lattice(gpu, small_bag, n_pairs):
+    """include/nautilus_hip.h: "Lists of 192 pairs and more run as two kernels".  Round 4's launcher tested for the state of
+    512 pairs before it sized the rounds, and nhip_csm_workspace_bytes(n) of 192 .. 487 pairs at 61 rotations is less than
+    that: those lists ran as one kernel per pair with hand-over lists (same records, slower; the only form assertion
+    used 9 rotations, where the threshold was 2.4 MB).  At the production lattice, through the handle API (whose
+    workspace is exactly nhip_csm_workspace_bytes(n)): split form, one round, no hand-over kernel; one pair fewer than
+    192: one kernel per pair."""
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, 16)
+    search = csm.search_spec(61, 81, 81, DEG)
+    st = csm.ScanTable.from_list(small_bag.scans)
+    ids = np.arange(0, 48, 4, dtype=np.int32)
+    grids = csm.LikelihoodGrids(st, ids, spec)
+    rng = np.random.default_rng(n_pairs)
+    src = rng.integers(0, 48, n_pairs).astype(np.int32)
+    slot = rng.integers(0, len(ids), n_pairs).astype(np.int32)
+    th0 = rng.uniform(-0.1, 0.1, n_pairs)
+    got, sums = csm.match_pairs(st, grids, src, slot, th0, search)
+    info = csm.last_launch()
+    assert info["form_id"] == 1 and info["pairs_per_round"] == n_pairs and info["rounds"] == 1 and not info["hand_over_kernel"], info
+    got1, sums1 = csm.match_pairs(st, grids, src[:191], slot[:191], th0[:191], search)
+    info1 = csm.last_launch()
+    assert info1["form_id"] == 0 and info1["hand_over_kernel"], info1
+    assert got1.tobytes() == got[:191].tobytes() and np.array_equal(sums1, sums[:191])
+    grids.close()
+    st.close()
