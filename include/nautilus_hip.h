@@ -182,6 +182,13 @@ typedef struct nhip_match {
   float score; /* mean log-likelihood (<= 0), cf. csm_score_threshold = -5 (default_config.lua:85) */
 } nhip_match_t;
 
+/* Wall-clock seconds of the calling thread's last handle-API call (nhip_scans_upload, nhip_grids_build, nhip_csm_match and
+ * the _free calls), by what the host waited for: out[0] hipMalloc, [1] zero-fill + host-to-device copies, [2] from the first
+ * kernel launch to the end of the call (nhip_grids_build: the launches alone), [3] waiting for the kernels, [4] device-to-host
+ * copies, [5] hipFree, [6] the whole call (nhip_csm_match), [7] unused.  Diagnostic: bench.py prints it per run of its
+ * host-buffer leg, so that a slow call says where it was slow. */
+int nhip_host_phases(double out[8]);
+
 /* Host helpers: (cos, sin) of theta0 per pair and of the lattice offsets, in double. */
 int nhip_csm_rot0(const double *rot_a, const double *rot_b, int32_t n, double *cs_out /* 2n */);
 int nhip_csm_delta_table(const nhip_search_t *search, double *cs_out /* 2*n_theta */);

@@ -76,6 +76,7 @@ PROTOTYPES = {
                                           _P(C.c_float), _P(C.c_float), _P(C.c_float)]),
     "nhip_score_from_sum": (_f64, [_P(GridSpec), _i64, _i32]),
     "nhip_dev_status": (C.c_int, [_vp, _P(_i32)]),
+    "nhip_host_phases": (C.c_int, [_P(_f64)]),
     "nhip_grid_build_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
     "nhip_grid_rebuild_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
     "nhip_csm_match_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _vp, _vp, _vp, _vp, _vp, _i32,

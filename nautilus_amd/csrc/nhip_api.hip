@@ -3,6 +3,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstddef>
 #include <map>
@@ -228,6 +229,23 @@ void timer_end(int id, hipStream_t s) {
   g_slots[id].open = nullptr;
 }
 
+// ---------------------------------------------------------------- host phases of the handle API
+// Wall-clock seconds of the calling thread's LAST handle-API call (nhip_scans_upload, nhip_grids_build, nhip_csm_match,
+// the *_free calls), by what the host was waiting for: nhip_host_phases().  Round 4's bench saw one call in five of the
+// host-buffer route take 4 s instead of 12 ms and could not say where (a median hid it); the clocks cost two
+// steady_clock reads per phase.
+enum { PH_ALLOC = 0, PH_UPLOAD, PH_ENQUEUE, PH_WAIT, PH_DOWNLOAD, PH_FREE, PH_HOST, PH_COUNT };
+static thread_local double t_phase[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+struct PhaseClock {
+  int id;
+  std::chrono::steady_clock::time_point t0;
+  explicit PhaseClock(int i) : id(i), t0(std::chrono::steady_clock::now()) {}
+  ~PhaseClock() { t_phase[id] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); }
+};
+static void phases_reset() {
+  for (double &v : t_phase) v = 0.0;
+}
+
 // ---------------------------------------------------------------- handles
 struct DevBuf {
   void *p = nullptr;
@@ -235,6 +253,7 @@ struct DevBuf {
   int alloc(size_t n) {
     free();
     if (n == 0) n = 16;
+    PhaseClock pc(PH_ALLOC);
     hipError_t e = hipMalloc(&p, n);
     if (e != hipSuccess) {
       p = nullptr;
@@ -245,7 +264,10 @@ struct DevBuf {
     return NHIP_OK;
   }
   void free() {
-    if (p) (void)hipFree(p);
+    if (p) {
+      PhaseClock pc(PH_FREE);
+      (void)hipFree(p);
+    }
     p = nullptr;
     bytes = 0;
   }
@@ -483,6 +505,12 @@ int nhip_dev_status(void *stream, int32_t info[4]) {
   return NHIP_ERR_ARG;
 }
 
+int nhip_host_phases(double out[8]) {
+  NHIP_REQUIRE(out != nullptr, "host_phases: null out");
+  for (int i = 0; i < 8; i++) out[i] = t_phase[i];
+  return NHIP_OK;
+}
+
 int nhip_csm_last_launch(int32_t out[8]) {
   NHIP_REQUIRE(out != nullptr, "csm_last_launch: null out");
   bnb_last_launch(out);
@@ -626,6 +654,7 @@ int nhip_scans_upload(const float *xy, const int32_t *offsets, int32_t n_scans, 
   int rc = require_device();
   if (rc) return rc;
   NHIP_REQUIRE(offsets && out && n_scans >= 0, "scans_upload: bad arguments");
+  phases_reset();
   NHIP_REQUIRE(offsets[0] == 0, "scans_upload: offsets[0] must be 0");
   for (int32_t i = 0; i < n_scans; i++)
     NHIP_REQUIRE(offsets[i + 1] >= offsets[i], "scans_upload: offsets not monotone at scan %d", i);
@@ -641,9 +670,12 @@ int nhip_scans_upload(const float *xy, const int32_t *offsets, int32_t n_scans, 
     return rc;
   }
   hipError_t e = hipSuccess;
-  if (n_points) e = hipMemcpy(s->xy.p, xy, sizeof(float) * 2 * (size_t)n_points, hipMemcpyHostToDevice);
-  if (e == hipSuccess)
-    e = hipMemcpy(s->offsets.p, offsets, sizeof(int32_t) * (size_t)(n_scans + 1), hipMemcpyHostToDevice);
+  {
+    PhaseClock pc(PH_UPLOAD);
+    if (n_points) e = hipMemcpy(s->xy.p, xy, sizeof(float) * 2 * (size_t)n_points, hipMemcpyHostToDevice);
+    if (e == hipSuccess)
+      e = hipMemcpy(s->offsets.p, offsets, sizeof(int32_t) * (size_t)(n_scans + 1), hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     delete s;
     return hip_fail(e, "scans_upload memcpy", __FILE__, __LINE__);
@@ -653,6 +685,7 @@ int nhip_scans_upload(const float *xy, const int32_t *offsets, int32_t n_scans, 
 }
 
 int nhip_scans_free(nhip_scans_t *scans) {
+  phases_reset();
   delete scans;
   return NHIP_OK;
 }
@@ -662,6 +695,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
   int rc = require_device();
   if (rc) return rc;
   NHIP_REQUIRE(scans && out && n_targets >= 0 && (target_ids || n_targets == 0), "grids_build: bad arguments");
+  phases_reset();
   for (int32_t i = 0; i < n_targets; i++)
     NHIP_REQUIRE(target_ids[i] >= 0 && target_ids[i] < scans->n_scans,
                  "grids_build: target id %d out of range", target_ids[i]);
@@ -681,19 +715,27 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
     delete g;
     return rc;
   }
-  hipError_t e = hipMemset(g->grids.p, 0, g->grids.bytes);
-  if (e == hipSuccess && n_targets)
-    e = hipMemcpy(ids.p, target_ids, sizeof(int32_t) * (size_t)n_targets, hipMemcpyHostToDevice);
+  hipError_t e;
+  {
+    PhaseClock pc(PH_UPLOAD);
+    e = hipMemset(g->grids.p, 0, g->grids.bytes);
+    if (e == hipSuccess && n_targets)
+      e = hipMemcpy(ids.p, target_ids, sizeof(int32_t) * (size_t)n_targets, hipMemcpyHostToDevice);
+  }
   if (e != hipSuccess) {
     delete g;
     return hip_fail(e, "grids_build setup", __FILE__, __LINE__);
   }
   if (n_targets) {
-    rc = launch_grid_build(static_cast<const float *>(scans->xy.p),
-                           static_cast<const int32_t *>(scans->offsets.p), scans->n_scans,
-                           static_cast<const int32_t *>(ids.p), n_targets, spec, L,
-                           static_cast<uint8_t *>(g->grids.p), ws.p, ws_bytes, nullptr);
+    {
+      PhaseClock pc(PH_ENQUEUE);
+      rc = launch_grid_build(static_cast<const float *>(scans->xy.p),
+                             static_cast<const int32_t *>(scans->offsets.p), scans->n_scans,
+                             static_cast<const int32_t *>(ids.p), n_targets, spec, L,
+                             static_cast<uint8_t *>(g->grids.p), ws.p, ws_bytes, nullptr);
+    }
     if (rc == NHIP_OK) {
+      PhaseClock pc(PH_WAIT);
       e = hipDeviceSynchronize();
       if (e != hipSuccess) rc = hip_fail(e, "grids_build sync", __FILE__, __LINE__);
     }
@@ -707,6 +749,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
 }
 
 int nhip_grids_free(nhip_grids_t *grids) {
+  phases_reset();
   delete grids;
   return NHIP_OK;
 }
@@ -802,6 +845,8 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
   if (rc) return rc;
   NHIP_REQUIRE(scans && grids && search && n_pairs >= 0, "csm_match: bad arguments");
   NHIP_REQUIRE(n_pairs == 0 || (pair_src && pair_slot && theta0 && out), "csm_match: null array");
+  phases_reset();
+  PhaseClock pc_host(PH_HOST);  // (the whole call; the phases below are inside it)
   for (int32_t i = 0; i < n_pairs; i++) {
     NHIP_REQUIRE(pair_src[i] >= 0 && pair_src[i] < scans->n_scans, "csm_match: pair %d source %d out of range", i, pair_src[i]);
     NHIP_REQUIRE(pair_slot[i] >= 0 && pair_slot[i] < grids->n, "csm_match: pair %d grid slot %d out of range", i, pair_slot[i]);
@@ -855,11 +900,16 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
       (rc = d_keys.alloc(sizeof(uint64_t) * (size_t)n_pairs)) || (rc = d_out.alloc(sizeof(nhip_match_t) * (size_t)n_pairs)) ||
       (rc = d_sums.alloc(sizeof(int32_t) * (size_t)n_pairs)))
     return rc;
-  NHIP_TRY_HIP(hipMemcpy(d_src.p, pair_src, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyHostToDevice));
-  NHIP_TRY_HIP(hipMemcpy(d_slot.p, pair_slot, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyHostToDevice));
-  NHIP_TRY_HIP(hipMemcpy(d_rot0.p, rot0.data(), sizeof(double) * rot0.size(), hipMemcpyHostToDevice));
-  NHIP_TRY_HIP(hipMemcpy(d_delta.p, delta.data(), sizeof(double) * delta.size(), hipMemcpyHostToDevice));
+  {
+    PhaseClock pc(PH_UPLOAD);
+    NHIP_TRY_HIP(hipMemcpy(d_src.p, pair_src, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyHostToDevice));
+    NHIP_TRY_HIP(hipMemcpy(d_slot.p, pair_slot, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyHostToDevice));
+    NHIP_TRY_HIP(hipMemcpy(d_rot0.p, rot0.data(), sizeof(double) * rot0.size(), hipMemcpyHostToDevice));
+    NHIP_TRY_HIP(hipMemcpy(d_delta.p, delta.data(), sizeof(double) * delta.size(), hipMemcpyHostToDevice));
+  }
   const IdBounds idb = {scans->n_scans, grids->n, dev_status()};  // (checked on the host above; the kernels check again)
+  PhaseClock pc_enq(PH_ENQUEUE);  // (to the end of the call minus the phases inside it; nhip_host_phases subtracts nothing:
+                                  //  read it as "enqueue + wait + download + frees")
   rc = launch_csm_match(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p), idb,
                         static_cast<const uint8_t *>(grids->grids.p), &spec_now, grids->L,
                         static_cast<const int32_t *>(d_src.p), static_cast<const int32_t *>(d_slot.p),
@@ -867,8 +917,15 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
                         pair_origin ? static_cast<const int32_t *>(d_org.p) : nullptr, n_pairs, search, static_cast<uint64_t *>(d_keys.p), static_cast<nhip_match_t *>(d_out.p),
                         static_cast<int32_t *>(d_sums.p), nullptr, d_ws.p, ws_bytes);
   if (rc) return rc;
-  NHIP_TRY_HIP(hipMemcpy(out, d_out.p, sizeof(nhip_match_t) * (size_t)n_pairs, hipMemcpyDeviceToHost));
-  if (out_sums) NHIP_TRY_HIP(hipMemcpy(out_sums, d_sums.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+  {
+    PhaseClock pc(PH_WAIT);  // (the kernels; the downloads below find them done)
+    NHIP_TRY_HIP(hipStreamSynchronize(nullptr));
+  }
+  {
+    PhaseClock pc(PH_DOWNLOAD);
+    NHIP_TRY_HIP(hipMemcpy(out, d_out.p, sizeof(nhip_match_t) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+    if (out_sums) NHIP_TRY_HIP(hipMemcpy(out_sums, d_sums.p, sizeof(int32_t) * (size_t)n_pairs, hipMemcpyDeviceToHost));
+  }
   return NHIP_OK;
 }
 
