@@ -278,6 +278,49 @@ def run_sharded(plan, rank, world, device, matcher, steps, warmup, dist=None, on
     return elapsed, full
 
 
+def one_gpu_same_workload(src, tgt, th0, weights, make_matcher, device, rank, world, dist=None, full=None, steps=1):
+    """The N = 1 point of the SAME workload inside an N > 1 run: rank 0 matches the whole list on its own GPU (one warm-up
+    step, then `steps` timed ones, outside the run's timed region) while the other ranks wait at the barrier; every rank
+    returns the same dict.  Without it a driver that divides value(N) by the N = 1 run's value compares two workloads --
+    `--gpus 1` is BASELINE configs[1] (10,000 pairs), `--gpus N` configs[3] (1,000,000 pairs, on which one GPU is 1.25x
+    faster per pair): a true 6x would read 7.5x.  make_matcher(shard) -> an object with step() (bench.HipMatcher; the CPU
+    test injects the oracle).  `full`: the sharded run's all-gathered table; the one-GPU records must equal it."""
+    import torch
+    from nautilus_amd import sharding
+    is_cuda = torch.device(device).type == "cuda"
+    res = torch.zeros(3, dtype=torch.float64)
+    if rank == 0:
+        plan1 = sharding.ShardPlan(src, tgt, th0, 1, weights)
+        m1 = make_matcher(plan1.shard(0))
+        rec = plan1.all_gather(m1.step(), 0, plan1.new_buffers(device))
+        if is_cuda:
+            torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            rec = plan1.all_gather(m1.step(), 0, plan1.new_buffers(device))
+        if is_cuda:
+            torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        same = 1.0 if full is None or torch.equal(rec.to(full.device), full) else 0.0
+        res = torch.tensor([len(src) / dt, 1e3 * dt, same], dtype=torch.float64)
+        if hasattr(m1, "free_grids"):
+            m1.free_grids()
+        del m1, rec
+    if dist is not None and world > 1:
+        res = res.to(device)
+        dist.broadcast(res, src=0)
+        res = res.cpu()
+    return {"one_gpu_same_workload_pairs_per_s": float(res[0]), "one_gpu_same_workload_ms_per_step": float(res[1]),
+            "one_gpu_records_equal_sharded_table": bool(res[2] == 1.0), "one_gpu_steps_timed": steps}
+
+
+def scaling_fields(value, one, world, comm_world):
+    """What an N > 1 bench line says about scaling beside `value`: the same-workload N = 1 point and the ratio."""
+    return dict(one, speedup_vs_one_gpu=value / one["one_gpu_same_workload_pairs_per_s"], rccl_world_size=int(comm_world),
+                scaling_note="speedup_vs_one_gpu = value / one_gpu_same_workload_pairs_per_s: the whole list on rank 0's GPU, timed in "
+                             "this run; the --gpus 1 bench line is BASELINE configs[1], another workload")
+
+
 # ------------------------------------------------------------------------------------------ helpers
 def _cpu_info():
     model, phys, threads = "unknown", set(), 0
@@ -506,6 +549,11 @@ def worker(a):
     # this rank's block of the gathered table must equal what this rank computed
     got_local = full.index_select(0, torch.from_numpy(shard[0].astype(np.int64)).to(dev))
     assert torch.equal(got_local, m.records()[0]), "all-gather returned a different block for this rank"
+    one = None
+    if world > 1:
+        # the same list on ONE GPU (rank 0's), timed in this run: the N = 1 point the speed-up is quoted against
+        one = one_gpu_same_workload(wl.src, wl.tgt, wl.th0, weights, lambda sh: HipMatcher(wl, sh, dev, a.cell_bits), dev,
+                                    rank, world, dist if use_dist else None, full)
     if rank != 0:
         dist.destroy_process_group()
         return 0
@@ -642,6 +690,8 @@ def worker(a):
                               "(secondary.exhaustive_u16 / exhaustive_u8)",
                       "stats": bnb},
     }
+    if one is not None:
+        out.update(scaling_fields(out["value"], one, world, dist.get_world_size() if use_dist else 1))
     legs = world == 1 and a.mode == "weak"
     if legs and a.cpu_seconds > 0:
         try:
@@ -687,6 +737,10 @@ def worker(a):
                 sec[name] = fn()
             except Exception as e:
                 sec[name + "_error"] = repr(e)
+        if "config4_one_gpu" in sec:
+            # (the N = 1 point of the workload a --gpus N > 1 run measures: what its `speedup_vs_one_gpu` is the ratio to)
+            out["one_gpu_same_workload_pairs_per_s"] = sec["config4_one_gpu"]["value"]
+            out["one_gpu_same_workload"] = "BASELINE configs[3] (10,000 scans, 1,000,000 pairs) on this one GPU: secondary.config4_one_gpu"
         if "parity_vs_f64" in sec:  # (the summary beside the headline; the lists and the disagreements stay in `secondary`)
             out["parity_vs_f64"] = {k_: sec["parity_vs_f64"][k_] for k_ in ("pairs", "index_agreement", "max_rel_score", "max_gap_nat",
                                                                              "guaranteed_max_gap_nat", "cell_bits")}

@@ -90,7 +90,11 @@ def _worker(rank, world, port, q, weighted=False):
         plan = sharding.ShardPlan(src, tgt, th0, world, _weights(src, tgt) if weighted else None)
         m = _OracleMatcher(xy, off, plan.shard(rank), gs, ss)
         elapsed, full = bench.run_sharded(plan, rank, world, "cpu", m, steps=2, warmup=1, dist=dist)
-        q.put((rank, full.numpy().tobytes(), m.calls, elapsed, len(plan.shard(rank)[1])))
+        # the N = 1 point of the same list, timed inside the N-rank run (what bench.py's N > 1 line quotes its speed-up against)
+        one = bench.one_gpu_same_workload(src, tgt, th0, _weights(src, tgt) if weighted else None,
+                                          lambda sh: _OracleMatcher(xy, off, sh, gs, ss), "cpu", rank, world, dist, full)
+        fields = bench.scaling_fields(len(src) * 2 / elapsed, one, world, dist.get_world_size())
+        q.put((rank, full.numpy().tobytes(), m.calls, elapsed, len(plan.shard(rank)[1]), fields))
     finally:
         dist.destroy_process_group()
 
@@ -111,6 +115,11 @@ def test_bench_sharded_step_over_gloo_world_2():
     assert all(r[2] == 3 for r in res), "warm-up + steps = 3 matcher calls per rank"
     assert res[0][3] == res[1][3] > 0, "elapsed is the max over ranks, identical everywhere"
     assert res[0][4] + res[1][4] == 15 and min(res[0][4], res[1][4]) >= 6, "pairs are split between the ranks by target"
+    # every rank reports the same one-GPU figure of the same list, measured by rank 0, and the ratio to it
+    f0, f1 = res[0][5], res[1][5]
+    assert f0 == f1 and f0["rccl_world_size"] == 2 and f0["one_gpu_records_equal_sharded_table"]
+    assert f0["one_gpu_same_workload_pairs_per_s"] > 0
+    assert abs(f0["speedup_vs_one_gpu"] - (15 * 2 / res[0][3]) / f0["one_gpu_same_workload_pairs_per_s"]) < 1e-9
     # equal to the unsharded computation in the ORIGINAL (unsorted) pair order
     xy, off, src, tgt, th0 = _workload()
     gs, ss = O.grid_spec(30.0, 0.05, 2.0, 1e-10), O.search_spec(5, 11, 11, math.radians(2))
