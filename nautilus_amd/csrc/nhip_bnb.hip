@@ -48,63 +48,19 @@
 #ifndef NHIP_BNB_INSTR
 #define NHIP_BNB_INSTR 0
 #endif
-#ifndef NHIP_BNB_RS_DPP
-#define NHIP_BNB_RS_DPP 1   // 0: every step beyond the quad through ds_bpermute (measurement)
-#endif
-#ifndef NHIP_BNB_RUN_MAX
-#define NHIP_BNB_RUN_MAX 64  // lanes per run group in the bounds phase (8 / 16: measurement)
-#endif
-#ifndef NHIP_BNB_P1_PREFETCH
-#define NHIP_BNB_P1_PREFETCH 2  // chunks of points in flight in the bounds phase
-#endif
-#ifndef NHIP_BNB_UNALIGNED
-#define NHIP_BNB_UNALIGNED 0  // 1: exact block sums read their rows at byte addresses (4 / 8 bytes instead of 8 / 12)
-#endif
-#ifndef NHIP_BNB_MAX_FIRST
-#define NHIP_BNB_MAX_FIRST 0  // 1: a rotation's candidates highest bound first instead of in block order (measurement)
-#endif
-#ifndef NHIP_BNB_MERGE_ORIGINS
-#define NHIP_BNB_MERGE_ORIGINS 1  // 0: one list entry per point in the candidates' phase (measurement)
-#endif
-#ifndef NHIP_BNB_WAVE_SLOW_PATH
-#define NHIP_BNB_WAVE_SLOW_PATH 1  // window origins: one wave-level test for the double-precision path (0: per-lane nesting)
-#endif
-#ifndef NHIP_BNB_TILED
-#define NHIP_BNB_TILED 1  // exact block sums on the tiled 8-bit plane (0: 8-bit grids read their row-major image)
-#endif
-#ifndef NHIP_BNB_MERGE_U8
-#define NHIP_BNB_MERGE_U8 1  // merged list entries for 8-bit grids too (0: measurement)
-#endif
-#ifndef NHIP_BNB_F32_ORIGINS
-#define NHIP_BNB_F32_ORIGINS 1  // 0: window origins through two double-precision quotients (measurement)
-#endif
-#ifndef NHIP_BNB_LDS_UNALIGNED
-#define NHIP_BNB_LDS_UNALIGNED 0  // 1: the bounds' gather reads its 12 bytes per row at their byte address (ds_read_b96, no funnel shifts)
-#endif
-#ifndef NHIP_BNB_FRACT_NEAR
-#define NHIP_BNB_FRACT_NEAR 0  // 1: the origins' near-an-integer test on v_fract_f32 (fewer instructions per coordinate)
-#endif
-#ifndef NHIP_BNB_LEAN_ORIGINS
-#define NHIP_BNB_LEAN_ORIGINS 1  // window origins: non-finite points leave through the rare path, one constant per coordinate (0: round 3's form)
-#endif
-#ifndef NHIP_BNB_POS_RUNS
-#define NHIP_BNB_POS_RUNS 1  // bounds' run lists: an entry carries its first point's index, the gather takes the length from the next entry (0: lengths at the heads)
-#endif
+// (The compile-time measurement switches of rounds 2-4 -- lane exchanges through ds_bpermute, runs cut at 8 / 16 lanes,
+//  unaligned row loads, highest-bound-first order, unmerged origin lists, per-lane nesting and double-precision forms of
+//  the window origins, the row-major 8-bit plane, unaligned LDS reads, the v_fract near test, run lengths at the heads --
+//  are out of the source: each lost its A/B, the numbers are in profiles/r03_matcher_experiments.txt and
+//  profiles/r04_bounds_variants.txt, the code in the commits those files name.  What is left is what ships.)
 #if NHIP_BNB_INSTR
 #define csm_bnb_kernel csm_bnb_kernel_instr          // (their own names in profiles)
 #define csm_bnb_rot_kernel csm_bnb_rot_kernel_instr
 #define BNB_STATS(P) ((P).stats)
 #define BNB_TIMELINE(P) ((P).timeline)
-#define BNB_DEBUG(P) ((P).debug)
 #else
 #define BNB_STATS(P) (static_cast<unsigned long long *>(nullptr))
 #define BNB_TIMELINE(P) (static_cast<unsigned long long *>(nullptr))
-// (tools/bnb_variants.sh builds product kernels with a timing experiment compiled in -- WRONG results, no counters whose
-//  atomics would distort the time: -DNHIP_BNB_EXPERIMENT=<a NHIP_BNB_DEBUG value>)
-#ifndef NHIP_BNB_EXPERIMENT
-#define NHIP_BNB_EXPERIMENT 0
-#endif
-#define BNB_DEBUG(P) NHIP_BNB_EXPERIMENT
 #endif
 
 namespace nhip {
@@ -113,51 +69,25 @@ namespace {
 
 using namespace bnb;
 
-constexpr int BNB_WAVES = 8;
 constexpr int BNB_THREADS = 64 * BNB_WAVES;
-// Waves per workgroup of the split form's first kernel (bounds + seeds); measurement.  What bounds that kernel is the
-// latency of a wave's own instruction chain more than issue slots: with ONE workgroup per CU (two waves per SIMD;
-// NHIP_BNB_LDS_PAD=12000) it takes 1.63x the time of two.  Five waves per SIMD would need workgroups of ten waves at 96
-// registers; built (=10: same records) and twice as slow -- ten waves spread 3 + 3 + 2 + 2 over the SIMDs, a second
-// workgroup's would make six on two of them, which 96 registers do not allow, so ONE workgroup was resident per CU.
-// Twelve waves need 80 registers, a third workgroup of eight also 53 KB of LDS.  Seeds are evaluated by at most eight waves.
-#ifndef NHIP_BNB_SPLIT_WAVES
-#define NHIP_BNB_SPLIT_WAVES 8
-#endif
-constexpr int SPLIT_WAVES = NHIP_BNB_SPLIT_WAVES;
-static_assert(SPLIT_WAVES >= 8 && SPLIT_WAVES <= 16, "workgroups of 512 to 1024 threads");
-constexpr int NB = BNB_MAX_NB;        // blocks per axis held in registers (11: nx, ny <= 88)
+// Waves per workgroup of the split form's first kernel (bounds + seeds).  What bounds that kernel is the latency of a
+// wave's own instruction chain more than issue slots: with ONE workgroup per CU (two waves per SIMD) it takes 1.63x the
+// time of two.  Five waves per SIMD would need workgroups of ten waves at 96 registers; built and twice as slow -- ten
+// waves spread 3 + 3 + 2 + 2 over the SIMDs, a second workgroup's would make six on two of them, which 96 registers do
+// not allow, so ONE workgroup was resident per CU.  Twelve waves need 80 registers, a third workgroup of eight also 53 KB
+// of LDS (profiles/r04_bounds_variants.txt).
+constexpr int SPLIT_WAVES = 8;
 constexpr int SEG_CHUNKS = 32;        // 64-point chunks between reductions: 32 * 255 * 8 lanes < 65536 (16-bit fields); even
-#ifndef NHIP_BNB_EVAL_CHUNKS
-#define NHIP_BNB_EVAL_CHUNKS 2
-#endif
-constexpr int EVAL_CHUNKS = NHIP_BNB_EVAL_CHUNKS;  // 64-point chunks whose row loads a block evaluation keeps in flight
-constexpr int MAX_ROT = 340;          // rotations per search: QCAP * 4 bytes hold their 12 bytes of ordering data
-constexpr int QCAP = 1024;            // candidate queue entries per workgroup (overflow is evaluated by the wave that found it)
+constexpr int EVAL_CHUNKS = 2;  // 64-point chunks whose row loads a block evaluation keeps in flight
 constexpr uint32_t M8 = 0x00ff00ffu;
-constexpr int BNB_STATS_PAIRS = 1 << 20;
-constexpr int BNB_STATS_HEAD = 16;       // totals: 4 counts, then shader-clock sums of the by-rotation kernel (see nhip_bnb_stats_levels)  // per-pair counters kept by NHIP_BNB_STATS=1
 
-// floor(double(v) / res) clamped to [lo, hi], as the spec defines it (cimg_debug.h:31-37: float promoted to double,
-// double division) -- from single-precision arithmetic.  m = RN(v * RN_f32(1 / res)) differs from the true quotient q
-// by at most |q| * 2^-23 (one rounding of the reciprocal, one of the product), and the spec's RN_double(q) by 2^-53 |q|
-// more: the floors can differ only if m lies within that distance of an integer.  Lanes within |m| * 2^-22 of one
-// (twice the bound; about one coordinate in 2,000 on the 1200-cell grid) take the double-precision path, so the result
-// is the spec's, always.  From |m| >= 2^22 on (no fraction bits left to test) the cell is far outside any grid
-// (sides <= 16384) on either path and the clamp decides; v_cvt_i32_f32 saturates.
-__device__ __forceinline__ __attribute__((unused)) int32_t cell_floor(float v, const BnbParams &P, int32_t lo, int32_t hi) {
-  const float m = __fmul_rn(v, P.inv_res_f);
-  const float f = floorf(m);
-  const float frac = __fsub_rn(m, f);  // exact
-  const float tol = __fmul_rn(fabsf(m), 0x1p-22f);
-  int32_t c = (int32_t)f;
-  if (!NHIP_BNB_F32_ORIGINS || (fabsf(m) < 0x1p22f && (frac <= tol || __fsub_rn(1.0f, frac) <= tol))) {
-    const double d = floor_quotient((double)v, P.res, P.inv_res);
-    c = (int32_t)fmin(fmax(d, -2147483000.0), 2147483000.0);
-  }
-  return min(max(c, lo), hi);
-}
-
+// Window origins from single-precision arithmetic.  The spec's cell is floor(double(v) / res) (cimg_debug.h:31-37: float
+// promoted to double, double division).  m = RN(v * RN_f32(1 / res)) differs from the true quotient q by at most
+// |q| * 2^-23 (one rounding of the reciprocal, one of the product), and the spec's RN_double(q) by 2^-53 |q| more: the
+// floors can differ only if m lies within that distance of an integer.  Lanes within |m| * 2^-22 of one (twice the bound;
+// about one coordinate in 2,000 on the 1200-cell grid) take the double-precision path, so the result is the spec's,
+// always.  From |m| >= 2^22 on (no fraction bits left to test) the cell is far outside any grid (sides <= 16384) on
+// either path and the clamp decides; v_cvt_i32_f32 saturates.
 // Window origin (stored-grid row, column of the top-left lookup cell) of point q under rotation (cf, sf): the
 // same arithmetic as window_cell of nhip_csm.hip (spec: DESIGN.md section 3, items 1 and 3).
 // LEAN (the bounds phase): see below; the candidates' kernels keep round 3's form -- the lean one costs the candidates'
@@ -170,21 +100,18 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
   const int32_t half = P.S / 2;
   const bool finite __attribute__((unused)) = (fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f);
   int32_t ix, iy;
-#if NHIP_BNB_F32_ORIGINS && NHIP_BNB_WAVE_SLOW_PATH
-  // cell_floor of both coordinates with ONE test for the rare path, taken by the wave only if some lane needs it
+  // the floors of both quotients with ONE test for the rare path, taken by the wave only if some lane needs it
   // (about one chunk in 16): the straight-line code has no nested exec masks.  A lane is "near" when either quotient
   // lies within |m| * 2^-22 of an integer -- which includes every |m| >= 2^22 (no fraction bits left), whose floors
   // the double-precision path then takes like any other.
   const float mx = __fmul_rn(xr, P.inv_res_f), my = __fmul_rn(yr, P.inv_res_f);
   const float fx = floorf(mx), fy = floorf(my);
-#if NHIP_BNB_LEAN_ORIGINS
   if (LEAN) {
-  // The same test written so that it also holds for what is not a number: !(min(r, 1 - r) > tol) is true for NaN (an
-  // infinite quotient: inf - inf), and every |v| >= 1e9 has |m| >= 2^22 at any cell size below 238 m, i.e. r == 0.  So
-  // the points the spec calls non-finite all take the rare path, which gives them the floor that clamps to the window
-  // position of a point that scores nothing (column -hx - 1, row -hy - 1: the lower clamp bounds), and the straight-line
-  // code needs neither the two magnitude compares nor the selects -- one constant per coordinate after the clamp.
-  {
+    // The same test written so that it also holds for what is not a number: !(min(r, 1 - r) > tol) is true for NaN (an
+    // infinite quotient: inf - inf), and every |v| >= 1e9 has |m| >= 2^22 at any cell size below 238 m, i.e. r == 0.  So
+    // the points the spec calls non-finite all take the rare path, which gives them the floor that clamps to the window
+    // position of a point that scores nothing (column -hx - 1, row -hy - 1: the lower clamp bounds), and the straight-line
+    // code needs neither the two magnitude compares nor the selects -- one constant per coordinate after the clamp.
     const float rx = __fsub_rn(mx, fx), ry = __fsub_rn(my, fy);  // exact
     const bool slow = !(fminf(rx, __fsub_rn(1.0f, rx)) > __fmul_rn(fabsf(mx), 0x1p-22f)) ||
                       !(fminf(ry, __fsub_rn(1.0f, ry)) > __fmul_rn(fabsf(my), 0x1p-22f));
@@ -207,20 +134,9 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
     *prow = iy + (half + cy - P.hy + P.pad);
     return;
   }
-  }
-#endif
-#if NHIP_BNB_FRACT_NEAR
-  // near an integer <=> |fract(m) - 1/2| >= 1/2 - tol.  v_fract_f32 is m - floor(m) exactly for the finite |m| < 2^22 that
-  // matter (larger ones take the double-precision path through the second term: their tolerance exceeds 1/2)
-  const float gx = __builtin_amdgcn_fractf(mx), gy = __builtin_amdgcn_fractf(my);
-  // (+ 2^-22 absolute: g - 1/2 is rounded for g < 1/4, and v_fract_f32 clamps just below 1 -- both errors are < 2^-24)
-  const bool near = fabsf(__fsub_rn(gx, 0.5f)) >= __fsub_rn(0.5f, __fmaf_rn(fabsf(mx), 0x1p-22f, 0x1p-22f)) ||
-                    fabsf(__fsub_rn(gy, 0.5f)) >= __fsub_rn(0.5f, __fmaf_rn(fabsf(my), 0x1p-22f, 0x1p-22f));
-#else
   const float rx = __fsub_rn(mx, fx), ry = __fsub_rn(my, fy);  // exact
   const bool near = fminf(rx, __fsub_rn(1.0f, rx)) <= __fmul_rn(fabsf(mx), 0x1p-22f) ||
                     fminf(ry, __fsub_rn(1.0f, ry)) <= __fmul_rn(fabsf(my), 0x1p-22f);
-#endif
   ix = (int32_t)fx;
   iy = (int32_t)fy;
   if (__builtin_amdgcn_ballot_w64(near && finite) != 0ull) {
@@ -231,13 +147,6 @@ __device__ __forceinline__ void window_origin(float2 q, float cf, float sf, cons
   }
   ix = min(max(ix, -P.hx - 1 - half - cx), P.S + P.hx - half - cx);
   iy = min(max(iy, -P.hy - 1 - half - cy), P.S + P.hy - half - cy);
-#else
-  ix = iy = 0;
-  if (finite) {
-    ix = cell_floor(xr, P, -P.hx - 1 - half - cx, P.S + P.hx - half - cx);
-    iy = cell_floor(yr, P, -P.hy - 1 - half - cy, P.S + P.hy - half - cy);
-  }
-#endif
   // col = clamp(S / 2 + floor(xr / res) + cx, -hx - 1, S + hx), as window_cell of nhip_csm.hip -- with the clamp
   // applied to the quotient's floor, so that everything stays in 32-bit arithmetic; non-finite points score nothing
   const int32_t col = finite ? half + ix + cx : -P.hx - 1, row = finite ? half + iy + cy : -P.hy - 1;
@@ -318,7 +227,7 @@ __device__ __forceinline__ uint32_t shfl_xor_c(uint32_t v) {
 
 template <int MASK>
 __device__ __forceinline__ uint32_t rs_pair(uint32_t x, uint32_t y, bool bit) {
-  if (NHIP_BNB_RS_DPP && MASK == 4) {
+  if (MASK == 4) {
     uint32_t r;
     // (s_nop 1: a DPP operand written by the previous vector instruction needs two wait states)
     asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_ror:12 row_mask:0xf bank_mask:0x5\n\t"
@@ -326,18 +235,18 @@ __device__ __forceinline__ uint32_t rs_pair(uint32_t x, uint32_t y, bool bit) {
                  : "=&v"(r) : "v"(x), "v"(y));
     return r;
   }
-  if (NHIP_BNB_RS_DPP && MASK == 8) {
+  if (MASK == 8) {
     uint32_t r;
     asm volatile("s_nop 1\n\tv_add_u32_dpp %0, %1, %1 row_ror:8 row_mask:0xf bank_mask:0x3\n\t"
                  "v_add_u32_dpp %0, %2, %2 row_ror:8 row_mask:0xf bank_mask:0xc"
                  : "=&v"(r) : "v"(x), "v"(y));
     return r;
   }
-  if (NHIP_BNB_RS_DPP && MASK == 16) {
+  if (MASK == 16) {
     const auto sw = __builtin_amdgcn_permlane16_swap(x, y, false, false);
     return sw[0] + sw[1];
   }
-  if (NHIP_BNB_RS_DPP && MASK == 32) {
+  if (MASK == 32) {
     const auto sw = __builtin_amdgcn_permlane32_swap(x, y, false, false);
     return sw[0] + sw[1];
   }
@@ -355,11 +264,11 @@ __device__ __forceinline__ void rs_step(uint32_t (&R)[CAP], bool bit) {
 // sum over the lane pairs MASK apart of one register (the tail of a reduction whose copies may coincide)
 template <int MASK>
 __device__ __forceinline__ uint32_t add_xor(uint32_t v) {
-  if (NHIP_BNB_RS_DPP && MASK == 16) {
+  if (MASK == 16) {
     const auto sw = __builtin_amdgcn_permlane16_swap(v, v, false, false);
     return sw[0] + sw[1];
   }
-  if (NHIP_BNB_RS_DPP && MASK == 32) {
+  if (MASK == 32) {
     const auto sw = __builtin_amdgcn_permlane32_swap(v, v, false, false);
     return sw[0] + sw[1];
   }
@@ -381,12 +290,8 @@ __device__ __forceinline__ uint32_t add_xor(uint32_t v) {
 // Field widths: the accumulators and the first two reduction steps (over 4 lanes) hold 16-bit fields, so a lane may
 // gather a total run length of at most LANE_WEIGHT = 64 between two reductions (4 lanes * 64 * 255 = 65,280); the
 // wave reduces early when a pass would take some lane past that, otherwise once per rotation.
-constexpr int RUN_MAX = NHIP_BNB_RUN_MAX;  // longest run = lanes per group whose first lane always starts a run: 8, 16 or 64
 constexpr uint32_t LANE_WEIGHT = 64u;
-constexpr int RUN_SHIFT = 25;     // entry = pooled offset | (run length - 1) << RUN_SHIFT
 constexpr int LIST_ENTRIES = 128; // ring of pending entries per wave (a chunk appends <= 64, 64 are consumed at a time)
-static_assert(RUN_MAX == 8 || RUN_MAX == 16 || RUN_MAX == 64, "runs are cut at DPP row or chunk boundaries");
-static_assert(!NHIP_BNB_POS_RUNS || RUN_MAX == 64, "the position form of the run lists cuts runs at chunk boundaries only");
 
 template <bool POOL_LDS>
 __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_t *pool, __amdgpu_buffer_rsrc_t prs,
@@ -408,16 +313,9 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
   auto gather = [&](uint32_t a, uint32_t cnt) {
     const uint32_t sh = (a & 3u) * 8u;
     const uint32_t *q = reinterpret_cast<const uint32_t *>(pool + (a & ~3u));
-    struct __attribute__((packed)) Bytes12 { uint32_t a, b, c; };
 #pragma unroll
     for (int y = 0; y < NB; y++) {
       uint32_t w0, w1, w2, w3;
-      uint32_t n0, n1, n2;
-      if (POOL_LDS && NHIP_BNB_LDS_UNALIGNED) {
-        // (LDS reads need no alignment on this target: the row's 12 bytes in one ds_read_b96 at their own address)
-        const Bytes12 v = *reinterpret_cast<const Bytes12 *>(pool + a + (uint32_t)(y * DP));
-        n0 = v.a; n1 = v.b; n2 = v.c;
-      } else {
       if (POOL_LDS) {
         const uint32_t *row = q + (y * DP) / 4;  // DP is a multiple of 16
         w0 = row[0]; w1 = row[1]; w2 = row[2]; w3 = row[3];
@@ -425,9 +323,8 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
         const u32x4 r4 = __builtin_amdgcn_raw_buffer_load_b128(prs, (int)((a & ~3u) + (uint32_t)(y * DP)), 0, 0);
         w0 = r4.x; w1 = r4.y; w2 = r4.z; w3 = r4.w;
       }
-      n0 = __builtin_amdgcn_alignbit(w1, w0, sh); n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
-      n2 = __builtin_amdgcn_alignbit(w3, w2, sh);
-      }
+      const uint32_t n0 = __builtin_amdgcn_alignbit(w1, w0, sh), n1 = __builtin_amdgcn_alignbit(w2, w1, sh);
+      const uint32_t n2 = __builtin_amdgcn_alignbit(w3, w2, sh);
       // even: b0 | b2 << 16; odd (raw): w >> 8 = b1 + 256 b2 + 65536 b3, repaired at the reduction
       E[y][0] += __umul24(n0 & M8, cnt); O[y][0] += __umul24(n0 >> 8, cnt);
       E[y][1] += __umul24(n1 & M8, cnt); O[y][1] += __umul24(n1 >> 8, cnt);
@@ -483,36 +380,17 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
   auto feed = [&](uint32_t a, int32_t c, bool more) {
     if (more) {
       const bool live = c + lane < n_pts;
-      // runs of equal offsets inside groups of RUN_MAX lanes: the predecessor's offset by a DPP shift (inside the row
-      // of 16 lanes, or -- RUN_MAX 64 -- across the wave), no LDS round trip; a group's first lane is a head anyway
-#if !NHIP_BNB_RS_DPP
-      const uint32_t prev = (uint32_t)__shfl_up((int)a, 1, 64);
-#elif NHIP_BNB_RUN_MAX == 64
+      // runs of equal offsets inside the chunk: the predecessor's offset by a DPP shift across the wave, no LDS round
+      // trip; the chunk's first lane is a head anyway
       const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x138 /* wave_shr:1 */, 0xF, 0xF, false);
-#else
-      const uint32_t prev = (uint32_t)__builtin_amdgcn_update_dpp((int)a, (int)a, 0x111 /* row_shr:1 */, 0xF, 0xF, false);
-#endif
-      const bool is_head = (lane & (RUN_MAX - 1)) == 0 || a != prev;
+      const bool is_head = (lane & 63) == 0 || a != prev;
       // (the lane masks straight from the compares: a ballot of the bools goes through a 0 / 1 register and back)
-      constexpr unsigned long long GROUP_HEADS = RUN_MAX == 64 ? 1ull : (RUN_MAX == 16 ? 0x0001000100010001ull : 0x0101010101010101ull);
-      const unsigned long long H = __builtin_amdgcn_uicmp(a, prev, 33 /* ne */) | GROUP_HEADS;
-      // run length = distance to the next head of the lane's group (or to the group's end)
-      uint32_t cnt;
-      if (NHIP_BNB_POS_RUNS) {
-        // (position form: the entry carries its first point's index modulo 128; the gather subtracts it from the next
-        //  entry's -- one more LDS read per 64 entries instead of two 64-bit shifts, a compare and two bit searches per
-        //  64 points.  The last run ends at the sentinel entry written after the last chunk.)
-        cnt = (uint32_t)(c + lane) & 127u;
-        cnt += 1u;  // (stored as cnt - 1 below)
-      } else if (RUN_MAX == 64) {
-        const unsigned long long rest = (H >> lane) >> 1;
-        cnt = rest ? (uint32_t)__builtin_ctzll(rest) + 1u : (uint32_t)(64 - lane);
-      } else {
-        const uint32_t Hh = (lane & 32) ? (uint32_t)(H >> 32) : (uint32_t)H;  // the half of H that holds the lane's group
-        const uint32_t g = (Hh >> (lane & 31 & ~(RUN_MAX - 1))) & ((1u << (RUN_MAX & 31)) - 1u);
-        const uint32_t rest = g >> ((lane & (RUN_MAX - 1)) + 1);
-        cnt = rest ? (uint32_t)__builtin_ctz(rest) + 1u : (uint32_t)(RUN_MAX - (lane & (RUN_MAX - 1)));
-      }
+      const unsigned long long H = __builtin_amdgcn_uicmp(a, prev, 33 /* ne */) | 1ull;
+      // (the entry carries its first point's index modulo 128; the gather subtracts it from the next entry's -- one LDS
+      //  read per 64 entries instead of two 64-bit shifts, a compare and two bit searches per 64 points.  The last run
+      //  ends at the sentinel entry written after the last chunk.)
+      uint32_t cnt = (uint32_t)(c + lane) & 127u;
+      cnt += 1u;  // (stored as cnt - 1 below)
       const int32_t n_live = n_pts - c;  // (lanes past the scan's end emit nothing)
       const unsigned long long He = H & (n_live >= 64 ? ~0ull : (1ull << n_live) - 1ull);
       if (is_head && live) {
@@ -523,39 +401,34 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    if (NHIP_BNB_POS_RUNS && !more) {
+    if (!more) {
       // the sentinel: where the last run ends.  (At most 64 entries are pending here -- the last chunk's turn drained
       // the list below 65 -- so the slot is free.)
       if (lane == 0) list[tail & (LIST_ENTRIES - 1)] = ((uint32_t)n_pts & 127u) << RUN_SHIFT;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
     }
-    // gather passes: whenever 64 entries are pending (position form: and the one after them, which ends the 64th's run),
+    // gather passes: whenever 64 entries are pending (and the one after them, which ends the 64th's run),
     // and to the last entry once the scan is through; then one more turn for the rotation's (only, as a rule)
     // reduction -- one copy of that code
     for (;;) {
       const uint32_t avail = tail - head;
-      if (avail < (NHIP_BNB_POS_RUNS ? 65u : 64u) && more) break;
+      if (avail < 65u && more) break;
       const bool last = avail == 0u;  // (!more)
       // (lanes past the list gather the zero rows with length 0)
       const bool mine = (uint32_t)lane < avail;
       const uint32_t entry = mine ? list[(head + (uint32_t)lane) & (LIST_ENTRIES - 1)] : zero_a;
       const uint32_t ea = entry & ((1u << RUN_SHIFT) - 1u);
-      uint32_t cnt;
-      if (NHIP_BNB_POS_RUNS) {
-        const uint32_t next = mine ? list[(head + (uint32_t)lane + 1u) & (LIST_ENTRIES - 1)] : 0u;
-        cnt = mine ? ((next >> RUN_SHIFT) - (entry >> RUN_SHIFT)) & 127u : 0u;
-      } else {
-        cnt = mine ? (entry >> RUN_SHIFT) + 1u : 0u;
-      }
+      const uint32_t next = mine ? list[(head + (uint32_t)lane + 1u) & (LIST_ENTRIES - 1)] : 0u;
+      const uint32_t cnt = mine ? ((next >> RUN_SHIFT) - (entry >> RUN_SHIFT)) & 127u : 0u;
       // (also before a pass that could overflow some lane's fields)
-      if (pending && (last || __ballot(weight + cnt > LANE_WEIGHT) != 0ull) && BNB_DEBUG(P) != 26) {
+      if (pending && (last || __ballot(weight + cnt > LANE_WEIGHT) != 0ull)) {
         reduce();
         pending = false;
         weight = 0u;
       }
       if (last) break;
-      if (BNB_DEBUG(P) != 27) gather(ea, cnt);
+      gather(ea, cnt);
       weight += cnt;
       pending = true;
       head += avail < 64u ? avail : 64u;
@@ -567,12 +440,11 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
   //  chains -- bounds + seeds 3.18 -> 3.23 ms, profiles/r04_bounds_variants.txt: the chains' latency is hidden already.)
   // (the points of the next PD chunks are in flight while one chunk is worked: with two workgroups per CU gathering
   //  from their grids, a point load takes ~1,300 clocks, more than a chunk's work)
-  constexpr int PD = NHIP_BNB_P1_PREFETCH;
+  constexpr int PD = 2;
   float2 qn[PD];
 #pragma unroll
   for (int d = 0; d < PD; d++) qn[d] = 64 * d + lane < n_pts ? pts[64 * d + lane] : make_float2(0.f, 0.f);
   for (int32_t c = 0;; c += 64) {
-    if (BNB_DEBUG(P) == 30) break;  // (timing experiment: no chunk loop at all)
     const bool more = c < n_pts;  // (one more turn after the last chunk drains the list)
     uint32_t a = zero_a;
     if (more) {
@@ -581,19 +453,11 @@ __device__ __forceinline__ void coarse_rotation(const BnbParams &P, const uint8_
       for (int d = 0; d < PD - 1; d++) qn[d] = qn[d + 1];
       if (c + 64 * PD + lane < n_pts) qn[PD - 1] = pts[c + 64 * PD + lane];
       const bool live = c + lane < n_pts;
-      if (live && BNB_DEBUG(P) != 29) {  // (timing experiments 28 / 29: without the run lists / without the origins too)
+      if (live) {
         int32_t prow, pcol;
         window_origin<true>(pt, cf, sf, P, cx, cy, &prow, &pcol);
-#if NHIP_BNB_LEAN_ORIGINS
         // (both factors are below 2^12: rows and pitch of the pooled image; the padding keeps prow positive)
         a = __umul24((uint32_t)prow >> 3, (uint32_t)DP) + ((uint32_t)pcol >> 3);
-#else
-        a = (uint32_t)((prow >> 3) * DP + (pcol >> 3));
-#endif
-      }
-      if (BNB_DEBUG(P) >= 28 && BNB_DEBUG(P) <= 29) {
-        tot[0] += a;
-        continue;
       }
     }
     feed(a, c, more);
@@ -948,10 +812,6 @@ __device__ __forceinline__ unsigned long long eval_sub(const BnbParams &P, __amd
 // the register allocator kept the array in scratch memory and the kernel wrote 7 GB of it per launch.)  Lanes
 // without a point hold origin (0, 0): every patch of theirs lies in the zero border (8 * NB + 7 < pad) and pooled
 // entries there are zero.
-constexpr int OC = 18;                      // chunks the passes are unrolled for
-constexpr int OCL = 17;                     // chunks held: 1088 points (a 1081-beam scan)
-constexpr int ORG_WAVE = OCL * 64;          // words of LDS per wave
-constexpr int ORG_LDS = BNB_WAVES * ORG_WAVE * 4;  // bytes per workgroup (34,816: the 1200 x 1200 grid's pooled table is 35,712)
 
 // Entry format: row << 19 | column << 6 | (points - 1): consecutive beams that fall into the SAME stored cell (a third
 // of a 1081-beam scan's) have the same window origin and read the same bytes in every bound and every exact sum of
@@ -959,7 +819,6 @@ constexpr int ORG_LDS = BNB_WAVES * ORG_WAVE * 4;  // bytes per workgroup (34,81
 // 749 entries instead of 1081 points on the bench workload: 12 chunks of loads instead of 17 in everything that
 // follows.  Rows and columns < 8192 (grids up to 8000 cells + border; larger ones take the general kernel).
 constexpr int ORG_COL_SHIFT = 6, ORG_ROW_SHIFT = 19;
-constexpr uint32_t ORG_LIMIT = 1u << 13;
 __device__ __forceinline__ uint32_t org_row(uint32_t o) { return o >> ORG_ROW_SHIFT; }
 __device__ __forceinline__ uint32_t org_col(uint32_t o) { return (o >> ORG_COL_SHIFT) & (ORG_LIMIT - 1u); }
 __device__ __forceinline__ uint32_t org_cnt(uint32_t o) { return (o & 63u) + 1u; }
@@ -979,7 +838,7 @@ __device__ __forceinline__ uint32_t origin_of(const uint32_t *org, int c) { retu
 __device__ __forceinline__ int32_t cache_origins(const BnbParams &P, const float2 *pts, int32_t n_pts, float cf, float sf,
                                                  int32_t cx, int32_t cy, int lane, uint32_t *org, bool merged) {
   uint32_t *base = org - lane;  // the wave's list
-  for (int merge = merged && NHIP_BNB_MERGE_ORIGINS ? 1 : 0; merge >= 0; merge--) {
+  for (int merge = merged ? 1 : 0; merge >= 0; merge--) {
     // (rolled: the origin arithmetic holds a division on its rare path.  The points of the next D chunks are in flight
     //  while one chunk's origins are computed; that array rotates so that its indices stay static.)
     constexpr int D = 6;
@@ -1056,12 +915,10 @@ __device__ __forceinline__ void strip_bounds_c(const BnbParams &P, __amdgpu_buff
   const uint32_t DP = (uint32_t)P.pool4_pitch;
   const uint32_t off = (uint32_t)(2 * Y) * DP + (uint32_t)(4 * X0);
   uint32_t E[3] = {0u, 0u, 0u}, O[3] = {0u, 0u, 0u};  // 16-bit fields: 18 chunks * 255 * 8 lanes < 65536
-#ifndef NHIP_BNB_STRIP_ROUNDS
-#define NHIP_BNB_STRIP_ROUNDS 2
-#endif
-  constexpr int H = OC / NHIP_BNB_STRIP_ROUNDS;  // chunks whose loads are in flight together
+  constexpr int ROUNDS = 2;
+  constexpr int H = OC / ROUNDS;  // chunks whose loads are in flight together
 #pragma unroll
-  for (int h = 0; h < NHIP_BNB_STRIP_ROUNDS; h++) {
+  for (int h = 0; h < ROUNDS; h++) {
     if (H * h >= nch) continue;
     u32x4 w[H];
     uint32_t sh[H], cn[H];
@@ -1143,26 +1000,21 @@ __device__ __forceinline__ uint32_t best_sum_cached(unsigned long long *best, ui
   return GLOBAL ? copy : best_sum<false>(best);
 }
 
-// Exact sums on an 8-BIT plane (the stored image of 8-bit grids; the plane of high bytes of 16-bit grids) of pitch
-// `pitch`, for the rotation whose origins the wave holds.
+// Exact sums on the matcher's 8-BIT plane (the cells of 8-bit grids; the high bytes of 16-bit cells), for the rotation
+// whose origins the wave holds.  The plane is tiled, two copies (nhip_common.h hi_tiled; `pitch` = tiles per tile row,
+// `copy_bytes` = bytes of a copy): a row's bytes come from the copy in which they start in a tile's first half, so no
+// read crosses a tile, and the rows of a point's window are 16 bytes apart inside a tile and (tiles per row - 1) * 128
+// + 16 further at its end.
 // 4 x 4 sub-block (sy, sx) of block (Y, X): four 8-byte row loads per point.  Returns the sum of this lane's pose
 // (*dy, *dx inside the sub-block; lanes 16.. hold copies of lanes 0..15).
-// TILED: the plane is the tiled plane of high bytes (two copies; `pitch` = tiles per tile row, `copy_bytes` = bytes of a
-// copy): a row's 8 bytes come from the copy in which they start in a tile's first half, so no read crosses a tile, and
-// the rows of a point's window are 16 bytes apart inside a tile and (tiles per row - 1) * 128 + 16 further at its end.
-template <bool TILED>
 __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint32_t pitch, uint32_t copy_bytes, const uint32_t *org,
                                               int32_t nch, int32_t Y, int32_t X, int32_t sy, int32_t sx, int lane, int *dy, int *dx) {
-  const uint32_t off = (uint32_t)(BNB_B * Y + BNB_B4 * sy) * pitch + (uint32_t)(BNB_B * X + BNB_B4 * sx);
   const uint32_t roff = (uint32_t)(BNB_B * Y + BNB_B4 * sy), coff = (uint32_t)(BNB_B * X + BNB_B4 * sx);
-  const uint32_t wrap = pitch * HI_TILE_BYTES - HI_TILE_BYTES;  // (TILED) from a tile's last row to the next tile's first
-#ifndef NHIP_BNB_SUB_U8
-#define NHIP_BNB_SUB_U8 2
-#endif
-  // chunks per round: 4 U row loads in flight.  (6 -> 2 together with NHIP_BNB_BLOCK_ROWS 8 -> 4: the same speed within
-  // the run-to-run spread -- profiles/r03_bnb_ab_scratch_free.log -- and the by-rotation kernels fit their 128 registers: no
-  // scratch memory at all, where each launch used to write 225-370 MB of spills for 160 KB of records.)
-  constexpr int U = NHIP_BNB_SUB_U8;
+  const uint32_t wrap = pitch * HI_TILE_BYTES - HI_TILE_BYTES;  // from a tile's last row to the next tile's first
+  // chunks per round: 4 U row loads in flight.  (6 -> 2 together with block_sums8's rows in two groups of four: the same
+  // speed within the run-to-run spread -- profiles/r03_bnb_ab_scratch_free.log -- and the by-rotation kernels fit their 128
+  // registers: no scratch memory at all, where each launch used to write 225-370 MB of spills for 160 KB of records.)
+  constexpr int U = 2;
   static_assert(OC % U == 0, "whole rounds");
   // (18 chunks * 255 * 8 lanes < 65536: the packed fields hold a whole scan)
   uint32_t E[4] = {0u, 0u, 0u, 0u}, O[4] = {0u, 0u, 0u, 0u};
@@ -1174,42 +1026,20 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
 #pragma unroll
     for (int j = 0; j < U; j++) {
       const uint32_t o = origin_of(org, U * r + j);
-#ifdef NHIP_BNB_ROWBAND_EXPERIMENT  // (timing, WRONG results: every 8-row band reads one row -- what a tiled plane could save in L1 lookups)
-      const uint32_t g = (org_row(o) & ~7u) * pitch + org_col(o) + off;
-#else
-      const uint32_t g = org_row(o) * pitch + org_col(o) + off;
-#endif
       cn[j] = org_cnt(o);
-      if (TILED) {
-        const uint32_t row0 = org_row(o) + roff, col0 = org_col(o) + coff, col4 = col0 & ~3u;
-        const uint32_t cp = (col4 >> 3) & 1u, q = row0 & 7u;
-        const uint32_t v0 = hi_tiled(row0, col4, cp, pitch, copy_bytes);
-        sh[j] = (col0 & 3u) * 8u;
+      const uint32_t row0 = org_row(o) + roff, col0 = org_col(o) + coff, col4 = col0 & ~3u;
+      const uint32_t cp = (col4 >> 3) & 1u, q = row0 & 7u;
+      const uint32_t v0 = hi_tiled(row0, col4, cp, pitch, copy_bytes);
+      sh[j] = (col0 & 3u) * 8u;
 #pragma unroll
-        for (int y = 0; y < 4; y++)
-          w[j][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(v0 + (q + (uint32_t)y >= 8u ? wrap : 0u) + 16u * (uint32_t)y), 0, 0);
-        continue;
-      }
-#if NHIP_BNB_UNALIGNED
-      // (the four bytes of a row from their own address: vector memory takes byte addresses on this target, and the
-      //  address unit's time goes with the dwords a lane loads -- one here, two with the aligned read)
-      sh[j] = 0u;
-#pragma unroll
-      for (int y = 0; y < 4; y++) {
-        w[j][y].x = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(g + (uint32_t)y * pitch), 0, 0);
-        w[j][y].y = 0u;
-      }
-#else
-      sh[j] = (g & 3u) * 8u;
-#pragma unroll
-      for (int y = 0; y < 4; y++) w[j][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)((g & ~3u) + (uint32_t)y * pitch), 0, 0);
-#endif
+      for (int y = 0; y < 4; y++)
+        w[j][y] = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(v0 + (q + (uint32_t)y >= 8u ? wrap : 0u) + 16u * (uint32_t)y), 0, 0);
     }
 #pragma unroll
     for (int j = 0; j < U; j++)
 #pragma unroll
       for (int y = 0; y < 4; y++) {
-        const uint32_t n = NHIP_BNB_UNALIGNED && !TILED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+        const uint32_t n = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
         E[y] += __umul24(n & M8, cn[j]);
         O[y] += __umul24(n >> 8, cn[j]);
       }
@@ -1233,17 +1063,12 @@ __device__ __forceinline__ uint32_t sub_sums8(__amdgpu_buffer_rsrc_t rsrc, uint3
 }
 
 // whole 8 x 8 block (Y, X): eight 12-byte row loads per point; lane l holds the sum of pose (*dy, *dx) of the block
-template <bool TILED>
 __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uint32_t pitch, uint32_t copy_bytes, const uint32_t *org,
                                                 int32_t nch, int32_t Y, int32_t X, int lane, int *dy, int *dx) {
-  const uint32_t off = (uint32_t)(BNB_B * Y) * pitch + (uint32_t)(BNB_B * X);
   const uint32_t roff = (uint32_t)(BNB_B * Y), coff = (uint32_t)(BNB_B * X);
-  const uint32_t wrap = pitch * HI_TILE_BYTES - HI_TILE_BYTES;  // (TILED) from a tile's last row to the next tile's first
-// (one chunk's eight row loads in flight: with two the 32 accumulators + 48 row registers spill, measured 5 % slower)
-#ifndef NHIP_BNB_BLOCK_U
-#define NHIP_BNB_BLOCK_U 1
-#endif
-  constexpr int U = NHIP_BNB_BLOCK_U;
+  const uint32_t wrap = pitch * HI_TILE_BYTES - HI_TILE_BYTES;  // from a tile's last row to the next tile's first
+  // (one chunk's eight row loads in flight: with two the 32 accumulators + 48 row registers spill, measured 5 % slower)
+  constexpr int U = 1;
   uint32_t E[8][2], O[8][2];
 #pragma unroll
   for (int y = 0; y < 8; y++) E[y][0] = E[y][1] = O[y][0] = O[y][1] = 0u;
@@ -1252,29 +1077,17 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
     if (U * r >= nch) continue;
     // rows in groups of ROWS per chunk: 8 -> all eight 12-byte loads of a chunk in flight (24 registers), 4 -> two
     // groups of four (12 registers: with the 32 accumulators the kernel then stays inside its 128 registers)
-#ifndef NHIP_BNB_BLOCK_ROWS
-#define NHIP_BNB_BLOCK_ROWS 4
-#endif
-    constexpr int ROWS = NHIP_BNB_BLOCK_ROWS;
+    constexpr int ROWS = 4;
     uint32_t gg[U], sh[U], cn[U], qq[U];
 #pragma unroll
     for (int j = 0; j < U; j++) {
       const uint32_t o = origin_of(org, U * r + j);
-#ifdef NHIP_BNB_ROWBAND_EXPERIMENT  // (timing, WRONG results: every 8-row band reads one row -- what a tiled plane could save in L1 lookups)
-      const uint32_t g = (org_row(o) & ~7u) * pitch + org_col(o) + off;
-#else
-      const uint32_t g = org_row(o) * pitch + org_col(o) + off;
-#endif
       cn[j] = org_cnt(o);
-      sh[j] = NHIP_BNB_UNALIGNED ? 0u : (g & 3u) * 8u;
-      gg[j] = NHIP_BNB_UNALIGNED ? g : g & ~3u;
-      qq[j] = 0u;
-      if (TILED) {  // (12 bytes from a 4-aligned column: the copy in which they start in a tile's first half)
-        const uint32_t row0 = org_row(o) + roff, col0 = org_col(o) + coff, col4 = col0 & ~3u;
-        qq[j] = row0 & 7u;
-        gg[j] = hi_tiled(row0, col4, (col4 >> 3) & 1u, pitch, copy_bytes);
-        sh[j] = (col0 & 3u) * 8u;
-      }
+      // (12 bytes from a 4-aligned column: the copy in which they start in a tile's first half)
+      const uint32_t row0 = org_row(o) + roff, col0 = org_col(o) + coff, col4 = col0 & ~3u;
+      qq[j] = row0 & 7u;
+      gg[j] = hi_tiled(row0, col4, (col4 >> 3) & 1u, pitch, copy_bytes);
+      sh[j] = (col0 & 3u) * 8u;
     }
 #pragma unroll
     for (int y0 = 0; y0 < 8; y0 += ROWS) {
@@ -1282,26 +1095,14 @@ __device__ __forceinline__ uint32_t block_sums8(__amdgpu_buffer_rsrc_t rsrc, uin
 #pragma unroll
       for (int j = 0; j < U; j++)
 #pragma unroll
-        for (int y = 0; y < ROWS; y++) {
-          if (TILED) {
-            w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gg[j] + (qq[j] + (uint32_t)(y0 + y) >= 8u ? wrap : 0u) + 16u * (uint32_t)(y0 + y)), 0, 0);
-            continue;
-          }
-#if NHIP_BNB_UNALIGNED
-          const u32x2 v = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(gg[j] + (uint32_t)(y0 + y) * pitch), 0, 0);
-          w[j][y].x = v.x;
-          w[j][y].y = v.y;
-          w[j][y].z = 0u;
-#else
-          w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gg[j] + (uint32_t)(y0 + y) * pitch), 0, 0);
-#endif
-        }
+        for (int y = 0; y < ROWS; y++)
+          w[j][y] = __builtin_amdgcn_raw_buffer_load_b96(rsrc, (int)(gg[j] + (qq[j] + (uint32_t)(y0 + y) >= 8u ? wrap : 0u) + 16u * (uint32_t)(y0 + y)), 0, 0);
 #pragma unroll
       for (int j = 0; j < U; j++)
 #pragma unroll
         for (int y = 0; y < ROWS; y++) {
-          const uint32_t n0 = NHIP_BNB_UNALIGNED && !TILED ? w[j][y].x : __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
-          const uint32_t n1 = NHIP_BNB_UNALIGNED && !TILED ? w[j][y].y : __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
+          const uint32_t n0 = __builtin_amdgcn_alignbit(w[j][y].y, w[j][y].x, sh[j]);
+          const uint32_t n1 = __builtin_amdgcn_alignbit(w[j][y].z, w[j][y].y, sh[j]);
           E[y0 + y][0] += __umul24(n0 & M8, cn[j]); O[y0 + y][0] += __umul24(n0 >> 8, cn[j]);
           E[y0 + y][1] += __umul24(n1 & M8, cn[j]); O[y0 + y][1] += __umul24(n1 >> 8, cn[j]);
         }
@@ -1480,9 +1281,13 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
   const int alive = (sb0 != 0u && sb0 >= bsum) + (sb1 != 0u && sb1 >= bsum) + (sb2 != 0u && sb2 >= bsum) +
                     (sb3 != 0u && sb3 >= bsum);
   if (alive == 0) return;
-  if (alive >= P.whole_min) {
+  // a block with this many live sub-blocks is evaluated whole: one pass of 8 row loads per point instead of up to four
+  // passes of 4, all 64 poses in one reduction (row-major planes: 2 beat 3, 7.70 -> 7.45 ms per 10,000 pairs; tiled planes:
+  // loads are cheaper and 3 beats 2, 6.37 -> 6.22 ms)
+  constexpr int WHOLE_MIN = 3;
+  if (alive >= WHOLE_MIN) {
     int dy, dx;
-    const uint32_t total = block_sums8<NHIP_BNB_TILED != 0>(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, lane, &dy, &dx);
+    const uint32_t total = block_sums8(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, lane, &dy, &dx);
     const int32_t ix = BNB_B * X + dx, iy = BNB_B * Y + dy;
     if (CB == 1) {
       const unsigned long long key = best_key(P, k, ix, iy, total, 32);
@@ -1499,7 +1304,7 @@ __device__ __forceinline__ void process_candidate_c(const BnbParams &P, __amdgpu
     const uint32_t b = q == 0 ? sb0 : (q == 1 ? sb1 : (q == 2 ? sb2 : sb3));
     if (b == 0u || b < best_sum_cached<GLOBAL>(best, bcopy)) continue;
     int dy, dx;
-    const uint32_t total = sub_sums8<NHIP_BNB_TILED != 0>(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, q >> 1, q & 1, lane, &dy, &dx);
+    const uint32_t total = sub_sums8(rsrc, pitch8, (uint32_t)P.hi_copy_bytes, org, nch, Y, X, q >> 1, q & 1, lane, &dy, &dx);
     const int32_t ix = BNB_B * X + BNB_B4 * (q & 1) + dx, iy = BNB_B * Y + BNB_B4 * (q >> 1) + dy;
     if (CB == 1) {
       const unsigned long long key = best_key(P, k, ix, iy, total, 8);  // (lanes 16.. hold copies)
@@ -1528,32 +1333,20 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
   float cf, sf;
   rotation_k(P, C.pair, k, &cf, &sf);
   if (BNB_STATS(P)) t_mark = clock64();
-  const int32_t nch = cache_origins(P, C.pts, C.n_pts, cf, sf, C.cx, C.cy, lane, org, CB == 2 || NHIP_BNB_MERGE_U8);
+  const int32_t nch = cache_origins(P, C.pts, C.n_pts, cf, sf, C.cx, C.cy, lane, org, true);
   if (BNB_STATS(P)) clk.org += clock64() - t_mark;
   // (stored image + skip map: every offset an evaluation can form lies inside; see nhip_api.hip make_layout)
   // (8-bit grids: the image, on which the exact sums run; 16-bit grids: the tiled copy of the image, for pose_sum16)
   const __amdgpu_buffer_rsrc_t rsrc16 = CB == 1 ? uniform_rsrc(C.grid, P.grid_bytes + P.skip_bytes)
                                                 : uniform_rsrc(C.grid + P.hi_offset + 2 * P.hi_copy_bytes, P.t16_bytes);
-  // the 8-bit plane of the exact block sums: the image itself, or the high bytes of 16-bit cells (+ the 16 bytes a row
-  // load may reach past the plane's last cell: the next slot, or the buffer's read slack)
-  // (the matcher's 8-bit plane, tiled, two copies: the cells of 8-bit grids, the high bytes of 16-bit ones;
-  //  NHIP_BNB_TILED=0, measurement on 8-bit grids only: the row-major image instead)
-  const __amdgpu_buffer_rsrc_t rsrc = (CB == 1 && !NHIP_BNB_TILED) ? rsrc16 : uniform_rsrc(C.grid + P.hi_offset, 2 * P.hi_copy_bytes);
-  const uint32_t pitch8 = (CB == 1 && !NHIP_BNB_TILED) ? (uint32_t)P.pitch : (uint32_t)P.hi_tpr;
+  // the 8-bit plane of the exact block sums, tiled, two copies: the cells of 8-bit grids, the high bytes of 16-bit ones;
+  // pitch8 = its tiles per tile row
+  const __amdgpu_buffer_rsrc_t rsrc = uniform_rsrc(C.grid + P.hi_offset, 2 * P.hi_copy_bytes);
+  const uint32_t pitch8 = (uint32_t)P.hi_tpr;
   const __amdgpu_buffer_rsrc_t p4 = uniform_rsrc(C.grid + P.grid_bytes + P.skip_bytes + P.pool_bytes, P.pool4_bytes);
   // candidates in block order b = NB * Y + X; neighbours in X (up to three) share one pass over the table
   while ((m0 | m1) != 0ull) {
-#if NHIP_BNB_MAX_FIRST
-    // the remaining candidate with the highest bound first (lowest block index among equals): its exact sums are the
-    // likeliest to raise the best, which the others are then checked against
-    const int lane_ = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
-    const uint32_t v0 = ((m0 >> lane_) & 1ull) ? u0 : 0u, v1 = ((m1 >> lane_) & 1ull) ? u1 : 0u;
-    const uint32_t vmax = (uint32_t)__builtin_amdgcn_readfirstlane((int)wave_max(v0 > v1 ? v0 : v1));
-    const unsigned long long e0 = __ballot(v0 == vmax && ((m0 >> lane_) & 1ull)), e1 = __ballot(v1 == vmax && ((m1 >> lane_) & 1ull));
-    const int b0 = e0 ? (int)__builtin_ctzll(e0) : 64 + (int)__builtin_ctzll(e1);
-#else
     const int b0 = m0 ? (int)__builtin_ctzll(m0) : 64 + (int)__builtin_ctzll(m1);
-#endif
     const int Y = b0 / NB, X0 = b0 - NB * Y;
     int len = 1;
     while (len < 3 && X0 + len < NB) {
@@ -1563,7 +1356,6 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
     }
     uint32_t sb[12];
     uint32_t bcopy = GLOBAL ? best_sum<true>(best) : 0u;  // (one look per strip at a best in global memory)
-    if (BNB_DEBUG(P) == 5) break;  // (timing: origins only)
     if (P.levels >= 2) {
       if (BNB_STATS(P)) t_mark = clock64();
       strip_bounds_c(P, p4, org, nch, Y, X0, len, CB == 1 ? 1u : 257u, sb);
@@ -1579,7 +1371,7 @@ __device__ __forceinline__ void rotation_pass(const BnbParams &P, const PairCtx 
       if (b < 64) m0 &= ~(1ull << b);
       else m1 &= ~(1ull << (b - 64));
       const uint32_t ub = (uint32_t)__builtin_amdgcn_readlane((int)(b < 64 ? u0 : u1), b & 63);
-      if (ub < best_sum_cached<GLOBAL>(best, bcopy) || (BNB_DEBUG(P) == 4 && !done)) continue;  // the best has risen meanwhile
+      if (ub < best_sum_cached<GLOBAL>(best, bcopy)) continue;  // the best has risen meanwhile
       // (selects, not an indexed array: that would live in scratch)
       const uint32_t s0 = t == 0 ? sb[0] : (t == 1 ? sb[4] : sb[8]), s1 = t == 0 ? sb[1] : (t == 1 ? sb[5] : sb[9]);
       const uint32_t s2 = t == 0 ? sb[2] : (t == 1 ? sb[6] : sb[10]), s3 = t == 0 ? sb[3] : (t == 1 ? sb[7] : sb[11]);
@@ -1672,8 +1464,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
   if (BNB_TIMELINE(P) && threadIdx.x == 0 && pair < BNB_STATS_PAIRS) BNB_TIMELINE(P)[4 * pair] = wall_clock64();
   if (threadIdx.x == 0) {
     *s_slow = 0ull;
-    // (NHIP_BNB_DEBUG=3, experiments only: start from the keys a previous launch left = the ideal threshold)
-    *s_best = BNB_DEBUG(P) == 3 ? (P.keys[pair] & 0xffffffff00000000ull) : key0;
+    *s_best = key0;
     s_cnt[0] = s_cnt[3] = s_cnt[4] = s_cnt[5] = 0u;
     *s_qn = 0u;
     *s_qhead = 0u;
@@ -1702,7 +1493,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
   // (1) bounds of every block of every rotation this wave owns; the wave's own best bound
   const uint32_t scale = CB == 1 ? 1u : 257u;
   unsigned long long wbest = 0ull;  // (U << 32) | (k << 8 | slot)
-  for (int32_t k = wave; k < P.n_theta && BNB_DEBUG(P) != 31; k += WAVES) {
+  for (int32_t k = wave; k < P.n_theta; k += WAVES) {
     float cf, sf;
     rotation_k(P, pair, k, &cf, &sf);
     uint32_t umax = 0u;
@@ -1748,23 +1539,10 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
   // Longer scans take the general path below.
   if (BY_ROT) {
     // (the pooled table's space becomes the origins' once every wave is done with its bounds)
-    // Seeds: only the P.seeds waves with the highest bounds evaluate theirs (a whole block costs the memory pipeline
-    // what ~50 sub-block bounds do, and the eight blocks are mostly neighbours in rotation: the lower ones rarely raise
-    // the best).  Each wave leaves its bound in its own, now idle, run list.
-    unsigned long long *s_wbest = reinterpret_cast<unsigned long long *>(s_list + wave * LIST_ENTRIES);
-    if (wave_leader(lane)) *s_wbest = wbest;
+    // Seeds: every wave evaluates its highest-bound block.  (Fewer seeds -- only the waves with the highest bounds -- were
+    // measured: 6 -> 8.1 ms, 4 -> 8.3, 1 -> 9.3 against 8.0 per 10,000 pairs; profiles/r03_matcher_experiments.txt.)
     __syncthreads();
-    // (the origins' space holds eight waves' lists: of more waves at most eight evaluate a seed, and a seed's wave
-    //  takes the list of its rank among them)
-    uint32_t org_slot = (uint32_t)wave;
-    if (P.seeds < WAVES || WAVES > BNB_WAVES) {
-      uint32_t above = 0u;
-      for (int w = 0; w < WAVES; w++)
-        above += *reinterpret_cast<unsigned long long *>(s_list + w * LIST_ENTRIES) > wbest ? 1u : 0u;
-      if (above >= (P.seeds < (uint32_t)BNB_WAVES ? P.seeds : (uint32_t)BNB_WAVES)) wbest = 0ull;  // (this wave sits the seeds out)
-      if (WAVES > BNB_WAVES) org_slot = above < (uint32_t)BNB_WAVES ? above : 0u;
-    }
-    uint32_t *org = s_org + org_slot * ORG_WAVE + lane;
+    uint32_t *org = s_org + wave * ORG_WAVE + lane;
     // (NHIP_BNB_STATS=1: shader-clock sums -- wave time in phase 3 by part, and the workgroup's wall time)
     PhaseClocks clk = {0, 0, 0};
     long long t_busy = 0, t_wall = 0;
@@ -1792,7 +1570,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
       unsigned long long m0 = 0ull, m1 = 0ull;
       uint32_t *done = nullptr;
       if (state == SEED) {
-        if ((uint32_t)(wbest >> 32) != 0u && BNB_DEBUG(P) < 2) {
+        if ((uint32_t)(wbest >> 32) != 0u) {
           const int32_t v = (int32_t)(wbest & 0xffu);
           const uint32_t ub = (uint32_t)(wbest >> 32);
           k = (int32_t)((uint32_t)wbest >> 8);
@@ -1804,10 +1582,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
           have = true;
         }
       } else if (state == OWN) {
-        int32_t rank = P.n_theta;
-        if (BNB_DEBUG(P) == 0 || (BNB_DEBUG(P) >= 3 && BNB_DEBUG(P) < 26)) {
-          rank = (int32_t)wave_fetch_add(s_qhead, 1u, lane);
-        }
+        const int32_t rank = (int32_t)wave_fetch_add(s_qhead, 1u, lane);
         if (rank >= P.n_theta) break;
         k = (int32_t)s_order[rank];
         u0 = s_U[k * 128 + lane];
@@ -1905,7 +1680,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
       }
     }
   } else {
-  if ((uint32_t)(wbest >> 32) != 0u && BNB_DEBUG(P) < 2) {
+  if ((uint32_t)(wbest >> 32) != 0u) {
       const int32_t k = (int32_t)((uint32_t)wbest >> 8), v = (int32_t)(wbest & 0xffu);
       const int Y = v / NB, X = v - NB * Y;
       float cf, sf;
@@ -1920,7 +1695,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
     __syncthreads();
     // (3) every block whose bound reaches the best sum found so far.  The survivors cluster in a few rotations,
     // i.e. in a few waves: they go through one queue per workgroup that all eight waves drain.
-    for (int32_t k = wave; k < P.n_theta && (BNB_DEBUG(P) == 0 || BNB_DEBUG(P) == 3); k += BNB_WAVES) {
+    for (int32_t k = wave; k < P.n_theta; k += BNB_WAVES) {
   #pragma unroll
       for (int i = 0; i < 2; i++) {
         const uint32_t u = s_U[k * 128 + lane + 64 * i];
@@ -1946,7 +1721,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
     __syncthreads();
     {
       const uint32_t qn = min(*s_qn, (uint32_t)QCAP);
-      while (BNB_DEBUG(P) == 0 || BNB_DEBUG(P) == 3) {
+      for (;;) {
         const uint32_t i = wave_fetch_add(s_qhead, 1u, lane);
         if (i >= qn) break;
         const unsigned long long entry = s_queue[i];
@@ -2033,21 +1808,21 @@ __global__ __launch_bounds__(256, 4) void csm_bnb_rot_kernel(BnbParams P) {
 
 // ---- the split form's second and third launch ----------------------------------------------------------------
 // The candidates' launch: per XCD (the pairs of a target stay where its grid is L2-resident) the list of its workgroups'
-// pairs.  The pairs with the most candidates left get one more workgroup per P.split_min of them, up to P.split_max (they
-// share the pair's rotations through ps_next and its best through keys[pair]), as long as the XCD's list has room.
-// The list can be ordered by that count, most first (longest-first list scheduling; buckets of 2^sort_coarse
-// sixteenths of an octave) -- measured on the 10,000-pair workload it is not worth it: the candidates' kernel is bound
-// by the vector-memory address unit (TA busy 82 %), the shared heavy pairs leave no tail to hide, and an order by count
-// scatters the pairs of a target in time (L2 misses 4 % -> 30 %): 8.02 ms ordered, 7.78 ms in target order.  So one
-// bucket is the default (sort_coarse = 9).  (sort_coarse = 10, the shared pairs first and the rest in target order:
-// 7.9 ms -- the heavy pairs are better spread over the launch.)  One workgroup per XCD segment.
+// pairs, IN PAIR ORDER -- the workgroups of a target's pairs then run together and share its lines in the XCD's L2.  The
+// pairs with the most candidates left get one more workgroup per P.split_min of them, up to P.split_max (they share the
+// pair's rotations through ps_next and its best through keys[pair]), granted by candidate count from the heaviest down
+// while the XCD's list has room for a whole bucket's.  (Ordering the list by that count -- longest first -- was measured
+// on the 10,000-pair workload and lost: 8.02 ms against 7.78 in target order; the kernel is bound by its memory pipeline,
+// the shared heavy pairs leave no tail to hide, and the order scatters a target's pairs in time, L2 misses 4 % -> 30 %;
+// shared pairs first: 7.9 ms.  profiles/r03_matcher_experiments.txt, commit 5048845 holds the code.)
+// One workgroup per XCD segment.
 constexpr int SORT_THREADS = 1024;
 constexpr int SORT_BUCKETS = 16 * 21;
-__device__ __forceinline__ int cand_bucket(uint32_t c, uint32_t coarse) {  // heaviest = bucket 0
+__device__ __forceinline__ int cand_bucket(uint32_t c) {  // sixteenths of an octave of the count; heaviest = bucket 0
   if (c == 0u) return SORT_BUCKETS - 1;
   const int e = 31 - __builtin_clz(c);                  // floor(log2 c)
   const int f = e >= 4 ? (int)((c >> (e - 4)) & 15u) : (int)((c << (4 - e)) & 15u);
-  const int b = ((16 * e + f) >> coarse) << coarse;      // ascending in c
+  const int b = 16 * e + f;                              // ascending in c
   return b >= SORT_BUCKETS - 1 ? 0 : SORT_BUCKETS - 2 - b;
 }
 __device__ __forceinline__ uint32_t cand_shares(const BnbParams &P, uint32_t c) {
@@ -2056,19 +1831,22 @@ __device__ __forceinline__ uint32_t cand_shares(const BnbParams &P, uint32_t c) 
 }
 
 __global__ __launch_bounds__(SORT_THREADS) void csm_bnb_order_kernel(BnbParams P) {
-  __shared__ uint32_t s_size[SORT_BUCKETS], s_extra[SORT_BUCKETS], s_off[SORT_BUCKETS], s_cur[SORT_BUCKETS];
+  __shared__ uint32_t s_extra[SORT_BUCKETS];
+  __shared__ uint32_t s_wave[SORT_THREADS / 64];
+  __shared__ uint32_t s_base, s_idle;
   __shared__ int s_grant;
   const int32_t xcd = blockIdx.x;
   const int32_t lo = xcd * P.pairs_per_xcd, hi = min(lo + P.pairs_per_xcd, P.n_pairs);
   int32_t *work = P.ps_work + (size_t)xcd * P.ps_work_stride;
-  for (int i = threadIdx.x; i < SORT_BUCKETS; i += SORT_THREADS) s_size[i] = s_extra[i] = s_cur[i] = 0u;
+  for (int i = threadIdx.x; i < SORT_BUCKETS; i += SORT_THREADS) s_extra[i] = 0u;
   for (int i = threadIdx.x; i < P.ps_work_stride; i += SORT_THREADS) work[i] = -1;
+  if (threadIdx.x == 0) s_base = s_idle = 0u;
   __syncthreads();
-  // additional workgroups are granted by candidate count (fine buckets), from the heaviest pairs down, while the list
-  // has room for a whole bucket's
+  // additional workgroups are granted by candidate count, from the heaviest pairs down, while the list has room for a
+  // whole bucket's
   for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
     const uint32_t c = P.ps_count[p];
-    atomicAdd(&s_extra[cand_bucket(c, 0u)], cand_shares(P, c) - 1u);
+    atomicAdd(&s_extra[cand_bucket(c)], cand_shares(P, c) - 1u);
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -2078,64 +1856,33 @@ __global__ __launch_bounds__(SORT_THREADS) void csm_bnb_order_kernel(BnbParams P
     s_grant = grant;
   }
   __syncthreads();
-  // the list's order: buckets of 2^sort_coarse sixteenths of an octave (9: one bucket, the pairs stay in target order)
-  for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
-    const uint32_t c = P.ps_count[p];
-    const uint32_t w = cand_bucket(c, 0u) < s_grant ? cand_shares(P, c) : 1u;
-    atomicAdd(&s_size[P.sort_coarse == 10u ? (w > 1u ? 0 : 1) : cand_bucket(c, P.sort_coarse)], w);
-    P.ps_nw[p] = w;
-  }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    uint32_t off = 0u;
-    for (int b = 0; b < SORT_BUCKETS; b++) {
-      s_off[b] = off;
-      off += s_size[b];
-    }
-  }
-  __syncthreads();
-  if (P.sort_coarse == 9u) {
-    // one bucket: the list in pair order EXACTLY (a prefix sum, not atomics whose order scrambles windows of 1024 pairs):
-    // the workgroups of a target's pairs then run together and share its lines in the XCD's L2
-    __shared__ uint32_t s_wave[SORT_THREADS / 64];
-    __shared__ uint32_t s_base;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    if (threadIdx.x == 0) s_base = s_off[cand_bucket(1u, 9u)];  // (pairs without candidates sit in the last bucket, after these)
-    __syncthreads();
-    for (int32_t p0 = lo; p0 < hi; p0 += SORT_THREADS) {
-      const int32_t p = p0 + (int32_t)threadIdx.x;
-      const bool in = p < hi && P.ps_count[p] != 0u;
-      const uint32_t w = in ? P.ps_nw[p] : 0u;
-      uint32_t v = w;
+  // the pairs with candidates, in pair order EXACTLY (a prefix sum, not atomics whose order scrambles windows of 1024 pairs)
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int32_t p0 = lo; p0 < hi; p0 += SORT_THREADS) {
+    const int32_t p = p0 + (int32_t)threadIdx.x;
+    const uint32_t c = p < hi ? P.ps_count[p] : 0u;
+    const uint32_t w = c != 0u ? (cand_bucket(c) < s_grant ? cand_shares(P, c) : 1u) : 0u;
+    if (p < hi) P.ps_nw[p] = c != 0u ? w : 1u;
+    uint32_t v = w;
 #pragma unroll
-      for (int off = 1; off < 64; off <<= 1) {
-        const uint32_t u = (uint32_t)__shfl_up((int)v, off, 64);
-        if (lane >= off) v += u;
-      }
-      if (lane == 63) s_wave[wv] = v;
-      __syncthreads();
-      uint32_t before = s_base;
-      for (int q = 0; q < wv; q++) before += s_wave[q];
-      const uint32_t at = before + v - w;
-      for (uint32_t j = 0; j < w; j++) work[at + j] = p;
-      __syncthreads();
-      if (threadIdx.x == SORT_THREADS - 1) s_base = before + v;
-      __syncthreads();
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t u = (uint32_t)__shfl_up((int)v, off, 64);
+      if (lane >= off) v += u;
     }
-    // (pairs with no candidate left: their workgroups return at once; any order)
-    for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
-      if (P.ps_count[p] != 0u) continue;
-      const int b = cand_bucket(0u, 9u);
-      work[s_off[b] + atomicAdd(&s_cur[b], 1u)] = p;
-    }
-    return;
-  }
-  for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS) {
-    const uint32_t w = P.ps_nw[p];
-    const int b = P.sort_coarse == 10u ? (w > 1u ? 0 : 1) : cand_bucket(P.ps_count[p], P.sort_coarse);  // (10: the shared pairs first)
-    const uint32_t at = s_off[b] + atomicAdd(&s_cur[b], w);
+    if (lane == 63) s_wave[wv] = v;
+    __syncthreads();
+    uint32_t before = s_base;
+    for (int q = 0; q < wv; q++) before += s_wave[q];
+    const uint32_t at = before + v - w;
     for (uint32_t j = 0; j < w; j++) work[at + j] = p;
+    __syncthreads();
+    if (threadIdx.x == SORT_THREADS - 1) s_base = before + v;
+    __syncthreads();
   }
+  // (behind them the pairs with no candidate left: their workgroups return at once; any order)
+  const uint32_t tail0 = s_base;
+  for (int32_t p = lo + (int32_t)threadIdx.x; p < hi; p += SORT_THREADS)
+    if (P.ps_count[p] == 0u) work[tail0 + atomicAdd(&s_idle, 1u)] = p;
 }
 
 // The work lists, spread form (the default): every pair ONCE in its home XCD's list, in pair order (the pairs of a target
@@ -2172,19 +1919,13 @@ __global__ __launch_bounds__(ORDER_THREADS) void csm_bnb_order_spread_kernel(Bnb
 // the pair's live rotations one at a time, best first.  A pair with one workgroup keeps its hand-out counter and its
 // best in LDS; a shared pair uses ps_next[pair] and keys[pair] -- the code is the same, through generic pointers, with
 // the look-once-per-strip discipline of a best that may live in global memory.
-#ifndef NHIP_BNB_CAND_OCC
-#define NHIP_BNB_CAND_OCC 4  // waves per SIMD the candidates' kernel is compiled for (register budget 512 / that)
-#endif
-#ifndef NHIP_BNB_CAND_WAVES
-#define NHIP_BNB_CAND_WAVES 4  // waves per workgroup of the candidates' kernel
-#endif
-constexpr int CAND_THREADS = 64 * NHIP_BNB_CAND_WAVES;
-#ifndef NHIP_BNB_CAND_OCC16
-#define NHIP_BNB_CAND_OCC16 5  // the same for 16-bit grids: with their planes tiled the working set fits five waves per SIMD
-#endif                         // (6.78 -> 6.43 ms; the row-major 8-bit image thrashes with more than four: 6.7 -> 7.0)
+constexpr int CAND_WAVES = 4;  // waves per workgroup of the candidates' kernel
+constexpr int CAND_THREADS = 64 * CAND_WAVES;
+// waves per SIMD the kernel is compiled for (register budget 512 / that): 4 for 8-bit grids, 5 for 16-bit grids -- with
+// their planes tiled the working set fits five (6.78 -> 6.43 ms; 4 / 6: profiles/r04_bounds_variants.txt)
 template <int CB>
-__global__ __launch_bounds__(CAND_THREADS, CB == 2 ? NHIP_BNB_CAND_OCC16 : NHIP_BNB_CAND_OCC) void csm_bnb_cand_kernel(BnbParams P) {
-  __shared__ uint32_t s_org2[NHIP_BNB_CAND_WAVES * ORG_WAVE];
+__global__ __launch_bounds__(CAND_THREADS, CB == 2 ? 5 : 4) void csm_bnb_cand_kernel(BnbParams P) {
+  __shared__ uint32_t s_org2[CAND_WAVES * ORG_WAVE];
   __shared__ unsigned long long s_best2;
   __shared__ uint32_t s_next2;
   const int lane = threadIdx.x & 63;
@@ -2268,13 +2009,6 @@ int launch_main(const BnbParams &P, size_t lds, int64_t blocks, hipStream_t s) {
                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     if (dev >= 0) lds_set[dev].store(lds, std::memory_order_relaxed);
   }
-#if NHIP_BNB_INSTR
-  if (P.stats && tunable("NHIP_BNB_OCCUPANCY")) {
-    int nb = -1;
-    (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, csm_bnb_kernel<CB, PL, BR, SP>, THREADS, lds);
-    fprintf(stderr, "csm_bnb_kernel<%d,%d,%d,%d>: lds %zu B, %d workgroups per CU\n", CB, (int)PL, (int)BR, (int)SP, lds, nb);
-  }
-#endif
   hipLaunchKernelGGL((csm_bnb_kernel<CB, PL, BR, SP>), dim3((uint32_t)blocks), dim3(THREADS), lds, s, P);
   return NHIP_OK;
 }
@@ -2345,444 +2079,12 @@ int launch_bnb_split_b_instr(const BnbParams &P, int cb, hipStream_t s) {
 #else
 int launch_bnb_split_b(const BnbParams &P, int cb, hipStream_t s) {
 #endif
-  // (NHIP_BNB_CAND_LDS_PAD=<bytes>, measurement: unused dynamic LDS that lowers the workgroups a CU holds)
-  const char *padv = tunable("NHIP_BNB_CAND_LDS_PAD");
-  const size_t lds_pad = padv ? (size_t)atoi(padv) : 0;
-  if (lds_pad > 0) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_cand_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void *>(csm_bnb_cand_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_pad);
-  }
-  if (cb == 1) hipLaunchKernelGGL(csm_bnb_cand_kernel<1>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(CAND_THREADS), lds_pad, s, P);
-  else hipLaunchKernelGGL(csm_bnb_cand_kernel<2>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(CAND_THREADS), lds_pad, s, P);
+  if (cb == 1) hipLaunchKernelGGL(csm_bnb_cand_kernel<1>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(CAND_THREADS), 0, s, P);
+  else hipLaunchKernelGGL(csm_bnb_cand_kernel<2>, dim3((uint32_t)(8 * P.ps_work_stride)), dim3(CAND_THREADS), 0, s, P);
   return NHIP_OK;
 }
 
 }  // namespace bnb
 
-#if !NHIP_BNB_INSTR
-// ---- host side (product build only)
-namespace {
-
-size_t bnb_lds_first(const GridLayout &L, bool pool_lds) {
-  const size_t pool = pool_lds ? (size_t)L.pool_bytes : 0;
-  return pool > (size_t)ORG_LDS ? pool : (size_t)ORG_LDS;
-}
-size_t bnb_lds_bytes(const GridLayout &L, const nhip_search_t *search, bool pool_lds) {
-  return bnb_lds_first(L, pool_lds) + (size_t)search->n_theta * 128 * 4 + (size_t)QCAP * 8 + 64;
-}
-constexpr size_t LDS_MAX = 160 * 1024;
-
-}  // namespace
-
-bool bnb_fits(const GridLayout &L, const nhip_search_t *search) {
-  const int nbx = (search->nx + BNB_B - 1) / BNB_B, nby = (search->ny + BNB_B - 1) / BNB_B;
-  // (the pooled table goes to LDS when it fits beside the bounds; else it is read from global memory)
-  return nbx <= NB && nby <= NB && bnb_lds_bytes(L, search, false) <= LDS_MAX && L.pool_bytes % 16 == 0 &&
-         L.pool_bytes < (1ll << RUN_SHIFT) && L.S + 2 * L.pad < 65536 && search->n_theta <= MAX_ROT;
-}
-
-// Instrumentation buffers (NHIP_BNB_INSTRUMENT=1 only): process-wide, allocated on first use, guarded by g_instr_mu
-static std::mutex g_instr_mu;
-static unsigned long long *g_bnb_timeline = nullptr;
-static unsigned long long *g_bnb_stats = nullptr;
-
-constexpr int64_t BNB_WS_HEADER = 256;  // per XCD 32 bytes: {entries filled, next entry to work}
-// Lists of fewer than SPLIT_MIN_PAIRS pairs: room for 16 handed-over rotations per pair on average (what does not fit is
-// worked by the pair's own workgroup).  The split form: per pair its four counters, 1.5 entries of the candidates' work
-// list and the rows of bounds of up to 64 rotations.  Lists of SPLIT_MIN_PAIRS .. SPLIT_PAIRS pairs take it in ONE round;
-// longer lists in rounds of SPLIT_PAIRS with the candidates of a round on a helper stream beside the next round's bounds,
-// which needs two rounds' state (8.6 GB at 61 rotations); with less workspace they stay fused.  Measured (match ms,
-// one kernel per pair + hand-over / split; tools/r04_small_lists.sh, profiles/r04_small_lists.txt): 30 pairs 0.21 / 0.21,
-// 100 pairs 0.23 / 0.28, 200 pairs 0.71 / 0.60, 300 pairs 1.09 / 0.79, 500 pairs 1.12 / 0.86, 1,000 pairs 1.60 / 1.21,
-// 2,000 pairs 4.02 / 1.95, 3,000 pairs 4.08 / 2.63 (round 3's per-XCD work lists: 4.70), 10,000 pairs 8.1 / 6.4; round 3,
-// 40,000 pairs 27.1 / 22.8, 1,000,000 pairs at 100 per target 606 fused, 663 in rounds of 65,536 without the helper
-// stream (every round pays its own tail), 600 with it, 543 in rounds of 131,072 with it.
-constexpr int64_t SPLIT_PAIRS = 131072, SPLIT_MIN_PAIRS = 192, SPLIT_RING = 16;
-// Rounds of fewer pairs than this deal the additional workgroups of their heavy pairs over all eight XCDs' lists
-// (csm_bnb_order_spread_kernel); longer ones keep them in the pair's home list (csm_bnb_order_kernel), where every XCD
-// has heavy pairs of its own and the tables stay L2-resident.  Measured, match ms home / spread: 3,000 pairs 4.70 / 2.63,
-// 4,500 pairs 3.39 / 3.46, 10,000 pairs 6.38 / 6.54 (profiles/r04_small_lists.txt).
-constexpr int64_t SPREAD_BELOW_PAIRS = 4096;
-int64_t split_bytes_per_pair(int32_t n_theta) { return 16 + 6 + (int64_t)n_theta * 512; }
-constexpr int64_t SPLIT_SLOT_FIXED = 8 * 64 * 4 + 1024;  // per batch: the work lists' floor of 64 extra entries, alignment
-int64_t bnb_workspace_bytes_lists(int32_t n_pairs) {  // (the hand-over lists alone: the one-kernel form)
-  const int64_t n = n_pairs > 0 ? n_pairs : 0;
-  return BNB_WS_HEADER + 8 * (((n + 7) / 8) * 16 + 64) * (int64_t)sizeof(RotEntry);
-}
-int64_t bnb_workspace_bytes(int32_t n_pairs) {
-  const int64_t n = n_pairs > 0 ? n_pairs : 0;
-  const int64_t lists = bnb_workspace_bytes_lists(n_pairs);
-  const char *sp = tunable("NHIP_BNB_SPLIT");  // (=1: the split form for small batches too -- tests)
-  const char *spp = tunable("NHIP_BNB_SPLIT_PAIRS");  // (measurement: pairs the workspace holds state for)
-  const int64_t cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
-  const int64_t m = n <= cap ? n : 2 * cap;  // (a longer list: two rounds' state, so that the helper stream can be used)
-  const bool forced = n > 0 && ((sp && sp[0] == '1') || tunable("NHIP_BNB_SPLIT_BATCH"));
-  const int64_t split = n >= SPLIT_MIN_PAIRS || forced
-                            ? BNB_WS_HEADER + (m / 512 + 4) * SPLIT_SLOT_FIXED + m * split_bytes_per_pair(64) : 0;
-  return lists > split ? lists : split;
-}
-
-// The helper stream of the split form (the candidates of round i run beside the bounds of round i + 1) and the events
-// that order the two.  One set per CALL IN FLIGHT, taken from a per-device pool: a host with one thread per device
-// (nhip_set_device) gets a stream and events of ITS device, and two threads on one device never share
-// events -- a wait binds to the event's latest record, so a shared ring would let one caller's candidates start on the
-// other's bounds.  The pool's mutex is held only to take a set and to put it back, never across the enqueue: the set
-// goes back as soon as the call has enqueued its work (the waits already issued stay bound to their records, and the
-// helper stream runs in order, so the next user queues up behind).  Sets live until the process ends.
-struct SplitSet {
-  int device = -1;
-  hipStream_t stream = nullptr;
-  hipEvent_t ea[SPLIT_RING], eb[SPLIT_RING];
-};
-static std::mutex g_split_mu;
-static std::vector<SplitSet *> g_split_free;
-
-static int split_set_acquire(SplitSet **out) {
-  int dev = -1;
-  NHIP_TRY_HIP(hipGetDevice(&dev));
-  {
-    std::lock_guard<std::mutex> lock(g_split_mu);
-    for (size_t i = 0; i < g_split_free.size(); i++)
-      if (g_split_free[i]->device == dev) {
-        *out = g_split_free[i];
-        g_split_free.erase(g_split_free.begin() + (long)i);
-        return NHIP_OK;
-      }
-  }
-  SplitSet *n = new SplitSet();
-  n->device = dev;
-  hipError_t e = hipStreamCreateWithFlags(&n->stream, hipStreamNonBlocking);
-  for (int i = 0; i < SPLIT_RING && e == hipSuccess; i++) {
-    e = hipEventCreateWithFlags(&n->ea[i], hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&n->eb[i], hipEventDisableTiming);
-  }
-  if (e != hipSuccess) {
-    delete n;  // (what was created stays with the runtime: an allocation failure of streams / events is not a path to tidy)
-    return hip_fail(e, "split form: helper stream / events", __FILE__, __LINE__);
-  }
-  *out = n;
-  return NHIP_OK;
-}
-static void split_set_release(SplitSet *set) {
-  if (!set) return;
-  std::lock_guard<std::mutex> lock(g_split_mu);
-  g_split_free.push_back(set);
-}
-
-// NHIP_BNB_INSTRUMENT=1 selects the instrumented build of the kernels; only then are NHIP_BNB_STATS, NHIP_BNB_TIMELINE
-// and NHIP_BNB_DEBUG (timing experiments: WRONG results) read at all.
-static bool instrumented() {
-  const char *e = tunable("NHIP_BNB_INSTRUMENT");
-  return e && e[0] == '1';
-}
-
-// What the calling thread's last launch_csm_bnb did (nhip_csm_last_launch: tests assert the form a list took).
-static thread_local int32_t t_last_launch[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-void bnb_last_launch(int32_t out[8]) { memcpy(out, t_last_launch, sizeof(t_last_launch)); }
-
-int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
-                   const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
-                   const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
-                   const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
-                   uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s, int *handled,
-                   void *d_workspace, int64_t workspace_bytes, const int32_t *d_pair_kbase) {
-  *handled = 0;
-  if (!bnb_fits(L, search)) return NHIP_OK;
-  *handled = 1;
-  if (n_pairs == 0) return NHIP_OK;
-  BnbParams P;
-  memset(&P, 0, sizeof(P));
-  P.xy = reinterpret_cast<const float2 *>(d_xy);
-  P.offsets = d_offsets;
-  P.grids = d_grids;
-  P.pair_src = d_pair_src;
-  P.pair_slot = d_pair_slot;
-  P.ids = ids;
-  P.rot0_cs = d_rot0_cs;
-  P.delta_cs = d_delta_cs;
-  P.pair_origin = d_pair_origin;
-  P.pair_kbase = d_pair_kbase;
-  P.keys = reinterpret_cast<unsigned long long *>(d_keys);
-  P.n_pairs = n_pairs;
-  P.n_theta = search->n_theta;
-  P.nx = search->nx;
-  P.ny = search->ny;
-  P.hx = (search->nx - 1) / 2;
-  P.hy = (search->ny - 1) / 2;
-  P.nbx = (search->nx + BNB_B - 1) / BNB_B;
-  P.nby = (search->ny + BNB_B - 1) / BNB_B;
-  P.S = L.S;
-  P.pad = L.pad;
-  P.pitch = L.pitch;
-  P.rows = L.S + 2 * L.pad;
-  P.max_shift = spec->max_shift;
-  P.pool_pitch = L.pool_pitch;
-  P.pool_rows = L.pool_rows;
-  P.pairs_per_xcd = (n_pairs + 7) / 8;
-  P.grid_bytes = L.grid_bytes;
-  P.skip_bytes = L.skip_bytes;
-  P.slot_bytes = L.slot_bytes;
-  P.pool_bytes = L.pool_bytes;
-  P.pool4_bytes = L.pool4_bytes;
-  P.pool4_pitch = L.pool4_pitch;
-  P.hi_offset = L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes;
-  P.hi_bytes = L.hi_bytes;
-  P.hi_pitch = L.hi_pitch;
-  P.hi_tpr = L.hi_tpr;
-  P.hi_copy_bytes = L.hi_copy_bytes;
-  P.t16_bytes = L.t16_bytes;
-  P.t16_tpr = L.t16_tpr;
-  // Policies that never change the records (tests run the matcher in every form and compare): read per launch.
-  const char *lv = tunable("NHIP_BNB_LEVELS");  // (1: without the sub-block bounds)
-  P.levels = lv && lv[0] == '1' ? 1 : 2;
-  const char *sd = tunable("NHIP_BNB_SEEDS");  // (waves that evaluate a seed block)
-  P.seeds = sd && atoi(sd) > 0 ? (uint32_t)atoi(sd) : 8u;
-  const char *wm = tunable("NHIP_BNB_WHOLE_MIN");
-  // (row-major planes -- 8-bit grids, and 16-bit grids before their planes were tiled: 2 beats 3, 7.70 -> 7.45 ms per
-  //  10,000 pairs, 1: 7.8, 4: 7.9; tiled planes, both widths now: loads are cheaper and 3 beats 2, 6.37 -> 6.22 ms)
-  P.whole_min = wm ? atoi(wm) : 3;
-  const char *qe = tunable("NHIP_BNB_QUEUE");  // (the general path for every scan)
-  P.general_all = qe && qe[0] == '1';
-  static_assert(NHIP_SHORT_SCAN_POINTS == 64 * OCL, "the header's promise is the by-rotation form's limit");
-  P.short_scans = (search->flags & NHIP_SEARCH_SHORT_SCANS) != 0 && !P.general_all && (uint32_t)P.rows < ORG_LIMIT;
-  P.res = spec->res;
-  P.inv_res = 1.0 / spec->res;
-  P.inv_res_f = (float)P.inv_res;
-  const bool instr = instrumented();
-  if (instr) {
-    std::lock_guard<std::mutex> lock(g_instr_mu);
-    const char *dbg = tunable("NHIP_BNB_DEBUG");
-    P.debug = dbg ? atoi(dbg) : 0;
-    const char *st = tunable("NHIP_BNB_STATS");
-    if (st && st[0] == '1') {
-      if (!g_bnb_stats) {
-        NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_stats), 8 * (BNB_STATS_HEAD + (size_t)BNB_STATS_PAIRS)));
-        NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 8 * (BNB_STATS_HEAD + (size_t)BNB_STATS_PAIRS)));
-      }
-      P.stats = g_bnb_stats;
-    }
-    const char *tl = tunable("NHIP_BNB_TIMELINE");
-    if (tl && tl[0] == '1') {
-      if (!g_bnb_timeline) NHIP_TRY_HIP(hipMalloc(reinterpret_cast<void **>(&g_bnb_timeline), 48 * (size_t)BNB_STATS_PAIRS + 16));
-      P.timeline = g_bnb_timeline;
-      // (the candidates' launch of the split form: first start / last end per pair)
-      NHIP_TRY_HIP(hipMemsetAsync(g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS + 2, 0xff, 8 * (size_t)BNB_STATS_PAIRS, s));
-      NHIP_TRY_HIP(hipMemsetAsync(g_bnb_timeline + 5 * (size_t)BNB_STATS_PAIRS + 2, 0, 8 * (size_t)BNB_STATS_PAIRS, s));
-      const unsigned long long init[2] = {~0ull, 0ull};  // the second kernel's first start and last end
-      NHIP_TRY_HIP(hipMemcpyAsync(g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS, init, 16, hipMemcpyHostToDevice, s));
-    }
-  }
-  // Work sharing.  A flat landscape leaves a pair thousands of candidates (the median pair: ~30): alone on the
-  // chip its workgroup is busy for 3 ms (the median pair: 0.2 ms), and a batch that does not fill the chip many
-  // times over waits for it.  Such a pair (>= heavy_min candidates after bounds and seeds) works only its first
-  // keep_ranks rotations in best-first order (one per wave) itself and hands the others, with the masks of their
-  // candidate blocks, to per-XCD lists in the caller's workspace; a second kernel works the lists with every wave of
-  // the chip, sharing the pair's running best through keys[pair].  Measured (tools/bnb_heavy.py, bnb_quick.py;
-  // profiles/r02_bnb_heavy.json): the heaviest pair alone 2.2 -> 0.94 ms; 30 pairs 0.80 -> 0.45 ms; 500 pairs + the
-  // three heaviest 2.5 -> 1.3 ms.  From ~1000 pairs on the chip is full anyway and handing over only loses pruning
-  // and L2 locality (2,000 pairs 4.6 -> 7.3 ms, 10,000 pairs unchanged), so large batches do not.  (Also tried:
-  // letting the waves of finished workgroups take entries inside the first kernel, and persistent workgroups -- never
-  // a gain.)
-  // NHIP_BNB_KERNELS=1: never, =2: always; NHIP_BNB_HEAVY_MIN=<candidates>, NHIP_BNB_KEEP_RANKS=<n>.
-  const char *force = tunable("NHIP_BNB_KERNELS");
-  const char *hm = tunable("NHIP_BNB_HEAVY_MIN");
-  const char *kr = tunable("NHIP_BNB_KEEP_RANKS");
-  // (lists that take the split form -- SPLIT_MIN_PAIRS pairs and more -- do not hand rotations over: their candidates'
-  //  launch shares the heavy pairs among several workgroups)
-  // The form is decided ONCE, here, from the sizes: the split form's rounds as the workspace allows them, and the
-  // hand-over lists only for lists that do not take the split form.  (Round 4 asked "is there room for 512 pairs' state"
-  // at this point and sized the rounds further down.  nhip_csm_workspace_bytes(n) of a list of 192 .. 487 pairs at 61
-  // rotations is LESS than 512 pairs' state, so for those lists the first test said no, the hand-over lists were set
-  // up, and the split form -- which the header promises from 192 pairs -- was never taken.  Same records; slower.)
-  const char *sp = tunable("NHIP_BNB_SPLIT");
-  const char *sbat = tunable("NHIP_BNB_SPLIT_BATCH");
-  const char *spp = tunable("NHIP_BNB_SPLIT_PAIRS");
-  const int64_t split_cap = spp && atoi(spp) > 0 ? atoi(spp) : SPLIT_PAIRS;
-  int64_t split_batch = 0, split_slots = 0, slot_bytes = 0;
-  if (d_workspace && !P.general_all && P.debug == 0 && !(sp && sp[0] == '0') && !(force && force[0] == '2') &&
-      (n_pairs >= SPLIT_MIN_PAIRS || (sp && sp[0] == '1'))) {
-    split_batch = sbat && atoi(sbat) > 0 ? atoi(sbat) : split_cap;
-    if (split_batch > n_pairs) split_batch = n_pairs;
-    for (;;) {  // (a workspace too small for two batches in flight: smaller batches, down to 512 pairs)
-      slot_bytes = (SPLIT_SLOT_FIXED + split_batch * split_bytes_per_pair(P.n_theta) + 511) & ~(int64_t)511;
-      split_slots = (workspace_bytes - BNB_WS_HEADER - 512) / slot_bytes;
-      const int64_t rounds = (n_pairs + split_batch - 1) / split_batch;
-      if (split_slots >= (rounds < 2 ? rounds : 2) || split_batch <= 512) break;
-      split_batch = split_batch / 2 > 512 ? split_batch / 2 : 512;
-    }
-    if (split_slots > SPLIT_RING) split_slots = SPLIT_RING;
-    if (split_slots < 1) split_batch = 0;  // (no room: the fused form)
-    // (several rounds pay off only with the helper stream, i.e. with two rounds' state, and in rounds that are long)
-    if (!sbat && split_batch > 0 && n_pairs > split_batch && (split_slots < 2 || split_batch < split_cap)) split_batch = 0;
-  }
-  const bool second = force ? force[0] == '2' : (n_pairs < 1024 && split_batch == 0);
-  P.heavy_min = hm ? (uint32_t)atoi(hm) : (n_pairs <= 64 ? 1u : 384u);
-  P.keep_ranks = kr ? (uint32_t)atoi(kr) : 8u;
-  if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * (int64_t)sizeof(RotEntry) && second && !P.general_all) {
-    P.rot_count = static_cast<uint32_t *>(d_workspace);
-    P.rot_list = reinterpret_cast<RotEntry *>(static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER);
-    const int64_t cap = (workspace_bytes - BNB_WS_HEADER) / (int64_t)sizeof(RotEntry) / 8;  // entries per XCD list
-    P.rot_cap = (uint32_t)(cap < 0x0fffffffll ? cap : 0x0fffffffll);
-    NHIP_TRY_HIP(hipMemsetAsync(d_workspace, 0, BNB_WS_HEADER, s));
-  }
-  const bool pool_lds = bnb_lds_bytes(L, search, true) <= LDS_MAX;
-  size_t lds = bnb_lds_bytes(L, search, pool_lds);
-  // (NHIP_BNB_LDS_PAD=<bytes>, measurement: unused LDS behind the workgroup's own, which lowers the workgroups a CU holds)
-  if (const char *lp = tunable("NHIP_BNB_LDS_PAD"))
-    if (atoi(lp) > 0 && lds + (size_t)atoi(lp) <= LDS_MAX) lds += (size_t)atoi(lp);
-  P.lds_first = (int32_t)bnb_lds_first(L, pool_lds);
-  const int64_t blocks = (int64_t)P.pairs_per_xcd * 8;
-  const bool second_kernel = P.rot_list && (P.debug == 0 || (P.debug >= 3 && P.debug < 26));
-  // Large batches: the split form, in rounds of as many pairs as the workspace holds state for.
-  // NHIP_BNB_SPLIT=0: never, =1: whenever the workspace allows; NHIP_BNB_SPLIT_MIN=<candidates per additional
-  // workgroup of a pair>, NHIP_BNB_SPLIT_MAX=<workgroups per pair>.
-  const char *smin = tunable("NHIP_BNB_SPLIT_MIN");
-  const char *smax = tunable("NHIP_BNB_SPLIT_MAX");
-  const char *sov = tunable("NHIP_BNB_SPLIT_OVERLAP");
-  const char *sco = tunable("NHIP_BNB_SORT_COARSE");  // (buckets of 2^n sixteenths of an octave: 4 = one per octave)
-  const char *spr = tunable("NHIP_BNB_SPREAD");       // (0: round 3's work lists, a pair's workgroups all in its home XCD's)
-  const bool spread_forced = spr && spr[0] == '1';
-  if (P.rot_list) split_batch = 0;  // (hand-over lists in the workspace: one kernel per pair)
-  // (an error return between timer_begin and timer_end closes the open slot)
-  struct TimerScope {
-    int id;
-    hipStream_t s;
-    bool open = true;
-    TimerScope(int i, hipStream_t st) : id(i), s(st) { timer_begin(id, s); }
-    void end() {
-      if (open) timer_end(id, s);
-      open = false;
-    }
-    ~TimerScope() { end(); }
-  };
-  TimerScope t_all(NHIP_TIMER_CSM, s);
-  {
-    const int64_t rounds = split_batch > 0 ? (n_pairs + split_batch - 1) / split_batch : 1;
-    const bool ov = split_batch > 0 && !(sov && sov[0] == '0') && split_slots >= 2 && n_pairs > split_batch;
-    const int32_t info[8] = {split_batch > 0 ? (ov ? 3 : (rounds > 1 ? 2 : 1)) : 0, (int32_t)split_batch, (int32_t)split_slots,
-                             (int32_t)rounds, P.short_scans, second_kernel ? 1 : 0, instr ? 1 : 0, n_pairs};
-    memcpy(t_last_launch, info, sizeof(info));
-  }
-  if (split_batch > 0) {
-    // Candidates (bound by the L1's lookups) beside the next batch's bounds (bound by the vector ALUs): the first part
-    // of every batch on the caller's stream, the second on the helper stream, each batch's state in its own slot of the
-    // workspace.  NHIP_BNB_SPLIT_OVERLAP=0: everything on the caller's stream.
-    const bool overlap = !(sov && sov[0] == '0') && split_slots >= 2 && n_pairs > split_batch;
-    SplitSet *set = nullptr;
-    if (overlap) {
-      const int rc = split_set_acquire(&set);
-      if (rc) return rc;
-    }
-    struct SetGuard {
-      SplitSet *p;
-      ~SetGuard() { split_set_release(p); }
-    } set_guard{set};
-    hipStream_t s2 = overlap ? set->stream : s;
-    uint8_t *base = static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER;
-    base += (512 - (reinterpret_cast<uintptr_t>(base) & 511)) & 511;
-    int64_t round = 0;
-    for (int64_t b0 = 0; b0 < n_pairs; b0 += split_batch, round++) {
-      const int32_t nb = (int32_t)(n_pairs - b0 < split_batch ? n_pairs - b0 : split_batch);
-      BnbParams Q = P;
-      Q.pair_src += b0;
-      Q.pair_slot += b0;
-      Q.rot0_cs += 2 * b0;
-      if (Q.pair_origin) Q.pair_origin += 2 * b0;
-      Q.keys += b0;
-      Q.n_pairs = nb;
-      Q.pairs_per_xcd = (nb + 7) / 8;
-      Q.ps_work_stride = Q.pairs_per_xcd + (Q.pairs_per_xcd / 2 > 64 ? Q.pairs_per_xcd / 2 : 64);
-      Q.split_min = smin ? (uint32_t)(atoi(smin) > 0 ? atoi(smin) : 1) : 300u;
-      Q.split_max = smax ? (uint32_t)(atoi(smax) > 0 ? atoi(smax) : 1) : (nb < SPREAD_BELOW_PAIRS ? 16u : 8u);
-      Q.sort_coarse = sco ? (uint32_t)atoi(sco) : 9u;  // (one bucket: see csm_bnb_order_kernel)
-      uint8_t *w = base + (round % split_slots) * slot_bytes;
-      Q.ps_count = reinterpret_cast<uint32_t *>(w);
-      Q.ps_live = Q.ps_count + nb;
-      Q.ps_next = Q.ps_live + nb;
-      Q.ps_nw = Q.ps_next + nb;
-      // (spread form: the ticket counter of the additional workgroups, zeroed with the four arrays before it)
-      const bool spread = !sco && (spread_forced || (!(spr && spr[0] == '0') && nb < SPREAD_BELOW_PAIRS));
-      Q.ps_ticket = spread ? Q.ps_nw + nb : nullptr;
-      Q.ps_work = reinterpret_cast<int32_t *>(Q.ps_nw + nb + 4);
-      const uintptr_t rows = (reinterpret_cast<uintptr_t>(Q.ps_work + 8 * (size_t)Q.ps_work_stride) + 511) & ~(uintptr_t)511;
-      Q.ps_rows = reinterpret_cast<uint32_t *>(rows);
-      NHIP_REQUIRE((int64_t)(rows - reinterpret_cast<uintptr_t>(w)) + (int64_t)nb * P.n_theta * 512 <= slot_bytes &&
-                       w + slot_bytes <= static_cast<uint8_t *>(d_workspace) + workspace_bytes,
-                   "csm_bnb: workspace accounting");
-      // (the slot's previous batch must be through its candidates)
-      if (overlap && round >= split_slots) NHIP_TRY_HIP(hipStreamWaitEvent(s, set->eb[(round - split_slots) % SPLIT_RING], 0));
-      NHIP_TRY_HIP(hipMemsetAsync(w, 0, 16 * (size_t)nb + 16, s));
-      if (spread) NHIP_TRY_HIP(hipMemsetAsync(Q.ps_work, 0xff, 32 * (size_t)Q.ps_work_stride, s));  // (-1: no pair)
-      const int64_t blocks_b = (int64_t)Q.pairs_per_xcd * 8;
-      {
-        TimerScope t_a(NHIP_TIMER_CSM_BOUNDS, s);
-        const int rc = instr ? bnb::launch_bnb_split_a_instr(Q, L.cb, pool_lds, lds, blocks_b, s)
-                             : bnb::launch_bnb_split_a(Q, L.cb, pool_lds, lds, blocks_b, s);
-        if (rc) return rc;
-      }
-      if (overlap) {
-        NHIP_TRY_HIP(hipEventRecord(set->ea[round % SPLIT_RING], s));
-        NHIP_TRY_HIP(hipStreamWaitEvent(s2, set->ea[round % SPLIT_RING], 0));
-      }
-      {
-        TimerScope t_b(NHIP_TIMER_CSM_CAND, s2);
-        const int rc = instr ? bnb::launch_bnb_split_b_instr(Q, L.cb, s2) : bnb::launch_bnb_split_b(Q, L.cb, s2);
-        if (rc) return rc;
-      }
-      if (overlap) NHIP_TRY_HIP(hipEventRecord(set->eb[round % SPLIT_RING], s2));
-    }
-    // (the helper stream works in order: its last batch done, all are)
-    if (overlap) NHIP_TRY_HIP(hipStreamWaitEvent(s, set->eb[(round - 1) % SPLIT_RING], 0));
-    t_all.end();
-    NHIP_TRY_HIP(hipGetLastError());
-    launch_csm_finalize(d_keys, d_pair_src, d_offsets, ids.n_scans, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
-    NHIP_TRY_HIP(hipGetLastError());
-    return NHIP_OK;
-  }
-  // (Tried and removed: the batch as K launches on K streams, so that one hardware queue's in-order dispatch does not
-  //  keep free slots empty -- 2 / 4 / 8 queues took 10 / 30 / 45 % longer, profiles/r03_matcher_experiments.txt.)
-  const int rc = instr ? bnb::launch_bnb_kernels_instr(P, L.cb, pool_lds, lds, blocks, second_kernel, s)
-                       : bnb::launch_bnb_kernels(P, L.cb, pool_lds, lds, blocks, second_kernel, s);
-  if (rc) return rc;
-  t_all.end();
-  NHIP_TRY_HIP(hipGetLastError());
-  launch_csm_finalize(d_keys, d_pair_src, d_offsets, ids.n_scans, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
-  NHIP_TRY_HIP(hipGetLastError());
-  return NHIP_OK;
-}
-
-// NHIP_BNB_STATS=1: (blocks evaluated exactly, blocks in all) since the last call; resets the counters
-int bnb_stats_per_pair(unsigned long long *out, int32_t n) {
-  if (!g_bnb_stats || n <= 0) return NHIP_OK;
-  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_stats + BNB_STATS_HEAD, 8 * (size_t)(n < BNB_STATS_PAIRS ? n : BNB_STATS_PAIRS), hipMemcpyDeviceToHost));
-  return NHIP_OK;
-}
-
-int bnb_timeline_read(unsigned long long *out, int32_t n) {
-  if (!g_bnb_timeline || n <= 0) return NHIP_OK;
-  if (n > BNB_STATS_PAIRS) n = BNB_STATS_PAIRS;
-  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_timeline, 32 * (size_t)n, hipMemcpyDeviceToHost));
-  // (the last pair's slot is followed by the second kernel's first start / last end)
-  NHIP_TRY_HIP(hipMemcpy(out + 4 * (size_t)n, g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS, 16, hipMemcpyDeviceToHost));
-  return NHIP_OK;
-}
-
-int bnb_timeline_cand_read(unsigned long long *out, int32_t n) {  // out[0..n): first start, out[n..2n): last end
-  if (!g_bnb_timeline || n <= 0) return NHIP_OK;
-  if (n > BNB_STATS_PAIRS) n = BNB_STATS_PAIRS;
-  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_timeline + 4 * (size_t)BNB_STATS_PAIRS + 2, 8 * (size_t)n, hipMemcpyDeviceToHost));
-  NHIP_TRY_HIP(hipMemcpy(out + n, g_bnb_timeline + 5 * (size_t)BNB_STATS_PAIRS + 2, 8 * (size_t)n, hipMemcpyDeviceToHost));
-  return NHIP_OK;
-}
-
-int bnb_stats_read(unsigned long long out[16]) {
-  for (int i = 0; i < BNB_STATS_HEAD; i++) out[i] = 0;
-  if (!g_bnb_stats) return NHIP_OK;
-  NHIP_TRY_HIP(hipMemcpy(out, g_bnb_stats, 8 * BNB_STATS_HEAD, hipMemcpyDeviceToHost));
-  NHIP_TRY_HIP(hipMemset(g_bnb_stats, 0, 8 * BNB_STATS_HEAD));
-  return NHIP_OK;
-}
-
-#endif  // !NHIP_BNB_INSTR
 
 }  // namespace nhip

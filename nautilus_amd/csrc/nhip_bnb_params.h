@@ -6,6 +6,20 @@
 namespace nhip {
 namespace bnb {
 
+// ---- sizes the kernels (nhip_bnb.hip) and their host side (nhip_bnb_host.hip) share
+constexpr int BNB_WAVES = 8;          // waves per workgroup of csm_bnb_kernel
+constexpr int NB = BNB_MAX_NB;        // blocks per axis held in registers (11: nx, ny <= 88)
+constexpr int MAX_ROT = 340;          // rotations per search: QCAP * 4 bytes hold their 12 bytes of ordering data
+constexpr int QCAP = 1024;            // candidate queue entries per workgroup (overflow is evaluated by the wave that found it)
+constexpr int RUN_SHIFT = 25;         // run-list entry = pooled offset | (index of the run's first point mod 128) << RUN_SHIFT
+constexpr int OC = 18;                // 64-entry chunks the by-rotation passes are unrolled for
+constexpr int OCL = 17;               // chunks of window origins a wave holds: 1088 points (a 1081-beam scan)
+constexpr int ORG_WAVE = OCL * 64;    // words of LDS per wave
+constexpr int ORG_LDS = BNB_WAVES * ORG_WAVE * 4;  // bytes per workgroup (34,816: the 1200 x 1200 grid's pooled table is 35,712)
+constexpr uint32_t ORG_LIMIT = 1u << 13;           // rows / columns of a stored grid the packed origins hold
+constexpr int BNB_STATS_PAIRS = 1 << 20;           // per-pair counters kept by NHIP_BNB_STATS=1
+constexpr int BNB_STATS_HEAD = 16;    // totals: 4 counts, then shader-clock sums of the by-rotation kernel (see nhip_bnb_stats_levels)
+
 // One rotation of a pair with many candidates, handed to the second kernel: (pair, rotation) and the mask of its
 // 121 candidate blocks.
 struct RotEntry {
@@ -46,23 +60,14 @@ struct BnbParams {
   int32_t ps_work_stride;
   uint32_t split_min;   // candidates per additional workgroup of a pair
   uint32_t split_max;   // workgroups per pair at most
-  uint32_t sort_coarse; // log2 of the width of the ordering's buckets in sixteenths of an octave of the candidate count
-  uint32_t seeds;       // waves of a pair's workgroup that evaluate a seed block (those with the highest bounds)
   int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
   int32_t S, pad, pitch, rows, max_shift;
   int32_t pool_pitch, pool_rows, pairs_per_xcd;
   int32_t pool4_pitch;
   int32_t lds_first;    // bytes of the kernel's first LDS region: max(pooled table if staged, origins)
-  int32_t whole_min;    // sub-blocks alive from which an 8-bit block is evaluated whole (3; NHIP_BNB_WHOLE_MIN)
   int32_t general_all;  // the general instantiation takes every pair (NHIP_BNB_QUEUE=1)
   int32_t short_scans;  // the caller vouches that every scan fits the by-rotation form (NHIP_SEARCH_SHORT_SCANS)
   int32_t levels;  // 2: candidates are refined through the 4 x 4 sub-block bounds; 1: evaluated whole (NHIP_BNB_LEVELS)
-  int32_t debug;   // NHIP_BNB_DEBUG (timing experiments only, results are wrong): 1 = no phase 3, 2 = bounds only,
-                   // 4 = phase 3 without exact sums, 5 = phase 3 without sub-block bounds and exact sums,
-                   // 26 / 27 = bounds only, without their reductions / gathers; 28 = without the run lists too,
-                   // 29 = without the window origins too, 30 = no chunk loop, 31 = no rotations (staging + launch).
-                   // With NHIP_BNB_STATS=1 the counters' atomics dominate the short forms: time those as product
-                   // builds with -DNHIP_BNB_EXPERIMENT=<value> (tools/bnb_variants.sh)
   int64_t grid_bytes, skip_bytes, slot_bytes, pool_bytes, pool4_bytes;
   int64_t hi_offset, hi_bytes;  // 16-bit grids: the plane of high bytes inside a slot
   int32_t hi_pitch;
