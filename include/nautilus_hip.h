@@ -104,8 +104,8 @@ typedef struct nhip_grid_layout {
                           so the correlation kernel can leave out window strips that only add zeros (same
                           sums, bit for bit).  Built for 8-bit cells always, for 16-bit cells when the spec carries
                           NHIP_GRID_SKIP_MAP (the branch-and-bound matcher never reads it); zero otherwise */
-  int64_t slot_bytes;  /* grid_bytes + skip_bytes + pool_bytes + pool4_bytes + hi_bytes: grid t of a buffer starts at
-                          byte t*slot_bytes */
+  int64_t slot_bytes;  /* grid_bytes + skip_bytes + pool_bytes + pool4_bytes + hi_bytes + hits_bytes: grid t of a buffer
+                          starts at byte t*slot_bytes */
   int64_t pool_bytes;  /* bytes of the max-pooled table stored after the skip map (branch-and-bound bounds):
                           pool_rows x pool_pitch bytes, entry (i, j) = max of stored cells [8i, 8i+15) x [8j, 8j+15)
                           (16-bit cells: ceil(max / 257)), so that the sum of pooled entries bounds every score of
@@ -126,7 +126,10 @@ typedef struct nhip_grid_layout {
                           255*points bounds a pose's 16-bit sum from above -- and reads 16-bit cells for the few poses
                           whose bound still reaches the best sum: same records, bit for bit */
   int32_t hi_pitch;
-  int32_t reserved;
+  int32_t hits_pitch;  /* bytes per bit row of the hit raster (below) */
+  int64_t hits_bytes;  /* after the matcher's planes, the HIT RASTER the table was blurred from: one bit per cell, rows
+                          side + 64 (a zero border of 32 cells on every side), hits_pitch bytes each; bit (row, col) is bit
+                          (col + 32) & 31 of dword (col + 32) >> 5 of bit row row + 32.  NHIP_SEARCH_EXACT_SCORE reads it */
 } nhip_grid_layout_t;
 
 /* Pure host helpers (work without a GPU). */
@@ -173,6 +176,14 @@ typedef struct nhip_search {
  * whatever d_keys held).  The handle API (nhip_csm_match) knows the lengths and sets the flag itself. */
 #define NHIP_SEARCH_SHORT_SCANS 4
 #define NHIP_SHORT_SCAN_POINTS 1088
+/* NHIP_SEARCH_EXACT_SCORE: the record's `score` is the winning pose's mean log-likelihood on the UNQUANTISED table -- what a
+ * table of doubles (the reference's CImg<double>, cimg_debug.h:19) gives at that pose -- instead of Lf + step * sum / N on the
+ * quantised cells.  Indices and integer sums are unchanged (the search itself runs on the quantised table); one more kernel
+ * recomputes, for the one pose that won, the exact integer blur sum of each cell a point reads from the slot's hit raster
+ * and its logarithm in double (~0.05 ms per 10,000 pairs).  Without the flag a reported score is within half a
+ * quantisation step of that value per cell -- measured up to 2.3e-5 relative on 1,300 pairs with 16-bit cells, 8.5e-4 with
+ * 8-bit cells; with it, within double rounding (the record's float: 6e-8). */
+#define NHIP_SEARCH_EXACT_SCORE 8
 
 /* One result per candidate pair: 16 bytes, the record that is all-gathered across GPUs. */
 typedef struct nhip_match {
@@ -181,6 +192,18 @@ typedef struct nhip_match {
   int32_t iy;
   float score; /* mean log-likelihood (<= 0), cf. csm_score_threshold = -5 (default_config.lua:85) */
 } nhip_match_t;
+
+/* Device memory of the handle API.  Handles own their device buffers; a buffer a handle lets go of (nhip_*_free, the
+ * workspace and scratch of nhip_csm_match, ...) is KEPT for the next allocation of the same device that it fits (at most
+ * twice the size asked for) instead of going back to the driver: hipFree is a device-wide synchronisation whose cost is not
+ * the library's to bound (measured: 0.2 - 8 ms per call on a quiet device, 0.33 s per call for seconds after another client
+ * of the process released 130 GB).  At most max_bytes are kept per process (default 32 GB; least
+ * recently released out first; 0 = nothing is kept, every release is a hipFree); nhip_device_pool_release() returns
+ * everything to the driver now; _stats reports what is held.  A failed allocation releases the pool and tries again.
+ * The "_dev" entry points never allocate and are not concerned. */
+int nhip_device_pool_configure(int64_t max_bytes);
+int nhip_device_pool_release(void);
+int nhip_device_pool_stats(int64_t *entries, int64_t *bytes);
 
 /* Wall-clock seconds of the calling thread's last handle-API call (nhip_scans_upload, nhip_grids_build, nhip_csm_match and
  * the _free calls), by what the host waited for: out[0] hipMalloc, [1] zero-fill + host-to-device copies, [2] from the first
@@ -412,6 +435,8 @@ int nhip_grids_download_skip_map(const nhip_grids_t *grids, int32_t slot, uint8_
 int nhip_grids_download_pool(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* the same for the second-level table: layout.pool4_bytes bytes (pool4_rows x pool4_pitch) */
 int nhip_grids_download_pool4(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
+/* the hit raster of grid `slot`: layout.hits_bytes bytes (bit rows of hits_pitch bytes; see nhip_grid_layout_t.hits_bytes) */
+int nhip_grids_download_hits(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 
 /* Batched GetTransformation: theta0[i] = AngleMod(rot_a - rot_b) of pair i;
  * pair_origin: NULL or 2 int32 per pair (search centre in cells). */

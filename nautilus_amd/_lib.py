@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("NHIP_LIB") or os.path.join(_HERE, "lib", "libnautilus
 
 NHIP_OK, NHIP_ERR_ARG, NHIP_ERR_NODEV, NHIP_ERR_HIP, NHIP_ERR_ALLOC, NHIP_ERR_STATE = 0, -1, -2, -3, -4, -5
 NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1
-NHIP_SEARCH_EXHAUSTIVE, NHIP_SEARCH_DENSE, NHIP_SEARCH_SHORT_SCANS = 1, 2, 4
+NHIP_SEARCH_EXHAUSTIVE, NHIP_SEARCH_DENSE, NHIP_SEARCH_SHORT_SCANS, NHIP_SEARCH_EXACT_SCORE = 1, 2, 4, 8
 NHIP_SHORT_SCAN_POINTS = 1088
 NHIP_GRID_SKIP_MAP = 1
 NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ, NHIP_TIMER_GRID_CLEAR = 0, 1, 2, 3, 4, 5
@@ -39,7 +39,7 @@ class GridLayout(C.Structure):
                 ("skip_bytes", C.c_int64), ("slot_bytes", C.c_int64), ("pool_bytes", C.c_int64),
                 ("pool_pitch", C.c_int32), ("pool_rows", C.c_int32), ("pool4_bytes", C.c_int64),
                 ("pool4_pitch", C.c_int32), ("pool4_rows", C.c_int32), ("hi_bytes", C.c_int64),
-                ("hi_pitch", C.c_int32), ("reserved", C.c_int32)]
+                ("hi_pitch", C.c_int32), ("hits_pitch", C.c_int32), ("hits_bytes", C.c_int64)]
 
 
 class Search(C.Structure):
@@ -77,6 +77,9 @@ PROTOTYPES = {
     "nhip_score_from_sum": (_f64, [_P(GridSpec), _i64, _i32]),
     "nhip_dev_status": (C.c_int, [_vp, _P(_i32)]),
     "nhip_host_phases": (C.c_int, [_P(_f64)]),
+    "nhip_device_pool_configure": (C.c_int, [_i64]),
+    "nhip_device_pool_release": (C.c_int, []),
+    "nhip_device_pool_stats": (C.c_int, [_P(_i64), _P(_i64)]),
     "nhip_grid_build_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
     "nhip_grid_rebuild_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _vp, _vp, _i64, _vp]),
     "nhip_csm_match_dev": (C.c_int, [_vp, _vp, _i32, _vp, _i32, _P(GridSpec), _vp, _vp, _vp, _vp, _vp, _i32,
@@ -113,6 +116,7 @@ PROTOTYPES = {
     "nhip_grids_download_tiled16": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_pool": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_pool4": (C.c_int, [_vp, _i32, _vp]),
+    "nhip_grids_download_hits": (C.c_int, [_vp, _i32, _vp]),
     "nhip_csm_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _P(Search), _vp, _vp]),
     "nhip_csm_scores": (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, _i32, _P(Search), _vp]),
     "nhip_lc_scatter_scores_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),

@@ -28,12 +28,14 @@ def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, ce
                     _lib.NHIP_GRID_SKIP_MAP if skip_map else 0, 0)
 
 
-def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0), exhaustive=False, dense=False, short_scans=False):
+def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0), exhaustive=False, dense=False, short_scans=False,
+                exact_score=False):
     """exhaustive=True forces the kernel that performs every add (dense=True: the all-zero strips too); the default
     (branch and bound) returns the same records bit for bit.  short_scans=True is the caller's promise that no source
-    scan of the list has more than 1088 points (nautilus_hip.h, NHIP_SEARCH_SHORT_SCANS)."""
+    scan of the list has more than 1088 points (nautilus_hip.h, NHIP_SEARCH_SHORT_SCANS).  exact_score=True: the records'
+    scores are the winning poses' scores on the unquantised table (NHIP_SEARCH_EXACT_SCORE)."""
     flags = (_lib.NHIP_SEARCH_EXHAUSTIVE if exhaustive else 0) | (_lib.NHIP_SEARCH_DENSE if dense else 0) | \
-            (_lib.NHIP_SEARCH_SHORT_SCANS if short_scans else 0)
+            (_lib.NHIP_SEARCH_SHORT_SCANS if short_scans else 0) | (_lib.NHIP_SEARCH_EXACT_SCORE if exact_score else 0)
     return Search(int(n_theta), int(nx), int(ny), flags, float(theta_step))
 
 
@@ -150,6 +152,16 @@ class LikelihoodGrids:
             out = np.empty((L.pool4_rows, L.pool4_pitch), dtype=np.uint8)
             check(_lib.load().nhip_grids_download_pool4(self._h, int(slot), ptr(out)))
         return out
+
+    def hits(self, slot):
+        """The hit raster the table was blurred from, as (side, side) uint8 of 0 / 1 (on the device: one bit per cell with a
+        zero border of 32 cells; NHIP_SEARCH_EXACT_SCORE reads it)."""
+        L = self.layout
+        raw = np.empty(L.hits_bytes, dtype=np.uint8)
+        check(_lib.load().nhip_grids_download_hits(self._h, int(slot), ptr(raw)))
+        rows = raw[:L.hits_pitch * (L.side + 64)].reshape(L.side + 64, L.hits_pitch)
+        bits = np.unpackbits(rows, axis=1, bitorder="little")
+        return bits[32:32 + L.side, 32:32 + L.side]
 
     def interior(self, slot):
         L = self.layout

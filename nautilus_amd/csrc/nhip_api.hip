@@ -118,7 +118,10 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   L->t16_tpr = L->cb == 2 ? L->hi_pitch / 8 : 0;
   L->t16_bytes = (int64_t)((L->S + 2 * L->pad + 7) / 8) * L->t16_tpr * (int64_t)HI_TILE_BYTES;
   L->hi_bytes = 2 * L->hi_copy_bytes + L->t16_bytes;  // (the matcher's private planes, all three)
-  L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes + L->hi_bytes;
+  // the hit raster, one bit per cell + a zero border of HIT_PAD cells: bit rows of whole dwords
+  L->hits_pitch = ((L->S + 2 * HIT_PAD + 31) / 32) * 4;
+  L->hits_bytes = (((int64_t)L->hits_pitch * (L->S + 2 * HIT_PAD) + 8) + 15) & ~15ll;  // (+ 8: a row's last 64-bit window)
+  L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes + L->hi_bytes + L->hits_bytes;
   L->Lf = log(spec->floor_p);
   L->step = -L->Lf / (double)L->levels;
   // integer taps: round(16384 * g_i / sum g)
@@ -246,7 +249,75 @@ static void phases_reset() {
   for (double &v : t_phase) v = 0.0;
 }
 
-// ---------------------------------------------------------------- handles
+// ---------------------------------------------------------------- device buffers of the handle API
+// The handle entry points own their device memory and used to hipMalloc / hipFree it per call.  Measured in round 5
+// (tools/r05_host_api_stall.py, profiles/r05_host_api_stall.txt): on a quiet device the pair costs microseconds, but
+// hipFree is a device-wide synchronisation whose cost is the driver's -- 0.2 to 8 ms per nhip_csm_match call for its 328 MB
+// of workspace, and 0.33 s PER hipFree of the 12 GB of tables for seconds after another client of the process (torch's
+// caching allocator) had released 130 GB; round 4's bench saw one host-buffer call in five take 4 s.  So released buffers
+// are kept, per device, up to a byte cap (nhip_device_pool_configure; least recently released out first) and handed to
+// the next allocation they fit (at most twice the size asked for): a loop of build / match / free touches the driver's
+// allocator once.  Contents are never assumed: every user initialises what it reads.
+namespace {
+struct PoolEntry {
+  void *p;
+  size_t bytes;
+  int device;
+};
+std::mutex g_pool_mu;
+std::vector<PoolEntry> &g_pool = *new std::vector<PoolEntry>();  // oldest first (never destroyed: see the drop-in cache below)
+int64_t g_pool_cap = 32ll << 30;
+constexpr size_t POOL_MAX_ENTRIES = 32;
+
+int current_device() {
+  int d = -1;
+  if (hipGetDevice(&d) != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
+  }
+  return d;
+}
+void *pool_take(size_t n, size_t *got) {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  size_t best = g_pool.size();
+  for (size_t i = 0; i < g_pool.size(); i++)
+    if (g_pool[i].device == dev && g_pool[i].bytes >= n && g_pool[i].bytes <= 2 * n + (1u << 20) &&
+        (best == g_pool.size() || g_pool[i].bytes < g_pool[best].bytes))
+      best = i;
+  if (best == g_pool.size()) return nullptr;
+  void *p = g_pool[best].p;
+  *got = g_pool[best].bytes;
+  g_pool.erase(g_pool.begin() + (long)best);
+  return p;
+}
+// true: the pool keeps the buffer; `evict` receives what it lets go of for it (freed by the caller, outside the lock)
+bool pool_put(void *p, size_t bytes, std::vector<void *> *evict) {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  if (dev < 0 || (int64_t)bytes > g_pool_cap) return false;
+  g_pool.push_back({p, bytes, dev});
+  int64_t tot = 0;
+  for (auto &e : g_pool) tot += (int64_t)e.bytes;
+  while (!g_pool.empty() && (tot > g_pool_cap || g_pool.size() > POOL_MAX_ENTRIES)) {
+    tot -= (int64_t)g_pool.front().bytes;
+    evict->push_back(g_pool.front().p);
+    g_pool.erase(g_pool.begin());
+  }
+  return true;
+}
+void pool_drain(std::vector<void *> *out, int device /* -1: every device */) {
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  for (size_t i = 0; i < g_pool.size();)
+    if (device < 0 || g_pool[i].device == device) {
+      out->push_back(g_pool[i].p);
+      g_pool.erase(g_pool.begin() + (long)i);
+    } else {
+      i++;
+    }
+}
+}  // namespace
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
@@ -254,8 +325,22 @@ struct DevBuf {
     free();
     if (n == 0) n = 16;
     PhaseClock pc(PH_ALLOC);
+    size_t got = 0;
+    if (void *q = pool_take(n, &got)) {
+      p = q;
+      bytes = got;
+      return NHIP_OK;
+    }
     hipError_t e = hipMalloc(&p, n);
+    if (e != hipSuccess) {  // (what the pool holds may be what is missing: let go of it and ask once more)
+      (void)hipGetLastError();
+      std::vector<void *> drop;
+      pool_drain(&drop, current_device());
+      for (void *d : drop) (void)hipFree(d);
+      e = drop.empty() ? e : hipMalloc(&p, n);
+    }
     if (e != hipSuccess) {
+      (void)hipGetLastError();
       p = nullptr;
       set_error("hipMalloc(%zu) failed: %s", n, hipGetErrorString(e));
       return NHIP_ERR_ALLOC;
@@ -266,7 +351,9 @@ struct DevBuf {
   void free() {
     if (p) {
       PhaseClock pc(PH_FREE);
-      (void)hipFree(p);
+      std::vector<void *> evict;
+      if (!pool_put(p, bytes, &evict)) (void)hipFree(p);
+      for (void *d : evict) (void)hipFree(d);
     }
     p = nullptr;
     bytes = 0;
@@ -355,7 +442,8 @@ int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out) {
   out->pool4_rows = L.pool4_rows;
   out->hi_bytes = L.hi_bytes;
   out->hi_pitch = L.hi_pitch;
-  out->reserved = 0;
+  out->hits_pitch = L.hits_pitch;
+  out->hits_bytes = L.hits_bytes;
   return NHIP_OK;
 }
 
@@ -503,6 +591,40 @@ int nhip_dev_status(void *stream, int32_t info[4]) {
   set_error("an id read from device memory was out of range: %s = %d at index %d (kinds seen since the last check: 0x%x); "
             "the kernels treated every such entry as empty", what, (int32_t)w[2], (int32_t)w[3], w[0]);
   return NHIP_ERR_ARG;
+}
+
+int nhip_device_pool_configure(int64_t max_bytes) {
+  NHIP_REQUIRE(max_bytes >= 0, "device_pool_configure: negative size");
+  std::vector<void *> drop;
+  {
+    std::lock_guard<std::mutex> lock(g_pool_mu);
+    g_pool_cap = max_bytes;
+    int64_t tot = 0;
+    for (auto &e : g_pool) tot += (int64_t)e.bytes;
+    while (!g_pool.empty() && tot > g_pool_cap) {
+      tot -= (int64_t)g_pool.front().bytes;
+      drop.push_back(g_pool.front().p);
+      g_pool.erase(g_pool.begin());
+    }
+  }
+  for (void *d : drop) (void)hipFree(d);
+  return NHIP_OK;
+}
+
+int nhip_device_pool_release(void) {
+  std::vector<void *> drop;
+  pool_drain(&drop, -1);
+  for (void *d : drop) (void)hipFree(d);
+  return NHIP_OK;
+}
+
+int nhip_device_pool_stats(int64_t *entries, int64_t *bytes) {
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  int64_t tot = 0;
+  for (auto &e : g_pool) tot += (int64_t)e.bytes;
+  if (entries) *entries = (int64_t)g_pool.size();
+  if (bytes) *bytes = tot;
+  return NHIP_OK;
 }
 
 int nhip_host_phases(double out[8]) {
@@ -718,7 +840,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
   hipError_t e;
   {
     PhaseClock pc(PH_UPLOAD);
-    e = hipMemset(g->grids.p, 0, g->grids.bytes);
+    e = hipMemset(g->grids.p, 0, (size_t)n_targets * L.slot_bytes + 256);  // (what was asked for: a pooled buffer may be larger)
     if (e == hipSuccess && n_targets)
       e = hipMemcpy(ids.p, target_ids, sizeof(int32_t) * (size_t)n_targets, hipMemcpyHostToDevice);
   }
@@ -808,6 +930,15 @@ int nhip_grids_download_pool(const nhip_grids_t *grids, int32_t slot, uint8_t *o
   const GridLayout &L = grids->L;
   NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes + L.skip_bytes,
                          (size_t)L.pool_bytes, hipMemcpyDeviceToHost));
+  return NHIP_OK;
+}
+
+int nhip_grids_download_hits(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
+  NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_hits: bad arguments");
+  const GridLayout &L = grids->L;
+  NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes + L.skip_bytes +
+                                  L.pool_bytes + L.pool4_bytes + L.hi_bytes,
+                         (size_t)L.hits_bytes, hipMemcpyDeviceToHost));
   return NHIP_OK;
 }
 

@@ -90,7 +90,10 @@ struct GridLayout {
   int64_t hi_copy_bytes;  // bytes of one copy
   int64_t t16_bytes;   // 16-bit cells: after the two copies, the 16-bit image once more, tiled 8 rows x 8 cells (t16_tiled())
   int32_t t16_tpr;     // its tiles per tile row
-  int64_t slot_bytes;  // grid_bytes + skip_bytes + pool_bytes + pool4_bytes + hi_bytes: stride between consecutive grids
+  int64_t hits_bytes;  // after the matcher's planes: the HIT RASTER, one bit per cell (rows S + 2 * HIT_PAD, hits_pitch bytes each):
+  int32_t hits_pitch;  // what the table was blurred from.  The exact-score pass (NHIP_SEARCH_EXACT_SCORE) recomputes the
+                       // integer blur sums of the 1081 cells the winning pose reads from it, and their logarithms in double
+  int64_t slot_bytes;  // grid_bytes + skip_bytes + pool_bytes + pool4_bytes + hi_bytes + hits_bytes: stride between grids
   int32_t pool_pitch, pool_rows;
   int32_t pool4_pitch, pool4_rows;
   double Lf, step;
@@ -112,6 +115,11 @@ __host__ __device__ __forceinline__ uint32_t hi_tiled(uint32_t row, uint32_t col
 __host__ __device__ __forceinline__ uint32_t t16_tiled(uint32_t row, uint32_t col, uint32_t tpr) {
   return ((row >> 3) * tpr + (col >> 3)) * HI_TILE_BYTES + (row & 7u) * 16u + (col & 7u) * 2u;
 }
+
+// The hit raster's zero border, in cells, on every side: >= the largest blur radius (16), and a multiple of 32 so that the
+// 64 x 64 tiles of the build start on dword boundaries of the bit rows.  Bit (row, col) of the raster is bit
+// (col + HIT_PAD) & 31 of dword (col + HIT_PAD) >> 5 of bit row row + HIT_PAD.
+constexpr int HIT_PAD = 32;
 
 // Branch and bound works on 8 x 8 blocks of translations; a pooled entry covers the 15 x 15 stored cells an 8 x 8
 // block can reach from any window origin with the same (row >> 3, col >> 3).

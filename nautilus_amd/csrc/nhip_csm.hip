@@ -411,6 +411,132 @@ __global__ void csm_finalize_kernel(const unsigned long long *__restrict__ keys,
   if (sums) sums[i] = (int32_t)sum;
 }
 
+// ---- NHIP_SEARCH_EXACT_SCORE: the winning pose's score on the UNQUANTISED table -----------------------------------------
+// The argmax is found on quantised cells (bit-exact against the oracle; on 1,300 pairs of the bench workload it is also the
+// argmax of a double table every time).  The score reported with it, Lf + step * sum / N, carries the cells' rounding: up
+// to 2.3e-5 relative at the best-matching pairs of that sample, where |score| is smallest -- outside the north star's
+// 1e-5.  This pass recomputes the score of the ONE pose that won the way the reference's table type would give it
+// (CImg<double>, cimg_debug.h:19): for each of the scan's points the exact integer blur sum V of the cell it reads --
+// from the hit raster the table was blurred from (13 x 13 bits around the cell at sigma = 2) --, ln(max(V / K^2, floor))
+// in double, the mean over the points in double.  One wave per pair; 1081 x 13 dword pairs of a 190 KB raster.
+struct ExactParams {
+  const float2 *xy;
+  const int32_t *offsets;
+  const uint8_t *grids;
+  const int32_t *pair_src, *pair_slot;
+  const double *rot0_cs, *delta_cs;
+  const int32_t *pair_origin;
+  const int32_t *pair_kbase;  // optional: entry of delta_cs that is pair i's rotation 0 (nhip_bnb_params.h)
+  nhip_match_t *out;
+  IdBounds ids;
+  int32_t n_pairs, nx, ny, hx, hy, S, R, hits_pitch;
+  int64_t slot_bytes, hits_offset;
+  double res, inv_res, K2, floor_p, Lf;
+  int32_t taps[2 * 16 + 1];
+};
+
+__global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
+  const int lane = threadIdx.x & 63;
+  const int32_t pair = (int32_t)(blockIdx.x * 4u + (threadIdx.x >> 6));
+  if (pair >= P.n_pairs) return;
+  int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
+  const bool ids_ok = pair_ids_ok(P.ids, src, slot, pair, false);  // (the matcher reported it)
+  if (!ids_ok) src = slot = 0;
+  const int32_t beg = ids_ok ? P.offsets[src] : 0, n_pts = ids_ok ? P.offsets[src + 1] - beg : 0;
+  const nhip_match_t m = P.out[pair];
+  const int32_t cx = (P.pair_origin ? P.pair_origin[2 * pair] : 0) + m.ix - P.hx;
+  const int32_t cy = (P.pair_origin ? P.pair_origin[2 * pair + 1] : 0) + m.iy - P.hy;
+  // rotation itheta: R(theta0) * R(delta_k), composed in double with individually rounded ops, as every matcher kernel
+  const double c0 = P.rot0_cs[2 * pair], s0 = P.rot0_cs[2 * pair + 1];
+  const int32_t kd = m.itheta + (P.pair_kbase ? P.pair_kbase[pair] : 0);
+  const double cd = P.delta_cs[2 * kd], sd = P.delta_cs[2 * kd + 1];
+  const float cf = __double2float_rn(__dsub_rn(__dmul_rn(c0, cd), __dmul_rn(s0, sd)));
+  const float sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
+  const uint8_t *hits = P.grids + (size_t)slot * P.slot_bytes + P.hits_offset;
+  const uint32_t mask = (1u << (2 * P.R + 1)) - 1u;  // (R <= 15 here: 2R + 1 <= 31 bits)
+  double acc = 0.0;
+  for (int32_t p = lane; p < n_pts; p += 64) {
+    const float2 q = P.xy[beg + p];
+    const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
+    const float yr = __fadd_rn(__fmul_rn(sf, q.x), __fmul_rn(cf, q.y));
+    double L = P.Lf;  // non-finite points and lookups outside the grid contribute the floor
+    if ((fabsf(xr) < 1e9f) && (fabsf(yr) < 1e9f)) {
+      const double fc = floor_quotient((double)xr, P.res, P.inv_res) + (double)(P.S / 2 + cx);
+      const double fr = floor_quotient((double)yr, P.res, P.inv_res) + (double)(P.S / 2 + cy);
+      if (fc >= 0.0 && fc < (double)P.S && fr >= 0.0 && fr < (double)P.S) {
+        const int32_t col = (int32_t)fc, row = (int32_t)fr;
+        const uint32_t bit0 = (uint32_t)(col - P.R + HIT_PAD);  // first bit of the row windows
+        const uint8_t *w = hits + (size_t)(row - P.R + HIT_PAD) * P.hits_pitch + 4 * (size_t)(bit0 >> 5);
+        uint32_t V = 0u;
+        for (int i = 0; i <= 2 * P.R; i++) {
+          const uint32_t lo = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch);
+          const uint32_t hi = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch + 4);
+          uint32_t bits = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (bit0 & 31u)) & mask;
+          uint32_t rowsum = 0u;
+          while (bits) {
+            rowsum += (uint32_t)P.taps[__builtin_ctz(bits)];
+            bits &= bits - 1u;
+          }
+          V += (uint32_t)P.taps[i] * rowsum;
+        }
+        double v = __ddiv_rn((double)V, P.K2);
+        if (v < P.floor_p) v = P.floor_p;
+        L = log(v);
+      }
+    }
+    acc += L;
+  }
+#pragma unroll
+  for (int s = 32; s >= 1; s >>= 1) {
+    const unsigned long long o = shfl_xor_u64(__double_as_longlong(acc), s);
+    acc += __longlong_as_double((long long)o);
+  }
+  if (lane == 0) P.out[pair].score = __double2float_rn(n_pts > 0 ? __ddiv_rn(acc, (double)n_pts) : P.Lf);
+}
+
+int launch_csm_exact_score(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
+                           const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
+                           const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
+                           const int32_t *d_pair_origin, const int32_t *d_pair_kbase, int32_t n_pairs,
+                           const nhip_search_t *search, nhip_match_t *d_out, hipStream_t s) {
+  NHIP_REQUIRE(L.R <= 15, "exact score: blur radius %d > 15", L.R);
+  GridTables T;
+  int rc = make_tables(spec, L, &T);
+  if (rc) return rc;
+  ExactParams P;
+  memset(&P, 0, sizeof(P));
+  P.xy = reinterpret_cast<const float2 *>(d_xy);
+  P.offsets = d_offsets;
+  P.grids = d_grids;
+  P.pair_src = d_pair_src;
+  P.pair_slot = d_pair_slot;
+  P.rot0_cs = d_rot0_cs;
+  P.delta_cs = d_delta_cs;
+  P.pair_origin = d_pair_origin;
+  P.pair_kbase = d_pair_kbase;
+  P.out = d_out;
+  P.ids = ids;
+  P.n_pairs = n_pairs;
+  P.nx = search->nx;
+  P.ny = search->ny;
+  P.hx = (search->nx - 1) / 2;
+  P.hy = (search->ny - 1) / 2;
+  P.S = L.S;
+  P.R = L.R;
+  P.hits_pitch = L.hits_pitch;
+  P.slot_bytes = L.slot_bytes;
+  P.hits_offset = L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes;
+  P.res = spec->res;
+  P.inv_res = 1.0 / spec->res;
+  P.K2 = (double)L.K * (double)L.K;
+  P.floor_p = spec->floor_p;
+  P.Lf = L.Lf;
+  for (int i = 0; i <= 2 * L.R; i++) P.taps[i] = T.taps[i];
+  hipLaunchKernelGGL(csm_exact_score_kernel, dim3((uint32_t)((n_pairs + 3) / 4)), dim3(256), 0, s, P);
+  NHIP_TRY_HIP(hipGetLastError());
+  return NHIP_OK;
+}
+
 int check_search(const nhip_grid_spec_t *spec, const GridLayout &L, const nhip_search_t *search, bool exhaustive) {
   NHIP_REQUIRE(search->n_theta >= 1 && (search->n_theta & 1), "search: n_theta must be odd >= 1");
   NHIP_REQUIRE(search->nx >= 1 && (search->nx & 1), "search: nx must be odd >= 1");
@@ -465,12 +591,34 @@ void launch_csm_finalize(const uint64_t *d_keys, const int32_t *d_pair_src, cons
                      L.step, d_out, d_sums);
 }
 
+static int launch_csm_match_quantised(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
+                                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
+                                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
+                                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
+                                      uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s,
+                                      void *d_workspace, int64_t workspace_bytes, const int32_t *d_pair_kbase);
+
 int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
                      uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s,
                      void *d_workspace, int64_t workspace_bytes, const int32_t *d_pair_kbase) {
+  int rc = launch_csm_match_quantised(d_xy, d_offsets, ids, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
+                                      d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s, d_workspace, workspace_bytes,
+                                      d_pair_kbase);
+  if (rc || n_pairs == 0 || !(search->flags & NHIP_SEARCH_EXACT_SCORE)) return rc;
+  // (the records are final -- indices and integer sums; the pass replaces their score field)
+  return launch_csm_exact_score(d_xy, d_offsets, ids, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
+                                d_pair_origin, d_pair_kbase, n_pairs, search, d_out, s);
+}
+
+static int launch_csm_match_quantised(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
+                                      const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
+                                      const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
+                                      const int32_t *d_pair_origin, int32_t n_pairs, const nhip_search_t *search,
+                                      uint64_t *d_keys, nhip_match_t *d_out, int32_t *d_sums, hipStream_t s,
+                                      void *d_workspace, int64_t workspace_bytes, const int32_t *d_pair_kbase) {
   const bool exhaustive = csm_takes_exhaustive(L, search);
   // (per-pair offsets into the rotation table are the branch-and-bound matcher's: an internal caller that passes them has
   //  made sure the lattice is one it takes)

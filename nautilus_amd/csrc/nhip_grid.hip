@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
                                                         int32_t R, double res, double inv_res, GridKernelTables tab,
                                                         const uint32_t *__restrict__ thr16, int64_t hi_offset,
                                                         int32_t hi_tpr, int64_t hi_copy_bytes, int32_t t16_tpr,
-                                                        int32_t n_scans) {
+                                                        int32_t n_scans, int64_t hits_offset, int32_t hits_pitch) {
   __shared__ uint32_t sA[TILE][TILE + 1];
   __shared__ uint16_t sHits[MAX_TILE_HITS];
   __shared__ uint32_t sSeen[(TH_MAX * TH_MAX + 31) / 32];  // one bit per neighbourhood cell: a cell is a hit once
@@ -206,6 +206,19 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
     __syncthreads();
     const int32_t nh = sNH;
     if (nh == 0) continue;
+    // the tile's own hits into the hit raster (64 rows x 64 bits = two dwords per row; pre-zeroed, a tile owns its dwords:
+    // tiles start at multiples of 64 cells and the raster's border is 32): what the exact-score pass reads
+    if (threadIdx.x < 2 * TILE) {
+      const int r = threadIdx.x >> 1, h = threadIdx.x & 1;
+      if (r0 + r < S && c0 + 32 * h < S) {
+        const uint32_t b0 = (uint32_t)((R + r) * TH + R + 32 * h);  // the row's first bit of this half in sSeen
+        const uint32_t w0 = sSeen[b0 >> 5], w1 = sSeen[(b0 >> 5) + 1], sh = b0 & 31u;
+        const uint32_t bits = sh ? (w0 >> sh) | (w1 << (32u - sh)) : w0;
+        if (bits)
+          *reinterpret_cast<uint32_t *>(g + hits_offset + (size_t)(r0 + r + HIT_PAD) * hits_pitch +
+                                        4 * (size_t)(((c0 + HIT_PAD) >> 5) + h)) = bits;
+      }
+    }
     // one work item per (hit, output row): up to 2R+1 atomic adds
     for (int32_t wi = threadIdx.x; wi < nh * NT; wi += 256) {
       const int32_t hit = sHits[wi / NT], di = wi % NT;
@@ -685,7 +698,8 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
                                                          int32_t pitch, int32_t cb, int64_t slot_bytes, int64_t table_offset,
                                                          int64_t table_bytes, int64_t hi_offset, int32_t hi_tpr,
                                                          int64_t hi_copy_bytes, int32_t t16_tpr, int64_t p4_offset,
-                                                         int32_t p4_pitch, int64_t p8_offset, int32_t p8_pitch) {
+                                                         int32_t p4_pitch, int64_t p8_offset, int32_t p8_pitch,
+                                                         int64_t hits_offset, int32_t hits_pitch) {
   const uint64_t tag = *reinterpret_cast<const uint64_t *>(header + 2);
   if (tag != expect) {  // unknown contents: everything goes (16-byte stores, grid-stride)
     uint4 *p = reinterpret_cast<uint4 *>(grids);
@@ -702,6 +716,12 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
     const int32_t r0 = (tile / tiles) * TILE, c0 = (tile % tiles) * TILE;
     uint8_t *g = grids + (size_t)t * slot_bytes;
     zero_tile<W>(g, pitch, r0, pad, S, (c0 + pad) * cb, TILE * cb);
+    // the tile's bits of the hit raster (two dwords per row)
+    for (int i = threadIdx.x; i < 2 * TILE; i += 256) {
+      const int r = i >> 1, h = i & 1;
+      if (r0 + r < S && c0 + 32 * h < S)
+        *reinterpret_cast<uint32_t *>(g + hits_offset + (size_t)(r0 + r + HIT_PAD) * hits_pitch + 4 * (size_t)(((c0 + HIT_PAD) >> 5) + h)) = 0u;
+    }
     if (p4_pitch > 0) {
       // the second-level entries this tile's cells can have reached (grid_pool4_tiles_kernel: 17 x 17 entries from four
       // cells before the tile, each also the second byte of the pair one row up): 18 rows x 17 byte pairs.  Entries
@@ -854,7 +874,7 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_sca
 #define NHIP_CLEAR(W, WH)                                                                                             \
   hipLaunchKernelGGL((grid_clear_kernel<W, WH>), dim3(4096), dim3(256), 0, s, count, tag, list, g, n, L.S, tiles, L.pad, \
                      L.pitch, L.cb, L.slot_bytes, to, tb, hio, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr, p4o, p4p, \
-                     L.grid_bytes + L.skip_bytes, L.pool_pitch)
+                     L.grid_bytes + L.skip_bytes, L.pool_pitch, hio + L.hi_bytes, L.hits_pitch)
       if (w == 16 && wh == 16) NHIP_CLEAR(16, 16);
       else if (w == 16) NHIP_CLEAR(16, 4);
       else if (w == 8) NHIP_CLEAR(8, 4);
@@ -887,12 +907,14 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_sca
       hipLaunchKernelGGL(grid_blur_kernel<1>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, 0, n_scans);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, 0, n_scans,
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch);
     else
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr, n_scans);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr, n_scans,
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch);
     // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernels that
     // perform every add; the branch-and-bound matcher never reads it, so 16-bit grids -- its product path -- carry
     // one only when the spec asks.)
