@@ -34,7 +34,7 @@ def test_struct_sizes_match_header():
     assert C.sizeof(_lib.Match) == 16
     assert C.sizeof(_lib.GridSpec) == 48  # + flags, reserved
     assert C.sizeof(_lib.Search) == 24
-    assert C.sizeof(_lib.GridLayout) == 120  # + pool_*, pool4_* (branch-and-bound tables), hi_* (high bytes of 16-bit cells)
+    assert C.sizeof(_lib.GridLayout) == 128  # + pool_*, pool4_* (branch-and-bound tables), hi_* (high bytes of 16-bit cells), hits_*
 
 
 def test_grid_layout_follows_cimg_debug():
@@ -51,7 +51,9 @@ def test_grid_layout_follows_cimg_debug():
     assert L.pool4_rows == 348 + 24 and L.pool4_pitch == 768 and L.pool4_bytes == 372 * 768
     # the matcher's tiled 8-bit plane (8-bit grids: the cells themselves): two copies of 174 x 88 tiles of 8 rows x 16 bytes
     assert L.hi_pitch == 1392 and L.hi_bytes == 2 * 174 * 88 * 128
-    assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes and L.slot_bytes % 16 == 0
+    # the hit raster: one bit per cell + a border of 32 cells: 1264 bit rows of 40 dwords
+    assert L.hits_pitch == 160 and L.hits_bytes == (160 * 1264 + 8 + 15) // 16 * 16
+    assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes + L.hits_bytes and L.slot_bytes % 16 == 0
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
     L16 = csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40))  # the default width: 16-bit cells (0 means 16 too)
     zero = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=0)
@@ -60,7 +62,7 @@ def test_grid_layout_follows_cimg_debug():
     # the plane of high bytes: plain form at the 8-bit pitch; stored as two copies of 174 x 88 tiles of 8 rows x 16 bytes
     # ... and the 16-bit image once more in 174 x 174 tiles of 8 rows x 8 cells
     assert L16.hi_pitch == 1392 and L16.hi_bytes == 2 * 174 * 88 * 128 + 174 * 174 * 128
-    assert L16.slot_bytes == L16.grid_bytes + L16.skip_bytes + L16.pool_bytes + L16.pool4_bytes + L16.hi_bytes
+    assert L16.slot_bytes == L16.grid_bytes + L16.skip_bytes + L16.pool_bytes + L16.pool4_bytes + L16.hi_bytes + L16.hits_bytes
     for (r, res, side) in [(30, 0.3, 200), (30, 0.01, 6000), (10, 0.03, 666)]:
         assert csm.grid_layout(csm.grid_spec(r, res, 2.0, 1e-10, 4)).side == side
 

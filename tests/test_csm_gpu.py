@@ -1304,7 +1304,8 @@ def test_parity_against_the_double_table_at_scale(gpu):
     this test puts a number on the distance to the reference's table type at scale: 1,000 pairs of configs[1] and 300 pairs
     in the style of configs[3] (100 per target, sources up to 3.5 m away), 16-bit cells, against the exhaustive search on an
     unquantised double table (bench.parity_vs_f64, the leg the bench line's `parity_vs_f64` comes from).  Asserted: every
-    reported score within 1e-5 relative of the double table's score at the same pose; wherever the quantised argmax is
+    score reported with NHIP_SEARCH_EXACT_SCORE within 2e-7 relative of the double table's score at the same pose (north_star
+    asks for 1e-5); wherever the quantised argmax is
     another pose than the double table's, the two poses' double-table scores differ by less than one quantisation step
     (3.5e-4 nat: the bound that holds by construction) -- and by how much less is printed and recorded in DESIGN.md section 3."""
     import bench
@@ -1313,9 +1314,11 @@ def test_parity_against_the_double_table_at_scale(gpu):
     r = bench.parity_vs_f64(wl, 1000, 300, 16, n_threads=bench._omp_threads())
     print("parity vs double table:", json.dumps(r))
     assert r["configs[1]"]["pairs"] >= 1000 and r["configs[3]-style"]["pairs"] >= 300
-    # (measured at 1,300 pairs: 2.3e-5 at the worst pair, median 9e-7 -- the 20-pair test's 4e-6 was luck of the sample;
-    #  NHIP_SEARCH_EXACT_SCORE below brings the reported score itself onto the double table)
-    assert r["max_rel_score"] < 5e-5
+    # scores with NHIP_SEARCH_EXACT_SCORE: the double table's score at the winning pose (the record is a float: 6e-8).
+    # The quantised formula Lf + step * sum / N is within 2.3e-5 at the worst of these pairs (median 9e-7): the 20-pair
+    # test's 4e-6 was luck of the sample, and 1e-5 is NOT met by it at scale -- which is why the flag exists.
+    assert r["max_rel_score"] < 2e-7
+    assert 1e-6 < r["max_rel_score_quantised_formula"] < 5e-5
     assert r["max_gap_nat"] <= r["guaranteed_max_gap_nat"]
     for name in ("configs[1]", "configs[3]-style"):
         assert r[name]["index_agreement"] >= 0.97, (name, r[name])
