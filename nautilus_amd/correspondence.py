@@ -18,12 +18,10 @@ from ._lib import check
 
 def window_pairs(n_scans, window):
     """All (i, j), j in [max(i - window, 0), i): solver.cc:324-330."""
-    src, tgt = [], []
-    for i in range(n_scans):
-        for j in range(max(i - window, 0), i):
-            src.append(i)
-            tgt.append(j)
-    return np.asarray(src, dtype=np.int32), np.asarray(tgt, dtype=np.int32)
+    i = np.repeat(np.arange(n_scans, dtype=np.int64), window)
+    j = i - window + np.tile(np.arange(window, dtype=np.int64), n_scans)  # i - window .. i - 1, ascending, as the loop does
+    keep = j >= 0
+    return i[keep].astype(np.int32), j[keep].astype(np.int32)
 
 
 class IcpBatch:

@@ -34,7 +34,11 @@ from .correspondence import IcpBatch, window_pairs
 # path of this repo: correspondence search, residuals / normal equations, gating, scan matching (every one returns
 # host data, so the device is drained when the clock stops); "host_solver" = the sparse linear solves (Ceres' job in
 # the reference: out of scope, the same code whatever the backend); the rest of a run is host bookkeeping.
-CLOCK = {"path": 0.0, "host_solver": 0.0}
+# "marshal" = host work at the path's boundary: building the block lists and input arrays the backend calls take and
+# turning their outputs into what the caller asked for; "assemble" = the sparse system's assembly from the per-block
+# normal equations and factor Jacobians (numpy: what Ceres does inside its solve, like "host_solver"); "hitl_select" =
+# GetRelevantPosesForHITL's point selection (host-side HITL curation, solver.cc:479-513).
+CLOCK = {"path": 0.0, "host_solver": 0.0, "marshal": 0.0, "assemble": 0.0, "hitl_select": 0.0}
 
 
 def clock_reset():
@@ -234,13 +238,18 @@ class HitlConstraint:
         self.chosen_line_pose = np.zeros(3)
 
     def arrays(self, line_index):
-        nb = len(self.blocks)
-        seg = np.tile(self.line_a, (nb, 1)).astype(np.float32)
-        pts = np.concatenate([p for _, p in self.blocks]).astype(np.float32) if nb else np.zeros((0, 2), np.float32)
-        pb = np.concatenate([np.full(len(p), k, np.int32) for k, (_, p) in enumerate(self.blocks)]) if nb else np.zeros(0, np.int32)
-        bp = np.array([i for i, _ in self.blocks], dtype=np.int32)
-        bl = np.full(nb, line_index, dtype=np.int32)
-        return seg, pts, pb, bp, bl
+        """The input arrays of nhip_resid_point_to_line for this constraint's blocks.  The blocks never change after
+        construction (like the functors' copied vectors, slam_residuals.h:214-215): built once, not per evaluation -- at
+        10,000 scans they hold 1.3 M points, and a solve evaluates them dozens of times."""
+        if getattr(self, "_arrays", None) is None or self._arrays[0] != line_index:
+            nb = len(self.blocks)
+            seg = np.tile(self.line_a, (nb, 1)).astype(np.float32)
+            pts = np.concatenate([p for _, p in self.blocks]).astype(np.float32) if nb else np.zeros((0, 2), np.float32)
+            pb = np.repeat(np.arange(nb, dtype=np.int32), [len(p) for _, p in self.blocks]) if nb else np.zeros(0, np.int32)
+            bp = np.array([i for i, _ in self.blocks], dtype=np.int32)
+            bl = np.full(nb, line_index, dtype=np.int32)
+            self._arrays = (line_index, (seg, pts, pb, bp, bl))
+        return self._arrays[1]
 
 
 class PoseGraph:
@@ -249,7 +258,8 @@ class PoseGraph:
         self.n = len(odom)
         self.kind = kind
         self.backend = backend if backend is not None else HipBackend(device)
-        bs, bt = window_pairs(self.n, window)
+        with clocked("marshal"):
+            bs, bt = window_pairs(self.n, window)
         with clocked("path"):  # (uploads of the clouds, block lists)
             self.icp = self.backend.icp(xy, normals, offsets, bs, bt, outlier_threshold)
         self.odo = odometry_factors_from_poses(odom, tw=odom_weights[0], rw=odom_weights[1])
@@ -269,6 +279,15 @@ class PoseGraph:
         return 3 * self.n + 3 * len(self.hitl)
 
     def _assemble(self, poses, lines, research):
+        """The sparse normal equations at `poses`.  Clocks: the backend calls are "path", building their input arrays
+        "marshal", everything else here "assemble" (numpy: the solver's own bookkeeping)."""
+        t_in, path0, marsh0 = time.perf_counter(), CLOCK["path"], CLOCK["marshal"]
+        try:
+            return self._assemble_inner(poses, lines, research)
+        finally:
+            CLOCK["assemble"] += (time.perf_counter() - t_in) - (CLOCK["path"] - path0) - (CLOCK["marshal"] - marsh0)
+
+    def _assemble_inner(self, poses, lines, research):
         import scipy.sparse as sp
         N, NU = self.n, self.n_unknowns
         with clocked("path"):
@@ -304,7 +323,8 @@ class PoseGraph:
             np.add.at(g, idf.ravel(), gf.ravel())
             cost += 0.5 * float((r * r).sum())
         for c, con in enumerate(self.hitl):
-            seg, pts, pb, bp, bl = con.arrays(c)
+            with clocked("marshal"):
+                seg, pts, pb, bp, bl = con.arrays(c)
             if len(pts) == 0:
                 continue
             with clocked("path"):
