@@ -542,6 +542,7 @@ def worker(a):
     c_ms, _ = _timer(lib, _lib, _lib.NHIP_TIMER_GRID_CLEAR)
     kb_ms, kb_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM_BOUNDS)   # split form of the matcher: its two kernels
     kc_ms, kc_n = _timer(lib, _lib, _lib.NHIP_TIMER_CSM_CAND)
+    ex_ms, _ = _timer(lib, _lib, _lib.NHIP_TIMER_EXACT_SCORE)
     avg_ms = k_ms / max(k_n, 1)
 
     # per-rank load balance: pairs, targets, correlate-kernel ms per step
@@ -689,9 +690,9 @@ def worker(a):
                                        "HBM bytes per launch / kernel time / 8 TB/s"},
         "kernels_ms_per_step": {"csm_match": k_ms / a.steps, "of_which_bounds_and_seeds": kb_ms / a.steps if split else None,
                                 "of_which_candidates": kc_ms / a.steps if split else None, "grid_build": g_ms / a.steps,
-                                "of_which_grid_clear": c_ms / a.steps,
-                                "host_trig_h2d_finalize_gather": 1e3 * elapsed / a.steps - (k_ms + g_ms) / a.steps,
-                                "kernels_share_of_step": (k_ms + g_ms) / (1e3 * elapsed)},
+                                "of_which_grid_clear": c_ms / a.steps, "exact_score": ex_ms / a.steps,
+                                "host_trig_h2d_finalize_gather": 1e3 * elapsed / a.steps - (k_ms + g_ms + ex_ms) / a.steps,
+                                "kernels_share_of_step": (k_ms + g_ms + ex_ms) / (1e3 * elapsed)},
         "onchip_roofline": oc,
         "algorithm": {"name": "branch and bound, exact: bounds of 8x8 blocks of translations from a max-pooled table "
                               "(run-length compressed points), 4x4 sub-block bounds from a second table, exact sums for "

@@ -552,7 +552,8 @@ int nhip_allgather_matches(void *comm, const nhip_match_t *d_local, int32_t n_lo
 #define NHIP_TIMER_GRID_CLEAR 5
 #define NHIP_TIMER_CSM_BOUNDS 6 /* split form of the matcher: bounds + seeds (csm_bnb_kernel<., ., true, true>) ... */
 #define NHIP_TIMER_CSM_CAND 7   /* ... and the candidates (csm_bnb_cand_kernel); both inside NHIP_TIMER_CSM */
-#define NHIP_TIMER_COUNT 8
+#define NHIP_TIMER_EXACT_SCORE 8 /* the pass of NHIP_SEARCH_EXACT_SCORE (after, not inside, NHIP_TIMER_CSM) */
+#define NHIP_TIMER_COUNT 9
 int nhip_timing_enable(int on);
 int nhip_timing_reset(void);
 /* synchronises the recorded events; total_ms / launches since the last reset */

@@ -17,7 +17,7 @@ NHIP_SEARCH_EXHAUSTIVE, NHIP_SEARCH_DENSE, NHIP_SEARCH_SHORT_SCANS, NHIP_SEARCH_
 NHIP_SHORT_SCAN_POINTS = 1088
 NHIP_GRID_SKIP_MAP = 1
 NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ, NHIP_TIMER_GRID_CLEAR = 0, 1, 2, 3, 4, 5
-NHIP_TIMER_CSM_BOUNDS, NHIP_TIMER_CSM_CAND = 6, 7
+NHIP_TIMER_CSM_BOUNDS, NHIP_TIMER_CSM_CAND, NHIP_TIMER_EXACT_SCORE = 6, 7, 8
 
 
 class NhipError(RuntimeError):

@@ -418,7 +418,7 @@ __global__ void csm_finalize_kernel(const unsigned long long *__restrict__ keys,
 // 1e-5.  This pass recomputes the score of the ONE pose that won the way the reference's table type would give it
 // (CImg<double>, cimg_debug.h:19): for each of the scan's points the exact integer blur sum V of the cell it reads --
 // from the hit raster the table was blurred from (13 x 13 bits around the cell at sigma = 2) --, ln(max(V / K^2, floor))
-// in double, the mean over the points in double.  One wave per pair; 1081 x 13 dword pairs of a 190 KB raster.
+// in double, the mean over the points in double: 1081 x 13 dword pairs of a 200 KB raster per pair.
 struct ExactParams {
   const float2 *xy;
   const int32_t *offsets;
@@ -435,10 +435,15 @@ struct ExactParams {
   int32_t taps[2 * 16 + 1];
 };
 
+// One 256-thread workgroup per pair; a thread takes the points tid, tid + 256, ... (five at most on a 1081-beam scan).  The
+// first version ran one wave per pair with a rolled loop over the window's rows: 17 points x 13 dependent round trips per
+// lane, 0.44 ms per 10,000 pairs of pure latency.  Here the 2 NR dword loads of a point's window are issued together
+// (NR = 2 R + 1 rows, a compile-time constant for the blur radii in use; the generic instantiation loops).
+template <int NR>
 __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
-  const int lane = threadIdx.x & 63;
-  const int32_t pair = (int32_t)(blockIdx.x * 4u + (threadIdx.x >> 6));
-  if (pair >= P.n_pairs) return;
+  __shared__ double s_part[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int32_t pair = (int32_t)blockIdx.x;
   int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
   const bool ids_ok = pair_ids_ok(P.ids, src, slot, pair, false);  // (the matcher reported it)
   if (!ids_ok) src = slot = 0;
@@ -453,9 +458,10 @@ __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
   const float cf = __double2float_rn(__dsub_rn(__dmul_rn(c0, cd), __dmul_rn(s0, sd)));
   const float sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
   const uint8_t *hits = P.grids + (size_t)slot * P.slot_bytes + P.hits_offset;
-  const uint32_t mask = (1u << (2 * P.R + 1)) - 1u;  // (R <= 15 here: 2R + 1 <= 31 bits)
+  const int nr = NR > 0 ? NR : 2 * P.R + 1;
+  const uint32_t mask = (1u << nr) - 1u;  // (R <= 15: at most 31 bits)
   double acc = 0.0;
-  for (int32_t p = lane; p < n_pts; p += 64) {
+  for (int32_t p = (int32_t)threadIdx.x; p < n_pts; p += 256) {
     const float2 q = P.xy[beg + p];
     const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
     const float yr = __fadd_rn(__fmul_rn(sf, q.x), __fmul_rn(cf, q.y));
@@ -465,19 +471,38 @@ __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
       const double fr = floor_quotient((double)yr, P.res, P.inv_res) + (double)(P.S / 2 + cy);
       if (fc >= 0.0 && fc < (double)P.S && fr >= 0.0 && fr < (double)P.S) {
         const int32_t col = (int32_t)fc, row = (int32_t)fr;
-        const uint32_t bit0 = (uint32_t)(col - P.R + HIT_PAD);  // first bit of the row windows
+        const uint32_t bit0 = (uint32_t)(col - P.R + HIT_PAD), sh = bit0 & 31u;  // first bit of the row windows
         const uint8_t *w = hits + (size_t)(row - P.R + HIT_PAD) * P.hits_pitch + 4 * (size_t)(bit0 >> 5);
         uint32_t V = 0u;
-        for (int i = 0; i <= 2 * P.R; i++) {
-          const uint32_t lo = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch);
-          const uint32_t hi = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch + 4);
-          uint32_t bits = (uint32_t)((((unsigned long long)hi << 32) | lo) >> (bit0 & 31u)) & mask;
-          uint32_t rowsum = 0u;
-          while (bits) {
-            rowsum += (uint32_t)P.taps[__builtin_ctz(bits)];
-            bits &= bits - 1u;
+        if (NR > 0) {
+          uint32_t lo[NR > 0 ? NR : 1], hi[NR > 0 ? NR : 1];
+#pragma unroll
+          for (int i = 0; i < NR; i++) {
+            lo[i] = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch);
+            hi[i] = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch + 4);
           }
-          V += (uint32_t)P.taps[i] * rowsum;
+#pragma unroll
+          for (int i = 0; i < NR; i++) {
+            uint32_t bits = (uint32_t)((((unsigned long long)hi[i] << 32) | lo[i]) >> sh) & mask;
+            uint32_t rowsum = 0u;
+            while (bits) {
+              rowsum += (uint32_t)P.taps[__builtin_ctz(bits)];
+              bits &= bits - 1u;
+            }
+            V += (uint32_t)P.taps[i] * rowsum;
+          }
+        } else {
+          for (int i = 0; i < nr; i++) {
+            const uint32_t lo = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch);
+            const uint32_t hi = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch + 4);
+            uint32_t bits = (uint32_t)((((unsigned long long)hi << 32) | lo) >> sh) & mask;
+            uint32_t rowsum = 0u;
+            while (bits) {
+              rowsum += (uint32_t)P.taps[__builtin_ctz(bits)];
+              bits &= bits - 1u;
+            }
+            V += (uint32_t)P.taps[i] * rowsum;
+          }
         }
         double v = __ddiv_rn((double)V, P.K2);
         if (v < P.floor_p) v = P.floor_p;
@@ -491,7 +516,12 @@ __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
     const unsigned long long o = shfl_xor_u64(__double_as_longlong(acc), s);
     acc += __longlong_as_double((long long)o);
   }
-  if (lane == 0) P.out[pair].score = __double2float_rn(n_pts > 0 ? __ddiv_rn(acc, (double)n_pts) : P.Lf);
+  if (lane == 0) s_part[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double tot = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+    P.out[pair].score = __double2float_rn(n_pts > 0 ? __ddiv_rn(tot, (double)n_pts) : P.Lf);
+  }
 }
 
 int launch_csm_exact_score(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
@@ -532,7 +562,11 @@ int launch_csm_exact_score(const float *d_xy, const int32_t *d_offsets, const Id
   P.floor_p = spec->floor_p;
   P.Lf = L.Lf;
   for (int i = 0; i <= 2 * L.R; i++) P.taps[i] = T.taps[i];
-  hipLaunchKernelGGL(csm_exact_score_kernel, dim3((uint32_t)((n_pairs + 3) / 4)), dim3(256), 0, s, P);
+  timer_begin(NHIP_TIMER_EXACT_SCORE, s);
+  if (L.R == 6) hipLaunchKernelGGL(csm_exact_score_kernel<13>, dim3((uint32_t)n_pairs), dim3(256), 0, s, P);  // sigma = 2
+  else if (L.R == 3) hipLaunchKernelGGL(csm_exact_score_kernel<7>, dim3((uint32_t)n_pairs), dim3(256), 0, s, P);  // sigma = 1
+  else hipLaunchKernelGGL(csm_exact_score_kernel<0>, dim3((uint32_t)n_pairs), dim3(256), 0, s, P);
+  timer_end(NHIP_TIMER_EXACT_SCORE, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }
