@@ -162,7 +162,7 @@ class HipMatcher:
     """This rank's shard on the MI355X: device-resident scans, pair list, grids; step() enqueues the
     host trig + K1 + K2/K3 and returns the (n_local, 4) int32 record tensor."""
 
-    def __init__(self, wl, shard, device, cell_bits=8, exhaustive=False, weights=None, exact_score=False):
+    def __init__(self, wl, shard, device, cell_bits=8, exhaustive=False, weights=None, exact_score=False, no_image=None):
         """weights: cost estimate per pair of the shard (sharding.predicted_pair_cost): the pairs are handed to the
         matcher heaviest first (one workgroup per pair, started in index order: a pair that takes milliseconds must
         not start last); step() returns the records in shard order either way.  exact_score: NHIP_SEARCH_EXACT_SCORE --
@@ -180,7 +180,9 @@ class HipMatcher:
         self.src, self.slot, self.ids = src, slot, ids
         # (the kernel that performs every add reads the skip maps; the branch-and-bound matcher does not, and 16-bit
         #  grids are built without them unless asked)
-        self.spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=cell_bits, skip_map=exhaustive)
+        # (and only that kernel reads the row-major image: the matcher's slots are built without it, NHIP_GRID_NO_IMAGE)
+        no_image = (not exhaustive) if no_image is None else bool(no_image)
+        self.spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=cell_bits, skip_map=exhaustive, no_image=no_image)
         # (the host knows its scan lengths: 1081-beam scans all fit the matcher's by-rotation form, and saying so saves
         #  the launch of the other instantiation's n_pairs workgroups, which would all return at once)
         lens = np.diff(np.asarray(wl.off))

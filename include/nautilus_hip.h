@@ -77,7 +77,7 @@ typedef struct nhip_grid_spec {
                          double table (cimg_debug.h:19 holds the reference's table as CImg<double>); 8-bit cells
                          (255 steps of 0.09 nat, scores within 1e-3) are the explicit opt-in for callers that only
                          gate on a threshold */
-  int32_t flags;      /* 0, or NHIP_GRID_SKIP_MAP */
+  int32_t flags;      /* 0, NHIP_GRID_SKIP_MAP or NHIP_GRID_NO_IMAGE */
   int32_t reserved;   /* 0 */
 } nhip_grid_spec_t;
 /* NHIP_GRID_SKIP_MAP: the slots of 16-bit grids carry a skip map too (8-bit grids always do).  Only the kernel that
@@ -86,6 +86,16 @@ typedef struct nhip_grid_spec {
  * the buffer: pass the same spec to the build and to the match.  The handle API builds missing maps itself the first
  * time an exhaustive search needs them. */
 #define NHIP_GRID_SKIP_MAP 1
+/* NHIP_GRID_NO_IMAGE: the slots carry no row-major image (layout.grid_bytes = 0, layout.skip_bytes = 0): 8.4 MB per
+ * 1200 x 1200 grid of 16-bit cells instead of 12.3, a third less to clear per rebuild, a quarter less for the build to
+ * store.  The branch-and-bound matcher on scans of at most NHIP_SHORT_SCAN_POINTS points -- the product path: every
+ * 1081-beam workload -- reads only the pooled tables, its tiled planes and (NHIP_SEARCH_EXACT_SCORE) the hit raster; the
+ * pooled tables are then built from the tiled copy of the cells.  What needs the image is refused on such grids with
+ * NHIP_ERR_ARG: the kernels that perform every add (NHIP_SEARCH_EXHAUSTIVE, lattices beyond the matcher's envelope, score
+ * volumes), lists that hold a longer scan (the caller must set NHIP_SEARCH_SHORT_SCANS; the handle API sets it itself),
+ * nhip_grids_download.  Not combinable with NHIP_GRID_SKIP_MAP.  The flag describes the buffer: pass the same spec to
+ * the build and to the match. */
+#define NHIP_GRID_NO_IMAGE 2
 
 typedef struct nhip_grid_layout {
   int32_t side;        /* S: cells per side (cimg_debug.h:21-22) */
@@ -95,7 +105,7 @@ typedef struct nhip_grid_layout {
   int32_t blur_radius; /* R = ceil(3*sigma) */
   int32_t cell_bytes;  /* 1 or 2 */
   int64_t tap_sum;     /* K = sum of the integer blur taps */
-  int64_t grid_bytes;  /* pitch*rows: bytes of one stored grid */
+  int64_t grid_bytes;  /* pitch*rows: bytes of one stored grid's row-major image (0 with NHIP_GRID_NO_IMAGE) */
   double score_floor;  /* Lf = ln(floor_p): value of cell 0 */
   double score_step;   /* log-likelihood per quantisation step = -Lf/255 (8-bit cells) or -Lf/65535 (16-bit) */
   int64_t skip_bytes;  /* bytes of the skip map stored right after each image: one bit per stored row

@@ -19,13 +19,14 @@ MATCH_DTYPE = np.dtype([("itheta", "<i4"), ("ix", "<i4"), ("iy", "<i4"), ("score
 assert MATCH_DTYPE.itemsize == C.sizeof(Match) == 16
 
 
-def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, cell_bits=16, skip_map=False):
-    """cell_bits: 16 (the default everywhere: 65535 quantisation steps over [ln floor_p, 0], scores within 1e-5 of an
-    unquantised table) or 8 (255 steps, scores within 1e-3: the explicit opt-in for callers that
-    only gate on a threshold).  skip_map: 16-bit grids carry a skip map too (only the kernel that performs
-    every add reads it; LikelihoodGrids builds a missing one the first time such a search needs it)."""
+def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, cell_bits=16, skip_map=False, no_image=False):
+    """cell_bits: 16 (the default everywhere: 65535 quantisation steps over [ln floor_p, 0]) or 8 (255 steps: the explicit
+    opt-in for callers that only gate on a threshold).  skip_map: 16-bit grids carry a skip map too (only the kernel that
+    performs every add reads it; LikelihoodGrids builds a missing one the first time such a search needs it).  no_image:
+    NHIP_GRID_NO_IMAGE -- slots without the row-major image (a third smaller; the branch-and-bound matcher on scans of at
+    most 1088 points needs none)."""
     return GridSpec(float(range_m), float(res), float(sigma), float(floor_p), int(max_shift), int(cell_bits),
-                    _lib.NHIP_GRID_SKIP_MAP if skip_map else 0, 0)
+                    (_lib.NHIP_GRID_SKIP_MAP if skip_map else 0) | (_lib.NHIP_GRID_NO_IMAGE if no_image else 0), 0)
 
 
 def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0), exhaustive=False, dense=False, short_scans=False,

@@ -85,8 +85,10 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   NHIP_REQUIRE(spec->max_shift >= 0 && spec->max_shift <= 4096, "grid spec: max_shift out of range");
   NHIP_REQUIRE(spec->cell_bits == 0 || spec->cell_bits == 8 || spec->cell_bits == 16,
                "grid spec: cell_bits must be 8 or 16 (0 = 16), got %d", spec->cell_bits);
-  NHIP_REQUIRE((spec->flags & ~NHIP_GRID_SKIP_MAP) == 0 && spec->reserved == 0, "grid spec: unknown flags %d / reserved %d",
-               spec->flags, spec->reserved);
+  NHIP_REQUIRE((spec->flags & ~(NHIP_GRID_SKIP_MAP | NHIP_GRID_NO_IMAGE)) == 0 && spec->reserved == 0,
+               "grid spec: unknown flags %d / reserved %d", spec->flags, spec->reserved);
+  NHIP_REQUIRE((spec->flags & (NHIP_GRID_SKIP_MAP | NHIP_GRID_NO_IMAGE)) != (NHIP_GRID_SKIP_MAP | NHIP_GRID_NO_IMAGE),
+               "grid spec: a skip map (the every-add kernels') needs the image NHIP_GRID_NO_IMAGE leaves out");
   const double side = floor((spec->range * 2.0) / spec->res);  // cimg_debug.h:21-22
   NHIP_REQUIRE(side >= 1 && side <= 16384, "grid spec: side %g out of range [1, 16384]", side);
   L->S = (int32_t)side;
@@ -95,8 +97,10 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   L->pad = ((2 * spec->max_shift + 16) + 3) & ~3;
   L->pitch = ((L->S + 2 * L->pad) * L->cb + 15) & ~15;
   L->R = (int32_t)ceil(3.0 * spec->sigma);
-  L->grid_bytes = (int64_t)L->pitch * (int64_t)(L->S + 2 * L->pad);
-  L->skip_bytes = (((int64_t)skip_pitch(L->pitch) * (int64_t)(L->S + 2 * L->pad)) + 15) & ~15ll;
+  L->plain_bytes = (int64_t)L->pitch * (int64_t)(L->S + 2 * L->pad);
+  L->has_image = !(spec->flags & NHIP_GRID_NO_IMAGE);
+  L->grid_bytes = L->has_image ? L->plain_bytes : 0;
+  L->skip_bytes = L->has_image ? (((int64_t)skip_pitch(L->pitch) * (int64_t)(L->S + 2 * L->pad)) + 15) & ~15ll : 0;
   // pooled table: one byte per 8 x 8 stored cells, + BNB_MAX_NB rows / + BNB_MAX_NB + 5 columns of zeros so that a
   // window origin anywhere in the stored image can read its 11 x 16-byte rows without bounds checks
   L->pool_rows = (L->S + 2 * L->pad + BNB_B - 1) / BNB_B + BNB_MAX_NB + 1;
@@ -878,6 +882,8 @@ int nhip_grids_free(nhip_grids_t *grids) {
 
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download: bad arguments");
+  NHIP_REQUIRE(grids->L.has_image, "grids_download: the grids were built with NHIP_GRID_NO_IMAGE (nhip_grids_download_tiled16 / "
+               "_hi_plane return the matcher's copies of the cells)");
   NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * grids->L.slot_bytes,
                          (size_t)grids->L.grid_bytes, hipMemcpyDeviceToHost));
   return NHIP_OK;
@@ -906,7 +912,7 @@ int nhip_grids_download_tiled16(const nhip_grids_t *grids, int32_t slot, uint8_t
                                          L.skip_bytes + L.pool_bytes + L.pool4_bytes + 2 * L.hi_copy_bytes,
                          (size_t)L.t16_bytes, hipMemcpyDeviceToHost));
   const int32_t rows = L.S + 2 * L.pad;
-  memset(out, 0, (size_t)L.grid_bytes);
+  memset(out, 0, (size_t)L.plain_bytes);
   for (int32_t r = 0; r < rows; r++)
     for (int32_t c = 0; c < rows; c++)  // (square image: `rows` cells per row; the plain pitch may end before hi_pitch cells)
       memcpy(out + (size_t)r * L.pitch + 2 * (size_t)c, raw.data() + t16_tiled((uint32_t)r, (uint32_t)c, (uint32_t)L.t16_tpr), 2);
@@ -919,6 +925,7 @@ int nhip_grids_download_hi_plane(const nhip_grids_t *grids, int32_t slot, uint8_
 
 int nhip_grids_download_skip_map(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_skip_map: bad arguments");
+  NHIP_REQUIRE(grids->L.has_image, "grids_download_skip_map: grids built with NHIP_GRID_NO_IMAGE carry no skip map");
   const GridLayout &L = grids->L;
   NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes,
                          (size_t)L.skip_bytes, hipMemcpyDeviceToHost));
@@ -956,7 +963,7 @@ static int ensure_skip_maps(const nhip_grids_t *grids, const nhip_search_t *sear
   // (writes to the handle -- the maps, then the flag -- under the handle's mutex, which is taken before the flag is looked
   //  at: concurrent nhip_csm_match calls on one handle are ordered, the loser finds the maps built.  L and n never change.)
   nhip_grids *g = const_cast<nhip_grids *>(grids);
-  if (g->L.cb != 2 || g->n == 0) return NHIP_OK;
+  if (g->L.cb != 2 || g->n == 0 || !g->L.has_image) return NHIP_OK;
   NHIP_REQUIRE(search->n_theta >= 1 && search->nx >= 1 && search->ny >= 1, "search: empty lattice");
   if (!csm_takes_exhaustive(g->L, search)) return NHIP_OK;
   std::lock_guard<std::mutex> lock(g->mu);

@@ -189,6 +189,9 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &
   P.general_all = qe && qe[0] == '1';
   static_assert(NHIP_SHORT_SCAN_POINTS == 64 * OCL, "the header's promise is the by-rotation form's limit");
   P.short_scans = (search->flags & NHIP_SEARCH_SHORT_SCANS) != 0 && !P.general_all && (uint32_t)P.rows < ORG_LIMIT;
+  // (the general instantiation -- scans of more than 1088 points, NHIP_BNB_QUEUE=1 -- takes its exact sums on the row-major image)
+  NHIP_REQUIRE(L.has_image || P.short_scans, "csm_match: grids built with NHIP_GRID_NO_IMAGE serve lists whose scans all have at most %d "
+               "points, and the caller must say so (NHIP_SEARCH_SHORT_SCANS; the handle API sets it itself)", NHIP_SHORT_SCAN_POINTS);
   P.res = spec->res;
   P.inv_res = 1.0 / spec->res;
   P.inv_res_f = (float)P.inv_res;

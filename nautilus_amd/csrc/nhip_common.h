@@ -79,7 +79,9 @@ struct GridLayout {
   int32_t cb;      // bytes per cell: 1 or 2
   int32_t levels;  // quantisation steps: 255 or 65535
   int64_t K;  // tap sum
-  int64_t grid_bytes;  // pitch * rows: the stored image
+  int64_t plain_bytes; // pitch * rows: a grid in plain row-major form (the downloads' form)
+  bool has_image;      // false with NHIP_GRID_NO_IMAGE: no row-major image (and no skip map) in the slot
+  int64_t grid_bytes;  // the stored image: plain_bytes, or 0 without one
   int64_t skip_bytes;  // skip_pitch(pitch) * rows rounded up to 16: the skip map that follows the image
   int64_t pool_bytes;  // pool_rows * pool_pitch: the max-pooled table (branch-and-bound bounds) after the skip map
   int64_t pool4_bytes; // pool4_rows * pool4_pitch: the stride-4 pooled table (second bound level) after the first

@@ -659,6 +659,9 @@ static int launch_csm_match_quantised(const float *d_xy, const int32_t *d_offset
   NHIP_REQUIRE(!d_pair_kbase || !exhaustive, "csm_match: rotation offsets per pair with a lattice the matcher does not take");
   int rc = check_search(spec, L, search, exhaustive);
   if (rc) return rc;
+  NHIP_REQUIRE(L.has_image || !exhaustive, "csm_match: this search takes the kernel that performs every add (NHIP_SEARCH_EXHAUSTIVE, or "
+               "a lattice beyond the branch-and-bound matcher's envelope), which reads the row-major image the grids were built "
+               "without (NHIP_GRID_NO_IMAGE)");
   if (n_pairs == 0) return NHIP_OK;
   if (!exhaustive) {  // branch and bound: the same records, most adds never performed (nhip_bnb.hip)
     int handled = 0;
@@ -713,6 +716,8 @@ int launch_csm_scores(const float *d_xy, const int32_t *d_offsets, const uint8_t
                       hipStream_t s) {
   int rc = check_search(spec, L, search, true);
   if (rc) return rc;
+  NHIP_REQUIRE(L.has_image, "csm_scores: the score volume comes from the kernel that performs every add, which reads the row-major "
+               "image the grids were built without (NHIP_GRID_NO_IMAGE)");
   if (L.cb == 2)
     return launch_csm16_scores(d_xy, d_offsets, d_grids, spec, L, src, slot, d_rot0_cs, d_delta_cs, origin_x, origin_y,
                                search, d_sums, s);

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
                                                         int32_t R, double res, double inv_res, GridKernelTables tab,
                                                         const uint32_t *__restrict__ thr16, int64_t hi_offset,
                                                         int32_t hi_tpr, int64_t hi_copy_bytes, int32_t t16_tpr,
-                                                        int32_t n_scans, int64_t hits_offset, int32_t hits_pitch) {
+                                                        int32_t n_scans, int64_t hits_offset, int32_t hits_pitch,
+                                                        int32_t has_image) {
   __shared__ uint32_t sA[TILE][TILE + 1];
   __shared__ uint16_t sHits[MAX_TILE_HITS];
   __shared__ uint32_t sSeen[(TH_MAX * TH_MAX + 31) / 32];  // one bit per neighbourhood cell: a cell is a hit once
@@ -307,7 +308,8 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
       }
       if (any == 0u) continue;  // the grid is pre-zeroed
       uint8_t *dst = g + (size_t)(r0 + r + pad) * pitch + (size_t)(c0 + c4 + pad) * CB;
-      if (c0 + c4 + 3 < S) {  // pad, c0, c4 are multiples of 4: a whole aligned dword / qword
+      if (!has_image) {  // (NHIP_GRID_NO_IMAGE: the cells live in the matcher's tiled copies only)
+      } else if (c0 + c4 + 3 < S) {  // pad, c0, c4 are multiples of 4: a whole aligned dword / qword
         if (CB == 1) *reinterpret_cast<uint32_t *>(dst) = qv[0] | (qv[1] << 8) | (qv[2] << 16) | (qv[3] << 24);
         else *reinterpret_cast<uint2 *>(dst) = make_uint2(qv[0] | (qv[1] << 16), qv[2] | (qv[3] << 16));
       } else {
@@ -535,7 +537,9 @@ template <int CB>
 __global__ __launch_bounds__(256) void grid_pool4_tiles_kernel(const int32_t *__restrict__ count, const int32_t *__restrict__ list,
                                                                int32_t tiles, uint8_t *__restrict__ grids, int32_t pad,
                                                                int32_t rows, int32_t pitch, int64_t table_offset,
-                                                               int64_t slot_bytes, int32_t pool_pitch) {
+                                                               int64_t slot_bytes, int32_t pool_pitch, int32_t has_image,
+                                                               int64_t hi_offset, int32_t hi_tpr, int64_t hi_copy_bytes,
+                                                               int32_t t16_tpr) {
   static_assert(BNB_B4 == 4, "windows of seven cells at stride four");
   // two cells per LDS word (16-bit cells as stored; 8-bit cells widened), 36 words per row of 71 (+ 1) cells
   constexpr int RW = (P4_REG + 1) / 2;
@@ -556,10 +560,14 @@ __global__ __launch_bounds__(256) void grid_pool4_tiles_kernel(const int32_t *__
       const int32_t sr = r0 + rr, sc = c0 + 2 * w;  // (even: the pitch covers whole pairs of cells)
       uint32_t v = 0u;                              // (windows are clipped to the image)
       if (sr < rows && sc < rows) {
+        // (two cells at an even column: one dword of the image, or -- NHIP_GRID_NO_IMAGE -- of the matcher's tiled copy of
+        //  the cells, where an even pair never straddles a tile row)
         if (CB == 2) {
-          v = *reinterpret_cast<const uint32_t *>(g + (size_t)sr * pitch + 2 * sc);
+          v = has_image ? *reinterpret_cast<const uint32_t *>(g + (size_t)sr * pitch + 2 * sc)
+                        : *reinterpret_cast<const uint32_t *>(g + hi_offset + 2 * hi_copy_bytes + t16_tiled((uint32_t)sr, (uint32_t)sc, (uint32_t)t16_tpr));
         } else {
-          const uint32_t h = *reinterpret_cast<const uint16_t *>(g + (size_t)sr * pitch + sc);
+          const uint32_t h = has_image ? *reinterpret_cast<const uint16_t *>(g + (size_t)sr * pitch + sc)
+                                       : *reinterpret_cast<const uint16_t *>(g + hi_offset + hi_tiled((uint32_t)sr, (uint32_t)sc, 0u, (uint32_t)hi_tpr, (uint32_t)hi_copy_bytes));
           v = (h & 0xffu) | ((h & 0xff00u) << 8);
         }
       }
@@ -699,7 +707,7 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
                                                          int64_t table_bytes, int64_t hi_offset, int32_t hi_tpr,
                                                          int64_t hi_copy_bytes, int32_t t16_tpr, int64_t p4_offset,
                                                          int32_t p4_pitch, int64_t p8_offset, int32_t p8_pitch,
-                                                         int64_t hits_offset, int64_t hits_bytes) {
+                                                         int64_t hits_offset, int64_t hits_bytes, int32_t has_image) {
   const uint64_t tag = *reinterpret_cast<const uint64_t *>(header + 2);
   if (tag != expect) {  // unknown contents: everything goes (16-byte stores, grid-stride)
     uint4 *p = reinterpret_cast<uint4 *>(grids);
@@ -715,7 +723,7 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
     const int32_t t = entry / (tiles * tiles), tile = entry % (tiles * tiles);
     const int32_t r0 = (tile / tiles) * TILE, c0 = (tile % tiles) * TILE;
     uint8_t *g = grids + (size_t)t * slot_bytes;
-    zero_tile<W>(g, pitch, r0, pad, S, (c0 + pad) * cb, TILE * cb);
+    if (has_image) zero_tile<W>(g, pitch, r0, pad, S, (c0 + pad) * cb, TILE * cb);
     if (p4_pitch > 0) {
       // the second-level entries this tile's cells can have reached (grid_pool4_tiles_kernel: 17 x 17 entries from four
       // cells before the tile, each also the second byte of the pair one row up): 18 rows x 17 byte pairs.  Entries
@@ -862,7 +870,7 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_sca
       // derived tables between the image and the plane of high bytes: skip map and the two pooled tables, every slot
       // (without a skip map -- 16-bit grids unless the spec asks for one -- only the second-level table: nothing reads
       //  the map's space, and the first-level table is rewritten entry by entry from the second)
-      const bool with_map = L.cb == 1 || (spec->flags & NHIP_GRID_SKIP_MAP);
+      const bool with_map = L.has_image && (L.cb == 1 || (spec->flags & NHIP_GRID_SKIP_MAP));
       const int64_t hio = L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes;
       // (without a map the second-level table is cleared tile by tile: p4p > 0)
       const int64_t tb = with_map ? L.skip_bytes + L.pool_bytes + L.pool4_bytes : 0;
@@ -873,7 +881,7 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_sca
 #define NHIP_CLEAR(W, WH)                                                                                             \
   hipLaunchKernelGGL((grid_clear_kernel<W, WH>), dim3(4096), dim3(256), 0, s, count, tag, list, g, n, L.S, tiles, L.pad, \
                      L.pitch, L.cb, L.slot_bytes, to, tb, hio, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr, p4o, p4p, \
-                     L.grid_bytes + L.skip_bytes, L.pool_pitch, hio + L.hi_bytes, L.hits_bytes)
+                     L.grid_bytes + L.skip_bytes, L.pool_pitch, hio + L.hi_bytes, L.hits_bytes, L.has_image ? 1 : 0)
       if (w == 16 && wh == 16) NHIP_CLEAR(16, 16);
       else if (w == 16) NHIP_CLEAR(16, 4);
       else if (w == 8) NHIP_CLEAR(8, 4);
@@ -907,17 +915,17 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_sca
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
                          L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, 0, n_scans,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch, L.has_image ? 1 : 0);
     else
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
                          L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr, n_scans,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch, L.has_image ? 1 : 0);
     // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernels that
     // perform every add; the branch-and-bound matcher never reads it, so 16-bit grids -- its product path -- carry
     // one only when the spec asks.)
-    const bool want_map = L.cb == 1 || (spec->flags & NHIP_GRID_SKIP_MAP);
+    const bool want_map = L.has_image && (L.cb == 1 || (spec->flags & NHIP_GRID_SKIP_MAP));
     for (int32_t z0 = 0; z0 < n && want_map; z0 += 65535) {
       const int32_t nz = n - z0 < 65535 ? n - z0 : 65535;
       const dim3 mg((mpitch + MT - 1) / MT, (rows + MT - 1) / MT, nz);
@@ -932,18 +940,20 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_sca
       // second-level table from the listed tiles (NHIP_GRID_POOL=bands: the band kernel, measurement), first from second
       const char *pk = tunable("NHIP_GRID_POOL");
       const int64_t off4 = L.grid_bytes + L.skip_bytes + L.pool_bytes;
-      if (pk && pk[0] == 'b') {
+      if (pk && pk[0] == 'b' && L.has_image) {  // (the band kernels walk the image)
         if (L.cb == 1) launch_pool<1, BNB_B4>(occ, g, L, tiles, n, s);
         else launch_pool<2, BNB_B4>(occ, g, L, tiles, n, s);
       } else if (L.cb == 1) {
         hipLaunchKernelGGL(grid_pool4_tiles_kernel<1>, dim3(blur_blocks), dim3(256), 0, s, count, list, tiles, g, L.pad, rows,
-                           L.pitch, off4, L.slot_bytes, L.pool4_pitch);
+                           L.pitch, off4, L.slot_bytes, L.pool4_pitch, L.has_image ? 1 : 0, off4 + L.pool4_bytes, L.hi_tpr,
+                           L.hi_copy_bytes, L.t16_tpr);
       } else {
         hipLaunchKernelGGL(grid_pool4_tiles_kernel<2>, dim3(blur_blocks), dim3(256), 0, s, count, list, tiles, g, L.pad, rows,
-                           L.pitch, off4, L.slot_bytes, L.pool4_pitch);
+                           L.pitch, off4, L.slot_bytes, L.pool4_pitch, L.has_image ? 1 : 0, off4 + L.pool4_bytes, L.hi_tpr,
+                           L.hi_copy_bytes, L.t16_tpr);
       }
-      const bool want_map8 = L.cb == 1 || (spec->flags & NHIP_GRID_SKIP_MAP);
-      if ((pk && pk[0] == 'b') || want_map8 || !(incremental && one_pass)) {
+      const bool want_map8 = L.has_image && (L.cb == 1 || (spec->flags & NHIP_GRID_SKIP_MAP));
+      if ((pk && pk[0] == 'b' && L.has_image) || want_map8 || !(incremental && one_pass)) {
         // (the whole table from the whole second-level table: first builds -- whose memset covers it anyway, but the
         //  handle API's late builds have no list -- and grids with a map, whose clear zeroes every derived table)
         launch_pool8_from_pool4(g, L, n, s);

@@ -37,7 +37,7 @@ def test_config3_full_list_takes_the_overlapped_rounds_and_equals_every_add(gpu)
     wl.tgt[50:100] = wl.tgt[100:150]
     plan = sharding.ShardPlan(wl.src, wl.tgt, wl.th0, 1)
     dev = torch.device("cuda", 0)
-    m = bench.HipMatcher(wl, plan.shard(0), dev, 16)
+    m = bench.HipMatcher(wl, plan.shard(0), dev, 16, no_image=False)  # (the every-add cross-check below reads the image)
     lib = _lib.load()
     lib.nhip_timing_reset()
     lib.nhip_timing_enable(1)

@@ -1385,3 +1385,91 @@ def test_exact_score_is_the_double_tables_score_at_the_winning_pose(gpu, small_b
     assert np.abs((a["score"].astype(np.float64) - at_small) / at_small).max() < 2e-7
     grids.close()
     st.close()
+
+
+@pytest.mark.parametrize("cell_bits", [16, 8])
+def test_grids_without_the_row_major_image(gpu, small_bag, cell_bits):
+    """NHIP_GRID_NO_IMAGE: the slots hold what the branch-and-bound matcher reads -- pooled tables, tiled planes, hit raster
+    -- and no row-major image: a third smaller.  Everything derived is byte for byte what a build WITH the image derives
+    (the pooled tables then come from the tiled copy of the cells); the matcher returns the same records in every form
+    that takes such slots, plain and exact scores; a rebuild equals a fresh build; what needs the image is refused with
+    an error code: the kernels that perform every add, score volumes, image downloads, lists with a scan of more than
+    1088 points, the skip-map flag."""
+    import os
+    import torch
+    lib = _lib.load()
+    full_spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits)
+    spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits, no_image=True)
+    Lf_, L = csm.grid_layout(full_spec), csm.grid_layout(spec)
+    assert L.grid_bytes == 0 and L.skip_bytes == 0 and L.slot_bytes == Lf_.slot_bytes - Lf_.grid_bytes - Lf_.skip_bytes
+    assert L.slot_bytes < 0.70 * Lf_.slot_bytes
+    bad = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, 16, skip_map=True, no_image=True)
+    assert lib.nhip_grid_layout(C.byref(bad), C.byref(_lib.GridLayout())) == _lib.NHIP_ERR_ARG
+    scans = [s.copy() for s in small_bag.scans]
+    scans.append(np.concatenate([scans[3], scans[4] + np.float32(0.01)]))  # 2162 points: beyond the by-rotation form
+    xy, off = csm.pack_scans(scans)
+    st = csm.ScanTable(xy, off)
+    ids = np.array([1, 9, 17, 25, 33, 41], dtype=np.int32)
+    gf, gl = csm.LikelihoodGrids(st, ids, full_spec), csm.LikelihoodGrids(st, ids, spec)
+    for slot in range(len(ids)):
+        for lv in (1, 2):
+            assert np.array_equal(gf.pooled(slot, lv), gl.pooled(slot, lv)), "pooled table, level %d" % lv
+        for cp in (0, 1):
+            assert np.array_equal(gf.hi_plane(slot, cp), gl.hi_plane(slot, cp))
+        if cell_bits == 16:
+            assert np.array_equal(gf.tiled16(slot), gl.tiled16(slot))
+        assert np.array_equal(gf.hits(slot), gl.hits(slot))
+    with pytest.raises(_lib.NhipError):
+        gl.download(0)
+    src, tgt, th0 = small_bag.sample_pairs(per_target=7, targets=ids, max_dist=3.5, min_sep=2)
+    slot = np.searchsorted(ids, tgt)
+    for search in (csm.search_spec(61, 81, 81, DEG), csm.search_spec(61, 81, 81, DEG, exact_score=True), csm.search_spec(9, 21, 21, DEG)):
+        want, want_sums = csm.match_pairs(st, gf, src, slot, th0, search)
+        for env in ({}, {"NHIP_BNB_KERNELS": "1"}, {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_LEVELS": "1"}, {"NHIP_BNB_KERNELS": "2", "NHIP_BNB_HEAVY_MIN": "1", "NHIP_BNB_KEEP_RANKS": "0"},
+                    {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_SPLIT": "1"}, {"NHIP_BNB_KERNELS": "1", "NHIP_BNB_SPLIT": "1", "NHIP_BNB_SPLIT_BATCH": "3", "NHIP_BNB_SPLIT_MIN": "1"}):
+            os.environ.update(env)
+            try:
+                got, sums = csm.match_pairs(st, gl, src, slot, th0, search)
+            finally:
+                for k_ in env:
+                    os.environ.pop(k_, None)
+            assert got.tobytes() == want.tobytes() and np.array_equal(sums, want_sums), env
+    # refused: every add, a lattice beyond the matcher's envelope, the general kernel (a long scan; the queue form), volumes
+    with pytest.raises(_lib.NhipError, match="NHIP_GRID_NO_IMAGE"):
+        csm.match_pairs(st, gl, src, slot, th0, csm.search_spec(61, 81, 81, DEG, exhaustive=True))
+    with pytest.raises(_lib.NhipError, match="NHIP_GRID_NO_IMAGE"):
+        csm.match_pairs(st, gl, src[:2], slot[:2], th0[:2], csm.search_spec(3, 97, 101, DEG))
+    with pytest.raises(_lib.NhipError, match="NHIP_GRID_NO_IMAGE"):
+        csm.match_pairs(st, gl, [len(scans) - 1], [0], [0.0], csm.search_spec(61, 81, 81, DEG))
+    os.environ["NHIP_BNB_QUEUE"] = "1"
+    try:
+        with pytest.raises(_lib.NhipError, match="NHIP_GRID_NO_IMAGE"):
+            csm.match_pairs(st, gl, src, slot, th0, csm.search_spec(61, 81, 81, DEG))
+    finally:
+        os.environ.pop("NHIP_BNB_QUEUE", None)
+    with pytest.raises(_lib.NhipError, match="NHIP_GRID_NO_IMAGE"):
+        csm.score_volume(st, gl, 0, 0, 0.0, csm.search_spec(3, 21, 21, DEG))
+    gf.close()
+    gl.close()
+    st.close()
+    # rebuild into image-less slots == fresh build, byte for byte (device-pointer API)
+    dev = torch.device("cuda:0")
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+    d_xy, d_off = t(xy), t(off)
+    n = 3
+    nbytes = lib.nhip_grids_bytes(C.byref(spec), n)
+    ws_bytes = lib.nhip_grid_workspace_bytes(C.byref(spec), n)
+    sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def call(fn, ids_, G, W):
+        d_ids = t(np.asarray(ids_, dtype=np.int32))
+        _lib.check(fn(d_xy.data_ptr(), d_off.data_ptr(), len(off) - 1, d_ids.data_ptr(), n, C.byref(spec), G.data_ptr(), W.data_ptr(), ws_bytes, sp))
+        torch.cuda.synchronize()
+        return G[:n * L.slot_bytes].cpu().numpy().copy()
+
+    fresh = call(lib.nhip_grid_build_dev, [25, 8, 3], torch.zeros(nbytes, dtype=torch.uint8, device=dev), torch.zeros(ws_bytes, dtype=torch.uint8, device=dev))
+    G, W = torch.empty(nbytes, dtype=torch.uint8, device=dev), torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    a = call(lib.nhip_grid_build_dev, [3, 17, 40], G, W)
+    assert not np.array_equal(a, fresh)
+    assert np.array_equal(call(lib.nhip_grid_rebuild_dev, [25, 8, 3], G, W), fresh), "rebuild over other targets"
+    assert np.array_equal(call(lib.nhip_grid_rebuild_dev, [25, 8, 3], G, W), fresh), "rebuild over the same targets"
