@@ -353,15 +353,15 @@ int nhip_resid_lidar_normal_eq_dev(int kind, const float *d_corr, const int32_t 
 int nhip_resid_point_to_line_dev(const float *d_segments, const float *d_points,
                                  const int32_t *d_point_block, int64_t n_points,
                                  const int32_t *d_block_pose, const int32_t *d_block_line,
-                                 int32_t n_blocks, const double *d_poses,
-                                 const double *d_line_poses, double *d_residuals,
+                                 int32_t n_blocks, const double *d_poses, int32_t n_poses,
+                                 const double *d_line_poses, int32_t n_line_poses, double *d_residuals,
                                  double *d_jac_pose, double *d_jac_line, void *stream);
 
 /* OdometryResidual (slam_residuals.h:18-40): factor f has T_odom d_t_odom[2f..] (Vector2f),
  * R_odom d_r_odom[f] (float), poses d_pose_i[f], d_pose_j[f].  3 residuals, 3x3 Jacobians. */
 int nhip_resid_odometry_dev(const float *d_t_odom, const float *d_r_odom, const int32_t *d_pose_i,
                             const int32_t *d_pose_j, int32_t n_factors, double translation_weight,
-                            double rotation_weight, const double *d_poses, double *d_residuals,
+                            double rotation_weight, const double *d_poses, int32_t n_poses, double *d_residuals,
                             double *d_jac_i, double *d_jac_j, void *stream);
 
 /* K5: correspondence search, the step that feeds K4 (Solver::GetPointToPointMatching,
@@ -376,7 +376,7 @@ int nhip_resid_odometry_dev(const float *d_t_odom, const float *d_r_odom, const 
  * valid.  nhip_corr_compact_dev packs them into the contiguous layout nhip_resid_lidar_dev takes
  * (d_block_offsets: n_blocks+1, d_corr: 8 floats/row, d_corr_block: block id per row). */
 int nhip_pose_affines(const double *poses, int32_t n, float *out /* 4n: cos sin x y */);
-int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets, int32_t n_scans,
                          const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                          const float *d_pose_aff, float outlier_threshold,
                          const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts,
@@ -387,7 +387,7 @@ int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_
  * |n_target . n_source| > min_abs_cosine (NormalsSimilar, math_util.h:46-49; the reference passes
  * cos(20 deg)); n_source is the source point's normal in the SOURCE frame, as in the reference.
  * Exactly equal distances go to the lowest target index (the reference's std::sort leaves that open). */
-int nhip_corr_search_normals_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+int nhip_corr_search_normals_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets, int32_t n_scans,
                                  const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                                  const float *d_pose_aff, float outlier_threshold, float min_abs_cosine,
                                  const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts,
@@ -411,9 +411,9 @@ int nhip_corr_compact_dev(const float *d_corr_padded, const int64_t *d_cap_offse
  * d_cov must be 16-byte aligned.  The covariance solve itself (ceres::Covariance) stays with the host's solver. */
 int nhip_lc_scatter_scores_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, double *d_scores,
                                void *stream);
-int nhip_lc_pair_gate_dev(const double *d_poses, const int32_t *d_candidates, int32_t n_candidates, double max_range,
-                          int32_t min_separation, uint8_t *d_flags, void *stream);
-int nhip_lc_chi_square_gate_dev(const double *d_poses, const int32_t *d_pair_src, const int32_t *d_pair_tgt,
+int nhip_lc_pair_gate_dev(const double *d_poses, int32_t n_poses, const int32_t *d_candidates, int32_t n_candidates,
+                          double max_range, int32_t min_separation, uint8_t *d_flags, void *stream);
+int nhip_lc_chi_square_gate_dev(const double *d_poses, int32_t n_poses, const int32_t *d_pair_src, const int32_t *d_pair_tgt,
                                 const float *d_cov, int32_t n_pairs, double max_score, double *d_scores,
                                 uint8_t *d_flags, void *stream);
 

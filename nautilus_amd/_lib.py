@@ -97,13 +97,13 @@ PROTOTYPES = {
                                        _vp, _vp, _vp, _vp]),
     "nhip_resid_lidar_normal_eq_dev": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _vp, _i32, _vp, _vp, _vp]),
     "nhip_pose_affines": (C.c_int, [_vp, _i32, _vp]),
-    "nhip_corr_search_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, _vp, _vp, _vp, _vp]),
-    "nhip_corr_search_normals_dev": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _vp, C.c_float, C.c_float, _vp, _vp, _vp,
+    "nhip_corr_search_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, C.c_float, _vp, _vp, _vp, _vp]),
+    "nhip_corr_search_normals_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp, C.c_float, C.c_float, _vp, _vp, _vp,
                                                _vp]),
     "nhip_corr_compact_dev": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
-    "nhip_resid_point_to_line_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _vp,
+    "nhip_resid_point_to_line_dev": (C.c_int, [_vp, _vp, _vp, _i64, _vp, _vp, _i32, _vp, _i32, _vp, _i32,
                                                _vp, _vp, _vp, _vp]),
-    "nhip_resid_odometry_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _vp, _vp,
+    "nhip_resid_odometry_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f64, _f64, _vp, _i32, _vp, _vp,
                                           _vp, _vp]),
     "nhip_scans_upload": (C.c_int, [_vp, _vp, _i32, _P(_vp)]),
     "nhip_scans_free": (C.c_int, [_vp]),
@@ -120,8 +120,8 @@ PROTOTYPES = {
     "nhip_csm_match": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i32, _P(Search), _vp, _vp]),
     "nhip_csm_scores": (C.c_int, [_vp, _vp, _i32, _i32, _f64, _i32, _i32, _P(Search), _vp]),
     "nhip_lc_scatter_scores_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp]),
-    "nhip_lc_pair_gate_dev": (C.c_int, [_vp, _vp, _i32, _f64, _i32, _vp, _vp]),
-    "nhip_lc_chi_square_gate_dev": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
+    "nhip_lc_pair_gate_dev": (C.c_int, [_vp, _i32, _vp, _i32, _f64, _i32, _vp, _vp]),
+    "nhip_lc_chi_square_gate_dev": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _f64, _vp, _vp, _vp]),
     "nhip_lc_chi_square_gate": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _i32, _f64, _vp, _vp]),
     "nhip_lc_scatter_scores": (C.c_int, [_vp, _vp]),
     "nhip_lc_pair_gate": (C.c_int, [_vp, _i32, _vp, _i32, _f64, _i32, _vp]),

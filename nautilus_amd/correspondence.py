@@ -74,13 +74,13 @@ class IcpBatch:
         """K5 + compaction.  Returns the number of correspondences (needs one sync to size outputs)."""
         sp = self._stream()
         if self.min_cos is None:
-            check(self.lib.nhip_corr_search_dev(self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(),
+            check(self.lib.nhip_corr_search_dev(self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(), self.n_scans,
                                                 self.d_bsrc.data_ptr(), self.d_btgt.data_ptr(), self.n_blocks,
                                                 self.d_aff.data_ptr(), self.thr, self.d_cap.data_ptr(),
                                                 self.d_padded.data_ptr(), self.d_counts.data_ptr(), sp))
         else:
             check(self.lib.nhip_corr_search_normals_dev(
-                self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(), self.d_bsrc.data_ptr(),
+                self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(), self.n_scans, self.d_bsrc.data_ptr(),
                 self.d_btgt.data_ptr(), self.n_blocks, self.d_aff.data_ptr(), self.thr, self.min_cos,
                 self.d_cap.data_ptr(), self.d_padded.data_ptr(), self.d_counts.data_ptr(), sp))
         check(self.lib.nhip_corr_compact_dev(self.d_padded.data_ptr(), self.d_cap.data_ptr(),

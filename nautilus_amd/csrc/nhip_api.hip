@@ -685,7 +685,7 @@ int nhip_resid_lidar_normal_eq_dev(int kind, const float *d_corr, const int32_t 
   NHIP_REQUIRE(d_corr && d_block_offsets && d_block_src && d_block_tgt && d_poses && d_block_consts && d_out,
                "resid_lidar_normal_eq_dev: null pointer");
   NHIP_REQUIRE(n_poses >= 0, "resid_lidar_normal_eq_dev: negative size");
-  return launch_resid_normal_eq(kind, d_corr, d_block_offsets, d_block_src, d_block_tgt, n_blocks, d_poses,
+  return launch_resid_normal_eq(kind, d_corr, d_block_offsets, d_block_src, d_block_tgt, n_blocks, d_poses, n_poses,
                                 d_block_consts, d_out, static_cast<hipStream_t>(stream));
 }
 
@@ -701,7 +701,7 @@ int nhip_pose_affines(const double *poses, int32_t n, float *out) {
   return NHIP_OK;
 }
 
-int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets, int32_t n_scans,
                          const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                          const float *d_pose_aff, float outlier_threshold,
                          const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts,
@@ -711,13 +711,13 @@ int nhip_corr_search_dev(const float *d_xy, const float *d_normals, const int32_
   NHIP_REQUIRE(d_xy && d_normals && d_offsets && d_block_src && d_block_tgt && d_pose_aff && d_cap_offsets &&
                    d_corr_padded && d_counts,
                "corr_search_dev: null pointer");
-  NHIP_REQUIRE(n_blocks >= 0 && outlier_threshold > 0, "corr_search_dev: bad size or threshold");
-  return launch_corr_search(d_xy, d_normals, d_offsets, d_block_src, d_block_tgt, n_blocks, d_pose_aff,
+  NHIP_REQUIRE(n_blocks >= 0 && n_scans >= 0 && outlier_threshold > 0, "corr_search_dev: bad size or threshold");
+  return launch_corr_search(d_xy, d_normals, d_offsets, n_scans, d_block_src, d_block_tgt, n_blocks, d_pose_aff,
                             outlier_threshold, 0.f, false, d_cap_offsets, d_corr_padded, d_counts,
                             static_cast<hipStream_t>(stream));
 }
 
-int nhip_corr_search_normals_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+int nhip_corr_search_normals_dev(const float *d_xy, const float *d_normals, const int32_t *d_offsets, int32_t n_scans,
                                  const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                                  const float *d_pose_aff, float outlier_threshold, float min_abs_cosine,
                                  const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts,
@@ -727,9 +727,9 @@ int nhip_corr_search_normals_dev(const float *d_xy, const float *d_normals, cons
   NHIP_REQUIRE(d_xy && d_normals && d_offsets && d_block_src && d_block_tgt && d_pose_aff && d_cap_offsets &&
                    d_corr_padded && d_counts,
                "corr_search_normals_dev: null pointer");
-  NHIP_REQUIRE(n_blocks >= 0 && outlier_threshold > 0, "corr_search_normals_dev: bad size or threshold");
+  NHIP_REQUIRE(n_blocks >= 0 && n_scans >= 0 && outlier_threshold > 0, "corr_search_normals_dev: bad size or threshold");
   NHIP_REQUIRE(min_abs_cosine >= 0.f && min_abs_cosine <= 1.f, "corr_search_normals_dev: min_abs_cosine outside [0, 1]");
-  return launch_corr_search(d_xy, d_normals, d_offsets, d_block_src, d_block_tgt, n_blocks, d_pose_aff,
+  return launch_corr_search(d_xy, d_normals, d_offsets, n_scans, d_block_src, d_block_tgt, n_blocks, d_pose_aff,
                             outlier_threshold, min_abs_cosine, true, d_cap_offsets, d_corr_padded, d_counts,
                             static_cast<hipStream_t>(stream));
 }
@@ -749,8 +749,8 @@ int nhip_corr_compact_dev(const float *d_corr_padded, const int64_t *d_cap_offse
 int nhip_resid_point_to_line_dev(const float *d_segments, const float *d_points,
                                  const int32_t *d_point_block, int64_t n_points,
                                  const int32_t *d_block_pose, const int32_t *d_block_line,
-                                 int32_t n_blocks, const double *d_poses,
-                                 const double *d_line_poses, double *d_residuals,
+                                 int32_t n_blocks, const double *d_poses, int32_t n_poses,
+                                 const double *d_line_poses, int32_t n_line_poses, double *d_residuals,
                                  double *d_jac_pose, double *d_jac_line, void *stream) {
   int rc = require_device();
   if (rc) return rc;
@@ -758,20 +758,20 @@ int nhip_resid_point_to_line_dev(const float *d_segments, const float *d_points,
                    d_line_poses && d_residuals,
                "resid_point_to_line_dev: null pointer");
   return launch_resid_point_to_line(d_segments, d_points, d_point_block, n_points, d_block_pose,
-                                    d_block_line, n_blocks, d_poses, d_line_poses, d_residuals,
+                                    d_block_line, n_blocks, d_poses, n_poses, d_line_poses, n_line_poses, d_residuals,
                                     d_jac_pose, d_jac_line, static_cast<hipStream_t>(stream));
 }
 
 int nhip_resid_odometry_dev(const float *d_t_odom, const float *d_r_odom, const int32_t *d_pose_i,
                             const int32_t *d_pose_j, int32_t n_factors, double translation_weight,
-                            double rotation_weight, const double *d_poses, double *d_residuals,
+                            double rotation_weight, const double *d_poses, int32_t n_poses, double *d_residuals,
                             double *d_jac_i, double *d_jac_j, void *stream) {
   int rc = require_device();
   if (rc) return rc;
   NHIP_REQUIRE(d_t_odom && d_r_odom && d_pose_i && d_pose_j && d_poses && d_residuals,
                "resid_odometry_dev: null pointer");
   return launch_resid_odometry(d_t_odom, d_r_odom, d_pose_i, d_pose_j, n_factors,
-                               translation_weight, rotation_weight, d_poses, d_residuals, d_jac_i,
+                               translation_weight, rotation_weight, d_poses, n_poses, d_residuals, d_jac_i,
                                d_jac_j, static_cast<hipStream_t>(stream));
 }
 
@@ -1107,25 +1107,25 @@ int nhip_lc_scatter_scores_dev(const float *d_xy, const int32_t *d_offsets, int3
   return launch_lc_scatter_scores(d_xy, d_offsets, n_scans, d_scores, static_cast<hipStream_t>(stream));
 }
 
-int nhip_lc_pair_gate_dev(const double *d_poses, const int32_t *d_candidates, int32_t n_candidates, double max_range,
-                          int32_t min_separation, uint8_t *d_flags, void *stream) {
+int nhip_lc_pair_gate_dev(const double *d_poses, int32_t n_poses, const int32_t *d_candidates, int32_t n_candidates,
+                          double max_range, int32_t min_separation, uint8_t *d_flags, void *stream) {
   int rc = require_device();
   if (rc) return rc;
-  NHIP_REQUIRE(n_candidates >= 0 && (n_candidates == 0 || (d_poses && d_candidates && d_flags)),
+  NHIP_REQUIRE(n_candidates >= 0 && n_poses >= 0 && (n_candidates == 0 || (d_poses && d_candidates && d_flags)),
                "lc_pair_gate_dev: bad arguments");
-  return launch_lc_pair_gate(d_poses, d_candidates, n_candidates, max_range, min_separation, d_flags,
+  return launch_lc_pair_gate(d_poses, n_poses, d_candidates, n_candidates, max_range, min_separation, d_flags,
                              static_cast<hipStream_t>(stream));
 }
 
-int nhip_lc_chi_square_gate_dev(const double *d_poses, const int32_t *d_pair_src, const int32_t *d_pair_tgt,
+int nhip_lc_chi_square_gate_dev(const double *d_poses, int32_t n_poses, const int32_t *d_pair_src, const int32_t *d_pair_tgt,
                                 const float *d_cov, int32_t n_pairs, double max_score, double *d_scores,
                                 uint8_t *d_flags, void *stream) {
   int rc = require_device();
   if (rc) return rc;
-  NHIP_REQUIRE(n_pairs >= 0 && (n_pairs == 0 || (d_poses && d_pair_src && d_pair_tgt && d_cov && d_scores && d_flags)),
+  NHIP_REQUIRE(n_pairs >= 0 && n_poses >= 0 && (n_pairs == 0 || (d_poses && d_pair_src && d_pair_tgt && d_cov && d_scores && d_flags)),
                "lc_chi_square_gate_dev: bad arguments");
   NHIP_REQUIRE((reinterpret_cast<uintptr_t>(d_cov) & 15) == 0, "lc_chi_square_gate_dev: d_cov must be 16-byte aligned");
-  return launch_lc_chi_square(d_poses, d_pair_src, d_pair_tgt, d_cov, n_pairs, max_score, d_scores, d_flags,
+  return launch_lc_chi_square(d_poses, n_poses, d_pair_src, d_pair_tgt, d_cov, n_pairs, max_score, d_scores, d_flags,
                               static_cast<hipStream_t>(stream));
 }
 
@@ -1148,7 +1148,7 @@ int nhip_lc_chi_square_gate(const double *poses, int32_t n_poses, const int32_t 
   NHIP_TRY_HIP(hipMemcpy(ds.p, pair_src, 4 * N, hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(dt.p, pair_tgt, 4 * N, hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(dc.p, cov, 16 * N, hipMemcpyHostToDevice));
-  rc = launch_lc_chi_square(static_cast<const double *>(dp.p), static_cast<const int32_t *>(ds.p),
+  rc = launch_lc_chi_square(static_cast<const double *>(dp.p), n_poses, static_cast<const int32_t *>(ds.p),
                             static_cast<const int32_t *>(dt.p), static_cast<const float *>(dc.p), n, max_score,
                             static_cast<double *>(dsc.p), static_cast<uint8_t *>(df.p), nullptr);
   if (rc) return rc;
@@ -1185,7 +1185,7 @@ int nhip_lc_pair_gate(const double *poses, int32_t n_poses, const int32_t *candi
     return rc;
   NHIP_TRY_HIP(hipMemcpy(dp.p, poses, sizeof(double) * 3 * (size_t)n_poses, hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(dc.p, candidates, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
-  rc = launch_lc_pair_gate(static_cast<const double *>(dp.p), static_cast<const int32_t *>(dc.p), n, max_range,
+  rc = launch_lc_pair_gate(static_cast<const double *>(dp.p), n_poses, static_cast<const int32_t *>(dc.p), n, max_range,
                            min_separation, static_cast<uint8_t *>(df.p), nullptr);
   if (rc) return rc;
   NHIP_TRY_HIP(hipMemcpy(flags, df.p, (size_t)n * n, hipMemcpyDeviceToHost));
@@ -1759,7 +1759,7 @@ int nhip_resid_odometry(const float *t_odom, const float *r_odom, const int32_t 
     return rc;
   rc = launch_resid_odometry(static_cast<const float *>(dt.p), static_cast<const float *>(dr.p),
                              static_cast<const int32_t *>(di.p), static_cast<const int32_t *>(dj.p), n, tw, rw,
-                             static_cast<const double *>(dp.p), static_cast<double *>(res.p),
+                             static_cast<const double *>(dp.p), n_poses, static_cast<double *>(res.p),
                              jac_i ? static_cast<double *>(ji.p) : nullptr,
                              jac_j ? static_cast<double *>(jj.p) : nullptr, nullptr);
   if (rc) return rc;
@@ -1795,8 +1795,8 @@ int nhip_resid_point_to_line(const float *segments, const float *points, const i
     return rc;
   rc = launch_resid_point_to_line(static_cast<const float *>(ds.p), static_cast<const float *>(dpt.p),
                                   static_cast<const int32_t *>(dpb.p), n_points, static_cast<const int32_t *>(dbp.p),
-                                  static_cast<const int32_t *>(dbl.p), n_blocks, static_cast<const double *>(dp.p),
-                                  static_cast<const double *>(dl.p), static_cast<double *>(res.p),
+                                  static_cast<const int32_t *>(dbl.p), n_blocks, static_cast<const double *>(dp.p), n_poses,
+                                  static_cast<const double *>(dl.p), n_line_poses, static_cast<double *>(res.p),
                                   jac_pose ? static_cast<double *>(j0.p) : nullptr,
                                   jac_line ? static_cast<double *>(j1.p) : nullptr, nullptr);
   if (rc) return rc;

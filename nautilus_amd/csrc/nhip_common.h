@@ -240,10 +240,10 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
 
 int launch_resid_normal_eq(int kind, const float *d_corr, const int32_t *d_block_offsets,
                            const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
-                           const double *d_poses, double *d_block_consts, double *d_out,
+                           const double *d_poses, int32_t n_poses, double *d_block_consts, double *d_out,
                            hipStream_t s);
 
-int launch_corr_search(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+int launch_corr_search(const float *d_xy, const float *d_normals, const int32_t *d_offsets, int32_t n_scans,
                        const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                        const float *d_pose_aff, float thr, float min_cos, bool gate, const int64_t *d_cap_offsets,
                        float *d_corr_padded, int32_t *d_counts, hipStream_t s);
@@ -253,20 +253,20 @@ int launch_corr_compact(const float *d_corr_padded, const int64_t *d_cap_offsets
                         float *d_corr, int32_t *d_corr_block, hipStream_t s);
 
 int launch_lc_scatter_scores(const float *d_xy, const int32_t *d_offsets, int32_t n_scans, double *d_scores, hipStream_t s);
-int launch_lc_chi_square(const double *d_poses, const int32_t *d_src, const int32_t *d_tgt, const float *d_cov, int32_t n,
-                         double max_score, double *d_scores, uint8_t *d_flags, hipStream_t s);
-int launch_lc_pair_gate(const double *d_poses, const int32_t *d_cand, int32_t n, double max_range, int32_t min_sep,
-                        uint8_t *d_flags, hipStream_t s);
+int launch_lc_chi_square(const double *d_poses, int32_t n_poses, const int32_t *d_src, const int32_t *d_tgt, const float *d_cov,
+                         int32_t n, double max_score, double *d_scores, uint8_t *d_flags, hipStream_t s);
+int launch_lc_pair_gate(const double *d_poses, int32_t n_poses, const int32_t *d_cand, int32_t n, double max_range,
+                        int32_t min_sep, uint8_t *d_flags, hipStream_t s);
 
 int launch_resid_point_to_line(const float *d_segments, const float *d_points,
                                const int32_t *d_point_block, int64_t n_points,
                                const int32_t *d_block_pose, const int32_t *d_block_line,
-                               int32_t n_blocks, const double *d_poses, const double *d_line_poses,
-                               double *d_res, double *d_jpose, double *d_jline, hipStream_t s);
+                               int32_t n_blocks, const double *d_poses, int32_t n_poses, const double *d_line_poses,
+                               int32_t n_line_poses, double *d_res, double *d_jpose, double *d_jline, hipStream_t s);
 
 int launch_resid_odometry(const float *d_t_odom, const float *d_r_odom, const int32_t *d_pose_i,
                           const int32_t *d_pose_j, int32_t n_factors, double tw, double rw,
-                          const double *d_poses, double *d_res, double *d_ji, double *d_jj,
+                          const double *d_poses, int32_t n_poses, double *d_res, double *d_ji, double *d_jj,
                           hipStream_t s);
 
 }  // namespace nhip

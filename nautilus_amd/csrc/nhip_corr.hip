@@ -115,7 +115,7 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
     const int32_t *__restrict__ offsets, const int32_t *__restrict__ block_src,
     const int32_t *__restrict__ block_tgt, const float *__restrict__ pose_aff, float thr, float min_cos,
     const int64_t *__restrict__ cap_offsets, float4 *__restrict__ corr,
-    int32_t *__restrict__ counts) {
+    int32_t *__restrict__ counts, int32_t n_scans, uint32_t *__restrict__ status) {
   __shared__ float2 s_tgt[TGT_CHUNK];
   __shared__ float2 s_tgn[GATE ? TGT_CHUNK : 1];  // target normals (gate only)
   __shared__ uint16_t s_sorted[TGT_CHUNK];  // target indices grouped by bucket
@@ -123,9 +123,15 @@ __global__ __launch_bounds__(CT) void corr_search_kernel(
   __shared__ uint32_t s_cur[NB];
   __shared__ int32_t s_scan[CT];
   const int b = blockIdx.x, tid = threadIdx.x;
-  const int32_t s = block_src[b], t = block_tgt[b];
-  const int32_t sb = offsets[s], ns = offsets[s + 1] - sb;
-  const int32_t tb = offsets[t], nt = offsets[t + 1] - tb;
+  int32_t s = block_src[b], t = block_tgt[b];
+  // (scan ids from device memory: a block with one outside [0, n_scans) is reported and matches nothing -- count 0)
+  const bool ids_ok = id_in(s, n_scans) && id_in(t, n_scans);
+  if (!ids_ok) {
+    if (tid == 0) flag_bad_id(status, BAD_SCAN_ID, id_in(s, n_scans) ? t : s, b);
+    s = t = 0;
+  }
+  const int32_t sb = ids_ok ? offsets[s] : 0, ns = ids_ok ? offsets[s + 1] - sb : 0;
+  const int32_t tb = ids_ok ? offsets[t] : 0, nt = ids_ok ? offsets[t + 1] - tb : 0;
   const Aff2f C = mul_f(inverse_f(pose_affine(pose_aff + 4 * (size_t)t)), pose_affine(pose_aff + 4 * (size_t)s));
   float4 *out = corr + 2 * (size_t)cap_offsets[b];
   int32_t written = 0;  // rows already emitted by earlier source passes (uniform)
@@ -385,7 +391,7 @@ __global__ __launch_bounds__(CT) void corr_compact_kernel(const float4 *__restri
 
 }  // namespace
 
-int launch_corr_search(const float *d_xy, const float *d_normals, const int32_t *d_offsets,
+int launch_corr_search(const float *d_xy, const float *d_normals, const int32_t *d_offsets, int32_t n_scans,
                        const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                        const float *d_pose_aff, float thr, float min_cos, bool gate,
                        const int64_t *d_cap_offsets, float *d_corr_padded, int32_t *d_counts, hipStream_t s) {
@@ -395,12 +401,12 @@ int launch_corr_search(const float *d_xy, const float *d_normals, const int32_t 
     hipLaunchKernelGGL(corr_search_kernel<true>, dim3(n_blocks), dim3(CT), 0, s,
                        reinterpret_cast<const float2 *>(d_xy), reinterpret_cast<const float2 *>(d_normals),
                        d_offsets, d_block_src, d_block_tgt, d_pose_aff, thr, min_cos, d_cap_offsets,
-                       reinterpret_cast<float4 *>(d_corr_padded), d_counts);
+                       reinterpret_cast<float4 *>(d_corr_padded), d_counts, n_scans, dev_status());
   else
     hipLaunchKernelGGL(corr_search_kernel<false>, dim3(n_blocks), dim3(CT), 0, s,
                        reinterpret_cast<const float2 *>(d_xy), reinterpret_cast<const float2 *>(d_normals),
                        d_offsets, d_block_src, d_block_tgt, d_pose_aff, thr, 0.f, d_cap_offsets,
-                       reinterpret_cast<float4 *>(d_corr_padded), d_counts);
+                       reinterpret_cast<float4 *>(d_corr_padded), d_counts, n_scans, dev_status());
   timer_end(NHIP_TIMER_CORR, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;

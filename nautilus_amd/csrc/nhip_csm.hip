@@ -442,6 +442,9 @@ struct ExactParams {
 template <int NR>
 __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
   __shared__ double s_part[4];
+  __shared__ uint32_t s_taps[2 * 16 + 1];  // (indexed by a set bit's position: from LDS, not from the kernel's argument block)
+  if (threadIdx.x <= 2 * 16) s_taps[threadIdx.x] = (uint32_t)P.taps[threadIdx.x];
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int32_t pair = (int32_t)blockIdx.x;
   int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
@@ -475,21 +478,20 @@ __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
         const uint8_t *w = hits + (size_t)(row - P.R + HIT_PAD) * P.hits_pitch + 4 * (size_t)(bit0 >> 5);
         uint32_t V = 0u;
         if (NR > 0) {
-          uint32_t lo[NR > 0 ? NR : 1], hi[NR > 0 ? NR : 1];
+          // (a row's 64-bit window in ONE load from its 4-byte-aligned address: the pass is bound by its load instructions)
+          struct __attribute__((packed, aligned(4))) Win { uint32_t lo, hi; };
+          Win win[NR > 0 ? NR : 1];
+#pragma unroll
+          for (int i = 0; i < NR; i++) win[i] = *reinterpret_cast<const Win *>(w + (size_t)i * P.hits_pitch);
 #pragma unroll
           for (int i = 0; i < NR; i++) {
-            lo[i] = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch);
-            hi[i] = *reinterpret_cast<const uint32_t *>(w + (size_t)i * P.hits_pitch + 4);
-          }
-#pragma unroll
-          for (int i = 0; i < NR; i++) {
-            uint32_t bits = (uint32_t)((((unsigned long long)hi[i] << 32) | lo[i]) >> sh) & mask;
+            uint32_t bits = (uint32_t)((((unsigned long long)win[i].hi << 32) | win[i].lo) >> sh) & mask;
             uint32_t rowsum = 0u;
             while (bits) {
-              rowsum += (uint32_t)P.taps[__builtin_ctz(bits)];
+              rowsum += s_taps[__builtin_ctz(bits)];
               bits &= bits - 1u;
             }
-            V += (uint32_t)P.taps[i] * rowsum;
+            V += s_taps[i] * rowsum;
           }
         } else {
           for (int i = 0; i < nr; i++) {
@@ -498,10 +500,10 @@ __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
             uint32_t bits = (uint32_t)((((unsigned long long)hi << 32) | lo) >> sh) & mask;
             uint32_t rowsum = 0u;
             while (bits) {
-              rowsum += (uint32_t)P.taps[__builtin_ctz(bits)];
+              rowsum += s_taps[__builtin_ctz(bits)];
               bits &= bits - 1u;
             }
-            V += (uint32_t)P.taps[i] * rowsum;
+            V += s_taps[i] * rowsum;
           }
         }
         double v = __ddiv_rn((double)V, P.K2);

@@ -62,11 +62,16 @@ __global__ __launch_bounds__(64) void lc_scatter_score_kernel(const float2 *__re
 // flags[i * n + j] = 1: candidate i (source) and candidate j (target) go to the matcher.
 __global__ __launch_bounds__(256) void lc_pair_gate_kernel(const double *__restrict__ poses, const int32_t *__restrict__ cand,
                                                            int32_t n, float max_range, int32_t min_sep,
-                                                           uint8_t *__restrict__ flags) {
+                                                           uint8_t *__restrict__ flags, int32_t n_poses, uint32_t *__restrict__ status) {
   const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (t >= (int64_t)n * n) return;
   const int32_t i = (int32_t)(t / n), j = (int32_t)(t % n);
   const int32_t a = cand[i], b = cand[j];
+  if (!id_in(a, n_poses) || !id_in(b, n_poses)) {  // (a candidate that is no node: reported, paired with nothing)
+    flag_bad_id(status, BAD_POSE_ID, id_in(a, n_poses) ? b : a, id_in(a, n_poses) ? j : i);
+    flags[t] = 0;
+    return;
+  }
   // GetPoseTranslation returns a Vector2f (slam_util.h:48-53): the distance is a float norm
   const float dx = __fsub_rn((float)poses[3 * b], (float)poses[3 * a]), dy = __fsub_rn((float)poses[3 * b + 1], (float)poses[3 * a + 1]);
   const float dist = __fsqrt_rn(__fadd_rn(__fmul_rn(dx, dx), __fmul_rn(dy, dy)));
@@ -81,10 +86,16 @@ __global__ __launch_bounds__(256) void lc_pair_gate_kernel(const double *__restr
 __global__ __launch_bounds__(256) void lc_chi_square_kernel(const double *__restrict__ poses, const int32_t *__restrict__ src,
                                                             const int32_t *__restrict__ tgt, const float *__restrict__ cov,
                                                             int32_t n, double max_score, double *__restrict__ scores,
-                                                            uint8_t *__restrict__ flags) {
+                                                            uint8_t *__restrict__ flags, int32_t n_poses, uint32_t *__restrict__ status) {
   const int32_t t = blockIdx.x * 256 + threadIdx.x;
   if (t >= n) return;
   const int32_t a = src[t], b = tgt[t];
+  if (!id_in(a, n_poses) || !id_in(b, n_poses)) {  // (a node index outside the poses: reported, score NaN, no match)
+    flag_bad_id(status, BAD_POSE_ID, id_in(a, n_poses) ? b : a, t);
+    scores[t] = __longlong_as_double(0x7ff8000000000000ll);
+    flags[t] = 0;
+    return;
+  }
   const float4 m = reinterpret_cast<const float4 *>(cov)[t];  // row major: m00 m01 m10 m11
   const float d0 = __fsub_rn((float)poses[3 * b], (float)poses[3 * a]), d1 = __fsub_rn((float)poses[3 * b + 1], (float)poses[3 * a + 1]);
   const float det = __fsub_rn(__fmul_rn(m.x, m.w), __fmul_rn(m.z, m.y));
@@ -98,11 +109,11 @@ __global__ __launch_bounds__(256) void lc_chi_square_kernel(const double *__rest
 
 }  // namespace
 
-int launch_lc_chi_square(const double *d_poses, const int32_t *d_src, const int32_t *d_tgt, const float *d_cov, int32_t n,
-                         double max_score, double *d_scores, uint8_t *d_flags, hipStream_t s) {
+int launch_lc_chi_square(const double *d_poses, int32_t n_poses, const int32_t *d_src, const int32_t *d_tgt, const float *d_cov,
+                         int32_t n, double max_score, double *d_scores, uint8_t *d_flags, hipStream_t s) {
   if (n == 0) return NHIP_OK;
   hipLaunchKernelGGL(lc_chi_square_kernel, dim3((n + 255) / 256), dim3(256), 0, s, d_poses, d_src, d_tgt, d_cov, n, max_score,
-                     d_scores, d_flags);
+                     d_scores, d_flags, n_poses, dev_status());
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }
@@ -115,13 +126,13 @@ int launch_lc_scatter_scores(const float *d_xy, const int32_t *d_offsets, int32_
   return NHIP_OK;
 }
 
-int launch_lc_pair_gate(const double *d_poses, const int32_t *d_cand, int32_t n, double max_range, int32_t min_sep,
-                        uint8_t *d_flags, hipStream_t s) {
+int launch_lc_pair_gate(const double *d_poses, int32_t n_poses, const int32_t *d_cand, int32_t n, double max_range,
+                        int32_t min_sep, uint8_t *d_flags, hipStream_t s) {
   if (n == 0) return NHIP_OK;
   const int64_t total = (int64_t)n * n;
   NHIP_REQUIRE(total < (int64_t)0x7fffffff * 256, "lc_pair_gate: too many candidates");
   hipLaunchKernelGGL(lc_pair_gate_kernel, dim3((uint32_t)((total + 255) / 256)), dim3(256), 0, s, d_poses, d_cand, n,
-                     (float)max_range, min_sep, d_flags);
+                     (float)max_range, min_sep, d_flags, n_poses, dev_status());
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }

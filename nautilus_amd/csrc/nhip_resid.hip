@@ -24,12 +24,18 @@ constexpr int RT = 256;
 // consts[8] = { l00, l01, l10, l11, tx, ty, i00 (= Linv(0,0)), i01 (= Linv(0,1)) }
 __global__ void resid_block_consts_kernel(const int32_t *__restrict__ block_src,
                                           const int32_t *__restrict__ block_tgt, int32_t n_blocks,
-                                          const double *__restrict__ poses,
-                                          double *__restrict__ consts) {
+                                          const double *__restrict__ poses, int32_t n_poses,
+                                          double *__restrict__ consts, uint32_t *__restrict__ status) {
   const int32_t b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= n_blocks) return;
-  const double *ps = poses + 3 * (size_t)block_src[b];
-  const double *pt = poses + 3 * (size_t)block_tgt[b];
+  // (pose indices from device memory: one outside [0, n_poses) is reported and read as pose 0 -- never dereferenced)
+  int32_t is = block_src[b], it = block_tgt[b];
+  if (!id_in(is, n_poses) || !id_in(it, n_poses)) {
+    flag_bad_id(status, BAD_POSE_ID, id_in(is, n_poses) ? it : is, b);
+    is = it = 0;
+  }
+  const double *ps = poses + 3 * (size_t)is;
+  const double *pt = poses + 3 * (size_t)it;
   const double cs = cos(ps[2]), ss = sin(ps[2]);
   const double ct = cos(pt[2]), st = sin(pt[2]);
   // A_t = [ct -st x_t; st ct y_t]; inverse: adj / det
@@ -67,17 +73,26 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
     const float4 *__restrict__ corr, const int32_t *__restrict__ corr_block, int64_t n_corr,
     const double *__restrict__ consts, double2 *__restrict__ residuals,
     double2 *__restrict__ jac_src, double2 *__restrict__ jac_tgt, double2 *__restrict__ jac_tgt_theta,
-    int32_t block_base) {
+    int32_t block_base, int32_t n_blocks, uint32_t *__restrict__ status) {
   __shared__ double2 s_j[WANT_J ? 2 * 3 * RT : 1];
   const int64_t i0 = (int64_t)blockIdx.x * RT;
   const int64_t i = i0 + threadIdx.x;
-  const bool live = i < n_corr;
+  bool live = i < n_corr;
+  // (a block id from device memory outside the batch's blocks: reported, the row's residuals and Jacobians are zero)
+  int32_t blk = 0;
+  if (live) {
+    blk = corr_block[i] - block_base;
+    if (!id_in(blk, n_blocks)) {
+      flag_bad_id(status, BAD_BLOCK_ID, blk + block_base, (int32_t)(i < 0x7fffffff ? i : 0x7fffffff));
+      live = false;
+    }
+  }
   double r0 = 0, r1 = 0;
   double js[6] = {0, 0, 0, 0, 0, 0}, jt[6] = {0, 0, 0, 0, 0, 0};
   if (live) {
     const float4 a = corr[2 * i];      // source point, target point
     const float4 n = corr[2 * i + 1];  // source normal, target normal
-    const double2 *c = reinterpret_cast<const double2 *>(consts + 8 * (size_t)(corr_block[i] - block_base));
+    const double2 *c = reinterpret_cast<const double2 *>(consts + 8 * (size_t)blk);
     const double2 c01 = c[0], c23 = c[1], c45 = c[2], c67 = c[3];
     const double l00 = c01.x, l01 = c01.y, l10 = c23.x, l11 = c23.y;
     const double i00 = c67.x, i01 = c67.y, i10 = -i01, i11 = i00;
@@ -313,12 +328,24 @@ __global__ __launch_bounds__(RT) void resid_point_to_line_kernel(
     const int32_t *__restrict__ point_block, int64_t n_points,
     const int32_t *__restrict__ block_pose, const int32_t *__restrict__ block_line,
     const double *__restrict__ poses, const double *__restrict__ line_poses,
-    double *__restrict__ residuals, double *__restrict__ jac_pose, double *__restrict__ jac_line) {
+    double *__restrict__ residuals, double *__restrict__ jac_pose, double *__restrict__ jac_line, int32_t n_blocks,
+    int32_t n_poses, int32_t n_line_poses, uint32_t *__restrict__ status) {
   const int64_t i = (int64_t)blockIdx.x * RT + threadIdx.x;
   if (i >= n_points) return;
+  // (ids from device memory: a block id outside the blocks, or a block whose pose / line-pose index is outside the arrays,
+  //  is reported and its point's residual and Jacobians are zero)
   const int32_t b = point_block[i];
-  const double *pp = poses + 3 * (size_t)block_pose[b];
-  const double *lp = line_poses + 3 * (size_t)block_line[b];
+  const bool b_ok = id_in(b, n_blocks);
+  const int32_t ip = b_ok ? block_pose[b] : -1, il = b_ok ? block_line[b] : -1;
+  if (!b_ok || !id_in(ip, n_poses) || !id_in(il, n_line_poses)) {
+    flag_bad_id(status, b_ok ? BAD_POSE_ID : BAD_BLOCK_ID, b_ok ? (id_in(ip, n_poses) ? il : ip) : b, (int32_t)(i < 0x7fffffff ? i : 0x7fffffff));
+    residuals[i] = 0.0;
+    if (jac_pose) { jac_pose[3 * i] = 0.0; jac_pose[3 * i + 1] = 0.0; jac_pose[3 * i + 2] = 0.0; }
+    if (jac_line) { jac_line[3 * i] = 0.0; jac_line[3 * i + 1] = 0.0; jac_line[3 * i + 2] = 0.0; }
+    return;
+  }
+  const double *pp = poses + 3 * (size_t)ip;
+  const double *lp = line_poses + 3 * (size_t)il;
   const float4 sg = segments[b];
   const float2 pt = points[i];
   // pose_to_world = T(x, y) * R(theta), slam_util.h:20-28; partials 0..2 = pose, 3..5 = line_pose
@@ -364,11 +391,20 @@ __global__ void resid_odometry_kernel(const float2 *__restrict__ t_odom,
                                       const int32_t *__restrict__ pose_j, int32_t n, double tw,
                                       double rw, const double *__restrict__ poses,
                                       double *__restrict__ residuals, double *__restrict__ ji,
-                                      double *__restrict__ jj) {
+                                      double *__restrict__ jj, int32_t n_poses, uint32_t *__restrict__ status) {
   const int32_t f = blockIdx.x * blockDim.x + threadIdx.x;
   if (f >= n) return;
-  const double *pi = poses + 3 * (size_t)pose_i[f];
-  const double *pj = poses + 3 * (size_t)pose_j[f];
+  // (pose indices from device memory: a factor with one outside [0, n_poses) is reported; residuals and Jacobians zero)
+  const int32_t ii = pose_i[f], ij = pose_j[f];
+  if (!id_in(ii, n_poses) || !id_in(ij, n_poses)) {
+    flag_bad_id(status, BAD_POSE_ID, id_in(ii, n_poses) ? ij : ii, f);
+    residuals[3 * f + 0] = residuals[3 * f + 1] = residuals[3 * f + 2] = 0.0;
+    if (ji) for (int q = 0; q < 9; q++) ji[9 * (size_t)f + q] = 0.0;
+    if (jj) for (int q = 0; q < 9; q++) jj[9 * (size_t)f + q] = 0.0;
+    return;
+  }
+  const double *pi = poses + 3 * (size_t)ii;
+  const double *pj = poses + 3 * (size_t)ij;
   const float2 t = t_odom[f];
   const double ex = pi[0] + (double)t.x - pj[0];
   const double ey = pi[1] + (double)t.y - pj[1];
@@ -400,7 +436,7 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
   NHIP_REQUIRE(n_corr >= 0 && n_blocks >= 0 && n_poses >= 0, "resid_lidar: negative size");
   if (n_corr == 0 || n_blocks == 0) return NHIP_OK;
   hipLaunchKernelGGL(resid_block_consts_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, s,
-                     d_block_src, d_block_tgt, n_blocks, d_poses, d_block_consts);
+                     d_block_src, d_block_tgt, n_blocks, d_poses, n_poses, d_block_consts, dev_status());
   const dim3 grid((uint32_t)((n_corr + RT - 1) / RT)), block(RT);
   const float4 *corr = reinterpret_cast<const float4 *>(d_corr);
   double2 *res = reinterpret_cast<double2 *>(d_res);
@@ -411,17 +447,17 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
   if (kind == NHIP_LIDAR_NORMAL) {
     if (want_j)
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_NORMAL, true>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base);
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status());
     else
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_NORMAL, false>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base);
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status());
   } else {
     if (want_j)
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_POINT, true>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base);
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status());
     else
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_POINT, false>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base);
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status());
   }
   timer_end(NHIP_TIMER_RESID, s);
   NHIP_TRY_HIP(hipGetLastError());
@@ -430,13 +466,13 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
 
 int launch_resid_normal_eq(int kind, const float *d_corr, const int32_t *d_block_offsets,
                            const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
-                           const double *d_poses, double *d_block_consts, double *d_out,
+                           const double *d_poses, int32_t n_poses, double *d_block_consts, double *d_out,
                            hipStream_t s) {
   NHIP_REQUIRE(kind == NHIP_LIDAR_NORMAL || kind == NHIP_LIDAR_POINT, "resid_normal_eq: bad kind %d", kind);
   NHIP_REQUIRE(n_blocks >= 0, "resid_normal_eq: negative size");
   if (n_blocks == 0) return NHIP_OK;
   hipLaunchKernelGGL(resid_block_consts_kernel, dim3((n_blocks + 255) / 256), dim3(256), 0, s,
-                     d_block_src, d_block_tgt, n_blocks, d_poses, d_block_consts);
+                     d_block_src, d_block_tgt, n_blocks, d_poses, n_poses, d_block_consts, dev_status());
   const float4 *corr = reinterpret_cast<const float4 *>(d_corr);
   timer_begin(NHIP_TIMER_NORMEQ, s);
   if (kind == NHIP_LIDAR_NORMAL)
@@ -453,27 +489,28 @@ int launch_resid_normal_eq(int kind, const float *d_corr, const int32_t *d_block
 int launch_resid_point_to_line(const float *d_segments, const float *d_points,
                                const int32_t *d_point_block, int64_t n_points,
                                const int32_t *d_block_pose, const int32_t *d_block_line,
-                               int32_t n_blocks, const double *d_poses, const double *d_line_poses,
-                               double *d_res, double *d_jpose, double *d_jline, hipStream_t s) {
-  NHIP_REQUIRE(n_points >= 0 && n_blocks >= 0, "resid_point_to_line: negative size");
+                               int32_t n_blocks, const double *d_poses, int32_t n_poses, const double *d_line_poses,
+                               int32_t n_line_poses, double *d_res, double *d_jpose, double *d_jline, hipStream_t s) {
+  NHIP_REQUIRE(n_points >= 0 && n_blocks >= 0 && n_poses >= 0 && n_line_poses >= 0, "resid_point_to_line: negative size");
   if (n_points == 0) return NHIP_OK;
   hipLaunchKernelGGL(resid_point_to_line_kernel, dim3((uint32_t)((n_points + RT - 1) / RT)),
                      dim3(RT), 0, s, reinterpret_cast<const float4 *>(d_segments),
                      reinterpret_cast<const float2 *>(d_points), d_point_block, n_points,
-                     d_block_pose, d_block_line, d_poses, d_line_poses, d_res, d_jpose, d_jline);
+                     d_block_pose, d_block_line, d_poses, d_line_poses, d_res, d_jpose, d_jline, n_blocks, n_poses,
+                     n_line_poses, dev_status());
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }
 
 int launch_resid_odometry(const float *d_t_odom, const float *d_r_odom, const int32_t *d_pose_i,
                           const int32_t *d_pose_j, int32_t n_factors, double tw, double rw,
-                          const double *d_poses, double *d_res, double *d_ji, double *d_jj,
+                          const double *d_poses, int32_t n_poses, double *d_res, double *d_ji, double *d_jj,
                           hipStream_t s) {
-  NHIP_REQUIRE(n_factors >= 0, "resid_odometry: negative size");
+  NHIP_REQUIRE(n_factors >= 0 && n_poses >= 0, "resid_odometry: negative size");
   if (n_factors == 0) return NHIP_OK;
   hipLaunchKernelGGL(resid_odometry_kernel, dim3((n_factors + 255) / 256), dim3(256), 0, s,
                      reinterpret_cast<const float2 *>(d_t_odom), d_r_odom, d_pose_i, d_pose_j,
-                     n_factors, tw, rw, d_poses, d_res, d_ji, d_jj);
+                     n_factors, tw, rw, d_poses, d_res, d_ji, d_jj, n_poses, dev_status());
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }

@@ -1438,7 +1438,7 @@ def test_grids_without_the_row_major_image(gpu, small_bag, cell_bits):
     with pytest.raises(_lib.NhipError, match="NHIP_GRID_NO_IMAGE"):
         csm.match_pairs(st, gl, src, slot, th0, csm.search_spec(61, 81, 81, DEG, exhaustive=True))
     with pytest.raises(_lib.NhipError, match="NHIP_GRID_NO_IMAGE"):
-        csm.match_pairs(st, gl, src[:2], slot[:2], th0[:2], csm.search_spec(3, 97, 101, DEG))
+        csm.match_pairs(st, gl, src[:2], slot[:2], th0[:2], csm.search_spec(361, 9, 9, DEG))
     with pytest.raises(_lib.NhipError, match="NHIP_GRID_NO_IMAGE"):
         csm.match_pairs(st, gl, [len(scans) - 1], [0], [0.0], csm.search_spec(61, 81, 81, DEG))
     os.environ["NHIP_BNB_QUEUE"] = "1"

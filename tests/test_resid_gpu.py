@@ -124,7 +124,7 @@ def test_point_to_line_matches_autodiff_oracle(gpu):
             _dev(np.asarray(bline, np.int32)), _dev(poses), _dev(lines)]
     _lib.check(_lib.load().nhip_resid_point_to_line_dev(
         args[0].data_ptr(), args[1].data_ptr(), args[2].data_ptr(), n, args[3].data_ptr(), args[4].data_ptr(), 8,
-        args[5].data_ptr(), args[6].data_ptr(), d_res.data_ptr(), d_j0.data_ptr(), d_j1.data_ptr(), None))
+        args[5].data_ptr(), 3, args[6].data_ptr(), 3, d_res.data_ptr(), d_j0.data_ptr(), d_j1.data_ptr(), None))
     torch.cuda.synchronize()
     res, j0, j1 = d_res.cpu().numpy(), d_j0.cpu().numpy().reshape(n, 3), d_j1.cpu().numpy().reshape(n, 3)
     o = 0
@@ -149,8 +149,8 @@ def test_reference_kats_through_the_hip_path(gpu):
          _dev(zero), _dev(zero)]
     d_res = torch.empty(6, dtype=torch.float64, device="cuda:0")
     _lib.check(_lib.load().nhip_resid_point_to_line_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), 6,
-                                                        d[3].data_ptr(), d[4].data_ptr(), 1, d[5].data_ptr(),
-                                                        d[6].data_ptr(), d_res.data_ptr(), None, None, None))
+                                                        d[3].data_ptr(), d[4].data_ptr(), 1, d[5].data_ptr(), 1,
+                                                        d[6].data_ptr(), 1, d_res.data_ptr(), None, None, None))
     torch.cuda.synchronize()
     got = d_res.cpu().numpy()
     assert got[0] == 0.0 and got[5] == 0.0                       # EXPECT_EQ(dist, 0) / EXPECT_FLOAT_EQ(dist, 0)
@@ -171,7 +171,7 @@ def test_odometry_matches_autodiff_oracle(gpu):
     d_ji = torch.empty(9 * n, dtype=torch.float64, device="cuda:0")
     d_jj = torch.empty(9 * n, dtype=torch.float64, device="cuda:0")
     _lib.check(_lib.load().nhip_resid_odometry_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(),
-                                                   d[3].data_ptr(), n, 1.0, 2.5, d[4].data_ptr(),
+                                                   d[3].data_ptr(), n, 1.0, 2.5, d[4].data_ptr(), n + 1,
                                                    d_res.data_ptr(), d_ji.data_ptr(), d_jj.data_ptr(), None))
     torch.cuda.synchronize()
     res = d_res.cpu().numpy().reshape(n, 3)
