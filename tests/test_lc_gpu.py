@@ -73,7 +73,7 @@ def test_chi_square_gate_bit_exact(gpu, chi_square_cases):
     d = [torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (poses, src, tgt, cov.reshape(-1, 4))]
     d_s, d_f = torch.empty(len(src), dtype=torch.float64, device=dev), torch.empty(len(src), dtype=torch.uint8, device=dev)
     sp = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-    _lib.check(_lib.load().nhip_lc_chi_square_gate_dev(d[0].data_ptr(), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
+    _lib.check(_lib.load().nhip_lc_chi_square_gate_dev(d[0].data_ptr(), len(poses), d[1].data_ptr(), d[2].data_ptr(), d[3].data_ptr(),
                                                       len(src), 100.0, d_s.data_ptr(), d_f.data_ptr(), sp))
     w_s, w_f = O.chi_square_gate(poses, src, tgt, cov, 100.0)
     assert d_s.cpu().numpy().tobytes() == w_s.tobytes() and d_f.cpu().numpy().tobytes() == w_f.tobytes()
