@@ -470,7 +470,8 @@ int nhip_lc_chi_square_gate(const double *poses, int32_t n_poses, const int32_t 
  * .GetTransformation(pc_a, pc_b, rot_a, rot_b, rot_restriction) -> (score, ((tx, ty), theta))
  * (solver.cc:56, 633-644; the class lives in the absent third_party/csm).  Build-defined search:
  * exhaustive on the low_res grid over +-trans_range and +-rot_restriction in 1 degree steps, then exhaustive on the
- * high_res grid over +-low_res around the coarse optimum in 0.1 degree steps.  This is the ONE implementation of that
+ * high_res grid over +-low_res around the coarse optimum in 0.1 degree steps; the returned score is the fine optimum's
+ * mean log-likelihood on the unquantised table (NHIP_SEARCH_EXACT_SCORE).  This is the ONE implementation of that
  * search: the C++ drop-in (adapters/CorrelativeScanMatcher.h) and the Python mirror (nautilus_amd/csm.py) both call it;
  * oracle/csm_oracle.c restates it independently for the tests.  Host pointers.  pc_a / pc_b: n x 2 floats
  * (std::vector<Eigen::Vector2f>).  The two tables built from pc_b stay in a cache of the last targets (keyed by the cloud's

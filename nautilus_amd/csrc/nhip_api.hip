@@ -1466,7 +1466,9 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   // the largest search centre a coarse optimum can produce (+ the fine half-width), so that they serve every source.
   const int32_t ratio = (int32_t)lround(p->low_res / p->high_res);
   const int32_t reach_max = (int32_t)lround((double)h1 * p->low_res / p->high_res) + ratio + 2;
-  const nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1, 0, coarse_step / 10.0};
+  // (the score the call returns is the fine optimum's on the UNQUANTISED table -- NHIP_SEARCH_EXACT_SCORE: the reference's
+  //  table holds doubles, cimg_debug.h:19; both searches run on the quantised tables)
+  const nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1, NHIP_SEARCH_EXACT_SCORE, coarse_step / 10.0};
   const bool cacheable = reach_max <= 4096 && n_b > 0;
 
   // ---- the target's tables: from the cache, or built now

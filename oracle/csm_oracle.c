@@ -423,6 +423,66 @@ int orc_csm_match_f64(const float *src_xy, int32_t n_points, const double *grid,
   return 0;
 }
 
+/*
+ * The spec's EXACT score (what NHIP_SEARCH_EXACT_SCORE reports) of ONE pose (k, ix, iy) of
+ * the lattice around (origin_x, origin_y): the mean over the source points, in point order, of the unquantised
+ * log-likelihood of the cell each point reads -- orc_loglik of the cell's exact integer blur sum, the floor for lookups
+ * outside the grid and for non-finite points.  The blur sums are evaluated around the cells that are read only, from the
+ * target's hit raster (the 6000 x 6000 table of the two-level search in doubles would be 288 MB); the values, and the
+ * order they are added in, are those of orc_csm_match_f64's score volume on the whole double table
+ * (tests/test_oracle_kat.py holds the two against each other where the table can be built).
+ */
+int orc_csm_pose_score_exact(const float *src_xy, int32_t n_src, const float *tgt_xy, int32_t n_tgt,
+                             const orc_grid_spec *gs, double theta0, const orc_search_spec *ss, int32_t origin_x,
+                             int32_t origin_y, int32_t k, int32_t ix, int32_t iy, double *score) {
+  const int32_t S = orc_grid_side(gs->range, gs->res);
+  const int32_t R = orc_blur_radius(gs->sigma);
+  if (S <= 0 || R < 0 || R > 64 || !score) return -1;
+  const int32_t hx = (ss->nx - 1) / 2, hy = (ss->ny - 1) / 2;
+  const double Lf = log(gs->floor_p);
+  if (n_src <= 0) { *score = Lf; return 0; }
+  int32_t taps[2 * 64 + 1];
+  const int64_t K = orc_blur_taps(gs->sigma, R, taps);
+  uint8_t *H = (uint8_t *)calloc((size_t)S * S, 1);
+  if (!H) return -2;
+  for (int32_t p = 0; p < n_tgt; p++) {
+    const int64_t c = orc_cell(tgt_xy[2 * p + 0], gs->res, S), r = orc_cell(tgt_xy[2 * p + 1], gs->res, S);
+    if (c < 0 || c >= S || r < 0 || r >= S) continue; /* cimg_debug.h:48-50 */
+    H[(size_t)r * S + c] = 1;
+  }
+  float cf, sf;
+  orc_rotation(theta0, ss, k, &cf, &sf);
+  double acc = 0.0;
+  for (int32_t p = 0; p < n_src; p++) {
+    const float x = src_xy[2 * p], y = src_xy[2 * p + 1];
+    const float ax = cf * x, bx_ = sf * y, ay = sf * x, by_ = cf * y;
+    const float xr = ax - bx_;
+    const float yr = ay + by_;
+    const int64_t c = orc_cell(xr, gs->res, S) + origin_x + (ix - hx);
+    const int64_t r = orc_cell(yr, gs->res, S) + origin_y + (iy - hy);
+    double L = Lf;
+    if (c >= 0 && c < S && r >= 0 && r < S) {
+      uint64_t V = 0;
+      for (int i = -R; i <= R; i++) {
+        const int64_t rr = r + i;
+        if (rr < 0 || rr >= S) continue;
+        uint32_t a = 0; /* the horizontal pass at (rr, c) */
+        for (int j = -R; j <= R; j++) {
+          const int64_t cc = c + j;
+          if (cc < 0 || cc >= S) continue;
+          a += (uint32_t)taps[j + R] * H[(size_t)rr * S + cc];
+        }
+        V += (uint64_t)taps[i + R] * a;
+      }
+      L = orc_loglik(V, K, gs->floor_p);
+    }
+    acc += L;
+  }
+  free(H);
+  *score = acc / (double)n_src;
+  return 0;
+}
+
 /* One unquantised table per pair's target is built and dropped inside the loop (11.5 MB each). */
 int orc_csm_match_f64_batch(const float *xy, const int32_t *offsets, const int32_t *pair_src,
                             const int32_t *pair_tgt, const double *theta0, int32_t n_pairs,
@@ -503,7 +563,12 @@ int orc_two_level_match(const float *pc_a, int32_t n_a, const float *pc_b, int32
   if (!rc) rc = orc_csm_match(pc_a, n_a, grid2, &g2, (double)th1, ox, oy, &s2, &m2);
   free(grid2);
   if (rc) return rc;
-  *score = (double)(float)m2.score; /* the product's record carries the score as float */
+  /* the reported score is the fine optimum's EXACT score (unquantised log-likelihoods: the reference's table holds
+   * doubles, cimg_debug.h:19); the searches themselves run on the quantised tables */
+  double exact = 0.0;
+  rc = orc_csm_pose_score_exact(pc_a, n_a, pc_b, n_b, &g2, (double)th1, &s2, ox, oy, m2.itheta, m2.ix, m2.iy, &exact);
+  if (rc) return rc;
+  *score = (double)(float)exact; /* the product's record carries the score as float */
   *tx = (float)((double)(ox + m2.ix - ratio) * high_res);
   *ty = (float)((double)(oy + m2.iy - ratio) * high_res);
   *theta = (float)((double)th1 + (double)(m2.itheta - 10) * s2.theta_step);

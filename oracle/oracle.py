@@ -65,6 +65,8 @@ def load():
     lib.orc_csm_match_f64.argtypes = [_vp, _i32, _vp, C.POINTER(GridSpec), _f64, C.POINTER(SearchSpec), _vp, _vp]
     lib.orc_csm_match_f64_batch.argtypes = [_vp, _vp, _vp, _vp, _vp, _i32, C.POINTER(GridSpec), C.POINTER(SearchSpec),
                                             _vp, _vp, _vp, _i32]
+    lib.orc_csm_pose_score_exact.argtypes = [_vp, _i32, _vp, _i32, C.POINTER(GridSpec), _f64, C.POINTER(SearchSpec), _i32, _i32,
+                                             _i32, _i32, _i32, C.POINTER(_f64)]
     lib.orc_two_level_match.argtypes = [_vp, _i32, _vp, _i32, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _f64,
                                         _i32, C.POINTER(_f64), C.POINTER(C.c_float), C.POINTER(C.c_float),
                                         C.POINTER(C.c_float)]
@@ -220,6 +222,16 @@ def csm_match_f64(src_points, grid_f64, gs, theta0, ss, want_scores=False):
     _chk(load().orc_csm_match_f64(_p(pts), len(pts), _p(g), C.byref(gs), float(theta0), C.byref(ss), _p(out), _p(vol)),
          "csm_match_f64")
     return (out[0], vol) if want_scores else out[0]
+
+
+def pose_score_exact(src_points, tgt_points, gs, theta0, ss, k, ix, iy, origin=(0, 0)):
+    """The exact score (unquantised log-likelihoods) of ONE pose of the lattice: what NHIP_SEARCH_EXACT_SCORE reports."""
+    a = np.ascontiguousarray(src_points, dtype=np.float32).reshape(-1, 2)
+    b = np.ascontiguousarray(tgt_points, dtype=np.float32).reshape(-1, 2)
+    out = C.c_double(0.0)
+    _chk(load().orc_csm_pose_score_exact(_p(a), len(a), _p(b), len(b), C.byref(gs), float(theta0), C.byref(ss), int(origin[0]),
+                                         int(origin[1]), int(k), int(ix), int(iy), C.byref(out)), "csm_pose_score_exact")
+    return out.value
 
 
 def csm_match_f64_batch(xy, offsets, pair_src, pair_tgt, theta0, gs, ss, probe=None, n_threads=0):

@@ -46,7 +46,8 @@ def test_adapter_binary_on_gpu(gpu, tmp_path):
             rot_a, rot_b, restrict, score, tx, ty, th = map(hexf, r[1:])
             a, b = (pc["a"], pc["b"]) if r[0] == "get_transformation" else (pc["b"], pc["a"])
             want = O.two_level_match(a, b, rot_a, rot_b, restrict, 30.0, 2.0, 0.3, 0.01, cell_bits=16)
-            assert score == want[0] and np.float32(tx) == want[1][0][0] and np.float32(ty) == want[1][0][1]
+            # (the score: the fine optimum's on the unquantised table, device / host logarithms: 2e-7 relative)
+            assert abs(score - want[0]) <= 2e-7 * abs(want[0]) and np.float32(tx) == want[1][0][0] and np.float32(ty) == want[1][0][1]
             assert np.float32(th) == want[1][1], (r[0], th, want)
             seen.add(r[0])
         elif r[0] == "batch":

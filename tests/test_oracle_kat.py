@@ -235,3 +235,22 @@ def test_csm_recovers_known_offset(small_bag):
         m = O.csm_match(src, O.grid_build(base, gs), gs, 0.0, ss)
         assert abs((m.ix - 20) * 0.05 - dx) <= 0.051 and abs((m.iy - 20) * 0.05 - dy) <= 0.051
         assert abs(math.radians(m.itheta - 15) - dth) <= math.radians(1.01)
+
+
+def test_exact_pose_score_equals_the_double_tables_volume(small_bag):
+    """orc_csm_pose_score_exact (the oracle's statement of NHIP_SEARCH_EXACT_SCORE: blur sums evaluated around the cells a
+    pose reads) against orc_csm_match_f64's score volume on the whole table of doubles: the same doubles, bit for bit, at
+    every pose probed -- lattice corners, the optimum, poses whose lookups leave the grid -- and with a shifted centre."""
+    gs, ss = O.grid_spec(12.0, 0.05, 2.0, 1e-10, 16), O.search_spec(5, 21, 21, math.radians(2.0))
+    src, tgt = small_bag.scans[9].copy(), small_bag.scans[7]
+    src[:3] = [[11.99, 0.0], [np.nan, 1.0], [-40.0, 2.0]]  # near the grid's edge, non-finite, outside
+    g = O.grid_build_f64(tgt, gs)
+    best, vol = O.csm_match_f64(src, g, gs, 0.03, ss, want_scores=True)
+    poses = [(0, 0, 0), (4, 20, 20), (2, 10, 10), (int(best["itheta"]), int(best["ix"]), int(best["iy"])), (1, 3, 17)]
+    for k, ix, iy in poses:
+        assert O.pose_score_exact(src, tgt, gs, 0.03, ss, k, ix, iy) == vol[k, ix, iy]
+    # a centre shifted by (3, -2) cells: pose (k, ix, iy) there is pose (k, ix + 3, iy - 2) here
+    small = O.search_spec(5, 11, 11, math.radians(2.0))
+    for k, ix, iy in [(0, 0, 0), (3, 5, 5), (4, 10, 10)]:
+        assert O.pose_score_exact(src, tgt, gs, 0.03, small, k, ix, iy, origin=(3, -2)) == vol[k, ix + 5 + 3, iy + 5 - 2]
+    assert O.pose_score_exact(np.zeros((0, 2), np.float32), tgt, gs, 0.0, ss, 0, 0, 0) == math.log(1e-10)
