@@ -77,7 +77,8 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
   __shared__ double2 s_j[WANT_J ? 2 * 3 * RT : 1];
   const int64_t i0 = (int64_t)blockIdx.x * RT;
   const int64_t i = i0 + threadIdx.x;
-  bool live = i < n_corr;
+  const bool in_range = i < n_corr;
+  bool live = in_range;
   // (a block id from device memory outside the batch's blocks: reported, the row's residuals and Jacobians are zero)
   int32_t blk = 0;
   if (live) {
@@ -130,6 +131,8 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
         jt[3] = i10;  jt[4] = i11;  jt[5] = qx;
       }
     }
+  }
+  if (in_range) {
     store_stream(&residuals[i], make_double2(r0, r1));
     // the theta column of the target Jacobian on its own: its x, y columns are the negated x, y columns of the
     // source Jacobian (dq/dt_t = -dq/dt_s), so a host that rebuilds them needs only these two values
