@@ -429,7 +429,7 @@ struct ExactParams {
   const int32_t *pair_kbase;  // optional: entry of delta_cs that is pair i's rotation 0 (nhip_bnb_params.h)
   nhip_match_t *out;
   IdBounds ids;
-  int32_t n_pairs, nx, ny, hx, hy, S, R, hits_pitch;
+  int32_t n_pairs, pairs_per_xcd, nx, ny, hx, hy, S, R, hits_pitch;
   int64_t slot_bytes, hits_offset;
   double res, inv_res, K2, floor_p, Lf;
   int32_t taps[2 * 16 + 1];
@@ -439,14 +439,32 @@ struct ExactParams {
 // first version ran one wave per pair with a rolled loop over the window's rows: 17 points x 13 dependent round trips per
 // lane, 0.44 ms per 10,000 pairs of pure latency.  Here the 2 NR dword loads of a point's window are issued together
 // (NR = 2 R + 1 rows, a compile-time constant for the blur radii in use; the generic instantiation loops).
+constexpr int EX_THREADS = 256;  // (512 -- three rounds of loads per thread instead of five -- measured slower: 0.140 against 0.131 ms)
 template <int NR>
-__global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
-  __shared__ double s_part[4];
+__global__ __launch_bounds__(EX_THREADS) void csm_exact_score_kernel(ExactParams P) {
+  __shared__ double s_part[EX_THREADS / 64];
   __shared__ uint32_t s_taps[2 * 16 + 1];  // (indexed by a set bit's position: from LDS, not from the kernel's argument block)
+  // Row sums by table: a window row of up to 14 bits is two 7-bit halves, s_lut[h][bits] = sum of the taps of the set
+  // bits of half h -- two LDS reads per row, where the loop over set bits ran as long as the wave's fullest lane needed
+  // (the pass was 420 vector instructions per point, most of them that loop: 0.145 -> 0.131 ms per 10,000 pairs).
+  __shared__ uint32_t s_lut[2][128];
   if (threadIdx.x <= 2 * 16) s_taps[threadIdx.x] = (uint32_t)P.taps[threadIdx.x];
   __syncthreads();
+  if (threadIdx.x < 256) {
+    const int h = threadIdx.x >> 7, b = threadIdx.x & 127;
+    uint32_t t = 0u;
+#pragma unroll
+    for (int i = 0; i < 7; i++)
+      if ((b >> i) & 1) t += s_taps[7 * h + i];  // (entries past 2 R are zero)
+    s_lut[h][b] = t;
+  }
+  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int32_t pair = (int32_t)blockIdx.x;
+  // consecutive pairs (one target's, usually) on ONE XCD, as in the matcher's kernels: its L2 then fetches the target's hit
+  // raster once -- with pair = blockIdx the eight XCDs each fetched it (536 MB of L2 misses per 10,000 pairs for 200 MB
+  // of rasters: the pass was bound by them)
+  const int32_t pair = (int32_t)(blockIdx.x & 7u) * P.pairs_per_xcd + (int32_t)(blockIdx.x >> 3);
+  if (pair >= P.n_pairs) return;
   int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
   const bool ids_ok = pair_ids_ok(P.ids, src, slot, pair, false);  // (the matcher reported it)
   if (!ids_ok) src = slot = 0;
@@ -464,7 +482,7 @@ __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
   const int nr = NR > 0 ? NR : 2 * P.R + 1;
   const uint32_t mask = (1u << nr) - 1u;  // (R <= 15: at most 31 bits)
   double acc = 0.0;
-  for (int32_t p = (int32_t)threadIdx.x; p < n_pts; p += 256) {
+  for (int32_t p = (int32_t)threadIdx.x; p < n_pts; p += EX_THREADS) {
     const float2 q = P.xy[beg + p];
     const float xr = __fsub_rn(__fmul_rn(cf, q.x), __fmul_rn(sf, q.y));
     const float yr = __fadd_rn(__fmul_rn(sf, q.x), __fmul_rn(cf, q.y));
@@ -487,9 +505,13 @@ __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
           for (int i = 0; i < NR; i++) {
             uint32_t bits = (uint32_t)((((unsigned long long)win[i].hi << 32) | win[i].lo) >> sh) & mask;
             uint32_t rowsum = 0u;
-            while (bits) {
-              rowsum += s_taps[__builtin_ctz(bits)];
-              bits &= bits - 1u;
+            if (NR <= 14) {
+              rowsum = s_lut[0][bits & 127u] + s_lut[1][bits >> 7];
+            } else {
+              while (bits) {
+                rowsum += s_taps[__builtin_ctz(bits)];
+                bits &= bits - 1u;
+              }
             }
             V += s_taps[i] * rowsum;
           }
@@ -521,7 +543,9 @@ __global__ __launch_bounds__(256) void csm_exact_score_kernel(ExactParams P) {
   if (lane == 0) s_part[wave] = acc;
   __syncthreads();
   if (threadIdx.x == 0) {
-    const double tot = ((s_part[0] + s_part[1]) + s_part[2]) + s_part[3];
+    double tot = s_part[0];
+#pragma unroll
+    for (int w = 1; w < EX_THREADS / 64; w++) tot += s_part[w];
     P.out[pair].score = __double2float_rn(n_pts > 0 ? __ddiv_rn(tot, (double)n_pts) : P.Lf);
   }
 }
@@ -549,6 +573,7 @@ int launch_csm_exact_score(const float *d_xy, const int32_t *d_offsets, const Id
   P.out = d_out;
   P.ids = ids;
   P.n_pairs = n_pairs;
+  P.pairs_per_xcd = (n_pairs + 7) / 8;
   P.nx = search->nx;
   P.ny = search->ny;
   P.hx = (search->nx - 1) / 2;
@@ -565,9 +590,9 @@ int launch_csm_exact_score(const float *d_xy, const int32_t *d_offsets, const Id
   P.Lf = L.Lf;
   for (int i = 0; i <= 2 * L.R; i++) P.taps[i] = T.taps[i];
   timer_begin(NHIP_TIMER_EXACT_SCORE, s);
-  if (L.R == 6) hipLaunchKernelGGL(csm_exact_score_kernel<13>, dim3((uint32_t)n_pairs), dim3(256), 0, s, P);  // sigma = 2
-  else if (L.R == 3) hipLaunchKernelGGL(csm_exact_score_kernel<7>, dim3((uint32_t)n_pairs), dim3(256), 0, s, P);  // sigma = 1
-  else hipLaunchKernelGGL(csm_exact_score_kernel<0>, dim3((uint32_t)n_pairs), dim3(256), 0, s, P);
+  if (L.R == 6) hipLaunchKernelGGL(csm_exact_score_kernel<13>, dim3(8u * (uint32_t)P.pairs_per_xcd), dim3(EX_THREADS), 0, s, P);  // sigma = 2
+  else if (L.R == 3) hipLaunchKernelGGL(csm_exact_score_kernel<7>, dim3(8u * (uint32_t)P.pairs_per_xcd), dim3(EX_THREADS), 0, s, P);  // sigma = 1
+  else hipLaunchKernelGGL(csm_exact_score_kernel<0>, dim3(8u * (uint32_t)P.pairs_per_xcd), dim3(EX_THREADS), 0, s, P);
   timer_end(NHIP_TIMER_EXACT_SCORE, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
