@@ -150,13 +150,15 @@ __device__ __forceinline__ double floor_quotient(double v, double res, double in
 #endif
 
 // grid-build workspace: 256-byte header, [16-bit cells: the 65536-entry quantiser threshold table,] then per
-// target one occupancy byte per 64x64 tile and one 4-byte list slot per tile (no hit raster: the blur gathers a
-// tile's hits from the point list)
+// target one occupancy byte per 64x64 tile, one 4-byte list slot per tile and GRID_WS_MASK_WORDS words of LINE MASKS per
+// list slot: which 128-byte lines of the matcher's tiled planes the blur wrote inside the tile (the next rebuild clears
+// those and no others -- two thirds of a listed tile's lines hold nothing)
 constexpr int64_t GRID_WS_HEADER = 256;
 constexpr int64_t GRID_WS_THR16 = 65536 * 4;
+constexpr int GRID_WS_MASK_WORDS = 5;  // 32 lines of the first copy of the 8-bit plane, 40 of the shifted copy, 64 of the 16-bit copy
 inline int64_t grid_ws_per_target(int32_t S) {
   const int64_t tiles = (S + 63) / 64;
-  return 5 * tiles * tiles;
+  return (5 + 4 * GRID_WS_MASK_WORDS) * tiles * tiles;
 }
 // bytes per skip-map row: one bit per aligned dword column, whole 8-byte words
 __host__ __device__ constexpr int32_t skip_pitch(int32_t pitch) { return ((pitch / 4 + 63) / 64) * 8; }

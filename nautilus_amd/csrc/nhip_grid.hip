@@ -161,7 +161,11 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
                                                         const uint32_t *__restrict__ thr16, int64_t hi_offset,
                                                         int32_t hi_tpr, int64_t hi_copy_bytes, int32_t t16_tpr,
                                                         int32_t n_scans, int64_t hits_offset, int32_t hits_pitch,
-                                                        int32_t has_image) {
+                                                        int32_t has_image, uint32_t *__restrict__ masks) {
+  // masks: null, or GRID_WS_MASK_WORDS words per list entry -- the lines of the tiled planes this build writes inside the
+  // entry's tile (geometries whose tiles start on line boundaries: pad a multiple of 16), for the next rebuild's clear
+  __shared__ uint32_t sMask[GRID_WS_MASK_WORDS];
+  __shared__ unsigned long long sBal[2][TILE / 4];  // per four rows of the tile: lanes = (row & 3) * 16 + group of four columns
   __shared__ uint32_t sA[TILE][TILE + 1];
   __shared__ uint16_t sHits[MAX_TILE_HITS];
   __shared__ uint32_t sSeen[(TH_MAX * TH_MAX + 31) / 32];  // one bit per neighbourhood cell: a cell is a hit once
@@ -181,6 +185,11 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
     for (int i = threadIdx.x; i < TILE * (TILE + 1); i += 256) (&sA[0][0])[i] = 0u;
     for (int i = threadIdx.x; i < (TH_MAX * TH_MAX + 31) / 32; i += 256) sSeen[i] = 0u;
     if (threadIdx.x == 0) sNH = 0;
+    if (threadIdx.x < GRID_WS_MASK_WORDS) {
+      sMask[threadIdx.x] = 0u;
+      if (masks) masks[(size_t)e * GRID_WS_MASK_WORDS + threadIdx.x] = 0u;  // (an entry without hits writes nothing)
+    }
+    if (threadIdx.x < 2 * (TILE / 4)) (&sBal[0][0])[threadIdx.x] = 0ull;
     __syncthreads();
     // hits of the neighbourhood -> list (row, column packed; TH <= 96): every point of the target scan
     // whose cell falls inside, each cell once
@@ -319,6 +328,18 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
             else reinterpret_cast<uint16_t *>(dst)[b] = (uint16_t)qv[b];
           }
       }
+      if (masks) {
+        // which of the wave's groups (four rows x 16 groups of four columns) store anything, and which store high bytes:
+        // two ballots, kept per (wave, turn) = per four rows; the entry's line masks are formed from them after the loop
+        bool hi_any = false;
+        for (int b = 0; b < 4; b++)
+          if (c0 + c4 + b < S && (CB == 2 ? qv[b] >> 8 : qv[b])) hi_any = true;
+        const unsigned long long act = __ballot(1), hib = __ballot(hi_any);  // (lanes still here: a non-zero group inside the raster)
+        if ((int)(threadIdx.x & 63u) == __ffsll((long long)act) - 1) {
+          sBal[0][r >> 2] = act;
+          sBal[1][r >> 2] = hib;
+        }
+      }
       if (CB == 2) {  // the matcher's tiled copy of the 16-bit cells (a 4-aligned group of four lies in one tile row)
         uint8_t *td = g + hi_offset + 2 * hi_copy_bytes + t16_tiled((uint32_t)(r0 + r + pad), (uint32_t)(c0 + c4 + pad), (uint32_t)t16_tpr);
         if (c0 + c4 + 3 < S) {
@@ -339,6 +360,40 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
           *reinterpret_cast<uint32_t *>(g + hi_offset + hi_tiled(hr, hc, 1u, (uint32_t)hi_tpr, (uint32_t)hi_copy_bytes)) = h;
         }
       }
+    }
+    if (masks) {
+      // one thread per line of the tile: 32 of the first copy of the 8-bit plane (row of eight lr, 16-byte column k: groups
+      // 4k .. 4k + 3 of the rows' ballots), 40 of the copy shifted by 8 columns (groups 4k - 2 .. 4k + 1), 64 of the
+      // 16-bit copy (8-cell column k: groups 2k, 2k + 1)
+      __syncthreads();
+      if (threadIdx.x < 136) {
+        const uint32_t t = threadIdx.x;
+        uint32_t lr, word, bit;
+        unsigned long long pat;  // the groups of one row; the ballot holds four rows, 16 lanes apart
+        bool hi = true;
+        if (t < 32) {
+          lr = t >> 2;
+          pat = 0xFull << (4u * (t & 3u));
+          word = 0u; bit = t;
+        } else if (t < 72) {
+          const uint32_t b1 = t - 32u, k = b1 % 5u;
+          lr = b1 / 5u;
+          pat = k == 0u ? 0x3ull : (k == 4u ? 0xC000ull : 0xFull << (4u * k - 2u));
+          word = 1u + (b1 >> 5); bit = b1 & 31u;
+        } else {
+          const uint32_t b2 = t - 72u;
+          lr = b2 >> 3;
+          pat = 0x3ull << (2u * (b2 & 7u));
+          word = 3u + (b2 >> 5); bit = b2 & 31u;
+          hi = false;
+        }
+        pat |= pat << 16;
+        pat |= pat << 32;
+        const unsigned long long any = (sBal[hi ? 1 : 0][2u * lr] | sBal[hi ? 1 : 0][2u * lr + 1u]) & pat;
+        if (any && (hi || CB == 2)) atomicOr(&sMask[word], 1u << bit);
+      }
+      __syncthreads();
+      if (threadIdx.x < GRID_WS_MASK_WORDS) masks[(size_t)e * GRID_WS_MASK_WORDS + threadIdx.x] = sMask[threadIdx.x];
     }
   }
 }
@@ -707,7 +762,9 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
                                                          int64_t table_bytes, int64_t hi_offset, int32_t hi_tpr,
                                                          int64_t hi_copy_bytes, int32_t t16_tpr, int64_t p4_offset,
                                                          int32_t p4_pitch, int64_t p8_offset, int32_t p8_pitch,
-                                                         int64_t hits_offset, int64_t hits_bytes, int32_t has_image) {
+                                                         int64_t hits_offset, int64_t hits_bytes, int32_t has_image,
+                                                         const uint32_t *__restrict__ masks) {
+  // masks: null, or per list entry the lines of the tiled planes the previous build wrote inside the tile (grid_blur_kernel)
   const uint64_t tag = *reinterpret_cast<const uint64_t *>(header + 2);
   if (tag != expect) {  // unknown contents: everything goes (16-byte stores, grid-stride)
     uint4 *p = reinterpret_cast<uint4 *>(grids);
@@ -748,21 +805,31 @@ __global__ __launch_bounds__(256) void grid_clear_kernel(const int32_t *__restri
       const uint32_t tpr = (uint32_t)hi_tpr, cpb = (uint32_t)hi_copy_bytes, cc = (uint32_t)(c0 + pad);
       if (((c0 + pad) & 15) == 0) {
         const int per = cb == 2 ? 17 : 9;  // (8-bit cells: no tiled 16-bit copy)
+        // the lines the previous build wrote (all of them without masks): bits 0..31 first copy (row of eight x 4 + column),
+        // 32..71 shifted copy (x 5), 96..159 16-bit copy (x 8)
+        uint32_t mk[GRID_WS_MASK_WORDS];
+#pragma unroll
+        for (int k = 0; k < GRID_WS_MASK_WORDS; k++) mk[k] = masks ? masks[(size_t)e * GRID_WS_MASK_WORDS + k] : 0xffffffffu;
         for (int i = threadIdx.x; i < TILE * per; i += 256) {
           // (eight consecutive threads take the eight rows of one tile = the eight 16-byte pieces of one 128-byte line:
           //  row-by-row order sent every line to memory as eight partial writes)
           const int r = 8 * (i / (8 * per)) + (i & 7), d = (i >> 3) % per;
           if (r0 + r >= S) continue;
-          const uint32_t row = (uint32_t)(r0 + r + pad);
+          const uint32_t row = (uint32_t)(r0 + r + pad), lr = (uint32_t)r >> 3;
           if (d < 4) {
+            if (!((mk[0] >> (lr * 4u + (uint32_t)d)) & 1u)) continue;
             *reinterpret_cast<uint4 *>(hp + hi_tiled(row, cc + 16u * (uint32_t)d, 0u, tpr, cpb)) = make_uint4(0, 0, 0, 0);
           } else if (d < 9) {
             const int e = d - 4;  // columns cc + 16 e - 8 ... of the plain plane = a tile row of the shifted copy
+            const uint32_t b1 = lr * 5u + (uint32_t)e;
+            if (!(((b1 < 32u ? mk[1] : mk[2]) >> (b1 & 31u)) & 1u)) continue;
             uint8_t *q = hp + hi_tiled(row, cc + 16u * (uint32_t)e, 1u, tpr, cpb) - 8;
             if (e == 0) *reinterpret_cast<uint2 *>(q + 8) = make_uint2(0, 0);
             else if (e == 4) *reinterpret_cast<uint2 *>(q) = make_uint2(0, 0);
             else *reinterpret_cast<uint4 *>(q) = make_uint4(0, 0, 0, 0);
           } else {
+            const uint32_t b2 = lr * 8u + (uint32_t)(d - 9);
+            if (!(((b2 < 32u ? mk[3] : mk[4]) >> (b2 & 31u)) & 1u)) continue;
             *reinterpret_cast<uint4 *>(hp + 2 * hi_copy_bytes + t16_tiled(row, cc + 8u * (uint32_t)(d - 9), (uint32_t)t16_tpr)) = make_uint4(0, 0, 0, 0);
           }
         }
@@ -863,6 +930,8 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_sca
     uint8_t *occ = base + fixed;
     const size_t occ_bytes = (size_t)n * tiles * tiles;
     int32_t *list = reinterpret_cast<int32_t *>(occ + ((occ_bytes + 3) & ~(size_t)3));
+    // line masks behind the list, for geometries whose tiles start on line boundaries of the tiled planes
+    uint32_t *masks = L.pad % 16 == 0 ? reinterpret_cast<uint32_t *>(list + (size_t)n * tiles * tiles) : nullptr;
     uint8_t *g = d_grids + (size_t)t0 * L.slot_bytes;
     timer_begin(NHIP_TIMER_GRID_CLEAR, s);
     if (incremental && one_pass) {
@@ -881,7 +950,7 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_sca
 #define NHIP_CLEAR(W, WH)                                                                                             \
   hipLaunchKernelGGL((grid_clear_kernel<W, WH>), dim3(4096), dim3(256), 0, s, count, tag, list, g, n, L.S, tiles, L.pad, \
                      L.pitch, L.cb, L.slot_bytes, to, tb, hio, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr, p4o, p4p, \
-                     L.grid_bytes + L.skip_bytes, L.pool_pitch, hio + L.hi_bytes, L.hits_bytes, L.has_image ? 1 : 0)
+                     L.grid_bytes + L.skip_bytes, L.pool_pitch, hio + L.hi_bytes, L.hits_bytes, L.has_image ? 1 : 0, masks)
       if (w == 16 && wh == 16) NHIP_CLEAR(16, 16);
       else if (w == 16) NHIP_CLEAR(16, 4);
       else if (w == 8) NHIP_CLEAR(8, 4);
@@ -915,13 +984,13 @@ int launch_grid_build(const float *d_xy, const int32_t *d_offsets, int32_t n_sca
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
                          L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, 0, n_scans,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch, L.has_image ? 1 : 0);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch, L.has_image ? 1 : 0, masks);
     else
       hipLaunchKernelGGL(grid_blur_kernel<2>, dim3(blur_blocks), dim3(256), 0, s,
                          reinterpret_cast<const float2 *>(d_xy), d_offsets, d_target_ids, (int32_t)t0, count, list,
                          tiles, g, L.S, L.pad, L.pitch, L.slot_bytes, L.R, spec->res, inv_res, kt, d_thr16,
                          L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes, L.hi_tpr, L.hi_copy_bytes, L.t16_tpr, n_scans,
-                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch, L.has_image ? 1 : 0);
+                         L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes, L.hits_pitch, L.has_image ? 1 : 0, masks);
     // gridDim.z is limited to 65,535: the targets of a chunk go in slices.  (The skip map serves the kernels that
     // perform every add; the branch-and-bound matcher never reads it, so 16-bit grids -- its product path -- carry
     // one only when the spec asks.)
