@@ -171,6 +171,7 @@ def run(n_scans=320, window=10, seed=20201114, drift_t=0.02, drift_th_deg=0.3, v
     # bookkeeping: Ceres does it inside Solve); GetRelevantPosesForHITL's point selection (host-side HITL curation);
     # and what is left: the harness (ground-truth comparisons, the synthetic HITL message).
     out["marshal_s"] = posegraph.CLOCK["marshal"]
+    out["path_setup_s"] = posegraph.CLOCK["path_setup"]  # (of the path seconds: uploads + device allocations of the per-pass batches)
     out["host_assembly_s"] = posegraph.CLOCK["assemble"]
     out["hitl_select_s"] = posegraph.CLOCK["hitl_select"]
     out["harness_s"] = out["host_other_s"] - out["marshal_s"] - out["host_assembly_s"] - out["hitl_select_s"]

@@ -38,7 +38,7 @@ from .correspondence import IcpBatch, window_pairs
 # turning their outputs into what the caller asked for; "assemble" = the sparse system's assembly from the per-block
 # normal equations and factor Jacobians (numpy: what Ceres does inside its solve, like "host_solver"); "hitl_select" =
 # GetRelevantPosesForHITL's point selection (host-side HITL curation, solver.cc:479-513).
-CLOCK = {"path": 0.0, "host_solver": 0.0, "marshal": 0.0, "assemble": 0.0, "hitl_select": 0.0}
+CLOCK = {"path": 0.0, "host_solver": 0.0, "marshal": 0.0, "assemble": 0.0, "hitl_select": 0.0, "path_setup": 0.0}
 
 
 def clock_reset():
@@ -68,9 +68,17 @@ class HipBackend:
     def __init__(self, device="cuda:0"):
         import torch
         self.torch, self.dev, self.lib = torch, torch.device(device), _lib.load()
+        from .correspondence import DeviceArena
+        self.arena = DeviceArena()  # the clouds and the work buffers of the ICP batches, kept across problem builds
 
     def icp(self, xy, normals, offsets, block_src, block_tgt, outlier_threshold):
-        return _HipIcp(IcpBatch(xy, normals, offsets, block_src, block_tgt, str(self.dev), outlier_threshold))
+        return _HipIcp(IcpBatch(xy, normals, offsets, block_src, block_tgt, str(self.dev), outlier_threshold, arena=self.arena))
+
+    def reserve_icp(self, offsets, window):
+        """Work buffers for the largest problem of a growing-window solve (all (i, j), j in [i - window, i)): allocated once."""
+        off = np.asarray(offsets, dtype=np.int64)
+        per = np.minimum(np.arange(len(off) - 1), int(window))  # blocks whose source is scan i
+        self.arena.reserve(self.torch, self.dev, int((np.diff(off) * per).sum()), int(per.sum()))
 
     def odometry(self, pose_i, pose_j, t_odom, r_odom, tw, rw, poses):
         """OdometryResidual blocks at `poses` (n, 3): residuals (F, 3), Jacobians (F, 3, 3) x 2."""
@@ -260,7 +268,7 @@ class PoseGraph:
         self.backend = backend if backend is not None else HipBackend(device)
         with clocked("marshal"):
             bs, bt = window_pairs(self.n, window)
-        with clocked("path"):  # (uploads of the clouds, block lists)
+        with clocked("path"), clocked("path_setup"):  # (uploads of the clouds and block lists, device allocations: part of "path")
             self.icp = self.backend.icp(xy, normals, offsets, bs, bt, outlier_threshold)
         self.odo = odometry_factors_from_poses(odom, tw=odom_weights[0], rw=odom_weights[1])
         self.lc = None
@@ -414,6 +422,9 @@ def solve_growing_window(xy, normals, offsets, odom, window_min=1, window_max=10
     estimate -- and solved.  Returns (PoseGraph of the last pass, poses)."""
     poses = np.array(odom if initial is None else initial, dtype=np.float64)
     backend = backend if backend is not None else HipBackend(device)
+    if hasattr(backend, "reserve_icp"):
+        with clocked("path"), clocked("path_setup"):
+            backend.reserve_icp(offsets, window_max)
     pg = None
     for w in range(window_min, window_max + 1):
         pg = PoseGraph(xy, normals, offsets, odom, window=w, kind=kind, outlier_threshold=outlier_threshold,
