@@ -146,7 +146,8 @@ typedef struct nhip_grid_layout {
 int nhip_grid_layout(const nhip_grid_spec_t *spec, nhip_grid_layout_t *out);
 /* bytes the caller must allocate for n grids (n*slot_bytes + 256 B read slack) */
 int64_t nhip_grids_bytes(const nhip_grid_spec_t *spec, int64_t n_grids);
-/* workspace for nhip_grid_build_dev processing `chunk` targets at a time */
+/* workspace for nhip_grid_build_dev processing `chunk` targets at a time: per target one occupancy byte, one list slot and
+ * 20 bytes of line masks per 64 x 64 tile (what nhip_grid_rebuild_dev clears is read from there), + the 16-bit quantiser's table */
 int64_t nhip_grid_workspace_bytes(const nhip_grid_spec_t *spec, int32_t chunk);
 /* integer blur taps (2R+1 values) and the quantiser threshold table: 256 entries for 8-bit cells,
  * 65536 for 16-bit cells (thresholds[k] = smallest integer blur sum whose quantised value is >= k) */
