@@ -263,3 +263,46 @@ def test_search_feeds_residuals_and_normal_equations(gpu, small_bag):
     batch.set_poses(poses + step.reshape(N, 3))
     cost1 = batch.normal_equations(_lib.NHIP_LIDAR_POINT).cpu().numpy()[:, 27].sum()
     assert cost1 < cost0
+
+
+@pytest.mark.gpu
+def test_batches_of_one_backend_share_a_device_arena(gpu, small_bag):
+    """A solver that rebuilds its problem per window pass (OptimizeOverGrowingWindow, solver.cc:339-355) builds thirty
+    IcpBatch objects in a run; with one DeviceArena they upload the clouds once and share their work buffers.  Same
+    numbers as private buffers, the clouds' device copies are the same tensors, the buffers do not grow for a smaller
+    problem -- and a batch whose arena a NEWER batch has bound takes it back when it is used again (its correspondences
+    searched anew at its poses) instead of reading the other batch's rows."""
+    from nautilus_amd.correspondence import DeviceArena, IcpBatch, window_pairs
+    import torch
+    poses = small_bag.odom.copy()
+    xy, off = csm.pack_scans(small_bag.scans)
+    nrm = _normals_table(small_bag)
+    arena = DeviceArena()
+    arena.reserve(torch, torch.device("cuda:0"), int((np.diff(off) * np.minimum(np.arange(small_bag.n_scans), 4)).sum()),
+                  int(np.minimum(np.arange(small_bag.n_scans), 4).sum()))
+    ptr_padded = arena.buf["padded"].data_ptr()
+    want = {}
+    for w in (4, 2):  # (the larger problem first, as a reserved arena sees it)
+        bs, bt = window_pairs(small_bag.n_scans, w)
+        plain = IcpBatch(xy, nrm, off, bs, bt)
+        plain.set_poses(poses)
+        plain.search()
+        want[w] = (plain.correspondences()[0].copy(), plain.normal_equations(_lib.NHIP_LIDAR_NORMAL).cpu().numpy().copy())
+    batches = {}
+    for w in (4, 2):
+        bs, bt = window_pairs(small_bag.n_scans, w)
+        b = batches[w] = IcpBatch(xy, nrm, off, bs, bt, arena=arena)
+        b.set_poses(poses)
+        b.search()
+        assert np.array_equal(b.correspondences()[0], want[w][0])
+        assert np.array_equal(b.normal_equations(_lib.NHIP_LIDAR_NORMAL).cpu().numpy(), want[w][1])
+    assert batches[4].d_xy.data_ptr() == batches[2].d_xy.data_ptr(), "the clouds are uploaded once per arena"
+    assert arena.buf["padded"].data_ptr() == ptr_padded, "reserved for the largest problem: no buffer grew"
+    assert arena.owner is batches[2]
+    # the older batch, used again: takes the arena back, uploads its block lists again, searches anew
+    got = batches[4].normal_equations(_lib.NHIP_LIDAR_NORMAL).cpu().numpy()
+    assert arena.owner is batches[4]
+    assert np.array_equal(got, want[4][1])
+    assert np.array_equal(batches[4].correspondences()[0], want[4][0])
+    # ... and the newer one after that, likewise
+    assert np.array_equal(batches[2].normal_equations(_lib.NHIP_LIDAR_NORMAL).cpu().numpy(), want[2][1])
