@@ -158,7 +158,9 @@ class HipBackend:
         rot0 = np.empty((n, 2))
         check(lib.nhip_csm_rot0(_lib.ptr(np.ascontiguousarray(theta0, dtype=np.float64)), None, n, _lib.ptr(rot0)))
         d_rot0, d_delta = t(rot0), t(csm.delta_table(search))
-        d_grids = torch.zeros(lib.nhip_grids_bytes(C.byref(spec), len(ids)), dtype=torch.uint8, device=dev)
+        # (nhip_grid_build_dev zero-fills the slots itself; only the 256 bytes of read slack behind them are this caller's)
+        d_grids = torch.empty(lib.nhip_grids_bytes(C.byref(spec), len(ids)), dtype=torch.uint8, device=dev)
+        d_grids[-256:].zero_()
         ws_g = lib.nhip_grid_workspace_bytes(C.byref(spec), len(ids))
         d_ws_g = torch.empty(ws_g, dtype=torch.uint8, device=dev)
         ws_m = lib.nhip_csm_workspace_bytes(n)
