@@ -430,6 +430,12 @@ int nhip_scans_free(nhip_scans_t *scans);
 int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32_t n_targets,
                      const nhip_grid_spec_t *spec, nhip_grids_t **out);
 int nhip_grids_free(nhip_grids_t *grids);
+/* 1 when this handle's tables were built by an incremental REBUILD: nhip_grids_free hands the table buffer and its build
+ * workspace back to the device buffer pool together, contents known; while nobody else has taken either, the next
+ * nhip_grids_build of the same spec and target count takes the pair and clears what the previous build wrote (as
+ * nhip_grid_rebuild_dev does, the workspace's tag checked on the device) instead of zero-filling every slot.  Same
+ * tables, bit for bit.  0: a fresh allocation or a buffer of unknown contents, zero-filled (diagnostic). */
+int nhip_grids_was_rebuilt(const nhip_grids_t *grids);
 /* copy stored (padded) grid `slot` to host: layout.grid_bytes bytes (uint8 or uint16 cells) */
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out);
 /* copy the plane of high bytes of grid `slot` (16-bit cells) to host in plain row-major form: rows x hi_pitch bytes.

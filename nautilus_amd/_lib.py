@@ -109,6 +109,7 @@ PROTOTYPES = {
     "nhip_scans_free": (C.c_int, [_vp]),
     "nhip_grids_build": (C.c_int, [_vp, _vp, _i32, _P(GridSpec), _P(_vp)]),
     "nhip_grids_free": (C.c_int, [_vp]),
+    "nhip_grids_was_rebuilt": (C.c_int, [_vp]),
     "nhip_grids_download": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_skip_map": (C.c_int, [_vp, _i32, _vp]),
     "nhip_grids_download_hi_plane": (C.c_int, [_vp, _i32, _vp]),

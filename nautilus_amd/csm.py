@@ -110,6 +110,11 @@ class LikelihoodGrids:
         check(_lib.load().nhip_grids_build(scans._h, ptr(self.target_ids), self.target_ids.size,
                                            C.byref(spec), C.byref(self._h)))
 
+    def was_rebuilt(self):
+        """True when the tables were rebuilt into the buffers a released handle of the same shape left in the library's
+        device pool (nhip_grids_was_rebuilt): only what that build wrote was cleared, nothing was zero-filled."""
+        return bool(_lib.load().nhip_grids_was_rebuilt(self._h))
+
     def download(self, slot):
         """Stored (padded) grid as (rows, pitch / cell_bytes) uint8 or uint16 cells."""
         L = self.layout

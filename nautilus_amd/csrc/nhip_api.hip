@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <map>
 #include <memory>
+#include <atomic>
 #include <mutex>
 
 #include "nhip_common.h"
@@ -267,6 +268,11 @@ struct PoolEntry {
   void *p;
   size_t bytes;
   int device;
+  // A table buffer and the workspace of the build that filled it may come back TOGETHER with their contents known: both carry
+  // the key of that release (0: contents unknown) and a digest of (spec, targets, which of the two).  While both are still in
+  // the pool nobody has written to either, so a build of the same shape takes the pair and rebuilds incrementally -- it clears
+  // the lines the previous build wrote instead of zero-filling gigabytes (pool_take_pair).
+  uint64_t key = 0, meta = 0;
 };
 std::mutex g_pool_mu;
 std::vector<PoolEntry> &g_pool = *new std::vector<PoolEntry>();  // oldest first (never destroyed: see the drop-in cache below)
@@ -284,11 +290,13 @@ int current_device() {
 void *pool_take(size_t n, size_t *got) {
   const int dev = current_device();
   std::lock_guard<std::mutex> lock(g_pool_mu);
+  // best fit; a buffer whose contents are known (half of a kept pair, see PoolEntry) only when nothing else fits
   size_t best = g_pool.size();
-  for (size_t i = 0; i < g_pool.size(); i++)
-    if (g_pool[i].device == dev && g_pool[i].bytes >= n && g_pool[i].bytes <= 2 * n + (1u << 20) &&
-        (best == g_pool.size() || g_pool[i].bytes < g_pool[best].bytes))
-      best = i;
+  for (int keyed = 0; keyed < 2 && best == g_pool.size(); keyed++)
+    for (size_t i = 0; i < g_pool.size(); i++)
+      if (g_pool[i].device == dev && (g_pool[i].key != 0) == (keyed == 1) && g_pool[i].bytes >= n &&
+          g_pool[i].bytes <= 2 * n + (1u << 20) && (best == g_pool.size() || g_pool[i].bytes < g_pool[best].bytes))
+        best = i;
   if (best == g_pool.size()) return nullptr;
   void *p = g_pool[best].p;
   *got = g_pool[best].bytes;
@@ -296,11 +304,11 @@ void *pool_take(size_t n, size_t *got) {
   return p;
 }
 // true: the pool keeps the buffer; `evict` receives what it lets go of for it (freed by the caller, outside the lock)
-bool pool_put(void *p, size_t bytes, std::vector<void *> *evict) {
+bool pool_put(void *p, size_t bytes, std::vector<void *> *evict, uint64_t key = 0, uint64_t meta = 0) {
   const int dev = current_device();
   std::lock_guard<std::mutex> lock(g_pool_mu);
   if (dev < 0 || (int64_t)bytes > g_pool_cap) return false;
-  g_pool.push_back({p, bytes, dev});
+  g_pool.push_back({p, bytes, dev, key, meta});
   int64_t tot = 0;
   for (auto &e : g_pool) tot += (int64_t)e.bytes;
   while (!g_pool.empty() && (tot > g_pool_cap || g_pool.size() > POOL_MAX_ENTRIES)) {
@@ -310,6 +318,25 @@ bool pool_put(void *p, size_t bytes, std::vector<void *> *evict) {
   }
   return true;
 }
+// the two buffers of one keyed release (metas `meta_a`, `meta_b`), if both are still here
+bool pool_take_pair(uint64_t meta_a, uint64_t meta_b, size_t need_a, size_t need_b, void **pa, size_t *ba, void **pb, size_t *bb) {
+  const int dev = current_device();
+  std::lock_guard<std::mutex> lock(g_pool_mu);
+  for (size_t i = g_pool.size(); i-- > 0;) {  // (newest first)
+    if (g_pool[i].device != dev || g_pool[i].key == 0 || g_pool[i].meta != meta_a || g_pool[i].bytes < need_a) continue;
+    for (size_t j = 0; j < g_pool.size(); j++) {
+      if (j == i || g_pool[j].device != dev || g_pool[j].key != g_pool[i].key || g_pool[j].meta != meta_b || g_pool[j].bytes < need_b)
+        continue;
+      *pa = g_pool[i].p; *ba = g_pool[i].bytes;
+      *pb = g_pool[j].p; *bb = g_pool[j].bytes;
+      g_pool.erase(g_pool.begin() + (long)(i > j ? i : j));
+      g_pool.erase(g_pool.begin() + (long)(i > j ? j : i));
+      return true;
+    }
+  }
+  return false;
+}
+std::atomic<uint64_t> g_pool_key{1};
 void pool_drain(std::vector<void *> *out, int device /* -1: every device */) {
   std::lock_guard<std::mutex> lock(g_pool_mu);
   for (size_t i = 0; i < g_pool.size();)
@@ -352,15 +379,20 @@ struct DevBuf {
     bytes = n;
     return NHIP_OK;
   }
-  void free() {
+  void free(uint64_t key = 0, uint64_t meta = 0) {  // (key, meta: the contents stay known to the pool, see PoolEntry)
     if (p) {
       PhaseClock pc(PH_FREE);
       std::vector<void *> evict;
-      if (!pool_put(p, bytes, &evict)) (void)hipFree(p);
+      if (!pool_put(p, bytes, &evict, key, meta)) (void)hipFree(p);
       for (void *d : evict) (void)hipFree(d);
     }
     p = nullptr;
     bytes = 0;
+  }
+  void adopt(void *q, size_t n) {
+    free();
+    p = q;
+    bytes = n;
   }
   ~DevBuf() { free(); }
 };
@@ -376,6 +408,10 @@ struct nhip_scans {
 
 struct nhip_grids {
   nhip::DevBuf grids;
+  nhip::DevBuf ws;         // the build's workspace: its tile list and line masks describe what `grids` holds
+  uint64_t shape = 0;      // digest of (spec as built, targets): what a later build must equal to rebuild into these buffers
+  bool dirty = false;      // something besides the build wrote into `grids` (a late skip-map build): contents no longer the list's
+  bool rebuilt = false;    // this handle's build was an incremental rebuild into a kept pair
   nhip_grid_spec_t spec;
   nhip::GridLayout L;
   int32_t n = 0;
@@ -393,6 +429,15 @@ struct nhip_resid_batch {
 };
 
 using namespace nhip;
+
+// digest of what a table buffer's layout and build depend on: the spec as handed in, the number of targets
+static uint64_t grids_shape(const nhip_grid_spec_t *spec, int32_t n_targets) {
+  uint64_t h = 0xcbf29ce484222325ull;
+  const unsigned char *b = reinterpret_cast<const unsigned char *>(spec);
+  for (size_t i = 0; i < sizeof(*spec); i++) h = (h ^ b[i]) * 0x100000001b3ull;
+  for (int i = 0; i < 4; i++) h = (h ^ (uint64_t)((uint32_t)n_targets >> (8 * i) & 0xffu)) * 0x100000001b3ull;
+  return h >> 1;  // (the low bit is the pool's: which buffer of the pair)
+}
 
 extern "C" {
 
@@ -832,19 +877,33 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
   g->spec = *spec;
   g->L = L;
   g->n = n_targets;
-  DevBuf ids, ws;
-  const int32_t chunk = n_targets > 0 ? n_targets : 1;  // workspace is ~5 bytes per 64x64 tile: all targets in one pass
+  g->shape = grids_shape(spec, n_targets);
+  DevBuf ids;
+  DevBuf &ws = g->ws;
+  const int32_t chunk = n_targets > 0 ? n_targets : 1;  // workspace is ~25 bytes per 64x64 tile: all targets in one pass
   const int64_t ws_bytes = nhip_grid_workspace_bytes(spec, chunk);
-  if ((rc = g->grids.alloc((size_t)n_targets * L.slot_bytes + 256)) ||
-      (rc = ids.alloc(sizeof(int32_t) * (size_t)(n_targets > 0 ? n_targets : 1))) ||
-      (rc = ws.alloc((size_t)ws_bytes))) {
+  const size_t grid_bytes = (size_t)n_targets * L.slot_bytes + 256;
+  // the buffers of the last build of this shape, if a handle released them and nobody has touched them since: the build
+  // clears what that build wrote (its tile list and line masks are in the workspace, vouched for by a tag the clearing
+  // kernel checks on the device) instead of zero-filling the slots -- 1.3 ms per 1000 targets at 1200 x 1200
+  {
+    void *pg = nullptr, *pw = nullptr;
+    size_t bg = 0, bw = 0;
+    if (n_targets > 0 && pool_take_pair(g->shape << 1, (g->shape << 1) | 1u, grid_bytes, (size_t)ws_bytes, &pg, &bg, &pw, &bw)) {
+      g->grids.adopt(pg, bg);
+      ws.adopt(pw, bw);
+      g->rebuilt = true;
+    }
+  }
+  if ((!g->rebuilt && ((rc = g->grids.alloc(grid_bytes)) || (rc = ws.alloc((size_t)ws_bytes)))) ||
+      (rc = ids.alloc(sizeof(int32_t) * (size_t)(n_targets > 0 ? n_targets : 1)))) {
     delete g;
     return rc;
   }
-  hipError_t e;
+  hipError_t e = hipSuccess;
   {
     PhaseClock pc(PH_UPLOAD);
-    e = hipMemset(g->grids.p, 0, (size_t)n_targets * L.slot_bytes + 256);  // (what was asked for: a pooled buffer may be larger)
+    if (!g->rebuilt) e = hipMemset(g->grids.p, 0, grid_bytes);  // (what was asked for: a pooled buffer may be larger)
     if (e == hipSuccess && n_targets)
       e = hipMemcpy(ids.p, target_ids, sizeof(int32_t) * (size_t)n_targets, hipMemcpyHostToDevice);
   }
@@ -858,7 +917,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
       rc = launch_grid_build(static_cast<const float *>(scans->xy.p),
                              static_cast<const int32_t *>(scans->offsets.p), scans->n_scans,
                              static_cast<const int32_t *>(ids.p), n_targets, spec, L,
-                             static_cast<uint8_t *>(g->grids.p), ws.p, ws_bytes, nullptr);
+                             static_cast<uint8_t *>(g->grids.p), ws.p, ws_bytes, nullptr, g->rebuilt);
     }
     if (rc == NHIP_OK) {
       PhaseClock pc(PH_WAIT);
@@ -866,6 +925,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
       if (e != hipSuccess) rc = hip_fail(e, "grids_build sync", __FILE__, __LINE__);
     }
     if (rc) {
+      g->dirty = true;  // (a failed build: contents unknown)
       delete g;
       return rc;
     }
@@ -876,9 +936,17 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
 
 int nhip_grids_free(nhip_grids_t *grids) {
   phases_reset();
+  if (grids && grids->n > 0 && !grids->dirty && grids->grids.p && grids->ws.p) {
+    // the pair goes back with its contents known (see PoolEntry): the next build of this shape may rebuild into it
+    const uint64_t key = g_pool_key.fetch_add(1);
+    grids->grids.free(key, grids->shape << 1);
+    grids->ws.free(key, (grids->shape << 1) | 1u);
+  }
   delete grids;
   return NHIP_OK;
 }
+
+int nhip_grids_was_rebuilt(const nhip_grids_t *grids) { return grids && grids->rebuilt ? 1 : 0; }
 
 int nhip_grids_download(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download: bad arguments");
@@ -968,6 +1036,7 @@ static int ensure_skip_maps(const nhip_grids_t *grids, const nhip_search_t *sear
   if (!csm_takes_exhaustive(g->L, search)) return NHIP_OK;
   std::lock_guard<std::mutex> lock(g->mu);
   if (g->spec.flags & NHIP_GRID_SKIP_MAP) return NHIP_OK;
+  g->dirty = true;  // (maps the build's tile list does not know of)
   int rc = launch_skipmap_build(static_cast<uint8_t *>(g->grids.p), g->n, g->L, nullptr);
   if (rc) return rc;
   NHIP_TRY_HIP(hipStreamSynchronize(nullptr));
