@@ -262,7 +262,8 @@ static void phases_reset() {
 // caching allocator) had released 130 GB; round 4's bench saw one host-buffer call in five take 4 s.  So released buffers
 // are kept, per device, up to a byte cap (nhip_device_pool_configure; least recently released out first) and handed to
 // the next allocation they fit (at most twice the size asked for): a loop of build / match / free touches the driver's
-// allocator once.  Contents are never assumed: every user initialises what it reads.
+// allocator once.  Contents are never assumed -- every user initialises what it reads -- with one exception, stated on the
+// entries themselves: a table buffer and its build workspace released together (PoolEntry::key).
 namespace {
 struct PoolEntry {
   void *p;
