@@ -241,31 +241,52 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
       }
     }
     __syncthreads();
-    // quantise; each thread produces 4 consecutive columns of one row
-    for (int i = threadIdx.x; i < TILE * (TILE / 4); i += 256) {
+    // quantise; each thread produces 4 consecutive columns of one row, in four turns
+    // 16-bit cells.  The thresholds grow exponentially: a first guess from ln(a) is the answer except next to a threshold, and
+    // the table settles it exactly.  The guesses of the eight cells of TWO turns first, then their table entries (thr[g],
+    // thr[g + 1]), all in flight at once: two trips to the L2-resident table per thread and tile (round 4 made one per turn;
+    // the cell-by-cell form before it two to four dependent ones per cell; all four turns at once need 171 registers).
+    constexpr int TURNS = TILE * (TILE / 4) / 256, GROUP = 2;
+    static_assert(TURNS % GROUP == 0, "whole groups of turns");
+#pragma unroll 1
+    for (int t0 = 0; t0 < TURNS; t0 += GROUP) {
+    uint32_t avT[GROUP][4], gvT[GROUP][4];
+    uint2 tvT[GROUP][4];
+    if (CB == 2) {
+#pragma unroll
+      for (int t = 0; t < GROUP; t++) {
+        const int i = threadIdx.x + 256 * (t0 + t), r = i / (TILE / 4), c4 = (i % (TILE / 4)) * 4;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          avT[t][b] = r0 + r < S ? sA[r][c4 + b] : 0u;
+          const float gf = tab.q16_a * __logf((float)(avT[t][b] ? avT[t][b] : 1u)) + tab.q16_b;
+          gvT[t][b] = gf <= 0.f ? 0u : (gf >= 65534.f ? 65534u : (uint32_t)gf);
+        }
+      }
+#pragma unroll
+      for (int t = 0; t < GROUP; t++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+          // (cells without a sum load nothing)
+          tvT[t][b] = make_uint2(0u, 0u);
+          if (avT[t][b]) tvT[t][b] = make_uint2(thr16[gvT[t][b]], thr16[gvT[t][b] + 1u]);
+        }
+    }
+#pragma unroll
+    for (int t = 0; t < GROUP; t++) {
+      const int i = threadIdx.x + 256 * (t0 + t);
       const int r = i / (TILE / 4), c4 = (i % (TILE / 4)) * 4;
       if (r0 + r >= S) continue;
       uint32_t qv[4];
       uint32_t any = 0;
       if (CB == 2) {
-        // 16-bit cells.  The thresholds grow exponentially: a first guess from ln(a) is the answer except next to a
-        // threshold, and the table settles it exactly.  The four cells' guesses first, then their table entries
-        // (thr[g], thr[g + 1]: one 8-byte load each, all four in flight) -- one trip to the L2-resident table per
-        // thread where the cell-by-cell form made two to four dependent ones per cell (0.2 of the build's 1.0 ms).
         uint32_t av[4], gv[4];
         uint2 tv[4];
 #pragma unroll
         for (int b = 0; b < 4; b++) {
-          av[b] = sA[r][c4 + b];
-          const float gf = tab.q16_a * __logf((float)(av[b] ? av[b] : 1u)) + tab.q16_b;
-          const uint32_t gq = gf <= 0.f ? 0u : (gf >= 65534.f ? 65534u : (uint32_t)gf);
-          gv[b] = gq;
-        }
-#pragma unroll
-        for (int b = 0; b < 4; b++) {
-          // (cells without a sum load nothing)
-          tv[b] = make_uint2(0u, 0u);
-          if (av[b]) tv[b] = make_uint2(thr16[gv[b]], thr16[gv[b] + 1u]);
+          av[b] = avT[t][b];
+          gv[b] = gvT[t][b];
+          tv[b] = tvT[t][b];
         }
 #pragma unroll
         for (int b = 0; b < 4; b++) {
@@ -361,6 +382,7 @@ __global__ __launch_bounds__(256) void grid_blur_kernel(const float2 *__restrict
         }
       }
     }
+    }  // (groups of turns)
     if (masks) {
       // one thread per line of the tile: 32 of the first copy of the 8-bit plane (row of eight lr, 16-byte column k: groups
       // 4k .. 4k + 3 of the rows' ballots), 40 of the copy shifted by 8 columns (groups 4k - 2 .. 4k + 1), 64 of the
