@@ -1594,9 +1594,15 @@ def bench_config4_loop(n_scans, with_cpu, sample_blocks=1500, sample_pairs=160):
     # (residuals + both Jacobians of the block rows by Jet<6> autodiff under OpenMP -- what Ceres' Evaluate() does with the
     #  reference's functors; the oracle backend's own normal_equations() then reduces them to 6 x 6 blocks in numpy, on one
     #  thread, which is 30x the evaluation and belongs to the solver's side of the reference: not timed)
-    t0 = time.perf_counter()
+    # (one evaluation of the sample is 0.02-0.09 s -- thread start-up and a cold cache are a visible part of it, and round 4's
+    #  and round 5's single timings differed 4x: the median of seven evaluations after one untimed)
     O.lidar_batch(_lib.NHIP_LIDAR_NORMAL, icp.corr, icp.boff, icp.block_src, icp.block_tgt, icp.poses, True, cpu.n_threads)
-    t_neq = time.perf_counter() - t0
+    t_runs = []
+    for _ in range(7):
+        t0 = time.perf_counter()
+        O.lidar_batch(_lib.NHIP_LIDAR_NORMAL, icp.corr, icp.boff, icp.block_src, icp.block_tgt, icp.poses, True, cpu.n_threads)
+        t_runs.append(time.perf_counter() - t0)
+    t_neq = float(np.median(t_runs))
     s_block, s_row = t_search / len(pick), t_neq / max(icp.n_corr, 1)
     t0 = time.perf_counter()
     cpu.scatter_scores(xy, off)
