@@ -477,6 +477,173 @@ def onchip_roofline(n_pairs, avg_ms, cell_bits, kernel="bnb"):
     return out
 
 
+# ------------------------------------------------------------------------------------------ the line
+def ideal_matcher(wl, n_pairs, cell_bits):
+    """profiles/ideal_matcher.json (tools/ideal_matcher.py): what an ideally-pruned matcher -- one
+    that knew every pair's final best sum before it started -- would cost on this chip for the profiled pair list: the
+    bounds of the rotations that still hold a block reaching that sum at the vector-instruction peak, plus the wave-level
+    loads of the candidate blocks reaching it at the gather cost the microbenchmark measured.  None unless this run's
+    pair list is the one the file was computed on."""
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "ideal_matcher.json")))
+    except Exception:
+        return None
+    w = d.get("workload") or {}
+    if not (wl.mode == w.get("mode") and n_pairs == w.get("pairs") and wl.per_target == w.get("per_target")
+            and cell_bits == w.get("cell_bits")):
+        return None
+    return d
+
+
+def matcher_roofline(cell_bits, split, avg_ms, launches, n_pairs, matches, prof, matcher, oc, traffic, parts, wl):
+    """The matcher as a whole under FIXED keys (the kernel is not chosen by which of its two launches happened to be
+    longer): frac = ideal_ms / avg_launch_ms, achieved / peak in pairs/s through the matcher's kernels.  The unit
+    fractions of the kernels (vector-instruction issue, vector-memory address unit, L1 lookups, HBM) are other_ceilings."""
+    cb = cell_bits // 8
+    ideal = ideal_matcher(wl, n_pairs, cell_bits)
+    ideal_ms = ideal["ideal_ms"] if ideal else None
+    r = {"bound": "onchip-model",
+         "kernel": ("csm_bnb_kernel<%d, true, true, true> + csm_bnb_cand_kernel<%d>" % (cb, cb)) if split
+                   else "csm_bnb_kernel<%d, true, true, false>" % cb,
+         "avg_launch_ms": avg_ms, "launches": launches,
+         "achieved": n_pairs / (avg_ms * 1e-3) if avg_ms else None,
+         "peak": n_pairs / (ideal_ms * 1e-3) if ideal_ms else None,
+         "unit": "pairs/s through the matcher's kernels; peak = an ideally-pruned matcher (ideal_ms)",
+         "frac": ideal_ms / avg_ms if ideal_ms and avg_ms else None,
+         "ideal_ms": ideal_ms,
+         "ideal_ms_bounds": ideal["ideal_ms_bounds"] if ideal else None,
+         "ideal_ms_candidates": ideal["ideal_ms_candidates"] if ideal else None,
+         "traffic": None, "stale": prof["stale"]}
+    oth = {}
+    if split:
+        bounds_avg, cand_avg, rates_b, rates_c, tb, tc = parts
+        r["traffic"] = (tb + tc) if tb and tc else None
+        oth = {"bounds_ms": bounds_avg, "candidates_ms": cand_avg,
+               "bounds_valu_frac": rates_b.get("valu_frac") if rates_b else None,
+               "bounds_waves_waiting_frac": rates_b.get("wave_wait_frac") if rates_b else None,
+               "candidates_ta_busy_frac": rates_c.get("ta_busy_frac") if rates_c else None,
+               "candidates_l1_lookups_per_clk_per_cu": rates_c.get("l1_tag_frac") if rates_c else None,
+               "candidates_valu_frac": rates_c.get("valu_frac") if rates_c else None,
+               "candidates_l2_miss_frac": rates_c.get("l2_miss_frac") if rates_c else None,
+               "valu_frac_both_kernels": oc["valu_frac"] if oc else None}
+    else:
+        r["traffic"] = traffic
+        oth = {"valu_frac": oc["valu_frac"] if oc else None, "l1_lookups_per_clk_per_cu": oc.get("l1_tag_frac") if oc else None,
+               "waves_waiting_frac": oc.get("wave_wait_frac") if oc else None}
+    oth["hbm_traffic_frac"] = (r["traffic"] / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if r["traffic"] and avg_ms else None
+    r["other_ceilings"] = oth
+    r["matcher"] = matcher
+    r["profile"] = prof
+    r["ideal_model"] = ideal
+    r["note"] = ("frac = ideal_ms / avg_launch_ms.  ideal_ms (profiles/ideal_matcher.json, tools/ideal_matcher.py): the pair "
+                 "list's rotations / candidate blocks whose bound reaches the pair's FINAL best sum, priced at the vector-"
+                 "instruction peak (bounds) and at the measured cost of a wave-level gather (candidates, "
+                 "profiles/r05_ubench_gather.txt).  Counters per launch from profiles/traffic.json (null when taken from other "
+                 "kernel sources or another pair list); launch time measured live with HIP events on the launch stream")
+    return r
+
+
+COMPACT_LIMIT = 4096  # bytes: BENCH_r05.json's `parsed` was null on a 22 KB line
+
+
+def _round_floats(x, sig=6):
+    if isinstance(x, float):
+        if x != x or x in (float("inf"), float("-inf")):
+            return None
+        return float("%.*g" % (sig, x))
+    if isinstance(x, dict):
+        return {k: _round_floats(v, sig) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return [_round_floats(v, sig) for v in x]
+    if isinstance(x, (np.floating,)):
+        return _round_floats(float(x), sig)
+    if isinstance(x, (np.integer,)):
+        return int(x)
+    if isinstance(x, (np.bool_,)):
+        return bool(x)
+    return x
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d}
+
+
+def compact_line(out, details_path=None):
+    """The ONE stdout line: headline, config, roofline, cpu_baseline, kernel milliseconds, the parity summary and (N > 1)
+    the same-workload scaling fields -- scalars only, below COMPACT_LIMIT bytes.  Everything else (secondary legs, notes,
+    per-rank tables, per-run host phases) is in the details file the line names.  tests/test_bench_line.py builds a line
+    through this function and checks size, keys and strict JSON."""
+    c = _pick(out, ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                    "vs_baseline", "dtype", "data"))
+    cfg = out.get("config") or {}
+    c["config"] = _pick(cfg, ("workload", "mode", "pairs_total", "scans_total", "lattice", "grid", "cell_bytes",
+                              "rccl_world_size", "collective_backend", "collective"))
+    if isinstance(c["config"].get("workload"), str) and len(c["config"]["workload"]) > 400:
+        c["config"]["workload"] = c["config"]["workload"][:397] + "..."
+    sb = cfg.get("shard_balance")
+    if sb:
+        c["config"]["shard_balance"] = _pick(sb, ("max_over_mean_predicted_cost", "max_over_mean_correlate_ms"))
+    rf = out.get("roofline") or {}
+    c["roofline"] = _pick(rf, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches",
+                               "ideal_ms", "ideal_ms_bounds", "ideal_ms_candidates", "stale"))
+    oc = rf.get("other_ceilings")
+    if oc:
+        c["roofline"]["other_ceilings"] = {k: v for k, v in oc.items() if not isinstance(v, (dict, list, str))}
+    k4 = ((out.get("secondary") or {}).get("resid_lidar") or {}).get("roofline")
+    if k4:  # the one literally HBM-bound kernel of the path (SURVEY 8d: residuals + Jacobians, 144 B per correspondence)
+        c["roofline_resid_lidar"] = _pick(k4, ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms"))
+    cb = out.get("cpu_baseline")
+    if cb:
+        c["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "kind", "sample", "gpu_matches_oracle_on_sample",
+                                       "single_thread_pairs_per_s"))
+        if isinstance(c["cpu_baseline"].get("sample"), str) and len(c["cpu_baseline"]["sample"]) > 300:
+            c["cpu_baseline"]["sample"] = c["cpu_baseline"]["sample"][:297] + "..."
+    if "cpu_baseline_error" in out:
+        c["cpu_baseline_error"] = str(out["cpu_baseline_error"])[:200]
+    km = out.get("kernels_ms_per_step")
+    if km:
+        c["kernels_ms_per_step"] = {k: v for k, v in km.items() if not isinstance(v, (dict, list, str))}
+    if "parity_vs_f64" in out:
+        c["parity_vs_f64"] = {k: v for k, v in out["parity_vs_f64"].items() if not isinstance(v, (dict, list, str))}
+    for k in ("one_gpu_same_workload_pairs_per_s", "one_gpu_same_workload_ms_per_step", "one_gpu_records_equal_sharded_table",
+              "speedup_vs_one_gpu", "rccl_world_size"):
+        if k in out:
+            c[k] = out[k]
+    sec = out.get("secondary")
+    if sec:
+        c["secondary_errors"] = sorted(k for k in sec if k.endswith("_error"))
+    c["details"] = details_path
+    c = _round_floats(c)
+    line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+    if len(line) > COMPACT_LIMIT:  # never lose the headline to a long string: drop the optional parts, longest first
+        for k in ("roofline_resid_lidar", "parity_vs_f64", "kernels_ms_per_step", "secondary_errors"):
+            c.pop(k, None)
+            line = json.dumps(c, allow_nan=False, separators=(",", ":"))
+            if len(line) <= COMPACT_LIMIT:
+                break
+    assert len(line) <= COMPACT_LIMIT, "bench line of %d bytes" % len(line)
+    return line
+
+
+def emit(out, name="bench_details.json"):
+    """Write the full result beside bench.py (and under gpurun_out/ when that exists: it travels back from the GPU box),
+    then print the compact line as the LAST line of stdout."""
+    full = json.dumps(_round_floats(out, 9), allow_nan=False)
+    path = None
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        if os.path.isdir(d):
+            try:
+                with open(os.path.join(d, name), "w") as f:
+                    f.write(full + "\n")
+                path = path or name
+            except OSError:
+                pass
+    line = compact_line(out, path)
+    sys.stdout.flush()
+    print(line, flush=True)
+    return line
+
+
 # ------------------------------------------------------------------------------------------ worker
 def worker(a):
     rank = int(os.environ.get("RANK", "0"))
@@ -645,44 +812,11 @@ def worker(a):
                    "shard_balance": {"by": "pair count" if a.no_cost_model else "predicted cost (sharding.predicted_pair_cost)",
                                      "max_over_mean_predicted_cost": float(np.max(per_rank[:, 4]) / max(np.mean(per_rank[:, 4]), 1e-30)),
                                      "max_over_mean_correlate_ms": float(np.max(per_rank[:, 2]) / max(np.mean(per_rank[:, 2]), 1e-30))}},
-        # The matcher in its split form is two kernels; the LONGER one of this run carries the roofline, the other sits in
-        # roofline.matcher.  Bounds + seeds: vector-ALU work on the LDS-resident pooled table, priced against the
-        # vector-instruction peak.  Candidates: gathers through the vector L1, priced against the busy time of the
-        # vector-memory address units (TA), with the L1's lookup rate, the VALU rate and the HBM traffic beside it.
-        # (Fused form, NHIP_BNB_SPLIT=0 or a workspace without room: one kernel, priced against the VALU peak.)
-        "roofline": (({"bound": "valu", "kernel": "csm_bnb_kernel<%d, true, true, true>" % cb_tag, "avg_launch_ms": bounds_avg,
-                       "launches": kb_n,
-                       "achieved": (rates_b["valu_frac"] * VALU_PEAK_WAVE_INSTR / 1e12 if rates_b and "valu_frac" in rates_b else None),
-                       "peak": VALU_PEAK_WAVE_INSTR / 1e12, "unit": "T wave-instr/s (1024 SIMDs x 2.4 GHz / 2 clk)",
-                       "frac": rates_b.get("valu_frac") if rates_b else None, "traffic": tb,
-                       "other_ceilings": {"l1_lookups_per_clk_per_cu": rates_b.get("l1_tag_frac") if rates_b else None,
-                                          "ta_busy_frac": rates_b.get("ta_busy_frac") if rates_b else None,
-                                          "hbm_traffic_frac": (tb / (bounds_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if tb else None,
-                                          "waves_waiting_frac": rates_b.get("wave_wait_frac") if rates_b else None}}
-                      if bounds_avg >= cand_avg else
-                      {"bound": "vmem", "kernel": "csm_bnb_cand_kernel<%d>" % cb_tag, "avg_launch_ms": cand_avg, "launches": kc_n,
-                       "achieved": (rates_c["ta_busy_frac"] * 256 * 2.4 if rates_c and "ta_busy_frac" in rates_c else None),
-                       "peak": 256 * 2.4, "unit": "G busy cycles/s of the 256 vector-memory address units (TA_TA_BUSY)",
-                       "frac": rates_c.get("ta_busy_frac") if rates_c else None, "traffic": traffic,
-                       "other_ceilings": {"l1_lookups_per_clk_per_cu": rates_c.get("l1_tag_frac") if rates_c else None,
-                                          "valu_frac": rates_c.get("valu_frac") if rates_c else None,
-                                          "hbm_traffic_frac": (traffic / (cand_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                                          "l2_miss_frac": rates_c.get("l2_miss_frac") if rates_c else None}}) |
-                     {"matcher": matcher, "stale": prof["stale"], "profile": prof,
-                      "note": "counters per launch from the rocprofv3 passes in profiles/traffic.json / the kernel's launch "
-                              "time measured live with HIP events on its stream; the counters belong to one build and one "
-                              "workload: the fractions are null when traffic.json was taken from other kernel sources "
-                              "(stale) or this run's pair list is not the profiled one"}
-                     if split else
-                     {"bound": "valu", "kernel": "csm_bnb_kernel<%d, true, true, false>" % cb_tag, "avg_launch_ms": avg_ms, "launches": k_n,
-                      "achieved": oc["valu_wave_instr_per_s"] / 1e12 if oc else None, "peak": VALU_PEAK_WAVE_INSTR / 1e12,
-                      "unit": "T wave-instr/s", "frac": oc["valu_frac"] if oc else None, "traffic": traffic,
-                      "other_ceilings": {"l1_lookups_per_clk_per_cu": oc.get("l1_tag_frac") if oc else None,
-                                         "hbm_traffic_frac": (traffic / (avg_ms * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                                         "waves_waiting_frac": oc.get("wave_wait_frac") if oc else None},
-                      "matcher": matcher, "stale": prof["stale"], "profile": prof,
-                      "note": "VALU wave64 instructions per launch (rocprofv3 SQ_INSTS_VALU, profiles/traffic.json) / kernel "
-                              "time measured live with HIP events on the launch stream; peak = 1024 SIMDs x 2.4 GHz / 2 clk"}),
+        # ONE figure for the matcher as a whole, under fixed keys (matcher_roofline): the time an ideally-pruned matcher
+        # would need on this chip for this pair list (profiles/ideal_matcher.json, tools/ideal_matcher.py) over
+        # the time the matcher's kernels took in this run.  The per-kernel unit fractions sit in other_ceilings.
+        "roofline": matcher_roofline(a.cell_bits, split, avg_ms, k_n, m.n_pairs, matches, prof, matcher, oc, traffic,
+                                     (bounds_avg, cand_avg, rates_b, rates_c, tb, tc) if split else None, wl),
         # SURVEY 8(d)'s gather-equivalent figure: every lookup of the exhaustive definition priced at one cell.
         # It exceeds the HBM peak because the lookups are served from LDS: NOT a fraction of a physical ceiling.
         "roofline_hbm_equiv": {"bound": "hbm", "achieved": hbm_equiv, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -757,7 +891,7 @@ def worker(a):
             out["parity_vs_f64"] = {k_: sec["parity_vs_f64"][k_] for k_ in ("pairs", "index_agreement", "max_rel_score",
                                                                              "max_rel_score_quantised_formula", "max_gap_nat",
                                                                              "guaranteed_max_gap_nat", "cell_bits")}
-    print(json.dumps(out))
+    emit(out)
     if use_dist:
         dist.destroy_process_group()
     return 0
@@ -1211,8 +1345,8 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
     gbs = bytes_alg / (avg * 1e-3) / 1e9
     out = {"workload": "configs[2]: %d blocks x %d correspondences, LIDARNormal residual + 2 Jacobians" % (n_blocks, n_per),
            "correspondences_per_s": n_corr / (avg * 1e-3), "avg_launch_ms": avg, "launches": n,
-           "roofline": {"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic("resid_lidar_bytes_per_launch_%dcorr" % n_corr),
+           "roofline": {"bound": "hbm", "kernel": "resid_lidar_kernel<0, true>", "avg_launch_ms": avg,
+                        "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": _traffic("resid_lidar_bytes_per_launch_%dcorr" % n_corr),
                         "algorithmic_bytes_per_launch": bytes_alg}}
     try:
         # PCIe-inclusive: the handle API a Ceres EvaluationCallback uses (adapters/slam_residuals_hip.h) -- poses in,
