@@ -543,6 +543,35 @@ def matcher_roofline(cell_bits, split, avg_ms, launches, n_pairs, matches, prof,
     return r
 
 
+def gather_per_rank(torch, dist, world, device, n_pairs, n_targets, match_ms_per_step, grid_ms_per_step, predicted_cost):
+    """One row per rank -- pairs, targets, matcher ms and table ms per step, the plan's cost estimate of the rank's shard --
+    on every rank (one small all_gather outside the timed region)."""
+    mine = torch.tensor([n_pairs, n_targets, match_ms_per_step, grid_ms_per_step, predicted_cost], dtype=torch.float64, device=device)
+    if dist is not None and world > 1:
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        return torch.stack(allr).cpu().numpy()
+    return mine.cpu().numpy()[None]
+
+
+def config_block(workload, mode, pairs_total, scans_total, side, cell_bytes, comm_world, backend, world, per_rank, balanced_by):
+    """The `config` object of the bench line: the workload by name, the communicator the collective ran on, and the ranks'
+    load balance (predicted_cost: the plan's estimate for the rank's shard, in units of one nearby pair -- what the contiguous
+    by-target split balances; beside it the time the rank's matcher actually took)."""
+    per_rank = np.asarray(per_rank, dtype=np.float64)
+    mean_cost = max(float(np.mean(per_rank[:, 4])), 1e-30)
+    return {"workload": workload, "mode": mode, "pairs_total": int(pairs_total), "scans_total": int(scans_total),
+            "lattice": [61, 81, 81], "grid": [int(side), int(side)], "cell_bytes": int(cell_bytes),
+            "rccl_world_size": int(comm_world), "collective_backend": backend,
+            "collective": "all_gather 16 B/pair" if world > 1 else "none",
+            "per_rank": [{"pairs": int(r[0]), "targets": int(r[1]), "correlate_ms_per_step": float(r[2]),
+                          "grid_ms_per_step": float(r[3]), "predicted_cost": float(r[4]),
+                          "predicted_cost_over_mean": float(r[4]) / mean_cost} for r in per_rank],
+            "shard_balance": {"by": balanced_by,
+                              "max_over_mean_predicted_cost": float(np.max(per_rank[:, 4]) / mean_cost),
+                              "max_over_mean_correlate_ms": float(np.max(per_rank[:, 2]) / max(np.mean(per_rank[:, 2]), 1e-30))}}
+
+
 COMPACT_LIMIT = 4096  # bytes: BENCH_r05.json's `parsed` was null on a 22 KB line
 
 
@@ -716,13 +745,7 @@ def worker(a):
 
     # per-rank load balance: pairs, targets, correlate-kernel ms per step
     cost_mine = float(plan.rank_weight[rank]) if plan.rank_weight is not None else float(m.n_pairs)
-    mine = torch.tensor([m.n_pairs, m.n_targets, k_ms / a.steps, g_ms / a.steps, cost_mine], dtype=torch.float64, device=dev)
-    if use_dist and world > 1:
-        allr = [torch.zeros_like(mine) for _ in range(world)]
-        dist.all_gather(allr, mine)
-        per_rank = torch.stack(allr).cpu().numpy()
-    else:
-        per_rank = mine.cpu().numpy()[None]
+    per_rank = gather_per_rank(torch, dist if use_dist else None, world, dev, m.n_pairs, m.n_targets, k_ms / a.steps, g_ms / a.steps, cost_mine)
     # this rank's block of the gathered table must equal what this rank computed
     got_local = full.index_select(0, torch.from_numpy(shard[0].astype(np.int64)).to(dev))
     assert torch.equal(got_local, m.records()[0]), "all-gather returned a different block for this rank"
@@ -797,21 +820,11 @@ def worker(a):
         "score": ("the winning pose's mean log-likelihood on the unquantised table, in double (NHIP_SEARCH_EXACT_SCORE; its kernel "
                   "is inside the timed step)" if exact else "Lf + step * sum / N on the quantised cells"),
         "data": "synthetic",
-        "config": {"workload": wl.describe(world) + "; 61x81x81 lattice (1 deg / 5 cm over +-30 deg / +-2 m), "
+        "config": config_block(wl.describe(world) + "; 61x81x81 lattice (1 deg / 5 cm over +-30 deg / +-2 m), "
                                "1200x1200 u%d log-likelihood grid at 0.05 m; grid build + match + all-gather" % a.cell_bits,
-                   "mode": a.mode, "pairs_total": wl.n_pairs, "scans_total": wl.n_scans, "lattice": [61, 81, 81],
-                   "grid": [L.side, L.side], "cell_bytes": cell_bytes,
-                   "rccl_world_size": dist.get_world_size() if use_dist else 1,
-                   "collective_backend": ("gloo (REHEARSAL on a shared GPU: not a measurement)" if rehearsal else "nccl (RCCL)") if use_dist else None,
-                   "collective": "all_gather 16 B/pair" if world > 1 else "none",
-                   # (predicted_cost: the plan's estimate for the rank's shard, in units of one nearby pair -- what the
-                   #  contiguous by-target split balances; beside it the time the rank's matcher actually took)
-                   "per_rank": [{"pairs": int(r[0]), "targets": int(r[1]), "correlate_ms_per_step": r[2],
-                                 "grid_ms_per_step": r[3], "predicted_cost": r[4],
-                                 "predicted_cost_over_mean": r[4] / max(float(np.mean(per_rank[:, 4])), 1e-30)} for r in per_rank],
-                   "shard_balance": {"by": "pair count" if a.no_cost_model else "predicted cost (sharding.predicted_pair_cost)",
-                                     "max_over_mean_predicted_cost": float(np.max(per_rank[:, 4]) / max(np.mean(per_rank[:, 4]), 1e-30)),
-                                     "max_over_mean_correlate_ms": float(np.max(per_rank[:, 2]) / max(np.mean(per_rank[:, 2]), 1e-30))}},
+                               a.mode, wl.n_pairs, wl.n_scans, L.side, cell_bytes, dist.get_world_size() if use_dist else 1,
+                               (("gloo (REHEARSAL on a shared GPU: not a measurement)" if rehearsal else "nccl (RCCL)") if use_dist else None),
+                               world, per_rank, "pair count" if a.no_cost_model else "predicted cost (sharding.predicted_pair_cost)"),
         # ONE figure for the matcher as a whole, under fixed keys (matcher_roofline): the time an ideally-pruned matcher
         # would need on this chip for this pair list (profiles/ideal_matcher.json, tools/ideal_matcher.py) over
         # the time the matcher's kernels took in this run.  The per-kernel unit fractions sit in other_ceilings.
@@ -1066,11 +1079,17 @@ def leg_host_api(wl, shard, m, got, got_sums, runs_n=6):
     device memory per call) on the same workload -- never the headline `value`.  Every run is reported, call by call and
     phase by phase: min / median / max, never the median alone (round 4's median hid a 4 s call in five)."""
     runs, with_frees, detail = [], [], []
-    for _ in range(runs_n):  # (the first run also pays for fresh device allocations: 12 GB of tables at 16-bit cells)
-        t_work, t_tot, calls, hm, hs = host_api_run(wl, shard, m.spec, m.search)
-        runs.append(t_work)
-        with_frees.append(t_tot)
-        detail.append(calls)
+    # the library keeps released device buffers up to 4 GB per device by default (a drop-in's footprint); a host that cycles
+    # 1000 targets' tables (8.3 GB) through build / free raises the cap, as a steady caller of this size would
+    m._lib.check(m.lib.nhip_device_pool_configure(32 << 30))
+    try:
+        for _ in range(runs_n):  # (the first run also pays for fresh device allocations: 8 GB of tables at 16-bit cells)
+            t_work, t_tot, calls, hm, hs = host_api_run(wl, shard, m.spec, m.search)
+            runs.append(t_work)
+            with_frees.append(t_tot)
+            detail.append(calls)
+    finally:
+        m._lib.check(m.lib.nhip_device_pool_configure(4 << 30))
     dt = float(np.median(runs))
     n = len(shard[1])
     return {"pairs_per_s": n / dt, "seconds": dt, "runs_s": runs, "runs_with_frees_s": with_frees,
@@ -1079,6 +1098,7 @@ def leg_host_api(wl, shard, m, got, got_sums, runs_n=6):
             "spread_max_over_min": float(np.max(runs) / np.min(runs)),
             "calls_of_the_slowest_run": detail[int(np.argmax(with_frees))], "calls_of_the_fastest_run": detail[int(np.argmin(with_frees))],
             "same_result_as_device_api": bool(np.array_equal(hs, got_sums) and hm.tobytes() == got.tobytes()),
+            "device_pool_cap_bytes": 32 << 30,
             "note": "nhip_scans_upload + nhip_grids_build + nhip_csm_match with host pointers, incl. hipMalloc and PCIe "
                     "copies (8.6 MB in, 0.2 MB out); runs_s = upload + build + match, runs_with_frees_s adds the two _free calls; "
                     "per call: seconds by phase (nhip_host_phases)"}

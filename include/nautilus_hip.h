@@ -19,7 +19,10 @@
  * failure (never aborts, never throws across the ABI); nhip_last_error() returns a
  * thread-local message.  "_dev" entry points take DEVICE pointers owned by the caller and
  * only enqueue work on `stream` (a hipStream_t passed as void*; NULL = default stream):
- * they allocate nothing and do not synchronise, so they can be captured in a hipGraph.
+ * they allocate nothing and do not synchronise, so they can be captured in a hipGraph -- on a device that was named to
+ * nhip_init (the current one) or nhip_set_device beforehand: those calls allocate the device's 16 status bytes (below).
+ * A "_dev" call on a device the library never heard of allocates them itself, once (one hipMalloc + one synchronising
+ * memset): do not let that be the first thing inside a stream capture.
  * Ids in device memory: the scan ids, grid slots, block ids and pose indices that a "_dev" entry point reads from DEVICE
  * arrays cannot be validated by the host without a round trip, so the KERNELS check each of them against the count
  * passed beside its array (n_scans, n_grids, n_blocks, n_poses ...).  An id outside [0, count) is never dereferenced: the
@@ -57,8 +60,12 @@ const char *nhip_version(void);
  * memory that was out of range (see "Ids in device memory" above): NHIP_OK, or NHIP_ERR_ARG with the message in
  * nhip_last_error().  info (may be NULL): {OR of the kinds seen, kind, value, index of the first one reported}; kinds:
  * 1 target scan id of a grid build, 2 source scan id of a pair, 4 grid slot of a pair, 8 block id of a correspondence,
- * 16 pose index of a block, 32 scan id of a correspondence-search block.  Clears the record.  One record per device:
- * a host with several streams on one device learns THAT an id was bad and which, not on which stream. */
+ * 16 pose index of a block, 32 scan id of a correspondence-search block.  Clears the record (in the order of `stream`).
+ * ONE record per DEVICE, shared by every stream and host thread that uses the library on it: a host with several streams
+ * on one device learns THAT an id was bad and which, not on which stream; a call that finds a record consumes it -- reports
+ * of kernels still running on OTHER streams at that moment can be reported by this call or wiped by its clear.  Clients
+ * that need their errors apart must check on their own device or serialise launch + nhip_dev_status.  The index reported is
+ * the entry's position in the CALLER's array (also for lists the matcher works in rounds). */
 int nhip_dev_status(void *stream, int32_t info[4]);
 
 /* ------------------------------------------------------------------ likelihood grids
@@ -208,9 +215,14 @@ typedef struct nhip_match {
  * workspace and scratch of nhip_csm_match, ...) is KEPT for the next allocation of the same device that it fits (at most
  * twice the size asked for) instead of going back to the driver: hipFree is a device-wide synchronisation whose cost is not
  * the library's to bound (measured: 0.2 - 8 ms per call on a quiet device, 0.33 s per call for seconds after another client
- * of the process released 130 GB).  At most max_bytes are kept per process (default 32 GB; least
- * recently released out first; 0 = nothing is kept, every release is a hipFree); nhip_device_pool_release() returns
- * everything to the driver now; _stats reports what is held.  A failed allocation releases the pool and tries again.
+ * of the process released 130 GB).  A buffer is filed under the device it was ALLOCATED on, whatever
+ * device is current when its handle is freed.  At most max_bytes are kept PER DEVICE (default 4 GB: the workspace of a
+ * 10,000-pair match, the tables of a few hundred targets; least recently released out first; 0 = nothing is kept, every
+ * release is a hipFree); a host that cycles larger tables through build / free raises it (bench.py's host-buffer leg: 32
+ * GB).  What the pool holds is invisible to other allocators in the process (torch's caching allocator): call
+ * nhip_device_pool_release() -- everything back to the driver now -- before handing the device's memory to them; _stats
+ * reports what is held (all devices).  A failed allocation releases the device's pool and tries again.  On an error path a
+ * handle call waits for the device before its buffers return to the pool.
  * The "_dev" entry points never allocate and are not concerned. */
 int nhip_device_pool_configure(int64_t max_bytes);
 int nhip_device_pool_release(void);

@@ -90,6 +90,8 @@ class IcpBatch:
         self.d_res = self.d_js = self.d_jt = self.d_neq = None
         self.n_corr = 0
         self._searched = False
+        self._stale = False        # the arena was taken back after a search: d_corr / d_boff / d_cblock are another batch's
+        self.d_aff_search = None   # the affines of the last search(): what a re-search after a take-back runs at
         self._bind()
 
     def _bind(self):
@@ -100,6 +102,10 @@ class IcpBatch:
         else:
             e = lambda name, n, dt: a.take(torch, self.dev, name, n, dt)
             a.owner = self
+            # a batch that re-takes an arena it had searched in holds stale correspondences, WHOEVER owns the arena when
+            # the next call that needs them arrives (set_poses() first, as PoseGraph._assemble_inner does, makes this
+            # batch the owner again without searching)
+            self._stale = self._searched
         up = lambda name, h, dt: e(name, len(h), dt)[:len(h)].copy_(torch.from_numpy(h)) if len(h) else e(name, 1, dt)[:0]
         self.d_bsrc, self.d_btgt = up("bsrc", self.block_src, torch.int32), up("btgt", self.block_tgt, torch.int32)
         self.d_cap = up("cap", self.cap_h, torch.int64)
@@ -117,9 +123,10 @@ class IcpBatch:
         the call needs correspondences, searches them anew at its current poses."""
         if self.arena is not None and self.arena.owner is not self:
             self._bind()
-            if need_corr and self._searched:
-                self._searched = False
-                self.search()
+        if need_corr and self._stale:
+            # at the poses the correspondences were FOUND at (a caller who keeps them across set_poses() calls --
+            # research=False -- evaluates new poses on the old matches), not at the current ones
+            self.search(_aff=self.d_aff_search)
 
     def _stream(self):
         return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
@@ -132,20 +139,26 @@ class IcpBatch:
         self.d_aff.copy_(self.torch.from_numpy(aff.reshape(-1)))
         self.d_poses.copy_(self.torch.from_numpy(poses.reshape(-1)))
 
-    def search(self, sync=True):
+    def search(self, sync=True, _aff=None):
         """K5 + compaction.  Returns the number of correspondences (needs one sync to size outputs)."""
         self._own(False)
         self._searched = True
+        self._stale = False
+        if _aff is None:  # (a fresh search: remember where it ran; a re-search after a take-back runs there again)
+            if self.d_aff_search is None:
+                self.d_aff_search = self.torch.empty_like(self.d_aff)
+            self.d_aff_search.copy_(self.d_aff)
+            _aff = self.d_aff
         sp = self._stream()
         if self.min_cos is None:
             check(self.lib.nhip_corr_search_dev(self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(), self.n_scans,
                                                 self.d_bsrc.data_ptr(), self.d_btgt.data_ptr(), self.n_blocks,
-                                                self.d_aff.data_ptr(), self.thr, self.d_cap.data_ptr(),
+                                                _aff.data_ptr(), self.thr, self.d_cap.data_ptr(),
                                                 self.d_padded.data_ptr(), self.d_counts.data_ptr(), sp))
         else:
             check(self.lib.nhip_corr_search_normals_dev(
                 self.d_xy.data_ptr(), self.d_nrm.data_ptr(), self.d_off.data_ptr(), self.n_scans, self.d_bsrc.data_ptr(),
-                self.d_btgt.data_ptr(), self.n_blocks, self.d_aff.data_ptr(), self.thr, self.min_cos,
+                self.d_btgt.data_ptr(), self.n_blocks, _aff.data_ptr(), self.thr, self.min_cos,
                 self.d_cap.data_ptr(), self.d_padded.data_ptr(), self.d_counts.data_ptr(), sp))
         check(self.lib.nhip_corr_compact_dev(self.d_padded.data_ptr(), self.d_cap.data_ptr(),
                                              self.d_counts.data_ptr(), self.n_blocks, self.d_boff.data_ptr(),

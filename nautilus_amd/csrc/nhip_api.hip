@@ -43,28 +43,53 @@ int require_device() {
   return NHIP_OK;
 }
 
-// The status words of the current device (nhip_common.h, "ids that live in device memory"): 16 bytes of device memory
-// per device, allocated the first time the device is used and kept to the end of the process.
+// The status words of a device (nhip_common.h, "ids that live in device memory"): 16 bytes of device memory per device,
+// kept to the end of the process.  They are allocated and zeroed by dev_status_prepare() -- called from nhip_init (every
+// visible device) and nhip_set_device, i.e. OUTSIDE any launch path -- so that dev_status(), which every `_dev` launcher
+// calls, is a lookup: no hipMalloc, no null-stream memset, nothing a stream capture could trip over.  A process that hands
+// the library a device it never named to nhip_init / nhip_set_device gets the words on that device's first launch (the
+// lazy path below; it synchronises once, and must not be the first thing inside a capture: include/nautilus_hip.h says so).
+namespace {
+constexpr int MAX_DEV = 64;
+std::mutex g_status_mu;
+std::atomic<uint32_t *> g_status_words[MAX_DEV];
+}  // namespace
+
+uint32_t *dev_status_prepare(int dev) {
+  if (dev < 0 || dev >= MAX_DEV) return nullptr;
+  if (uint32_t *w = g_status_words[dev].load(std::memory_order_acquire)) return w;
+  std::lock_guard<std::mutex> lock(g_status_mu);
+  if (uint32_t *w = g_status_words[dev].load(std::memory_order_acquire)) return w;
+  int cur = -1;
+  if (hipGetDevice(&cur) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (cur != dev && hipSetDevice(dev) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  void *p = nullptr;
+  bool ok = hipMalloc(&p, sizeof(uint32_t) * DEV_STATUS_WORDS) == hipSuccess;
+  if (ok && hipMemset(p, 0, sizeof(uint32_t) * DEV_STATUS_WORDS) != hipSuccess) {
+    (void)hipFree(p);  // (not leaked, and not retried with the same pointer)
+    ok = false;
+  }
+  if (!ok) (void)hipGetLastError();
+  if (cur != dev) (void)hipSetDevice(cur);
+  if (!ok) return nullptr;
+  g_status_words[dev].store(static_cast<uint32_t *>(p), std::memory_order_release);
+  return static_cast<uint32_t *>(p);
+}
+
 uint32_t *dev_status() {
-  constexpr int MAX_DEV = 64;
-  static std::mutex mu;
-  static uint32_t *words[MAX_DEV] = {nullptr};
   int dev = -1;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= MAX_DEV) {
     (void)hipGetLastError();
     return nullptr;
   }
-  std::lock_guard<std::mutex> lock(mu);
-  if (!words[dev]) {
-    void *p = nullptr;
-    if (hipMalloc(&p, sizeof(uint32_t) * DEV_STATUS_WORDS) != hipSuccess ||
-        hipMemset(p, 0, sizeof(uint32_t) * DEV_STATUS_WORDS) != hipSuccess) {
-      (void)hipGetLastError();
-      return nullptr;
-    }
-    words[dev] = static_cast<uint32_t *>(p);
-  }
-  return words[dev];
+  if (uint32_t *w = g_status_words[dev].load(std::memory_order_acquire)) return w;
+  return dev_status_prepare(dev);
 }
 
 const char *tunable(const char *name) {
@@ -277,7 +302,10 @@ struct PoolEntry {
 };
 std::mutex g_pool_mu;
 std::vector<PoolEntry> &g_pool = *new std::vector<PoolEntry>();  // oldest first (never destroyed: see the drop-in cache below)
-int64_t g_pool_cap = 32ll << 30;
+// PER DEVICE.  4 GB by default: enough for the workspace of a 10,000-pair match (0.33 GB), the tables of ~450 targets and the
+// small per-call buffers -- what a drop-in host that called the library once can defend holding.  A host that cycles
+// larger tables (bench.py's host-buffer leg: 8.3 GB) raises it with nhip_device_pool_configure.
+int64_t g_pool_cap = 4ll << 30;
 constexpr size_t POOL_MAX_ENTRIES = 32;
 
 int current_device() {
@@ -305,17 +333,29 @@ void *pool_take(size_t n, size_t *got) {
   return p;
 }
 // true: the pool keeps the buffer; `evict` receives what it lets go of for it (freed by the caller, outside the lock)
-bool pool_put(void *p, size_t bytes, std::vector<void *> *evict, uint64_t key = 0, uint64_t meta = 0) {
-  const int dev = current_device();
+// `dev`: the device the buffer was ALLOCATED on (DevBuf records it) -- not the device that happens to be current when it
+// is released: a handle built on device 0 and freed after nhip_set_device(1) stays a device-0 buffer.  Cap and entry limit
+// are per device: releases on one GPU never evict what another GPU's callers keep.
+bool pool_put(void *p, size_t bytes, int dev, std::vector<void *> *evict, uint64_t key = 0, uint64_t meta = 0) {
   std::lock_guard<std::mutex> lock(g_pool_mu);
   if (dev < 0 || (int64_t)bytes > g_pool_cap) return false;
   g_pool.push_back({p, bytes, dev, key, meta});
   int64_t tot = 0;
-  for (auto &e : g_pool) tot += (int64_t)e.bytes;
-  while (!g_pool.empty() && (tot > g_pool_cap || g_pool.size() > POOL_MAX_ENTRIES)) {
-    tot -= (int64_t)g_pool.front().bytes;
-    evict->push_back(g_pool.front().p);
-    g_pool.erase(g_pool.begin());
+  size_t cnt = 0;
+  for (auto &e : g_pool)
+    if (e.device == dev) {
+      tot += (int64_t)e.bytes;
+      cnt++;
+    }
+  for (size_t i = 0; i < g_pool.size() && (tot > g_pool_cap || cnt > POOL_MAX_ENTRIES);) {
+    if (g_pool[i].device != dev) {
+      i++;
+      continue;
+    }
+    tot -= (int64_t)g_pool[i].bytes;  // (oldest of this device first)
+    cnt--;
+    evict->push_back(g_pool[i].p);
+    g_pool.erase(g_pool.begin() + (long)i);
   }
   return true;
 }
@@ -350,14 +390,27 @@ void pool_drain(std::vector<void *> *out, int device /* -1: every device */) {
 }
 }  // namespace
 
+// Work this thread's current handle call has enqueued may still be running: set by the entry points that launch kernels
+// on buffers they own (InFlight), cleared once they have synchronised.  DevBuf::free used to be a hipFree -- an implicit
+// device-wide synchronisation -- and is now a hand-over to the pool: on an error path (a failed launch after earlier ones
+// were enqueued, a failed round of the split form with the helper stream still busy) the buffers would return to the pool
+// while kernels still read or write them.  So the first release under the flag waits for the device.
+static thread_local bool t_inflight = false;
+struct InFlight {
+  InFlight() { t_inflight = true; }
+  static void done() { t_inflight = false; }  // (the caller has synchronised)
+};
+
 struct DevBuf {
   void *p = nullptr;
   size_t bytes = 0;
+  int device = -1;  // the device the memory lives on
   int alloc(size_t n) {
     free();
     if (n == 0) n = 16;
     PhaseClock pc(PH_ALLOC);
     size_t got = 0;
+    device = current_device();
     if (void *q = pool_take(n, &got)) {
       p = q;
       bytes = got;
@@ -383,17 +436,23 @@ struct DevBuf {
   void free(uint64_t key = 0, uint64_t meta = 0) {  // (key, meta: the contents stay known to the pool, see PoolEntry)
     if (p) {
       PhaseClock pc(PH_FREE);
+      if (t_inflight) {  // an error path: nothing that was enqueued may outlive its buffers' release
+        (void)hipDeviceSynchronize();
+        (void)hipGetLastError();
+        t_inflight = false;
+      }
       std::vector<void *> evict;
-      if (!pool_put(p, bytes, &evict, key, meta)) (void)hipFree(p);
+      if (!pool_put(p, bytes, device, &evict, key, meta)) (void)hipFree(p);
       for (void *d : evict) (void)hipFree(d);
     }
     p = nullptr;
     bytes = 0;
   }
-  void adopt(void *q, size_t n) {
+  void adopt(void *q, size_t n) {  // (a buffer pool_take_pair returned: filed under the current device)
     free();
     p = q;
     bytes = n;
+    device = current_device();
   }
   ~DevBuf() { free(); }
 };
@@ -457,6 +516,12 @@ int nhip_init(int *n_devices) {
     set_error("no HIP device visible");
     return NHIP_ERR_NODEV;
   }
+  int cur = 0;
+  if (hipGetDevice(&cur) == hipSuccess) {
+    (void)dev_status_prepare(cur);  // (the other devices' words: nhip_set_device, before that device's first launch)
+  } else {
+    (void)hipGetLastError();
+  }
   return NHIP_OK;
 }
 
@@ -464,6 +529,7 @@ int nhip_set_device(int device) {
   int rc = require_device();
   if (rc) return rc;
   NHIP_TRY_HIP(hipSetDevice(device));
+  (void)dev_status_prepare(device);
   return NHIP_OK;
 }
 
@@ -630,7 +696,10 @@ int nhip_dev_status(void *stream, int32_t info[4]) {
   if (info)
     for (int i = 0; i < 4; i++) info[i] = (int32_t)w[i];
   if (w[0] == 0u) return NHIP_OK;
-  NHIP_TRY_HIP(hipMemset(st, 0, sizeof(w)));
+  // cleared in the order of the stream that was asked about (a null-stream memset would race with kernels that are
+  // flagging ids on other streams); the words are ONE set per device: see the header on what that means for several clients
+  NHIP_TRY_HIP(hipMemsetAsync(st, 0, sizeof(w), static_cast<hipStream_t>(stream)));
+  NHIP_TRY_HIP(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
   const char *what = w[1] == BAD_TARGET_ID  ? "target scan id (nhip_grid_build_dev / nhip_grid_rebuild_dev: d_target_ids)"
                      : w[1] == BAD_PAIR_SRC  ? "source scan id (nhip_csm_match_dev: d_pair_src)"
                      : w[1] == BAD_PAIR_SLOT ? "grid slot (nhip_csm_match_dev: d_pair_slot)"
@@ -649,12 +718,16 @@ int nhip_device_pool_configure(int64_t max_bytes) {
   {
     std::lock_guard<std::mutex> lock(g_pool_mu);
     g_pool_cap = max_bytes;
-    int64_t tot = 0;
-    for (auto &e : g_pool) tot += (int64_t)e.bytes;
-    while (!g_pool.empty() && tot > g_pool_cap) {
-      tot -= (int64_t)g_pool.front().bytes;
-      drop.push_back(g_pool.front().p);
-      g_pool.erase(g_pool.begin());
+    std::map<int, int64_t> tot;
+    for (auto &e : g_pool) tot[e.device] += (int64_t)e.bytes;
+    for (size_t i = 0; i < g_pool.size();) {  // (oldest first, each device against the cap on its own)
+      if (tot[g_pool[i].device] > g_pool_cap) {
+        tot[g_pool[i].device] -= (int64_t)g_pool[i].bytes;
+        drop.push_back(g_pool[i].p);
+        g_pool.erase(g_pool.begin() + (long)i);
+      } else {
+        i++;
+      }
     }
   }
   for (void *d : drop) (void)hipFree(d);
@@ -904,7 +977,9 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
   hipError_t e = hipSuccess;
   {
     PhaseClock pc(PH_UPLOAD);
-    if (!g->rebuilt) e = hipMemset(g->grids.p, 0, grid_bytes);  // (what was asked for: a pooled buffer may be larger)
+    // (a fresh build zero-fills its n_targets slots itself, on its stream: launch_grid_build; what it does not reach is the
+    //  256-byte tail past the last slot, which loads of the last slot's planes may run into)
+    if (!g->rebuilt) e = hipMemset(static_cast<uint8_t *>(g->grids.p) + (size_t)n_targets * L.slot_bytes, 0, 256);
     if (e == hipSuccess && n_targets)
       e = hipMemcpy(ids.p, target_ids, sizeof(int32_t) * (size_t)n_targets, hipMemcpyHostToDevice);
   }
@@ -913,6 +988,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
     return hip_fail(e, "grids_build setup", __FILE__, __LINE__);
   }
   if (n_targets) {
+    InFlight inflight;
     {
       PhaseClock pc(PH_ENQUEUE);
       rc = launch_grid_build(static_cast<const float *>(scans->xy.p),
@@ -924,6 +1000,7 @@ int nhip_grids_build(const nhip_scans_t *scans, const int32_t *target_ids, int32
       PhaseClock pc(PH_WAIT);
       e = hipDeviceSynchronize();
       if (e != hipSuccess) rc = hip_fail(e, "grids_build sync", __FILE__, __LINE__);
+      InFlight::done();
     }
     if (rc) {
       g->dirty = true;  // (a failed build: contents unknown)
@@ -1118,6 +1195,7 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
   const IdBounds idb = {scans->n_scans, grids->n, dev_status()};  // (checked on the host above; the kernels check again)
   PhaseClock pc_enq(PH_ENQUEUE);  // (to the end of the call minus the phases inside it; nhip_host_phases subtracts nothing:
                                   //  read it as "enqueue + wait + download + frees")
+  InFlight inflight;  // (a failure from here on: the DevBufs above wait for the device before they return to the pool)
   rc = launch_csm_match(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p), idb,
                         static_cast<const uint8_t *>(grids->grids.p), &spec_now, grids->L,
                         static_cast<const int32_t *>(d_src.p), static_cast<const int32_t *>(d_slot.p),
@@ -1128,6 +1206,7 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
   {
     PhaseClock pc(PH_WAIT);  // (the kernels; the downloads below find them done)
     NHIP_TRY_HIP(hipStreamSynchronize(nullptr));
+    InFlight::done();
   }
   {
     PhaseClock pc(PH_DOWNLOAD);
@@ -1160,12 +1239,14 @@ int nhip_csm_scores(const nhip_scans_t *scans, const nhip_grids_t *grids, int32_
     return rc;
   NHIP_TRY_HIP(hipMemcpy(d_rot0.p, rot0, sizeof(rot0), hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(d_delta.p, delta.data(), sizeof(double) * delta.size(), hipMemcpyHostToDevice));
+  InFlight inflight;
   rc = launch_csm_scores(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p),
                          static_cast<const uint8_t *>(grids->grids.p), &grids->spec, grids->L, src, slot,
                          static_cast<const double *>(d_rot0.p), static_cast<const double *>(d_delta.p),
                          origin_x, origin_y, search, static_cast<int32_t *>(d_vol.p), nullptr);
   if (rc) return rc;
-  NHIP_TRY_HIP(hipMemcpy(out_sums, d_vol.p, sizeof(int32_t) * vol, hipMemcpyDeviceToHost));
+  NHIP_TRY_HIP(hipMemcpy(out_sums, d_vol.p, sizeof(int32_t) * vol, hipMemcpyDeviceToHost));  // (synchronises the null stream)
+  InFlight::done();
   return NHIP_OK;
 }
 
@@ -1218,12 +1299,14 @@ int nhip_lc_chi_square_gate(const double *poses, int32_t n_poses, const int32_t 
   NHIP_TRY_HIP(hipMemcpy(ds.p, pair_src, 4 * N, hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(dt.p, pair_tgt, 4 * N, hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(dc.p, cov, 16 * N, hipMemcpyHostToDevice));
+  InFlight inflight;
   rc = launch_lc_chi_square(static_cast<const double *>(dp.p), n_poses, static_cast<const int32_t *>(ds.p),
                             static_cast<const int32_t *>(dt.p), static_cast<const float *>(dc.p), n, max_score,
                             static_cast<double *>(dsc.p), static_cast<uint8_t *>(df.p), nullptr);
   if (rc) return rc;
   NHIP_TRY_HIP(hipMemcpy(scores, dsc.p, 8 * N, hipMemcpyDeviceToHost));
   NHIP_TRY_HIP(hipMemcpy(flags, df.p, N, hipMemcpyDeviceToHost));
+  InFlight::done();  // (the downloads above synchronised the null stream)
   return NHIP_OK;
 }
 
@@ -1234,10 +1317,12 @@ int nhip_lc_scatter_scores(const nhip_scans_t *scans, double *scores) {
   if (scans->n_scans == 0) return NHIP_OK;
   DevBuf d;
   if ((rc = d.alloc(sizeof(double) * (size_t)scans->n_scans))) return rc;
+  InFlight inflight;
   rc = launch_lc_scatter_scores(static_cast<const float *>(scans->xy.p), static_cast<const int32_t *>(scans->offsets.p),
                                 scans->n_scans, static_cast<double *>(d.p), nullptr);
   if (rc) return rc;
   NHIP_TRY_HIP(hipMemcpy(scores, d.p, sizeof(double) * (size_t)scans->n_scans, hipMemcpyDeviceToHost));
+  InFlight::done();  // (the downloads above synchronised the null stream)
   return NHIP_OK;
 }
 
@@ -1255,10 +1340,12 @@ int nhip_lc_pair_gate(const double *poses, int32_t n_poses, const int32_t *candi
     return rc;
   NHIP_TRY_HIP(hipMemcpy(dp.p, poses, sizeof(double) * 3 * (size_t)n_poses, hipMemcpyHostToDevice));
   NHIP_TRY_HIP(hipMemcpy(dc.p, candidates, sizeof(int32_t) * (size_t)n, hipMemcpyHostToDevice));
+  InFlight inflight;
   rc = launch_lc_pair_gate(static_cast<const double *>(dp.p), n_poses, static_cast<const int32_t *>(dc.p), n, max_range,
                            min_separation, static_cast<uint8_t *>(df.p), nullptr);
   if (rc) return rc;
   NHIP_TRY_HIP(hipMemcpy(flags, df.p, (size_t)n * n, hipMemcpyDeviceToHost));
+  InFlight::done();  // (the downloads above synchronised the null stream)
   return NHIP_OK;
 }
 
@@ -1829,6 +1916,7 @@ int nhip_resid_odometry(const float *t_odom, const float *r_odom, const int32_t 
       (rc = up(dp, poses, sizeof(double) * 3 * (size_t)n_poses)) || (rc = res.alloc(sizeof(double) * 3 * (size_t)n)) ||
       (rc = ji.alloc(sizeof(double) * 9 * (size_t)n)) || (rc = jj.alloc(sizeof(double) * 9 * (size_t)n)))
     return rc;
+  InFlight inflight;
   rc = launch_resid_odometry(static_cast<const float *>(dt.p), static_cast<const float *>(dr.p),
                              static_cast<const int32_t *>(di.p), static_cast<const int32_t *>(dj.p), n, tw, rw,
                              static_cast<const double *>(dp.p), n_poses, static_cast<double *>(res.p),
@@ -1838,6 +1926,7 @@ int nhip_resid_odometry(const float *t_odom, const float *r_odom, const int32_t 
   NHIP_TRY_HIP(hipMemcpy(residuals, res.p, sizeof(double) * 3 * (size_t)n, hipMemcpyDeviceToHost));
   if (jac_i) NHIP_TRY_HIP(hipMemcpy(jac_i, ji.p, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost));
   if (jac_j) NHIP_TRY_HIP(hipMemcpy(jac_j, jj.p, sizeof(double) * 9 * (size_t)n, hipMemcpyDeviceToHost));
+  InFlight::done();  // (the downloads above synchronised the null stream)
   return NHIP_OK;
 }
 
@@ -1865,6 +1954,7 @@ int nhip_resid_point_to_line(const float *segments, const float *points, const i
       (rc = up(dl, line_poses, sizeof(double) * 3 * (size_t)n_line_poses)) || (rc = res.alloc(sizeof(double) * (size_t)n_points)) ||
       (rc = j0.alloc(sizeof(double) * 3 * (size_t)n_points)) || (rc = j1.alloc(sizeof(double) * 3 * (size_t)n_points)))
     return rc;
+  InFlight inflight;
   rc = launch_resid_point_to_line(static_cast<const float *>(ds.p), static_cast<const float *>(dpt.p),
                                   static_cast<const int32_t *>(dpb.p), n_points, static_cast<const int32_t *>(dbp.p),
                                   static_cast<const int32_t *>(dbl.p), n_blocks, static_cast<const double *>(dp.p), n_poses,
@@ -1875,6 +1965,7 @@ int nhip_resid_point_to_line(const float *segments, const float *points, const i
   NHIP_TRY_HIP(hipMemcpy(residuals, res.p, sizeof(double) * (size_t)n_points, hipMemcpyDeviceToHost));
   if (jac_pose) NHIP_TRY_HIP(hipMemcpy(jac_pose, j0.p, sizeof(double) * 3 * (size_t)n_points, hipMemcpyDeviceToHost));
   if (jac_line) NHIP_TRY_HIP(hipMemcpy(jac_line, j1.p, sizeof(double) * 3 * (size_t)n_points, hipMemcpyDeviceToHost));
+  InFlight::done();  // (the downloads above synchronised the null stream)
   return NHIP_OK;
 }
 

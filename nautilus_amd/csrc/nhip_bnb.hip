@@ -1445,7 +1445,7 @@ __global__ __launch_bounds__(SPLIT ? 64 * SPLIT_WAVES : BNB_THREADS, SPLIT ? SPL
   int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
   // (ids from device memory: a pair whose scan or slot lies outside the caller's counts is an empty scan -- it scores
   //  nothing, like a scan without points -- and is reported through the device's status words; both instantiations see it)
-  const bool ids_ok = pair_ids_ok(P.ids, src, slot, pair, threadIdx.x == 0);
+  const bool ids_ok = pair_ids_ok(P.ids, src, slot, pair + P.pair_base, threadIdx.x == 0);
   if (!ids_ok) src = slot = 0;
   const int32_t beg = ids_ok ? P.offsets[src] : 0, n_pts = ids_ok ? P.offsets[src + 1] - beg : 0;
   const float2 *pts = P.xy + beg;

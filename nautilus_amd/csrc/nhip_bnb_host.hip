@@ -153,6 +153,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &
   P.pair_origin = d_pair_origin;
   P.pair_kbase = d_pair_kbase;
   P.keys = reinterpret_cast<unsigned long long *>(d_keys);
+  P.pair_base = 0;
   P.n_pairs = n_pairs;
   P.n_theta = search->n_theta;
   P.nx = search->nx;
@@ -327,6 +328,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &
       Q.rot0_cs += 2 * b0;
       if (Q.pair_origin) Q.pair_origin += 2 * b0;
       Q.keys += b0;
+      Q.pair_base = (int32_t)b0;  // (what nhip_dev_status names is an index into the CALLER's arrays)
       Q.n_pairs = nb;
       Q.pairs_per_xcd = (nb + 7) / 8;
       Q.ps_work_stride = Q.pairs_per_xcd + (Q.pairs_per_xcd / 2 > 64 ? Q.pairs_per_xcd / 2 : 64);

@@ -429,7 +429,7 @@ struct ExactParams {
   const int32_t *pair_kbase;  // optional: entry of delta_cs that is pair i's rotation 0 (nhip_bnb_params.h)
   nhip_match_t *out;
   IdBounds ids;
-  int32_t n_pairs, pairs_per_xcd, nx, ny, hx, hy, S, R, hits_pitch;
+  int32_t n_pairs, pairs_per_xcd, nx, ny, hx, hy, S, R, hits_pitch, max_shift;
   int64_t slot_bytes, hits_offset;
   double res, inv_res, K2, floor_p, Lf;
   int32_t taps[2 * 16 + 1];
@@ -470,6 +470,12 @@ __global__ __launch_bounds__(EX_THREADS) void csm_exact_score_kernel(ExactParams
   if (!ids_ok) src = slot = 0;
   const int32_t beg = ids_ok ? P.offsets[src] : 0, n_pts = ids_ok ? P.offsets[src + 1] - beg : 0;
   const nhip_match_t m = P.out[pair];
+  {
+    // a search centre the stored border cannot cover "scores nothing" in every matcher kernel (sum 0, pose 0, score Lf):
+    // the record keeps that score -- the real score at pose 0 would contradict the sum beside it
+    const int32_t ox = P.pair_origin ? P.pair_origin[2 * pair] : 0, oy = P.pair_origin ? P.pair_origin[2 * pair + 1] : 0;
+    if (abs(ox) + P.hx > P.max_shift || abs(oy) + P.hy > P.max_shift) return;
+  }
   const int32_t cx = (P.pair_origin ? P.pair_origin[2 * pair] : 0) + m.ix - P.hx;
   const int32_t cy = (P.pair_origin ? P.pair_origin[2 * pair + 1] : 0) + m.iy - P.hy;
   // rotation itheta: R(theta0) * R(delta_k), composed in double with individually rounded ops, as every matcher kernel
@@ -580,6 +586,7 @@ int launch_csm_exact_score(const float *d_xy, const int32_t *d_offsets, const Id
   P.hy = (search->ny - 1) / 2;
   P.S = L.S;
   P.R = L.R;
+  P.max_shift = spec->max_shift;
   P.hits_pitch = L.hits_pitch;
   P.slot_bytes = L.slot_bytes;
   P.hits_offset = L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes;

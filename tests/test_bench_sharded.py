@@ -8,6 +8,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -94,7 +95,21 @@ def _worker(rank, world, port, q, weighted=False):
         one = bench.one_gpu_same_workload(src, tgt, th0, _weights(src, tgt) if weighted else None,
                                           lambda sh: _OracleMatcher(xy, off, sh, gs, ss), "cpu", rank, world, dist, full)
         fields = bench.scaling_fields(len(src) * 2 / elapsed, one, world, dist.get_world_size())
-        q.put((rank, full.numpy().tobytes(), m.calls, elapsed, len(plan.shard(rank)[1]), fields))
+        # the N > 1 bench line as bench.worker assembles it: per-rank table over the communicator, config block, scaling
+        # fields, then the compact stdout line (what the driver parses)
+        cost = float(plan.rank_weight[rank]) if plan.rank_weight is not None else float(len(plan.shard(rank)[1]))
+        per_rank = bench.gather_per_rank(torch, dist, world, "cpu", len(plan.shard(rank)[1]), len(plan.shard(rank)[4]),
+                                         1e3 * elapsed / 2, 0.1, cost)
+        out = {"metric": "loop-closure candidate pairs/sec (1081-beam)", "value": len(src) * 2 / elapsed, "unit": "pairs/s",
+               "n_gpus": world, "steps": 2, "warmup": 1, "ms_per_step": 1e3 * elapsed / 2, "higher_is_better": True,
+               "scaling": "strong", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+               "config": bench.config_block("test list", "config4", len(src), 20, 1200, 2, dist.get_world_size(), "gloo", world,
+                                            per_rank, "predicted cost" if weighted else "pair count"),
+               "roofline": {"bound": "onchip-model", "kernel": "k", "achieved": 1.0, "peak": None, "unit": "pairs/s", "frac": None,
+                            "traffic": None, "avg_launch_ms": 1.0, "launches": 2, "ideal_ms": None, "stale": True}}
+        out.update(fields)
+        line = bench.compact_line(out, "bench_details.json") if rank == 0 else None
+        q.put((rank, full.numpy().tobytes(), m.calls, elapsed, len(plan.shard(rank)[1]), fields, line))
     finally:
         dist.destroy_process_group()
 
@@ -160,3 +175,36 @@ def test_cost_aware_split_over_gloo_world_2():
     one = sharding.ShardPlan(src, tgt, th0, 1)
     want = one.all_gather(_OracleMatcher(xy, off, one.shard(0), gs, ss).step(), 0)
     assert res[0][1] == want.numpy().tobytes()
+
+
+@pytest.mark.parametrize("world", [4, 8])
+def test_n_gpu_bench_line_over_gloo(world):
+    """World sizes 4 and 8 (the launch path of `bench.py --gpus N` above two ranks; at 8 the list's five targets leave three
+    ranks with EMPTY shards -- they still take part in the one all-gather): every rank ends with the same table, and rank
+    0's compact line -- the one the driver parses -- is strict JSON below 4 KB that carries the communicator's size, the
+    same-workload one-GPU point with the ratio to it, and the ranks' load balance."""
+    import json
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert len({r[1] for r in res}) == 1, "ranks hold different tables"
+    assert sum(r[4] for r in res) == 15
+    line = res[0][6]
+    assert line and "\n" not in line and len(line) < 4096 and all(r[6] is None for r in res[1:])
+    d = json.loads(line, parse_constant=lambda c: (_ for _ in ()).throw(ValueError(c)))
+    assert d["n_gpus"] == world and d["rccl_world_size"] == world and d["config"]["rccl_world_size"] == world
+    assert d["config"]["collective"] == "all_gather 16 B/pair" and d["scaling"] == "strong"
+    assert d["one_gpu_same_workload_pairs_per_s"] > 0 and d["one_gpu_records_equal_sharded_table"] is True
+    assert abs(d["speedup_vs_one_gpu"] - d["value"] / d["one_gpu_same_workload_pairs_per_s"]) < 1e-4 * d["speedup_vs_one_gpu"]
+    xy, off, src, tgt, th0 = _workload()
+    plan = sharding.ShardPlan(src, tgt, th0, world, _weights(src, tgt))
+    want = float(np.max(plan.rank_weight) / np.mean(plan.rank_weight))
+    assert abs(d["config"]["shard_balance"]["max_over_mean_predicted_cost"] - want) < 1e-5 * want
+    assert "per_rank" not in d["config"], "the per-rank table belongs to the details file"

@@ -306,3 +306,18 @@ def test_batches_of_one_backend_share_a_device_arena(gpu, small_bag):
     assert np.array_equal(batches[4].correspondences()[0], want[4][0])
     # ... and the newer one after that, likewise
     assert np.array_equal(batches[2].normal_equations(_lib.NHIP_LIDAR_NORMAL).cpu().numpy(), want[2][1])
+    # The order PoseGraph._assemble_inner uses on an older graph (research=False): set_poses() FIRST -- which makes the batch
+    # the arena's owner again without searching -- then the normal equations.  The correspondences must be the ones found
+    # at the poses of the batch's last search(), evaluated at the new poses (round 5 read the newer batch's rows here).
+    moved = poses + np.random.default_rng(3).normal(0.0, [0.01, 0.01, 0.003], poses.shape)
+    bs, bt = window_pairs(small_bag.n_scans, 4)
+    plain = IcpBatch(xy, nrm, off, bs, bt)
+    plain.set_poses(poses)
+    plain.search()
+    plain.set_poses(moved)
+    want_moved = plain.normal_equations(_lib.NHIP_LIDAR_NORMAL).cpu().numpy().copy()
+    assert arena.owner is batches[2]
+    batches[4].set_poses(moved)
+    assert arena.owner is batches[4]
+    assert np.array_equal(batches[4].normal_equations(_lib.NHIP_LIDAR_NORMAL).cpu().numpy(), want_moved)
+    assert np.array_equal(batches[4].correspondences()[0], want[4][0]), "found at the poses of the last search()"

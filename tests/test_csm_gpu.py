@@ -1546,3 +1546,4 @@ def test_handle_builds_rebuild_into_the_buffers_a_released_handle_left(gpu, smal
     assert all(np.array_equal(x, y) for x, y in zip(planes(c), want))
     c.close()
     st.close()
+    _lib.check(lib.nhip_device_pool_configure(4 << 30))   # the library's default cap (per device)

@@ -28,6 +28,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("NHIP_TUNABLES", "1")  # (the library reads its switches only then)
 os.environ.setdefault("NHIP_BNB_STATS", "1")
 os.environ.setdefault("NHIP_BNB_INSTRUMENT", "1")
 
