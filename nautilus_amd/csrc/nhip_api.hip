@@ -138,6 +138,12 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   L->pool4_rows = (L->S + 2 * L->pad + BNB_B4 - 1) / BNB_B4 + 2 * BNB_MAX_NB + 2;
   L->pool4_pitch = ((2 * ((L->S + 2 * L->pad + BNB_B4 - 1) / BNB_B4 + 2 * BNB_MAX_NB + 2) + 16) + 15) & ~15;
   L->pool4_bytes = (int64_t)L->pool4_rows * L->pool4_pitch;
+  // The matcher's planes behind the two tables are stored ONE CACHE LINE PER TILE (128 bytes): they must start on a line
+  // boundary in EVERY slot, or each tile read touches two lines.  (Round 5 appended the hit raster, whose size is not a
+  // multiple of 128: slots 1, 2, ... started 16, 32, ... bytes off a line, and the candidates kernel's L2 fetch went from 0.86
+  // to 1.39 GB per 10,000 pairs -- profiles/r06_cand_traffic_bisect.txt.)  So the second table is padded to the next line
+  // boundary of the slot here, and the raster -- the slot's last part -- below.
+  L->pool4_bytes += (128 - ((L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes) & 127)) & 127;
   // 16-bit cells: the plane of their high bytes, one byte per cell at the 8-bit pitch.  The matcher sums exact 8 x 8
   // and 4 x 4 blocks on this plane at the cost of 8-bit cells (256 * sum(hi) + 255 * points bounds a pose's sum from
   // above) and reads 16-bit cells only for the poses that bound still admits (nhip_bnb.hip)
@@ -151,6 +157,9 @@ int make_layout(const nhip_grid_spec_t *spec, GridLayout *L) {
   // the hit raster, one bit per cell + a zero border of HIT_PAD cells: bit rows of whole dwords
   L->hits_pitch = ((L->S + 2 * HIT_PAD + 31) / 32) * 4;
   L->hits_bytes = (((int64_t)L->hits_pitch * (L->S + 2 * HIT_PAD) + 8) + 15) & ~15ll;  // (+ 8: a row's last 64-bit window)
+  L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes + L->hi_bytes + L->hits_bytes;
+  L->hits_bytes += (128 - (L->slot_bytes & 127)) & 127;  // (every slot starts on a line boundary: see pool4_bytes above)
+  if (const char *sp = tunable("NHIP_GRID_SLOT_PAD")) L->hits_bytes += (int64_t)(atoi(sp) > 0 ? atoi(sp) : 0) * 128;  // (measurement: slot stride vs. channels)
   L->slot_bytes = L->grid_bytes + L->skip_bytes + L->pool_bytes + L->pool4_bytes + L->hi_bytes + L->hits_bytes;
   L->Lf = log(spec->floor_p);
   L->step = -L->Lf / (double)L->levels;
@@ -1098,8 +1107,9 @@ int nhip_grids_download_hits(const nhip_grids_t *grids, int32_t slot, uint8_t *o
 int nhip_grids_download_pool4(const nhip_grids_t *grids, int32_t slot, uint8_t *out) {
   NHIP_REQUIRE(grids && out && slot >= 0 && slot < grids->n, "grids_download_pool4: bad arguments");
   const GridLayout &L = grids->L;
+  // (rows x pitch: pool4_bytes may hold padding behind the table)
   NHIP_TRY_HIP(hipMemcpy(out, static_cast<const uint8_t *>(grids->grids.p) + (size_t)slot * L.slot_bytes + L.grid_bytes + L.skip_bytes + L.pool_bytes,
-                         (size_t)L.pool4_bytes, hipMemcpyDeviceToHost));
+                         (size_t)L.pool4_rows * (size_t)L.pool4_pitch, hipMemcpyDeviceToHost));
   return NHIP_OK;
 }
 
@@ -1408,15 +1418,26 @@ struct DropInScratch {
   // double[16] @16, search centre per part int32[16] @144, rotation base per part int32[8] @208}; res: the records
   // nhip_match_t[8] @0 and their sums int32[8] @128, downloaded in one copy
   DevBuf xy, par, idx, keys, res, delta1, delta2, ws;
+  // the chained form (both levels enqueued behind one another, ONE synchronisation per call): the fine level's parameter
+  // block is written on the device by dropin_bridge_kernel from the coarse record and a table of the (cos, sin) every
+  // coarse rotation would hand to the fine level (libm values, computed by the host per call); its keys, workspace and
+  // records are its own, the host's blocks travel through pinned memory
+  DevBuf par2, rot1, keys2, ws2;
+  void *pin = nullptr;  // pinned host staging: upload block (256 B of parameters + the table) | download block (512 B)
   size_t xy_cap = 0;
   int32_t n_theta1 = -1, n_theta2 = -1;
   double step1 = 0, step2 = 0;
 };
 // (a few KB of device memory per calling thread, freed when the thread ends: thread-local destructors -- the main thread's
 //  too -- run before the process's static destructors, i.e. while the HIP runtime is still there)
+constexpr int DROPIN_CHAIN_ROT_MAX = 512;               // coarse rotations the chained form's table holds
+constexpr size_t DROPIN_UP_BYTES = 256 + 16 * (size_t)DROPIN_CHAIN_ROT_MAX, DROPIN_DOWN_BYTES = 512;
 struct ScratchHolder {
   DropInScratch *p = nullptr;
-  ~ScratchHolder() { delete p; }
+  ~ScratchHolder() {
+    if (p && p->pin) (void)hipHostFree(p->pin);
+    delete p;
+  }
 };
 thread_local ScratchHolder t_scratch;
 
@@ -1427,6 +1448,7 @@ int scratch_for(int device, int32_t n_a, const nhip_search_t &s1, const nhip_sea
   // (a failure below leaves the scratch EMPTY -- device -1 -- so that the thread's next call sets it up again instead of
   //  finding the device it asked for and null buffers behind it)
   auto reset = [&S]() {
+    if (S.pin) (void)hipHostFree(S.pin);
     S.~DropInScratch();
     new (&S) DropInScratch();
   };
@@ -1434,10 +1456,16 @@ int scratch_for(int device, int32_t n_a, const nhip_search_t &s1, const nhip_sea
     reset();
     const int32_t zeros[2 * DROPIN_PARTS_MAX] = {0};
     constexpr size_t G = DROPIN_PARTS_MAX;
-    if ((rc = S.par.alloc(256)) || (rc = S.idx.alloc(8 * G)) || (rc = S.keys.alloc(8 * G)) || (rc = S.res.alloc(256)) ||
-        (rc = S.ws.alloc((size_t)bnb_workspace_bytes_lists((int32_t)G)))) {
+    if ((rc = S.par.alloc(256)) || (rc = S.idx.alloc(8 * G)) || (rc = S.keys.alloc(8 * G)) || (rc = S.res.alloc(DROPIN_DOWN_BYTES)) ||
+        (rc = S.ws.alloc((size_t)bnb_workspace_bytes_lists((int32_t)G))) || (rc = S.par2.alloc(256)) ||
+        (rc = S.rot1.alloc(DROPIN_UP_BYTES)) || (rc = S.keys2.alloc(8 * G)) ||
+        (rc = S.ws2.alloc((size_t)bnb_workspace_bytes_lists((int32_t)G)))) {
       reset();
       return rc;
+    }
+    if (hipHostMalloc(&S.pin, DROPIN_UP_BYTES + DROPIN_DOWN_BYTES, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      S.pin = nullptr;  // (no pinned memory: the call falls back to the form with one synchronisation per level)
     }
     const hipError_t e = hipMemcpy(S.idx.p, zeros, 8 * G, hipMemcpyHostToDevice);  // source scan 0, grid slot 0 for every part
     if (e != hipSuccess) {
@@ -1480,78 +1508,184 @@ int scratch_for(int device, int32_t n_a, const nhip_search_t &s1, const nhip_sea
 // kernels they are `parts` pairs of the same scan and table whose rotation 0 is entry kbase of the rotation table
 // (BnbParams::pair_kbase) -- and the host takes the best of their records: the larger sum, on a tie the smaller index
 // ((k * nx + ix) * ny + iy with the part's rotations counted from the search's first), which is the one-workgroup result.
-int match_one(DropInScratch &S, int32_t n_a, nhip_grids_t *g, const nhip_search_t *search, const void *d_delta, double theta0,
-              const int32_t *origin, nhip_match_t *m) {
-  int rc = ensure_skip_maps(g, search);
-  if (rc) return rc;
-  nhip_grid_spec_t spec_now;
-  {
-    std::lock_guard<std::mutex> lock(g->mu);
-    spec_now = g->spec;
-  }
-  // parts: the fewest (2 .. 8) that give every workgroup an odd number (the lattice's rule) of at most 8 rotations
-  int parts = 1, per = search->n_theta;
+struct DropInPar {  // the per-call parameter block as the kernels read it (device copy: DropInScratch::par / par2)
+  int32_t off[4];   // scan offsets {0, n_a}
+  double cs[2 * DROPIN_PARTS_MAX];   // (cos, sin) theta0 per part
+  int32_t org[2 * DROPIN_PARTS_MAX], kb[DROPIN_PARTS_MAX];  // search centre per part, rotation base per part
+};
+static_assert(sizeof(DropInPar) == 240 && offsetof(DropInPar, cs) == 16 && offsetof(DropInPar, org) == 144 &&
+              offsetof(DropInPar, kb) == 208, "DropInPar layout");
+struct DropInRes {
+  nhip_match_t rec[DROPIN_PARTS_MAX];
+  int32_t sums[DROPIN_PARTS_MAX];
+};
+static_assert(sizeof(DropInRes) == 160 && offsetof(DropInRes, sums) == 128, "DropInRes layout");
+
+// parts: the fewest (2 .. 8) that give every workgroup an odd number (the lattice's rule) of at most 8 rotations
+void dropin_parts(const nhip_grids_t *g, const nhip_search_t *search, int *parts, int *per) {
+  *parts = 1;
+  *per = search->n_theta;
   const char *one = tunable("NHIP_DROPIN_PARTS");  // (measurement: "1" keeps the search in one workgroup)
   const int q0 = one && atoi(one) >= 2 ? atoi(one) : 2;  // (measurement: at least that many parts)
   if (!csm_takes_exhaustive(g->L, search) && search->n_theta > 8 && !(one && one[0] == '1'))
     for (int q = q0; q <= DROPIN_PARTS_MAX; q++) {
       const int r = (search->n_theta + q - 1) / q;
       if ((r & 1) && r <= 8) {
-        parts = q;
-        per = r;
+        *parts = q;
+        *per = r;
         break;
       }
     }
-  struct Par {
-    int32_t off[4];
-    double cs[2 * DROPIN_PARTS_MAX];
-    int32_t org[2 * DROPIN_PARTS_MAX], kb[DROPIN_PARTS_MAX];
-  } par;
-  static_assert(sizeof(Par) == 240 && offsetof(Par, cs) == 16 && offsetof(Par, org) == 144 && offsetof(Par, kb) == 208, "Par layout");
+}
+
+// enqueue one level: scan 0 of the scratch against slot 0 of `g`, parameters in the device block `d_par` (DropInPar),
+// records into the device block `d_res` (DropInRes)
+int dropin_enqueue(DropInScratch &S, int32_t n_a, nhip_grids_t *g, const nhip_grid_spec_t &spec_now, const nhip_search_t *search,
+                   const void *d_delta, const void *d_par, bool with_origin, int parts, int per, void *d_keys, void *d_ws,
+                   size_t ws_bytes, void *d_res) {
+  const uint8_t *dp = static_cast<const uint8_t *>(d_par);
+  uint8_t *dr = static_cast<uint8_t *>(d_res);
+  nhip_search_t part = *search;
+  part.n_theta = per;
+  // (the host holds the cloud: a source that fits the matcher's by-rotation form saves the launch of the other instantiation)
+  if (n_a <= NHIP_SHORT_SCAN_POINTS) part.flags |= NHIP_SEARCH_SHORT_SCANS;
+  const IdBounds idb = {1, g->n, dev_status()};  // (the scratch holds one scan; every part reads scan 0, slot 0)
+  return launch_csm_match(static_cast<const float *>(S.xy.p), reinterpret_cast<const int32_t *>(dp), idb,
+                          static_cast<const uint8_t *>(g->grids.p), &spec_now, g->L, static_cast<const int32_t *>(S.idx.p),
+                          static_cast<const int32_t *>(S.idx.p) + DROPIN_PARTS_MAX, reinterpret_cast<const double *>(dp + 16),
+                          static_cast<const double *>(d_delta), with_origin ? reinterpret_cast<const int32_t *>(dp + 144) : nullptr,
+                          parts, &part, static_cast<uint64_t *>(d_keys), reinterpret_cast<nhip_match_t *>(dr),
+                          reinterpret_cast<int32_t *>(dr + 128), nullptr, d_ws, (int64_t)ws_bytes,
+                          parts > 1 ? reinterpret_cast<const int32_t *>(dp + 208) : nullptr);
+}
+
+// the best of the parts' records
+void dropin_pick(DropInRes &res, int parts, int per, const nhip_search_t *search, nhip_match_t *m) {
+  int best = -1;
+  int64_t best_lin = 0;
+  for (int q = 0; q < parts; q++) {
+    // (a copy of the last rotation past the table's end IS the last rotation)
+    res.rec[q].itheta = std::min(res.rec[q].itheta + q * per, search->n_theta - 1);
+    const int64_t lin = ((int64_t)res.rec[q].itheta * search->nx + res.rec[q].ix) * search->ny + res.rec[q].iy;
+    if (best < 0 || res.sums[q] > res.sums[best] || (res.sums[q] == res.sums[best] && lin < best_lin)) {
+      best = q;
+      best_lin = lin;
+    }
+  }
+  *m = res.rec[best];
+}
+
+int spec_under_lock(nhip_grids_t *g, nhip_grid_spec_t *out) {
+  std::lock_guard<std::mutex> lock(g->mu);
+  *out = g->spec;
+  return NHIP_OK;
+}
+
+int match_one(DropInScratch &S, int32_t n_a, nhip_grids_t *g, const nhip_search_t *search, const void *d_delta, double theta0,
+              const int32_t *origin, nhip_match_t *m) {
+  int rc = ensure_skip_maps(g, search);
+  if (rc) return rc;
+  nhip_grid_spec_t spec_now;
+  spec_under_lock(g, &spec_now);
+  int parts, per;
+  dropin_parts(g, search, &parts, &per);
+  DropInPar par;
   memset(&par, 0, sizeof(par));
   par.off[1] = n_a;
   if ((rc = nhip_csm_rot0(&theta0, nullptr, 1, par.cs))) return rc;
-  int32_t *kb = par.kb;
   for (int q = 0; q < parts; q++) {
     par.cs[2 * q] = par.cs[0];
     par.cs[2 * q + 1] = par.cs[1];
     par.org[2 * q] = origin ? origin[0] : 0;
     par.org[2 * q + 1] = origin ? origin[1] : 0;
-    kb[q] = q * per;
+    par.kb[q] = q * per;
   }
   NHIP_TRY_HIP(hipMemcpyAsync(S.par.p, &par, sizeof(par), hipMemcpyHostToDevice, nullptr));
-  uint8_t *dp = static_cast<uint8_t *>(S.par.p), *dr = static_cast<uint8_t *>(S.res.p);
-  nhip_search_t part = *search;
-  part.n_theta = per;
-  const IdBounds idb = {1, g->n, dev_status()};  // (the scratch holds one scan; every part reads scan 0, slot 0)
-  rc = launch_csm_match(static_cast<const float *>(S.xy.p), reinterpret_cast<const int32_t *>(dp), idb,
-                        static_cast<const uint8_t *>(g->grids.p), &spec_now, g->L, static_cast<const int32_t *>(S.idx.p),
-                        static_cast<const int32_t *>(S.idx.p) + DROPIN_PARTS_MAX, reinterpret_cast<const double *>(dp + 16),
-                        static_cast<const double *>(d_delta), origin ? reinterpret_cast<const int32_t *>(dp + 144) : nullptr, parts,
-                        &part, static_cast<uint64_t *>(S.keys.p), reinterpret_cast<nhip_match_t *>(dr),
-                        reinterpret_cast<int32_t *>(dr + 128), nullptr, S.ws.p, (int64_t)S.ws.bytes,
-                        parts > 1 ? reinterpret_cast<const int32_t *>(dp + 208) : nullptr);
-  if (rc) return rc;
-  struct Res {
-    nhip_match_t rec[DROPIN_PARTS_MAX];
-    int32_t sums[DROPIN_PARTS_MAX];
-  } res;
-  static_assert(sizeof(Res) == 160 && offsetof(Res, sums) == 128, "Res layout");
+  if ((rc = dropin_enqueue(S, n_a, g, spec_now, search, d_delta, S.par.p, origin != nullptr, parts, per, S.keys.p, S.ws.p, S.ws.bytes, S.res.p)))
+    return rc;
+  DropInRes res;
   NHIP_TRY_HIP(hipMemcpy(&res, S.res.p, sizeof(res), hipMemcpyDeviceToHost));
-  nhip_match_t *rec = res.rec;
-  const int32_t *sums = res.sums;
-  int best = -1;
-  int64_t best_lin = 0;
-  for (int q = 0; q < parts; q++) {
-    // (a copy of the last rotation past the table's end IS the last rotation)
-    rec[q].itheta = std::min(rec[q].itheta + kb[q], search->n_theta - 1);
-    const int64_t lin = ((int64_t)rec[q].itheta * search->nx + rec[q].ix) * search->ny + rec[q].iy;
-    if (best < 0 || sums[q] > sums[best] || (sums[q] == sums[best] && lin < best_lin)) {
-      best = q;
-      best_lin = lin;
-    }
+  dropin_pick(res, parts, per, search, m);
+  return NHIP_OK;
+}
+
+// The fine level's parameter block from the coarse level's record, on the device (one thread): the same arithmetic as
+// nhip_match_to_transform + the host code between the two levels -- products and quotients of doubles, individually
+// rounded (the library is compiled with -ffp-contract=off), conversions to float by round-to-nearest, lround -- so the host,
+// which repeats it on the downloaded coarse record to report the transform, arrives at the same origin.  The (cos, sin) of
+// the fine search's centre angle are NOT computed here: device and host libm differ in the last place; the host tabulates
+// its own values for every coarse rotation and the kernel picks the winner's.
+__global__ void dropin_bridge_kernel(const nhip_match_t *rec1, const double *rot1, int32_t hx1, int32_t hy1, double low_res,
+                                     double high_res, int32_t n_a, int32_t parts2, int32_t per2, DropInPar *par2, int32_t *info) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const nhip_match_t m = rec1[0];
+  const float tx1 = __double2float_rn(__dmul_rn((double)(m.ix - hx1), low_res));
+  const float ty1 = __double2float_rn(__dmul_rn((double)(m.iy - hy1), low_res));
+  const int32_t ox = (int32_t)lround(__ddiv_rn((double)tx1, high_res)), oy = (int32_t)lround(__ddiv_rn((double)ty1, high_res));
+  par2->off[0] = 0;
+  par2->off[1] = n_a;
+  par2->off[2] = par2->off[3] = 0;
+  const int32_t k = m.itheta < 0 ? 0 : (m.itheta >= DROPIN_CHAIN_ROT_MAX ? DROPIN_CHAIN_ROT_MAX - 1 : m.itheta);
+  const double c = rot1[2 * k], s_ = rot1[2 * k + 1];
+  for (int q = 0; q < DROPIN_PARTS_MAX; q++) {
+    par2->cs[2 * q] = c;
+    par2->cs[2 * q + 1] = s_;
+    par2->org[2 * q] = ox;
+    par2->org[2 * q + 1] = oy;
+    par2->kb[q] = q < parts2 ? q * per2 : 0;
   }
-  *m = rec[best];
+  info[0] = ox;
+  info[1] = oy;
+}
+
+// Both levels behind one another on the null stream, ONE synchronisation: upload (source cloud; coarse parameters + the
+// table of fine-centre rotations, one pinned block), coarse search, bridge, fine search (+ exact score), download of both
+// levels' records in one pinned block.  Same records as two match_one calls (tests/test_csm_gpu.py, test_adapters_gpu.py
+// compare the call with the oracle's two-level search float for float).  Returns NHIP_ERR_STATE when the form does not
+// apply (no pinned staging, more coarse rotations than the table holds): the caller takes the two-synchronisation form.
+int match_chained(DropInScratch &S, const float *pc_a, int32_t n_a, CachedTarget &T, const nhip_search_t &s1, const nhip_search_t &s2,
+                  const nhip_grid_spec_t &spec1, double theta0, nhip_match_t *m1, nhip_match_t *m2) {
+  if (!S.pin || s1.n_theta > DROPIN_CHAIN_ROT_MAX) return NHIP_ERR_STATE;
+  int rc;
+  if ((rc = ensure_skip_maps(T.g1, &s1)) || (rc = ensure_skip_maps(T.g2, &s2))) return rc;
+  nhip_grid_spec_t spec1_now, spec2_now;
+  spec_under_lock(T.g1, &spec1_now);
+  spec_under_lock(T.g2, &spec2_now);
+  int parts1, per1, parts2, per2;
+  dropin_parts(T.g1, &s1, &parts1, &per1);
+  dropin_parts(T.g2, &s2, &parts2, &per2);
+  if (parts1 != 1) return NHIP_ERR_STATE;  // (the bridge reads ONE coarse record; the coarse lattice is the every-add kernels')
+  uint8_t *up = static_cast<uint8_t *>(S.pin), *down = up + DROPIN_UP_BYTES;
+  DropInPar *par1 = reinterpret_cast<DropInPar *>(up);
+  memset(par1, 0, sizeof(*par1));
+  par1->off[1] = n_a;
+  if ((rc = nhip_csm_rot0(&theta0, nullptr, 1, par1->cs))) return rc;
+  // what the host would hand the fine level for each coarse rotation k: theta1 = (double)(float)(theta0 + (k - half) * step)
+  double *rot = reinterpret_cast<double *>(up + 256);
+  const int32_t half1 = (s1.n_theta - 1) / 2;
+  for (int32_t k = 0; k < s1.n_theta; k++) {
+    const double theta1 = (double)(float)(theta0 + (double)(k - half1) * s1.theta_step);
+    if ((rc = nhip_csm_rot0(&theta1, nullptr, 1, rot + 2 * k))) return rc;
+  }
+  const size_t up_bytes = 256 + 16 * (size_t)s1.n_theta;
+  if (n_a) NHIP_TRY_HIP(hipMemcpyAsync(S.xy.p, pc_a, sizeof(float) * 2 * (size_t)n_a, hipMemcpyHostToDevice, nullptr));
+  NHIP_TRY_HIP(hipMemcpyAsync(S.rot1.p, up, up_bytes, hipMemcpyHostToDevice, nullptr));
+  uint8_t *dres = static_cast<uint8_t *>(S.res.p);
+  if ((rc = dropin_enqueue(S, n_a, T.g1, spec1_now, &s1, S.delta1.p, S.rot1.p, false, 1, per1, S.keys.p, S.ws.p, S.ws.bytes, dres))) return rc;
+  hipLaunchKernelGGL(dropin_bridge_kernel, dim3(1), dim3(64), 0, nullptr, reinterpret_cast<const nhip_match_t *>(dres),
+                     reinterpret_cast<const double *>(static_cast<uint8_t *>(S.rot1.p) + 256), (s1.nx - 1) / 2, (s1.ny - 1) / 2,
+                     spec1.res, T.spec2.res, n_a, parts2, per2, static_cast<DropInPar *>(S.par2.p),
+                     reinterpret_cast<int32_t *>(dres + 480));
+  NHIP_TRY_HIP(hipGetLastError());
+  if ((rc = dropin_enqueue(S, n_a, T.g2, spec2_now, &s2, S.delta2.p, S.par2.p, true, parts2, per2, S.keys2.p, S.ws2.p, S.ws2.bytes, dres + 256)))
+    return rc;
+  NHIP_TRY_HIP(hipMemcpyAsync(down, dres, DROPIN_DOWN_BYTES, hipMemcpyDeviceToHost, nullptr));
+  NHIP_TRY_HIP(hipStreamSynchronize(nullptr));
+  DropInRes r1, r2;
+  memcpy(&r1, down, sizeof(r1));
+  memcpy(&r2, down + 256, sizeof(r2));
+  dropin_pick(r1, 1, per1, &s1, m1);
+  dropin_pick(r2, parts2, per2, &s2, m2);
   return NHIP_OK;
 }
 
@@ -1716,18 +1850,26 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
       }
     }
   }
-  // ---- the two searches of this source against the target's tables
+  // ---- the two searches of this source against the target's tables: chained on the device (one synchronisation per call),
+  // or -- no pinned staging, a coarse search of more rotations than the chain's table holds, NHIP_DROPIN_CHAIN=0 -- one after
+  // the other with the host in between
   DropInScratch *S = nullptr;
   if ((rc = scratch_for(device, n_a, s1, s2, &S))) return rc;
-  if (n_a) NHIP_TRY_HIP(hipMemcpyAsync(S->xy.p, pc_a, sizeof(float) * 2 * (size_t)n_a, hipMemcpyHostToDevice, nullptr));
-  if ((rc = match_one(*S, n_a, T->g1, &s1, S->delta1.p, theta0, nullptr, &m1))) return rc;
+  nhip_match_t m2;
+  const char *ch = tunable("NHIP_DROPIN_CHAIN");
+  rc = (ch && ch[0] == '0') ? NHIP_ERR_STATE : match_chained(*S, pc_a, n_a, *T, s1, s2, spec1, theta0, &m1, &m2);
+  const bool chained = rc == NHIP_OK;
+  if (rc != NHIP_OK && rc != NHIP_ERR_STATE) return rc;
+  if (!chained) {
+    if (n_a) NHIP_TRY_HIP(hipMemcpyAsync(S->xy.p, pc_a, sizeof(float) * 2 * (size_t)n_a, hipMemcpyHostToDevice, nullptr));
+    if ((rc = match_one(*S, n_a, T->g1, &s1, S->delta1.p, theta0, nullptr, &m1))) return rc;
+  }
   if ((rc = nhip_match_to_transform(&m1, &spec1, &s1, theta0, 0, 0, &tx1, &ty1, &th1))) return rc;
   const int32_t origin[2] = {(int32_t)lround((double)tx1 / p->high_res), (int32_t)lround((double)ty1 / p->high_res)};
   NHIP_REQUIRE(std::max(abs(origin[0]), abs(origin[1])) + ratio <= reach_max, "csm_get_transformation: coarse optimum (%d, %d) beyond "
                "the fine tables' reach %d", origin[0], origin[1], reach_max);
   const double theta1 = th1;
-  nhip_match_t m2;
-  if ((rc = match_one(*S, n_a, T->g2, &s2, S->delta2.p, theta1, origin, &m2))) return rc;
+  if (!chained && (rc = match_one(*S, n_a, T->g2, &s2, S->delta2.p, theta1, origin, &m2))) return rc;
   if ((rc = nhip_match_to_transform(&m2, &T->spec2, &s2, theta1, origin[0], origin[1], tx, ty, theta))) return rc;
   *score = (double)m2.score;
   return NHIP_OK;

@@ -1857,12 +1857,17 @@ __global__ __launch_bounds__(SORT_THREADS) void csm_bnb_order_kernel(BnbParams P
   }
   __syncthreads();
   // the pairs with candidates, in pair order EXACTLY (a prefix sum, not atomics whose order scrambles windows of 1024 pairs)
+  // -- in two passes when P.front_min is set: first the pairs with at least that many candidates left (a few per cent of
+  // the list, a third of its work: a workgroup of theirs runs for 0.3 - 2 ms, and one that the in-order dispatch starts in
+  // the launch's last half millisecond IS the launch's tail), then the others, whose workgroups take 0.03 - 0.2 ms
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  for (int pass = P.front_min ? 0 : 1; pass < 2; pass++)
   for (int32_t p0 = lo; p0 < hi; p0 += SORT_THREADS) {
     const int32_t p = p0 + (int32_t)threadIdx.x;
     const uint32_t c = p < hi ? P.ps_count[p] : 0u;
-    const uint32_t w = c != 0u ? (cand_bucket(c) < s_grant ? cand_shares(P, c) : 1u) : 0u;
-    if (p < hi) P.ps_nw[p] = c != 0u ? w : 1u;
+    const bool mine = P.front_min == 0u || ((c >= P.front_min) == (pass == 0));
+    const uint32_t w = (c != 0u && mine) ? (cand_bucket(c) < s_grant ? cand_shares(P, c) : 1u) : 0u;
+    if (p < hi && mine) P.ps_nw[p] = c != 0u ? w : 1u;
     uint32_t v = w;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {

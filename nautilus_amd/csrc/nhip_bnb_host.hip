@@ -280,6 +280,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &
   // workgroup of a pair>, NHIP_BNB_SPLIT_MAX=<workgroups per pair>.
   const char *smin = tunable("NHIP_BNB_SPLIT_MIN");
   const char *smax = tunable("NHIP_BNB_SPLIT_MAX");
+  const char *sfront = tunable("NHIP_BNB_FRONT_MIN");  // (measurement: pairs with at least that many candidates first)
   const char *sov = tunable("NHIP_BNB_SPLIT_OVERLAP");
   if (P.rot_list) split_batch = 0;  // (hand-over lists in the workspace: one kernel per pair)
   // (an error return between timer_begin and timer_end closes the open slot)
@@ -334,6 +335,7 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &
       Q.ps_work_stride = Q.pairs_per_xcd + (Q.pairs_per_xcd / 2 > 64 ? Q.pairs_per_xcd / 2 : 64);
       Q.split_min = smin ? (uint32_t)(atoi(smin) > 0 ? atoi(smin) : 1) : 300u;
       Q.split_max = smax ? (uint32_t)(atoi(smax) > 0 ? atoi(smax) : 1) : (nb < SPREAD_BELOW_PAIRS ? 16u : 8u);
+      Q.front_min = sfront ? (uint32_t)(atoi(sfront) > 0 ? atoi(sfront) : 0) : 0u;
       uint8_t *w = base + (round % split_slots) * slot_bytes;
       Q.ps_count = reinterpret_cast<uint32_t *>(w);
       Q.ps_live = Q.ps_count + nb;

@@ -60,6 +60,7 @@ struct BnbParams {
   int32_t ps_work_stride;
   uint32_t split_min;   // candidates per additional workgroup of a pair
   uint32_t split_max;   // workgroups per pair at most
+  uint32_t front_min;   // candidates from which a pair's workgroups go to the FRONT of its XCD's list (0: pair order throughout)
   int32_t pair_base;    // index of this launch's pair 0 in the caller's arrays (rounds of the split form): what a bad id is reported at
   int32_t n_pairs, n_theta, nx, ny, hx, hy, nbx, nby;
   int32_t S, pad, pitch, rows, max_shift;

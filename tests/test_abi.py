@@ -52,8 +52,15 @@ def test_grid_layout_follows_cimg_debug():
     # the matcher's tiled 8-bit plane (8-bit grids: the cells themselves): two copies of 174 x 88 tiles of 8 rows x 16 bytes
     assert L.hi_pitch == 1392 and L.hi_bytes == 2 * 174 * 88 * 128
     # the hit raster: one bit per cell + a border of 32 cells: 1264 bit rows of 40 dwords
-    assert L.hits_pitch == 160 and L.hits_bytes == (160 * 1264 + 8 + 15) // 16 * 16
-    assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes + L.hits_bytes and L.slot_bytes % 16 == 0
+    # (+ padding to the next 128-byte boundary of the slot: the raster is the slot's last part)
+    assert L.hits_pitch == 160 and (160 * 1264 + 8) <= L.hits_bytes < (160 * 1264 + 8) + 16 + 128
+    assert L.slot_bytes == L.grid_bytes + L.skip_bytes + L.pool_bytes + L.pool4_bytes + L.hi_bytes + L.hits_bytes
+    # the matcher's tiled planes hold one 128-byte cache line per tile: they start on a line boundary in EVERY slot
+    for lay in (L, csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40)), csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, no_image=True)),
+                csm.grid_layout(csm.grid_spec(10.0, 0.03, 1.0, 1e-10, 7)), csm.grid_layout(csm.grid_spec(30.0, 0.3, 2.0, 1e-10, 6)),
+                csm.grid_layout(csm.grid_spec(17.0, 0.07, 2.0, 1e-10, 11, cell_bits=8, no_image=True))):
+        assert lay.slot_bytes % 128 == 0 and (lay.grid_bytes + lay.skip_bytes + lay.pool_bytes + lay.pool4_bytes) % 128 == 0
+        assert lay.pool4_bytes >= lay.pool4_rows * lay.pool4_pitch
     assert abs(L.score_floor - math.log(1e-10)) < 1e-15
     L16 = csm.grid_layout(csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40))  # the default width: 16-bit cells (0 means 16 too)
     zero = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits=0)

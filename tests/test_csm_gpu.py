@@ -1409,7 +1409,8 @@ def test_grids_without_the_row_major_image(gpu, small_bag, cell_bits):
     full_spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits)
     spec = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, cell_bits, no_image=True)
     Lf_, L = csm.grid_layout(full_spec), csm.grid_layout(spec)
-    assert L.grid_bytes == 0 and L.skip_bytes == 0 and L.slot_bytes == Lf_.slot_bytes - Lf_.grid_bytes - Lf_.skip_bytes
+    # (up to the padding that keeps every slot's tiled planes on cache-line boundaries)
+    assert L.grid_bytes == 0 and L.skip_bytes == 0 and abs(L.slot_bytes - (Lf_.slot_bytes - Lf_.grid_bytes - Lf_.skip_bytes)) < 256
     assert L.slot_bytes < 0.70 * Lf_.slot_bytes
     bad = csm.grid_spec(30.0, 0.05, 2.0, 1e-10, 40, 16, skip_map=True, no_image=True)
     assert lib.nhip_grid_layout(C.byref(bad), C.byref(_lib.GridLayout())) == _lib.NHIP_ERR_ARG
