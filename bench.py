@@ -1393,6 +1393,25 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
         for _ in range(3):
             ev(False)
         dt_r = (time.perf_counter() - t0) / 3
+        # the smallest form (round 6): residuals + q + 8 constants per block down, 32 B per correspondence; both Jacobians are
+        # rebuilt on the host from them (nhip_resid_jacobians_from_q, inside the consumer's per-block copy)
+        h_q, h_c = pin(2 * n_corr), np.empty(8 * n_blocks)
+        evq = lambda: _lib.check(lib.nhip_resid_batch_eval_q(hnd, _lib.ptr(h_poses), _lib.ptr(h_r), _lib.ptr(h_q), _lib.ptr(h_c)))
+        evq()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            evq()
+        dt_q = (time.perf_counter() - t0) / 3
+        kq = min(n_blocks, 64)   # (rebuild a sample of blocks on one host thread: the consumer does it per block, on its own threads)
+        jq_s, jq_t = np.empty(6 * kq * n_per), np.empty(6 * kq * n_per)
+        t0 = time.perf_counter()
+        for b in range(kq):
+            _lib.check(lib.nhip_resid_jacobians_from_q(0, _lib.ptr(h_corr[b * n_per:(b + 1) * n_per]), _lib.ptr(h_q[2 * b * n_per:2 * (b + 1) * n_per]),
+                                                       _lib.ptr(h_c[8 * b:8 * b + 8]), n_per, _lib.ptr(jq_s[6 * b * n_per:6 * (b + 1) * n_per]),
+                                                       _lib.ptr(jq_t[6 * b * n_per:6 * (b + 1) * n_per])))
+        dt_rebuild = (time.perf_counter() - t0) / (kq * n_per)
+        q_ok = bool(np.allclose(jq_s, js[:6 * kq * n_per].cpu().numpy(), rtol=1e-12, atol=1e-12) and
+                    np.allclose(jq_t, jt[:6 * kq * n_per].cpu().numpy(), rtol=1e-12, atol=1e-12))
         jt_h = jt.cpu().numpy().reshape(-1, 3)
         same = bool(np.array_equal(h_js, js.cpu().numpy()) and np.array_equal(h_jtt, jt_h[:, 2]) and
                     np.array_equal(jt_h[:, :2], -h_js.reshape(-1, 3)[:, :2]))
@@ -1406,14 +1425,18 @@ def bench_residuals(torch, lib, dev, sp, with_cpu=False, n_blocks=9945, n_per=10
         del p_r, p_js, p_jt
         lib.nhip_resid_batch_free(hnd)
         out["host_buffer_api"] = {
-            "seconds_per_eval_with_jacobians": dt_j, "seconds_per_eval_residuals_only": dt_r,
-            "correspondences_per_s_with_jacobians": n_corr / dt_j, "bytes_to_host_with_jacobians": 80.0 * n_corr,
+            "seconds_per_eval_with_jacobians": dt_q, "bytes_to_host_with_jacobians": 32.0 * n_corr + 64.0 * n_blocks,
+            "host_rebuild_ns_per_correspondence_one_thread": 1e9 * dt_rebuild, "rebuilt_jacobians_equal_device_to_1e-12": q_ok,
+            "seconds_per_eval_compact_80B_form": dt_j, "seconds_per_eval_residuals_only": dt_r,
+            "correspondences_per_s_with_jacobians": n_corr / dt_q,
             "seconds_per_eval_full_jacobians_pageable": dt_full,
             "same_result_as_device_api": same,
-            "note": "nhip_resid_batch_eval: 24 KB of poses up; residuals, J_src and the theta column of J_tgt down over "
-                    "PCIe through pinned staging (the x, y columns of J_tgt are -J_src's and are rebuilt on the host); "
-                    "the per-block normal equations (icp_front_half) move 224 B per BLOCK instead"}
-        del h_r, h_js, h_jtt
+            "note": "nhip_resid_batch_eval_q: 24 KB of poses up; residuals, q = S2T p_s and 8 constants per block down into "
+                    "pinned memory (32 B per correspondence), both Jacobians rebuilt by the consumer per block "
+                    "(nhip_resid_jacobians_from_q; the C++ adapter does it while it copies a block's slice); the 80 B form "
+                    "(J_src + the theta column of J_tgt shipped) beside it; the per-block normal equations (icp_front_half) "
+                    "move 224 B per BLOCK instead"}
+        del h_r, h_js, h_jtt, h_q
     except Exception as e:
         out["host_buffer_api_error"] = repr(e)
     if with_cpu:

@@ -515,6 +515,10 @@ int nhip_csm_cache_stats(int64_t *entries, int64_t *bytes, int64_t *hits, int64_
 int nhip_csm_get_transformation(const nhip_csm_params_t *params, const float *pc_a, int32_t n_a, const float *pc_b,
                                 int32_t n_b, double rot_a, double rot_b, double rot_restriction, double *score,
                                 float *tx, float *ty, float *theta);
+/* What the calling thread's last cached-target nhip_csm_get_transformation did: {the coarse optimum's score, 1 if the fine
+ * level went to the kernels that perform every add (0: the branch-and-bound matcher), 1 if the two levels were chained on the
+ * device, the coarse optimum's rotation index}.  (Measurement / tests.) */
+int nhip_csm_get_transformation_info(double out[4]);
 
 /* Residual batch: all LIDAR residual blocks of one ceres::Problem build (immutable after
  * creation, like the functors' copied vectors, slam_residuals.h:117-120). */
@@ -530,6 +534,18 @@ int nhip_resid_batch_eval(nhip_resid_batch_t *batch, const double *poses, double
  * copies its slice: 80 instead of 112 bytes per correspondence cross PCIe. */
 int nhip_resid_batch_eval_compact(nhip_resid_batch_t *batch, const double *poses, double *residuals,
                                   double *jac_src, double *jac_tgt_theta);
+/* The same evaluation in its SMALLEST form over PCIe: per correspondence the residual pair and q = S2T p_s (the source point
+ * in the target's frame, slam_residuals.h:78), per block the 8 constants {S2T's linear part l00 l01 l10 l11, its
+ * translation tx ty, and i00 i01 of inverse(A(target_pose))'s linear part (i10 = -i01, i11 = i00)}.  Every Jacobian entry
+ * ceres::AutoDiffCostFunction derives for these functors (slam_residuals.h:104-115, 160-171) is a closed form of q, those
+ * constants and the correspondence's own points / normals, which the host holds: a consumer rebuilds the
+ * rows of its block while it copies its slice -- nhip_resid_jacobians_from_q does exactly that, on the host, for `n` rows
+ * of ONE block (corr: its n x 8 floats; q: its n x 2 doubles; block_consts: its 8 doubles; jac_src / jac_tgt: 6 n doubles
+ * or NULL).  32 instead of 80 (compact) / 112 (full) bytes per correspondence cross PCIe; the Jacobians agree with
+ * nhip_resid_batch_eval's to 1e-14 relative (u is recovered as q - t). */
+int nhip_resid_batch_eval_q(nhip_resid_batch_t *batch, const double *poses, double *residuals, double *q, double *block_consts);
+int nhip_resid_jacobians_from_q(int kind, const float *corr, const double *q, const double *block_consts, int64_t n,
+                                double *jac_src, double *jac_tgt);
 /* ONE block of the batch at explicitly given parameter blocks (source_pose[3], target_pose[3]): what a
  * ceres::CostFunction::Evaluate() called outside the batched evaluation point needs (Problem::Evaluate,
  * Covariance::Compute, a rejected trial step).  residuals: 2 n_b doubles; jac_src / jac_tgt: n_b x 2 rows of 3

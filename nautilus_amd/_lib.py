@@ -86,6 +86,7 @@ PROTOTYPES = {
                                      _P(Search), _vp, _vp, _vp, _vp, _i64, _vp]),
     "nhip_csm_workspace_bytes": (_i64, [_i32]),
     "nhip_csm_last_launch": (C.c_int, [_P(_i32)]),
+    "nhip_csm_get_transformation_info": (C.c_int, [_vp]),
     "nhip_bnb_stats": (C.c_int, [_P(C.c_uint64), _P(C.c_uint64)]),
     "nhip_bnb_stats_per_pair": (C.c_int, [_vp, _i32]),
     "nhip_bnb_timeline": (C.c_int, [_vp, _i32]),
@@ -134,6 +135,8 @@ PROTOTYPES = {
     "nhip_resid_batch_create": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _i32, _i32, _P(_vp)]),
     "nhip_resid_batch_eval": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
     "nhip_resid_batch_eval_compact": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "nhip_resid_batch_eval_q": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "nhip_resid_jacobians_from_q": (C.c_int, [C.c_int, _vp, _vp, _vp, _i64, _vp, _vp]),
     "nhip_resid_batch_eval_block": (C.c_int, [_vp, _i32, _vp, _vp, _vp, _vp, _vp]),
     "nhip_resid_batch_free": (C.c_int, [_vp]),
     "nhip_host_alloc": (C.c_int, [C.c_size_t, _P(_vp)]),

@@ -261,8 +261,18 @@ int main(int argc, char **argv) {
   B.PrepareForEvaluation(true, true);
   REQUIRE(c0->Evaluate(params, r.data(), jac));
   REQUIRE(B.slow_path_calls() == 1);  // served from the batch
-  // batched (compact target Jacobian rebuilt from J_src) == single-block (full target Jacobian from the kernel), bit for bit
-  REQUIRE(r == r_one && j0 == j0_one && j1 == j1_one);
+  // batched (both Jacobians rebuilt on the host from q = S2T p_s and the block's constants: 32 B per correspondence over
+  // PCIe) against single-block (both Jacobians from the kernel): residuals bit for bit, Jacobian entries to rounding -- the
+  // host recovers u as q - t where the kernel had u before it added t
+  REQUIRE(r == r_one);
+  {
+    double worst = 0;
+    for (size_t i = 0; i < j0.size(); i++) {
+      worst = std::fmax(worst, std::fabs(j0[i] - j0_one[i]) / (1.0 + std::fabs(j0_one[i])));
+      worst = std::fmax(worst, std::fabs(j1[i] - j1_one[i]) / (1.0 + std::fabs(j1_one[i])));
+    }
+    REQUIRE(worst < 1e-13);
+  }
   // central differences through the same path (residual-only evaluations)
   double maxerr = 0;
   for (int k = 0; k < 3; k++) {
@@ -294,7 +304,9 @@ int main(int argc, char **argv) {
     std::memcpy(poses[0], moved, sizeof(moved));
     B.PrepareForEvaluation(true, true);
     REQUIRE(c0->Evaluate(params, r.data(), jac));
-    REQUIRE(r == rs && j0 == js0 && j1 == js1);
+    REQUIRE(r == rs);  // (Jacobians: the batch rebuilds them on the host from q, the single block gets the kernel's -- equal to rounding)
+    for (size_t i = 0; i < j0.size(); i++)
+      REQUIRE(std::fabs(j0[i] - js0[i]) <= 1e-13 * (1.0 + std::fabs(js0[i])) && std::fabs(j1[i] - js1[i]) <= 1e-13 * (1.0 + std::fabs(js1[i])));
     std::memcpy(poses[0], keep, sizeof(keep));
     B.PrepareForEvaluation(true, true);
   }

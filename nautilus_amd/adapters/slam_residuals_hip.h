@@ -232,10 +232,13 @@ class ResidualBatcher : public EvaluationCallbackBase {
       const size_t n = (size_t)rows_total_[k] / 2;
       res_[k].reserve(2 * n);
       if (J) {
-        j0_[k].reserve(6 * n);
+        // the smallest form over PCIe: residuals, q = S2T p_s per correspondence and 8 constants per block (32 bytes per
+        // correspondence instead of 80); a block's Jacobian rows are rebuilt from them and the block's own points and
+        // normals while its slice is copied (CopyPrepared -> nhip_resid_jacobians_from_q)
         jtt_[k].reserve(2 * n);
-        Check(nhip_resid_batch_eval_compact(batch_[k], poses.data(), res_[k].data(), j0_[k].data(), jtt_[k].data()),
-              "nhip_resid_batch_eval_compact");
+        consts_[k].resize(8 * live_[k].size());
+        Check(nhip_resid_batch_eval_q(batch_[k], poses.data(), res_[k].data(), jtt_[k].data(), consts_[k].data()),
+              "nhip_resid_batch_eval_q");
       } else {
         Check(nhip_resid_batch_eval(batch_[k], poses.data(), res_[k].data(), nullptr, nullptr), "nhip_resid_batch_eval");
       }
@@ -378,18 +381,16 @@ class ResidualBatcher : public EvaluationCallbackBase {
     const size_t r_off = (size_t)b.row0, r_n = (size_t)b.rows;
     std::memcpy(residuals, res_[family].data() + r_off, sizeof(double) * r_n);
     if (!jacobians) return;
+    if (family <= kLidarPoint) {
+      // both Jacobians of the block from its q values (2 doubles per correspondence = per two rows), the block's 8
+      // constants and its own points / normals: the closed forms of the device kernel, evaluated here
+      Check(nhip_resid_jacobians_from_q(family, b.data.data(), jtt_[family].data() + r_off, consts_[family].data() + 8 * (size_t)b.slot,
+                                        (int64_t)(r_n / 2), jacobians[0], jacobians[1]), "nhip_resid_jacobians_from_q");
+      return;
+    }
     const double *js = j0_[family].data() + 3 * r_off;
     if (jacobians[0]) std::memcpy(jacobians[0], js, sizeof(double) * 3 * r_n);
-    if (jacobians[1]) {
-      if (family <= kLidarPoint) {
-        // rows of J_tgt: the negated x, y entries of J_src's row and the shipped theta entry
-        const double *th = jtt_[family].data() + r_off;
-        double *jt = jacobians[1];
-        for (size_t i = 0; i < r_n; i++) { jt[3 * i] = -js[3 * i]; jt[3 * i + 1] = -js[3 * i + 1]; jt[3 * i + 2] = th[i]; }
-      } else {
-        std::memcpy(jacobians[1], j1_[family].data() + 3 * r_off, sizeof(double) * 3 * r_n);
-      }
-    }
+    if (jacobians[1]) std::memcpy(jacobians[1], j1_[family].data() + 3 * r_off, sizeof(double) * 3 * r_n);
   }
   // Slow path: this block alone, on the GPU, at the parameters passed in.
   bool EvaluateOne(Block *b, double const *const *parameters, double *residuals, double **jacobians) {
@@ -435,7 +436,8 @@ class ResidualBatcher : public EvaluationCallbackBase {
   // LIDAR families: the device batch and the parameter-block pattern it was built for
   std::vector<int32_t> bsrc_[2], btgt_[2];
   nhip_resid_batch_t *batch_[2] = {nullptr, nullptr};
-  PinnedDoubles jtt_[2];  // theta column of J_tgt, 2 per correspondence
+  PinnedDoubles jtt_[2];  // q = S2T p_s, 2 doubles per correspondence (nhip_resid_batch_eval_q)
+  std::vector<double> consts_[2];  // per block of the LIDAR families: S2T's linear part and translation, Linv's first row
   // staging of the two small families (rebuilt per pass: a few KB)
   std::vector<float> t_odom_, r_odom_, seg_, p2l_pts_;
   std::vector<int32_t> p2l_block_;

@@ -488,7 +488,7 @@ struct nhip_grids {
 };
 
 struct nhip_resid_batch {
-  nhip::DevBuf corr, corr_block, block_src, block_tgt, consts, poses, res, jsrc, jtgt, jtt;
+  nhip::DevBuf corr, corr_block, block_src, block_tgt, consts, poses, res, jsrc, jtgt, jtt;  // (jtt also holds q: nhip_resid_batch_eval_q)
   nhip::DevBuf one_poses, one_consts, one_idx;  // single-block evaluation: 2 poses, 8 constants, {0, 1}
   std::vector<int32_t> h_offsets;
   std::mutex one_mu;
@@ -1430,6 +1430,13 @@ struct DropInScratch {
 };
 // (a few KB of device memory per calling thread, freed when the thread ends: thread-local destructors -- the main thread's
 //  too -- run before the process's static destructors, i.e. while the HIP runtime is still there)
+// coarse score (mean log-likelihood on the low_res table) below which the fine level goes to the every-add kernels
+// (profiles/r06_dropin_fine_level.txt, 50 sources against two targets at the reference's constants: matching clouds score
+//  -1.44 .. -1.7 on the coarse table and take 0.27-0.41 ms by branch and bound against 0.39-0.53 by every add; from -1.8 down
+//  every add wins, by up to 40x -- 0.22 against 10 ms; mean over the 50: 0.33 ms with this threshold, 1.39 always by branch and
+//  bound, 0.36 always by every add, 0.32 with hindsight)
+constexpr double DROPIN_FINE_EVERY_ADD_BELOW = -1.75;
+static thread_local double t_dropin_info[4] = {0, 0, 0, 0};
 constexpr int DROPIN_CHAIN_ROT_MAX = 512;               // coarse rotations the chained form's table holds
 constexpr size_t DROPIN_UP_BYTES = 256 + 16 * (size_t)DROPIN_CHAIN_ROT_MAX, DROPIN_DOWN_BYTES = 512;
 struct ScratchHolder {
@@ -1725,6 +1732,12 @@ int nhip_csm_cache_stats(int64_t *entries, int64_t *bytes, int64_t *hits, int64_
   return NHIP_OK;
 }
 
+int nhip_csm_get_transformation_info(double out[4]) {
+  NHIP_REQUIRE(out != nullptr, "csm_get_transformation_info: null out");
+  for (int i = 0; i < 4; i++) out[i] = t_dropin_info[i];
+  return NHIP_OK;
+}
+
 int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, int32_t n_a, const float *pc_b,
                                 int32_t n_b, double rot_a, double rot_b, double rot_restriction, double *score,
                                 float *tx, float *ty, float *theta) {
@@ -1759,7 +1772,9 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   const int32_t reach_max = (int32_t)lround((double)h1 * p->low_res / p->high_res) + ratio + 2;
   // (the score the call returns is the fine optimum's on the UNQUANTISED table -- NHIP_SEARCH_EXACT_SCORE: the reference's
   //  table holds doubles, cimg_debug.h:19; both searches run on the quantised tables)
-  const nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1, NHIP_SEARCH_EXACT_SCORE, coarse_step / 10.0};
+  const char *l2 = tunable("NHIP_DROPIN_FINE");  // (measurement: "every_add" sends the fine level through the kernels that perform every add)
+  const nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1,
+                            NHIP_SEARCH_EXACT_SCORE | ((l2 && l2[0] == 'e') ? NHIP_SEARCH_EXHAUSTIVE : 0), coarse_step / 10.0};
   const bool cacheable = reach_max <= 4096 && n_b > 0;
 
   // ---- the target's tables: from the cache, or built now
@@ -1850,14 +1865,22 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
       }
     }
   }
-  // ---- the two searches of this source against the target's tables: chained on the device (one synchronisation per call),
-  // or -- no pinned staging, a coarse search of more rotations than the chain's table holds, NHIP_DROPIN_CHAIN=0 -- one after
-  // the other with the host in between
+  // ---- the two searches of this source against the target's tables.
+  // WHICH kernels take the fine level is decided by the coarse optimum's score (round 6, profiles/r06_dropin_fine_level.txt):
+  // the branch-and-bound matcher is the faster one where the clouds match (0.28 against 0.53 ms per call), and three to six
+  // times slower than the kernels that perform every add where they do not -- a flat landscape leaves it thousands of
+  // candidate blocks, while the every-add kernels skip the window strips the skip map shows empty (1.19 against 0.21 ms).
+  // Same records either way.  The host therefore looks at the coarse record before it enqueues the fine level: one
+  // synchronisation more than the chained form (NHIP_DROPIN_FINE=bnb / every_add forces one and chains; measured: the
+  // chain is worth 5 us of a 275 us call).
   DropInScratch *S = nullptr;
   if ((rc = scratch_for(device, n_a, s1, s2, &S))) return rc;
   nhip_match_t m2;
   const char *ch = tunable("NHIP_DROPIN_CHAIN");
-  rc = (ch && ch[0] == '0') ? NHIP_ERR_STATE : match_chained(*S, pc_a, n_a, *T, s1, s2, spec1, theta0, &m1, &m2);
+  const char *fs = tunable("NHIP_DROPIN_FINE_SCORE");  // (measurement: the coarse score below which the fine level takes every add)
+  const double fine_score = fs ? atof(fs) : DROPIN_FINE_EVERY_ADD_BELOW;
+  const bool forced = l2 && (l2[0] == 'e' || l2[0] == 'b');
+  rc = (!forced || (ch && ch[0] == '0')) ? NHIP_ERR_STATE : match_chained(*S, pc_a, n_a, *T, s1, s2, spec1, theta0, &m1, &m2);
   const bool chained = rc == NHIP_OK;
   if (rc != NHIP_OK && rc != NHIP_ERR_STATE) return rc;
   if (!chained) {
@@ -1869,7 +1892,13 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   NHIP_REQUIRE(std::max(abs(origin[0]), abs(origin[1])) + ratio <= reach_max, "csm_get_transformation: coarse optimum (%d, %d) beyond "
                "the fine tables' reach %d", origin[0], origin[1], reach_max);
   const double theta1 = th1;
-  if (!chained && (rc = match_one(*S, n_a, T->g2, &s2, S->delta2.p, theta1, origin, &m2))) return rc;
+  nhip_search_t s2_now = s2;
+  if (!forced && (double)m1.score < fine_score) s2_now.flags |= NHIP_SEARCH_EXHAUSTIVE;
+  t_dropin_info[0] = (double)m1.score;
+  t_dropin_info[1] = (s2_now.flags & NHIP_SEARCH_EXHAUSTIVE) ? 1.0 : 0.0;
+  t_dropin_info[2] = chained ? 1.0 : 0.0;
+  t_dropin_info[3] = (double)m1.itheta;
+  if (!chained && (rc = match_one(*S, n_a, T->g2, &s2_now, S->delta2.p, theta1, origin, &m2))) return rc;
   if ((rc = nhip_match_to_transform(&m2, &T->spec2, &s2, theta1, origin[0], origin[1], tx, ty, theta))) return rc;
   *score = (double)m2.score;
   return NHIP_OK;
@@ -1978,6 +2007,62 @@ int nhip_resid_batch_eval_compact(nhip_resid_batch_t *B, const double *poses, do
   NHIP_TRY_HIP(hipMemcpyAsync(jac_src, B->jsrc.p, sizeof(double) * 6 * (size_t)B->n_corr, hipMemcpyDeviceToHost, nullptr));
   NHIP_TRY_HIP(hipMemcpyAsync(jac_tgt_theta, B->jtt.p, sizeof(double) * 2 * (size_t)B->n_corr, hipMemcpyDeviceToHost, nullptr));
   NHIP_TRY_HIP(hipStreamSynchronize(nullptr));
+  return NHIP_OK;
+}
+
+int nhip_resid_batch_eval_q(nhip_resid_batch_t *B, const double *poses, double *residuals, double *q, double *block_consts) {
+  int rc = require_device();
+  if (rc) return rc;
+  NHIP_REQUIRE(B && poses && residuals && q && block_consts, "resid_batch_eval_q: bad arguments");
+  if (B->n_corr == 0) return NHIP_OK;
+  NHIP_TRY_HIP(hipMemcpy(B->poses.p, poses, sizeof(double) * 3 * (size_t)B->n_poses, hipMemcpyHostToDevice));
+  // (residual-only instantiation + one more 16-byte store per correspondence; q goes where the compact form keeps J_tgt's
+  //  theta column: the two forms of one batch are not in flight together -- the handle's calls synchronise)
+  rc = launch_resid_lidar(B->kind, static_cast<const float *>(B->corr.p), static_cast<const int32_t *>(B->corr_block.p),
+                          B->n_corr, static_cast<const int32_t *>(B->block_src.p),
+                          static_cast<const int32_t *>(B->block_tgt.p), B->n_blocks,
+                          static_cast<const double *>(B->poses.p), B->n_poses, static_cast<double *>(B->consts.p),
+                          static_cast<double *>(B->res.p), nullptr, nullptr, nullptr, nullptr, 0, static_cast<double *>(B->jtt.p));
+  if (rc) return rc;
+  NHIP_TRY_HIP(hipMemcpyAsync(residuals, B->res.p, sizeof(double) * 2 * (size_t)B->n_corr, hipMemcpyDeviceToHost, nullptr));
+  NHIP_TRY_HIP(hipMemcpyAsync(q, B->jtt.p, sizeof(double) * 2 * (size_t)B->n_corr, hipMemcpyDeviceToHost, nullptr));
+  NHIP_TRY_HIP(hipMemcpyAsync(block_consts, B->consts.p, sizeof(double) * 8 * (size_t)B->n_blocks, hipMemcpyDeviceToHost, nullptr));
+  NHIP_TRY_HIP(hipStreamSynchronize(nullptr));
+  return NHIP_OK;
+}
+
+int nhip_resid_jacobians_from_q(int kind, const float *corr, const double *q, const double *block_consts, int64_t n,
+                                double *jac_src, double *jac_tgt) {
+  NHIP_REQUIRE(kind == NHIP_LIDAR_NORMAL || kind == NHIP_LIDAR_POINT, "resid_jacobians_from_q: bad kind %d", kind);
+  NHIP_REQUIRE(n >= 0 && (n == 0 || (corr && q && block_consts)), "resid_jacobians_from_q: bad arguments");
+  // the closed forms of resid_lidar_kernel (nhip_resid.hip) with u = q - t; consts = {l00, l01, l10, l11, tx, ty, i00, i01}
+  const double tx = block_consts[4], ty = block_consts[5], i00 = block_consts[6], i01 = block_consts[7], i10 = -i01, i11 = i00;
+  for (int64_t i = 0; i < n; i++) {
+    const double qx = q[2 * i], qy = q[2 * i + 1], ux = qx - tx, uy = qy - ty;
+    double js[6], jt[6];
+    if (kind == NHIP_LIDAR_NORMAL) {
+      const double nsx = corr[8 * i + 4], nsy = corr[8 * i + 5], ntx = corr[8 * i + 6], nty = corr[8 * i + 7];
+      js[0] = ntx * i00 + nty * i10;
+      js[1] = ntx * i01 + nty * i11;
+      js[2] = ntx * (-uy) + nty * ux;
+      js[3] = -(nsx * i00 + nsy * i10);
+      js[4] = -(nsx * i01 + nsy * i11);
+      js[5] = -(nsx * (-uy) + nsy * ux);
+      jt[0] = -js[0];
+      jt[1] = -js[1];
+      jt[2] = ntx * qy - nty * qx;
+      jt[3] = -js[3];
+      jt[4] = -js[4];
+      jt[5] = -(nsx * qy - nsy * qx);
+    } else {
+      js[0] = -i00; js[1] = -i01; js[2] = uy;
+      js[3] = -i10; js[4] = -i11; js[5] = -ux;
+      jt[0] = i00;  jt[1] = i01;  jt[2] = -qy;
+      jt[3] = i10;  jt[4] = i11;  jt[5] = qx;
+    }
+    if (jac_src) memcpy(jac_src + 6 * i, js, sizeof(js));
+    if (jac_tgt) memcpy(jac_tgt + 6 * i, jt, sizeof(jt));
+  }
   return NHIP_OK;
 }
 

@@ -238,7 +238,7 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
                        const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                        const double *d_poses, int32_t n_poses, double *d_block_consts,
                        double *d_res, double *d_jsrc, double *d_jtgt, hipStream_t s, double *d_jtgt_theta = nullptr,
-                       int32_t block_base = 0);
+                       int32_t block_base = 0, double *d_q = nullptr);
 
 int launch_resid_normal_eq(int kind, const float *d_corr, const int32_t *d_block_offsets,
                            const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,

@@ -73,7 +73,10 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
     const float4 *__restrict__ corr, const int32_t *__restrict__ corr_block, int64_t n_corr,
     const double *__restrict__ consts, double2 *__restrict__ residuals,
     double2 *__restrict__ jac_src, double2 *__restrict__ jac_tgt, double2 *__restrict__ jac_tgt_theta,
-    int32_t block_base, int32_t n_blocks, uint32_t *__restrict__ status) {
+    int32_t block_base, int32_t n_blocks, uint32_t *__restrict__ status, double2 *__restrict__ q_out) {
+  // q_out (optional): the transformed source point q = S2T p_s per correspondence.  With the block's constants (Linv, t) it
+  // determines every Jacobian entry (u = q - t; the closed forms below), so a host that holds the correspondences rebuilds
+  // both Jacobians while it copies its slice: 32 instead of 80 bytes per correspondence cross PCIe (nhip_resid_batch_eval_q)
   __shared__ double2 s_j[WANT_J ? 2 * 3 * RT : 1];
   const int64_t i0 = (int64_t)blockIdx.x * RT;
   const int64_t i = i0 + threadIdx.x;
@@ -88,7 +91,7 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
       live = false;
     }
   }
-  double r0 = 0, r1 = 0;
+  double r0 = 0, r1 = 0, q_x = 0, q_y = 0;
   double js[6] = {0, 0, 0, 0, 0, 0}, jt[6] = {0, 0, 0, 0, 0, 0};
   if (live) {
     const float4 a = corr[2 * i];      // source point, target point
@@ -100,6 +103,8 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
     const double px = a.x, py = a.y, tx = a.z, ty = a.w;
     const double ux = l00 * px + l01 * py, uy = l10 * px + l11 * py;
     const double qx = ux + c45.x, qy = uy + c45.y;
+    q_x = qx;
+    q_y = qy;
     if (KIND == NHIP_LIDAR_NORMAL) {
       const double nsx = n.x, nsy = n.y, ntx = n.z, nty = n.w;
       const double ex = qx - tx, ey = qy - ty;
@@ -134,6 +139,7 @@ __global__ __launch_bounds__(RT) void resid_lidar_kernel(
   }
   if (in_range) {
     store_stream(&residuals[i], make_double2(r0, r1));
+    if (q_out) store_stream(&q_out[i], make_double2(q_x, q_y));
     // the theta column of the target Jacobian on its own: its x, y columns are the negated x, y columns of the
     // source Jacobian (dq/dt_t = -dq/dt_s), so a host that rebuilds them needs only these two values
     if (WANT_J && jac_tgt_theta) store_stream(&jac_tgt_theta[i], make_double2(jt[2], jt[5]));
@@ -433,7 +439,7 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
                        const int32_t *d_block_src, const int32_t *d_block_tgt, int32_t n_blocks,
                        const double *d_poses, int32_t n_poses, double *d_block_consts,
                        double *d_res, double *d_jsrc, double *d_jtgt, hipStream_t s, double *d_jtgt_theta,
-                       int32_t block_base) {
+                       int32_t block_base, double *d_q) {
   NHIP_REQUIRE(kind == NHIP_LIDAR_NORMAL || kind == NHIP_LIDAR_POINT, "resid_lidar: bad kind %d",
                kind);
   NHIP_REQUIRE(n_corr >= 0 && n_blocks >= 0 && n_poses >= 0, "resid_lidar: negative size");
@@ -446,21 +452,22 @@ int launch_resid_lidar(int kind, const float *d_corr, const int32_t *d_corr_bloc
   double2 *js = reinterpret_cast<double2 *>(d_jsrc), *jt = reinterpret_cast<double2 *>(d_jtgt);
   const bool want_j = d_jsrc || d_jtgt || d_jtgt_theta;
   double2 *jtt = reinterpret_cast<double2 *>(d_jtgt_theta);
+  double2 *qo = reinterpret_cast<double2 *>(d_q);
   timer_begin(NHIP_TIMER_RESID, s);
   if (kind == NHIP_LIDAR_NORMAL) {
     if (want_j)
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_NORMAL, true>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status());
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status(), qo);
     else
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_NORMAL, false>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status());
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status(), qo);
   } else {
     if (want_j)
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_POINT, true>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status());
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status(), qo);
     else
       hipLaunchKernelGGL((resid_lidar_kernel<NHIP_LIDAR_POINT, false>), grid, block, 0, s, corr,
-                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status());
+                         d_corr_block, n_corr, d_block_consts, res, js, jt, jtt, block_base, n_blocks, dev_status(), qo);
   }
   timer_end(NHIP_TIMER_RESID, s);
   NHIP_TRY_HIP(hipGetLastError());

@@ -103,6 +103,27 @@ class LidarResidualBatch:
         check(_lib.load().nhip_resid_batch_eval(self._h, ptr(poses), ptr(res), ptr(js), ptr(jt)))
         return res, js, jt
 
+    def evaluate_q(self, poses, rebuild=True):
+        """The smallest form over PCIe (nhip_resid_batch_eval_q): residuals, q = S2T p_s per correspondence and 8 constants
+        per block come down -- 32 bytes per correspondence -- and (rebuild) both Jacobians are rebuilt on the host, block by
+        block, by the library's own nhip_resid_jacobians_from_q (what the C++ adapter does while it copies a block's slice).
+        Returns (residuals, jac_src, jac_tgt) like evaluate(), or (residuals, q, block_consts) with rebuild=False."""
+        lib = _lib.load()
+        poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(self.n_poses, 3)
+        res = np.empty(2 * self.n_corr, dtype=np.float64)
+        q = np.empty((self.n_corr, 2), dtype=np.float64)
+        consts = np.empty((self.n_blocks, 8), dtype=np.float64)
+        check(lib.nhip_resid_batch_eval_q(self._h, ptr(poses), ptr(res), ptr(q), ptr(consts)))
+        if not rebuild:
+            return res, q, consts
+        js = np.empty((2 * self.n_corr, 3), dtype=np.float64)
+        jt = np.empty((2 * self.n_corr, 3), dtype=np.float64)
+        for b in range(self.n_blocks):
+            o, e = int(self.block_offsets[b]), int(self.block_offsets[b + 1])
+            check(lib.nhip_resid_jacobians_from_q(self.kind, ptr(self.corr[o:e]), ptr(q[o:e]), ptr(consts[b]), e - o,
+                                                  ptr(js[2 * o:2 * e]), ptr(jt[2 * o:2 * e])))
+        return res, js, jt
+
     def close(self):
         if self._h:
             _lib.load().nhip_resid_batch_free(self._h)

@@ -57,6 +57,16 @@ def test_lidar_blocks_match_autodiff_oracle(gpu, small_bag, kind):
     assert a3 is None and np.array_equal(b3, jt) and np.array_equal(r3, res)
     r4, a4, b4 = batch.evaluate(poses, True, False)
     assert b4 is None and np.array_equal(a4, js)
+    # the smallest form over PCIe (nhip_resid_batch_eval_q): residuals + q + 8 constants per block come down, both Jacobians
+    # are rebuilt on the host from them and the correspondences (nhip_resid_jacobians_from_q): same residuals bit for bit,
+    # Jacobians equal to the device's to rounding (u is recovered as q - t) and to the autodiff oracle's like the device's
+    rq, jsq, jtq = batch.evaluate_q(poses)
+    assert np.array_equal(rq, res)
+    assert np.allclose(jsq, js, rtol=1e-12, atol=1e-12) and np.allclose(jtq, jt, rtol=1e-12, atol=1e-12)
+    close(jsq, wj0, 30.0)
+    close(jtq, wj1, 30.0)
+    r5, q5, c5 = batch.evaluate_q(poses, rebuild=False)
+    assert q5.shape == (batch.n_corr, 2) and c5.shape == (batch.n_blocks, 8) and np.array_equal(r5, res)
     # batched oracle driver agrees with the per-block one (used by bench's cpu_baseline)
     br, bj0, bj1 = O.lidar_batch(kind, batch.corr, batch.block_offsets, batch.block_src, batch.block_tgt, poses)
     assert np.array_equal(br, wr) and np.array_equal(bj0, wj0) and np.array_equal(bj1, wj1)
