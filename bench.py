@@ -1090,12 +1090,17 @@ def leg_host_api(wl, shard, m, got, got_sums, runs_n=6):
             detail.append(calls)
     finally:
         m._lib.check(m.lib.nhip_device_pool_configure(4 << 30))
-    dt = float(np.median(runs))
+    # the first run allocates 8-12 GB of fresh device memory (hipMalloc right after torch released this process's 100+ GB:
+    # the driver's reclamation, 0.01 - 3 s); the others rebuild into the pair the previous run released.
+    # Both are reported; the rate is the steady caller's (median of the runs after the first).
+    steady = runs[1:] if len(runs) > 1 else runs
+    dt = float(np.median(steady))
     n = len(shard[1])
     return {"pairs_per_s": n / dt, "seconds": dt, "runs_s": runs, "runs_with_frees_s": with_frees,
-            "min_median_max_s": [float(np.min(runs)), dt, float(np.max(runs))],
-            "pairs_per_s_min_median_max": [n / float(np.max(runs)), n / dt, n / float(np.min(runs))],
-            "spread_max_over_min": float(np.max(runs) / np.min(runs)),
+            "first_run_s": runs[0], "first_run_device_allocation_s": detail[0].get("grids_build", {}).get("alloc"),
+            "min_median_max_s": [float(np.min(steady)), dt, float(np.max(steady))],
+            "pairs_per_s_min_median_max": [n / float(np.max(steady)), n / dt, n / float(np.min(steady))],
+            "spread_max_over_min": float(np.max(steady) / np.min(steady)),
             "calls_of_the_slowest_run": detail[int(np.argmax(with_frees))], "calls_of_the_fastest_run": detail[int(np.argmin(with_frees))],
             "same_result_as_device_api": bool(np.array_equal(hs, got_sums) and hm.tobytes() == got.tobytes()),
             "device_pool_cap_bytes": 32 << 30,
