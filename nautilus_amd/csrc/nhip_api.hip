@@ -1432,10 +1432,11 @@ struct DropInScratch {
 //  too -- run before the process's static destructors, i.e. while the HIP runtime is still there)
 // coarse score (mean log-likelihood on the low_res table) below which the fine level goes to the every-add kernels
 // (profiles/r06_dropin_fine_level.txt, 50 sources against two targets at the reference's constants: matching clouds score
-//  -1.44 .. -1.7 on the coarse table and take 0.27-0.41 ms by branch and bound against 0.39-0.53 by every add; from -1.8 down
+//  -1.44 .. -1.7 on the coarse table and take 0.27-0.41 ms by branch and bound against 0.39-0.53 by every add; from about -1.8 down
 //  every add wins, by up to 40x -- 0.22 against 10 ms; mean over the 50: 0.33 ms with this threshold, 1.39 always by branch and
-//  bound, 0.36 always by every add, 0.32 with hindsight)
-constexpr double DROPIN_FINE_EVERY_ADD_BELOW = -1.75;
+//  bound, 0.36 always by every add, 0.32 with hindsight; the threshold sits below the spread of matching clouds -- a thinned
+//  pair of the test suite scores -1.76 -- where either form costs about the same: -1.5 / -1.75 / -2.0 give 0.33 / 0.33 / 0.34)
+constexpr double DROPIN_FINE_EVERY_ADD_BELOW = -2.0;
 static thread_local double t_dropin_info[4] = {0, 0, 0, 0};
 constexpr int DROPIN_CHAIN_ROT_MAX = 512;               // coarse rotations the chained form's table holds
 constexpr size_t DROPIN_UP_BYTES = 256 + 16 * (size_t)DROPIN_CHAIN_ROT_MAX, DROPIN_DOWN_BYTES = 512;

@@ -674,6 +674,52 @@ def test_drop_in_flat_landscape_first_pose_wins_across_the_parts(gpu, small_bag)
     assert _same_call(e, we)
 
 
+def _dropin_info():
+    out = (C.c_double * 4)()
+    _lib.check(_lib.load().nhip_csm_get_transformation_info(out))
+    return {"coarse_score": out[0], "fine_every_add": out[1] == 1.0, "chained": out[2] == 1.0, "coarse_itheta": int(out[3])}
+
+
+def test_drop_in_fine_level_forms_return_the_same_floats(gpu, small_bag):
+    """Round 6: the fine level of GetTransformation is taken by the branch-and-bound matcher where the coarse optimum scores
+    like matching clouds and by the kernels that perform every add where it does not (a flat landscape costs the matcher
+    milliseconds on the 6000 x 6000 table; nhip_api.hip DROPIN_FINE_EVERY_ADD_BELOW).  Forced either way
+    (NHIP_DROPIN_FINE=bnb / every_add: both levels chained on the device, one synchronisation) and by default (the host
+    looks at the coarse score in between), a matching pair and a pair 6 m apart return the SAME floats, which are the
+    oracle's; the default takes the form the score calls for."""
+    import os
+    thin = lambda i: small_bag.scans[i][::3]
+    m = csm.CorrelativeScanMatcher(30, 2, 0.3, 0.01)
+    near = (thin(17), thin(15), small_bag.odom[17, 2], small_bag.odom[15, 2], math.radians(90))
+    j = int(np.argmax(np.hypot(*(small_bag.truth[:, :2] - small_bag.truth[15, :2]).T)))          # the scan farthest from 15
+    far = (thin(j), thin(15), small_bag.odom[j, 2], small_bag.odom[15, 2], math.radians(90))
+    got = {}
+    try:
+        for mode in ("bnb", "every_add", None):
+            if mode is None:
+                os.environ.pop("NHIP_DROPIN_FINE", None)
+            else:
+                os.environ["NHIP_DROPIN_FINE"] = mode
+            for name, args in (("near", near), ("far", far)):
+                got[(mode, name)] = m.GetTransformation(*args)
+                info = _dropin_info()
+                if mode is not None:
+                    assert info["chained"] and info["fine_every_add"] == (mode == "every_add")
+                else:
+                    assert not info["chained"]
+                    assert info["fine_every_add"] == (info["coarse_score"] < -2.0)
+                    got[("info", name)] = info
+    finally:
+        os.environ.pop("NHIP_DROPIN_FINE", None)
+    for name in ("near", "far"):
+        assert got[("bnb", name)] == got[("every_add", name)] == got[(None, name)], name
+    assert not got[("info", "near")]["fine_every_add"], got[("info", "near")]
+    assert got[("info", "far")]["fine_every_add"], got[("info", "far")]
+    for name, args in (("near", near), ("far", far)):
+        want = O.two_level_match(args[0], args[1], args[2], args[3], args[4], 30.0, 2.0, 0.3, 0.01, cell_bits=16)
+        assert _same_call(got[(None, name)], want), name
+
+
 def test_device_pointer_api_on_torch_stream(gpu, small_bag):
     """The *_dev entry points: caller-owned HBM (torch tensors), launched on torch's stream."""
     import torch
