@@ -260,9 +260,11 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &
     // (several rounds pay off only with the helper stream, i.e. with two rounds' state, and in rounds that are long)
     if (!sbat && split_batch > 0 && n_pairs > split_batch && (split_slots < 2 || split_batch < split_cap)) split_batch = 0;
   }
-  const bool second = force ? force[0] == '2' : (n_pairs < 1024 && split_batch == 0);
   P.heavy_min = hm ? (uint32_t)atoi(hm) : (n_pairs <= 64 ? 1u : 384u);
   P.keep_ranks = kr ? (uint32_t)atoi(kr) : 8u;
+  // (a pair keeps its first keep_ranks rotations: a search of no more rotations than that -- the seven per workgroup of
+  //  GetTransformation's fine level -- can hand nothing over, and the second kernel's launch, 22 us of a 230 us call, is left out)
+  const bool second = force ? force[0] == '2' : (n_pairs < 1024 && split_batch == 0 && (uint32_t)P.n_theta > P.keep_ranks);
   if (d_workspace && workspace_bytes >= BNB_WS_HEADER + 8 * (int64_t)sizeof(RotEntry) && second && !P.general_all) {
     P.rot_count = static_cast<uint32_t *>(d_workspace);
     P.rot_list = reinterpret_cast<RotEntry *>(static_cast<uint8_t *>(d_workspace) + BNB_WS_HEADER);

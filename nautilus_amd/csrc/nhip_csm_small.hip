@@ -22,6 +22,8 @@ namespace {
 
 using namespace csm;
 
+// (round 6: 16 waves per workgroup measured no faster -- 78.7 us either way: what bounds a rotation's workgroup is its CU's
+//  address unit, not a wave's chain of round trips; see the lanes' order below)
 constexpr int SMALL_WAVES = 8;
 constexpr int SMALL_THREADS = 64 * SMALL_WAVES;
 constexpr int SMALL_PASSES = 4;  // poses per lane: lattices of up to 256 translations
@@ -65,16 +67,22 @@ __global__ __launch_bounds__(SMALL_THREADS) void csm_small_plane_kernel(CsmParam
   const float cf = __double2float_rn(__dsub_rn(__dmul_rn(c0, cd), __dmul_rn(s0, sd)));
   const float sf = __double2float_rn(__dadd_rn(__dmul_rn(s0, cd), __dmul_rn(c0, sd)));
 
-  // this lane's poses: pose = pass * 64 + lane = ix * ny + iy; its lookups sit iy rows and ix cells from a point's origin
+  // this lane's poses: slot = pass * 64 + lane = iy * nx + ix -- ROW-major in the table, so that the 64 lookups of one load
+  // instruction fall into ~5 rows of 13 consecutive cells (5 cache lines) and a point's three loads touch each of its 13
+  // rows once; with slot = ix * ny + iy (the order of the lattice's linear index, round 4) every load touched all 13
+  // rows -- 39 line visits per point, and the kernel's life is the address unit's: one workgroup, i.e. one CU, per
+  // rotation.  The key below still carries the lattice's own index (k * nx + ix) * ny + iy.
   const int32_t n_poses = P.nx * P.ny;
   uint32_t off[PASSES];
+  int32_t lin_pose[PASSES];
   bool valid[PASSES];
 #pragma unroll
   for (int p = 0; p < PASSES; p++) {
-    const int32_t pose = p * 64 + lane;
-    valid[p] = pose < n_poses;
-    const int32_t ix = valid[p] ? pose / P.ny : 0, iy = valid[p] ? pose % P.ny : 0;
+    const int32_t q = p * 64 + lane;
+    valid[p] = q < n_poses;
+    const int32_t iy = valid[p] ? q / P.nx : 0, ix = valid[p] ? q % P.nx : 0;
     off[p] = (uint32_t)(iy * P.pitch + ix * CB);
+    lin_pose[p] = ix * P.ny + iy;
   }
   for (int i = threadIdx.x; i < 64 * SMALL_PASSES; i += SMALL_THREADS) s_sum[i] = 0u;
   __syncthreads();
@@ -125,8 +133,7 @@ __global__ __launch_bounds__(SMALL_THREADS) void csm_small_plane_kernel(CsmParam
 #pragma unroll
     for (int p = 0; p < PASSES; p++) {
       if (!valid[p]) continue;
-      const int32_t pose = p * 64 + lane;
-      const uint32_t lin = (uint32_t)(k * n_poses + pose);  // (k * nx + ix) * ny + iy
+      const uint32_t lin = (uint32_t)(k * n_poses + lin_pose[p]);  // (k * nx + ix) * ny + iy
       const unsigned long long key = ((unsigned long long)s_sum[p * 64 + lane] << 32) | (0xffffffffu - lin);
       best = key > best ? key : best;
     }
