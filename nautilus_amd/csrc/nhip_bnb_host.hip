@@ -336,7 +336,11 @@ int launch_csm_bnb(const float *d_xy, const int32_t *d_offsets, const IdBounds &
       Q.pairs_per_xcd = (nb + 7) / 8;
       Q.ps_work_stride = Q.pairs_per_xcd + (Q.pairs_per_xcd / 2 > 64 ? Q.pairs_per_xcd / 2 : 64);
       Q.split_min = smin ? (uint32_t)(atoi(smin) > 0 ? atoi(smin) : 1) : 300u;
-      Q.split_max = smax ? (uint32_t)(atoi(smax) > 0 ? atoi(smax) : 1) : (nb < SPREAD_BELOW_PAIRS ? 16u : 8u);
+      // (workgroups per pair at most.  With the heavy pairs at the front of the list -- front_min below -- their workgroups
+      //  start with the launch, and rounds of 8,192 pairs and more are long enough for four of them to finish the heaviest
+      //  pair inside it: 8 / 6 / 5 / 4 / 3 per pair measured 2.87 / 2.84 / 2.80 / 2.79 / 2.94 ms on configs[1], 16-bit cells,
+      //  2.86 / 3.00 / 2.79 / 2.72 / 2.79 with 8-bit cells: profiles/r06_front_min.txt)
+      Q.split_max = smax ? (uint32_t)(atoi(smax) > 0 ? atoi(smax) : 1) : (nb < SPREAD_BELOW_PAIRS ? 16u : (nb >= 8192 ? 4u : 8u));
       // pairs with at least 64 candidates left (a quarter of a configs[1] list, most of its work) go to the front of their
       // XCD's list: profiles/r06_front_min.txt -- 0 / 40 / 70 / 100 / 150: 3.01 / 2.90 / 2.87 / 2.92 / 2.96 ms per 10,000 pairs
       Q.front_min = sfront ? (uint32_t)(atoi(sfront) > 0 ? atoi(sfront) : 0) : 64u;

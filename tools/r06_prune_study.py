@@ -55,7 +55,7 @@ def main():
     d_delta = torch.from_numpy(csm.delta_table(m.search).reshape(-1, 2)).to(dev)
     xy, offs = m.d_xy, wl.off
     groups = {3: [], 5: []}
-    acc = {k: [] for k in ("live_final", "cand_final", "live_seed", "cand_seed", "live_prior", "cand_prior", "live_ps", "cand_ps",
+    acc = {k: [] for k in ("live_final", "cand_final", "live_seed", "cand_seed", "live_prior", "cand_prior", "live_ps", "cand_ps", "live_seedsub", "cand_seedsub", "seedsub_over_final",
                            "prior_over_final", "seed_over_final", "early_out_frac_dead", "dead_rot_prior", "far_frac_11m", "far_frac_23m")}
     gacc = {}
     t0 = time.time()
@@ -76,8 +76,10 @@ def main():
                 r_, c_ = min(t.shape[0], L.pool_rows), min(t.shape[1], L.pool_pitch)
                 tt[:r_, :c_] = t[:r_, :c_]
                 tabs[d] = tt
-            cache[sl] = (img, {d: t.unfold(0, NB, 1).unfold(1, NB, 1) for d, t in tabs.items()}, img.unfold(0, 8, 1).unfold(1, 8, 1))
-        img, W, W8 = cache[sl]
+            off2 = off1 + L.pool_bytes
+            P2 = G[base + off2: base + off2 + L.pool4_rows * L.pool4_pitch].view(L.pool4_rows, L.pool4_pitch)[:, 0::2]
+            cache[sl] = (img, {d: t.unfold(0, NB, 1).unfold(1, NB, 1) for d, t in tabs.items()}, img.unfold(0, 8, 1).unfold(1, 8, 1), P2)
+        img, W, W8, P2 = cache[sl]
         pts = xy[int(offs[s_]):int(offs[s_ + 1])]
         npts = pts.shape[0]
         c0, s0 = math.cos(float(m.h_th0[p])), math.sin(float(m.h_th0[p]))
@@ -99,24 +101,38 @@ def main():
             ny, nx = min(8, 81 - 8 * Y), min(8, 81 - 8 * X)
             return int(sm[:ny, :nx].max())
 
-        b_seed = 0
+        def exact_sub_max(k, Y, X, qy, qx):
+            w = W8[(prow[k] + 8 * Y).clamp(max=rows - 8), (pcol[k] + 8 * X).clamp(max=rows - 8)]   # (n, 8, 8)
+            sm = w.sum(dim=0, dtype=torch.int64)[4 * qy:4 * qy + 4, 4 * qx:4 * qx + 4]
+            ny, nx = max(0, min(4, 81 - 8 * Y - 4 * qy)), max(0, min(4, 81 - 8 * X - 4 * qx))
+            return int(sm[:ny, :nx].max()) if ny and nx else 0
+
+        b_seed, b_seed_sub = 0, 0
         for w_ in range(8):
             ks = torch.arange(w_, 61, 8, device=dev)
             flat = U1[ks].flatten(1)
             i = int(flat.argmax())
             k, bb = int(ks[i // (NB * NB)]), i % (NB * NB)
             b_seed = max(b_seed, exact_block_max(k, bb // NB, bb % NB))
+            # the seed evaluated as ONE 4 x 4 sub-block: the one with the highest second-level bound of the wave's best block
+            Yb, Xb = bb // NB, bb % NB
+            r4, c4 = (prow[k] >> 2), (pcol[k] >> 2)
+            bnds = [(int(P2[(r4 + 2 * Yb + qy).clamp(max=P2.shape[0] - 1), (c4 + 2 * Xb + qx).clamp(max=P2.shape[1] - 1)].sum(dtype=torch.int64)), qy, qx)
+                    for qy in (0, 1) for qx in (0, 1)]
+            _, qy, qx = max(bnds)
+            b_seed_sub = max(b_seed_sub, exact_sub_max(k, Yb, Xb, qy, qx))
         b_prior = 0
         for k in range(28, 33):
             for Y in (4, 5, 6):
                 for X in (4, 5, 6):
                     b_prior = max(b_prior, exact_block_max(k, Y, X))
-        for name, thr in (("final", b_final), ("seed", b_seed), ("prior", b_prior), ("ps", max(b_prior, b_seed))):
+        for name, thr in (("final", b_final), ("seed", b_seed), ("seedsub", b_seed_sub), ("prior", b_prior), ("ps", max(b_prior, b_seed))):
             c1 = U1 >= thr
             acc["live_" + name].append(int(c1.flatten(1).any(dim=1).sum()))
             acc["cand_" + name].append(int(c1.sum()))
         acc["prior_over_final"].append(b_prior / max(b_final, 1))
         acc["seed_over_final"].append(b_seed / max(b_final, 1))
+        acc["seedsub_over_final"].append(b_seed_sub / max(b_final, 1))
         # 6(a): early-out on partial sums, threshold = max(prior, seeds) (the best anything could know before the bounds)
         thr = max(b_prior, b_seed)
         dead = torch.nonzero(U1.flatten(1).max(dim=1).values < thr).flatten()
