@@ -202,6 +202,12 @@ typedef struct nhip_search {
  * quantisation step of that value per cell -- measured up to 2.3e-5 relative on 1,300 pairs with 16-bit cells, 8.5e-4 with
  * 8-bit cells; with it, within double rounding (the record's float: 6e-8). */
 #define NHIP_SEARCH_EXACT_SCORE 8
+/* NHIP_SEARCH_LATENCY (with NHIP_SEARCH_EXHAUSTIVE): the list is a FEW pairs and what counts is how soon the call returns, not
+ * lookups per second.  Every add is then performed by the kernel whose lanes are poses (csm_small_plane_kernel), a plane of
+ * more than 256 translations in tiles of whole rows, one workgroup per (pair, rotation, tile) -- as long as that is at most
+ * 2,048 workgroups (otherwise the flag is ignored and the strip kernels take the list).  GetTransformation's fine level
+ * (21 x 61 x 61 on a 6000 x 6000 table) takes ~45 us this way whatever the clouds.  Same records as every other form. */
+#define NHIP_SEARCH_LATENCY 16
 
 /* One result per candidate pair: 16 bytes, the record that is all-gathered across GPUs. */
 typedef struct nhip_match {
@@ -515,9 +521,9 @@ int nhip_csm_cache_stats(int64_t *entries, int64_t *bytes, int64_t *hits, int64_
 int nhip_csm_get_transformation(const nhip_csm_params_t *params, const float *pc_a, int32_t n_a, const float *pc_b,
                                 int32_t n_b, double rot_a, double rot_b, double rot_restriction, double *score,
                                 float *tx, float *ty, float *theta);
-/* What the calling thread's last cached-target nhip_csm_get_transformation did: {the coarse optimum's score, 1 if the fine
- * level went to the kernels that perform every add (0: the branch-and-bound matcher), 1 if the two levels were chained on the
- * device, the coarse optimum's rotation index}.  (Measurement / tests.) */
+/* What the calling thread's last cached-target nhip_csm_get_transformation did: {the coarse optimum's score, the fine level's
+ * form (0: the branch-and-bound matcher, 1: every add by the strip kernels, 2: every add by the kernel whose lanes are poses --
+ * the default), 1 if the two levels were chained on the device, the coarse optimum's rotation index}.  (Measurement / tests.) */
 int nhip_csm_get_transformation_info(double out[4]);
 
 /* Residual batch: all LIDAR residual blocks of one ceres::Problem build (immutable after

@@ -13,7 +13,7 @@ LIB_PATH = os.environ.get("NHIP_LIB") or os.path.join(_HERE, "lib", "libnautilus
 
 NHIP_OK, NHIP_ERR_ARG, NHIP_ERR_NODEV, NHIP_ERR_HIP, NHIP_ERR_ALLOC, NHIP_ERR_STATE = 0, -1, -2, -3, -4, -5
 NHIP_LIDAR_NORMAL, NHIP_LIDAR_POINT = 0, 1
-NHIP_SEARCH_EXHAUSTIVE, NHIP_SEARCH_DENSE, NHIP_SEARCH_SHORT_SCANS, NHIP_SEARCH_EXACT_SCORE = 1, 2, 4, 8
+NHIP_SEARCH_EXHAUSTIVE, NHIP_SEARCH_DENSE, NHIP_SEARCH_SHORT_SCANS, NHIP_SEARCH_EXACT_SCORE, NHIP_SEARCH_LATENCY = 1, 2, 4, 8, 16
 NHIP_SHORT_SCAN_POINTS = 1088
 NHIP_GRID_SKIP_MAP, NHIP_GRID_NO_IMAGE = 1, 2
 NHIP_TIMER_CSM, NHIP_TIMER_GRID, NHIP_TIMER_RESID, NHIP_TIMER_CORR, NHIP_TIMER_NORMEQ, NHIP_TIMER_GRID_CLEAR = 0, 1, 2, 3, 4, 5

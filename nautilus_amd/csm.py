@@ -30,13 +30,15 @@ def grid_spec(range_m=30.0, res=0.05, sigma=2.0, floor_p=1e-10, max_shift=40, ce
 
 
 def search_spec(n_theta=61, nx=81, ny=81, theta_step=math.radians(1.0), exhaustive=False, dense=False, short_scans=False,
-                exact_score=False):
+                exact_score=False, latency=False):
     """exhaustive=True forces the kernel that performs every add (dense=True: the all-zero strips too); the default
     (branch and bound) returns the same records bit for bit.  short_scans=True is the caller's promise that no source
     scan of the list has more than 1088 points (nautilus_hip.h, NHIP_SEARCH_SHORT_SCANS).  exact_score=True: the records'
-    scores are the winning poses' scores on the unquantised table (NHIP_SEARCH_EXACT_SCORE)."""
+    scores are the winning poses' scores on the unquantised table (NHIP_SEARCH_EXACT_SCORE).  latency=True (with exhaustive): a
+    list of few pairs through the kernel whose lanes are poses, larger planes in tiles of rows (NHIP_SEARCH_LATENCY)."""
     flags = (_lib.NHIP_SEARCH_EXHAUSTIVE if exhaustive else 0) | (_lib.NHIP_SEARCH_DENSE if dense else 0) | \
-            (_lib.NHIP_SEARCH_SHORT_SCANS if short_scans else 0) | (_lib.NHIP_SEARCH_EXACT_SCORE if exact_score else 0)
+            (_lib.NHIP_SEARCH_SHORT_SCANS if short_scans else 0) | (_lib.NHIP_SEARCH_EXACT_SCORE if exact_score else 0) | \
+            (_lib.NHIP_SEARCH_LATENCY if latency else 0)
     return Search(int(n_theta), int(nx), int(ny), flags, float(theta_step))
 
 

@@ -1115,13 +1115,16 @@ int nhip_grids_download_pool4(const nhip_grids_t *grids, int32_t slot, uint8_t *
 
 // 16-bit grids are built without skip maps unless their spec asks (the branch-and-bound matcher never reads them).
 // The first search on a handle that takes the kernel that performs every add builds them, once.
-static int ensure_skip_maps(const nhip_grids_t *grids, const nhip_search_t *search) {
+static int ensure_skip_maps(const nhip_grids_t *grids, const nhip_search_t *search, int32_t n_pairs = 0x7fffffff) {
   // (writes to the handle -- the maps, then the flag -- under the handle's mutex, which is taken before the flag is looked
   //  at: concurrent nhip_csm_match calls on one handle are ordered, the loser finds the maps built.  L and n never change.)
   nhip_grids *g = const_cast<nhip_grids *>(grids);
   if (g->L.cb != 2 || g->n == 0 || !g->L.has_image) return NHIP_OK;
   NHIP_REQUIRE(search->n_theta >= 1 && search->nx >= 1 && search->ny >= 1, "search: empty lattice");
   if (!csm_takes_exhaustive(g->L, search)) return NHIP_OK;
+  // (the kernel whose lanes are poses reads no skip map)
+  if (csm_small_plane_fits(search) || ((search->flags & NHIP_SEARCH_LATENCY) && csm_small_tiled_fits(search, n_pairs, nullptr, nullptr)))
+    return NHIP_OK;
   std::lock_guard<std::mutex> lock(g->mu);
   if (g->spec.flags & NHIP_GRID_SKIP_MAP) return NHIP_OK;
   g->dirty = true;  // (maps the build's tile list does not know of)
@@ -1430,13 +1433,6 @@ struct DropInScratch {
 };
 // (a few KB of device memory per calling thread, freed when the thread ends: thread-local destructors -- the main thread's
 //  too -- run before the process's static destructors, i.e. while the HIP runtime is still there)
-// coarse score (mean log-likelihood on the low_res table) below which the fine level goes to the every-add kernels
-// (profiles/r06_dropin_fine_level.txt, 50 sources against two targets at the reference's constants: matching clouds score
-//  -1.44 .. -1.7 on the coarse table and take 0.27-0.41 ms by branch and bound against 0.39-0.53 by every add; from about -1.8 down
-//  every add wins, by up to 40x -- 0.22 against 10 ms; mean over the 50: 0.33 ms with this threshold, 1.39 always by branch and
-//  bound, 0.36 always by every add, 0.32 with hindsight; the threshold sits below the spread of matching clouds -- a thinned
-//  pair of the test suite scores -1.76 -- where either form costs about the same: -1.5 / -1.75 / -2.0 give 0.33 / 0.33 / 0.34)
-constexpr double DROPIN_FINE_EVERY_ADD_BELOW = -2.0;
 static thread_local double t_dropin_info[4] = {0, 0, 0, 0};
 constexpr int DROPIN_CHAIN_ROT_MAX = 512;               // coarse rotations the chained form's table holds
 constexpr size_t DROPIN_UP_BYTES = 256 + 16 * (size_t)DROPIN_CHAIN_ROT_MAX, DROPIN_DOWN_BYTES = 512;
@@ -1591,12 +1587,12 @@ int spec_under_lock(nhip_grids_t *g, nhip_grid_spec_t *out) {
 
 int match_one(DropInScratch &S, int32_t n_a, nhip_grids_t *g, const nhip_search_t *search, const void *d_delta, double theta0,
               const int32_t *origin, nhip_match_t *m) {
-  int rc = ensure_skip_maps(g, search);
+  int parts, per;
+  dropin_parts(g, search, &parts, &per);
+  int rc = ensure_skip_maps(g, search, parts);
   if (rc) return rc;
   nhip_grid_spec_t spec_now;
   spec_under_lock(g, &spec_now);
-  int parts, per;
-  dropin_parts(g, search, &parts, &per);
   DropInPar par;
   memset(&par, 0, sizeof(par));
   par.off[1] = n_a;
@@ -1655,13 +1651,13 @@ int match_chained(DropInScratch &S, const float *pc_a, int32_t n_a, CachedTarget
                   const nhip_grid_spec_t &spec1, double theta0, nhip_match_t *m1, nhip_match_t *m2) {
   if (!S.pin || s1.n_theta > DROPIN_CHAIN_ROT_MAX) return NHIP_ERR_STATE;
   int rc;
-  if ((rc = ensure_skip_maps(T.g1, &s1)) || (rc = ensure_skip_maps(T.g2, &s2))) return rc;
-  nhip_grid_spec_t spec1_now, spec2_now;
-  spec_under_lock(T.g1, &spec1_now);
-  spec_under_lock(T.g2, &spec2_now);
   int parts1, per1, parts2, per2;
   dropin_parts(T.g1, &s1, &parts1, &per1);
   dropin_parts(T.g2, &s2, &parts2, &per2);
+  if ((rc = ensure_skip_maps(T.g1, &s1, parts1)) || (rc = ensure_skip_maps(T.g2, &s2, parts2))) return rc;
+  nhip_grid_spec_t spec1_now, spec2_now;
+  spec_under_lock(T.g1, &spec1_now);
+  spec_under_lock(T.g2, &spec2_now);
   if (parts1 != 1) return NHIP_ERR_STATE;  // (the bridge reads ONE coarse record; the coarse lattice is the every-add kernels')
   uint8_t *up = static_cast<uint8_t *>(S.pin), *down = up + DROPIN_UP_BYTES;
   DropInPar *par1 = reinterpret_cast<DropInPar *>(up);
@@ -1773,9 +1769,14 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   const int32_t reach_max = (int32_t)lround((double)h1 * p->low_res / p->high_res) + ratio + 2;
   // (the score the call returns is the fine optimum's on the UNQUANTISED table -- NHIP_SEARCH_EXACT_SCORE: the reference's
   //  table holds doubles, cimg_debug.h:19; both searches run on the quantised tables)
-  const char *l2 = tunable("NHIP_DROPIN_FINE");  // (measurement: "every_add" sends the fine level through the kernels that perform every add)
-  const nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1,
-                            NHIP_SEARCH_EXACT_SCORE | ((l2 && l2[0] == 'e') ? NHIP_SEARCH_EXHAUSTIVE : 0), coarse_step / 10.0};
+  // The fine level performs EVERY add, in the kernel whose lanes are poses (NHIP_SEARCH_LATENCY: 21 x 16 tiles of four rows of
+  // the 61 x 61 plane, ~45 us whatever the clouds).  Round 6 measured the alternatives (profiles/r06_dropin_fine_level.txt):
+  // the branch-and-bound matcher takes 110 us where the clouds match and 0.8-10 ms where they do not -- a flat landscape
+  // leaves it thousands of candidate blocks on a table whose pooled level does not fit LDS; the strip kernels 0.16-0.48 ms.
+  // NHIP_DROPIN_FINE=bnb / strips (under NHIP_TUNABLES=1) select those.  Same records in every form.
+  const char *l2 = tunable("NHIP_DROPIN_FINE");
+  const int32_t fine_flags = (l2 && l2[0] == 'b') ? 0 : ((l2 && l2[0] == 's') ? NHIP_SEARCH_EXHAUSTIVE : (NHIP_SEARCH_EXHAUSTIVE | NHIP_SEARCH_LATENCY));
+  const nhip_search_t s2 = {21, 2 * ratio + 1, 2 * ratio + 1, NHIP_SEARCH_EXACT_SCORE | fine_flags, coarse_step / 10.0};
   const bool cacheable = reach_max <= 4096 && n_b > 0;
 
   // ---- the target's tables: from the cache, or built now
@@ -1866,22 +1867,15 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
       }
     }
   }
-  // ---- the two searches of this source against the target's tables.
-  // WHICH kernels take the fine level is decided by the coarse optimum's score (round 6, profiles/r06_dropin_fine_level.txt):
-  // the branch-and-bound matcher is the faster one where the clouds match (0.28 against 0.53 ms per call), and three to six
-  // times slower than the kernels that perform every add where they do not -- a flat landscape leaves it thousands of
-  // candidate blocks, while the every-add kernels skip the window strips the skip map shows empty (1.19 against 0.21 ms).
-  // Same records either way.  The host therefore looks at the coarse record before it enqueues the fine level: one
-  // synchronisation more than the chained form (NHIP_DROPIN_FINE=bnb / every_add forces one and chains; measured: the
-  // chain is worth 5 us of a 275 us call).
+  // ---- the two searches of this source against the target's tables, chained on the device: upload, coarse search, bridge
+  // kernel (the fine level's parameter block from the coarse record), fine search, exact score, ONE download, ONE
+  // synchronisation.  (No pinned staging, a coarse search of more rotations than the chain's table holds, or
+  // NHIP_DROPIN_CHAIN=0: one level after the other with the host in between.)
   DropInScratch *S = nullptr;
   if ((rc = scratch_for(device, n_a, s1, s2, &S))) return rc;
   nhip_match_t m2;
   const char *ch = tunable("NHIP_DROPIN_CHAIN");
-  const char *fs = tunable("NHIP_DROPIN_FINE_SCORE");  // (measurement: the coarse score below which the fine level takes every add)
-  const double fine_score = fs ? atof(fs) : DROPIN_FINE_EVERY_ADD_BELOW;
-  const bool forced = l2 && (l2[0] == 'e' || l2[0] == 'b');
-  rc = (!forced || (ch && ch[0] == '0')) ? NHIP_ERR_STATE : match_chained(*S, pc_a, n_a, *T, s1, s2, spec1, theta0, &m1, &m2);
+  rc = (ch && ch[0] == '0') ? NHIP_ERR_STATE : match_chained(*S, pc_a, n_a, *T, s1, s2, spec1, theta0, &m1, &m2);
   const bool chained = rc == NHIP_OK;
   if (rc != NHIP_OK && rc != NHIP_ERR_STATE) return rc;
   if (!chained) {
@@ -1893,13 +1887,11 @@ int nhip_csm_get_transformation(const nhip_csm_params_t *p, const float *pc_a, i
   NHIP_REQUIRE(std::max(abs(origin[0]), abs(origin[1])) + ratio <= reach_max, "csm_get_transformation: coarse optimum (%d, %d) beyond "
                "the fine tables' reach %d", origin[0], origin[1], reach_max);
   const double theta1 = th1;
-  nhip_search_t s2_now = s2;
-  if (!forced && (double)m1.score < fine_score) s2_now.flags |= NHIP_SEARCH_EXHAUSTIVE;
   t_dropin_info[0] = (double)m1.score;
-  t_dropin_info[1] = (s2_now.flags & NHIP_SEARCH_EXHAUSTIVE) ? 1.0 : 0.0;
+  t_dropin_info[1] = (s2.flags & NHIP_SEARCH_LATENCY) ? 2.0 : ((s2.flags & NHIP_SEARCH_EXHAUSTIVE) ? 1.0 : 0.0);
   t_dropin_info[2] = chained ? 1.0 : 0.0;
   t_dropin_info[3] = (double)m1.itheta;
-  if (!chained && (rc = match_one(*S, n_a, T->g2, &s2_now, S->delta2.p, theta1, origin, &m2))) return rc;
+  if (!chained && (rc = match_one(*S, n_a, T->g2, &s2, S->delta2.p, theta1, origin, &m2))) return rc;
   if ((rc = nhip_match_to_transform(&m2, &T->spec2, &s2, theta1, origin[0], origin[1], tx, ty, theta))) return rc;
   *score = (double)m2.score;
   return NHIP_OK;

@@ -224,6 +224,7 @@ int launch_csm16_scores(const float *d_xy, const int32_t *d_offsets, const uint8
                         const nhip_search_t *search, int32_t *d_sums, hipStream_t s);
 // every add for lattices of few translations (nx * ny <= 256), both cell widths (nhip_csm_small.hip)
 bool csm_small_plane_fits(const nhip_search_t *search);
+bool csm_small_tiled_fits(const nhip_search_t *search, int32_t n_pairs, int32_t *tile_rows, int32_t *n_tiles);
 int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                            const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                            const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,

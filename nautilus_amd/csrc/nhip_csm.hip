@@ -707,7 +707,9 @@ static int launch_csm_match_quantised(const float *d_xy, const int32_t *d_offset
   // planes of few translations (the coarse level of GetTransformation: 13 x 13): the kernel whose lanes are poses
   // (NHIP_CSM_SMALL=0, measurement / tests: the strip kernels below for these lattices too)
   const char *sm = tunable("NHIP_CSM_SMALL");
-  if (csm_small_plane_fits(search) && !(sm && sm[0] == '0'))
+  // ... and, for lists of a few pairs, larger planes in tiles of whole rows (the fine level of GetTransformation)
+  if ((csm_small_plane_fits(search) || ((search->flags & NHIP_SEARCH_LATENCY) && csm_small_tiled_fits(search, n_pairs, nullptr, nullptr))) &&
+      !(sm && sm[0] == '0'))
     return launch_csm_small_match(d_xy, d_offsets, ids, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
                                   d_pair_origin, n_pairs, search, d_keys, d_out, d_sums, s);
   if (L.cb == 2)

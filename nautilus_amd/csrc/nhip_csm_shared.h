@@ -22,6 +22,7 @@ struct CsmParams {
   int32_t single_src, single_slot;  // scores kernel: the one pair
   int32_t single_ox, single_oy;
   int32_t dense;  // 1: ignore the skip maps (every strip is added, zero or not)
+  int32_t tile_rows, n_tiles;  // csm_small_plane_kernel: rows of the plane of translations per workgroup, workgroups per rotation
   IdBounds ids;   // counts the pairs' scan ids and grid slots are checked against (nhip_common.h)
   int64_t grid_bytes, slot_bytes;
   double res, inv_res;

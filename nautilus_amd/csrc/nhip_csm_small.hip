@@ -14,6 +14,14 @@
 //   the waves' partial sums meet in LDS (integer adds: any order), the plane's best key goes to keys[pair] by atomicMax.
 // Same sums, same argmax, same tie-break ((k * nx + ix) * ny + iy, first maximum wins) as every other kernel: tests
 // compare them on every lattice this one takes.
+//
+// Round 6: planes of MORE than 256 translations in TILES of whole rows -- a workgroup takes `tile_rows` rows of one rotation's
+// plane (at most 256 poses: four per lane), a rotation has n_tiles workgroups -- for searches of a FEW pairs, where the life
+// of a call is what counts, not the lookups per second: the fine level of GetTransformation (21 rotations of 61 x 61
+// translations on a 6000 x 6000 table: 336 workgroups of 4 rows) takes ~45 us here whatever the clouds, against 110 us by
+// branch and bound where they match and 0.2-10 ms where they do not, or 0.16-0.48 ms by the strip kernels.  Lists that
+// would need more than SMALL_TILED_MAX_BLOCKS workgroups stay with the strip kernels, whose LDS tiles make 17x the lookups
+// per second.
 #include "nhip_csm_shared.h"
 
 namespace nhip {
@@ -46,8 +54,11 @@ __global__ __launch_bounds__(SMALL_THREADS) void csm_small_plane_kernel(CsmParam
   // block -> (pair, rotation): consecutive rotations of a pair on consecutive blocks, i.e. dealt over the eight XCDs.
   // (The strip kernels keep a pair on ONE XCD for its L2; for the single pair of a GetTransformation call that put all
   //  181 workgroups on 32 of the 256 CUs: 440 us instead of 60.  A table this kernel serves is small enough for eight L2s.)
-  const int32_t pair = (int32_t)(blockIdx.x / (uint32_t)P.n_theta);
-  const int32_t k = (int32_t)(blockIdx.x % (uint32_t)P.n_theta);
+  // (... and a rotation's tiles on consecutive blocks: their windows overlap row by row)
+  const uint32_t per_pair = (uint32_t)P.n_theta * (uint32_t)P.n_tiles;
+  const int32_t pair = (int32_t)(blockIdx.x / per_pair);
+  const int32_t k = (int32_t)((blockIdx.x % per_pair) / (uint32_t)P.n_tiles);
+  const int32_t row0 = (int32_t)(blockIdx.x % (uint32_t)P.n_tiles) * P.tile_rows;  // first row (iy) of this workgroup's tile
   if (pair >= P.n_pairs) return;
   int32_t src = P.pair_src[pair], slot = P.pair_slot[pair];
   // (ids from device memory: a pair whose scan or slot lies outside the caller's counts scores nothing and is reported)
@@ -79,8 +90,8 @@ __global__ __launch_bounds__(SMALL_THREADS) void csm_small_plane_kernel(CsmParam
 #pragma unroll
   for (int p = 0; p < PASSES; p++) {
     const int32_t q = p * 64 + lane;
-    valid[p] = q < n_poses;
-    const int32_t iy = valid[p] ? q / P.nx : 0, ix = valid[p] ? q % P.nx : 0;
+    valid[p] = q < P.tile_rows * P.nx && row0 + q / P.nx < P.ny;
+    const int32_t iy = valid[p] ? row0 + q / P.nx : 0, ix = valid[p] ? q % P.nx : 0;
     off[p] = (uint32_t)(iy * P.pitch + ix * CB);
     lin_pose[p] = ix * P.ny + iy;
   }
@@ -150,6 +161,18 @@ __global__ __launch_bounds__(SMALL_THREADS) void csm_small_plane_kernel(CsmParam
 
 bool csm_small_plane_fits(const nhip_search_t *search) { return (int64_t)search->nx * search->ny <= 64 * SMALL_PASSES; }
 
+// Larger planes in tiles of whole rows, for lists of few pairs (see the top of the file): rows per workgroup and workgroups
+// per rotation; false if a row alone exceeds a workgroup's 256 poses or the list would need too many workgroups.
+constexpr int64_t SMALL_TILED_MAX_BLOCKS = 2048;
+bool csm_small_tiled_fits(const nhip_search_t *search, int32_t n_pairs, int32_t *tile_rows, int32_t *n_tiles) {
+  if (search->nx < 1 || search->ny < 1 || search->nx > 64 * SMALL_PASSES) return false;
+  const int32_t rows = std::min<int32_t>(search->ny, (64 * SMALL_PASSES) / search->nx);
+  const int32_t tiles = (search->ny + rows - 1) / rows;
+  if (tile_rows) *tile_rows = rows;
+  if (n_tiles) *n_tiles = tiles;
+  return (int64_t)n_pairs * search->n_theta * tiles <= SMALL_TILED_MAX_BLOCKS;
+}
+
 int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,
                            const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                            const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
@@ -182,11 +205,18 @@ int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const Id
   P.slot_bytes = L.slot_bytes;
   P.res = spec->res;
   P.inv_res = 1.0 / spec->res;
-  const int64_t blocks = (int64_t)n_pairs * (int64_t)P.n_theta;
+  if (csm_small_plane_fits(search)) {
+    P.tile_rows = P.ny;
+    P.n_tiles = 1;
+  } else {
+    NHIP_REQUIRE(csm_small_tiled_fits(search, n_pairs, &P.tile_rows, &P.n_tiles), "csm_match: lattice %d x %d x %d of %d pairs does not "
+                 "fit the small-plane kernel", search->n_theta, search->nx, search->ny, n_pairs);
+  }
+  const int64_t blocks = (int64_t)n_pairs * (int64_t)P.n_theta * (int64_t)P.n_tiles;
   NHIP_REQUIRE(blocks < 0x7fffffffll, "csm_match: %lld workgroups exceed one launch; split the batch", (long long)blocks);
   NHIP_TRY_HIP(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * (size_t)n_pairs, s));
   timer_begin(NHIP_TIMER_CSM, s);
-  const int passes = (P.nx * P.ny + 63) / 64;
+  const int passes = (P.tile_rows * P.nx + 63) / 64;
 #define NHIP_SMALL_LAUNCH(CB_, PS_) hipLaunchKernelGGL((csm_small_plane_kernel<CB_, PS_>), dim3((uint32_t)blocks), dim3(SMALL_THREADS), 0, s, P)
   if (L.cb == 1) {
     if (passes == 1) NHIP_SMALL_LAUNCH(1, 1); else if (passes == 2) NHIP_SMALL_LAUNCH(1, 2);

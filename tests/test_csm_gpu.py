@@ -677,16 +677,15 @@ def test_drop_in_flat_landscape_first_pose_wins_across_the_parts(gpu, small_bag)
 def _dropin_info():
     out = (C.c_double * 4)()
     _lib.check(_lib.load().nhip_csm_get_transformation_info(out))
-    return {"coarse_score": out[0], "fine_every_add": out[1] == 1.0, "chained": out[2] == 1.0, "coarse_itheta": int(out[3])}
+    return {"coarse_score": out[0], "fine_form": int(out[1]), "chained": out[2] == 1.0, "coarse_itheta": int(out[3])}
 
 
 def test_drop_in_fine_level_forms_return_the_same_floats(gpu, small_bag):
-    """Round 6: the fine level of GetTransformation is taken by the branch-and-bound matcher where the coarse optimum scores
-    like matching clouds and by the kernels that perform every add where it does not (a flat landscape costs the matcher
-    milliseconds on the 6000 x 6000 table; nhip_api.hip DROPIN_FINE_EVERY_ADD_BELOW).  Forced either way
-    (NHIP_DROPIN_FINE=bnb / every_add: both levels chained on the device, one synchronisation) and by default (the host
-    looks at the coarse score in between), a matching pair and a pair 6 m apart return the SAME floats, which are the
-    oracle's; the default takes the form the score calls for."""
+    """Round 6: the fine level of GetTransformation performs every add in the kernel whose lanes are poses (NHIP_SEARCH_LATENCY:
+    tiles of four rows of the 61 x 61 plane; ~45 us whatever the clouds), both levels chained on the device.  The forms it
+    replaced stay selectable (NHIP_DROPIN_FINE=bnb: the branch-and-bound matcher, which a flat landscape costs milliseconds
+    on the 6000 x 6000 table; =strips: the strip kernels): on a matching pair and on a pair 6 m apart all three return the
+    SAME floats, which are the oracle's -- chained or with the host between the levels (NHIP_DROPIN_CHAIN=0)."""
     import os
     thin = lambda i: small_bag.scans[i][::3]
     m = csm.CorrelativeScanMatcher(30, 2, 0.3, 0.01)
@@ -695,7 +694,7 @@ def test_drop_in_fine_level_forms_return_the_same_floats(gpu, small_bag):
     far = (thin(j), thin(15), small_bag.odom[j, 2], small_bag.odom[15, 2], math.radians(90))
     got = {}
     try:
-        for mode in ("bnb", "every_add", None):
+        for mode, form in (("bnb", 0), ("strips", 1), (None, 2)):
             if mode is None:
                 os.environ.pop("NHIP_DROPIN_FINE", None)
             else:
@@ -703,21 +702,50 @@ def test_drop_in_fine_level_forms_return_the_same_floats(gpu, small_bag):
             for name, args in (("near", near), ("far", far)):
                 got[(mode, name)] = m.GetTransformation(*args)
                 info = _dropin_info()
-                if mode is not None:
-                    assert info["chained"] and info["fine_every_add"] == (mode == "every_add")
-                else:
-                    assert not info["chained"]
-                    assert info["fine_every_add"] == (info["coarse_score"] < -2.0)
-                    got[("info", name)] = info
+                assert info["chained"] and info["fine_form"] == form, (mode, info)
+        os.environ["NHIP_DROPIN_CHAIN"] = "0"
+        for name, args in (("near", near), ("far", far)):
+            got[("unchained", name)] = m.GetTransformation(*args)
+            assert not _dropin_info()["chained"]
     finally:
         os.environ.pop("NHIP_DROPIN_FINE", None)
+        os.environ.pop("NHIP_DROPIN_CHAIN", None)
     for name in ("near", "far"):
-        assert got[("bnb", name)] == got[("every_add", name)] == got[(None, name)], name
-    assert not got[("info", "near")]["fine_every_add"], got[("info", "near")]
-    assert got[("info", "far")]["fine_every_add"], got[("info", "far")]
+        assert got[("bnb", name)] == got[("strips", name)] == got[(None, name)] == got[("unchained", name)], name
     for name, args in (("near", near), ("far", far)):
         want = O.two_level_match(args[0], args[1], args[2], args[3], args[4], 30.0, 2.0, 0.3, 0.01, cell_bits=16)
         assert _same_call(got[(None, name)], want), name
+
+
+@pytest.mark.parametrize("cell_bits", [16, 8])
+def test_small_plane_kernel_in_tiles_of_rows(gpu, small_bag, cell_bits):
+    """NHIP_SEARCH_LATENCY: planes of more than 256 translations through csm_small_plane_kernel in tiles of whole rows (one
+    workgroup per pair, rotation and tile) -- lattices whose rows do and do not divide into the tiles, a search centre off
+    the origin, a short and an empty scan: records and sums equal the oracle's and the branch-and-bound matcher's."""
+    spec, ospec = _specs(10.0, 0.05, 2.0, 40, cell_bits)
+    scans = [small_bag.scans[i][::2] for i in (3, 4, 12, 13)] + [small_bag.scans[5][:7], np.zeros((0, 2), np.float32)]
+    xy, off = csm.pack_scans(scans)
+    st = csm.ScanTable(xy, off)
+    ids = np.array([0, 2], dtype=np.int32)
+    grids = csm.LikelihoodGrids(st, ids, spec)
+    ogr = O.grid_build_batch(xy, off, ids, ospec)
+    src = np.array([1, 3, 4, 5], dtype=np.int32)
+    slot = np.array([0, 1, 1, 0], dtype=np.int32)
+    th0 = np.array([0.02, -0.03, 0.4, 0.0])
+    org = np.array([[3, -2], [0, 0], [-5, 4], [1, 1]], dtype=np.int32)
+    for nth, nx, ny in ((5, 61, 61), (3, 81, 33), (7, 17, 71), (3, 81, 5)):
+        search = csm.search_spec(nth, nx, ny, 0.5 * DEG, exhaustive=True, latency=True)
+        got, sums = csm.match_pairs(st, grids, src, slot, th0, search, org if max(nx, ny) <= 70 else None)
+        want = O.csm_match_batch(xy, off, ogr, ospec, src, slot, th0, O.search_spec(nth, nx, ny, 0.5 * DEG), org if max(nx, ny) <= 70 else None)
+        for f in ("itheta", "ix", "iy"):
+            assert np.array_equal(got[f], want[f]), (nth, nx, ny, f)
+        assert np.array_equal(sums, want["sum"]), (nth, nx, ny)
+        if nx <= 88 and ny <= 88:
+            bnb, bsums = csm.match_pairs(st, grids, src, slot, th0, csm.search_spec(nth, nx, ny, 0.5 * DEG),
+                                         org if max(nx, ny) <= 70 else None)
+            assert bnb.tobytes() == got.tobytes() and np.array_equal(bsums, sums)
+    grids.close()
+    st.close()
 
 
 def test_device_pointer_api_on_torch_stream(gpu, small_bag):
@@ -1574,9 +1602,11 @@ def test_handle_builds_rebuild_into_the_buffers_a_released_handle_left(gpu, smal
     search = csm.search_spec(61, 81, 81, DEG, exact_score=True)
     m_b, s_b = csm.match_pairs(st, b, src, slot, th0, search)
     if cell_bits == 16 and not no_image:
-        # a search that takes the every-add kernel builds skip maps late: the handle's tables are no longer what its tile
-        # list describes, and its buffers go back with contents unknown
+        # a search that takes the every-add STRIP kernels builds skip maps late: the handle's tables are no longer what its
+        # tile list describes, and its buffers go back with contents unknown  (a plane of at most 256 translations goes to
+        # the kernel whose lanes are poses, which reads no map: 11 x 11 builds none -- round 6)
         csm.match_pairs(st, b, src[:3], slot[:3], th0[:3], csm.search_spec(5, 11, 11, DEG, exhaustive=True))
+        csm.match_pairs(st, b, src[:3], slot[:3], th0[:3], csm.search_spec(5, 41, 41, DEG, exhaustive=True))
         b.close()
         c = csm.LikelihoodGrids(st, ids_b, spec)
         assert not c.was_rebuilt()

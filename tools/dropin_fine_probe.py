@@ -1,5 +1,7 @@
-"""Cached GetTransformation calls, fine level by the branch-and-bound matcher vs by the kernels that perform every add, against
-the coarse optimum's score (GPU box): where is the crossover?  -> the library's DROPIN_FINE_EVERY_ADD_BELOW."""
+"""Cached GetTransformation calls, fine level by the branch-and-bound matcher (NHIP_DROPIN_FINE=bnb) vs by every add
+(NHIP_DROPIN_FINE=every_add = the library's default form: the kernel whose lanes are poses in tiles of rows; profiles/
+r06_dropin_fine_level.txt was taken when that value still meant the STRIP kernels, now NHIP_DROPIN_FINE=strips), against the coarse
+optimum's score (GPU box)."""
 import os, sys, time, math, ctypes as C
 os.environ["NHIP_TUNABLES"] = "1"
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
