@@ -688,8 +688,10 @@ int nhip_csm_match_dev(const float *d_xy, const int32_t *d_offsets, int32_t n_sc
   rc = make_layout(spec, &L);
   if (rc) return rc;
   const IdBounds ids = {n_scans, n_grids, dev_status()};
+  nhip_search_t pub = *search;
+  pub.flags &= ~(SEARCH_I_KEYS_ZERO | SEARCH_I_NO_FINALIZE);  // (the library's own bits: never a caller's)
   return launch_csm_match(d_xy, d_offsets, ids, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs,
-                          d_delta_cs, d_pair_origin, n_pairs, search, d_keys, d_out, d_sums,
+                          d_delta_cs, d_pair_origin, n_pairs, &pub, d_keys, d_out, d_sums,
                           static_cast<hipStream_t>(stream), d_workspace, workspace_bytes);
 }
 
@@ -1170,6 +1172,7 @@ int nhip_csm_match(const nhip_scans_t *scans, const nhip_grids_t *grids, const i
   }
   // the host knows the scan lengths: when every source fits the by-rotation form the general kernel is not launched
   nhip_search_t search_now = *search;
+  search_now.flags &= ~(SEARCH_I_KEYS_ZERO | SEARCH_I_NO_FINALIZE);  // (the library's own bits: never a caller's)
   {
     bool all_short = true;
     for (int32_t i = 0; i < n_pairs && all_short; i++)
@@ -1620,9 +1623,28 @@ int match_one(DropInScratch &S, int32_t n_a, nhip_grids_t *g, const nhip_search_
 // the fine search's centre angle are NOT computed here: device and host libm differ in the last place; the host tabulates
 // its own values for every coarse rotation and the kernel picks the winner's.
 __global__ void dropin_bridge_kernel(const nhip_match_t *rec1, const double *rot1, int32_t hx1, int32_t hy1, double low_res,
-                                     double high_res, int32_t n_a, int32_t parts2, int32_t per2, DropInPar *par2, int32_t *info) {
+                                     double high_res, int32_t n_a, int32_t parts2, int32_t per2, DropInPar *par2, int32_t *info,
+                                     const unsigned long long *keys1, int32_t nx1, int32_t ny1, double Lf1, double step1,
+                                     nhip_match_t *rec1_out, int32_t *sums1_out, unsigned long long *keys2) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const nhip_match_t m = rec1[0];
+  nhip_match_t m;
+  if (keys1) {
+    // the coarse search left its keys undecoded (SEARCH_I_NO_FINALIZE): csm_finalize_kernel's decoding, here, and the fine
+    // search's keys zeroed for it (SEARCH_I_KEYS_ZERO) -- two small launches and a memset fewer per call
+    const unsigned long long key = keys1[0];
+    const uint32_t sum = (uint32_t)(key >> 32), lin = 0xffffffffu - (uint32_t)key;
+    m.iy = (int32_t)(lin % (uint32_t)ny1);
+    m.ix = (int32_t)((lin / (uint32_t)ny1) % (uint32_t)nx1);
+    m.itheta = (int32_t)(lin / ((uint32_t)ny1 * (uint32_t)nx1));
+    double sc = Lf1;
+    if (n_a > 0) sc = __dadd_rn(Lf1, __ddiv_rn(__dmul_rn(step1, (double)sum), (double)n_a));
+    m.score = __double2float_rn(sc);
+    rec1_out[0] = m;
+    sums1_out[0] = (int32_t)sum;
+    for (int q = 0; q < DROPIN_PARTS_MAX; q++) keys2[q] = 0ull;
+  } else {
+    m = rec1[0];
+  }
   const float tx1 = __double2float_rn(__dmul_rn((double)(m.ix - hx1), low_res));
   const float ty1 = __double2float_rn(__dmul_rn((double)(m.iy - hy1), low_res));
   const int32_t ox = (int32_t)lround(__ddiv_rn((double)tx1, high_res)), oy = (int32_t)lround(__ddiv_rn((double)ty1, high_res));
@@ -1675,13 +1697,26 @@ int match_chained(DropInScratch &S, const float *pc_a, int32_t n_a, CachedTarget
   if (n_a) NHIP_TRY_HIP(hipMemcpyAsync(S.xy.p, pc_a, sizeof(float) * 2 * (size_t)n_a, hipMemcpyHostToDevice, nullptr));
   NHIP_TRY_HIP(hipMemcpyAsync(S.rot1.p, up, up_bytes, hipMemcpyHostToDevice, nullptr));
   uint8_t *dres = static_cast<uint8_t *>(S.res.p);
-  if ((rc = dropin_enqueue(S, n_a, T.g1, spec1_now, &s1, S.delta1.p, S.rot1.p, false, 1, per1, S.keys.p, S.ws.p, S.ws.bytes, dres))) return rc;
+  // both levels through the kernel whose lanes are poses (the default): the bridge decodes the coarse keys and zeroes the fine
+  // ones, the exact-score pass decodes the fine keys -- no finalize launches, no second memset
+  const bool fused = csm_takes_exhaustive(T.g1->L, &s1) && csm_small_plane_fits(&s1) && csm_takes_exhaustive(T.g2->L, &s2) &&
+                     (csm_small_plane_fits(&s2) || ((s2.flags & NHIP_SEARCH_LATENCY) && csm_small_tiled_fits(&s2, parts2, nullptr, nullptr))) &&
+                     (s2.flags & NHIP_SEARCH_EXACT_SCORE) && parts2 == 1 && !tunable("NHIP_CSM_SMALL") && !tunable("NHIP_DROPIN_UNFUSED");
+  nhip_search_t s1c = s1, s2c = s2;
+  if (fused) {
+    s1c.flags |= SEARCH_I_NO_FINALIZE;
+    s2c.flags |= SEARCH_I_KEYS_ZERO | SEARCH_I_NO_FINALIZE;
+  }
+  if ((rc = dropin_enqueue(S, n_a, T.g1, spec1_now, &s1c, S.delta1.p, S.rot1.p, false, 1, per1, S.keys.p, S.ws.p, S.ws.bytes, dres))) return rc;
   hipLaunchKernelGGL(dropin_bridge_kernel, dim3(1), dim3(64), 0, nullptr, reinterpret_cast<const nhip_match_t *>(dres),
                      reinterpret_cast<const double *>(static_cast<uint8_t *>(S.rot1.p) + 256), (s1.nx - 1) / 2, (s1.ny - 1) / 2,
                      spec1.res, T.spec2.res, n_a, parts2, per2, static_cast<DropInPar *>(S.par2.p),
-                     reinterpret_cast<int32_t *>(dres + 480));
+                     reinterpret_cast<int32_t *>(dres + 480),
+                     fused ? static_cast<const unsigned long long *>(S.keys.p) : nullptr, s1.nx, s1.ny, T.g1->L.Lf, T.g1->L.step,
+                     reinterpret_cast<nhip_match_t *>(dres), reinterpret_cast<int32_t *>(dres + 128),
+                     static_cast<unsigned long long *>(S.keys2.p));
   NHIP_TRY_HIP(hipGetLastError());
-  if ((rc = dropin_enqueue(S, n_a, T.g2, spec2_now, &s2, S.delta2.p, S.par2.p, true, parts2, per2, S.keys2.p, S.ws2.p, S.ws2.bytes, dres + 256)))
+  if ((rc = dropin_enqueue(S, n_a, T.g2, spec2_now, &s2c, S.delta2.p, S.par2.p, true, parts2, per2, S.keys2.p, S.ws2.p, S.ws2.bytes, dres + 256)))
     return rc;
   NHIP_TRY_HIP(hipMemcpyAsync(down, dres, DROPIN_DOWN_BYTES, hipMemcpyDeviceToHost, nullptr));
   NHIP_TRY_HIP(hipStreamSynchronize(nullptr));

@@ -223,6 +223,12 @@ int launch_csm16_scores(const float *d_xy, const int32_t *d_offsets, const uint8
                         const double *d_rot0_cs, const double *d_delta_cs, int32_t origin_x, int32_t origin_y,
                         const nhip_search_t *search, int32_t *d_sums, hipStream_t s);
 // every add for lattices of few translations (nx * ny <= 256), both cell widths (nhip_csm_small.hip)
+// Internal bits of nhip_search_t::flags (never part of the ABI: the extern "C" entry points mask them off).  The chained
+// GetTransformation sets them for the searches it sends through the small-plane kernel: the keys were zeroed by the
+// kernel before (no memset node), and the kernel after decodes the keys itself (no finalize node) -- dropin_bridge_kernel for
+// the coarse level, csm_exact_score_kernel for the fine one.
+constexpr int32_t SEARCH_I_KEYS_ZERO = 1 << 28;
+constexpr int32_t SEARCH_I_NO_FINALIZE = 1 << 29;
 bool csm_small_plane_fits(const nhip_search_t *search);
 bool csm_small_tiled_fits(const nhip_search_t *search, int32_t n_pairs, int32_t *tile_rows, int32_t *n_tiles);
 int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,

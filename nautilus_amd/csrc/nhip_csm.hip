@@ -428,6 +428,8 @@ struct ExactParams {
   const int32_t *pair_origin;
   const int32_t *pair_kbase;  // optional: entry of delta_cs that is pair i's rotation 0 (nhip_bnb_params.h)
   nhip_match_t *out;
+  const unsigned long long *keys;  // optional: the search's keys, decoded here (the record's indices, the sum) instead of by csm_finalize_kernel
+  int32_t *sums;                   // with keys: where the integer sums go (may be null)
   IdBounds ids;
   int32_t n_pairs, pairs_per_xcd, nx, ny, hx, hy, S, R, hits_pitch, max_shift;
   int64_t slot_bytes, hits_offset;
@@ -469,7 +471,21 @@ __global__ __launch_bounds__(EX_THREADS) void csm_exact_score_kernel(ExactParams
   const bool ids_ok = pair_ids_ok(P.ids, src, slot, pair, false);  // (the matcher reported it)
   if (!ids_ok) src = slot = 0;
   const int32_t beg = ids_ok ? P.offsets[src] : 0, n_pts = ids_ok ? P.offsets[src + 1] - beg : 0;
-  const nhip_match_t m = P.out[pair];
+  nhip_match_t m;
+  if (P.keys) {  // (csm_finalize_kernel's decoding; the quantised-formula score it would store is what this pass replaces)
+    const unsigned long long key = P.keys[pair];
+    const uint32_t lin = 0xffffffffu - (uint32_t)key;
+    m.iy = (int32_t)(lin % (uint32_t)P.ny);
+    m.ix = (int32_t)((lin / (uint32_t)P.ny) % (uint32_t)P.nx);
+    m.itheta = (int32_t)(lin / ((uint32_t)P.ny * (uint32_t)P.nx));
+    m.score = (float)P.Lf;
+    if (threadIdx.x == 0) {
+      P.out[pair] = m;
+      if (P.sums) P.sums[pair] = (int32_t)(uint32_t)(key >> 32);
+    }
+  } else {
+    m = P.out[pair];
+  }
   {
     // a search centre the stored border cannot cover "scores nothing" in every matcher kernel (sum 0, pose 0, score Lf):
     // the record keeps that score -- the real score at pose 0 would contradict the sum beside it
@@ -560,7 +576,8 @@ int launch_csm_exact_score(const float *d_xy, const int32_t *d_offsets, const Id
                            const nhip_grid_spec_t *spec, const GridLayout &L, const int32_t *d_pair_src,
                            const int32_t *d_pair_slot, const double *d_rot0_cs, const double *d_delta_cs,
                            const int32_t *d_pair_origin, const int32_t *d_pair_kbase, int32_t n_pairs,
-                           const nhip_search_t *search, nhip_match_t *d_out, hipStream_t s) {
+                           const nhip_search_t *search, nhip_match_t *d_out, hipStream_t s,
+                           const uint64_t *d_keys_to_decode = nullptr, int32_t *d_sums = nullptr) {
   NHIP_REQUIRE(L.R <= 15, "exact score: blur radius %d > 15", L.R);
   GridTables T;
   int rc = make_tables(spec, L, &T);
@@ -577,6 +594,8 @@ int launch_csm_exact_score(const float *d_xy, const int32_t *d_offsets, const Id
   P.pair_origin = d_pair_origin;
   P.pair_kbase = d_pair_kbase;
   P.out = d_out;
+  P.keys = reinterpret_cast<const unsigned long long *>(d_keys_to_decode);
+  P.sums = d_sums;
   P.ids = ids;
   P.n_pairs = n_pairs;
   P.pairs_per_xcd = (n_pairs + 7) / 8;
@@ -677,8 +696,10 @@ int launch_csm_match(const float *d_xy, const int32_t *d_offsets, const IdBounds
                                       d_pair_kbase);
   if (rc || n_pairs == 0 || !(search->flags & NHIP_SEARCH_EXACT_SCORE)) return rc;
   // (the records are final -- indices and integer sums; the pass replaces their score field)
+  // (SEARCH_I_NO_FINALIZE: the search left its keys undecoded -- the small-plane kernel of a chained call; this pass decodes them)
+  const bool decode = (search->flags & SEARCH_I_NO_FINALIZE) != 0;
   return launch_csm_exact_score(d_xy, d_offsets, ids, d_grids, spec, L, d_pair_src, d_pair_slot, d_rot0_cs, d_delta_cs,
-                                d_pair_origin, d_pair_kbase, n_pairs, search, d_out, s);
+                                d_pair_origin, d_pair_kbase, n_pairs, search, d_out, s, decode ? d_keys : nullptr, decode ? d_sums : nullptr);
 }
 
 static int launch_csm_match_quantised(const float *d_xy, const int32_t *d_offsets, const IdBounds &ids, const uint8_t *d_grids,

@@ -6,8 +6,8 @@
 // plane and walks all of the scan's points through LDS tiles -- on a 13 x 13 plane most of its lanes idle and its
 // lifetime (0.2 ms) is the whole call's.  The branch-and-bound matcher computes the bounds of all 181 rotations in the
 // pair's one workgroup (23 rounds of its eight waves).  Here:
-//   one 512-thread workgroup per (pair, rotation); LANES ARE POSES (pose = ix * ny + iy, up to 256 of them: four per
-//   lane), the eight waves split the scan's points; a point's window origin is computed by the lane that owns it
+//   one 512-thread workgroup per (pair, rotation); LANES ARE POSES (up to 256 of them: four per lane, taken in the table's
+//   ROW order, slot = iy * nx + ix: see the kernel), the eight waves split the scan's points; a point's window origin is computed by the lane that owns it
 //   (window_cell: the spec's arithmetic, shared with the other kernels) and handed to the wave as a scalar, so every
 //   lookup is one buffer load whose address is scalar base + the lane's constant pose offset -- no address arithmetic
 //   in the vector unit at all -- from a table that is L2-resident (a 200 x 200 table with its border is 131 KB);
@@ -18,7 +18,7 @@
 // Round 6: planes of MORE than 256 translations in TILES of whole rows -- a workgroup takes `tile_rows` rows of one rotation's
 // plane (at most 256 poses: four per lane), a rotation has n_tiles workgroups -- for searches of a FEW pairs, where the life
 // of a call is what counts, not the lookups per second: the fine level of GetTransformation (21 rotations of 61 x 61
-// translations on a 6000 x 6000 table: 336 workgroups of 4 rows) takes ~45 us here whatever the clouds, against 110 us by
+// translations on a 6000 x 6000 table: 336 workgroups of 4 rows) takes 36 us here whatever the clouds, against 110 us by
 // branch and bound where they match and 0.2-10 ms where they do not, or 0.16-0.48 ms by the strip kernels.  Lists that
 // would need more than SMALL_TILED_MAX_BLOCKS workgroups stay with the strip kernels, whose LDS tiles make 17x the lookups
 // per second.
@@ -214,7 +214,7 @@ int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const Id
   }
   const int64_t blocks = (int64_t)n_pairs * (int64_t)P.n_theta * (int64_t)P.n_tiles;
   NHIP_REQUIRE(blocks < 0x7fffffffll, "csm_match: %lld workgroups exceed one launch; split the batch", (long long)blocks);
-  NHIP_TRY_HIP(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * (size_t)n_pairs, s));
+  if (!(search->flags & SEARCH_I_KEYS_ZERO)) NHIP_TRY_HIP(hipMemsetAsync(d_keys, 0, sizeof(uint64_t) * (size_t)n_pairs, s));
   timer_begin(NHIP_TIMER_CSM, s);
   const int passes = (P.tile_rows * P.nx + 63) / 64;
 #define NHIP_SMALL_LAUNCH(CB_, PS_) hipLaunchKernelGGL((csm_small_plane_kernel<CB_, PS_>), dim3((uint32_t)blocks), dim3(SMALL_THREADS), 0, s, P)
@@ -227,7 +227,8 @@ int launch_csm_small_match(const float *d_xy, const int32_t *d_offsets, const Id
   }
 #undef NHIP_SMALL_LAUNCH
   timer_end(NHIP_TIMER_CSM, s);
-  launch_csm_finalize(d_keys, d_pair_src, d_offsets, ids.n_scans, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
+  if (!(search->flags & SEARCH_I_NO_FINALIZE))
+    launch_csm_finalize(d_keys, d_pair_src, d_offsets, ids.n_scans, n_pairs, P.nx, P.ny, L, d_out, d_sums, s);
   NHIP_TRY_HIP(hipGetLastError());
   return NHIP_OK;
 }
